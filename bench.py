@@ -1,0 +1,279 @@
+"""bench.py -- training sequences/sec of the HPMN hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3|c1|c2] [--batch B] [--no-cpu-baseline]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one full training pass of the hot path over one batch of synthetic input already
+resident in HBM: fused gather + input projection, K-layer periodic GRU scan, attention read + head,
+BPTT through every layer, embedding-gradient scatter, (RCCL all-reduce of the flat gradient when
+N > 1), per-element clip + dense TF-form Adam over every variable including the embedding table --
+i.e. sess.run(train_step) of /root/reference/code/hpmn.py:336,482 with keep_prob 0.5.
+
+Default workload = BASELINE.json's metric configuration, XLong (configs[3]): Hpmn_Industry, 7 layers,
+hidden 64, max_len 1000(+1 target) -> 1024 steps, batch 500 per GPU (code/hpmn.py:663), vocabulary
+19002 + 3269017 + 20000 rows x 16 (code/hpmn.py:630-632, data_loader.py:49).  Weak scaling: the
+per-GPU batch is fixed as N grows.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_F32_TFLOPS = 157.3     # MI355X dense fp32 (vector == f32 MFMA) peak, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0       # HBM3E spec peak
+
+CONFIGS = {
+    # name: (class, F, T, H, K, periods, batch, V, lr, memory_reg)
+    "c3": dict(industry=True, F=2, T=1001, H=64, K=7, periods=[2] * 10 + [1], batch=500,
+               V=19002 + 3269017 + 20000, lr=0.001, memory_reg=5e-5,
+               name="XLong synthetic, Hpmn_Industry 7-layer H=64 max_len=1000(+1)->1024"),
+    "c2": dict(industry=False, F=4, T=300, H=64, K=5, periods=[2, 2, 3, 5, 5, 1], batch=128,
+               V=4160000 + 990000 + 9400 + 5, lr=0.001, memory_reg=1e-5,
+               name="Taobao synthetic, Hpmn 5-layer H=64 max_len=300"),
+    "c1": dict(industry=False, F=3, T=100, H=32, K=4, periods=[2, 2, 5, 5, 1], batch=128,
+               V=63001 + 801 + 192403, lr=0.003, memory_reg=1e-5,
+               name="Amazon synthetic, Hpmn 4-layer H=32 max_len=100"),
+}
+
+
+def synth_batches(c, n_batches, batch, seed, device):
+    """Synthetic id tensors of the config's shape (schema of data_loader.py:66-80 / preprocess_amazon
+    .py:151-164): column 0 = constant uid, other columns random ids; Hpmn configs get ragged front
+    padding (5 + Geometric(.25) real events)."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n_batches):
+        ids = rng.integers(1, c["V"] - 30000, size=(batch, c["T"], c["F"]), dtype=np.int64).astype(np.int32)
+        ids[:, :, 0] = rng.integers(c["V"] - 30000, c["V"], size=(batch, 1))
+        if not c["industry"]:
+            lens = np.minimum(5 + rng.geometric(0.25, size=batch), c["T"])
+            for b in range(batch):
+                ids[b, :c["T"] - lens[b]] = 0
+        label = rng.integers(0, 2, size=batch).astype(np.int32)
+        out.append((torch.as_tensor(ids).to(device), torch.as_tensor(label).to(device)))
+    return out
+
+
+def build_model(c, tmp, device, seed=0):
+    from hpmn_amd.hpmn import Hpmn, Hpmn_Industry
+    cls = Hpmn_Industry if c["industry"] else Hpmn
+    gen = np.random.default_rng(1234)
+    emb_init = None
+    if c["industry"]:
+        # graph_emb.npy stand-in: N(0, 0.1) rows
+        emb_init = (gen.standard_normal((c["V"], 16), dtype=np.float32) * 0.1)
+    return cls(tmp, [], [], c["V"], c["F"], 1, c["T"], 1, c["lr"], c["H"], 16, 3, c["periods"], [1], c["K"], 1,
+               True, False, emb_initializer=emb_init, l2_reg=0, memory_reg=c["memory_reg"], verbose=False, seed=seed)
+
+
+def layer_lengths(c):
+    t = c["T"] + (23 if c["industry"] else 0)
+    out = []
+    for i in range(c["K"]):
+        out.append(t)
+        t //= c["periods"][i]
+    return out
+
+
+def algorithmic_flops_fwd(c):
+    """Forward GRU flops per sequence: sum_i T_i * 2*(D_i+H)*3H  (SURVEY.md 8d)."""
+    H, D0 = c["H"], c["F"] * 16
+    return sum(T * 2 * ((D0 if i == 0 else H) + H) * 3 * H for i, T in enumerate(layer_lengths(c)))
+
+
+def time_kernel(fn, iters, stream):
+    """Average duration (ms) of fn()'s launches on `stream`, HIP events around `iters` launches."""
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(iters):
+        fn()
+    e1.record(stream)
+    e1.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def roofline_probes(model, c, ids):
+    """Per-kernel live timings of the dominant kernels on the stream they are launched on (torch's
+    current stream -- every HIP entry point takes it explicitly)."""
+    from hpmn_amd import ops
+    st = torch.cuda.current_stream()
+    H, B = c["H"], ids.shape[0]
+    T0 = layer_lengths(c)[0]
+    D0 = c["F"] * 16
+    w = [t.detach() for t in model._gru_weights()]
+    emb = model.params["Embedding/emb_mtx"].detach()
+    spec = model.spec
+    xp, x0 = ops.gru_input_proj(None, ids=ids, emb=emb, wg=w[0], bg=w[1], wc=w[2], bc=w[3], H=H, T=T0,
+                                front_zero=spec.front_zero, mask_id0=spec.mask_id0, want_x_out=True)
+    mem = torch.empty(B, H, device=ids.device)
+    y, hs, gates = ops.gru_scan_fwd(xp, w[0], w[2], D0, mem, spec.periods[0], True, True)
+    dmem = torch.randn(B, H, device=ids.device) * 0.01
+
+    t_fwd = time_kernel(lambda: ops.gru_scan_fwd(xp, w[0], w[2], D0, mem, spec.periods[0], True, True), 5, st)
+    t_bwd = time_kernel(lambda: ops.gru_scan_bwd(w[0], w[2], D0, hs, gates, dmem, None, spec.periods[0]), 5, st)
+    t_proj = time_kernel(lambda: ops.gru_input_proj(None, ids=ids, emb=emb, wg=w[0], bg=w[1], wc=w[2], bc=w[3],
+                                                    H=H, T=T0, front_zero=spec.front_zero,
+                                                    mask_id0=spec.mask_id0), 5, st)
+    t_gather = time_kernel(lambda: ops.embed_gather(ids, emb, spec.mask_id0), 10, st)
+    # serial-scan flops per launch (recurrent half only; the input half lives in input_proj)
+    scan_flops = B * T0 * 2 * H * 3 * H
+    gather_bytes = B * c["T"] * c["F"] * (4 + 2 * 16 * 4)      # id + row read + row write
+    proj_bytes = B * c["T"] * c["F"] * (4 + 64) + B * T0 * 3 * H * 4
+    dom_name, dom_t = ("gru_scan_bwd_kernel", t_bwd) if t_bwd >= t_fwd else ("gru_scan_fwd_kernel", t_fwd)
+    roof = {"kernel": dom_name + "<%d> layer 0 (T=%d)" % (H, T0), "bound": "mfma",
+            "achieved": scan_flops / (dom_t * 1e-3) / 1e12, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
+            "frac": scan_flops / (dom_t * 1e-3) / 1e12 / PEAK_F32_TFLOPS, "traffic": None,
+            "ms_per_launch": dom_t,
+            "note": "fp32 FMA chain, latency-bound serial recurrence; peak = dense fp32 (vector == f32 MFMA)"}
+    extra = {
+        "scan_fwd_ms": t_fwd, "scan_bwd_ms": t_bwd,
+        "scan_fwd_tflops": scan_flops / (t_fwd * 1e-3) / 1e12,
+        "scan_bwd_tflops": scan_flops / (t_bwd * 1e-3) / 1e12,
+        "input_proj": {"ms": t_proj, "bound": "hbm", "achieved": proj_bytes / (t_proj * 1e-3) / 1e9,
+                       "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": proj_bytes / (t_proj * 1e-3) / 1e9 / PEAK_HBM_GBS},
+        "gather": {"ms": t_gather, "bound": "hbm", "achieved": gather_bytes / (t_gather * 1e-3) / 1e9,
+                   "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                   "frac": gather_bytes / (t_gather * 1e-3) / 1e9 / PEAK_HBM_GBS},
+    }
+    return roof, extra
+
+
+def cpu_baseline(c, seed=0, budget_s=25.0):
+    """The oracle's PyTorch-CPU eager restatement (per-timestep small ops like the TF graph, dense
+    TF-form Adam over the whole table), float32, timed on this host on a bounded sample of the same
+    workload: full sequence length / layers / vocabulary, a reduced batch."""
+    from oracle import hpmn_oracle as O
+    from oracle import torch_restatement as R
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    cfg = O.HpmnConfig(feature_size=c["V"], user_dim=c["F"], user_maxlen=c["T"], hidden_size=c["H"],
+                       embedding_size=16, hop=3, user_layers=tuple(c["periods"]), user_num_layers=c["K"],
+                       industry=c["industry"], memory_reg=c["memory_reg"])
+    p = R.to_torch(O.init_params(cfg, seed=seed, dtype=np.float32), torch.float32)
+    opt = R.TFAdam(p, c["lr"])
+    Bs = min(c["batch"], 128)
+    rng = np.random.default_rng(seed + 1)
+    ids = torch.as_tensor(rng.integers(1, c["V"], size=(Bs, c["T"], c["F"])))
+    label = torch.as_tensor(rng.integers(0, 2, size=Bs))
+    times = []
+    t_all = time.perf_counter()
+    while len(times) < 3 and (time.perf_counter() - t_all) < budget_s:
+        t0 = time.perf_counter()
+        R.train_step(cfg, p, opt, ids, label)
+        times.append(time.perf_counter() - t0)
+    best = min(times)
+    return {"value": Bs / best, "unit": "sequences/s", "cores": threads, "kind": "port",
+            "sample": "%d train steps (fwd+BPTT+clip+dense Adam) of batch %d at the full %s shape, fp32 "
+                      "PyTorch-CPU eager restatement (oracle/torch_restatement.py), best step %.2fs"
+                      % (len(times), Bs, c["name"], best)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the reference literal)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+    c = dict(CONFIGS[args.config])
+    if args.batch:
+        c["batch"] = args.batch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from hpmn_amd import build
+    if rank == 0:
+        build.build_library()
+    if world > 1:
+        torch.distributed.barrier()
+
+    tmp = tempfile.mkdtemp(prefix="hpmn_bench_")
+    model = build_model(c, tmp, device, seed=0)          # same seed -> identical replicas
+    n_distinct = 4
+    batches = synth_batches(c, n_distinct, c["batch"], 20190521 + 3 + 1000 * rank, device)
+    global_batch = c["batch"] * world
+
+    def step(i):
+        ids, label = batches[i % n_distinct]
+        model.train_step(ids, label, keep_prob=0.5, global_batch=global_batch)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # quick quality signal on the bench batches (not a trained AUC: weights saw only W+K steps)
+    out = model.forward_inference(batches[0][0])
+    finite = bool(torch.isfinite(out["prediction"]).all())
+
+    result = None
+    if rank == 0:
+        seqs = global_batch * args.steps
+        result = {
+            "metric": "training sequences/sec (fwd+BPTT+clip+dense Adam), XLong max_len=1000" if args.config == "c3"
+                      else "training sequences/sec (fwd+BPTT+clip+dense Adam)",
+            "value": seqs / elapsed, "unit": "sequences/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": c["name"], "config_id": args.config, "per_gpu_batch": c["batch"],
+                       "global_batch": global_batch, "max_len": c["T"], "scan_steps": layer_lengths(c),
+                       "hidden": c["H"], "layers": c["K"], "vocab_rows": c["V"], "keep_prob": 0.5,
+                       "parallelism": "dp%d" % world, "predictions_finite": finite},
+            "algorithmic": {"gru_flops_fwd_per_seq": algorithmic_flops_fwd(c),
+                            "train_tflops_equiv": 3 * algorithmic_flops_fwd(c) * seqs / elapsed / 1e12},
+        }
+        if not args.no_roofline:
+            roof, extra = roofline_probes(model, c, batches[0][0])
+            result["roofline"] = roof
+            result["kernels"] = extra
+        if not args.no_cpu_baseline and world == 1:
+            result["cpu_baseline"] = cpu_baseline(c)
+            result["speedup_vs_cpu_baseline"] = result["value"] / result["cpu_baseline"]["value"]
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

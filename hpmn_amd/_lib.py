@@ -1,0 +1,123 @@
+"""ctypes binding of ``libhpmn_hip.so`` (C ABI declared in ``include/hpmn_hip.h``).
+
+The library is built in-tree by ``hpmn_amd.build.build_library()`` (hipcc, gfx950).  There
+is NO fallback: if the shared object is missing or a call fails the product path raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+HPMN_MAX_LAYERS = 12
+HPMN_ABI_VERSION = 1
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libhpmn_hip.so")
+
+c_float_p = C.POINTER(C.c_float)
+c_int32_p = C.POINTER(C.c_int32)
+
+
+class HpmnInputProj(C.Structure):
+    _fields_ = [
+        ("B", C.c_int32), ("T", C.c_int32), ("D", C.c_int32), ("H", C.c_int32),
+        ("x", C.c_void_p), ("ids", C.c_void_p), ("emb", C.c_void_p),
+        ("Tids", C.c_int32), ("F", C.c_int32), ("E", C.c_int32), ("front_zero", C.c_int32),
+        ("mask_id0", C.c_int32),
+        ("V", C.c_int64),
+        ("wg", C.c_void_p), ("bg", C.c_void_p), ("wc", C.c_void_p), ("bc", C.c_void_p),
+        ("xp", C.c_void_p), ("x_out", C.c_void_p),
+    ]
+
+
+class HpmnGruFwd(C.Structure):
+    _fields_ = [
+        ("B", C.c_int32), ("T", C.c_int32), ("D", C.c_int32), ("H", C.c_int32),
+        ("xp", C.c_void_p), ("wg", C.c_void_p), ("wc", C.c_void_p),
+        ("h_last", C.c_void_p), ("h_last_stride", C.c_int64),
+        ("y", C.c_void_p), ("period", C.c_int32),
+        ("hs", C.c_void_p), ("gates", C.c_void_p),
+    ]
+
+
+class HpmnGruBwd(C.Structure):
+    _fields_ = [
+        ("B", C.c_int32), ("T", C.c_int32), ("D", C.c_int32), ("H", C.c_int32),
+        ("wg", C.c_void_p), ("wc", C.c_void_p),
+        ("hs", C.c_void_p), ("gates", C.c_void_p),
+        ("d_h_last", C.c_void_p), ("d_h_last_stride", C.c_int64),
+        ("d_y", C.c_void_p), ("period", C.c_int32),
+        ("d_act", C.c_void_p),
+    ]
+
+
+class HpmnScanDesc(C.Structure):
+    _fields_ = [
+        ("B", C.c_int32), ("T", C.c_int32), ("F", C.c_int32), ("E", C.c_int32),
+        ("H", C.c_int32), ("K", C.c_int32),
+        ("front_zero", C.c_int32), ("mask_id0", C.c_int32), ("last_index", C.c_int32),
+        ("V", C.c_int64),
+        ("periods", C.c_int32 * HPMN_MAX_LAYERS),
+    ]
+
+
+# every symbol include/hpmn_hip.h declares: (restype, argtypes)
+SIGNATURES = {
+    "hpmn_abi_version": (C.c_int, []),
+    "hpmn_strerror": (C.c_char_p, [C.c_int]),
+    "hpmn_last_hip_error": (C.c_int, []),
+    "hpmn_gru_shape_supported": (C.c_int, [C.c_int32, C.c_int32]),
+    "hpmn_embed_gather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
+                                    C.c_int64, C.c_int32, C.c_void_p]),
+    "hpmn_gru_input_proj": (C.c_int, [C.POINTER(HpmnInputProj), C.c_void_p]),
+    "hpmn_gru_scan_fwd": (C.c_int, [C.POINTER(HpmnGruFwd), C.c_void_p]),
+    "hpmn_gru_scan_bwd": (C.c_int, [C.POINTER(HpmnGruBwd), C.c_void_p]),
+    "hpmn_scan_workspace_bytes": (C.c_size_t, [C.POINTER(HpmnScanDesc)]),
+    "hpmn_scan_fwd": (C.c_int, [C.POINTER(HpmnScanDesc), C.c_void_p, C.c_void_p,
+                                C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hpmn_embed_grad_scatter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                          C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_void_p]),
+    "hpmn_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                 C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                 C.c_void_p]),
+}
+
+
+class HpmnLibraryError(RuntimeError):
+    pass
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def load(path: Optional[str] = None) -> C.CDLL:
+    """dlopen the HIP library and bind every declared symbol.  Raises if it is missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise HpmnLibraryError(
+            "%s not found: the HIP extension is not built.  Run `python -c \"import __graft_entry__ as g; "
+            "g.build()\"` (or hpmn_amd.build.build_library()).  There is no CPU fallback." % p)
+    lib = C.CDLL(p)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)       # AttributeError if the export is missing
+        fn.restype = res
+        fn.argtypes = args
+    got = lib.hpmn_abi_version()
+    if got != HPMN_ABI_VERSION:
+        raise HpmnLibraryError("ABI version mismatch: library %d, binding %d" % (got, HPMN_ABI_VERSION))
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        lib = load()
+        msg = lib.hpmn_strerror(rc).decode()
+        raise HpmnLibraryError("%s failed: %s (code %d, hipError %d)" % (what, msg, rc, lib.hpmn_last_hip_error()))

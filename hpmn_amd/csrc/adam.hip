@@ -1,0 +1,64 @@
+// TF-form Adam with per-element gradient clip, one launch over a flat parameter buffer.
+// HBM-bound: 16 B read (p,g,m,v) + 12 B written (p,m,v) per element, float4-vectorised.
+#include "common.h"
+
+namespace hpmn {
+
+__device__ __forceinline__ void adam_elem(float &p, float g, float &m, float &v, float lr_t, float b1,
+                                          float b2, float eps, float clip, float gs) {
+    g *= gs;
+    g = fminf(fmaxf(g, -clip), clip);
+    m = fmaf(b1, m, (1.f - b1) * g);
+    v = fmaf(b2, v, (1.f - b2) * g * g);
+    p -= lr_t * m / (sqrtf(v) + eps);
+}
+
+__global__ __launch_bounds__(256) void adam_kernel_v4(float4 *__restrict__ p, const float4 *__restrict__ g,
+                                                      float4 *__restrict__ m, float4 *__restrict__ v, long n4,
+                                                      float lr_t, float b1, float b2, float eps, float clip,
+                                                      float gs) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 pp = p[i], mm = m[i], vv = v[i];
+        const float4 gg = g[i];
+        adam_elem(pp.x, gg.x, mm.x, vv.x, lr_t, b1, b2, eps, clip, gs);
+        adam_elem(pp.y, gg.y, mm.y, vv.y, lr_t, b1, b2, eps, clip, gs);
+        adam_elem(pp.z, gg.z, mm.z, vv.z, lr_t, b1, b2, eps, clip, gs);
+        adam_elem(pp.w, gg.w, mm.w, vv.w, lr_t, b1, b2, eps, clip, gs);
+        p[i] = pp; m[i] = mm; v[i] = vv;
+    }
+}
+
+__global__ __launch_bounds__(256) void adam_kernel_v1(float *__restrict__ p, const float *__restrict__ g,
+                                                      float *__restrict__ m, float *__restrict__ v, long n,
+                                                      float lr_t, float b1, float b2, float eps, float clip,
+                                                      float gs) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float pp = p[i], mm = m[i], vv = v[i];
+        adam_elem(pp, g[i], mm, vv, lr_t, b1, b2, eps, clip, gs);
+        p[i] = pp; m[i] = mm; v[i] = vv;
+    }
+}
+
+int adam_launch(float *p, const float *g, float *m, float *v, int64_t n, float lr_t, float b1, float b2,
+                float eps, float clip, float gs, hipStream_t st) {
+    if (n == 0) return HPMN_OK;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) |
+                           reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15) == 0;
+    if (aligned && n % 4 == 0) {
+        const long n4 = n / 4;
+        long blocks = (n4 + 255) / 256;
+        if (blocks > 256L * 16) blocks = 256L * 16;
+        hipLaunchKernelGGL(adam_kernel_v4, dim3((unsigned)blocks), dim3(256), 0, st, (float4 *)p,
+                           (const float4 *)g, (float4 *)m, (float4 *)v, n4, lr_t, b1, b2, eps, clip, gs);
+    } else {
+        long blocks = (n + 255) / 256;
+        if (blocks > 256L * 16) blocks = 256L * 16;
+        hipLaunchKernelGGL(adam_kernel_v1, dim3((unsigned)blocks), dim3(256), 0, st, p, g, m, v, (long)n, lr_t,
+                           b1, b2, eps, clip, gs);
+    }
+    return check_launch();
+}
+
+}  // namespace hpmn

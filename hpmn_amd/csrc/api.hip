@@ -1,0 +1,203 @@
+// extern "C" surface of libhpmn_hip.so (declared in include/hpmn_hip.h): argument
+// validation, shape dispatch, and the multi-layer build_memory forward chain.
+#include "common.h"
+
+namespace hpmn {
+
+static thread_local int g_last_hip_error = 0;
+void set_last_hip_error(int e) { g_last_hip_error = e; }
+
+bool gru_shape_supported(int H, int D);
+int gru_scan_fwd_dispatch(const HpmnGruFwd &a, hipStream_t st);
+int gru_scan_bwd_dispatch(const HpmnGruBwd &a, hipStream_t st);
+bool input_proj_supported(int H, int D);
+int input_proj_dispatch(const HpmnInputProj &a, hipStream_t st);
+int embed_gather_launch(const int32_t *ids, int64_t ids_stride, const float *emb, float *out, int64_t N,
+                        int32_t F, int32_t E, int32_t mask_id0, hipStream_t st);
+int embed_grad_scatter_launch(const int32_t *ids, const float *d_x, float *d_emb, int32_t B, int32_t T,
+                              int32_t F, int32_t E, int32_t front_zero, int32_t mask_id0, hipStream_t st);
+int adam_launch(float *p, const float *g, float *m, float *v, int64_t n, float lr_t, float b1, float b2,
+                float eps, float clip, float gs, hipStream_t st);
+
+static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// Layer lengths of code/hpmn.py:122-128; false if some reshape there would not divide.
+static bool layer_lengths(const HpmnScanDesc &d, int32_t *len) {
+    if (d.K < 1 || d.K > HPMN_MAX_LAYERS) return false;
+    long t = (long)d.T + d.front_zero;
+    for (int i = 0; i < d.K; ++i) {
+        len[i] = (int32_t)t;
+        if (d.periods[i] < 1 || t % d.periods[i] != 0) return false;
+        t /= d.periods[i];
+    }
+    return true;
+}
+
+}  // namespace hpmn
+
+using namespace hpmn;
+
+extern "C" {
+
+int hpmn_abi_version(void) { return HPMN_ABI_VERSION; }
+
+const char *hpmn_strerror(int code) {
+    switch (code) {
+        case HPMN_OK: return "ok";
+        case HPMN_EINVAL: return "invalid argument";
+        case HPMN_EUNSUPPORTED: return "unsupported shape for the gfx950 kernels";
+        case HPMN_EHIP: return "HIP runtime error (see hpmn_last_hip_error)";
+        case HPMN_ENODEVICE: return "no gfx950 device";
+        default: return "unknown error";
+    }
+}
+
+int hpmn_last_hip_error(void) { return g_last_hip_error; }
+
+int hpmn_gru_shape_supported(int32_t H, int32_t D) {
+    return (gru_shape_supported(H, D) && input_proj_supported(H, D)) ? 1 : 0;
+}
+
+int hpmn_embed_gather(const int32_t *ids, const float *emb, float *out, int64_t N, int32_t F, int32_t E,
+                      int64_t V, int32_t mask_id0, void *stream) {
+    if (N < 0 || F < 1 || E < 4 || V < 1) return HPMN_EINVAL;
+    if (E % 4 != 0) return HPMN_EUNSUPPORTED;
+    if (N == 0) return HPMN_OK;
+    if (!ids || !emb || !out) return HPMN_EINVAL;
+    return embed_gather_launch(ids, F, emb, out, N, F, E, mask_id0, (hipStream_t)stream);
+}
+
+int hpmn_gru_input_proj(const HpmnInputProj *a, void *stream) {
+    if (!a) return HPMN_EINVAL;
+    if (a->B < 0 || a->T < 1 || a->D < 1 || a->H < 1) return HPMN_EINVAL;
+    if (!a->wg || !a->bg || !a->wc || !a->bc || !a->xp) return HPMN_EINVAL;
+    if (a->x == nullptr) {
+        if (!a->ids || !a->emb) return HPMN_EINVAL;
+        if (a->F < 1 || a->E < 4 || a->F * a->E != a->D || a->front_zero < 0 || a->Tids < 1 ||
+            a->front_zero + a->Tids != a->T)
+            return HPMN_EINVAL;
+        if (a->E % 4 != 0) return HPMN_EUNSUPPORTED;
+    }
+    if (!input_proj_supported(a->H, a->D)) return HPMN_EUNSUPPORTED;
+    if (a->B == 0) return HPMN_OK;
+    return input_proj_dispatch(*a, (hipStream_t)stream);
+}
+
+int hpmn_gru_scan_fwd(const HpmnGruFwd *a, void *stream) {
+    if (!a) return HPMN_EINVAL;
+    if (a->B < 0 || a->T < 1 || a->D < 1 || a->H < 1) return HPMN_EINVAL;
+    if (!a->xp || !a->wg || !a->wc || !a->h_last) return HPMN_EINVAL;
+    if ((a->hs == nullptr) != (a->gates == nullptr)) return HPMN_EINVAL;
+    if (a->y && (a->period < 1 || a->T % a->period != 0)) return HPMN_EINVAL;
+    if (!gru_shape_supported(a->H, a->D)) return HPMN_EUNSUPPORTED;
+    if (a->B == 0) return HPMN_OK;
+    HpmnGruFwd k = *a;
+    if (k.period < 1) k.period = 1;
+    return gru_scan_fwd_dispatch(k, (hipStream_t)stream);
+}
+
+int hpmn_gru_scan_bwd(const HpmnGruBwd *a, void *stream) {
+    if (!a) return HPMN_EINVAL;
+    if (a->B < 0 || a->T < 1 || a->D < 1 || a->H < 1) return HPMN_EINVAL;
+    if (!a->wg || !a->wc || !a->hs || !a->gates || !a->d_h_last || !a->d_act) return HPMN_EINVAL;
+    if (a->d_y && (a->period < 1 || a->T % a->period != 0)) return HPMN_EINVAL;
+    if (!gru_shape_supported(a->H, a->D)) return HPMN_EUNSUPPORTED;
+    if (a->B == 0) return HPMN_OK;
+    HpmnGruBwd k = *a;
+    if (k.period < 1) k.period = 1;
+    return gru_scan_bwd_dispatch(k, (hipStream_t)stream);
+}
+
+// workspace carve of hpmn_scan_fwd: [xp: B*T0*3H] [y0: B*(T0/p0)*H] [y1: same]
+static void scan_ws_sizes(const HpmnScanDesc &d, const int32_t *len, size_t &xp_bytes, size_t &y_bytes) {
+    xp_bytes = align_up((size_t)d.B * (size_t)len[0] * 3 * d.H * sizeof(float), 256);
+    y_bytes = d.K > 1 ? align_up((size_t)d.B * (size_t)(len[0] / d.periods[0]) * d.H * sizeof(float), 256) : 0;
+}
+
+size_t hpmn_scan_workspace_bytes(const HpmnScanDesc *d) {
+    int32_t len[HPMN_MAX_LAYERS];
+    if (!d || d->B < 0 || d->H < 1 || !layer_lengths(*d, len)) return 0;
+    size_t xp_bytes, y_bytes;
+    scan_ws_sizes(*d, len, xp_bytes, y_bytes);
+    return xp_bytes + 2 * y_bytes + 256;
+}
+
+int hpmn_scan_fwd(const HpmnScanDesc *d, const int32_t *ids, const float *emb, const float *const *wg,
+                  const float *const *bg, const float *const *wc, const float *const *bc, float *memory,
+                  float *last, void *workspace, void *stream) {
+    int32_t len[HPMN_MAX_LAYERS];
+    if (!d || !ids || !emb || !wg || !bg || !wc || !bc || !memory || !workspace) return HPMN_EINVAL;
+    if (d->B < 0 || d->T < 1 || d->F < 1 || d->E < 4 || d->H < 1 || d->V < 1) return HPMN_EINVAL;
+    if (!layer_lengths(*d, len)) return HPMN_EINVAL;
+    if (d->last_index >= 0 || -d->last_index > len[0]) return HPMN_EINVAL;
+    const int D0 = d->F * d->E;
+    if (!hpmn_gru_shape_supported(d->H, D0) || (d->K > 1 && !hpmn_gru_shape_supported(d->H, d->H)))
+        return HPMN_EUNSUPPORTED;
+    if (d->B == 0) return HPMN_OK;
+    hipStream_t st = (hipStream_t)stream;
+
+    size_t xp_bytes, y_bytes;
+    scan_ws_sizes(*d, len, xp_bytes, y_bytes);
+    char *ws = reinterpret_cast<char *>(align_up(reinterpret_cast<size_t>(workspace), 256));
+    float *xp = reinterpret_cast<float *>(ws);
+    float *ybuf[2] = {reinterpret_cast<float *>(ws + xp_bytes), reinterpret_cast<float *>(ws + xp_bytes + y_bytes)};
+
+    for (int i = 0; i < d->K; ++i) {
+        HpmnInputProj p = {};
+        p.B = d->B; p.T = len[i]; p.H = d->H;
+        p.wg = wg[i]; p.bg = bg[i]; p.wc = wc[i]; p.bc = bc[i];
+        p.xp = xp;
+        if (i == 0) {
+            p.D = D0; p.ids = ids; p.emb = emb;
+            p.Tids = d->T; p.F = d->F; p.E = d->E; p.front_zero = d->front_zero;
+            p.mask_id0 = d->mask_id0; p.V = d->V;
+        } else {
+            p.D = d->H; p.x = ybuf[(i - 1) & 1];
+        }
+        int rc = hpmn_gru_input_proj(&p, stream);
+        if (rc != HPMN_OK) return rc;
+
+        HpmnGruFwd a = {};
+        a.B = d->B; a.T = len[i]; a.H = d->H; a.D = p.D;
+        a.xp = xp; a.wg = wg[i]; a.wc = wc[i];
+        a.h_last = memory + (size_t)i * d->H;
+        a.h_last_stride = (int64_t)d->K * d->H;
+        a.period = d->periods[i];
+        a.y = (i + 1 < d->K) ? ybuf[i & 1] : nullptr;
+        rc = hpmn_gru_scan_fwd(&a, stream);
+        if (rc != HPMN_OK) return rc;
+    }
+    if (last) {
+        // uinp[:, last_index, :]: scan position len0+last_index -> loader position minus the zero prefix
+        const long tid = (long)len[0] + d->last_index - d->front_zero;
+        if (tid < 0) {
+            hipError_t e = hipMemsetAsync(last, 0, (size_t)d->B * D0 * sizeof(float), st);
+            if (e != hipSuccess) { set_last_hip_error((int)e); return HPMN_EHIP; }
+        } else {
+            int rc = embed_gather_launch(ids + tid * d->F, (int64_t)d->T * d->F, emb, last, d->B, d->F, d->E,
+                                         d->mask_id0, st);
+            if (rc != HPMN_OK) return rc;
+        }
+    }
+    return HPMN_OK;
+}
+
+int hpmn_embed_grad_scatter(const int32_t *ids, const float *d_x, float *d_emb, int32_t B, int32_t T,
+                            int32_t F, int32_t E, int32_t front_zero, int64_t V, int32_t mask_id0,
+                            void *stream) {
+    if (B < 0 || T < 1 || F < 1 || E < 1 || front_zero < 0 || V < 1) return HPMN_EINVAL;
+    if (64 % E != 0) return HPMN_EUNSUPPORTED;
+    if (B == 0) return HPMN_OK;
+    if (!ids || !d_x || !d_emb) return HPMN_EINVAL;
+    return embed_grad_scatter_launch(ids, d_x, d_emb, B, T, F, E, front_zero, mask_id0, (hipStream_t)stream);
+}
+
+int hpmn_adam_step(float *param, const float *grad, float *m, float *v, int64_t n, float lr_t, float beta1,
+                   float beta2, float eps, float clip, float grad_scale, void *stream) {
+    if (n < 0) return HPMN_EINVAL;
+    if (n == 0) return HPMN_OK;
+    if (!param || !grad || !m || !v) return HPMN_EINVAL;
+    return adam_launch(param, grad, m, v, n, lr_t, beta1, beta2, eps, clip, grad_scale, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,103 @@
+"""Batch iterators with the reference's interface (input-format surface).
+
+``DataLoader`` mirrors /root/reference/code/data_loader.py:267-301 (in-memory list of
+``(label, user_seq, user_len, item_seq, item_len)`` samples -> batches, 1-based batch index,
+last partial batch included).  ``DataLoader_Mul`` reads the XLong TSV line format of
+/root/reference/code/data_loader.py:57-85 (one line -> one positive and one negative row).
+The reference's 1-producer + 8-worker process pipeline is replaced by a plain in-process
+reader: parsing is off the hot path here because ``Hpmn`` keeps an int32 device-resident
+copy of every dataset it is given (see ``hpmn_amd.hpmn._DeviceDataset``).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+XLONG_ITEM_CNT = 3269017     # data_loader.py:49
+XLONG_HIST_LEN = 1000        # data_loader.py:57 (1000 + 1 with the target)
+XLONG_USER_PART_LEN = 184    # data_loader.py:57
+
+
+class DataLoader:
+    """Same constructor, iteration protocol and batch tuple as the reference class."""
+
+    def __init__(self, dataset, batch_size):
+        self.batch_size = int(batch_size)
+        self.dataset = dataset
+        n = len(dataset)
+        self.num_of_step = (n + self.batch_size - 1) // self.batch_size
+        self.i = 0
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        if self.i >= self.num_of_step:
+            raise StopIteration
+        lo = self.i * self.batch_size
+        chunk = self.dataset[lo:lo + self.batch_size]
+        label = [s[0] for s in chunk]
+        item_part = np.array([s[1] for s in chunk])
+        item_part_len = [s[2] for s in chunk]
+        user_part = np.array([s[3] for s in chunk])
+        user_part_len = [s[4] for s in chunk]
+        self.i += 1
+        return self.i, (label, item_part, item_part_len, user_part, user_part_len)
+
+    next = __next__
+
+
+def parse_xlong_line(line: str, item_cnt: int = XLONG_ITEM_CNT):
+    """One TSV line -> (pos_hist, neg_hist, user_pos, user_neg); data_loader.py:59-73.
+    Fields: index, uid, 1000 comma-separated item ids, pos target, neg target,
+    184 user ids (pos), 184 user ids (neg).  Every step is [uid + item_cnt, item]."""
+    f = line.rstrip("\n").split("\t")
+    uid = int(f[1]) + item_cnt
+    hist = np.fromstring(f[2], dtype=np.int64, sep=",") if f[2] else np.zeros(0, np.int64)
+    n = hist.shape[0]
+    pos = np.empty((n + 1, 2), dtype=np.int64)
+    pos[:, 0] = uid
+    pos[:n, 1] = hist
+    neg = pos.copy()
+    pos[n, 1] = int(f[3])
+    neg[n, 1] = int(f[4])
+    up = np.fromstring(f[5], dtype=np.int64, sep=",") if len(f) > 5 and f[5] else np.zeros(0, np.int64)
+    un = np.fromstring(f[6], dtype=np.int64, sep=",") if len(f) > 6 and f[6] else np.zeros(0, np.int64)
+    return pos, neg, up, un
+
+
+class DataLoader_Mul:
+    """XLong text-file loader: ``batchsize // 2`` lines per batch, two rows per line
+    (label 1 with the positive target, label 0 with the negative one; data_loader.py:75-80).
+    Yields ``(None, (label, item_part [2n,1001,2], item_part_len, user_part [2n,184,1],
+    user_part_len))`` like data_loader.py:85."""
+
+    def __init__(self, dataset, batchsize, max_q_size=10, wait_time=0.1, worker_n=8):
+        self.lines_per_batch = max(1, int(batchsize) // 2)
+        self.path = dataset
+        self._fh = open(dataset)
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        lines = []
+        for _ in range(self.lines_per_batch):
+            ln = self._fh.readline()
+            if not ln:
+                break
+            lines.append(ln)
+        if not lines:
+            self._fh.close()
+            raise StopIteration
+        label, item_part, user_part = [], [], []
+        for ln in lines:
+            pos, neg, up, un = parse_xlong_line(ln)
+            label += [1, 0]
+            item_part += [pos, neg]
+            user_part += [up, un]
+        item_part = np.stack(item_part)
+        user_part = np.stack(user_part)[:, :, None]
+        n2 = len(label)
+        return None, (label, item_part, [item_part.shape[1]] * n2, user_part, [user_part.shape[1]] * n2)
+
+    next = __next__

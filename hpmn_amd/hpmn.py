@@ -1,0 +1,487 @@
+"""HPMN train/eval entrypoint on MI355X -- drop-in for the reference's ``code/hpmn.py``.
+
+Same classes (``Hpmn_Basic`` / ``Hpmn_Industry`` / ``Hpmn``), constructor arguments,
+``train/eval/save_model/load_model/get_weights/log`` methods, ``result.log`` line format and
+CLI (``python hpmn.py <amazon|taobao|xlong>``) as /root/reference/code/hpmn.py; everything
+below ``sess.run`` is replaced: the embedding gather, the periodic GRU memory update (forward
+and BPTT), the embedding-gradient scatter and the TF-form Adam run in ``libhpmn_hip.so``
+(hand-written HIP for gfx950), PyTorch-ROCm supplies device memory, streams, autograd glue
+for the small read path, and RCCL (``torch.distributed`` backend ``nccl``) for data parallel.
+
+There is no CPU fallback: constructing a model without a GPU + the built library raises.
+"""
+from __future__ import annotations
+
+import math
+import os
+import sys
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import dist, ops
+from .data_loader import DataLoader, DataLoader_Mul
+from .ops import ScanSpec
+
+BN_EPS = 1e-3        # tf.layers.batch_normalization default (code/hpmn.py:190)
+LOGLOSS_EPS = 1e-7   # tf.losses.log_loss default (code/hpmn.py:202)
+
+
+def _glorot_uniform_(t: torch.Tensor, gen: torch.Generator):
+    fan_in, fan_out = t.shape[0], t.shape[1]
+    lim = math.sqrt(6.0 / (fan_in + fan_out))
+    t.uniform_(-lim, lim, generator=gen)
+
+
+class _DeviceDataset:
+    """int32 device-resident copy of a dataset (list-of-samples or XLong TSV path), built once.
+    Replaces the per-batch Python-list -> ndarray -> feed_dict conversion of
+    code/data_loader.py:283-296 / code/hpmn.py:474-481; batches are slices in stored order,
+    exactly the batches ``DataLoader`` would yield."""
+
+    def __init__(self, dataset, device, industry: bool):
+        if isinstance(dataset, dict):
+            ids, label = dataset["ids"], dataset["label"]
+            length = dataset.get("length")
+        elif isinstance(dataset, str):
+            chunks, labels = [], []
+            for _, data in DataLoader_Mul(dataset, 512):
+                labels += data[0]
+                chunks.append(np.asarray(data[1], dtype=np.int32))
+            ids = np.concatenate(chunks, axis=0)
+            label = np.asarray(labels, dtype=np.int32)
+            length = None
+        else:
+            label = np.asarray([s[0] for s in dataset], dtype=np.int32)
+            ids = np.asarray([s[1] for s in dataset], dtype=np.int32)
+            length = np.asarray([s[2] for s in dataset], dtype=np.int32)
+        self.n = int(ids.shape[0])
+        self.ids = torch.as_tensor(np.ascontiguousarray(ids, dtype=np.int32)).to(device)
+        self.label_np = np.asarray(label, dtype=np.int32)
+        self.label = torch.as_tensor(self.label_np).to(device)
+        self.length_np = None if length is None else np.asarray(length)
+
+    def batches(self, batch_size: int):
+        for lo in range(0, self.n, batch_size):
+            yield lo, min(self.n, lo + batch_size)
+
+
+class Hpmn_Basic(object):
+    """Counterpart of ``Hpmn_Basic`` (code/hpmn.py:16-215): owns variables, optimiser state and
+    the train step.  ``dist`` = (rank, world) enables data parallel over RCCL."""
+
+    eval_every = 100
+    industry = False
+
+    def __init__(self, path, trainset, testset, feature_size, user_dim, item_dim, learning_rate,
+                 hidden_size, embedding_size, hop, user_layers, item_layers, user_num_layers,
+                 item_num_layers, user, item, emb_initializer=None, l2_reg=0, memory_reg=1e-5,
+                 device=None, seed: Optional[int] = None, verbose: bool = True):
+        if not torch.cuda.is_available():
+            raise RuntimeError("hpmn_amd needs an MI355X (ROCm) device: the hot path is HIP-only, "
+                               "there is no CPU fallback")
+        ops._lib.load()       # raises loudly if libhpmn_hip.so is not built
+        if not user:
+            raise NotImplementedError("item-only mode (user=False) is not built yet; every reference "
+                                      "configuration uses user=True, item=False (code/hpmn.py:591-592)")
+        if item:
+            raise NotImplementedError("dual mode (item=True) is not built yet (SURVEY.md 8f rank 3)")
+        self._path = path
+        self.trainset, self.testset = trainset, testset
+        self.feature_size = int(feature_size)
+        self.learning_rate = float(learning_rate)
+        self.l2_reg, self.memory_reg = float(l2_reg), float(memory_reg)
+        self.hidden_size, self.embedding_size = int(hidden_size), int(embedding_size)
+        self.hop = int(hop)
+        self.user_layers, self.item_layers = list(user_layers), list(item_layers)
+        self.user_num_layers, self.item_num_layers = int(user_num_layers), int(item_num_layers)
+        self.user_dim, self.item_dim = int(user_dim), int(item_dim)
+        self.user, self.item = user, item
+        self.verbose = verbose
+        self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+        assert self.user_num_layers <= len(self.user_layers)     # code/hpmn.py:115
+        self.rank, self.world = dist.rank_world()
+        self._save_path = None
+        self._datasets: Dict[int, _DeviceDataset] = {}
+        self.spec = self._make_spec()
+        self._build_variables(emb_initializer, seed)
+        self.adam_t = 0
+        self.beta1, self.beta2, self.adam_eps = 0.9, 0.999, 1e-8   # tf.train.AdamOptimizer defaults
+        os.makedirs(self._path, exist_ok=True)
+
+    # ------------------------------------------------------------------ graph description
+    def _make_spec(self) -> ScanSpec:
+        raise NotImplementedError
+
+    # ------------------------------------------------------------------ variables
+    def _param_shapes(self) -> List[Tuple[str, Tuple[int, ...]]]:
+        H, D0 = self.hidden_size, self.spec.D0
+        shp = [("Embedding/emb_mtx", (self.feature_size, self.embedding_size))]
+        for i in range(self.user_num_layers):
+            d = D0 if i == 0 else H
+            shp += [("User/GRU%d/gates/kernel" % i, (d + H, 2 * H)), ("User/GRU%d/gates/bias" % i, (2 * H,)),
+                    ("User/GRU%d/candidate/kernel" % i, (d + H, H)), ("User/GRU%d/candidate/bias" % i, (H,))]
+        shp += [("User/dense/kernel", (D0, H)), ("User/dense/bias", (H,)), ("User/map", (H, H))]
+        n = 1
+        for _ in range(self.hop):
+            for fin, fout in ((4 * H, 80), (80, 40), (40, 1)):      # code/hpmn.py:137-139
+                shp += [("User/dense_%d/kernel" % n, (fin, fout)), ("User/dense_%d/bias" % n, (fout,))]
+                n += 1
+        shp += [("output/bn1/gamma", (H + D0,)), ("output/bn1/beta", (H + D0,))]
+        for name, fin, fout in (("fc1", H + D0, 200), ("fc2", 200, 80), ("fc3", 80, 1)):   # :191-195
+            shp += [("output/%s/kernel" % name, (fin, fout)), ("output/%s/bias" % name, (fout,))]
+        return shp
+
+    def _build_variables(self, emb_initializer, seed):
+        """All variables live in ONE flat fp32 buffer (with matching flat grad / Adam m / v), so the
+        optimiser is one kernel launch and data parallel is one all-reduce.  Initialisers are
+        TF1.4's defaults: glorot-uniform kernels, zero biases, GRU gate bias 1.0."""
+        shapes = self._param_shapes()
+        offs, n = {}, 0
+        for name, shape in shapes:
+            offs[name] = n
+            n += (int(np.prod(shape)) + 3) // 4 * 4      # keep every view 16-byte aligned
+        self._n_flat = n
+        dev = self.device
+        self.flat_param = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.flat_grad = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.flat_m = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.flat_v = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.params: Dict[str, torch.Tensor] = {}
+        self.grads: Dict[str, torch.Tensor] = {}
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(0 if seed is None else int(seed))
+        for name, shape in shapes:
+            k = int(np.prod(shape))
+            p = self.flat_param[offs[name]:offs[name] + k].view(shape)
+            g = self.flat_grad[offs[name]:offs[name] + k].view(shape)
+            if name == "Embedding/emb_mtx" and emb_initializer is not None:
+                p.copy_(torch.as_tensor(np.asarray(emb_initializer, dtype=np.float32)))
+            elif name.endswith("gates/bias") or name.endswith("gamma"):
+                p.fill_(1.0)
+            elif len(shape) == 2:
+                _glorot_uniform_(p, gen)
+            p.requires_grad_(True)
+            self.params[name] = p
+            self.grads[name] = g
+        self._emb_numel_padded = offs[shapes[1][0]]     # emb is first; dense part starts here
+        self._gru_names = [["User/GRU%d/%s" % (i, s) for s in
+                            ("gates/kernel", "gates/bias", "candidate/kernel", "candidate/bias")]
+                           for i in range(self.user_num_layers)]
+
+    def set_params(self, values: Dict[str, np.ndarray]):
+        """Inject weights (parity tests: identical weights => identical logits)."""
+        with torch.no_grad():
+            for k, v in values.items():
+                self.params[k].copy_(torch.as_tensor(np.asarray(v, dtype=np.float32)).to(self.device))
+
+    def get_params(self) -> Dict[str, np.ndarray]:
+        return {k: v.detach().cpu().numpy().copy() for k, v in self.params.items()}
+
+    def _gru_weights(self) -> List[torch.Tensor]:
+        return [self.params[n] for names in self._gru_names for n in names]
+
+    # ------------------------------------------------------------------ read path (code/hpmn.py:133-199)
+    @staticmethod
+    def get_covreg(memory):
+        H = memory.shape[2]
+        c = memory - memory.mean(dim=2, keepdim=True)
+        cov = torch.matmul(c, c.transpose(1, 2)) / float(H)
+        cov = cov - torch.diag_embed(torch.diagonal(cov, dim1=1, dim2=2))
+        return torch.sqrt((cov * cov).sum(dim=(1, 2))).sum()
+
+    def attention(self, first_dense, memory, query):
+        p = self.params
+        B, K, H = memory.shape
+        q = query.unsqueeze(1).expand(B, K, H)
+        inp = torch.cat([q, memory, q - memory, q * memory], dim=-1)
+        n = first_dense
+        fc1 = torch.relu(torch.addmm(p["User/dense_%d/bias" % n], inp.reshape(B * K, 4 * H), p["User/dense_%d/kernel" % n]))
+        fc2 = torch.relu(torch.addmm(p["User/dense_%d/bias" % (n + 1)], fc1, p["User/dense_%d/kernel" % (n + 1)]))
+        fc3 = torch.addmm(p["User/dense_%d/bias" % (n + 2)], fc2, p["User/dense_%d/kernel" % (n + 2)])
+        score = torch.softmax(fc3.reshape(B, K), dim=1)
+        return (memory * score.unsqueeze(2)).sum(dim=1), score
+
+    def query_memory(self, last, memory):
+        p = self.params
+        q = torch.addmm(p["User/dense/bias"], last, p["User/dense/kernel"])
+        w0 = None
+        for hop in range(self.hop):
+            read, w = self.attention(3 * hop + 1, memory, q)
+            q = q @ p["User/map"] + read
+            if hop == 0:
+                w0 = w
+        return q, w0
+
+    def build_fc_net(self, repre, keep_prob=1.0, masks=None):
+        p = self.params
+        bn = repre * (p["output/bn1/gamma"] / math.sqrt(1.0 + BN_EPS)) + p["output/bn1/beta"]
+        fc1 = torch.nn.functional.elu(torch.addmm(p["output/fc1/bias"], bn, p["output/fc1/kernel"]))
+        if masks is not None:
+            fc1 = fc1 * masks[0] / keep_prob
+        elif keep_prob < 1.0:
+            fc1 = torch.nn.functional.dropout(fc1, 1.0 - keep_prob, training=True)
+        fc2 = torch.nn.functional.elu(torch.addmm(p["output/fc2/bias"], fc1, p["output/fc2/kernel"]))
+        if masks is not None:
+            fc2 = fc2 * masks[1] / keep_prob
+        elif keep_prob < 1.0:
+            fc2 = torch.nn.functional.dropout(fc2, 1.0 - keep_prob, training=True)
+        logit = torch.addmm(p["output/fc3/bias"], fc2, p["output/fc3/kernel"]).reshape(-1)
+        return logit, torch.sigmoid(logit)
+
+    # ------------------------------------------------------------------ forward passes
+    def _read(self, memory, last, keep_prob=1.0, masks=None):
+        mem_loss = self.get_covreg(memory)
+        q, w0 = self.query_memory(last, memory)
+        repre = torch.cat([q, last], dim=-1)
+        logit, pred = self.build_fc_net(repre, keep_prob, masks)
+        return dict(memory=memory, memory_loss=mem_loss, query=q, user_weights=w0, logit=logit,
+                    prediction=pred)
+
+    @torch.no_grad()
+    def forward_inference(self, ids: torch.Tensor):
+        """Eval-mode forward (keep_prob 1): HIP scan chain via hpmn_scan_fwd + read path."""
+        memory, last = ops.scan_forward_inference(self.spec, ids, self.params["Embedding/emb_mtx"],
+                                                  [w.detach() for w in self._gru_weights()])
+        return self._read(memory, last)
+
+    def forward_train(self, ids: torch.Tensor, keep_prob=0.5, masks=None, scatter_into_flat=True):
+        emb = self.params["Embedding/emb_mtx"]
+        memory, last = ops.memory_scan(self.spec, ids, emb, self._gru_weights(),
+                                       d_emb_out=self.grads["Embedding/emb_mtx"] if scatter_into_flat else None)
+        return self._read(memory, last, keep_prob, masks)
+
+    def loss(self, out, label: torch.Tensor, global_batch: int):
+        """cross_entropy of code/hpmn.py:202-207 for a (possibly sharded) batch: the log-loss is a
+        MEAN over the global batch, the memory regulariser a SUM."""
+        y = label.to(torch.float32)
+        pred = out["prediction"]
+        ll_sum = (-y * torch.log(pred + LOGLOSS_EPS) - (1.0 - y) * torch.log(1.0 - pred + LOGLOSS_EPS)).sum()
+        ce = dist.sharded_loss(ll_sum, out["memory_loss"], global_batch, self.memory_reg)
+        if self.l2_reg:
+            # every rank holds every variable: add the l2 term once (scaled by 1/world before the sum-reduce)
+            ce = ce + (self.l2_reg / self.world) * sum(0.5 * (v * v).sum() for v in self.params.values())
+        return ce
+
+    # ------------------------------------------------------------------ one training step
+    def train_step(self, ids: torch.Tensor, label: torch.Tensor, keep_prob=0.5, masks=None,
+                   global_batch: Optional[int] = None):
+        """sess.run(train_step) of code/hpmn.py:482: forward, BPTT, clip, dense TF Adam."""
+        if global_batch is None:
+            global_batch = ids.shape[0] * self.world
+        self.flat_grad.zero_()
+        for name, p in self.params.items():
+            p.grad = self.grads[name]
+        out = self.forward_train(ids, keep_prob, masks)
+        ce = self.loss(out, label, global_batch)
+        ce.backward()
+        dist.allreduce_sum_(self.flat_grad)                     # RCCL sum; clip happens after (8e)
+        self.apply_gradients()
+        return out, ce
+
+    def apply_gradients(self):
+        self.adam_t += 1
+        t = self.adam_t
+        lr_t = self.learning_rate * math.sqrt(1.0 - self.beta2 ** t) / (1.0 - self.beta1 ** t)
+        with torch.no_grad():
+            ops.adam_step(self.flat_param, self.flat_grad, self.flat_m, self.flat_v, lr_t,
+                          self.beta1, self.beta2, self.adam_eps, clip=1.0)
+
+    # ------------------------------------------------------------------ datasets
+    def _dev(self, dataset) -> _DeviceDataset:
+        key = id(dataset)
+        ds = self._datasets.get(key)
+        if ds is None:
+            ds = self._datasets[key] = _DeviceDataset(dataset, self.device, self.industry)
+        return ds
+
+    # ------------------------------------------------------------------ harness (code/hpmn.py:467-519)
+    def train(self, epochs, batchsize):
+        step, count, best = 0, 0, 0.0
+        ds = self._dev(self.trainset)
+        for _ in range(epochs):
+            for lo, hi in ds.batches(batchsize):
+                step += 1
+                # data parallel: every rank takes a contiguous slice of the global batch
+                a, b = dist.shard_bounds(lo, hi, self.rank, self.world)
+                self.train_step(ds.ids[a:b], ds.label[a:b], keep_prob=0.5, global_batch=hi - lo)
+                if step % self.eval_every == 0:
+                    result = list(self.eval(self.trainset, 4 * batchsize))
+                    result += list(self.eval(self.testset, 4 * batchsize))
+                    self.log(step, result)
+                    if result[3] <= best:
+                        count += 1
+                        if count > 3:
+                            return best
+                    else:
+                        count = 0
+                        best = result[3]
+        return best
+
+    def eval(self, dataset, batchsize):
+        """-> (auc, log-loss, mean of per-batch memory_loss); code/hpmn.py:497-519.  With data
+        parallel every rank scores a slice of each batch and predictions are all-gathered."""
+        from sklearn.metrics import log_loss, roc_auc_score
+        ds = self._dev(dataset)
+        preds, mem_losses = [], []
+        for lo, hi in ds.batches(batchsize):
+            a, b = dist.shard_bounds(lo, hi, self.rank, self.world)
+            out = self.forward_inference(ds.ids[a:b])
+            pred, ml = out["prediction"], out["memory_loss"].reshape(1)
+            if self.world > 1:
+                pred = dist.gather_predictions(pred.contiguous(), hi - lo)
+                dist.allreduce_sum_(ml)
+            preds.append(pred)
+            mem_losses.append(ml)
+        preds = torch.cat(preds).cpu().numpy().astype(np.float64)
+        mem_loss = float(torch.cat(mem_losses).mean().item())
+        labels = ds.label_np
+        auc = roc_auc_score(labels, preds)
+        loss = log_loss(labels, preds)
+        return auc, loss, mem_loss
+
+    def get_weights(self):
+        """code/hpmn.py:521-560: first-hop attention weights over train+test at batch 512."""
+        weights, lengths, labels = [], [], []
+        for dataset in (self.trainset, self.testset):
+            ds = self._dev(dataset)
+            for lo, hi in ds.batches(512):
+                weights.append(self.forward_inference(ds.ids[lo:hi])["user_weights"].cpu().numpy())
+            if ds.length_np is not None:
+                lengths.append(ds.length_np)
+            labels.append(ds.label_np)
+        np.save(self._path + "/weights.npy", np.concatenate(weights))
+        if lengths:
+            np.save(self._path + "/lengths.npy", np.concatenate(lengths))
+        np.save(self._path + "/labels.npy", np.concatenate(labels))
+
+    # ------------------------------------------------------------------ artefacts
+    @property
+    def save_path(self):
+        if self._save_path is None:
+            d = "%s/ckpt" % self._path
+            os.makedirs(d, exist_ok=True)
+            self._save_path = os.path.join(d, "model.ckpt")
+        return self._save_path
+
+    def save_model(self, global_step=None):
+        if self.rank != 0:
+            return
+        path = self.save_path if global_step is None else "%s-%s" % (self.save_path, global_step)
+        torch.save({"variables": {k: v.detach().cpu() for k, v in self.params.items()},
+                    "adam_m": self.flat_m.cpu(), "adam_v": self.flat_v.cpu(), "adam_t": self.adam_t}, path)
+
+    def load_model(self):
+        try:
+            ck = torch.load(self.save_path, map_location="cpu")
+            self.set_params({k: v.numpy() for k, v in ck["variables"].items()})
+            self.flat_m.copy_(ck["adam_m"])
+            self.flat_v.copy_(ck["adam_v"])
+            self.adam_t = int(ck["adam_t"])
+        except Exception:
+            raise IOError("Failed to load model from save path: %s" % self.save_path)
+        print("Successfully load model from save path: %s" % self.save_path)
+
+    def log(self, step, result):
+        if self.rank != 0:
+            return
+        if self.verbose:
+            print("Step: %s\tTrain AUC: %.5f\tTrain Loss: %.5f\tTrain Mem_loss: %.5f"
+                  "\tTest AUC: %.5f\tTest Loss: %.5f\tTest Mem_loss: %.5f" % ((str(step),) + tuple(result[:6])))
+        with open(self._path + "/result.log", "a") as fout:
+            fout.write("%s\t%.5f\t%.5f\t%.5f\t%.5f\t%.5f\t%.5f\n" % ((str(step),) + tuple(result[:6])))
+
+
+class Hpmn_Industry(Hpmn_Basic):
+    """XLong graph (code/hpmn.py:217-410): bare embedding lookup, 23 zero steps in front
+    (1001 -> 1024), query row = position -2, eval every 10 steps."""
+
+    eval_every = 10
+    industry = True
+
+    def __init__(self, path, trainset, testset, feature_size, user_dim, item_dim, user_maxlen, item_maxlen,
+                 learning_rate, hidden_size, embedding_size, hop, user_layers, item_layers, user_num_layers,
+                 item_num_layers, user, item, emb_initializer=None, l2_reg=0, memory_reg=1e-5, **kw):
+        self.user_maxlen, self.item_maxlen = int(user_maxlen), int(item_maxlen)
+        super(Hpmn_Industry, self).__init__(path, trainset, testset, feature_size, user_dim, item_dim,
+                                            learning_rate, hidden_size, embedding_size, hop, user_layers,
+                                            item_layers, user_num_layers, item_num_layers, user, item,
+                                            emb_initializer, l2_reg, memory_reg, **kw)
+
+    def _make_spec(self) -> ScanSpec:
+        # code/hpmn.py:288-292
+        return ScanSpec(F=self.user_dim, E=self.embedding_size, H=self.hidden_size, K=self.user_num_layers,
+                        T=self.user_maxlen, periods=tuple(self.user_layers[:self.user_num_layers]),
+                        front_zero=23,     # literal of code/hpmn.py:288 (1001 + 23 = 1024 = the literal of :290)
+                        mask_id0=False, last_index=-2)
+
+    def get_weights(self):
+        """code/hpmn.py:375-410."""
+        weights, ids = [], []
+        for dataset in (self.trainset, self.testset):
+            ds = self._dev(dataset)
+            for lo, hi in ds.batches(512):
+                weights.append(self.forward_inference(ds.ids[lo:hi])["user_weights"].cpu().numpy())
+                ids.append(ds.ids[lo:hi, :, 1].cpu().numpy())
+        np.save(self._path + "/weights_new.npy", np.concatenate(weights))
+        np.save(self._path + "/ids.npy", np.concatenate(ids))
+
+
+class Hpmn(Hpmn_Industry):
+    """Amazon/Taobao graph (code/hpmn.py:413-560): masked embedding (id 0 -> zero row), no zero
+    prefix, query row = the target (position -1), eval every 100 steps."""
+
+    eval_every = 100
+    industry = False
+
+    def _make_spec(self) -> ScanSpec:
+        return ScanSpec(F=self.user_dim, E=self.embedding_size, H=self.hidden_size, K=self.user_num_layers,
+                        T=self.user_maxlen, periods=tuple(self.user_layers[:self.user_num_layers]),
+                        front_zero=0, mask_id0=True, last_index=-1)
+
+    get_weights = Hpmn_Basic.get_weights
+
+
+# ---------------------------------------------------------------------------------------
+# CLI (code/hpmn.py:563-667): same argv, same relative data paths, same hyper-parameters
+# ---------------------------------------------------------------------------------------
+def main(argv: Sequence[str]) -> int:
+    from .datasets import load_dataset_pkl
+    if len(argv) != 2:
+        print("Useage: python hpmn.py [dataset]")
+        return 1
+    dataset_name = argv[1]
+    if dataset_name == "amazon":
+        trainset, testset, feature_size = load_dataset_pkl("../data/amazon/dataset_hpmn.pkl")
+        model = Hpmn("model/amazon/hpmn/", trainset, testset, feature_size, 3, 2, 100, 100, 0.003, 32, 16, 3,
+                     [2, 2, 5, 5, 1], [2, 2, 5, 5, 1], 3, 3, True, False, l2_reg=0., memory_reg=1e-5)
+        model.train(2, 128)
+        model.save_model()
+    elif dataset_name == "taobao":
+        trainset, testset, feature_size = load_dataset_pkl("../data/taobao/dataset_hpmn.pkl")
+        model = Hpmn("model/taobao/hpmn/", trainset, testset, feature_size, 4, 3, 300, 36, 0.001, 32, 16, 3,
+                     [2, 2, 3, 5, 5, 1], [2, 2, 3, 3, 1], 4, 5, True, False, l2_reg=0, memory_reg=1e-5)
+        model.train(2, 128)
+        model.save_model()
+    elif dataset_name == "xlong":
+        train_set = "../data/xlong/train_corpus_total_dual.txt"
+        test_set = "../data/xlong/test_corpus_total_dual.txt"
+        pv_cnt = 19002
+        graph_emb = np.load("../data/xlong/graph_emb.npy")
+        feature_size = pv_cnt + graph_emb.shape[0] + 20000
+        emb_initializer = np.concatenate((graph_emb, np.zeros([20000, 16]), np.zeros([pv_cnt, 16])),
+                                         0).astype(np.float32)
+        model = Hpmn_Industry("model/xlong/hpmn/", train_set, test_set, feature_size, 2, 1, 1000 + 1, 184,
+                              0.001, 32, 16, 3, [2] * 10 + [1], [3, 2, 2, 2, 2, 2, 2, 1], 5, 8, True, False,
+                              emb_initializer, l2_reg=0, memory_reg=5e-5)
+        model.train(epochs=3, batchsize=500)
+        model.get_weights()
+    else:
+        print("Dataset must be one of taobao or amazon.")
+        return 1
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv))

@@ -1,0 +1,309 @@
+"""Host-side operators over the C ABI of libhpmn_hip.so.
+
+Everything numerical on the hot path runs in the HIP library; PyTorch supplies device
+memory, the current stream, autograd plumbing and the plain library GEMMs that turn the
+reverse scan's pre-activation gradients into weight/input gradients.
+
+Reference being replaced: ``Hpmn.embedding`` + ``Hpmn_Basic.build_memory`` of
+/root/reference/code/hpmn.py:414-430, :113-129 (the covariance loss of :130 and the read
+path stay in ``hpmn_amd.model``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import HpmnGruBwd, HpmnGruFwd, HpmnInputProj, HpmnScanDesc
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _chk_f32(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise ValueError("expected contiguous float32 CUDA tensor, got %s %s contiguous=%s"
+                             % (t.device, t.dtype, t.is_contiguous()))
+
+
+def _chk_ids(ids):
+    if not (ids.is_cuda and ids.dtype == torch.int32 and ids.is_contiguous()):
+        raise ValueError("ids must be a contiguous int32 CUDA tensor")
+
+
+@dataclass(frozen=True)
+class ScanSpec:
+    """Static description of one branch's build_memory (code/hpmn.py:113-131, 284-296, 436-442)."""
+    F: int
+    E: int
+    H: int
+    K: int
+    T: int                       # user_maxlen as fed by the loader
+    periods: Tuple[int, ...]     # li_layer
+    front_zero: int = 0          # 23 for Hpmn_Industry (code/hpmn.py:288-290)
+    mask_id0: bool = True        # Hpmn (code/hpmn.py:417-422); False for Hpmn_Industry
+    last_index: int = -1         # code/hpmn.py:439 (-1) / :292 (-2)
+
+    @property
+    def D0(self) -> int:
+        return self.F * self.E
+
+    def layer_lengths(self) -> List[int]:
+        out, t = [], self.T + self.front_zero
+        for i in range(self.K):
+            out.append(t)
+            if t % self.periods[i] != 0:
+                raise ValueError("layer %d: length %d not divisible by period %d (the tf.reshape at "
+                                 "code/hpmn.py:124 would fail too)" % (i, t, self.periods[i]))
+            t //= self.periods[i]
+        return out
+
+    def desc(self, B: int, V: int) -> HpmnScanDesc:
+        d = HpmnScanDesc()
+        d.B, d.T, d.F, d.E, d.H, d.K = B, self.T, self.F, self.E, self.H, self.K
+        d.front_zero, d.mask_id0, d.last_index, d.V = self.front_zero, int(self.mask_id0), self.last_index, V
+        for i in range(self.K):
+            d.periods[i] = self.periods[i]
+        return d
+
+
+# ---------------------------------------------------------------------------------------
+# thin wrappers, one per C entry point
+# ---------------------------------------------------------------------------------------
+def embed_gather(ids: torch.Tensor, emb: torch.Tensor, mask_id0: bool) -> torch.Tensor:
+    """hpmn_embed_gather: ids [..., F] int32 -> [..., F*E]."""
+    _chk_ids(ids)
+    _chk_f32(emb)
+    F = ids.shape[-1]
+    V, E = emb.shape
+    N = ids.numel() // F
+    out = torch.empty(*ids.shape[:-1], F * E, device=emb.device, dtype=torch.float32)
+    rc = _lib.load().hpmn_embed_gather(ids.data_ptr(), emb.data_ptr(), out.data_ptr(), N, F, E, V,
+                                        int(mask_id0), _stream())
+    _lib.check(rc, "hpmn_embed_gather")
+    return out
+
+
+def gru_input_proj(spec_or_none, *, x=None, ids=None, emb=None, wg, bg, wc, bc, H, T, front_zero=0,
+                   mask_id0=False, want_x_out=False):
+    """hpmn_gru_input_proj.  Returns (xp [B,T,3H], x_out or None)."""
+    a = HpmnInputProj()
+    _chk_f32(wg, bg, wc, bc)
+    if x is not None:
+        _chk_f32(x)
+        B, Tx, D = x.shape
+        assert Tx == T
+        a.x = x.data_ptr()
+        dev = x.device
+    else:
+        _chk_ids(ids)
+        _chk_f32(emb)
+        B, Tids, F = ids.shape
+        V, E = emb.shape
+        D = F * E
+        a.ids, a.emb = ids.data_ptr(), emb.data_ptr()
+        a.Tids, a.F, a.E, a.front_zero, a.mask_id0, a.V = Tids, F, E, front_zero, int(mask_id0), V
+        dev = emb.device
+    a.B, a.T, a.D, a.H = B, T, D, H
+    a.wg, a.bg, a.wc, a.bc = wg.data_ptr(), bg.data_ptr(), wc.data_ptr(), bc.data_ptr()
+    xp = torch.empty(B, T, 3 * H, device=dev, dtype=torch.float32)
+    x_out = None
+    if want_x_out and x is None:
+        x_out = torch.empty(B, T, D, device=dev, dtype=torch.float32)
+        a.x_out = x_out.data_ptr()
+    a.xp = xp.data_ptr()
+    rc = _lib.load().hpmn_gru_input_proj(C.byref(a), _stream())
+    _lib.check(rc, "hpmn_gru_input_proj")
+    return xp, x_out
+
+
+def gru_scan_fwd(xp, wg, wc, D, h_last, period, want_y, train):
+    """hpmn_gru_scan_fwd.  h_last is a [B,H] strided view (e.g. memory[:, i, :])."""
+    B, T, H3 = xp.shape
+    H = H3 // 3
+    _chk_f32(xp, wg, wc)
+    a = HpmnGruFwd()
+    a.B, a.T, a.D, a.H = B, T, D, H
+    a.xp, a.wg, a.wc = xp.data_ptr(), wg.data_ptr(), wc.data_ptr()
+    assert h_last.stride(1) == 1 and h_last.shape == (B, H)
+    a.h_last, a.h_last_stride = h_last.data_ptr(), h_last.stride(0)
+    a.period = period
+    y = hs = gates = None
+    if want_y:
+        y = torch.empty(B, T // period, H, device=xp.device, dtype=torch.float32)
+        a.y = y.data_ptr()
+    if train:
+        hs = torch.empty(B, T + 1, H, device=xp.device, dtype=torch.float32)
+        gates = torch.empty(B, T, 4 * H, device=xp.device, dtype=torch.float32)
+        a.hs, a.gates = hs.data_ptr(), gates.data_ptr()
+    rc = _lib.load().hpmn_gru_scan_fwd(C.byref(a), _stream())
+    _lib.check(rc, "hpmn_gru_scan_fwd")
+    return y, hs, gates
+
+
+def gru_scan_bwd(wg, wc, D, hs, gates, d_h_last, d_y, period):
+    """hpmn_gru_scan_bwd -> d_act [B,T,3H]."""
+    B, T1, H = hs.shape
+    T = T1 - 1
+    _chk_f32(wg, wc, hs, gates, d_y)
+    a = HpmnGruBwd()
+    a.B, a.T, a.D, a.H = B, T, D, H
+    a.wg, a.wc, a.hs, a.gates = wg.data_ptr(), wc.data_ptr(), hs.data_ptr(), gates.data_ptr()
+    assert d_h_last.stride(1) == 1 and d_h_last.shape == (B, H) and d_h_last.dtype == torch.float32
+    a.d_h_last, a.d_h_last_stride = d_h_last.data_ptr(), d_h_last.stride(0)
+    a.d_y = _ptr(d_y)
+    a.period = period
+    d_act = torch.empty(B, T, 3 * H, device=hs.device, dtype=torch.float32)
+    a.d_act = d_act.data_ptr()
+    rc = _lib.load().hpmn_gru_scan_bwd(C.byref(a), _stream())
+    _lib.check(rc, "hpmn_gru_scan_bwd")
+    return d_act
+
+
+def embed_grad_scatter(ids, d_x, d_emb, front_zero, mask_id0):
+    """hpmn_embed_grad_scatter: d_emb[ids] += d_x rows (atomic, run-length pre-reduced)."""
+    _chk_ids(ids)
+    _chk_f32(d_x, d_emb)
+    B, T, F = ids.shape
+    V, E = d_emb.shape
+    assert d_x.shape == (B, front_zero + T, F * E)
+    rc = _lib.load().hpmn_embed_grad_scatter(ids.data_ptr(), d_x.data_ptr(), d_emb.data_ptr(), B, T, F, E,
+                                              front_zero, V, int(mask_id0), _stream())
+    _lib.check(rc, "hpmn_embed_grad_scatter")
+
+
+def adam_step(param, grad, m, v, lr_t, beta1=0.9, beta2=0.999, eps=1e-8, clip=1.0, grad_scale=1.0):
+    """hpmn_adam_step over flat fp32 buffers (code/hpmn.py:209-214)."""
+    _chk_f32(param, grad, m, v)
+    n = param.numel()
+    assert grad.numel() == n and m.numel() == n and v.numel() == n
+    rc = _lib.load().hpmn_adam_step(param.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(), n,
+                                     lr_t, beta1, beta2, eps, clip, grad_scale, _stream())
+    _lib.check(rc, "hpmn_adam_step")
+
+
+def scan_forward_inference(spec: ScanSpec, ids, emb, weights: Sequence[torch.Tensor], workspace=None):
+    """hpmn_scan_fwd: whole build_memory forward (no saved states).  weights = [wg0,bg0,wc0,bc0, wg1,...].
+    Returns (memory [B,K,H], last [B,D0])."""
+    _chk_ids(ids)
+    _chk_f32(emb, *weights)
+    B = ids.shape[0]
+    V = emb.shape[0]
+    lib = _lib.load()
+    d = spec.desc(B, V)
+    need = lib.hpmn_scan_workspace_bytes(C.byref(d))
+    if need == 0:
+        raise ValueError("inconsistent scan description (layer lengths must divide by the periods)")
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(need, device=emb.device, dtype=torch.uint8)
+    K = spec.K
+    arr = lambda i0: (C.c_void_p * K)(*[weights[4 * i + i0].data_ptr() for i in range(K)])
+    memory = torch.empty(B, K, spec.H, device=emb.device, dtype=torch.float32)
+    last = torch.empty(B, spec.D0, device=emb.device, dtype=torch.float32)
+    rc = lib.hpmn_scan_fwd(C.byref(d), ids.data_ptr(), emb.data_ptr(), arr(0), arr(1), arr(2), arr(3),
+                           memory.data_ptr(), last.data_ptr(), workspace.data_ptr(), _stream())
+    _lib.check(rc, "hpmn_scan_fwd")
+    return memory, last
+
+
+# ---------------------------------------------------------------------------------------
+# autograd: build_memory with saved states + BPTT
+# ---------------------------------------------------------------------------------------
+class _MemoryScan(torch.autograd.Function):
+    """memory, last = build_memory(embedding(ids))  with gradients for the GRU variables and
+    the embedding table.  The embedding gradient is scattered straight into ``d_emb_out``
+    (the optimiser's flat gradient buffer) when given, else returned densely."""
+
+    @staticmethod
+    def forward(ctx, spec: ScanSpec, ids, emb, d_emb_out, *weights):
+        lens = spec.layer_lengths()
+        B = ids.shape[0]
+        H, K = spec.H, spec.K
+        memory = torch.empty(B, K, H, device=emb.device, dtype=torch.float32)
+        saved = []
+        x_in = None
+        x0 = None
+        for i in range(K):
+            wg, bg, wc, bc = weights[4 * i:4 * i + 4]
+            if i == 0:
+                xp, x0 = gru_input_proj(None, ids=ids, emb=emb, wg=wg, bg=bg, wc=wc, bc=bc, H=H, T=lens[0],
+                                        front_zero=spec.front_zero, mask_id0=spec.mask_id0, want_x_out=True)
+                D = spec.D0
+                x_in = x0
+            else:
+                xp, _ = gru_input_proj(None, x=x_in, wg=wg, bg=bg, wc=wc, bc=bc, H=H, T=lens[i])
+                D = H
+            y, hs, gates = gru_scan_fwd(xp, wg, wc, D, memory[:, i, :], spec.periods[i],
+                                        want_y=(i + 1 < K), train=True)
+            del xp
+            saved.append((x_in, hs, gates))
+            x_in = y
+        last = x0[:, spec.last_index, :].contiguous()
+        ctx.spec = spec
+        ctx.saved = saved
+        ctx.ids = ids
+        ctx.d_emb_out = d_emb_out
+        ctx.emb_shape = emb.shape
+        ctx.weights = weights
+        return memory, last
+
+    @staticmethod
+    def backward(ctx, d_memory, d_last):
+        spec: ScanSpec = ctx.spec
+        H, K = spec.H, spec.K
+        weights = ctx.weights
+        d_memory = d_memory.contiguous()
+        grads: List[Optional[torch.Tensor]] = [None] * (4 * K)
+        d_y = None
+        for i in range(K - 1, -1, -1):
+            wg, bg, wc, bc = weights[4 * i:4 * i + 4]
+            x_in, hs, gates = ctx.saved[i]
+            B, T, D = x_in.shape
+            d_act = gru_scan_bwd(wg, wc, D, hs, gates, d_memory[:, i, :], d_y, spec.periods[i])
+            a2 = d_act.view(B * T, 3 * H)
+            ag, ac = a2[:, :2 * H], a2[:, 2 * H:]
+            x2 = x_in.reshape(B * T, D)
+            hp2 = hs[:, :T, :].reshape(B * T, H)
+            rh2 = gates.view(B * T, 4 * H)[:, 3 * H:]
+            dwg = torch.empty_like(wg)
+            dwc = torch.empty_like(wc)
+            torch.mm(x2.t(), ag, out=dwg[:D])
+            torch.mm(hp2.t(), ag, out=dwg[D:])
+            torch.mm(x2.t(), ac, out=dwc[:D])
+            torch.mm(rh2.t(), ac, out=dwc[D:])
+            db = a2.sum(dim=0)
+            grads[4 * i + 0] = dwg
+            grads[4 * i + 1] = db[:2 * H]
+            grads[4 * i + 2] = dwc
+            grads[4 * i + 3] = db[2 * H:]
+            # dx = d_act [Wg[:D] | Wc[:D]]^T
+            wx = torch.cat([wg[:D], wc[:D]], dim=1)           # [D, 3H]
+            d_y = torch.mm(a2, wx.t()).view(B, T, D)
+            del d_act, a2, hp2
+        d_x0 = d_y
+        if d_last is not None:
+            d_x0[:, spec.last_index, :] += d_last
+        d_emb = None
+        if ctx.d_emb_out is not None:
+            embed_grad_scatter(ctx.ids, d_x0, ctx.d_emb_out, spec.front_zero, spec.mask_id0)
+        else:
+            d_emb = torch.zeros(ctx.emb_shape, device=d_x0.device, dtype=torch.float32)
+            embed_grad_scatter(ctx.ids, d_x0, d_emb, spec.front_zero, spec.mask_id0)
+        ctx.saved = None
+        return (None, None, d_emb, None) + tuple(grads)
+
+
+def memory_scan(spec: ScanSpec, ids, emb, weights: Sequence[torch.Tensor], d_emb_out=None):
+    """Differentiable build_memory: returns (memory [B,K,H], last [B,D0])."""
+    return _MemoryScan.apply(spec, ids, emb, d_emb_out, *weights)

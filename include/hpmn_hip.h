@@ -1,0 +1,186 @@
+/*
+ * hpmn_hip.h -- C ABI of libhpmn_hip.so, the MI355X (gfx950) implementation of the
+ * HPMN hot path: embedding gather -> K-layer periodic GRU memory update -> (saved
+ * states for BPTT) -> reverse scan -> embedding-gradient scatter -> TF-form Adam.
+ *
+ * The reference (alimamarankgroup/HPMN, Python 2.7 + TensorFlow 1.4) has no FFI: the
+ * path is inline TF graph code.  Each entry point below names the reference lines it
+ * replaces (paths relative to the reference checkout); INTEGRATION.md shows the
+ * ctypes stub a maintainer would add on the reference side.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer borrowed from the caller (PyTorch tensors in
+ *    this repo); the library never allocates, frees or synchronises;
+ *  - all work is enqueued on `stream` (a hipStream_t passed as void*); no host sync;
+ *  - all tensors are dense row-major, fp32 unless stated, ids are int32;
+ *  - return value: 0 (HPMN_OK) or a negative HPMN_E* code; a failing HIP runtime call
+ *    is reported as HPMN_EHIP and its hipError_t kept in hpmn_last_hip_error();
+ *  - nothing throws across the ABI; thread-safe for distinct streams (the only global
+ *    state is the thread-local last-hip-error word).
+ */
+#ifndef HPMN_HIP_H_
+#define HPMN_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HPMN_ABI_VERSION 1
+#define HPMN_MAX_LAYERS 12
+
+enum {
+    HPMN_OK = 0,
+    HPMN_EINVAL = -1,      /* null pointer / non-positive size / inconsistent desc      */
+    HPMN_EUNSUPPORTED = -2,/* shape outside what the gfx950 kernels are instantiated for */
+    HPMN_EHIP = -3,        /* HIP runtime error, see hpmn_last_hip_error()               */
+    HPMN_ENODEVICE = -4    /* no gfx950 device visible                                   */
+};
+
+int hpmn_abi_version(void);
+const char *hpmn_strerror(int code);
+int hpmn_last_hip_error(void);
+/* 1 when a (H, D) GRU layer shape has a kernel instantiation, else 0. */
+int hpmn_gru_shape_supported(int32_t H, int32_t D);
+
+/* ------------------------------------------------------------------------------------
+ * Embedding gather.  Replaces Hpmn.embedding / Hpmn_Industry.embedding
+ * (code/hpmn.py:414-423, :266-276):  out[n, f*E:(f+1)*E] = emb[ids[n,f]] * (mask_id0 ?
+ * ids[n,f] != 0 : 1).  Also the gather-only roofline micro-benchmark.
+ *   ids [N,F] int32, emb [V,E], out [N, F*E].   E % 4 == 0.
+ * ---------------------------------------------------------------------------------- */
+int hpmn_embed_gather(const int32_t *ids, const float *emb, float *out,
+                      int64_t N, int32_t F, int32_t E, int64_t V, int32_t mask_id0,
+                      void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * One GRU layer of build_memory, forward, in two launches.  Together they replace one
+ * iteration of the loop at code/hpmn.py:116-128: tf.nn.rnn_cell.GRUCell (arithmetic
+ * mirrored at code/util.py:81-110 without line 108) driven by tf.nn.dynamic_rnn from a
+ * zero state with no sequence_length masking (code/rnn.py:583-588, 754-768), followed by
+ * the "take every period-th output" reshape+gather (code/hpmn.py:124-128).
+ *
+ *   wg [D+H, 2H], bg [2H], wc [D+H, H], bc [H]      TF variable layout (input rows first)
+ *
+ * (1) hpmn_gru_input_proj -- the time-parallel half (the x rows of _Linear,
+ *     code/util.py:88-95, 99-107):
+ *        xp[b,t, 0:2H] = x[b,t] wg[0:D] + bg,    xp[b,t, 2H:3H] = x[b,t] wc[0:D] + bc.
+ *     Input is EITHER x [B,T,D] (layers >= 1: the subsampled outputs of the layer below)
+ *     OR, when x == NULL, gathered on the fly from (ids [B,Tids,F], emb [V,E]) with
+ *     `front_zero` all-zero steps in front (code/hpmn.py:288-289), T == front_zero+Tids,
+ *     D == F*E, and the id-0 mask of code/hpmn.py:417-422 when mask_id0 != 0 -- i.e. it
+ *     also replaces Hpmn.embedding (code/hpmn.py:414-423 / :266-276) for the scan.
+ *        x_out : optional [B,T,D], the materialised gathered input (training only).
+ *
+ * (2) hpmn_gru_scan_fwd -- the serial half: for t in 0..T-1
+ *        [r,u] = sigmoid(xp[:, t, 0:2H] + h wg[D:]);  c = tanh(xp[:, t, 2H:] + (r*h) wc[D:])
+ *        h = u*h + (1-u)*c
+ *   h_last  : final state, written at h_last[b*h_last_stride + 0..H)   (memory[:, i, :])
+ *   y       : optional [B, T/period, H]  = outputs[:, period-1::period, :]   (next layer's input)
+ *   hs      : optional [B, T+1, H]  hs[b,0]=0, hs[b,t+1] = state after step t      (training)
+ *   gates   : optional [B, T, 4H]   (r, u, c, r*h_prev) per step                    (training)
+ * ---------------------------------------------------------------------------------- */
+typedef struct HpmnInputProj {
+    int32_t B, T, D, H;
+    const float *x;
+    const int32_t *ids;
+    const float *emb;
+    int32_t Tids, F, E, front_zero, mask_id0;
+    int64_t V;
+    const float *wg, *bg, *wc, *bc;
+    float *xp;     /* [B, T, 3H] */
+    float *x_out;  /* optional [B, T, D] (gather mode) */
+} HpmnInputProj;
+
+int hpmn_gru_input_proj(const HpmnInputProj *args, void *stream);
+
+typedef struct HpmnGruFwd {
+    int32_t B, T, D, H;
+    const float *xp;   /* [B, T, 3H] from hpmn_gru_input_proj */
+    const float *wg, *wc;
+    float *h_last;
+    int64_t h_last_stride;
+    float *y;
+    int32_t period;
+    float *hs;
+    float *gates;
+} HpmnGruFwd;
+
+int hpmn_gru_scan_fwd(const HpmnGruFwd *args, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * One GRU layer, reverse scan (BPTT) -- the serial part of the gradient of
+ * hpmn_gru_scan_fwd (TF autodiff through the while_loop of code/hpmn.py:119-120).
+ *   d_h_last [B] rows at d_h_last[b*stride + 0..H) : gradient wrt the final state
+ *   d_y      : optional [B, T/period, H]  gradient wrt the subsampled outputs
+ *   hs, gates: as saved by the forward
+ *   d_act    : out [B, T, 3H] = gradients wrt the pre-activations (a_r, a_u, a_c)
+ * Weight / input gradients are then plain GEMMs over d_act (host side):
+ *   dWg = [x | h_prev]^T d_act[:, :2H],  dWc = [x | r*h_prev]^T d_act[:, 2H:],
+ *   dx  = d_act[:, :2H] Wg[:D]^T + d_act[:, 2H:] Wc[:D]^T.
+ * ---------------------------------------------------------------------------------- */
+typedef struct HpmnGruBwd {
+    int32_t B, T, D, H;
+    const float *wg, *wc;
+    const float *hs, *gates;
+    const float *d_h_last;
+    int64_t d_h_last_stride;
+    const float *d_y;
+    int32_t period;
+    float *d_act;
+} HpmnGruBwd;
+
+int hpmn_gru_scan_bwd(const HpmnGruBwd *args, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * Whole build_memory forward (code/hpmn.py:113-129 without the covariance loss): K
+ * layers chained through a caller-provided workspace.  Inference form (no saved
+ * states).   memory [B,K,H];  last [B, F*E] = uinp[:, last_index, :] (code/hpmn.py:439
+ * last_index=-1, :292 last_index=-2), may be NULL.
+ * ---------------------------------------------------------------------------------- */
+typedef struct HpmnScanDesc {
+    int32_t B, T, F, E, H, K;        /* T = user_maxlen as fed by the loader          */
+    int32_t front_zero;              /* 23 for Hpmn_Industry, 0 for Hpmn              */
+    int32_t mask_id0;                /* 1 for Hpmn, 0 for Hpmn_Industry               */
+    int32_t last_index;              /* -1 or -2                                      */
+    int64_t V;
+    int32_t periods[HPMN_MAX_LAYERS];/* li_layer[i]                                   */
+} HpmnScanDesc;
+
+size_t hpmn_scan_workspace_bytes(const HpmnScanDesc *desc);
+int hpmn_scan_fwd(const HpmnScanDesc *desc, const int32_t *ids, const float *emb,
+                  const float *const *wg, const float *const *bg,
+                  const float *const *wc, const float *const *bc,
+                  float *memory, float *last, void *workspace, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * Embedding-gradient scatter-add: gradient of hpmn_embed_gather / the gather inside the
+ * layer-0 scan (TF: IndexedSlices densified by the l2 term, code/hpmn.py:204-205).
+ *   d_emb[ids[b,t,f]] += d_x[b, front_zero + t, f*E:(f+1)*E]   (skipping id 0 when mask_id0)
+ * Runs of equal ids along t (the constant uid column, the id-0 padding) are pre-reduced
+ * in registers before one atomic row add.  d_emb must be zeroed by the caller.
+ *   ids [B,T,F], d_x [B, front_zero+T, F*E], d_emb [V,E]
+ * ---------------------------------------------------------------------------------- */
+int hpmn_embed_grad_scatter(const int32_t *ids, const float *d_x, float *d_emb,
+                            int32_t B, int32_t T, int32_t F, int32_t E, int32_t front_zero,
+                            int64_t V, int32_t mask_id0, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * Optimiser step.  Replaces code/hpmn.py:209-214: per-element clip_by_value(g,-1,1) then
+ * tf.train.AdamOptimizer in its TF form
+ *   m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= lr_t m / (sqrt(v) + eps),
+ *   lr_t = lr sqrt(1-b2^t)/(1-b1^t)  (computed by the caller).
+ * One launch over a flat buffer holding every variable (dense over the embedding table,
+ * as TF does).  grad_scale is applied before the clip (1/world for averaged gradients;
+ * 1.0 normally).  n % 4 == 0 and 16-byte aligned pointers give the vectorised path.
+ * ---------------------------------------------------------------------------------- */
+int hpmn_adam_step(float *param, const float *grad, float *m, float *v, int64_t n,
+                   float lr_t, float beta1, float beta2, float eps, float clip,
+                   float grad_scale, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HPMN_HIP_H_ */

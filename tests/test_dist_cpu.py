@@ -1,0 +1,93 @@
+"""World-size-2 data-parallel scheme on CPU (gloo): slicing a global batch, per-rank loss
+weighting (log-loss MEAN over the global batch, memory regulariser SUM), one sum all-reduce of
+the flat gradient, and the prediction all-gather -- must reproduce the single-process result.
+The model here is the oracle's torch restatement (the product kernels need a GPU); what is
+under test is hpmn_amd.dist, the code every rank of the GPU path runs."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as td
+import torch.multiprocessing as mp
+
+from hpmn_amd import dist
+from oracle import hpmn_oracle as O
+from oracle import torch_restatement as R
+
+
+def _cfg():
+    return O.HpmnConfig(feature_size=60, user_dim=3, user_maxlen=20, hidden_size=8, embedding_size=4, hop=2,
+                        user_layers=(2, 2, 5, 5, 1), user_num_layers=3, memory_reg=1e-2)
+
+
+def _batch(B=7):
+    rng = np.random.default_rng(5)
+    ids = rng.integers(0, 60, size=(B, 20, 3))
+    return torch.as_tensor(ids), torch.as_tensor(rng.integers(0, 2, size=B))
+
+
+def _flat_grads(cfg, p, ids, label, global_batch):
+    out = R.forward(cfg, p, ids, label)
+    y = label.to(torch.float64)
+    pred = out["prediction"]
+    ll_sum = (-y * torch.log(pred + 1e-7) - (1 - y) * torch.log(1 - pred + 1e-7)).sum()
+    loss = dist.sharded_loss(ll_sum, out["memory_loss"], global_batch, cfg.memory_reg)
+    names = sorted(p)
+    gs = torch.autograd.grad(loss, [p[k] for k in names], allow_unused=True)
+    flat = torch.cat([(g if g is not None else torch.zeros_like(p[k])).reshape(-1) for g, k in zip(gs, names)])
+    return flat, out["prediction"].detach(), float(loss)
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cfg = _cfg()
+        p = R.to_torch(O.randomize_params(O.init_params(cfg, seed=1), seed=2), requires_grad=True)
+        ids, label = _batch()
+        assert dist.rank_world() == (rank, world)
+        a, b = dist.shard_bounds(0, ids.shape[0], rank, world)
+        flat, pred, _ = _flat_grads(cfg, p, ids[a:b], label[a:b], ids.shape[0])
+        dist.allreduce_sum_(flat)
+        allpred = dist.gather_predictions(pred, ids.shape[0])
+        q.put((rank, flat.numpy(), allpred.numpy()))
+    finally:
+        td.destroy_process_group()
+
+
+def test_two_rank_gradients_and_predictions_match_single_process():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    cfg = _cfg()
+    p = R.to_torch(O.randomize_params(O.init_params(cfg, seed=1), seed=2), requires_grad=True)
+    ids, label = _batch()
+    want, pred, loss = _flat_grads(cfg, p, ids, label, ids.shape[0])
+    # single-process loss == code/hpmn.py:202-207
+    ref = R.forward(cfg, p, ids, label)
+    assert abs(loss - float(ref["cross_entropy"])) < 1e-12
+    for rank, flat, allpred in res:
+        np.testing.assert_allclose(flat, want.numpy(), rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(allpred, pred.numpy(), rtol=0, atol=1e-14)
+
+
+def test_shard_bounds_cover_batch_without_overlap():
+    for n in (1, 2, 7, 128, 500, 501):
+        for world in (1, 2, 3, 4, 8):
+            cuts = [dist.shard_bounds(10, 10 + n, r, world) for r in range(world)]
+            assert cuts[0][0] == 10 and cuts[-1][1] == 10 + n
+            assert all(cuts[i][1] == cuts[i + 1][0] for i in range(world - 1))
+            assert [b - a for a, b in cuts] == dist.shard_sizes(n, world)
+            assert max(dist.shard_sizes(n, world)) - min(dist.shard_sizes(n, world)) <= 1

@@ -1,0 +1,99 @@
+"""Train/eval harness semantics of code/hpmn.py:467-495 (step/eval cadence, early stop, return
+value, result.log format) with the numerical path stubbed out -- runs on CPU."""
+import os
+
+import numpy as np
+import torch
+
+from hpmn_amd.hpmn import Hpmn, Hpmn_Industry, _DeviceDataset, main
+
+
+def _stub(cls, tmp_path, n_train, aucs, eval_every=None):
+    m = object.__new__(cls)
+    m.rank, m.world = 0, 1
+    m.device = torch.device("cpu")
+    m._datasets = {}
+    m._path = str(tmp_path)
+    m.verbose = False
+    m.trainset = dict(ids=np.zeros((n_train, 4, 3), np.int32), label=np.zeros(n_train, np.int32))
+    m.testset = dict(ids=np.zeros((5, 4, 3), np.int32), label=np.zeros(5, np.int32))
+    if eval_every:
+        m.eval_every = eval_every
+    calls = dict(steps=[], evals=0)
+    script = iter(aucs)
+
+    def train_step(ids, label, keep_prob=0.5, masks=None, global_batch=None):
+        calls["steps"].append((ids.shape[0], keep_prob, global_batch))
+
+    def fake_eval(dataset, batchsize):
+        calls["evals"] += 1
+        if dataset is m.testset:
+            return next(script), 0.5, 0.25
+        return 0.9, 0.4, 0.2
+    m.train_step = train_step
+    m.eval = fake_eval
+    return m, calls
+
+
+def test_cadence_and_partial_last_batch(tmp_path):
+    m, calls = _stub(Hpmn, tmp_path, n_train=10 * 7 + 3, aucs=[0.6, 0.7, 0.8, 0.75], eval_every=5)
+    best = m.train(2, 7)              # 11 steps per epoch (last batch of 3), 22 steps, evals at 5,10,15,20
+    assert len(calls["steps"]) == 22
+    assert calls["steps"][10] == (3, 0.5, 3) and calls["steps"][0] == (7, 0.5, 7)
+    assert calls["evals"] == 8        # train + test at each of the 4 eval points
+    assert best == 0.8
+
+
+def test_cadence_exhausts_script_safely(tmp_path):
+    m, calls = _stub(Hpmn, tmp_path, n_train=20, aucs=[0.6, 0.7, 0.8, 0.9], eval_every=5)
+    best = m.train(2, 2)              # 10 steps/epoch -> evals at 5,10,15,20
+    assert calls["evals"] == 8 and best == 0.9
+    lines = open(os.path.join(str(tmp_path), "result.log")).read().splitlines()
+    assert len(lines) == 4
+    assert lines[0] == "5\t0.90000\t0.40000\t0.20000\t0.60000\t0.50000\t0.25000"   # code/hpmn.py:101-103
+
+
+def test_early_stop_after_more_than_three_non_improving_evals(tmp_path):
+    # best 0.7 at eval 2; evals 3..6 do not improve -> count reaches 4 (>3) at eval 6 -> return 0.7
+    m, calls = _stub(Hpmn, tmp_path, n_train=100, aucs=[0.6, 0.7, 0.7, 0.65, 0.69, 0.7, 0.99], eval_every=1)
+    best = m.train(1, 10)
+    assert best == 0.7
+    assert len(calls["steps"]) == 6           # stopped inside the epoch
+    # an improvement resets the counter
+    m, calls = _stub(Hpmn, tmp_path, n_train=100, aucs=[0.6, 0.5, 0.5, 0.5, 0.61, 0.5, 0.5, 0.5, 0.5, 0.5],
+                     eval_every=1)
+    assert m.train(1, 10) == 0.61 and len(calls["steps"]) == 9
+
+
+def test_industry_evaluates_every_10_steps(tmp_path):
+    assert Hpmn_Industry.eval_every == 10 and Hpmn.eval_every == 100      # code/hpmn.py:338 / :483
+    m, calls = _stub(Hpmn_Industry, tmp_path, n_train=50, aucs=[0.6] * 10)
+    m.train(1, 2)                      # 25 steps -> evals at 10, 20
+    assert calls["evals"] == 4
+
+
+def test_device_dataset_accepts_reference_sample_lists():
+    samples = [(1, [[0, 0, 0], [5, 6, 7]], 1, [[6, 5]], 1), (0, [[1, 2, 3], [4, 5, 6]], 2, [[5, 4]], 1)]
+    ds = _DeviceDataset(samples, torch.device("cpu"), False)
+    assert ds.ids.dtype == torch.int32 and tuple(ds.ids.shape) == (2, 2, 3)
+    assert ds.label_np.tolist() == [1, 0] and ds.length_np.tolist() == [1, 2]
+    assert list(ds.batches(1)) == [(0, 1), (1, 2)]
+
+
+def test_cli_usage_and_unknown_dataset(capsys):
+    assert main(["hpmn.py"]) == 1                      # code/hpmn.py:564-566
+    assert "Useage" in capsys.readouterr().out
+    assert main(["hpmn.py", "movielens"]) == 1         # code/hpmn.py:665-667
+    assert "Dataset must be one of" in capsys.readouterr().out
+
+
+def test_constructor_fails_loudly_without_gpu(tmp_path):
+    if torch.cuda.is_available():
+        return
+    try:
+        Hpmn(str(tmp_path), [], [], 10, 3, 2, 100, 100, 0.003, 32, 16, 3, [2, 2, 5, 5, 1], [2, 2, 5, 5, 1],
+             3, 3, True, False)
+    except RuntimeError as e:
+        assert "no CPU fallback" in str(e)
+    else:
+        raise AssertionError("constructing without a GPU must raise")
