@@ -150,34 +150,45 @@ def roofline_probes(model, c, ids):
     return roof, extra
 
 
-def cpu_baseline(c, seed=0, budget_s=25.0):
+def log(msg):
+    print("[bench %.1fs] %s" % (time.perf_counter() - T_START, msg), file=sys.stderr, flush=True)
+
+
+T_START = time.perf_counter()
+
+
+def cpu_baseline(c, seed=0, budget_s=20.0):
     """The oracle's PyTorch-CPU eager restatement (per-timestep small ops like the TF graph, dense
     TF-form Adam over the whole table), float32, timed on this host on a bounded sample of the same
-    workload: full sequence length / layers / vocabulary, a reduced batch."""
+    workload: full sequence length / layers / vocabulary, a batch sized by a calibration step so the
+    timed step costs about `budget_s` seconds."""
     from oracle import hpmn_oracle as O
     from oracle import torch_restatement as R
-    threads = os.cpu_count() or 1
+    threads = min(os.cpu_count() or 1, 32)      # tiny per-step ops: more threads only add sync cost
     torch.set_num_threads(threads)
     cfg = O.HpmnConfig(feature_size=c["V"], user_dim=c["F"], user_maxlen=c["T"], hidden_size=c["H"],
                        embedding_size=16, hop=3, user_layers=tuple(c["periods"]), user_num_layers=c["K"],
                        industry=c["industry"], memory_reg=c["memory_reg"])
     p = R.to_torch(O.init_params(cfg, seed=seed, dtype=np.float32), torch.float32)
     opt = R.TFAdam(p, c["lr"])
-    Bs = min(c["batch"], 128)
     rng = np.random.default_rng(seed + 1)
-    ids = torch.as_tensor(rng.integers(1, c["V"], size=(Bs, c["T"], c["F"])))
-    label = torch.as_tensor(rng.integers(0, 2, size=Bs))
-    times = []
-    t_all = time.perf_counter()
-    while len(times) < 3 and (time.perf_counter() - t_all) < budget_s:
+
+    def run(bs):
+        ids = torch.as_tensor(rng.integers(1, c["V"], size=(bs, c["T"], c["F"])))
+        label = torch.as_tensor(rng.integers(0, 2, size=bs))
         t0 = time.perf_counter()
         R.train_step(cfg, p, opt, ids, label)
-        times.append(time.perf_counter() - t0)
-    best = min(times)
-    return {"value": Bs / best, "unit": "sequences/s", "cores": threads, "kind": "port",
-            "sample": "%d train steps (fwd+BPTT+clip+dense Adam) of batch %d at the full %s shape, fp32 "
-                      "PyTorch-CPU eager restatement (oracle/torch_restatement.py), best step %.2fs"
-                      % (len(times), Bs, c["name"], best)}
+        return time.perf_counter() - t0
+
+    t_cal = run(8)
+    log("cpu baseline calibration: batch 8 step %.2fs on %d threads" % (t_cal, threads))
+    bs = int(max(8, min(c["batch"], 8 * budget_s / max(t_cal, 1e-3))))
+    t = run(bs) if bs > 8 else t_cal
+    log("cpu baseline: batch %d step %.2fs" % (bs, t))
+    return {"value": bs / t, "unit": "sequences/s", "cores": threads, "kind": "port",
+            "sample": "1 train step (fwd+BPTT+clip+dense Adam) of batch %d at the full %s shape, fp32 "
+                      "PyTorch-CPU eager restatement (oracle/torch_restatement.py), %.2fs; calibration "
+                      "step of batch 8 took %.2fs" % (bs, c["name"], t, t_cal)}
 
 
 def main():
@@ -213,6 +224,7 @@ def main():
         torch.distributed.barrier()
 
     tmp = tempfile.mkdtemp(prefix="hpmn_bench_")
+    log("building model %s" % c["name"])
     model = build_model(c, tmp, device, seed=0)          # same seed -> identical replicas
     n_distinct = 4
     batches = synth_batches(c, n_distinct, c["batch"], 20190521 + 3 + 1000 * rank, device)
@@ -222,9 +234,14 @@ def main():
         ids, label = batches[i % n_distinct]
         model.train_step(ids, label, keep_prob=0.5, global_batch=global_batch)
 
+    log("data ready; warmup")
     for i in range(args.warmup):
         step(i)
+        if i == 0:
+            torch.cuda.synchronize()
+            log("first step done")
     torch.cuda.synchronize()
+    log("timing %d steps" % args.steps)
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
@@ -241,6 +258,7 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    log("timed region done: %.1f ms/step" % (elapsed / args.steps * 1e3))
     # quick quality signal on the bench batches (not a trained AUC: weights saw only W+K steps)
     out = model.forward_inference(batches[0][0])
     finite = bool(torch.isfinite(out["prediction"]).all())
@@ -262,6 +280,7 @@ def main():
                             "train_tflops_equiv": 3 * algorithmic_flops_fwd(c) * seqs / elapsed / 1e12},
         }
         if not args.no_roofline:
+            log("roofline probes")
             roof, extra = roofline_probes(model, c, batches[0][0])
             result["roofline"] = roof
             result["kernels"] = extra

@@ -201,6 +201,8 @@ def scan_forward_inference(spec: ScanSpec, ids, emb, weights: Sequence[torch.Ten
     B = ids.shape[0]
     V = emb.shape[0]
     lib = _lib.load()
+    if B == 0:       # nothing to launch (and a 0-element tensor has a null data pointer)
+        return (torch.empty(0, spec.K, spec.H, device=emb.device), torch.empty(0, spec.D0, device=emb.device))
     d = spec.desc(B, V)
     need = lib.hpmn_scan_workspace_bytes(C.byref(d))
     if need == 0:
