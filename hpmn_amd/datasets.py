@@ -56,7 +56,9 @@ def make_synthetic_amazon(n_samples=3000, n_item=2000, n_cate=50, n_user=3000, m
     Lengths ~ 5 + Geometric(0.25) capped at max_len (5-core => >= 5 events); items Zipf(1.1);
     category = fixed map item -> cate; uid constant per sample; label Bernoulli(.5) with a
     planted signal: the positive target is drawn from the user's modal category, the negative
-    from a different one, so AUC is learnable.  user_dim 3 rows = [uid, item, cate]; user_dim 4
+    from a different one (history-dependent part); favourites concentrate on the lower half of the
+    categories and negatives on the upper half (marginal part, learnable from the target row
+    alone within ~100 steps), so AUC is learnable.  user_dim 3 rows = [uid, item, cate]; user_dim 4
     (Taobao) adds a behaviour tag.  Returns (trainset, testset, feature_size) or, with
     ``as_arrays``, dict(ids [N,T,F] int32, label [N] int32, length [N]) per split.
     """
@@ -76,7 +78,9 @@ def make_synthetic_amazon(n_samples=3000, n_item=2000, n_cate=50, n_user=3000, m
     for n in range(n_samples):
         L = int(lengths[n])
         uid = off_u + int(rng.integers(0, n_user))
-        fav = int(rng.integers(0, n_cate))
+        # marginal signal: users mostly favour the "attractive" lower half of the categories ...
+        half = max(1, n_cate // 2)
+        fav = int(rng.integers(0, half)) if rng.random() < 0.85 else int(rng.integers(0, n_cate))
         hist = rng.choice(n_item, size=L - 1, p=zipf_p)
         # half of the history from the favourite category -> modal category is recoverable
         k = (L - 1 + 1) // 2
@@ -85,7 +89,10 @@ def make_synthetic_amazon(n_samples=3000, n_item=2000, n_cate=50, n_user=3000, m
         if labels[n] == 1:
             tgt = int(rng.choice(cate_items[fav]))
         else:
-            other = (fav + 1 + int(rng.integers(0, n_cate - 1))) % n_cate
+            # ... and negatives mostly come from the upper half (never from the favourite category)
+            other = int(rng.integers(half, n_cate)) if rng.random() < 0.85 else int(rng.integers(0, n_cate))
+            if other == fav:
+                other = (fav + 1) % n_cate
             tgt = int(rng.choice(cate_items[other]))
         items = np.concatenate([hist, [tgt]]).astype(np.int64)
         # item id 0 is the padding id: shift real items into [1, n_item)

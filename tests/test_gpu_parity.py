@@ -150,7 +150,10 @@ def test_batch_composition_independence_and_determinism_full_xlong_shape(dev, tm
     assert torch.equal(a["logit"], b["logit"]) and torch.equal(a["memory"], b["memory"])
     assert torch.equal(a["memory"][7], a["memory"][3])
     sub = m.forward_inference(t[[3, 250, 499]].contiguous())
-    np.testing.assert_allclose(sub["logit"].cpu().numpy(), a["logit"][[3, 250, 499]].cpu().numpy(), atol=1e-6)
+    # the HIP scan is batch-independent bit for bit; the read path's library GEMMs may pick another
+    # kernel for another batch size, hence a (tiny) tolerance on the logits only
+    assert torch.equal(sub["memory"], a["memory"][[3, 250, 499]])
+    np.testing.assert_allclose(sub["logit"].cpu().numpy(), a["logit"][[3, 250, 499]].cpu().numpy(), atol=2e-5)
     want = O.forward(cfg, p, ids[[3, 250, 499]])
     np.testing.assert_allclose(sub["logit"].cpu().numpy(), want["logit"], atol=TOL)
     np.testing.assert_allclose(sub["memory"].cpu().numpy(), want["memory"], atol=TOL)
@@ -251,12 +254,26 @@ def test_three_training_steps_track_the_restatement(dev, tmp_path, industry):
     opt = R.TFAdam(tp, 0.003)
     m = make_model(cfg, tmp_path, p, lr=0.003)
     ti, tl = torch.as_tensor(ids).to(dev), torch.as_tensor(label).to(dev)
-    for _ in range(3):
-        R.train_step(cfg, tp, opt, torch.as_tensor(ids.astype(np.int64)), torch.as_tensor(label.astype(np.int64)))
+    steps, lr = 3, 0.003
+    gmin = {k: np.full(v.shape, np.inf) for k, v in p.items()}
+    gmax = {k: 0.0 for k in p}
+    for _ in range(steps):
+        _, g = R.train_step(cfg, tp, opt, torch.as_tensor(ids.astype(np.int64)),
+                            torch.as_tensor(label.astype(np.int64)))
+        for k in p:
+            ga = np.abs(g[k].numpy())
+            gmin[k] = np.minimum(gmin[k], ga)
+            gmax[k] = max(gmax[k], float(ga.max()))
         m.train_step(ti, tl, keep_prob=1.0)
     for k in p:
-        np.testing.assert_allclose(m.params[k].detach().cpu().numpy(), tp[k].detach().numpy(), rtol=0, atol=3e-5,
-                                   err_msg=k)
+        got, want = m.params[k].detach().cpu().numpy(), tp[k].detach().numpy()
+        # Adam divides by sqrt(v): where a gradient is ~0 (below fp32 resolution of the sum it came
+        # from) the normalised update is ill-conditioned, so those elements are only required to stay
+        # within the trust region lr*steps; everything else must agree tightly.
+        well = gmin[k] > 1e-3 * max(gmax[k], 1e-30)
+        assert well.mean() > 0.5 or k.endswith("emb_mtx"), k
+        np.testing.assert_allclose(got[well], want[well], rtol=0, atol=3e-5, err_msg=k)
+        np.testing.assert_allclose(got, want, rtol=0, atol=lr * steps * 1.05, err_msg=k)
     # rows never touched still moved only if their Adam moments are non-zero: untouched rows stay put
     untouched = np.setdiff1d(np.arange(cfg.feature_size), np.unique(ids))
     if len(untouched):
@@ -294,7 +311,7 @@ def test_training_learns_planted_signal_and_save_load(dev, tmp_path):
     m.eval_every = 10 ** 9                       # no periodic eval inside this short run
     m.train(6, 128)
     auc1, loss1, mem1 = m.eval(te, 512)
-    assert auc1 > 0.65 and auc1 > auc0 + 0.1, (auc0, auc1)
+    assert auc1 > 0.8 and auc1 > auc0 + 0.1, (auc0, auc1)
     m.save_model()
     before = m.forward_inference(m._dev(te).ids[:16])["prediction"].clone()
     m.set_params({k: np.zeros_like(v) for k, v in m.get_params().items()})
