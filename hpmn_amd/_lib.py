@@ -52,6 +52,17 @@ class HpmnGruBwd(C.Structure):
     ]
 
 
+class HpmnGruWgrad(C.Structure):
+    _fields_ = [
+        ("B", C.c_int32), ("T", C.c_int32), ("D", C.c_int32), ("H", C.c_int32),
+        ("x", C.c_void_p), ("hs", C.c_void_p), ("gates", C.c_void_p), ("d_act", C.c_void_p),
+        ("wg", C.c_void_p), ("wc", C.c_void_p),
+        ("d_wg", C.c_void_p), ("d_bg", C.c_void_p), ("d_wc", C.c_void_p), ("d_bc", C.c_void_p),
+        ("d_x", C.c_void_p),
+        ("seq_per_wg", C.c_int32),
+    ]
+
+
 class HpmnScanDesc(C.Structure):
     _fields_ = [
         ("B", C.c_int32), ("T", C.c_int32), ("F", C.c_int32), ("E", C.c_int32),
@@ -73,6 +84,7 @@ SIGNATURES = {
     "hpmn_gru_input_proj": (C.c_int, [C.POINTER(HpmnInputProj), C.c_void_p]),
     "hpmn_gru_scan_fwd": (C.c_int, [C.POINTER(HpmnGruFwd), C.c_void_p]),
     "hpmn_gru_scan_bwd": (C.c_int, [C.POINTER(HpmnGruBwd), C.c_void_p]),
+    "hpmn_gru_param_grads": (C.c_int, [C.POINTER(HpmnGruWgrad), C.c_void_p]),
     "hpmn_scan_workspace_bytes": (C.c_size_t, [C.POINTER(HpmnScanDesc)]),
     "hpmn_scan_fwd": (C.c_int, [C.POINTER(HpmnScanDesc), C.c_void_p, C.c_void_p,
                                 C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),

@@ -248,8 +248,10 @@ class Hpmn_Basic(object):
 
     def forward_train(self, ids: torch.Tensor, keep_prob=0.5, masks=None, scatter_into_flat=True):
         emb = self.params["Embedding/emb_mtx"]
-        memory, last = ops.memory_scan(self.spec, ids, emb, self._gru_weights(),
-                                       d_emb_out=self.grads["Embedding/emb_mtx"] if scatter_into_flat else None)
+        grad_out = None
+        if scatter_into_flat:
+            grad_out = [self.grads["Embedding/emb_mtx"]] + [self.grads[n] for names in self._gru_names for n in names]
+        memory, last = ops.memory_scan(self.spec, ids, emb, self._gru_weights(), grad_out=grad_out)
         return self._read(memory, last, keep_prob, masks)
 
     def loss(self, out, label: torch.Tensor, global_batch: int):

@@ -17,7 +17,7 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import HpmnGruBwd, HpmnGruFwd, HpmnInputProj, HpmnScanDesc
+from ._lib import HpmnGruBwd, HpmnGruFwd, HpmnGruWgrad, HpmnInputProj, HpmnScanDesc
 
 
 def _stream() -> int:
@@ -171,6 +171,25 @@ def gru_scan_bwd(wg, wc, D, hs, gates, d_h_last, d_y, period):
     return d_act
 
 
+def gru_param_grads(x, hs, gates, d_act, wg, wc, d_wg, d_bg, d_wc, d_bc, want_dx=True):
+    """hpmn_gru_param_grads: accumulates into d_wg/d_bg/d_wc/d_bc (caller-zeroed), returns dx or None."""
+    B, T, D = x.shape
+    H = hs.shape[2]
+    _chk_f32(x, hs, gates, d_act, wg, wc, d_wg, d_bg, d_wc, d_bc)
+    a = HpmnGruWgrad()
+    a.B, a.T, a.D, a.H = B, T, D, H
+    a.x, a.hs, a.gates, a.d_act = x.data_ptr(), hs.data_ptr(), gates.data_ptr(), d_act.data_ptr()
+    a.wg, a.wc = wg.data_ptr(), wc.data_ptr()
+    a.d_wg, a.d_bg, a.d_wc, a.d_bc = d_wg.data_ptr(), d_bg.data_ptr(), d_wc.data_ptr(), d_bc.data_ptr()
+    d_x = None
+    if want_dx:
+        d_x = torch.empty(B, T, D, device=x.device, dtype=torch.float32)
+        a.d_x = d_x.data_ptr()
+    rc = _lib.load().hpmn_gru_param_grads(C.byref(a), _stream())
+    _lib.check(rc, "hpmn_gru_param_grads")
+    return d_x
+
+
 def embed_grad_scatter(ids, d_x, d_emb, front_zero, mask_id0):
     """hpmn_embed_grad_scatter: d_emb[ids] += d_x rows (atomic, run-length pre-reduced)."""
     _chk_ids(ids)
@@ -224,11 +243,11 @@ def scan_forward_inference(spec: ScanSpec, ids, emb, weights: Sequence[torch.Ten
 # ---------------------------------------------------------------------------------------
 class _MemoryScan(torch.autograd.Function):
     """memory, last = build_memory(embedding(ids))  with gradients for the GRU variables and
-    the embedding table.  The embedding gradient is scattered straight into ``d_emb_out``
-    (the optimiser's flat gradient buffer) when given, else returned densely."""
+    the embedding table.  Gradients are accumulated straight into ``grad_out`` (views of the
+    optimiser's flat gradient buffer) when given, else returned densely."""
 
     @staticmethod
-    def forward(ctx, spec: ScanSpec, ids, emb, d_emb_out, *weights):
+    def forward(ctx, spec: ScanSpec, ids, emb, grad_out, *weights):
         lens = spec.layer_lengths()
         B = ids.shape[0]
         H, K = spec.H, spec.K
@@ -255,7 +274,7 @@ class _MemoryScan(torch.autograd.Function):
         ctx.spec = spec
         ctx.saved = saved
         ctx.ids = ids
-        ctx.d_emb_out = d_emb_out
+        ctx.grad_out = grad_out
         ctx.emb_shape = emb.shape
         ctx.weights = weights
         return memory, last
@@ -263,49 +282,36 @@ class _MemoryScan(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_memory, d_last):
         spec: ScanSpec = ctx.spec
-        H, K = spec.H, spec.K
+        K = spec.K
         weights = ctx.weights
         d_memory = d_memory.contiguous()
-        grads: List[Optional[torch.Tensor]] = [None] * (4 * K)
+        direct = ctx.grad_out is not None
+        if direct:      # accumulate straight into the optimiser's (pre-zeroed) flat gradient views
+            d_emb, gw = ctx.grad_out[0], list(ctx.grad_out[1:])
+        else:
+            d_emb = torch.zeros(ctx.emb_shape, device=d_memory.device, dtype=torch.float32)
+            gw = [torch.zeros_like(w) for w in weights]
         d_y = None
         for i in range(K - 1, -1, -1):
             wg, bg, wc, bc = weights[4 * i:4 * i + 4]
             x_in, hs, gates = ctx.saved[i]
-            B, T, D = x_in.shape
+            D = x_in.shape[2]
             d_act = gru_scan_bwd(wg, wc, D, hs, gates, d_memory[:, i, :], d_y, spec.periods[i])
-            a2 = d_act.view(B * T, 3 * H)
-            ag, ac = a2[:, :2 * H], a2[:, 2 * H:]
-            x2 = x_in.reshape(B * T, D)
-            hp2 = hs[:, :T, :].reshape(B * T, H)
-            rh2 = gates.view(B * T, 4 * H)[:, 3 * H:]
-            dwg = torch.empty_like(wg)
-            dwc = torch.empty_like(wc)
-            torch.mm(x2.t(), ag, out=dwg[:D])
-            torch.mm(hp2.t(), ag, out=dwg[D:])
-            torch.mm(x2.t(), ac, out=dwc[:D])
-            torch.mm(rh2.t(), ac, out=dwc[D:])
-            db = a2.sum(dim=0)
-            grads[4 * i + 0] = dwg
-            grads[4 * i + 1] = db[:2 * H]
-            grads[4 * i + 2] = dwc
-            grads[4 * i + 3] = db[2 * H:]
-            # dx = d_act [Wg[:D] | Wc[:D]]^T
-            wx = torch.cat([wg[:D], wc[:D]], dim=1)           # [D, 3H]
-            d_y = torch.mm(a2, wx.t()).view(B, T, D)
-            del d_act, a2, hp2
+            d_y = gru_param_grads(x_in, hs, gates, d_act, wg, wc, gw[4 * i], gw[4 * i + 1], gw[4 * i + 2],
+                                  gw[4 * i + 3], want_dx=True)
+            del d_act
         d_x0 = d_y
         if d_last is not None:
             d_x0[:, spec.last_index, :] += d_last
-        d_emb = None
-        if ctx.d_emb_out is not None:
-            embed_grad_scatter(ctx.ids, d_x0, ctx.d_emb_out, spec.front_zero, spec.mask_id0)
-        else:
-            d_emb = torch.zeros(ctx.emb_shape, device=d_x0.device, dtype=torch.float32)
-            embed_grad_scatter(ctx.ids, d_x0, d_emb, spec.front_zero, spec.mask_id0)
+        embed_grad_scatter(ctx.ids, d_x0, d_emb, spec.front_zero, spec.mask_id0)
         ctx.saved = None
-        return (None, None, d_emb, None) + tuple(grads)
+        if direct:
+            return (None, None, None, None) + (None,) * (4 * K)
+        return (None, None, d_emb, None) + tuple(gw)
 
 
-def memory_scan(spec: ScanSpec, ids, emb, weights: Sequence[torch.Tensor], d_emb_out=None):
-    """Differentiable build_memory: returns (memory [B,K,H], last [B,D0])."""
-    return _MemoryScan.apply(spec, ids, emb, d_emb_out, *weights)
+def memory_scan(spec: ScanSpec, ids, emb, weights: Sequence[torch.Tensor], grad_out=None):
+    """Differentiable build_memory: returns (memory [B,K,H], last [B,D0]).  ``grad_out`` =
+    [d_emb, d_wg0, d_bg0, d_wc0, d_bc0, d_wg1, ...]: pre-zeroed buffers (views of the optimiser's
+    flat gradient) that backward accumulates into directly instead of returning gradients."""
+    return _MemoryScan.apply(spec, ids, emb, grad_out, *weights)

@@ -135,6 +135,27 @@ typedef struct HpmnGruBwd {
 int hpmn_gru_scan_bwd(const HpmnGruBwd *args, void *stream);
 
 /* ------------------------------------------------------------------------------------
+ * One GRU layer, parameter and input gradients -- the time-parallel half of BPTT (TF
+ * autodiff of the two _Linear matmuls, code/util.py:88-107, summed over all time steps):
+ *   d_wg [D+H,2H] += [x | h_prev]^T d_act[:, 0:2H]     d_bg [2H] += sum d_act[:, 0:2H]
+ *   d_wc [D+H, H] += [x | r*h_prev]^T d_act[:, 2H:]    d_bc [H]  += sum d_act[:, 2H:]
+ *   d_x  [B,T,D]   = d_act [wg[0:D] | wc[0:D]]^T       (optional; overwritten, not added)
+ * x [B,T,D] is the layer input, hs/gates as saved by hpmn_gru_scan_fwd, d_act from
+ * hpmn_gru_scan_bwd.  The d_w / d_b outputs are ACCUMULATED with fp32 atomics: the caller
+ * zeroes them (they are views of the optimiser's flat gradient buffer in this repo).
+ * ---------------------------------------------------------------------------------- */
+typedef struct HpmnGruWgrad {
+    int32_t B, T, D, H;
+    const float *x, *hs, *gates, *d_act;
+    const float *wg, *wc;
+    float *d_wg, *d_bg, *d_wc, *d_bc;
+    float *d_x;
+    int32_t seq_per_wg;   /* set by the library */
+} HpmnGruWgrad;
+
+int hpmn_gru_param_grads(const HpmnGruWgrad *args, void *stream);
+
+/* ------------------------------------------------------------------------------------
  * Whole build_memory forward (code/hpmn.py:113-129 without the covariance loss): K
  * layers chained through a caller-provided workspace.  Inference form (no saved
  * states).   memory [B,K,H];  last [B, F*E] = uinp[:, last_index, :] (code/hpmn.py:439
