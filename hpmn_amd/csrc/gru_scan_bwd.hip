@@ -4,20 +4,29 @@
 // The two transposed mat-vecs of the reverse step
 //     d(r*h)[k]  = sum_n dc_pre[n] * Wc[D+k][n]
 //     dh_prev[k] = dh[k]*u[k] + d(r*h)[k]*r[k] + sum_n (da_r[n]*Wg[D+k][n] + da_u[n]*Wg[D+k][H+n])
-// use ROW k of the recurrent blocks, kept register-stationary in lane k (3H VGPRs); the
-// broadcast operands (dc_pre, da_r, da_u) go through LDS as wave-uniform 16-byte reads.
-// Saved activations (r,u,c,h_prev) and the incoming output gradients are prefetched one
-// CHB-step chunk ahead into registers, so the only HBM access on the serial chain is the
-// fire-and-forget store of d_act.  Weight/input gradients are GEMMs over d_act (host).
+// use ROW k of the recurrent blocks, kept register-stationary in lane k (3H VGPRs, packed in
+// pairs for v_pk_fma_f32); the broadcast operands (dc_pre, da_r, da_u) go through LDS as
+// wave-uniform 16-byte reads.  Saved activations (r,u,c | h_prev) are contiguous per 4-step
+// chunk in HBM: they are fetched three 2-step chunks ahead (4 x 8 B per lane), parked in an LDS ring
+// and read back per step, so the only HBM access on the serial chain is the fire-and-forget
+// store of d_act.  Weight/input gradients are MFMA reductions over d_act (gru_wgrad.hip).
 #include "common.h"
 
 namespace hpmn {
 
-constexpr int CHB = 8;  // reverse steps per prefetched chunk
+constexpr int BCS = 2;    // steps per staged chunk
+constexpr int BPD = 3;    // prefetch distance in chunks
+constexpr int BRING = 4;  // chunks in the LDS ring (> BPD)
 
 template <int H>
 __global__ __launch_bounds__(64, 1) void gru_scan_bwd_kernel(const HpmnGruBwd a) {
     constexpr int SPW = 64 / H;
+    constexpr int GF = BCS * 3 * H;   // gates floats per sequence per chunk (r,u,c)
+    constexpr int HF = BCS * H;       // h_prev floats per sequence per chunk
+    static_assert(GF / 2 == 3 * H && HF / 2 == H, "3 + 1 float2 per lane per chunk");
+    __shared__ __attribute__((aligned(16))) float gring[BRING][SPW * GF];
+    __shared__ __attribute__((aligned(16))) float hring[BRING][SPW * HF];
+    __shared__ float dring[BRING][BCS * 64];
     __shared__ __attribute__((aligned(16))) float bufA[SPW * H];
     __shared__ __attribute__((aligned(16))) float bufB[SPW * 2 * H];
 
@@ -25,99 +34,123 @@ __global__ __launch_bounds__(64, 1) void gru_scan_bwd_kernel(const HpmnGruBwd a)
     const int s = lane / H;
     const int l = lane % H;
     const int B = a.B, T = a.T, D = a.D;
-    const long b_raw = (long)blockIdx.x * SPW + s;
-    const bool live = b_raw < B;
+    const long b_raw = SPW == 1 ? (long)blockIdx.x : (long)blockIdx.x * SPW + s;
+    const bool live = SPW == 1 ? true : (b_raw < B);
     const long b = live ? b_raw : (long)B - 1;
 
-    float wcT[H], wgT[2 * H];
+    f2 wcT[H / 2], wgT[H];
 #pragma unroll
-    for (int n = 0; n < H; n += 4) {
-        const float4 v = *reinterpret_cast<const float4 *>(a.wc + (long)(D + l) * H + n);
-        wcT[n] = v.x; wcT[n + 1] = v.y; wcT[n + 2] = v.z; wcT[n + 3] = v.w;
-    }
+    for (int n = 0; n < H / 2; ++n) wcT[n] = *reinterpret_cast<const f2 *>(a.wc + (long)(D + l) * H + 2 * n);
 #pragma unroll
-    for (int n = 0; n < 2 * H; n += 4) {
-        const float4 v = *reinterpret_cast<const float4 *>(a.wg + (long)(D + l) * 2 * H + n);
-        wgT[n] = v.x; wgT[n + 1] = v.y; wgT[n + 2] = v.z; wgT[n + 3] = v.w;
-    }
+    for (int n = 0; n < H; ++n) wgT[n] = *reinterpret_cast<const f2 *>(a.wg + (long)(D + l) * 2 * H + 2 * n);
 
     const int period = a.period;
     const bool has_dy = a.d_y != nullptr;
-    const int Ty = has_dy ? T / period : 0;
+    const float *gb = a.gates + b * (long)T * 3 * H;
+    const float *hsb = a.hs + b * (long)(T + 1) * H;
+    const float *dyb = has_dy ? a.d_y + b * (long)(T / period) * H + l : nullptr;
 
-    struct Saved { float r, u, c, hp, dy; };
-    auto fetch = [&](int j, Saved &o) {
-        const int t = T - 1 - j;
-        o.r = o.u = o.c = o.hp = o.dy = 0.f;
-        if (t >= 0) {
-            const float *g = a.gates + (b * T + t) * 4 * H;
-            o.r = g[l];
-            o.u = g[H + l];
-            o.c = g[2 * H + l];
-            o.hp = a.hs[(b * (T + 1) + t) * H + l];
-            if (has_dy && (t + 1) % period == 0)
-                o.dy = a.d_y[(b * Ty + (t + 1) / period - 1) * H + l];
+    // chunk q covers steps t in [T - BCS*(q+1), T - BCS*q); float2 i of lane (s,l) covers elements
+    // e = 2*(i*H + l), e+1 of the [BCS x 3H] gates image; the [BCS x H] h_prev image takes one float2.
+    // Rows with t < 0 (tail chunk / run-ahead past the start) are clamped to 0: loaded, never consumed.
+    int g_row[3], g_col[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int e = 2 * (i * H + l);
+        g_row[i] = e / (3 * H);
+        g_col[i] = e - g_row[i] * 3 * H;
+    }
+    const int h_row = (2 * l) / H, h_col = 2 * l - h_row * H;
+    // incoming output gradients: d_y row j belongs to step (j+1)*period - 1; walking backwards the
+    // prefetch stream keeps "the next step that has one" instead of dividing every step
+    int pf_fire = T - 1, pf_row = T / period - 1;
+
+    struct Pre { f2 g[3]; f2 hp; float dy[BCS]; };
+    auto load_chunk = [&](int q, Pre &p) {
+        const int t_lo = T - BCS * (q + 1);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            int t = t_lo + g_row[i];
+            t = t > 0 ? t : 0;
+            p.g[i] = *reinterpret_cast<const f2 *>(gb + (long)t * 3 * H + g_col[i]);
+        }
+        {
+            int t = t_lo + h_row;
+            t = t > 0 ? t : 0;
+            p.hp = *reinterpret_cast<const f2 *>(hsb + (long)t * H + h_col);
+        }
+#pragma unroll
+        for (int tt = BCS - 1; tt >= 0; --tt) {
+            p.dy[tt] = 0.f;
+            if (has_dy && t_lo + tt == pf_fire && pf_row >= 0) {
+                p.dy[tt] = dyb[(long)pf_row * H];
+                pf_row -= 1;
+                pf_fire -= period;
+            }
         }
     };
-
-    Saved cur[CHB], nxt[CHB];
+    auto park_chunk = [&](int q, const Pre &p) {
+        float *gd = &gring[q % BRING][s * GF];
 #pragma unroll
-    for (int jj = 0; jj < CHB; ++jj) fetch(jj, cur[jj]);
+        for (int i = 0; i < 3; ++i) *reinterpret_cast<f2 *>(gd + 2 * (i * H + l)) = p.g[i];
+        *reinterpret_cast<f2 *>(&hring[q % BRING][s * HF + 2 * l]) = p.hp;
+#pragma unroll
+        for (int tt = 0; tt < BCS; ++tt) dring[q % BRING][tt * 64 + lane] = p.dy[tt];
+    };
 
+    const int nchunk = (T + BCS - 1) / BCS;
+    {
+        Pre p;
+#pragma unroll
+        for (int q = 0; q < BPD; ++q) {
+            load_chunk(q, p);
+            park_chunk(q, p);
+        }
+    }
     float dh = a.d_h_last[b * a.d_h_last_stride + l];
-    const int nchunk = (T + CHB - 1) / CHB;
+    wave_sync();
+
     for (int q = 0; q < nchunk; ++q) {
+        Pre pre;
+        load_chunk(q + BPD, pre);
+        const int t_lo = T - BCS * (q + 1);
+        const float *gc = &gring[q % BRING][s * GF + l];
+        const float *hc = &hring[q % BRING][s * HF + l];
+        const float *dc = &dring[q % BRING][lane];
 #pragma unroll
-        for (int jj = 0; jj < CHB; ++jj) fetch((q + 1) * CHB + jj, nxt[jj]);
-#pragma unroll
-        for (int jj = 0; jj < CHB; ++jj) {
-            const int j = q * CHB + jj;
-            if (j < T) {
-                const int t = T - 1 - j;
-                const Saved sv = cur[jj];
-                dh += sv.dy;
-                const float omu = 1.f - sv.u;
-                const float dcp = dh * omu * (1.f - sv.c * sv.c);
-                const float dau = dh * (sv.hp - sv.c) * sv.u * omu;
+        for (int jj = 0; jj < BCS; ++jj) {
+            const int tt = BCS - 1 - jj;       // row inside the chunk, walking backwards in time
+            const int t = t_lo + tt;
+            if (t >= 0) {
+                const float r = gc[tt * 3 * H], u = gc[tt * 3 * H + H], c = gc[tt * 3 * H + 2 * H];
+                const float hp = hc[tt * H];
+                dh += dc[tt * 64];
+                const float omu = 1.f - u;
+                const float dcp = dh * omu * (1.f - c * c);
+                const float dau = dh * (hp - c) * u * omu;
                 bufA[lane] = dcp;
                 wave_sync();
-                const float4 *ra = reinterpret_cast<const float4 *>(&bufA[s * H]);
-                float d0 = 0.f, d1 = 0.f;
-#pragma unroll
-                for (int n = 0; n < H / 4; ++n) {
-                    const float4 v = ra[n];
-                    d0 = fmaf(v.x, wcT[4 * n + 0], d0);
-                    d1 = fmaf(v.y, wcT[4 * n + 1], d1);
-                    d0 = fmaf(v.z, wcT[4 * n + 2], d0);
-                    d1 = fmaf(v.w, wcT[4 * n + 3], d1);
-                }
-                const float drh = d0 + d1;
-                const float dar = drh * sv.hp * sv.r * (1.f - sv.r);
+                f2 d0 = {0.f, 0.f}, d1 = {0.f, 0.f};
+                bcast_matvec<H / 4>(reinterpret_cast<const float4 *>(&bufA[s * H]), wcT, d0, d1);
+                const float drh = (d0.x + d0.y) + (d1.x + d1.y);
+                const float dar = drh * hp * r * (1.f - r);
                 bufB[s * 2 * H + l] = dar;
                 bufB[s * 2 * H + H + l] = dau;
                 wave_sync();
-                const float4 *rb = reinterpret_cast<const float4 *>(&bufB[s * 2 * H]);
-                float e0 = 0.f, e1 = 0.f;
-#pragma unroll
-                for (int n = 0; n < 2 * H / 4; ++n) {
-                    const float4 v = rb[n];
-                    e0 = fmaf(v.x, wgT[4 * n + 0], e0);
-                    e1 = fmaf(v.y, wgT[4 * n + 1], e1);
-                    e0 = fmaf(v.z, wgT[4 * n + 2], e0);
-                    e1 = fmaf(v.w, wgT[4 * n + 3], e1);
-                }
+                f2 e0 = {0.f, 0.f}, e1 = {0.f, 0.f};
+                bcast_matvec<2 * H / 4>(reinterpret_cast<const float4 *>(&bufB[s * 2 * H]), wgT, e0, e1);
                 if (live) {
-                    float *da = a.d_act + (b * T + t) * 3 * H;
-                    da[l] = dar;
-                    da[H + l] = dau;
-                    da[2 * H + l] = dcp;
+                    float *da = a.d_act + (b * T + t) * 3 * H + l;
+                    da[0] = dar;
+                    da[H] = dau;
+                    da[2 * H] = dcp;
                 }
-                dh = fmaf(dh, sv.u, fmaf(drh, sv.r, e0 + e1));
+                dh = fmaf(dh, u, fmaf(drh, r, (e0.x + e0.y) + (e1.x + e1.y)));
                 wave_sync();
             }
         }
-#pragma unroll
-        for (int jj = 0; jj < CHB; ++jj) cur[jj] = nxt[jj];
+        park_chunk(q + BPD, pre);
+        wave_sync();
     }
 }
 

@@ -7,24 +7,33 @@
 //     so there is no s_barrier anywhere in the time loop.
 //   * the input half of both GRU kernels (x_t Wg[:D] + bg, x_t Wc[:D] + bc) has no serial
 //     dependency and is hoisted into input_proj.hip; this kernel streams the projected
-//     rows xp[b,t,0:3H] (prefetched CHF steps ahead into registers).
+//     rows xp[b,t,0:3H].  They are fetched one 2-step chunk (3 x 8 B per lane, contiguous
+//     in HBM) three chunks ahead, parked in an LDS ring, and read back 4 bytes per lane per
+//     gate when the step needs them, so HBM latency never sits on the serial chain and the
+//     prefetch costs 6 VGPRs.
 //   * the recurrent half is register-stationary: lane l keeps column l of the r, u and c
-//     blocks of the state rows (3H arch VGPRs -- VALU cannot source AGPRs, which is what
-//     bounds the per-lane weight budget at 256 and is why the input half is hoisted).
-//   * the per-step broadcast operands (h_{t-1}, r*h_{t-1}) go through LDS as wave-uniform
-//     16-byte reads (a broadcast, conflict-free); each value read feeds 2 (r,u) or 1 (c)
-//     FMAs per lane.
+//     blocks of the state rows (3H arch VGPRs -- VALU cannot source AGPRs, which bounds the
+//     per-lane weight budget at 256 and is why the input half is hoisted).
+//   * a single wave issues one VALU instruction per ~5.3 cycles whatever it is (measured,
+//     tools/micro), so the step is instruction-count bound: all mat-vec FMAs are packed
+//     (v_pk_fma_f32 over two consecutive k: 3H/2 instructions per step instead of 3H) with
+//     the broadcast operands (h_{t-1}, r*h_{t-1}) read from LDS as wave-uniform 16-byte
+//     loads, each feeding two packed FMAs.
 #include "common.h"
 
 namespace hpmn {
 
-constexpr int CHF = 8;  // steps of projected input prefetched per chunk
+constexpr int CS = 2;    // steps per staged chunk of projected input
+constexpr int PD = 3;    // prefetch distance in chunks
+constexpr int RING = 4;  // chunks in the LDS ring (> PD)
 
 template <int H, bool TRAIN>
 __global__ __launch_bounds__(64, 1) void gru_scan_fwd_kernel(const HpmnGruFwd a) {
-    constexpr int SPW = 64 / H;  // sequences per wave
-    static_assert(64 % H == 0, "shape");
+    constexpr int SPW = 64 / H;          // sequences per wave
+    constexpr int CF = CS * 3 * H;       // floats per sequence per chunk
+    static_assert(64 % H == 0 && CF / 2 == 3 * H, "3 float2 per lane per chunk");
 
+    __shared__ __attribute__((aligned(16))) float ring[RING][SPW * CF];
     __shared__ __attribute__((aligned(16))) float hb[SPW * H];
     __shared__ __attribute__((aligned(16))) float rhb[SPW * H];
 
@@ -32,34 +41,54 @@ __global__ __launch_bounds__(64, 1) void gru_scan_fwd_kernel(const HpmnGruFwd a)
     const int s = lane / H;  // which of this wave's sequences
     const int l = lane % H;  // hidden unit
     const int B = a.B, T = a.T, D = a.D;
-    const long b_raw = (long)blockIdx.x * SPW + s;
-    const bool live = b_raw < B;
+    // SPW == 1: the sequence index is wave-uniform (addresses stay in SGPRs)
+    const long b_raw = SPW == 1 ? (long)blockIdx.x : (long)blockIdx.x * SPW + s;
+    const bool live = SPW == 1 ? true : (b_raw < B);
     const long b = live ? b_raw : (long)B - 1;
 
-    // register-stationary recurrent weights (TF layout: rows [D, D+H) are the state rows)
-    float whr[H], whu[H], whc[H];
+    // register-stationary recurrent weights, packed over consecutive k (TF layout: rows [D, D+H))
+    f2 whr[H / 2], whu[H / 2], whc[H / 2];
 #pragma unroll
-    for (int k = 0; k < H; ++k) {
-        whr[k] = a.wg[(long)(D + k) * 2 * H + l];
-        whu[k] = a.wg[(long)(D + k) * 2 * H + H + l];
-        whc[k] = a.wc[(long)(D + k) * H + l];
+    for (int k = 0; k < H / 2; ++k) {
+        whr[k] = f2{a.wg[(long)(D + 2 * k) * 2 * H + l], a.wg[(long)(D + 2 * k + 1) * 2 * H + l]};
+        whu[k] = f2{a.wg[(long)(D + 2 * k) * 2 * H + H + l], a.wg[(long)(D + 2 * k + 1) * 2 * H + H + l]};
+        whc[k] = f2{a.wc[(long)(D + 2 * k) * H + l], a.wc[(long)(D + 2 * k + 1) * H + l]};
     }
 
-    struct XP { float r, u, c; };
-    const float *xpb = a.xp + b * (long)T * 3 * H + l;
-    auto fetch = [&](int t, XP &o) {
-        o.r = o.u = o.c = 0.f;
-        if (t < T) {
-            const float *p = xpb + (long)t * 3 * H;
-            o.r = p[0];
-            o.u = p[H];
-            o.c = p[2 * H];
+    // chunk staging: float2 i of lane (s,l) covers elements e = 2*(i*H + l), e+1 of the sequence's
+    // [CS x 3H] chunk image, i.e. row e / 3H, column e % 3H.  Rows past the end are clamped to T-1
+    // (they are loaded but never consumed), so the prefetch has no branches.
+    const float *xpb = a.xp + b * (long)T * 3 * H;
+    int c_row[3], c_col[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int e = 2 * (i * H + l);
+        c_row[i] = e / (3 * H);
+        c_col[i] = e - c_row[i] * 3 * H;
+    }
+    auto load_chunk = [&](int c, f2 (&v)[3]) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            int t = c * CS + c_row[i];
+            t = t < T ? t : T - 1;
+            v[i] = *reinterpret_cast<const f2 *>(xpb + (long)t * 3 * H + c_col[i]);
         }
     };
-
-    XP cur[CHF], nxt[CHF];
+    auto park_chunk = [&](int c, const f2 (&v)[3]) {
+        float *dst = &ring[c % RING][s * CF];
 #pragma unroll
-    for (int i = 0; i < CHF; ++i) fetch(i, cur[i]);
+        for (int i = 0; i < 3; ++i) *reinterpret_cast<f2 *>(dst + 2 * (i * H + l)) = v[i];
+    };
+
+    const int nchunk = (T + CS - 1) / CS;
+    {
+        f2 v[3];
+#pragma unroll
+        for (int c = 0; c < PD; ++c) {
+            load_chunk(c, v);
+            park_chunk(c, v);
+        }
+    }
 
     float h = 0.f;
     hb[lane] = 0.f;
@@ -68,62 +97,56 @@ __global__ __launch_bounds__(64, 1) void gru_scan_fwd_kernel(const HpmnGruFwd a)
     }
     wave_sync();
 
+    // subsampled outputs y[:, j] = outputs[:, (j+1)*period - 1]: running "next firing step" counter
     const int period = a.period;
-    const int nchunk = (T + CHF - 1) / CHF;
+    const bool has_y = a.y != nullptr;
+    int next_fire = period - 1;
+    float *yp = has_y ? a.y + (b * (long)(T / period)) * H + l : nullptr;
+    float *hsp = TRAIN ? a.hs + (b * (long)(T + 1) + 1) * H + l : nullptr;
+    float *gp = TRAIN ? a.gates + (b * (long)T) * 3 * H + l : nullptr;
+
     for (int c = 0; c < nchunk; ++c) {
-        const int t0 = c * CHF;
+        f2 pre[3];
+        load_chunk(c + PD, pre);          // in flight for the steps below
+        const float *xc = &ring[c % RING][s * CF + l];
 #pragma unroll
-        for (int i = 0; i < CHF; ++i) fetch(t0 + CHF + i, nxt[i]);
-#pragma unroll
-        for (int tt = 0; tt < CHF; ++tt) {
-            const int t = t0 + tt;
+        for (int tt = 0; tt < CS; ++tt) {
+            const int t = c * CS + tt;
             if (t < T) {
-                const float4 *hrow = reinterpret_cast<const float4 *>(&hb[s * H]);
-                float ar = cur[tt].r, au = cur[tt].u;
-                float ar2 = 0.f, au2 = 0.f;
-#pragma unroll
-                for (int k = 0; k < H / 4; ++k) {
-                    const float4 v = hrow[k];
-                    ar = fmaf(v.x, whr[4 * k + 0], ar);   au = fmaf(v.x, whu[4 * k + 0], au);
-                    ar2 = fmaf(v.y, whr[4 * k + 1], ar2); au2 = fmaf(v.y, whu[4 * k + 1], au2);
-                    ar = fmaf(v.z, whr[4 * k + 2], ar);   au = fmaf(v.z, whu[4 * k + 2], au);
-                    ar2 = fmaf(v.w, whr[4 * k + 3], ar2); au2 = fmaf(v.w, whu[4 * k + 3], au2);
-                }
-                const float r = fast_sigmoid(ar + ar2);
-                const float u = fast_sigmoid(au + au2);
-                const float rh = r * h;
-                rhb[lane] = rh;
+                const float xr = xc[tt * 3 * H], xu = xc[tt * 3 * H + H], xcand = xc[tt * 3 * H + 2 * H];
+                f2 ar = {0.f, 0.f}, au = {0.f, 0.f};
+                bcast_matvec2<H / 4>(reinterpret_cast<const float4 *>(&hb[s * H]), whr, whu, ar, au);
+                const float r = fast_sigmoid(xr + (ar.x + ar.y));
+                const float u = fast_sigmoid(xu + (au.x + au.y));
+                rhb[lane] = r * h;
                 wave_sync();
-                const float4 *rrow = reinterpret_cast<const float4 *>(&rhb[s * H]);
-                float ac = cur[tt].c, ac2 = 0.f, ac3 = 0.f, ac4 = 0.f;
-#pragma unroll
-                for (int k = 0; k < H / 4; ++k) {
-                    const float4 v = rrow[k];
-                    ac = fmaf(v.x, whc[4 * k + 0], ac);
-                    ac2 = fmaf(v.y, whc[4 * k + 1], ac2);
-                    ac3 = fmaf(v.z, whc[4 * k + 2], ac3);
-                    ac4 = fmaf(v.w, whc[4 * k + 3], ac4);
-                }
-                const float cc = fast_tanh((ac + ac2) + (ac3 + ac4));
+                f2 ac = {0.f, 0.f}, ac2 = {0.f, 0.f};
+                bcast_matvec<H / 4>(reinterpret_cast<const float4 *>(&rhb[s * H]), whc, ac, ac2);
+                const float cc = fast_tanh(xcand + ((ac.x + ac.y) + (ac2.x + ac2.y)));
                 h = fmaf(u, h - cc, cc);  // u*h + (1-u)*c
                 hb[lane] = h;
                 wave_sync();
                 if (live) {
                     if constexpr (TRAIN) {
-                        a.hs[(b * (T + 1) + t + 1) * H + l] = h;
-                        float *g = a.gates + (b * T + t) * 4 * H;
-                        g[l] = r;
-                        g[H + l] = u;
-                        g[2 * H + l] = cc;
-                        g[3 * H + l] = rh;
+                        *hsp = h;
+                        gp[0] = r;
+                        gp[H] = u;
+                        gp[2 * H] = cc;
                     }
-                    if (a.y != nullptr && (t + 1) % period == 0)
-                        a.y[(b * (T / period) + (t + 1) / period - 1) * H + l] = h;
+                    if (has_y && t == next_fire) *yp = h;
+                }
+                if constexpr (TRAIN) {
+                    hsp += H;
+                    gp += 3 * H;
+                }
+                if (t == next_fire) {
+                    next_fire += period;
+                    yp += H;
                 }
             }
         }
-#pragma unroll
-        for (int i = 0; i < CHF; ++i) cur[i] = nxt[i];
+        park_chunk(c + PD, pre);
+        wave_sync();
     }
     if (live) a.h_last[b * a.h_last_stride + l] = h;
 }

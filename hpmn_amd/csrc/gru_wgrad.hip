@@ -55,7 +55,7 @@ __global__ __launch_bounds__(64 * (HT + DT)) void gru_wgrad_kernel(const HpmnGru
         const float *dab = a.d_act + (long)b * T * 3 * H + c;
         const float *xb = a.x + (long)b * T * D + xcol;
         const float *hb = a.hs + (long)b * (T + 1) * H + 32 * tile + c;
-        const float *gb = a.gates + (long)b * T * 4 * H + 3 * H + 32 * tile + c;
+        const float *gb = a.gates + (long)b * T * 3 * H + 32 * tile + c;   // r column of this tile
         for (int t0 = 0; t0 < T; t0 += 2 * WU) {
             float A1[WU], A2[WU], Bv[WU][NJ];
 #pragma unroll
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(64 * (HT + DT)) void gru_wgrad_kernel(const HpmnGru
                     A2[s] = 0.f;
                 } else {
                     A1[s] = ok ? hb[(long)t * H] : 0.f;
-                    A2[s] = ok ? gb[(long)t * 4 * H] : 0.f;
+                    A2[s] = ok ? gb[(long)t * 3 * H] : 0.f;          // r; becomes r*h_prev below
                 }
             }
             if (role_x) {
@@ -84,6 +84,8 @@ __global__ __launch_bounds__(64 * (HT + DT)) void gru_wgrad_kernel(const HpmnGru
                     }
                 }
             } else {
+#pragma unroll
+                for (int s = 0; s < WU; ++s) A2[s] *= A1[s];
 #pragma unroll
                 for (int s = 0; s < WU; ++s) {
 #pragma unroll

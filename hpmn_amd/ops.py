@@ -145,7 +145,7 @@ def gru_scan_fwd(xp, wg, wc, D, h_last, period, want_y, train):
         a.y = y.data_ptr()
     if train:
         hs = torch.empty(B, T + 1, H, device=xp.device, dtype=torch.float32)
-        gates = torch.empty(B, T, 4 * H, device=xp.device, dtype=torch.float32)
+        gates = torch.empty(B, T, 3 * H, device=xp.device, dtype=torch.float32)
         a.hs, a.gates = hs.data_ptr(), gates.data_ptr()
     rc = _lib.load().hpmn_gru_scan_fwd(C.byref(a), _stream())
     _lib.check(rc, "hpmn_gru_scan_fwd")

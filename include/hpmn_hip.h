@@ -80,7 +80,7 @@ int hpmn_embed_gather(const int32_t *ids, const float *emb, float *out,
  *   h_last  : final state, written at h_last[b*h_last_stride + 0..H)   (memory[:, i, :])
  *   y       : optional [B, T/period, H]  = outputs[:, period-1::period, :]   (next layer's input)
  *   hs      : optional [B, T+1, H]  hs[b,0]=0, hs[b,t+1] = state after step t      (training)
- *   gates   : optional [B, T, 4H]   (r, u, c, r*h_prev) per step                    (training)
+ *   gates   : optional [B, T, 3H]   (r, u, c) per step                               (training)
  * ---------------------------------------------------------------------------------- */
 typedef struct HpmnInputProj {
     int32_t B, T, D, H;
