@@ -180,15 +180,16 @@ def cpu_baseline(c, seed=0, budget_s=20.0):
         R.train_step(cfg, p, opt, ids, label)
         return time.perf_counter() - t0
 
-    t_cal = run(8)
-    log("cpu baseline calibration: batch 8 step %.2fs on %d threads" % (t_cal, threads))
-    bs = int(max(8, min(c["batch"], 8 * budget_s / max(t_cal, 1e-3))))
-    t = run(bs) if bs > 8 else t_cal
+    run(8)                                   # warm-up (allocator, thread pool, first-touch of the table)
+    t_cal = run(16)
+    log("cpu baseline calibration: batch 16 step %.2fs on %d threads" % (t_cal, threads))
+    bs = int(max(16, min(c["batch"], 16 * budget_s / max(t_cal, 1e-3))))
+    t = run(bs) if bs > 16 else t_cal
     log("cpu baseline: batch %d step %.2fs" % (bs, t))
     return {"value": bs / t, "unit": "sequences/s", "cores": threads, "kind": "port",
             "sample": "1 train step (fwd+BPTT+clip+dense Adam) of batch %d at the full %s shape, fp32 "
                       "PyTorch-CPU eager restatement (oracle/torch_restatement.py), %.2fs; calibration "
-                      "step of batch 8 took %.2fs" % (bs, c["name"], t, t_cal)}
+                      "step of batch 16 took %.2fs" % (bs, c["name"], t, t_cal)}
 
 
 def main():
