@@ -127,6 +127,12 @@ def roofline_probes(model, c, ids):
                                                     H=H, T=T0, front_zero=spec.front_zero,
                                                     mask_id0=spec.mask_id0), 5, st)
     t_gather = time_kernel(lambda: ops.embed_gather(ids, emb, spec.mask_id0), 10, st)
+    d_act = ops.gru_scan_bwd(w[0], w[2], D0, hs, gates, dmem, None, spec.periods[0])
+    gw = [torch.zeros_like(t) for t in w[:4]]
+    t_wgrad = time_kernel(lambda: ops.gru_param_grads(x0, hs, gates, d_act, w[0], w[2], gw[0], gw[1], gw[2], gw[3],
+                                                      want_dx=False), 5, st)
+    t_wgrad_dx = time_kernel(lambda: ops.gru_param_grads(x0, hs, gates, d_act, w[0], w[2], gw[0], gw[1], gw[2],
+                                                         gw[3], want_dx=True), 5, st)
     # serial-scan flops per launch (recurrent half only; the input half lives in input_proj)
     scan_flops = B * T0 * 2 * H * 3 * H
     gather_bytes = B * c["T"] * c["F"] * (4 + 2 * 16 * 4)      # id + row read + row write
@@ -137,8 +143,13 @@ def roofline_probes(model, c, ids):
             "frac": scan_flops / (dom_t * 1e-3) / 1e12 / PEAK_F32_TFLOPS, "traffic": None,
             "ms_per_launch": dom_t,
             "note": "fp32 FMA chain, latency-bound serial recurrence; peak = dense fp32 (vector == f32 MFMA)"}
+    wgrad_flops = B * T0 * 2 * (D0 + H) * 3 * H
     extra = {
         "scan_fwd_ms": t_fwd, "scan_bwd_ms": t_bwd,
+        "wgrad": {"ms": t_wgrad, "bound": "mfma", "achieved": wgrad_flops / (t_wgrad * 1e-3) / 1e12,
+                  "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
+                  "frac": wgrad_flops / (t_wgrad * 1e-3) / 1e12 / PEAK_F32_TFLOPS},
+        "dx_ms": t_wgrad_dx - t_wgrad,
         "scan_fwd_tflops": scan_flops / (t_fwd * 1e-3) / 1e12,
         "scan_bwd_tflops": scan_flops / (t_bwd * 1e-3) / 1e12,
         "input_proj": {"ms": t_proj, "bound": "hbm", "achieved": proj_bytes / (t_proj * 1e-3) / 1e9,

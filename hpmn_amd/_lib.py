@@ -59,6 +59,7 @@ class HpmnGruWgrad(C.Structure):
         ("wg", C.c_void_p), ("wc", C.c_void_p),
         ("d_wg", C.c_void_p), ("d_bg", C.c_void_p), ("d_wc", C.c_void_p), ("d_bc", C.c_void_p),
         ("d_x", C.c_void_p),
+        ("workspace", C.c_void_p),
         ("seq_per_wg", C.c_int32),
     ]
 
@@ -84,6 +85,7 @@ SIGNATURES = {
     "hpmn_gru_input_proj": (C.c_int, [C.POINTER(HpmnInputProj), C.c_void_p]),
     "hpmn_gru_scan_fwd": (C.c_int, [C.POINTER(HpmnGruFwd), C.c_void_p]),
     "hpmn_gru_scan_bwd": (C.c_int, [C.POINTER(HpmnGruBwd), C.c_void_p]),
+    "hpmn_gru_param_grads_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "hpmn_gru_param_grads": (C.c_int, [C.POINTER(HpmnGruWgrad), C.c_void_p]),
     "hpmn_scan_workspace_bytes": (C.c_size_t, [C.POINTER(HpmnScanDesc)]),
     "hpmn_scan_fwd": (C.c_int, [C.POINTER(HpmnScanDesc), C.c_void_p, C.c_void_p,

@@ -13,6 +13,7 @@ int gru_scan_bwd_dispatch(const HpmnGruBwd &a, hipStream_t st);
 bool input_proj_supported(int H, int D);
 int input_proj_dispatch(const HpmnInputProj &a, hipStream_t st);
 int gru_wgrad_dispatch(const HpmnGruWgrad &a, hipStream_t st);
+size_t gru_wgrad_workspace_bytes(int B, int T, int D, int H);
 int embed_gather_launch(const int32_t *ids, int64_t ids_stride, const float *emb, float *out, int64_t N,
                         int32_t F, int32_t E, int32_t mask_id0, hipStream_t st);
 int embed_grad_scatter_launch(const int32_t *ids, const float *d_x, float *d_emb, int32_t B, int32_t T,
@@ -109,13 +110,18 @@ int hpmn_gru_scan_bwd(const HpmnGruBwd *a, void *stream) {
     return gru_scan_bwd_dispatch(k, (hipStream_t)stream);
 }
 
+size_t hpmn_gru_param_grads_workspace_bytes(int32_t B, int32_t T, int32_t D, int32_t H) {
+    if (B < 1 || T < 1 || D < 1 || H < 1) return 0;
+    return gru_wgrad_workspace_bytes(B, T, D, H);
+}
+
 int hpmn_gru_param_grads(const HpmnGruWgrad *a, void *stream) {
     if (!a) return HPMN_EINVAL;
     if (a->B < 0 || a->T < 1 || a->D < 1 || a->H < 1) return HPMN_EINVAL;
     if (!gru_shape_supported(a->H, a->D) || !input_proj_supported(a->H, a->D)) return HPMN_EUNSUPPORTED;
     if (a->B == 0) return HPMN_OK;
     if (!a->x || !a->hs || !a->gates || !a->d_act || !a->wg || !a->wc || !a->d_wg || !a->d_bg || !a->d_wc ||
-        !a->d_bc)
+        !a->d_bc || !a->workspace)
         return HPMN_EINVAL;
     return gru_wgrad_dispatch(*a, (hipStream_t)stream);
 }

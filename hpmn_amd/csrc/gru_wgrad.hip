@@ -13,8 +13,10 @@
 //     register layout -- no LDS staging, no transposes.  A workgroup owns whole sequences;
 //     its waves split the OUTPUT tiles (wave w<DT: 32 input columns x all 3H gate columns;
 //     the others: 32 state columns of h_prev x 2H and of r*h_prev x H) and keep their
-//     3H/32 accumulator tiles (<=96 VGPRs) resident over all rows, finishing with one fp32
-//     atomic add per accumulator element (dW must be zeroed by the caller).
+//     3H/32 accumulator tiles (<=96 registers) resident over all rows; the operands of the
+//     next 16 rows are in flight under the current 16 rows' MFMAs.  Each workgroup stores its
+//     partial result as a slab in a caller-provided workspace and wgrad_reduce_kernel adds the
+//     slabs into dW (single writer per element: deterministic, no atomics).
 // (2) gru_dx_kernel -- also fp32 MFMA: d_act tile staged in LDS as the A operand, the input
 //     rows of the kernels as register-stationary B operands, coalesced stores.
 #include "common.h"
@@ -23,7 +25,11 @@ namespace hpmn {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int WU = 8;  // 2-row MFMA steps per unrolled block (16 rows)
+constexpr int WU = 8;          // 2-row MFMA steps per iteration (16 rows)
+constexpr int WG_MIN_ROWS = 128;  // a workgroup takes whole sequences, at least this many rows
+
+// Slab layout of one workgroup's partial result (floats): [d_wg (D+H)x2H][d_bg 2H][d_wc (D+H)xH][d_bc H]
+__host__ __device__ inline long wgrad_slab_floats(int D, int H) { return (long)(D + H) * 3 * H + 3 * H; }
 
 template <int HT, int DT>
 __global__ __launch_bounds__(64 * (HT + DT)) void gru_wgrad_kernel(const HpmnGruWgrad a) {
@@ -51,75 +57,112 @@ __global__ __launch_bounds__(64 * (HT + DT)) void gru_wgrad_kernel(const HpmnGru
 
     const int b_begin = blockIdx.x * a.seq_per_wg;
     const int b_end = (b_begin + a.seq_per_wg) < a.B ? (b_begin + a.seq_per_wg) : a.B;
-    for (int b = b_begin; b < b_end; ++b) {
+    const int ipt = (T + 2 * WU - 1) / (2 * WU);          // iterations per sequence
+    const int niter = (b_end - b_begin) * ipt;
+
+    struct Ops { float A1[WU], A2[WU], Bv[WU][NJ]; };
+    // operands of iteration `it`: rows t0..t0+15 of sequence b, straight into MFMA register layout
+    auto load_ops = [&](int it, Ops &o) {
+        const int b = b_begin + it / ipt;
+        const int t0 = (it % ipt) * 2 * WU;
         const float *dab = a.d_act + (long)b * T * 3 * H + c;
-        const float *xb = a.x + (long)b * T * D + xcol;
-        const float *hb = a.hs + (long)b * (T + 1) * H + 32 * tile + c;
-        const float *gb = a.gates + (long)b * T * 3 * H + 32 * tile + c;   // r column of this tile
-        for (int t0 = 0; t0 < T; t0 += 2 * WU) {
-            float A1[WU], A2[WU], Bv[WU][NJ];
 #pragma unroll
-            for (int s = 0; s < WU; ++s) {
-                const int t = t0 + 2 * s + rp;
-                const bool ok = t < T;
+        for (int s = 0; s < WU; ++s) {
+            const int t = t0 + 2 * s + rp;
+            const bool ok = t < T;
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) Bv[s][j] = ok ? dab[(long)t * 3 * H + 32 * j] : 0.f;
-                if (role_x) {
-                    A1[s] = (ok && xcol_ok) ? xb[(long)t * D] : 0.f;
-                    A2[s] = 0.f;
-                } else {
-                    A1[s] = ok ? hb[(long)t * H] : 0.f;
-                    A2[s] = ok ? gb[(long)t * 3 * H] : 0.f;          // r; becomes r*h_prev below
-                }
-            }
+            for (int j = 0; j < NJ; ++j) o.Bv[s][j] = ok ? dab[(long)t * 3 * H + 32 * j] : 0.f;
             if (role_x) {
-#pragma unroll
-                for (int s = 0; s < WU; ++s) {
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j)
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[s], Bv[s][j], acc[j], 0, 0, 0);
-                    if (tile == 0) {
-#pragma unroll
-                        for (int j = 0; j < NJ; ++j) bsum[j] += Bv[s][j];
-                    }
-                }
+                o.A1[s] = (ok && xcol_ok) ? a.x[((long)b * T + t) * D + xcol] : 0.f;
+                o.A2[s] = 0.f;
             } else {
-#pragma unroll
-                for (int s = 0; s < WU; ++s) A2[s] *= A1[s];
-#pragma unroll
-                for (int s = 0; s < WU; ++s) {
-#pragma unroll
-                    for (int j = 0; j < 2 * HT; ++j)
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[s], Bv[s][j], acc[j], 0, 0, 0);
-#pragma unroll
-                    for (int j = 2 * HT; j < NJ; ++j)
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(A2[s], Bv[s][j], acc[j], 0, 0, 0);
-                }
+                o.A1[s] = ok ? a.hs[((long)b * (T + 1) + t) * H + 32 * tile + c] : 0.f;
+                o.A2[s] = ok ? a.gates[((long)b * T + t) * 3 * H + 32 * tile + c] : 0.f;   // r
             }
         }
+    };
+
+    Ops cur, nxt;
+    if (niter > 0) load_ops(0, cur);
+    for (int it = 0; it < niter; ++it) {
+        if (it + 1 < niter) load_ops(it + 1, nxt);      // in flight under this iteration's MFMAs
+        if (role_x) {
+#pragma unroll
+            for (int s = 0; s < WU; ++s) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.A1[s], cur.Bv[s][j], acc[j], 0, 0, 0);
+                if (tile == 0) {
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) bsum[j] += cur.Bv[s][j];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < WU; ++s) {
+                const float rh = cur.A2[s] * cur.A1[s];   // r * h_prev (not stored by the forward)
+#pragma unroll
+                for (int j = 0; j < 2 * HT; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.A1[s], cur.Bv[s][j], acc[j], 0, 0, 0);
+#pragma unroll
+                for (int j = 2 * HT; j < NJ; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(rh, cur.Bv[s][j], acc[j], 0, 0, 0);
+            }
+        }
+        cur = nxt;
     }
 
-    // ---- epilogue: C/D layout of 32x32x2: lane holds rows (r&3) + 8*(r>>2) + 4*(lane>>5), col lane&31
+    // ---- epilogue: plain coalesced stores of this workgroup's partial slab (summed by
+    //      wgrad_reduce_kernel).  C/D layout of 32x32x2: rows (r&3) + 8*(r>>2) + 4*(lane>>5), col lane&31
+    float *slab = a.workspace + (long)blockIdx.x * wgrad_slab_floats(D, H);
+    float *s_wg = slab, *s_bg = slab + (long)(D + H) * 2 * H, *s_wc = s_bg + 2 * H;
+    float *s_bc = s_wc + (long)(D + H) * H;
     const int row_base = role_x ? 32 * tile : D + 32 * tile;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const bool gate_tile = j < 2 * HT;
-        float *dst = gate_tile ? a.d_wg : a.d_wc;
+        float *dst = gate_tile ? s_wg : s_wc;
         const int ld = gate_tile ? 2 * H : H;
         const int col = gate_tile ? 32 * j + c : 32 * (j - 2 * HT) + c;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int i = (r & 3) + 8 * (r >> 2) + 4 * rp;
-            if (!role_x || 32 * tile + i < D) atomicAdd(dst + (long)(row_base + i) * ld + col, acc[j][r]);
+            if (!role_x || 32 * tile + i < D) dst[(long)(row_base + i) * ld + col] = acc[j][r];
         }
     }
     if (role_x && tile == 0) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            if (j < 2 * HT) atomicAdd(a.d_bg + 32 * j + c, bsum[j]);
-            else            atomicAdd(a.d_bc + 32 * (j - 2 * HT) + c, bsum[j]);
+            // the two half-waves hold the even / odd rows' sums of the same column
+            const float tot = bsum[j] + __shfl_xor(bsum[j], 32);
+            if (rp == 0) {
+                if (j < 2 * HT) s_bg[32 * j + c] = tot;
+                else            s_bc[32 * (j - 2 * HT) + c] = tot;
+            }
         }
     }
+}
+
+// dst[e] += sum over workgroups of slab[w][e]  (single writer per element: deterministic, no atomics)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ ws, int nwg, long n,
+                                                           float *d_wg, float *d_bg, float *d_wc, float *d_bc,
+                                                           long n_wg, long n_bg, long n_wc) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int w = 0;
+    for (; w + 3 < nwg; w += 4) {
+        s0 += ws[(long)w * n + e];
+        s1 += ws[(long)(w + 1) * n + e];
+        s2 += ws[(long)(w + 2) * n + e];
+        s3 += ws[(long)(w + 3) * n + e];
+    }
+    for (; w < nwg; ++w) s0 += ws[(long)w * n + e];
+    const float tot = (s0 + s1) + (s2 + s3);
+    if (e < n_wg) d_wg[e] += tot;
+    else if (e < n_wg + n_bg) d_bg[e - n_wg] += tot;
+    else if (e < n_wg + n_bg + n_wc) d_wc[e - n_wg - n_bg] += tot;
+    else d_bc[e - n_wg - n_bg - n_wc] += tot;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -198,14 +241,29 @@ __global__ __launch_bounds__(128) void gru_dx_kernel(const HpmnGruWgrad a) {
     }
 }
 
+static int wgrad_seq_per_wg(int T) {
+    int spw = (WG_MIN_ROWS + T - 1) / T;
+    return spw < 1 ? 1 : spw;
+}
+
+size_t gru_wgrad_workspace_bytes(int B, int T, int D, int H) {
+    const int spw = wgrad_seq_per_wg(T);
+    const long nwg = (B + spw - 1) / spw;
+    return (size_t)nwg * (size_t)wgrad_slab_floats(D, H) * sizeof(float);
+}
+
 template <int HT, int DT>
 static int launch_wgrad(const HpmnGruWgrad &a, hipStream_t st) {
     HpmnGruWgrad k = a;
-    int spw = (512 + a.T - 1) / a.T;          // >= ~512 rows per workgroup amortise the atomic epilogue
-    if (spw < 1) spw = 1;
-    k.seq_per_wg = spw;
-    const unsigned grid = (unsigned)((a.B + spw - 1) / spw);
-    hipLaunchKernelGGL((gru_wgrad_kernel<HT, DT>), dim3(grid), dim3(64 * (HT + DT)), 0, st, k);
+    k.seq_per_wg = wgrad_seq_per_wg(a.T);
+    const int nwg = (a.B + k.seq_per_wg - 1) / k.seq_per_wg;
+    hipLaunchKernelGGL((gru_wgrad_kernel<HT, DT>), dim3((unsigned)nwg), dim3(64 * (HT + DT)), 0, st, k);
+    int rc = check_launch();
+    if (rc != HPMN_OK) return rc;
+    const int H = a.H, D = a.D;
+    const long n = wgrad_slab_floats(D, H);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a.workspace, nwg, n,
+                       a.d_wg, a.d_bg, a.d_wc, a.d_bc, (long)(D + H) * 2 * H, (long)2 * H, (long)(D + H) * H);
     return check_launch();
 }
 

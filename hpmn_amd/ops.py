@@ -185,7 +185,11 @@ def gru_param_grads(x, hs, gates, d_act, wg, wc, d_wg, d_bg, d_wc, d_bc, want_dx
     if want_dx:
         d_x = torch.empty(B, T, D, device=x.device, dtype=torch.float32)
         a.d_x = d_x.data_ptr()
-    rc = _lib.load().hpmn_gru_param_grads(C.byref(a), _stream())
+    lib = _lib.load()
+    ws = torch.empty(lib.hpmn_gru_param_grads_workspace_bytes(B, T, D, H) // 4, device=x.device,
+                     dtype=torch.float32)
+    a.workspace = ws.data_ptr()
+    rc = lib.hpmn_gru_param_grads(C.byref(a), _stream())
     _lib.check(rc, "hpmn_gru_param_grads")
     return d_x
 

@@ -141,8 +141,9 @@ int hpmn_gru_scan_bwd(const HpmnGruBwd *args, void *stream);
  *   d_wc [D+H, H] += [x | r*h_prev]^T d_act[:, 2H:]    d_bc [H]  += sum d_act[:, 2H:]
  *   d_x  [B,T,D]   = d_act [wg[0:D] | wc[0:D]]^T       (optional; overwritten, not added)
  * x [B,T,D] is the layer input, hs/gates as saved by hpmn_gru_scan_fwd, d_act from
- * hpmn_gru_scan_bwd.  The d_w / d_b outputs are ACCUMULATED with fp32 atomics: the caller
- * zeroes them (they are views of the optimiser's flat gradient buffer in this repo).
+ * hpmn_gru_scan_bwd.  The d_w / d_b outputs are ACCUMULATED (+=; they are views of the
+ * optimiser's pre-zeroed flat gradient buffer in this repo) by a deterministic two-stage
+ * reduction through `workspace` (>= hpmn_gru_param_grads_workspace_bytes(B,T,D,H) bytes).
  * ---------------------------------------------------------------------------------- */
 typedef struct HpmnGruWgrad {
     int32_t B, T, D, H;
@@ -150,9 +151,11 @@ typedef struct HpmnGruWgrad {
     const float *wg, *wc;
     float *d_wg, *d_bg, *d_wc, *d_bc;
     float *d_x;
+    float *workspace;
     int32_t seq_per_wg;   /* set by the library */
 } HpmnGruWgrad;
 
+size_t hpmn_gru_param_grads_workspace_bytes(int32_t B, int32_t T, int32_t D, int32_t H);
 int hpmn_gru_param_grads(const HpmnGruWgrad *args, void *stream);
 
 /* ------------------------------------------------------------------------------------
