@@ -9,12 +9,15 @@
 //     skinny (<=128 x 192 outputs, up to 10^6 reduction rows), which is exactly the shape
 //     v_mfma_f32_32x32x2_f32 wants when the REDUCTION index is the MFMA k: lane l supplies
 //     A[i=l&31][k=l>>5] = Z[row+k][i0+i] and B[k][j] = d_act[row+k][j0+j], i.e. both operands
-//     are plain coalesced 128-byte row segments loaded straight from HBM into the MFMA
-//     register layout -- no LDS staging, no transposes.  A workgroup owns whole sequences;
+//     are plain 128-byte row segments -- no transposes, and row-major LDS images are read
+//     conflict-free.  16-row tiles of (d_act | x | h_prev | r) are staged once per workgroup
+//     with 16-byte coalesced loads, double-buffered in LDS (every wave needs all of d_act, so
+//     staging cuts the global load instructions 12x vs operand loads straight from HBM --
+//     measured 0.52-0.65 ms -> see DESIGN.md).  A workgroup owns whole sequences;
 //     its waves split the OUTPUT tiles (wave w<DT: 32 input columns x all 3H gate columns;
 //     the others: 32 state columns of h_prev x 2H and of r*h_prev x H) and keep their
-//     3H/32 accumulator tiles (<=96 registers) resident over all rows; the operands of the
-//     next 16 rows are in flight under the current 16 rows' MFMAs.  Each workgroup stores its
+//     3H/32 accumulator tiles (<=96 registers) resident over all rows; the next tile's HBM
+//     loads are in flight under the current tile's MFMAs.  Each workgroup stores its
 //     partial result as a slab in a caller-provided workspace and wgrad_reduce_kernel adds the
 //     slabs into dW (single writer per element: deterministic, no atomics).
 // (2) gru_dx_kernel -- also fp32 MFMA: d_act tile staged in LDS as the A operand, the input
@@ -32,11 +35,23 @@ constexpr int WG_MIN_ROWS = 128;  // a workgroup takes whole sequences, at least
 __host__ __device__ inline long wgrad_slab_floats(int D, int H) { return (long)(D + H) * 3 * H + 3 * H; }
 
 template <int HT, int DT>
-__global__ __launch_bounds__(64 * (HT + DT)) void gru_wgrad_kernel(const HpmnGruWgrad a) {
+__global__ __launch_bounds__(64 * (HT + DT), 2) void gru_wgrad_kernel(const HpmnGruWgrad a) {
     constexpr int H = 32 * HT;
-    constexpr int NJ = 3 * HT;        // 32-column tiles of d_act
-    const int wave = threadIdx.x >> 6;
-    const int lane = threadIdx.x & 63;
+    constexpr int NJ = 3 * HT;            // 32-column tiles of d_act
+    constexpr int NT = 64 * (HT + DT);    // threads
+    constexpr int R = 2 * WU;             // rows per staged tile
+    constexpr int XS = 32 * DT;           // row stride of the x image (zero-filled beyond D)
+    // float4 items of one tile image and per-thread staging registers
+    constexpr int N_DA = R * 3 * H / 4, N_X = R * XS / 4, N_H = R * H / 4;
+    constexpr int P_DA = (N_DA + NT - 1) / NT, P_X = (N_X + NT - 1) / NT, P_H = (N_H + NT - 1) / NT;
+    __shared__ __attribute__((aligned(16))) float l_da[2][R * 3 * H];
+    __shared__ __attribute__((aligned(16))) float l_x[2][R * XS];
+    __shared__ __attribute__((aligned(16))) float l_h[2][R * H];
+    __shared__ __attribute__((aligned(16))) float l_r[2][R * H];
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6;
+    const int lane = tid & 63;
     const int c = lane & 31;          // column within a tile
     const int rp = lane >> 5;         // row parity (MFMA k index)
     const int T = a.T, D = a.D;
@@ -52,64 +67,112 @@ __global__ __launch_bounds__(64 * (HT + DT)) void gru_wgrad_kernel(const HpmnGru
 
     const bool role_x = wave < DT;
     const int tile = role_x ? wave : wave - DT;
-    const int xcol = 32 * tile + c;
-    const bool xcol_ok = xcol < D;
 
     const int b_begin = blockIdx.x * a.seq_per_wg;
     const int b_end = (b_begin + a.seq_per_wg) < a.B ? (b_begin + a.seq_per_wg) : a.B;
-    const int ipt = (T + 2 * WU - 1) / (2 * WU);          // iterations per sequence
+    const int ipt = (T + R - 1) / R;                      // tiles per sequence
     const int niter = (b_end - b_begin) * ipt;
 
-    struct Ops { float A1[WU], A2[WU], Bv[WU][NJ]; };
-    // operands of iteration `it`: rows t0..t0+15 of sequence b, straight into MFMA register layout
-    auto load_ops = [&](int it, Ops &o) {
+    struct Stage { float4 da[P_DA], x[P_X], h[P_H], r[P_H]; };
+    // tile `it` = rows t0..t0+R-1 of sequence b; rows >= T are zero.  All loads are 16-byte, coalesced.
+    auto load_tile = [&](int it, Stage &g) {
         const int b = b_begin + it / ipt;
-        const int t0 = (it % ipt) * 2 * WU;
-        const float *dab = a.d_act + (long)b * T * 3 * H + c;
+        const int t0 = (it % ipt) * R;
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int s = 0; s < WU; ++s) {
-            const int t = t0 + 2 * s + rp;
-            const bool ok = t < T;
+        for (int p = 0; p < P_DA; ++p) {
+            const int i = p * NT + tid;
+            const int row = i / (3 * H / 4), q = i % (3 * H / 4);
+            g.da[p] = z;
+            if (i < N_DA && t0 + row < T)
+                g.da[p] = *reinterpret_cast<const float4 *>(a.d_act + ((long)b * T + t0 + row) * 3 * H + 4 * q);
+        }
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) o.Bv[s][j] = ok ? dab[(long)t * 3 * H + 32 * j] : 0.f;
-            if (role_x) {
-                o.A1[s] = (ok && xcol_ok) ? a.x[((long)b * T + t) * D + xcol] : 0.f;
-                o.A2[s] = 0.f;
-            } else {
-                o.A1[s] = ok ? a.hs[((long)b * (T + 1) + t) * H + 32 * tile + c] : 0.f;
-                o.A2[s] = ok ? a.gates[((long)b * T + t) * 3 * H + 32 * tile + c] : 0.f;   // r
+        for (int p = 0; p < P_X; ++p) {
+            const int i = p * NT + tid;
+            const int row = i / (XS / 4), q = i % (XS / 4);
+            g.x[p] = z;
+            if (i < N_X && t0 + row < T && 4 * q < D)
+                g.x[p] = *reinterpret_cast<const float4 *>(a.x + ((long)b * T + t0 + row) * D + 4 * q);
+        }
+#pragma unroll
+        for (int p = 0; p < P_H; ++p) {
+            const int i = p * NT + tid;
+            const int row = i / (H / 4), q = i % (H / 4);
+            g.h[p] = z;
+            g.r[p] = z;
+            if (i < N_H && t0 + row < T) {
+                g.h[p] = *reinterpret_cast<const float4 *>(a.hs + ((long)b * (T + 1) + t0 + row) * H + 4 * q);
+                g.r[p] = *reinterpret_cast<const float4 *>(a.gates + ((long)b * T + t0 + row) * 3 * H + 4 * q);
+            }
+        }
+    };
+    auto park_tile = [&](int buf, const Stage &g) {
+#pragma unroll
+        for (int p = 0; p < P_DA; ++p) {
+            const int i = p * NT + tid;
+            if (i < N_DA) reinterpret_cast<float4 *>(l_da[buf])[i] = g.da[p];
+        }
+#pragma unroll
+        for (int p = 0; p < P_X; ++p) {
+            const int i = p * NT + tid;
+            if (i < N_X) reinterpret_cast<float4 *>(l_x[buf])[i] = g.x[p];
+        }
+#pragma unroll
+        for (int p = 0; p < P_H; ++p) {
+            const int i = p * NT + tid;
+            if (i < N_H) {
+                reinterpret_cast<float4 *>(l_h[buf])[i] = g.h[p];
+                reinterpret_cast<float4 *>(l_r[buf])[i] = g.r[p];
             }
         }
     };
 
-    Ops cur, nxt;
-    if (niter > 0) load_ops(0, cur);
+    Stage st;
+    if (niter > 0) {
+        load_tile(0, st);
+        park_tile(0, st);
+    }
+    __syncthreads();
     for (int it = 0; it < niter; ++it) {
-        if (it + 1 < niter) load_ops(it + 1, nxt);      // in flight under this iteration's MFMAs
+        const int buf = it & 1;
+        if (it + 1 < niter) load_tile(it + 1, st);       // HBM loads in flight under this tile's MFMAs
+        const float *pda = &l_da[buf][rp * 3 * H + c];
         if (role_x) {
+            const float *px = &l_x[buf][rp * XS + 32 * tile + c];
 #pragma unroll
             for (int s = 0; s < WU; ++s) {
+                const float av = px[2 * s * XS];
+                float bv[NJ];
 #pragma unroll
-                for (int j = 0; j < NJ; ++j)
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.A1[s], cur.Bv[s][j], acc[j], 0, 0, 0);
+                for (int j = 0; j < NJ; ++j) bv[j] = pda[2 * s * 3 * H + 32 * j];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[j], acc[j], 0, 0, 0);
                 if (tile == 0) {
 #pragma unroll
-                    for (int j = 0; j < NJ; ++j) bsum[j] += cur.Bv[s][j];
+                    for (int j = 0; j < NJ; ++j) bsum[j] += bv[j];
                 }
+                if (s & 1) asm volatile("" ::: "memory");   // bound the LDS reads hoisted ahead (VGPR budget)
             }
         } else {
+            const float *ph = &l_h[buf][rp * H + 32 * tile + c];
+            const float *pr = &l_r[buf][rp * H + 32 * tile + c];
 #pragma unroll
             for (int s = 0; s < WU; ++s) {
-                const float rh = cur.A2[s] * cur.A1[s];   // r * h_prev (not stored by the forward)
+                const float hv = ph[2 * s * H];
+                const float rh = pr[2 * s * H] * hv;      // r * h_prev (not stored by the forward)
+                float bv[NJ];
 #pragma unroll
-                for (int j = 0; j < 2 * HT; ++j)
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.A1[s], cur.Bv[s][j], acc[j], 0, 0, 0);
+                for (int j = 0; j < NJ; ++j) bv[j] = pda[2 * s * 3 * H + 32 * j];
 #pragma unroll
-                for (int j = 2 * HT; j < NJ; ++j)
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(rh, cur.Bv[s][j], acc[j], 0, 0, 0);
+                for (int j = 0; j < 2 * HT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(hv, bv[j], acc[j], 0, 0, 0);
+#pragma unroll
+                for (int j = 2 * HT; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(rh, bv[j], acc[j], 0, 0, 0);
+                if (s & 1) asm volatile("" ::: "memory");
             }
         }
-        cur = nxt;
+        if (it + 1 < niter) park_tile(buf ^ 1, st);
+        __syncthreads();
     }
 
     // ---- epilogue: plain coalesced stores of this workgroup's partial slab (summed by
