@@ -64,6 +64,17 @@ class HpmnGruWgrad(C.Structure):
     ]
 
 
+class HpmnReadDesc(C.Structure):
+    _fields_ = [
+        ("B", C.c_int32), ("K", C.c_int32), ("H", C.c_int32), ("D0", C.c_int32), ("hop", C.c_int32),
+        ("off_wq", C.c_int32), ("off_bq", C.c_int32), ("off_map", C.c_int32),
+        ("off_att", (C.c_int32 * 6) * 4),
+        ("off_gamma", C.c_int32), ("off_beta", C.c_int32),
+        ("off_fc", C.c_int32 * 6),
+        ("n_params", C.c_int32),
+    ]
+
+
 class HpmnScanDesc(C.Structure):
     _fields_ = [
         ("B", C.c_int32), ("T", C.c_int32), ("F", C.c_int32), ("E", C.c_int32),
@@ -92,6 +103,10 @@ SIGNATURES = {
                                 C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                 C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hpmn_read_workspace_bytes": (C.c_size_t, [C.POINTER(HpmnReadDesc)]),
+    "hpmn_read_fwd": (C.c_int, [C.POINTER(HpmnReadDesc)] + [C.c_void_p] * 8),
+    "hpmn_read_fwd_bwd": (C.c_int, [C.POINTER(HpmnReadDesc)] + [C.c_void_p] * 6 +
+                          [C.c_float, C.c_float, C.c_float] + [C.c_void_p] * 7),
     "hpmn_embed_grad_scatter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                           C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_void_p]),
     "hpmn_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,

@@ -14,6 +14,13 @@ bool input_proj_supported(int H, int D);
 int input_proj_dispatch(const HpmnInputProj &a, hipStream_t st);
 int gru_wgrad_dispatch(const HpmnGruWgrad &a, hipStream_t st);
 size_t gru_wgrad_workspace_bytes(int B, int T, int D, int H);
+size_t read_workspace_bytes(const HpmnReadDesc &d);
+int read_fwd_launch(const HpmnReadDesc &d, const float *P, const float *memory, const float *last, float *pred,
+                    float *logit, float *att_w0, float *mem_loss, hipStream_t st);
+int read_fwd_bwd_launch(const HpmnReadDesc &d, const float *P, const float *memory, const float *last,
+                        const int32_t *label, const float *mask1, const float *mask2, float keep_prob,
+                        float inv_global_batch, float memory_reg, float *pred, float *loss_out, float *d_memory,
+                        float *d_last, float *d_params, float *workspace, hipStream_t st);
 int embed_gather_launch(const int32_t *ids, int64_t ids_stride, const float *emb, float *out, int64_t N,
                         int32_t F, int32_t E, int32_t mask_id0, hipStream_t st);
 int embed_grad_scatter_launch(const int32_t *ids, const float *d_x, float *d_emb, int32_t B, int32_t T,
@@ -198,6 +205,36 @@ int hpmn_scan_fwd(const HpmnScanDesc *d, const int32_t *ids, const float *emb, c
         }
     }
     return HPMN_OK;
+}
+
+size_t hpmn_read_workspace_bytes(const HpmnReadDesc *d) {
+    if (!d || d->B < 1 || d->n_params < 1) return 0;
+    return read_workspace_bytes(*d);
+}
+
+int hpmn_read_fwd(const HpmnReadDesc *d, const float *params, const float *memory, const float *last, float *pred,
+                  float *logit, float *att_w0, float *mem_loss, void *stream) {
+    if (!d) return HPMN_EINVAL;
+    if (d->B < 0) return HPMN_EINVAL;
+    if (d->B == 0) return HPMN_OK;
+    if (!params || !memory || !last || !pred || !mem_loss) return HPMN_EINVAL;
+    return read_fwd_launch(*d, params, memory, last, pred, logit, att_w0, mem_loss, (hipStream_t)stream);
+}
+
+int hpmn_read_fwd_bwd(const HpmnReadDesc *d, const float *params, const float *memory, const float *last,
+                      const int32_t *label, const float *mask1, const float *mask2, float keep_prob,
+                      float inv_global_batch, float memory_reg, float *pred, float *loss_out, float *d_memory,
+                      float *d_last, float *d_params, float *workspace, void *stream) {
+    if (!d) return HPMN_EINVAL;
+    if (d->B < 0 || !(keep_prob > 0.f)) return HPMN_EINVAL;
+    if (d->B == 0) return HPMN_OK;
+    if (!params || !memory || !last || !label || !pred || !loss_out || !d_memory || !d_last || !d_params ||
+        !workspace)
+        return HPMN_EINVAL;
+    if ((mask1 == nullptr) != (mask2 == nullptr)) return HPMN_EINVAL;
+    return read_fwd_bwd_launch(*d, params, memory, last, label, mask1, mask2, keep_prob, inv_global_batch,
+                               memory_reg, pred, loss_out, d_memory, d_last, d_params, workspace,
+                               (hipStream_t)stream);
 }
 
 int hpmn_embed_grad_scatter(const int32_t *ids, const float *d_x, float *d_emb, int32_t B, int32_t T,

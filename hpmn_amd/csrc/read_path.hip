@@ -1,0 +1,532 @@
+// Memory read path for gfx950: covariance regulariser + multi-hop attention over the K memory
+// slots + prediction head + log-loss, forward and (fused) forward+backward.
+//
+// Reference: Hpmn_Basic.get_covreg / query_memory / attention / build_fc_net,
+// code/hpmn.py:161-170, 172-182, 133-146, 184-207.
+//
+// The work is tiny (K <= 12 slots, ~0.55 MFLOP-pairs per sample) but the reference graph -- and a
+// library implementation -- spends it in ~150 launches per step.  Here one workgroup owns a tile of
+// RS samples and keeps every activation of the tile in LDS:
+//   * inference: one pass, writes prediction / first-hop attention weights / covariance loss;
+//   * training : the same forward (activations stay in LDS), then the backward in the same launch:
+//     d_memory, d_last and the tile's contribution to every read-path weight gradient, written as a
+//     slab that mirrors the contiguous read-path range of the flat parameter buffer and summed over
+//     tiles by read_reduce_kernel (single writer per element, deterministic).
+// Dense layers are thread-per-output VALU loops with activations broadcast from LDS: the kernel is
+// latency/launch bound, not FLOP bound (all tiles run concurrently, one per CU).
+#include "common.h"
+
+namespace hpmn {
+
+constexpr int RS = 4;          // samples per workgroup
+constexpr int RT = 256;        // threads
+constexpr int A1 = 80, A2 = 40;      // attention MLP widths (code/hpmn.py:137-138)
+constexpr int F1 = 200, F2 = 80;     // head widths (code/hpmn.py:191,193)
+constexpr int MAXK = HPMN_MAX_LAYERS;
+constexpr int MAXHOP = 4;
+
+__device__ __forceinline__ float elu(float x) { return x > 0.f ? x : __expf(x) - 1.f; }
+
+// Y[r][n] = act(b[n] + sum_i X[r][i] W[i][n]) for r < R, n < N.  X, Y in LDS; W [I,N] row-major in
+// global (coalesced over n).  ACT: 0 none, 1 relu, 2 elu.
+template <int ACT>
+__device__ __forceinline__ void dense_fwd(const float *X, int ldx, int R, int I, const float *W, const float *b,
+                                          int N, float *Y, int ldy) {
+    for (int o = threadIdx.x; o < R * N; o += RT) {
+        const int r = o / N, n = o - r * N;
+        float acc = b[n];
+        const float *x = X + r * ldx;
+        for (int i = 0; i < I; ++i) acc = fmaf(x[i], W[(long)i * N + n], acc);
+        if (ACT == 1) acc = fmaxf(acc, 0.f);
+        if (ACT == 2) acc = elu(acc);
+        Y[r * ldy + n] = acc;
+    }
+}
+
+// dX[r][i] (+)= sum_n dY[r][n] W[i][n]
+template <bool ACCUM>
+__device__ __forceinline__ void dense_bwd_x(const float *dY, int ldy, int R, int N, const float *W, int I, float *dX,
+                                            int ldx) {
+    for (int o = threadIdx.x; o < R * I; o += RT) {
+        const int r = o / I, i = o - r * I;
+        const float *w = W + (long)i * N;
+        const float *d = dY + r * ldy;
+        float acc = 0.f;
+        for (int n = 0; n < N; ++n) acc = fmaf(d[n], w[n], acc);
+        if (ACCUM) dX[r * ldx + i] += acc;
+        else dX[r * ldx + i] = acc;
+    }
+}
+
+// gW[i][n] (+)= sum_r X[r][i] dY[r][n];  gb[n] (+)= sum_r dY[r][n]   (slab in global, owned by this workgroup)
+template <bool ACCUM>
+__device__ __forceinline__ void dense_bwd_w(const float *X, int ldx, const float *dY, int ldy, int R, int I, int N,
+                                            float *gW, float *gb) {
+    for (int o = threadIdx.x; o < I * N; o += RT) {
+        const int i = o / N, n = o - i * N;
+        float acc = 0.f;
+        for (int r = 0; r < R; ++r) acc = fmaf(X[r * ldx + i], dY[r * ldy + n], acc);
+        if (ACCUM) gW[o] += acc;
+        else gW[o] = acc;
+    }
+    for (int n = threadIdx.x; n < N; n += RT) {
+        float acc = 0.f;
+        for (int r = 0; r < R; ++r) acc += dY[r * ldy + n];
+        if (ACCUM) gb[n] += acc;
+        else gb[n] = acc;
+    }
+}
+
+struct ReadSmem {
+    // sizes depend on (K, H, D0, hop); carved from dynamic LDS
+    float *mem;      // [RS*K][H]        memory slots of the tile
+    float *dmem;     // [RS*K][H]        gradient wrt memory (training)
+    float *last;     // [RS][D0]
+    float *q;        // [hop+1][RS][H]   query before each hop and after the last
+    float *inp;      // [RS*K][4H]       attention MLP input of the current hop
+    float *x1;       // [hop][RS*K][A1]
+    float *x2;       // [hop][RS*K][A2]
+    float *sc;       // [hop][RS*K]      softmax scores
+    float *rep;      // [RS][H+D0]       head input (bn output after the affine map)
+    float *h1;       // [RS][F1]
+    float *h2;       // [RS][F2]
+    float *t1;       // scratch [RS*K][A1] (d of x1) / [RS][F1]
+    float *t2;       // scratch [RS*K][A2] / [RS][F2]
+    float *t3;       // scratch [RS*K] / [RS]
+    float *dq;       // [RS][H]
+    float *drep;     // [RS][H+D0]
+};
+
+__host__ __device__ inline size_t read_smem_floats(int K, int H, int D0, int hop, bool train) {
+    const size_t RK = (size_t)RS * K;
+    size_t n = RK * H + (size_t)RS * D0 + (size_t)(hop + 1) * RS * H + RK * 4 * H + (size_t)hop * RK * (A1 + A2 + 1) +
+               (size_t)RS * (H + D0) + (size_t)RS * (F1 + F2);
+    if (train) n += RK * H + RK * (A1 + A2 + 1) + (size_t)RS * H + (size_t)RS * (H + D0) + 64;
+    else n += 64;
+    return n + 64;
+}
+
+__device__ inline void carve(ReadSmem &s, float *base, int K, int H, int D0, int hop, bool train) {
+    const int RK = RS * K;
+    float *p = base;
+    auto take = [&](size_t n) { float *r = p; p += (n + 3) / 4 * 4; return r; };
+    s.mem = take((size_t)RK * H);
+    s.last = take((size_t)RS * D0);
+    s.q = take((size_t)(hop + 1) * RS * H);
+    s.inp = take((size_t)RK * 4 * H);
+    s.x1 = take((size_t)hop * RK * A1);
+    s.x2 = take((size_t)hop * RK * A2);
+    s.sc = take((size_t)hop * RK);
+    s.rep = take((size_t)RS * (H + D0));
+    s.h1 = take((size_t)RS * F1);
+    s.h2 = take((size_t)RS * F2);
+    s.t3 = take(64);
+    if (train) {
+        s.dmem = take((size_t)RK * H);
+        s.t1 = take((size_t)RK * A1 > (size_t)RS * F1 ? (size_t)RK * A1 : (size_t)RS * F1);
+        s.t2 = take((size_t)RK * A2 > (size_t)RS * F2 ? (size_t)RK * A2 : (size_t)RS * F2);
+        s.dq = take((size_t)RS * H);
+        s.drep = take((size_t)RS * (H + D0));
+    } else {
+        s.dmem = s.t1 = s.t2 = s.dq = s.drep = nullptr;
+    }
+}
+
+// ---- forward of one tile; leaves every activation in LDS --------------------------------------
+// returns (in s.t3[0..R)) the logits; covariance loss of the tile accumulated into *cov_out.
+__device__ void read_forward_tile(const HpmnReadDesc &d, const float *P, const ReadSmem &s, int R,
+                                  const float *mask1, const float *mask2, float keep_prob, long b0, float *cov_sum) {
+    const int K = d.K, H = d.H, D0 = d.D0, RK = R * K;
+    const int tid = threadIdx.x;
+    // q0 = last Wq + bq  (code/hpmn.py:173)
+    dense_fwd<0>(s.last, D0, R, D0, P + d.off_wq, P + d.off_bq, H, s.q, H);
+    __syncthreads();
+    for (int hop = 0; hop < d.hop; ++hop) {
+        const float *q = s.q + (size_t)hop * RS * H;
+        // inp = [q, m, q-m, q*m]  (code/hpmn.py:135-136)
+        for (int o = tid; o < RK * H; o += RT) {
+            const int row = o / H, i = o - row * H;
+            const float qv = q[(row / K) * H + i], mv = s.mem[row * H + i];
+            float *x = s.inp + (size_t)row * 4 * H;
+            x[i] = qv; x[H + i] = mv; x[2 * H + i] = qv - mv; x[3 * H + i] = qv * mv;
+        }
+        __syncthreads();
+        float *x1 = s.x1 + (size_t)hop * RS * K * A1, *x2 = s.x2 + (size_t)hop * RS * K * A2;
+        float *sc = s.sc + (size_t)hop * RS * K;
+        const int *oa = d.off_att[hop];
+        dense_fwd<1>(s.inp, 4 * H, RK, 4 * H, P + oa[0], P + oa[1], A1, x1, A1);
+        __syncthreads();
+        dense_fwd<1>(x1, A1, RK, A1, P + oa[2], P + oa[3], A2, x2, A2);
+        __syncthreads();
+        dense_fwd<0>(x2, A2, RK, A2, P + oa[4], P + oa[5], 1, sc, 1);
+        __syncthreads();
+        // softmax over the K slots of each sample (code/hpmn.py:141)
+        if (tid < R) {
+            float mx = -3.4e38f;
+            for (int k = 0; k < K; ++k) mx = fmaxf(mx, sc[tid * K + k]);
+            float den = 0.f;
+            for (int k = 0; k < K; ++k) { const float e = __expf(sc[tid * K + k] - mx); sc[tid * K + k] = e; den += e; }
+            const float inv = 1.f / den;
+            for (int k = 0; k < K; ++k) sc[tid * K + k] *= inv;
+        }
+        __syncthreads();
+        // q' = q Hmap + sum_k score_k m_k   (code/hpmn.py:143-144, 179)
+        float *qn = s.q + (size_t)(hop + 1) * RS * H;
+        for (int o = tid; o < R * H; o += RT) {
+            const int r = o / H, n = o - r * H;
+            float acc = 0.f;
+            for (int i = 0; i < H; ++i) acc = fmaf(q[r * H + i], P[d.off_map + (long)i * H + n], acc);
+            for (int k = 0; k < K; ++k) acc = fmaf(sc[r * K + k], s.mem[(r * K + k) * H + n], acc);
+            qn[o] = acc;
+        }
+        __syncthreads();
+    }
+    // covariance regulariser (code/hpmn.py:161-170): per-sample Frobenius norm of the off-diagonal cov
+    if (tid < R) {
+        const float *m = s.mem + (size_t)tid * K * H;
+        float mean[MAXK];
+        for (int k = 0; k < K; ++k) {
+            float a = 0.f;
+            for (int i = 0; i < H; ++i) a += m[k * H + i];
+            mean[k] = a / H;
+        }
+        float ss = 0.f;
+        for (int k = 0; k < K; ++k)
+            for (int j = 0; j < K; ++j) {
+                if (j == k) continue;
+                float c = 0.f;
+                for (int i = 0; i < H; ++i) c = fmaf(m[k * H + i] - mean[k], m[j * H + i] - mean[j], c);
+                c /= H;
+                ss += c * c;
+            }
+        cov_sum[tid] = sqrtf(ss);
+    }
+    // head (code/hpmn.py:190-199): repre = [q, last]; bn (inference affine); fc1 elu; dropout; fc2 elu; dropout; fc3
+    const float *qf = s.q + (size_t)d.hop * RS * H;
+    const float bn_scale = rsqrtf(1.f + 1e-3f);
+    for (int o = tid; o < R * (H + D0); o += RT) {
+        const int r = o / (H + D0), i = o - r * (H + D0);
+        const float v = i < H ? qf[r * H + i] : s.last[r * D0 + (i - H)];
+        s.rep[o] = v * (P[d.off_gamma + i] * bn_scale) + P[d.off_beta + i];
+    }
+    __syncthreads();
+    dense_fwd<2>(s.rep, H + D0, R, H + D0, P + d.off_fc[0], P + d.off_fc[1], F1, s.h1, F1);
+    __syncthreads();
+    if (mask1 != nullptr) {
+        for (int o = tid; o < R * F1; o += RT) s.h1[o] *= mask1[(b0 + o / F1) * F1 + o % F1] / keep_prob;
+        __syncthreads();
+    }
+    dense_fwd<2>(s.h1, F1, R, F1, P + d.off_fc[2], P + d.off_fc[3], F2, s.h2, F2);
+    __syncthreads();
+    if (mask2 != nullptr) {
+        for (int o = tid; o < R * F2; o += RT) s.h2[o] *= mask2[(b0 + o / F2) * F2 + o % F2] / keep_prob;
+        __syncthreads();
+    }
+    dense_fwd<0>(s.h2, F2, R, F2, P + d.off_fc[4], P + d.off_fc[5], 1, s.t3, 1);
+    __syncthreads();
+}
+
+__device__ inline void load_tile_inputs(const HpmnReadDesc &d, const ReadSmem &s, const float *memory, const float *last,
+                                        long b0, int R) {
+    const int K = d.K, H = d.H, D0 = d.D0;
+    for (int o = threadIdx.x; o < R * K * H; o += RT) s.mem[o] = memory[b0 * K * H + o];
+    for (int o = threadIdx.x; o < R * D0; o += RT) s.last[o] = last[b0 * D0 + o];
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(RT) void read_fwd_kernel(const HpmnReadDesc d, const float *__restrict__ P,
+                                                      const float *__restrict__ memory,
+                                                      const float *__restrict__ last, float *pred, float *logit,
+                                                      float *att_w0, float *mem_loss) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    ReadSmem s;
+    carve(s, smem, d.K, d.H, d.D0, d.hop, false);
+    const long b0 = (long)blockIdx.x * RS;
+    const int R = (d.B - b0) < RS ? (int)(d.B - b0) : RS;
+    load_tile_inputs(d, s, memory, last, b0, R);
+    float *cov = s.t3 + 32;
+    read_forward_tile(d, P, s, R, nullptr, nullptr, 1.f, b0, cov);
+    const int tid = threadIdx.x;
+    if (tid < R) {
+        const float lg = s.t3[tid];
+        if (logit) logit[b0 + tid] = lg;
+        pred[b0 + tid] = 1.f / (1.f + __expf(-lg));
+        atomicAdd(mem_loss, cov[tid]);
+    }
+    if (att_w0) for (int o = tid; o < R * d.K; o += RT) att_w0[b0 * d.K + o] = s.sc[o];   // first hop (code/hpmn.py:182)
+}
+
+// Training: forward + loss + backward of the tile in one launch.
+//   loss = sum_b ll_b * inv_global_batch + memory_reg * sum_b cov_b        (code/hpmn.py:202-207)
+// outputs: pred [B]; loss_out[0] += sum ll_b, loss_out[1] += sum cov_b (atomics); d_memory [B,K,H];
+// d_last [B,D0]; slab[blockIdx] = this tile's read-path weight gradients (layout == parameter range).
+__global__ __launch_bounds__(RT) void read_fwd_bwd_kernel(const HpmnReadDesc d, const float *__restrict__ P,
+                                                          const float *__restrict__ memory,
+                                                          const float *__restrict__ last,
+                                                          const int32_t *__restrict__ label,
+                                                          const float *__restrict__ mask1,
+                                                          const float *__restrict__ mask2, float keep_prob,
+                                                          float inv_global_batch, float memory_reg, float *pred,
+                                                          float *loss_out, float *d_memory, float *d_last,
+                                                          float *slabs) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    ReadSmem s;
+    const int K = d.K, H = d.H, D0 = d.D0;
+    carve(s, smem, K, H, D0, d.hop, true);
+    const int tid = threadIdx.x;
+    const long b0 = (long)blockIdx.x * RS;
+    const int R = (d.B - b0) < RS ? (int)(d.B - b0) : RS;
+    const int RK = R * K;
+    float *G = slabs + (long)blockIdx.x * d.n_params;      // this tile's gradient slab
+    load_tile_inputs(d, s, memory, last, b0, R);
+    float *cov = s.t3 + 32;
+    read_forward_tile(d, P, s, R, mask1, mask2, keep_prob, b0, cov);
+
+    // ---- loss and d logit -------------------------------------------------------------------
+    float *dlg = s.t3 + 48;       // [R]
+    if (tid < R) {
+        const float lg = s.t3[tid];
+        const float p = 1.f / (1.f + __expf(-lg));
+        const float y = (float)label[b0 + tid];
+        const float eps = 1e-7f;
+        pred[b0 + tid] = p;
+        atomicAdd(loss_out, -y * __logf(p + eps) - (1.f - y) * __logf(1.f - p + eps));
+        atomicAdd(loss_out + 1, cov[tid]);
+        // d ll / d p, then through the sigmoid
+        const float dp = (-y / (p + eps) + (1.f - y) / (1.f - p + eps)) * inv_global_batch;
+        dlg[tid] = dp * p * (1.f - p);
+    }
+    __syncthreads();
+
+    // ---- head backward ------------------------------------------------------------------------
+    // fc3: logit = h2 W3 + b3
+    dense_bwd_w<false>(s.h2, F2, dlg, 1, R, F2, 1, G + d.off_fc[4], G + d.off_fc[5]);
+    dense_bwd_x<false>(dlg, 1, R, 1, P + d.off_fc[4], F2, s.t2, F2);        // d h2 (post-dropout)
+    __syncthreads();
+    // through dropout2 and elu2: h2 = elu(a2) * mask/keep.  elu'(a) = a>0 ? 1 : elu(a)+1; recover from h2.
+    for (int o = tid; o < R * F2; o += RT) {
+        float mk = 1.f;
+        if (mask2 != nullptr) mk = mask2[(b0 + o / F2) * F2 + o % F2] / keep_prob;
+        const float hv = mk != 0.f ? s.h2[o] / mk : 0.f;                    // elu(a2); irrelevant where mask==0
+        s.t2[o] = s.t2[o] * mk * (hv > 0.f ? 1.f : hv + 1.f);
+    }
+    __syncthreads();
+    dense_bwd_w<false>(s.h1, F1, s.t2, F2, R, F1, F2, G + d.off_fc[2], G + d.off_fc[3]);
+    dense_bwd_x<false>(s.t2, F2, R, F2, P + d.off_fc[2], F1, s.t1, F1);     // d h1 (post-dropout)
+    __syncthreads();
+    for (int o = tid; o < R * F1; o += RT) {
+        float mk = 1.f;
+        if (mask1 != nullptr) mk = mask1[(b0 + o / F1) * F1 + o % F1] / keep_prob;
+        const float hv = mk != 0.f ? s.h1[o] / mk : 0.f;
+        s.t1[o] = s.t1[o] * mk * (hv > 0.f ? 1.f : hv + 1.f);
+    }
+    __syncthreads();
+    dense_bwd_w<false>(s.rep, H + D0, s.t1, F1, R, H + D0, F1, G + d.off_fc[0], G + d.off_fc[1]);
+    dense_bwd_x<false>(s.t1, F1, R, F1, P + d.off_fc[0], H + D0, s.drep, H + D0);   // d bn-output
+    __syncthreads();
+    // bn affine: rep = v*gamma*scale + beta  ->  d gamma, d beta, d v; v = [q_final, last]
+    const float bn_scale = rsqrtf(1.f + 1e-3f);
+    const float *qf = s.q + (size_t)d.hop * RS * H;
+    for (int i = tid; i < H + D0; i += RT) {
+        float gg = 0.f, gb = 0.f;
+        for (int r = 0; r < R; ++r) {
+            const float v = i < H ? qf[r * H + i] : s.last[r * D0 + (i - H)];
+            const float dy = s.drep[r * (H + D0) + i];
+            gg = fmaf(dy, v * bn_scale, gg);
+            gb += dy;
+        }
+        G[d.off_gamma + i] = gg;
+        G[d.off_beta + i] = gb;
+    }
+    __syncthreads();          // the loop below rescales s.drep in place
+    // d q_final -> s.dq ; d last (head part) -> kept in s.drep[:, H:] scaled
+    for (int o = tid; o < R * (H + D0); o += RT) {
+        const int r = o / (H + D0), i = o - r * (H + D0);
+        const float dv = s.drep[o] * P[d.off_gamma + i] * bn_scale;
+        if (i < H) s.dq[r * H + i] = dv;
+        else s.drep[o] = dv;
+    }
+    // covariance regulariser backward into dmem (code/hpmn.py:161-170): loss_b = ||C_off||_F,
+    // C = cc^T / H with c = m - mean_H(m):  d m = (2/(H*norm)) * (C_off c) projected off the mean
+    for (int o = tid; o < RK * H; o += RT) s.dmem[o] = 0.f;
+    __syncthreads();
+    if (tid < R && memory_reg != 0.f) {
+        const float *m = s.mem + (size_t)tid * K * H;
+        float *dm = s.dmem + (size_t)tid * K * H;
+        const float nrm = cov[tid];
+        if (nrm > 0.f) {
+            float mean[MAXK], C[MAXK][MAXK];
+            for (int k = 0; k < K; ++k) {
+                float a = 0.f;
+                for (int i = 0; i < H; ++i) a += m[k * H + i];
+                mean[k] = a / H;
+            }
+            for (int k = 0; k < K; ++k)
+                for (int j = 0; j < K; ++j) {
+                    float c = 0.f;
+                    if (j != k) {
+                        for (int i = 0; i < H; ++i) c = fmaf(m[k * H + i] - mean[k], m[j * H + i] - mean[j], c);
+                        c /= H;
+                    }
+                    C[k][j] = c;
+                }
+            // dL/dC_kj = C_kj / nrm (off-diagonal); dL/dc_k = (1/H) sum_j (dC_kj + dC_jk) c_j = (2/H) sum_j dC_kj c_j
+            // the mean subtraction projects: dm_k = dc_k - mean_i(dc_k); sum_i c_j[i] = 0 so the projection is a no-op
+            const float sc = memory_reg * 2.f / (H * nrm);
+            for (int k = 0; k < K; ++k)
+                for (int i = 0; i < H; ++i) {
+                    float a = 0.f;
+                    for (int j = 0; j < K; ++j) a = fmaf(C[k][j], m[j * H + i] - mean[j], a);
+                    dm[k * H + i] = sc * a;
+                }
+        }
+    }
+    __syncthreads();
+
+    // ---- hops backward (reverse order) ---------------------------------------------------------
+    // zero the shared-across-hops gradient of Hmap in the slab, accumulate per hop
+    for (int o = tid; o < H * H; o += RT) G[d.off_map + o] = 0.f;
+    __syncthreads();
+    for (int hop = d.hop - 1; hop >= 0; --hop) {
+        const float *q = s.q + (size_t)hop * RS * H;           // query entering this hop
+        float *x1 = s.x1 + (size_t)hop * RS * K * A1, *x2 = s.x2 + (size_t)hop * RS * K * A2;
+        float *sc = s.sc + (size_t)hop * RS * K;
+        const int *oa = d.off_att[hop];
+        // q' = q Hmap + sum_k sc_k m_k : d Hmap += q^T dq';  d sc_k = <dq', m_k>;  d m_k += sc_k dq'
+        for (int o = tid; o < H * H; o += RT) {
+            const int i = o / H, n = o - i * H;
+            float acc = 0.f;
+            for (int r = 0; r < R; ++r) acc = fmaf(q[r * H + i], s.dq[r * H + n], acc);
+            G[d.off_map + o] += acc;
+        }
+        float *dsc = s.t3;          // [RK]
+        for (int o = tid; o < RK; o += RT) {
+            const int r = o / K;
+            float acc = 0.f;
+            for (int i = 0; i < H; ++i) acc = fmaf(s.dq[r * H + i], s.mem[o * H + i], acc);
+            dsc[o] = acc;
+        }
+        for (int o = tid; o < RK * H; o += RT) {
+            const int row = o / H, i = o - row * H;
+            s.dmem[o] = fmaf(sc[row], s.dq[(row / K) * H + i], s.dmem[o]);
+        }
+        __syncthreads();
+        // softmax backward: d s_k = sc_k (d sc_k - sum_j sc_j d sc_j)
+        if (tid < R) {
+            float dot = 0.f;
+            for (int k = 0; k < K; ++k) dot = fmaf(sc[tid * K + k], dsc[tid * K + k], dot);
+            for (int k = 0; k < K; ++k) dsc[tid * K + k] = sc[tid * K + k] * (dsc[tid * K + k] - dot);
+        }
+        __syncthreads();
+        // rebuild inp of this hop (the forward overwrote it hop by hop)
+        for (int o = tid; o < RK * H; o += RT) {
+            const int row = o / H, i = o - row * H;
+            const float qv = q[(row / K) * H + i], mv = s.mem[row * H + i];
+            float *x = s.inp + (size_t)row * 4 * H;
+            x[i] = qv; x[H + i] = mv; x[2 * H + i] = qv - mv; x[3 * H + i] = qv * mv;
+        }
+        // fc3 (A2 -> 1, no activation)
+        dense_bwd_w<false>(x2, A2, dsc, 1, RK, A2, 1, G + oa[4], G + oa[5]);
+        dense_bwd_x<false>(dsc, 1, RK, 1, P + oa[4], A2, s.t2, A2);
+        __syncthreads();
+        for (int o = tid; o < RK * A2; o += RT) s.t2[o] = x2[o] > 0.f ? s.t2[o] : 0.f;      // relu
+        __syncthreads();
+        dense_bwd_w<false>(x1, A1, s.t2, A2, RK, A1, A2, G + oa[2], G + oa[3]);
+        dense_bwd_x<false>(s.t2, A2, RK, A2, P + oa[2], A1, s.t1, A1);
+        __syncthreads();
+        for (int o = tid; o < RK * A1; o += RT) s.t1[o] = x1[o] > 0.f ? s.t1[o] : 0.f;      // relu
+        __syncthreads();
+        dense_bwd_w<false>(s.inp, 4 * H, s.t1, A1, RK, 4 * H, A1, G + oa[0], G + oa[1]);
+        // d inp [RK, 4H] -> reuse s.inp AFTER the weight gradient has consumed it
+        __syncthreads();
+        dense_bwd_x<false>(s.t1, A1, RK, A1, P + oa[0], 4 * H, s.inp, 4 * H);
+        __syncthreads();
+        // inp = [q, m, q-m, q*m]:  dq_row = d0 + d2 + d3*m ; dm += d1 - d2 + d3*q
+        // new dq (gradient wrt the query entering the hop) = dq' Hmap^T + sum_k dq_row
+        float *dqn = s.drep;        // [R][H] scratch: only columns [0,H) of each row are used here ...
+        for (int o = tid; o < R * H; o += RT) {
+            const int r = o / H, i = o - r * H;
+            float acc = 0.f;
+            for (int n = 0; n < H; ++n) acc = fmaf(s.dq[r * H + n], P[d.off_map + (long)i * H + n], acc);
+            for (int k = 0; k < K; ++k) {
+                const float *di = s.inp + (size_t)(r * K + k) * 4 * H;
+                acc += di[i] + di[2 * H + i] + di[3 * H + i] * s.mem[(r * K + k) * H + i];
+            }
+            dqn[r * (H + D0) + i] = acc;     // ... with the head's row stride so d_last (cols >= H) is untouched
+        }
+        for (int o = tid; o < RK * H; o += RT) {
+            const int row = o / H, i = o - row * H;
+            const float *di = s.inp + (size_t)row * 4 * H;
+            s.dmem[o] += di[H + i] - di[2 * H + i] + di[3 * H + i] * q[(row / K) * H + i];
+        }
+        __syncthreads();
+        for (int o = tid; o < R * H; o += RT) s.dq[o] = dqn[(o / H) * (H + D0) + (o % H)];
+        __syncthreads();
+    }
+    // q0 = last Wq + bq
+    dense_bwd_w<false>(s.last, D0, s.dq, H, R, D0, H, G + d.off_wq, G + d.off_bq);
+    for (int o = tid; o < R * D0; o += RT) {
+        const int r = o / D0, i = o - r * D0;
+        float acc = s.drep[r * (H + D0) + H + i];                          // head part
+        for (int n = 0; n < H; ++n) acc = fmaf(s.dq[r * H + n], P[d.off_wq + (long)i * H + n], acc);
+        d_last[b0 * D0 + o] = acc;
+    }
+    for (int o = tid; o < RK * H; o += RT) d_memory[b0 * K * H + o] = s.dmem[o];
+}
+
+// grad[e] += sum over tiles of slabs[w][e]
+__global__ __launch_bounds__(256) void read_reduce_kernel(const float *__restrict__ slabs, int ntile, int n, float *grad) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    float s0 = 0.f, s1 = 0.f;
+    int w = 0;
+    for (; w + 1 < ntile; w += 2) {
+        s0 += slabs[(long)w * n + e];
+        s1 += slabs[(long)(w + 1) * n + e];
+    }
+    if (w < ntile) s0 += slabs[(long)w * n + e];
+    grad[e] += s0 + s1;
+}
+
+static bool read_desc_ok(const HpmnReadDesc &d) {
+    return d.B >= 0 && d.K >= 1 && d.K <= MAXK && d.H >= 1 && d.D0 >= 1 && d.hop >= 1 && d.hop <= MAXHOP &&
+           d.n_params > 0 && RS * d.K <= 48;
+}
+
+size_t read_workspace_bytes(const HpmnReadDesc &d) {
+    const long ntile = (d.B + RS - 1) / RS;
+    return (size_t)ntile * (size_t)d.n_params * sizeof(float);
+}
+
+int read_fwd_launch(const HpmnReadDesc &d, const float *P, const float *memory, const float *last, float *pred,
+                    float *logit, float *att_w0, float *mem_loss, hipStream_t st) {
+    if (!read_desc_ok(d)) return HPMN_EUNSUPPORTED;
+    const size_t lds = read_smem_floats(d.K, d.H, d.D0, d.hop, false) * sizeof(float);
+    if (lds > 160 * 1024) return HPMN_EUNSUPPORTED;
+    hipError_t e = hipFuncSetAttribute((const void *)read_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { set_last_hip_error((int)e); return HPMN_EHIP; }
+    const unsigned grid = (unsigned)((d.B + RS - 1) / RS);
+    hipLaunchKernelGGL(read_fwd_kernel, dim3(grid), dim3(RT), lds, st, d, P, memory, last, pred, logit, att_w0, mem_loss);
+    return check_launch();
+}
+
+int read_fwd_bwd_launch(const HpmnReadDesc &d, const float *P, const float *memory, const float *last,
+                        const int32_t *label, const float *mask1, const float *mask2, float keep_prob,
+                        float inv_global_batch, float memory_reg, float *pred, float *loss_out, float *d_memory,
+                        float *d_last, float *d_params, float *workspace, hipStream_t st) {
+    if (!read_desc_ok(d)) return HPMN_EUNSUPPORTED;
+    const size_t lds = read_smem_floats(d.K, d.H, d.D0, d.hop, true) * sizeof(float);
+    if (lds > 160 * 1024) return HPMN_EUNSUPPORTED;
+    hipError_t e = hipFuncSetAttribute((const void *)read_fwd_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { set_last_hip_error((int)e); return HPMN_EHIP; }
+    const unsigned grid = (unsigned)((d.B + RS - 1) / RS);
+    hipLaunchKernelGGL(read_fwd_bwd_kernel, dim3(grid), dim3(RT), lds, st, d, P, memory, last, label, mask1, mask2,
+                       keep_prob, inv_global_batch, memory_reg, pred, loss_out, d_memory, d_last, workspace);
+    int rc = check_launch();
+    if (rc != HPMN_OK) return rc;
+    hipLaunchKernelGGL(read_reduce_kernel, dim3((unsigned)((d.n_params + 255) / 256)), dim3(256), 0, st, workspace,
+                       (int)grid, d.n_params, d_params);
+    return check_launch();
+}
+
+}  // namespace hpmn

@@ -5,8 +5,8 @@ Same classes (``Hpmn_Basic`` / ``Hpmn_Industry`` / ``Hpmn``), constructor argume
 CLI (``python hpmn.py <amazon|taobao|xlong>``) as /root/reference/code/hpmn.py; everything
 below ``sess.run`` is replaced: the embedding gather, the periodic GRU memory update (forward
 and BPTT), the embedding-gradient scatter and the TF-form Adam run in ``libhpmn_hip.so``
-(hand-written HIP for gfx950), PyTorch-ROCm supplies device memory, streams, autograd glue
-for the small read path, and RCCL (``torch.distributed`` backend ``nccl``) for data parallel.
+(hand-written HIP for gfx950), as does the memory read path (attention hops, head, loss, and
+their backward); PyTorch-ROCm supplies device memory, streams, the dropout RNG and RCCL (``torch.distributed`` backend ``nccl``) for data parallel.
 
 There is no CPU fallback: constructing a model without a GPU + the built library raises.
 """
@@ -143,6 +143,7 @@ class Hpmn_Basic(object):
             offs[name] = n
             n += (int(np.prod(shape)) + 3) // 4 * 4      # keep every view 16-byte aligned
         self._n_flat = n
+        self._offs = offs
         dev = self.device
         self.flat_param = torch.zeros(n, device=dev, dtype=torch.float32)
         self.flat_grad = torch.zeros(n, device=dev, dtype=torch.float32)
@@ -162,13 +163,13 @@ class Hpmn_Basic(object):
                 p.fill_(1.0)
             elif len(shape) == 2:
                 _glorot_uniform_(p, gen)
-            p.requires_grad_(True)
             self.params[name] = p
             self.grads[name] = g
         self._emb_numel_padded = offs[shapes[1][0]]     # emb is first; dense part starts here
         self._gru_names = [["User/GRU%d/%s" % (i, s) for s in
                             ("gates/kernel", "gates/bias", "candidate/kernel", "candidate/bias")]
                            for i in range(self.user_num_layers)]
+        self._make_read_desc()
 
     def set_params(self, values: Dict[str, np.ndarray]):
         """Inject weights (parity tests: identical weights => identical logits)."""
@@ -182,102 +183,75 @@ class Hpmn_Basic(object):
     def _gru_weights(self) -> List[torch.Tensor]:
         return [self.params[n] for names in self._gru_names for n in names]
 
-    # ------------------------------------------------------------------ read path (code/hpmn.py:133-199)
-    @staticmethod
-    def get_covreg(memory):
-        H = memory.shape[2]
-        c = memory - memory.mean(dim=2, keepdim=True)
-        cov = torch.matmul(c, c.transpose(1, 2)) / float(H)
-        cov = cov - torch.diag_embed(torch.diagonal(cov, dim1=1, dim2=2))
-        return torch.sqrt((cov * cov).sum(dim=(1, 2))).sum()
-
-    def attention(self, first_dense, memory, query):
-        p = self.params
-        B, K, H = memory.shape
-        q = query.unsqueeze(1).expand(B, K, H)
-        inp = torch.cat([q, memory, q - memory, q * memory], dim=-1)
-        n = first_dense
-        fc1 = torch.relu(torch.addmm(p["User/dense_%d/bias" % n], inp.reshape(B * K, 4 * H), p["User/dense_%d/kernel" % n]))
-        fc2 = torch.relu(torch.addmm(p["User/dense_%d/bias" % (n + 1)], fc1, p["User/dense_%d/kernel" % (n + 1)]))
-        fc3 = torch.addmm(p["User/dense_%d/bias" % (n + 2)], fc2, p["User/dense_%d/kernel" % (n + 2)])
-        score = torch.softmax(fc3.reshape(B, K), dim=1)
-        return (memory * score.unsqueeze(2)).sum(dim=1), score
-
-    def query_memory(self, last, memory):
-        p = self.params
-        q = torch.addmm(p["User/dense/bias"], last, p["User/dense/kernel"])
-        w0 = None
-        for hop in range(self.hop):
-            read, w = self.attention(3 * hop + 1, memory, q)
-            q = q @ p["User/map"] + read
-            if hop == 0:
-                w0 = w
-        return q, w0
-
-    def build_fc_net(self, repre, keep_prob=1.0, masks=None):
-        p = self.params
-        bn = repre * (p["output/bn1/gamma"] / math.sqrt(1.0 + BN_EPS)) + p["output/bn1/beta"]
-        fc1 = torch.nn.functional.elu(torch.addmm(p["output/fc1/bias"], bn, p["output/fc1/kernel"]))
-        if masks is not None:
-            fc1 = fc1 * masks[0] / keep_prob
-        elif keep_prob < 1.0:
-            fc1 = torch.nn.functional.dropout(fc1, 1.0 - keep_prob, training=True)
-        fc2 = torch.nn.functional.elu(torch.addmm(p["output/fc2/bias"], fc1, p["output/fc2/kernel"]))
-        if masks is not None:
-            fc2 = fc2 * masks[1] / keep_prob
-        elif keep_prob < 1.0:
-            fc2 = torch.nn.functional.dropout(fc2, 1.0 - keep_prob, training=True)
-        logit = torch.addmm(p["output/fc3/bias"], fc2, p["output/fc3/kernel"]).reshape(-1)
-        return logit, torch.sigmoid(logit)
+    # ------------------------------------------------------------------ read path (code/hpmn.py:133-207)
+    def _make_read_desc(self):
+        """Offsets of the read-path variables inside their contiguous range of the flat buffer."""
+        from ._lib import HpmnReadDesc
+        start = self._offs["User/dense/kernel"]
+        rel = lambda name: self._offs[name] - start
+        d = HpmnReadDesc()
+        d.K, d.H, d.D0, d.hop = self.user_num_layers, self.hidden_size, self.spec.D0, self.hop
+        d.off_wq, d.off_bq, d.off_map = rel("User/dense/kernel"), rel("User/dense/bias"), rel("User/map")
+        for h in range(self.hop):
+            for j in range(3):
+                d.off_att[h][2 * j] = rel("User/dense_%d/kernel" % (3 * h + j + 1))
+                d.off_att[h][2 * j + 1] = rel("User/dense_%d/bias" % (3 * h + j + 1))
+        d.off_gamma, d.off_beta = rel("output/bn1/gamma"), rel("output/bn1/beta")
+        for j, name in enumerate(("fc1", "fc2", "fc3")):
+            d.off_fc[2 * j] = rel("output/%s/kernel" % name)
+            d.off_fc[2 * j + 1] = rel("output/%s/bias" % name)
+        d.n_params = self._n_flat - start
+        self._read_desc = d
+        self._read_params = self.flat_param[start:]
+        self._read_grads = self.flat_grad[start:]
 
     # ------------------------------------------------------------------ forward passes
-    def _read(self, memory, last, keep_prob=1.0, masks=None):
-        mem_loss = self.get_covreg(memory)
-        q, w0 = self.query_memory(last, memory)
-        repre = torch.cat([q, last], dim=-1)
-        logit, pred = self.build_fc_net(repre, keep_prob, masks)
-        return dict(memory=memory, memory_loss=mem_loss, query=q, user_weights=w0, logit=logit,
-                    prediction=pred)
+    @torch.no_grad()
+    def forward_inference(self, ids: torch.Tensor, want_logit=True, want_att=True):
+        """Eval-mode forward (keep_prob 1): hpmn_scan_fwd chain + hpmn_read_fwd."""
+        memory, last = ops.scan_forward_inference(self.spec, ids, self.params["Embedding/emb_mtx"],
+                                                  self._gru_weights())
+        if ids.shape[0] == 0:
+            z = torch.empty(0, device=self.device)
+            return dict(memory=memory, prediction=z, logit=z, user_weights=torch.empty(0, self.spec.K, device=self.device),
+                        memory_loss=torch.zeros((), device=self.device))
+        return ops.read_fwd(self._read_desc, self._read_params, memory, last, want_logit, want_att)
 
     @torch.no_grad()
-    def forward_inference(self, ids: torch.Tensor):
-        """Eval-mode forward (keep_prob 1): HIP scan chain via hpmn_scan_fwd + read path."""
-        memory, last = ops.scan_forward_inference(self.spec, ids, self.params["Embedding/emb_mtx"],
-                                                  [w.detach() for w in self._gru_weights()])
-        return self._read(memory, last)
-
-    def forward_train(self, ids: torch.Tensor, keep_prob=0.5, masks=None, scatter_into_flat=True):
+    def compute_gradients(self, ids: torch.Tensor, label: torch.Tensor, keep_prob=0.5, masks=None,
+                          global_batch: Optional[int] = None):
+        """Forward + BPTT of cross_entropy (code/hpmn.py:202-207) for a (possibly sharded) batch into
+        the flat gradient buffer: log-loss is a MEAN over the GLOBAL batch, the memory regulariser a
+        SUM.  Pure kernel sequence: scan fwd -> read fwd+loss+bwd -> scan bwd."""
+        B = ids.shape[0]
+        if global_batch is None:
+            global_batch = B * self.world
+        self.flat_grad.zero_()
+        if B == 0:
+            return dict(prediction=torch.empty(0, device=self.device)), torch.zeros((), device=self.device)
         emb = self.params["Embedding/emb_mtx"]
-        grad_out = None
-        if scatter_into_flat:
-            grad_out = [self.grads["Embedding/emb_mtx"]] + [self.grads[n] for names in self._gru_names for n in names]
-        memory, last = ops.memory_scan(self.spec, ids, emb, self._gru_weights(), grad_out=grad_out)
-        return self._read(memory, last, keep_prob, masks)
-
-    def loss(self, out, label: torch.Tensor, global_batch: int):
-        """cross_entropy of code/hpmn.py:202-207 for a (possibly sharded) batch: the log-loss is a
-        MEAN over the global batch, the memory regulariser a SUM."""
-        y = label.to(torch.float32)
-        pred = out["prediction"]
-        ll_sum = (-y * torch.log(pred + LOGLOSS_EPS) - (1.0 - y) * torch.log(1.0 - pred + LOGLOSS_EPS)).sum()
-        ce = dist.sharded_loss(ll_sum, out["memory_loss"], global_batch, self.memory_reg)
+        weights = self._gru_weights()
+        memory, last, saved = ops.scan_forward_train(self.spec, ids, emb, weights)
+        if masks is None and keep_prob < 1.0:
+            masks = ((torch.rand(B, 200, device=self.device) < keep_prob).float(),
+                     (torch.rand(B, 80, device=self.device) < keep_prob).float())
+        out = ops.read_fwd_bwd(self._read_desc, self._read_params, self._read_grads, memory, last, label, masks,
+                               keep_prob, 1.0 / float(global_batch), self.memory_reg)
+        grad_out = [self.grads["Embedding/emb_mtx"]] + [self.grads[n] for names in self._gru_names for n in names]
+        ops.scan_backward(self.spec, ids, saved, weights, out["d_memory"], out["d_last"], grad_out)
         if self.l2_reg:
-            # every rank holds every variable: add the l2 term once (scaled by 1/world before the sum-reduce)
-            ce = ce + (self.l2_reg / self.world) * sum(0.5 * (v * v).sum() for v in self.params.values())
-        return ce
+            # l2_reg * tf.nn.l2_loss(v) for every trainable variable (code/hpmn.py:204-205); every rank holds
+            # every variable, so each adds 1/world of it before the sum all-reduce
+            self.flat_grad.add_(self.flat_param, alpha=self.l2_reg / self.world)
+        ce = out["log_loss_sum"] / float(global_batch) + self.memory_reg * out["memory_loss"]
+        out["memory"] = memory
+        return out, ce
 
     # ------------------------------------------------------------------ one training step
     def train_step(self, ids: torch.Tensor, label: torch.Tensor, keep_prob=0.5, masks=None,
                    global_batch: Optional[int] = None):
         """sess.run(train_step) of code/hpmn.py:482: forward, BPTT, clip, dense TF Adam."""
-        if global_batch is None:
-            global_batch = ids.shape[0] * self.world
-        self.flat_grad.zero_()
-        for name, p in self.params.items():
-            p.grad = self.grads[name]
-        out = self.forward_train(ids, keep_prob, masks)
-        ce = self.loss(out, label, global_batch)
-        ce.backward()
+        out, ce = self.compute_gradients(ids, label, keep_prob, masks, global_batch)
         dist.allreduce_sum_(self.flat_grad)                     # RCCL sum; clip happens after (8e)
         self.apply_gradients()
         return out, ce

@@ -243,79 +243,106 @@ def scan_forward_inference(spec: ScanSpec, ids, emb, weights: Sequence[torch.Ten
 
 
 # ---------------------------------------------------------------------------------------
-# autograd: build_memory with saved states + BPTT
+# build_memory with saved states (training) and its BPTT -- plain kernel sequences, no autograd
 # ---------------------------------------------------------------------------------------
-class _MemoryScan(torch.autograd.Function):
-    """memory, last = build_memory(embedding(ids))  with gradients for the GRU variables and
-    the embedding table.  Gradients are accumulated straight into ``grad_out`` (views of the
-    optimiser's flat gradient buffer) when given, else returned densely."""
-
-    @staticmethod
-    def forward(ctx, spec: ScanSpec, ids, emb, grad_out, *weights):
-        lens = spec.layer_lengths()
-        B = ids.shape[0]
-        H, K = spec.H, spec.K
-        memory = torch.empty(B, K, H, device=emb.device, dtype=torch.float32)
-        saved = []
-        x_in = None
-        x0 = None
-        for i in range(K):
-            wg, bg, wc, bc = weights[4 * i:4 * i + 4]
-            if i == 0:
-                xp, x0 = gru_input_proj(None, ids=ids, emb=emb, wg=wg, bg=bg, wc=wc, bc=bc, H=H, T=lens[0],
-                                        front_zero=spec.front_zero, mask_id0=spec.mask_id0, want_x_out=True)
-                D = spec.D0
-                x_in = x0
-            else:
-                xp, _ = gru_input_proj(None, x=x_in, wg=wg, bg=bg, wc=wc, bc=bc, H=H, T=lens[i])
-                D = H
-            y, hs, gates = gru_scan_fwd(xp, wg, wc, D, memory[:, i, :], spec.periods[i],
-                                        want_y=(i + 1 < K), train=True)
-            del xp
-            saved.append((x_in, hs, gates))
-            x_in = y
-        last = x0[:, spec.last_index, :].contiguous()
-        ctx.spec = spec
-        ctx.saved = saved
-        ctx.ids = ids
-        ctx.grad_out = grad_out
-        ctx.emb_shape = emb.shape
-        ctx.weights = weights
-        return memory, last
-
-    @staticmethod
-    def backward(ctx, d_memory, d_last):
-        spec: ScanSpec = ctx.spec
-        K = spec.K
-        weights = ctx.weights
-        d_memory = d_memory.contiguous()
-        direct = ctx.grad_out is not None
-        if direct:      # accumulate straight into the optimiser's (pre-zeroed) flat gradient views
-            d_emb, gw = ctx.grad_out[0], list(ctx.grad_out[1:])
+def scan_forward_train(spec: ScanSpec, ids, emb, weights: Sequence[torch.Tensor]):
+    """Training-mode build_memory (code/hpmn.py:113-129 on the embedded ids): per layer the input
+    projection + the serial scan with saved states.  Returns (memory [B,K,H], last [B,D0], saved)."""
+    lens = spec.layer_lengths()
+    B = ids.shape[0]
+    H, K = spec.H, spec.K
+    memory = torch.empty(B, K, H, device=emb.device, dtype=torch.float32)
+    saved = []
+    x_in = x0 = None
+    for i in range(K):
+        wg, bg, wc, bc = weights[4 * i:4 * i + 4]
+        if i == 0:
+            xp, x0 = gru_input_proj(None, ids=ids, emb=emb, wg=wg, bg=bg, wc=wc, bc=bc, H=H, T=lens[0],
+                                    front_zero=spec.front_zero, mask_id0=spec.mask_id0, want_x_out=True)
+            D = spec.D0
+            x_in = x0
         else:
-            d_emb = torch.zeros(ctx.emb_shape, device=d_memory.device, dtype=torch.float32)
-            gw = [torch.zeros_like(w) for w in weights]
-        d_y = None
-        for i in range(K - 1, -1, -1):
-            wg, bg, wc, bc = weights[4 * i:4 * i + 4]
-            x_in, hs, gates = ctx.saved[i]
-            D = x_in.shape[2]
-            d_act = gru_scan_bwd(wg, wc, D, hs, gates, d_memory[:, i, :], d_y, spec.periods[i])
-            d_y = gru_param_grads(x_in, hs, gates, d_act, wg, wc, gw[4 * i], gw[4 * i + 1], gw[4 * i + 2],
-                                  gw[4 * i + 3], want_dx=True)
-            del d_act
-        d_x0 = d_y
-        if d_last is not None:
-            d_x0[:, spec.last_index, :] += d_last
-        embed_grad_scatter(ctx.ids, d_x0, d_emb, spec.front_zero, spec.mask_id0)
-        ctx.saved = None
-        if direct:
-            return (None, None, None, None) + (None,) * (4 * K)
-        return (None, None, d_emb, None) + tuple(gw)
+            xp, _ = gru_input_proj(None, x=x_in, wg=wg, bg=bg, wc=wc, bc=bc, H=H, T=lens[i])
+            D = H
+        y, hs, gates = gru_scan_fwd(xp, wg, wc, D, memory[:, i, :], spec.periods[i], want_y=(i + 1 < K), train=True)
+        del xp
+        saved.append((x_in, hs, gates))
+        x_in = y
+    last = x0[:, spec.last_index, :].contiguous()
+    return memory, last, saved
 
 
-def memory_scan(spec: ScanSpec, ids, emb, weights: Sequence[torch.Tensor], grad_out=None):
-    """Differentiable build_memory: returns (memory [B,K,H], last [B,D0]).  ``grad_out`` =
-    [d_emb, d_wg0, d_bg0, d_wc0, d_bc0, d_wg1, ...]: pre-zeroed buffers (views of the optimiser's
-    flat gradient) that backward accumulates into directly instead of returning gradients."""
-    return _MemoryScan.apply(spec, ids, emb, grad_out, *weights)
+def scan_backward(spec: ScanSpec, ids, saved, weights: Sequence[torch.Tensor], d_memory, d_last, grad_out):
+    """BPTT of scan_forward_train.  ``grad_out`` = [d_emb, d_wg0, d_bg0, d_wc0, d_bc0, d_wg1, ...]:
+    pre-zeroed buffers (views of the optimiser's flat gradient) that are accumulated into."""
+    K = spec.K
+    d_emb, gw = grad_out[0], list(grad_out[1:])
+    d_y = None
+    for i in range(K - 1, -1, -1):
+        wg, bg, wc, bc = weights[4 * i:4 * i + 4]
+        x_in, hs, gates = saved[i]
+        D = x_in.shape[2]
+        d_act = gru_scan_bwd(wg, wc, D, hs, gates, d_memory[:, i, :], d_y, spec.periods[i])
+        d_y = gru_param_grads(x_in, hs, gates, d_act, wg, wc, gw[4 * i], gw[4 * i + 1], gw[4 * i + 2],
+                              gw[4 * i + 3], want_dx=True)
+        del d_act
+    d_x0 = d_y
+    d_x0[:, spec.last_index, :] += d_last
+    embed_grad_scatter(ids, d_x0, d_emb, spec.front_zero, spec.mask_id0)
+
+
+# ---------------------------------------------------------------------------------------
+# read path (covariance regulariser + attention hops + head + loss)
+# ---------------------------------------------------------------------------------------
+_read_ws = {}
+
+
+def _read_workspace(desc, device):
+    """Zero-initialised once, then reused: the kernel only rewrites parameter positions."""
+    need = _lib.load().hpmn_read_workspace_bytes(C.byref(desc)) // 4
+    key = (str(device), int(desc.n_params))
+    ws = _read_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _read_ws[key] = torch.zeros(need, device=device, dtype=torch.float32)
+    return ws
+
+
+def read_fwd(desc, params, memory, last, want_logit=False, want_att=False):
+    """hpmn_read_fwd -> dict(prediction, logit?, user_weights?, memory_loss)."""
+    _chk_f32(params, memory, last)
+    B, K, H = memory.shape
+    desc.B = B
+    dev = memory.device
+    pred = torch.empty(B, device=dev)
+    logit = torch.empty(B, device=dev) if want_logit else None
+    att = torch.empty(B, K, device=dev) if want_att else None
+    mem_loss = torch.zeros(1, device=dev)
+    rc = _lib.load().hpmn_read_fwd(C.byref(desc), params.data_ptr(), memory.data_ptr(), last.data_ptr(),
+                                    pred.data_ptr(), _ptr(logit), _ptr(att), mem_loss.data_ptr(), _stream())
+    _lib.check(rc, "hpmn_read_fwd")
+    return dict(prediction=pred, logit=logit, user_weights=att, memory_loss=mem_loss[0], memory=memory)
+
+
+def read_fwd_bwd(desc, params, d_params, memory, last, label, masks, keep_prob, inv_global_batch, memory_reg):
+    """hpmn_read_fwd_bwd: forward + loss + backward of the read path; accumulates into d_params."""
+    _chk_f32(params, d_params, memory, last)
+    B, K, H = memory.shape
+    desc.B = B
+    dev = memory.device
+    assert label.dtype == torch.int32 and label.is_contiguous()
+    pred = torch.empty(B, device=dev)
+    loss_out = torch.zeros(2, device=dev)
+    d_memory = torch.empty_like(memory)
+    d_last = torch.empty_like(last)
+    m1 = m2 = None
+    if masks is not None:
+        m1, m2 = masks
+        _chk_f32(m1, m2)
+    ws = _read_workspace(desc, dev)
+    rc = _lib.load().hpmn_read_fwd_bwd(C.byref(desc), params.data_ptr(), memory.data_ptr(), last.data_ptr(),
+                                        label.data_ptr(), _ptr(m1), _ptr(m2), float(keep_prob),
+                                        float(inv_global_batch), float(memory_reg), pred.data_ptr(),
+                                        loss_out.data_ptr(), d_memory.data_ptr(), d_last.data_ptr(),
+                                        d_params.data_ptr(), ws.data_ptr(), _stream())
+    _lib.check(rc, "hpmn_read_fwd_bwd")
+    return dict(prediction=pred, log_loss_sum=loss_out[0], memory_loss=loss_out[1], d_memory=d_memory, d_last=d_last)

@@ -180,6 +180,46 @@ int hpmn_scan_fwd(const HpmnScanDesc *desc, const int32_t *ids, const float *emb
                   float *memory, float *last, void *workspace, void *stream);
 
 /* ------------------------------------------------------------------------------------
+ * Memory read path: covariance regulariser (code/hpmn.py:161-170), multi-hop attention over
+ * the K memory slots (query_memory :172-182, attention :133-146), prediction head in
+ * inference-mode batch-norm (build_fc_net :190-199) and the loss of :202-207.
+ *
+ * All read-path variables live in ONE contiguous fp32 range `params` (n_params floats; in this
+ * repo a sub-range of the flat parameter buffer) addressed by the offsets below, TF layout
+ * (dense kernels [in,out]):
+ *   off_wq/off_bq  User/dense {kernel [D0,H], bias [H]}       off_map  User/map [H,H]
+ *   off_att[h][0..5]  hop h: dense_{3h+1..3h+3} {kernel,bias}: [4H,80],[80],[80,40],[40],[40,1],[1]
+ *   off_gamma/off_beta  output/bn1 [H+D0]                      off_fc[0..5]  fc1,fc2,fc3 {kernel,bias}
+ *
+ * hpmn_read_fwd      : memory [B,K,H], last [B,D0] -> pred [B], optional logit [B], optional
+ *                      att_w0 [B,K] (first-hop weights, code/hpmn.py:182); *mem_loss += sum_b covreg_b.
+ * hpmn_read_fwd_bwd  : training.  loss = inv_global_batch * sum_b logloss_b + memory_reg * sum_b covreg_b
+ *                      (log-loss is a MEAN over the global batch, the regulariser a SUM).
+ *                      mask1 [B,200] / mask2 [B,80]: dropout keep masks (0/1) or NULL; outputs scaled
+ *                      by 1/keep_prob.  Writes pred [B], d_memory [B,K,H], d_last [B,D0];
+ *                      loss_out[0] += sum_b logloss_b, loss_out[1] += sum_b covreg_b;
+ *                      d_params[0..n_params) += gradients (deterministic two-stage reduction through
+ *                      `workspace`, >= hpmn_read_workspace_bytes(); zero it ONCE after allocation --
+ *                      only parameter positions are ever rewritten).
+ * ---------------------------------------------------------------------------------- */
+typedef struct HpmnReadDesc {
+    int32_t B, K, H, D0, hop;
+    int32_t off_wq, off_bq, off_map;
+    int32_t off_att[4][6];
+    int32_t off_gamma, off_beta;
+    int32_t off_fc[6];
+    int32_t n_params;
+} HpmnReadDesc;
+
+size_t hpmn_read_workspace_bytes(const HpmnReadDesc *desc);
+int hpmn_read_fwd(const HpmnReadDesc *desc, const float *params, const float *memory, const float *last,
+                  float *pred, float *logit, float *att_w0, float *mem_loss, void *stream);
+int hpmn_read_fwd_bwd(const HpmnReadDesc *desc, const float *params, const float *memory, const float *last,
+                      const int32_t *label, const float *mask1, const float *mask2, float keep_prob,
+                      float inv_global_batch, float memory_reg, float *pred, float *loss_out,
+                      float *d_memory, float *d_last, float *d_params, float *workspace, void *stream);
+
+/* ------------------------------------------------------------------------------------
  * Embedding-gradient scatter-add: gradient of hpmn_embed_gather / the gather inside the
  * layer-0 scan (TF: IndexedSlices densified by the l2 term, code/hpmn.py:204-205).
  *   d_emb[ids[b,t,f]] += d_x[b, front_zero + t, f*E:(f+1)*E]   (skipping id 0 when mask_id0)

@@ -100,10 +100,11 @@ def test_forward_logits_match_oracle(dev, tmp_path, name, cfg, B):
     for k in ("memory", "logit", "prediction", "user_weights"):
         np.testing.assert_allclose(out[k].cpu().numpy(), want[k], rtol=0, atol=TOL, err_msg=k)
     np.testing.assert_allclose(float(out["memory_loss"]), want["memory_loss"], rtol=1e-4, atol=1e-5)
-    # training-mode forward (saved-state kernels) gives the same numbers with keep_prob 1
-    out_t = m.forward_train(torch.as_tensor(ids).to(dev), keep_prob=1.0)
-    np.testing.assert_allclose(out_t["logit"].detach().cpu().numpy(), out["logit"].cpu().numpy(), atol=1e-6)
-    np.testing.assert_allclose(out_t["memory"].detach().cpu().numpy(), out["memory"].cpu().numpy(), atol=1e-6)
+    # training path (saved-state scan kernels + fused read fwd/bwd kernel) gives the same numbers at keep_prob 1
+    out_t, ce = m.compute_gradients(torch.as_tensor(ids).to(dev), torch.as_tensor(label).to(dev), keep_prob=1.0)
+    np.testing.assert_allclose(out_t["prediction"].cpu().numpy(), out["prediction"].cpu().numpy(), atol=2e-6)
+    np.testing.assert_allclose(out_t["memory"].cpu().numpy(), out["memory"].cpu().numpy(), atol=1e-6)
+    np.testing.assert_allclose(float(ce), want["cross_entropy"], atol=TOL)
 
 
 @pytest.mark.parametrize("fname,industry", [("oracle_c0.npz", False), ("oracle_industry.npz", True)])
@@ -115,7 +116,7 @@ def test_forward_matches_committed_golden_vectors(dev, tmp_path, fname, industry
     out = m.forward_inference(torch.as_tensor(z["ids"]).to(dev))
     for k in ("memory", "logit", "prediction", "user_weights"):
         np.testing.assert_allclose(out[k].cpu().numpy(), z[k], rtol=0, atol=TOL, err_msg=k)
-    ce = m.loss(out, torch.as_tensor(z["label"]).to(dev), len(z["label"]))
+    _, ce = m.compute_gradients(torch.as_tensor(z["ids"]).to(dev), torch.as_tensor(z["label"]).to(dev), keep_prob=1.0)
     np.testing.assert_allclose(float(ce), float(z["cross_entropy"]), atol=TOL)
 
 
@@ -190,13 +191,9 @@ def test_gradients_match_float64_autograd(dev, tmp_path, name, cfg, B):
     ref = R.forward(cfg, tp, torch.as_tensor(ids.astype(np.int64)), torch.as_tensor(label.astype(np.int64)))
     ref["cross_entropy"].backward()
     m = make_model(cfg, tmp_path, p)
-    m.flat_grad.zero_()
-    for n, q in m.params.items():
-        q.grad = m.grads[n]
-    out = m.forward_train(torch.as_tensor(ids).to(dev), keep_prob=1.0)
-    ce = m.loss(out, torch.as_tensor(label).to(dev), B)
+    out, ce = m.compute_gradients(torch.as_tensor(ids).to(dev), torch.as_tensor(label).to(dev), keep_prob=1.0,
+                                  global_batch=B)
     np.testing.assert_allclose(float(ce), float(ref["cross_entropy"]), atol=1e-5)
-    ce.backward()
     for k in p:
         want = tp[k].grad.numpy()
         got = m.grads[k].cpu().numpy()
@@ -217,8 +214,19 @@ def test_dropout_masks_are_honoured(dev, tmp_path):
     want = O.forward(cfg, p, ids, label, mask1=m1, mask2=m2, keep_prob=0.5)
     m = make_model(cfg, tmp_path, p)
     masks = (torch.as_tensor(m1, dtype=torch.float32).to(dev), torch.as_tensor(m2, dtype=torch.float32).to(dev))
-    out = m.forward_train(torch.as_tensor(ids).to(dev), keep_prob=0.5, masks=masks)
-    np.testing.assert_allclose(out["logit"].detach().cpu().numpy(), want["logit"], atol=TOL)
+    out, ce = m.compute_gradients(torch.as_tensor(ids).to(dev), torch.as_tensor(label).to(dev), keep_prob=0.5,
+                                  masks=masks)
+    np.testing.assert_allclose(out["prediction"].cpu().numpy(), want["prediction"], atol=TOL)
+    np.testing.assert_allclose(float(ce), want["cross_entropy"], atol=TOL)
+    # and the gradients with dropout active
+    tp = R.to_torch(p, torch.float64, requires_grad=True)
+    ref = R.forward(cfg, tp, torch.as_tensor(ids.astype(np.int64)), torch.as_tensor(label.astype(np.int64)),
+                    torch.as_tensor(m1), torch.as_tensor(m2), 0.5)
+    ref["cross_entropy"].backward()
+    for k in ("output/fc1/kernel", "output/fc2/kernel", "User/dense_1/kernel", "User/GRU0/gates/kernel"):
+        wantg = tp[k].grad.numpy()
+        np.testing.assert_allclose(m.grads[k].cpu().numpy(), wantg, rtol=0, atol=2e-4 * np.abs(wantg).max() + 1e-7,
+                                   err_msg=k)
 
 
 # ------------------------------------------------------------------------------- optimiser + steps
