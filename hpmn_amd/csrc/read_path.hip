@@ -18,7 +18,7 @@
 
 namespace hpmn {
 
-constexpr int RS = 4;          // samples per workgroup
+constexpr int RS = 2;          // samples per workgroup
 constexpr int RT = 256;        // threads
 constexpr int A1 = 80, A2 = 40;      // attention MLP widths (code/hpmn.py:137-138)
 constexpr int F1 = 200, F2 = 80;     // head widths (code/hpmn.py:191,193)
@@ -29,32 +29,67 @@ __device__ __forceinline__ float elu(float x) { return x > 0.f ? x : __expf(x) -
 
 // Y[r][n] = act(b[n] + sum_i X[r][i] W[i][n]) for r < R, n < N.  X, Y in LDS; W [I,N] row-major in
 // global (coalesced over n).  ACT: 0 none, 1 relu, 2 elu.
+// Register blocking: a work item = (column n, block of RB rows) carries RB accumulators, so one
+// weight load feeds RB FMAs (the x operands are LDS broadcasts).  Single owner per output:
+// deterministic, no atomics, no internal barriers.
+constexpr int RB = 8;
+
 template <int ACT>
 __device__ __forceinline__ void dense_fwd(const float *X, int ldx, int R, int I, const float *W, const float *b,
                                           int N, float *Y, int ldy) {
-    for (int o = threadIdx.x; o < R * N; o += RT) {
-        const int r = o / N, n = o - r * N;
-        float acc = b[n];
-        const float *x = X + r * ldx;
-        for (int i = 0; i < I; ++i) acc = fmaf(x[i], W[(long)i * N + n], acc);
-        if (ACT == 1) acc = fmaxf(acc, 0.f);
-        if (ACT == 2) acc = elu(acc);
-        Y[r * ldy + n] = acc;
+    const int nrb = (R + RB - 1) / RB;
+    for (int o = threadIdx.x; o < nrb * N; o += RT) {
+        const int rb = o / N, n = o - rb * N;
+        const int r0 = rb * RB;
+        float acc[RB];
+#pragma unroll
+        for (int j = 0; j < RB; ++j) acc[j] = b[n];
+        const float *xr[RB];
+#pragma unroll
+        for (int j = 0; j < RB; ++j) xr[j] = X + ((r0 + j) < R ? (r0 + j) : (R - 1)) * ldx;
+#pragma unroll 4
+        for (int i = 0; i < I; ++i) {
+            const float w = W[(long)i * N + n];
+#pragma unroll
+            for (int j = 0; j < RB; ++j) acc[j] = fmaf(xr[j][i], w, acc[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < RB; ++j) {
+            if (r0 + j < R) {
+                float v = acc[j];
+                if (ACT == 1) v = fmaxf(v, 0.f);
+                if (ACT == 2) v = elu(v);
+                Y[(r0 + j) * ldy + n] = v;
+            }
+        }
     }
 }
 
-// dX[r][i] (+)= sum_n dY[r][n] W[i][n]
+// dX[r][i] (+)= sum_n dY[r][n] W[i][n]      thread = input unit i, walks its weight row once per RB rows
 template <bool ACCUM>
 __device__ __forceinline__ void dense_bwd_x(const float *dY, int ldy, int R, int N, const float *W, int I, float *dX,
                                             int ldx) {
-    for (int o = threadIdx.x; o < R * I; o += RT) {
-        const int r = o / I, i = o - r * I;
+    for (int i = threadIdx.x; i < I; i += RT) {
         const float *w = W + (long)i * N;
-        const float *d = dY + r * ldy;
-        float acc = 0.f;
-        for (int n = 0; n < N; ++n) acc = fmaf(d[n], w[n], acc);
-        if (ACCUM) dX[r * ldx + i] += acc;
-        else dX[r * ldx + i] = acc;
+        for (int r0 = 0; r0 < R; r0 += RB) {
+            float acc[RB];
+#pragma unroll
+            for (int j = 0; j < RB; ++j) acc[j] = 0.f;
+            for (int n = 0; n < N; ++n) {
+                const float wv = w[n];
+#pragma unroll
+                for (int j = 0; j < RB; ++j) {
+                    const int r = (r0 + j) < R ? (r0 + j) : (R - 1);
+                    acc[j] = fmaf(dY[r * ldy + n], wv, acc[j]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < RB; ++j)
+                if (r0 + j < R) {
+                    if (ACCUM) dX[(r0 + j) * ldx + i] += acc[j];
+                    else dX[(r0 + j) * ldx + i] = acc[j];
+                }
+        }
     }
 }
 
