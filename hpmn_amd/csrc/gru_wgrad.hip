@@ -20,8 +20,7 @@
 //     loads are in flight under the current tile's MFMAs.  Each workgroup stores its
 //     partial result as a slab in a caller-provided workspace and wgrad_reduce_kernel adds the
 //     slabs into dW (single writer per element: deterministic, no atomics).
-// (2) gru_dx_kernel -- also fp32 MFMA: d_act tile staged in LDS as the A operand, the input
-//     rows of the kernels as register-stationary B operands, coalesced stores.
+// (2) dx = d_act Wx^T is a row-wise transform: gru_dx_kernel in input_proj.hip.
 #include "common.h"
 
 namespace hpmn {
@@ -228,81 +227,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
     else d_bc[e - n_wg - n_bg - n_wc] += tot;
 }
 
-// ------------------------------------------------------------------------------------------
-// dx[m][d] = sum_j d_act[m][j] * Wx[d][j],  Wx = [Wg[0:D] | Wc[0:D]]  ([D, 3H], row d contiguous
-// per source).  MFMA with the d_act tile as the A operand read from LDS (row stride 3H+1 floats
-// -> the 32 rows of a half-wave hit 32 different banks) and the weights as register-stationary B
-// operands; the C/D layout then puts 32 consecutive d of one row in 32 consecutive lanes, so the
-// stores are coalesced.  One wave = 32 rows; a workgroup = 2 waves = one contiguous 64-row tile.
-constexpr int XR = 64;
-
-template <int HT, int DT>
-__global__ __launch_bounds__(128) void gru_dx_kernel(const HpmnGruWgrad a) {
-    constexpr int H = 32 * HT;
-    constexpr int N = 3 * H;
-    constexpr int LD = N + 1;
-    constexpr int KS = N / 2;                 // MFMA k-steps
-    __shared__ float tile[XR * LD];
-    const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
-    const int c = lane & 31, kp = lane >> 5;
-    const int D = a.D;
-    const long M = (long)a.B * a.T;
-    const long ntiles = (M + XR - 1) / XR;
-
-    // B operand (loaded once per persistent workgroup): lane (n = c -> d, k = kp): Wx[32*dt + c][2*ks + kp]
-    float wb[DT][KS];
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt) {
-        const int d = 32 * dt + c;
-        const bool ok = d < D;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const int j = 2 * ks + kp;
-            float v = 0.f;
-            if (ok) v = (j < 2 * H) ? a.wg[(long)d * 2 * H + j] : a.wc[(long)d * H + (j - 2 * H)];
-            wb[dt][ks] = v;
-        }
-    }
-
-    for (long ti = blockIdx.x; ti < ntiles; ti += gridDim.x) {
-        const long m0 = ti * XR;
-        __syncthreads();   // previous tile fully consumed
-        // stage the contiguous [64 x 3H] d_act tile (coalesced float4), scalar LDS stores (odd stride)
-        for (int i = tid; i < XR * (N / 4); i += 128) {
-            const int r = i / (N / 4);
-            const int q = i % (N / 4);
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m0 + r < M) v = *reinterpret_cast<const float4 *>(a.d_act + (m0 + r) * N + 4 * q);
-            float *t = &tile[r * LD + 4 * q];
-            t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
-        }
-        __syncthreads();
-
-        f32x16 acc[DT];
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
-        const float *arow = &tile[(wave * 32 + c) * LD + kp];
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const float av = arow[2 * ks];
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
-                acc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wb[dt][ks], acc[dt], 0, 0, 0);
-        }
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-            const int d = 32 * dt + c;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const long m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kp;
-                if (d < D && m < M) a.d_x[m * D + d] = acc[dt][r];
-            }
-        }
-    }
-}
+int gru_dx_dispatch(const HpmnGruWgrad &a, hipStream_t st);   // input_proj.hip (row-wise MFMA)
 
 static int wgrad_seq_per_wg(int T) {
     int spw = (WG_MIN_ROWS + T - 1) / T;
@@ -330,15 +255,6 @@ static int launch_wgrad(const HpmnGruWgrad &a, hipStream_t st) {
     return check_launch();
 }
 
-template <int HT, int DT>
-static int launch_dx(const HpmnGruWgrad &a, hipStream_t st) {
-    const long M = (long)a.B * a.T;
-    long grid = (M + XR - 1) / XR;
-    if (grid > 256 * 3) grid = 256 * 3;      // persistent: 3 workgroups per CU (LDS-limited), tile-stride loop
-    hipLaunchKernelGGL((gru_dx_kernel<HT, DT>), dim3((unsigned)grid), dim3(128), 0, st, a);
-    return check_launch();
-}
-
 int gru_wgrad_dispatch(const HpmnGruWgrad &a, hipStream_t st) {
     const int DT = (a.D + 31) / 32;
     int rc = HPMN_EUNSUPPORTED;
@@ -347,11 +263,7 @@ int gru_wgrad_dispatch(const HpmnGruWgrad &a, hipStream_t st) {
     else if (a.H == 64 && DT == 1) rc = launch_wgrad<2, 1>(a, st);
     else if (a.H == 64 && DT == 2) rc = launch_wgrad<2, 2>(a, st);
     if (rc != HPMN_OK || a.d_x == nullptr) return rc;
-    if (a.H == 32 && DT == 1) return launch_dx<1, 1>(a, st);
-    if (a.H == 32 && DT == 2) return launch_dx<1, 2>(a, st);
-    if (a.H == 64 && DT == 1) return launch_dx<2, 1>(a, st);
-    if (a.H == 64 && DT == 2) return launch_dx<2, 2>(a, st);
-    return HPMN_EUNSUPPORTED;
+    return gru_dx_dispatch(a, st);
 }
 
 }  // namespace hpmn

@@ -1,113 +1,208 @@
-// Input projection of one GRU layer for gfx950: the time-parallel half of the cell.
+// Row-wise dense transforms of one GRU layer for gfx950 -- the two time-parallel, HBM-bound
+// GEMMs on either side of the serial scan, both as f32 MFMA with NO LDS staging:
 //
-//   xp[m, 0:2H]  = x[m] Wg[0:D, :] + bg          (r and u pre-activations, input part)
-//   xp[m, 2H:3H] = x[m] Wc[0:D, :] + bc          (candidate pre-activation, input part)
+//   input projection (forward):  xp[m, 0:3H] = x[m, 0:D] [Wg[0:D] | Wc[0:D]] + [bg | bc]
+//       (layer 0 gathers x[m] from (ids, emb) on the fly: id-0 mask, zero prefix; optional x_out)
+//   input gradient  (backward):  dx[m, 0:D]  = d_act[m, 0:3H] [Wg[0:D] | Wc[0:D]]^T
 //
-// for every row m = (b, t) at once -- no serial dependency, so it is hoisted out of the
-// scan (gru_scan_fwd.hip).  Layer 0 fuses the embedding gather: the rows of x are built
-// from (ids, emb) with the id-0 mask and the zero prefix and never round-trip through HBM
-// unless the caller asks for x_out (training needs it for the weight-gradient GEMM).
-//
-// One workgroup = PR rows x all 3H columns.  The x tile is staged in LDS (coalesced
-// float4 loads; 4 lanes per 64-byte embedding row in gather mode), thread n keeps column n
-// of the [D, 3H] input weights in registers and walks the tile 4 rows at a time reading x
-// as wave-uniform 16-byte LDS broadcasts; output rows are written fully coalesced (3H
-// consecutive floats).  HBM-bound by the xp write (12H bytes per row).
+// out[M,N] = in[M,K] W[K,N] with v_mfma_f32_32x32x2_f32: A[i=row][k], B[k][n].  The MFMA k index
+// is split across the two half-waves (lanes 0-31: k slot 0, lanes 32-63: k slot 1); because the
+// reduction order is free we map half-wave p to the CONTIGUOUS half [p*K/2, (p+1)*K/2) of the row,
+// so each lane's A operands are simply 16-byte loads of its own row half (every fetched line is
+// fully used; a gathered 64-byte embedding row is exactly one lane's half row at D=32) and B is
+// W[p*K/2 + ks][n] kept register-stationary for the whole launch.  The C/D layout puts 32
+// consecutive n of one row in 32 consecutive lanes: stores are whole 128-byte lines.
+// Persistent waves walk 32-row tiles; the next tile's A is in flight under the current MFMAs.
 #include "common.h"
 
 namespace hpmn {
 
-constexpr int PR = 64;  // rows per workgroup
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int D, bool GATHER>
-__global__ __launch_bounds__(256) void input_proj_kernel(const HpmnInputProj a) {
-    constexpr int D4 = D / 4;
-    __shared__ __attribute__((aligned(16))) float xs[PR * D];
+constexpr int RW_WAVES = 4;     // waves per workgroup (each owns its own 32-row tiles)
 
-    const int tid = threadIdx.x;
-    const int H = a.H;
-    const int N = 3 * H;
+// K = reduction length; a wave computes NT 32-column output tiles, the NS column groups of a row tile
+// go to NS different waves (NT*NS*32 = 3H): at H=64 the 6 tiles are split 3+3 so the stationary
+// weights (NT*K/2 registers) + accumulators + double-buffered A fit without scratch.
+template <int K, int NT, int NS, bool GATHER>
+__global__ __launch_bounds__(64 * RW_WAVES, 1) void input_proj_kernel(const HpmnInputProj a) {
+    constexpr int KH = K / 2;        // k range of one half-wave
+    constexpr int Q = KH / 4;        // float4 loads per lane per tile
+    static_assert(K % 8 == 0, "K/2 must be a multiple of 4");
+    const int lane = threadIdx.x & 63;
+    const int c = lane & 31, p = lane >> 5;
+    const int H = a.H, N = 3 * H;
     const long M = (long)a.B * a.T;
-    const long m0 = (long)blockIdx.x * PR;
+    const long ntile = (M + 31) / 32;
+    const long gwave = (long)blockIdx.x * RW_WAVES + (threadIdx.x >> 6);
+    const int ns = (int)(gwave % NS);              // which column group
+    const long wave_id = gwave / NS;
+    const long nwave = (long)gridDim.x * RW_WAVES / NS;
+    const int n_base = ns * NT * 32;
 
-    // ---- stage the x tile ------------------------------------------------------------------
-    for (int i = tid; i < PR * D4; i += blockDim.x) {
-        const int r = i / D4;
-        const int d = (i % D4) * 4;
-        const long m = m0 + r;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (m < M) {
-            if constexpr (GATHER) {
-                const long b = m / a.T;
-                const int t = (int)(m - b * a.T) - a.front_zero;
+    // B operand: Wcat[p*KH + ks][n_base + 32*nt + c], Wcat = [wg[0:D] | wc[0:D]]
+    float wb[NT][KH];
+    float bias[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = n_base + 32 * nt + c;
+        bias[nt] = n < 2 * H ? a.bg[n] : a.bc[n - 2 * H];
+#pragma unroll
+        for (int ks = 0; ks < KH; ++ks) {
+            const int j = p * KH + ks;
+            wb[nt][ks] = n < 2 * H ? a.wg[(long)j * 2 * H + n] : a.wc[(long)j * H + (n - 2 * H)];
+        }
+    }
+
+    auto load_a = [&](long tile, float4 (&v)[Q]) {
+        const long m = tile * 32 + c;
+        const bool ok = m < M;
+        if constexpr (GATHER) {
+            const long b = ok ? m / a.T : 0;
+            const int t = ok ? (int)(m - b * a.T) - a.front_zero : -1;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                const int j = p * KH + 4 * q;
+                const int f = j / a.E;
+                v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (t >= 0) {
-                    const int f = d / a.E;
                     const int id = a.ids[(b * a.Tids + t) * a.F + f];
                     if (!(a.mask_id0 && id == 0))
-                        v = *reinterpret_cast<const float4 *>(a.emb + (long)id * a.E + (d - f * a.E));
+                        v[q] = *reinterpret_cast<const float4 *>(a.emb + (long)id * a.E + (j - f * a.E));
                 }
-                if (a.x_out != nullptr) *reinterpret_cast<float4 *>(a.x_out + m * D + d) = v;
-            } else {
-                v = *reinterpret_cast<const float4 *>(a.x + m * D + d);
             }
-        }
-        *reinterpret_cast<float4 *>(&xs[r * D + d]) = v;
-    }
-
-    // ---- column weights ----------------------------------------------------------------------
-    const int n = tid;
-    float w[D];
-    float bias = 0.f;
-    if (n < N) {
-        if (n < 2 * H) {
-#pragma unroll
-            for (int j = 0; j < D; ++j) w[j] = a.wg[(long)j * 2 * H + n];
-            bias = a.bg[n];
         } else {
 #pragma unroll
-            for (int j = 0; j < D; ++j) w[j] = a.wc[(long)j * H + (n - 2 * H)];
-            bias = a.bc[n - 2 * H];
+            for (int q = 0; q < Q; ++q) {
+                v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ok) v[q] = *reinterpret_cast<const float4 *>(a.x + m * K + p * KH + 4 * q);
+            }
         }
-    }
-    __syncthreads();
-    if (n >= N) return;
+    };
 
-    const int rows = (M - m0) < PR ? (int)(M - m0) : PR;
-    for (int r = 0; r < rows; r += 4) {
-        float acc0 = bias, acc1 = bias, acc2 = bias, acc3 = bias;
-        const float4 *x0 = reinterpret_cast<const float4 *>(&xs[(r + 0) * D]);
-        const float4 *x1 = reinterpret_cast<const float4 *>(&xs[(r + 1) * D]);
-        const float4 *x2 = reinterpret_cast<const float4 *>(&xs[(r + 2) * D]);
-        const float4 *x3 = reinterpret_cast<const float4 *>(&xs[(r + 3) * D]);
+    float4 cur[Q], nxt[Q];
+    if (wave_id < ntile) load_a(wave_id, cur);
+    for (long tile = wave_id; tile < ntile; tile += nwave) {
+        if (tile + nwave < ntile) load_a(tile + nwave, nxt);
+        if constexpr (GATHER) {
+            const long m = tile * 32 + c;
+            if (ns == 0 && a.x_out != nullptr && m < M) {
 #pragma unroll
-        for (int j = 0; j < D4; ++j) {
-            const float4 v0 = x0[j], v1 = x1[j], v2 = x2[j], v3 = x3[j];
-            acc0 = fmaf(v0.x, w[4 * j], acc0); acc0 = fmaf(v0.y, w[4 * j + 1], acc0);
-            acc0 = fmaf(v0.z, w[4 * j + 2], acc0); acc0 = fmaf(v0.w, w[4 * j + 3], acc0);
-            acc1 = fmaf(v1.x, w[4 * j], acc1); acc1 = fmaf(v1.y, w[4 * j + 1], acc1);
-            acc1 = fmaf(v1.z, w[4 * j + 2], acc1); acc1 = fmaf(v1.w, w[4 * j + 3], acc1);
-            acc2 = fmaf(v2.x, w[4 * j], acc2); acc2 = fmaf(v2.y, w[4 * j + 1], acc2);
-            acc2 = fmaf(v2.z, w[4 * j + 2], acc2); acc2 = fmaf(v2.w, w[4 * j + 3], acc2);
-            acc3 = fmaf(v3.x, w[4 * j], acc3); acc3 = fmaf(v3.y, w[4 * j + 1], acc3);
-            acc3 = fmaf(v3.z, w[4 * j + 2], acc3); acc3 = fmaf(v3.w, w[4 * j + 3], acc3);
+                for (int q = 0; q < Q; ++q) *reinterpret_cast<float4 *>(a.x_out + m * K + p * KH + 4 * q) = cur[q];
+            }
         }
-        float *o = a.xp + (m0 + r) * N + n;
-        o[0] = acc0;
-        if (r + 1 < rows) o[N] = acc1;
-        if (r + 2 < rows) o[2 * (long)N] = acc2;
-        if (r + 3 < rows) o[3 * (long)N] = acc3;
+        f32x16 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][r] = bias[nt];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const float av[4] = {cur[q].x, cur[q].y, cur[q].z, cur[q].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], wb[nt][4 * q + e], acc[nt], 0, 0, 0);
+        }
+        // C/D layout: reg r -> row (r&3) + 8*(r>>2) + 4*p, col c
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long m = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * p;
+            if (m < M) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) a.xp[m * N + n_base + 32 * nt + c] = acc[nt][r];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < Q; ++q) cur[q] = nxt[q];
     }
 }
 
-template <int D>
-static int launch_proj(const HpmnInputProj &a, hipStream_t st) {
+// dx[m, d] = sum_j d_act[m, j] Wx[d][j];  K = 3H (reduction), NT = ceil(D/32) output tiles (masked to D)
+template <int K, int NT>
+__global__ __launch_bounds__(64 * RW_WAVES, 1) void gru_dx_kernel(const HpmnGruWgrad a) {
+    constexpr int KH = K / 2;
+    constexpr int Q = KH / 4;
+    constexpr int H = K / 3;
+    const int lane = threadIdx.x & 63;
+    const int c = lane & 31, p = lane >> 5;
+    const int D = a.D;
     const long M = (long)a.B * a.T;
-    const unsigned grid = (unsigned)((M + PR - 1) / PR);
-    const int threads = (3 * a.H + 63) / 64 * 64;
+    const long ntile = (M + 31) / 32;
+    const long wave_id = (long)blockIdx.x * RW_WAVES + (threadIdx.x >> 6);
+    const long nwave = (long)gridDim.x * RW_WAVES;
+
+    // B operand: B[k = j][n = d] = Wx[d][j], j = p*KH + ks;  row d of [wg[0:D] | wc[0:D]] is contiguous per source
+    float wb[NT][KH];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int d = 32 * nt + c;
+#pragma unroll
+        for (int ks = 0; ks < KH; ++ks) {
+            const int j = p * KH + ks;
+            float v = 0.f;
+            if (d < D) v = j < 2 * H ? a.wg[(long)d * 2 * H + j] : a.wc[(long)d * H + (j - 2 * H)];
+            wb[nt][ks] = v;
+        }
+    }
+    auto load_a = [&](long tile, float4 (&v)[Q]) {
+        const long m = tile * 32 + c;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < M) v[q] = *reinterpret_cast<const float4 *>(a.d_act + m * K + p * KH + 4 * q);
+        }
+    };
+    float4 cur[Q], nxt[Q];
+    if (wave_id < ntile) load_a(wave_id, cur);
+    for (long tile = wave_id; tile < ntile; tile += nwave) {
+        if (tile + nwave < ntile) load_a(tile + nwave, nxt);
+        f32x16 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const float av[4] = {cur[q].x, cur[q].y, cur[q].z, cur[q].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], wb[nt][4 * q + e], acc[nt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long m = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * p;
+            if (m < M) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    if (32 * nt + c < D) a.d_x[m * D + 32 * nt + c] = acc[nt][r];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < Q; ++q) cur[q] = nxt[q];
+    }
+}
+
+static unsigned rowwise_grid(long M) {
+    const long ntile = (M + 31) / 32;
+    long wg = (ntile + RW_WAVES - 1) / RW_WAVES;
+    if (wg > 256) wg = 256;            // one persistent workgroup per CU (1 wave per SIMD: 3H..6H weight registers)
+    return (unsigned)(wg < 1 ? 1 : wg);
+}
+
+template <int K, int NT, int NS>
+static int launch_proj(const HpmnInputProj &a, hipStream_t st) {
+    const long ntile = ((long)a.B * a.T + 31) / 32;
+    long wg = (ntile * NS + RW_WAVES - 1) / RW_WAVES;
+    if (wg > 256) wg = 256;            // one persistent workgroup per CU, one wave per SIMD
+    const unsigned grid = (unsigned)(wg < 1 ? 1 : wg);
     if (a.x == nullptr)
-        hipLaunchKernelGGL((input_proj_kernel<D, true>), dim3(grid), dim3(threads), 0, st, a);
+        hipLaunchKernelGGL((input_proj_kernel<K, NT, NS, true>), dim3(grid), dim3(64 * RW_WAVES), 0, st, a);
     else
-        hipLaunchKernelGGL((input_proj_kernel<D, false>), dim3(grid), dim3(threads), 0, st, a);
+        hipLaunchKernelGGL((input_proj_kernel<K, NT, NS, false>), dim3(grid), dim3(64 * RW_WAVES), 0, st, a);
     return check_launch();
 }
 
@@ -116,13 +211,22 @@ bool input_proj_supported(int H, int D) {
 }
 
 int input_proj_dispatch(const HpmnInputProj &a, hipStream_t st) {
-    switch (a.D) {
-        case 16: return launch_proj<16>(a, st);
-        case 32: return launch_proj<32>(a, st);
-        case 48: return launch_proj<48>(a, st);
-        case 64: return launch_proj<64>(a, st);
-        default: return HPMN_EUNSUPPORTED;
-    }
+#define X(d) \
+    if (a.D == d) return a.H == 32 ? launch_proj<d, 3, 1>(a, st) : launch_proj<d, 3, 2>(a, st);
+    X(16) X(32) X(48) X(64)
+#undef X
+    return HPMN_EUNSUPPORTED;
+}
+
+int gru_dx_dispatch(const HpmnGruWgrad &a, hipStream_t st) {
+    const unsigned grid = rowwise_grid((long)a.B * a.T);
+    const int DT = (a.D + 31) / 32;
+    if (a.H == 32 && DT == 1) hipLaunchKernelGGL((gru_dx_kernel<96, 1>), dim3(grid), dim3(64 * RW_WAVES), 0, st, a);
+    else if (a.H == 32 && DT == 2) hipLaunchKernelGGL((gru_dx_kernel<96, 2>), dim3(grid), dim3(64 * RW_WAVES), 0, st, a);
+    else if (a.H == 64 && DT == 1) hipLaunchKernelGGL((gru_dx_kernel<192, 1>), dim3(grid), dim3(64 * RW_WAVES), 0, st, a);
+    else if (a.H == 64 && DT == 2) hipLaunchKernelGGL((gru_dx_kernel<192, 2>), dim3(grid), dim3(64 * RW_WAVES), 0, st, a);
+    else return HPMN_EUNSUPPORTED;
+    return check_launch();
 }
 
 }  // namespace hpmn
