@@ -13,6 +13,7 @@ int gru_scan_bwd_dispatch(const HpmnGruBwd &a, hipStream_t st);
 bool input_proj_supported(int H, int D);
 int input_proj_dispatch(const HpmnInputProj &a, hipStream_t st);
 int gru_wgrad_dispatch(const HpmnGruWgrad &a, hipStream_t st);
+int gru_dx_dispatch(const HpmnGruWgrad &a, hipStream_t st);
 size_t gru_wgrad_workspace_bytes(int B, int T, int D, int H);
 size_t read_workspace_bytes(const HpmnReadDesc &d);
 int read_fwd_launch(const HpmnReadDesc &d, const float *P, const float *memory, const float *last, float *pred,
@@ -131,6 +132,18 @@ int hpmn_gru_param_grads(const HpmnGruWgrad *a, void *stream) {
         !a->d_bc || !a->workspace)
         return HPMN_EINVAL;
     return gru_wgrad_dispatch(*a, (hipStream_t)stream);
+}
+
+int hpmn_gru_input_grad(const float *d_act, const float *wg, const float *wc, float *d_x, int32_t B, int32_t T,
+                        int32_t D, int32_t H, void *stream) {
+    if (B < 0 || T < 1 || D < 1 || H < 1) return HPMN_EINVAL;
+    if (!gru_shape_supported(H, D) || !input_proj_supported(H, D)) return HPMN_EUNSUPPORTED;
+    if (B == 0) return HPMN_OK;
+    if (!d_act || !wg || !wc || !d_x) return HPMN_EINVAL;
+    HpmnGruWgrad a = {};
+    a.B = B; a.T = T; a.D = D; a.H = H;
+    a.d_act = d_act; a.wg = wg; a.wc = wc; a.d_x = d_x;
+    return gru_dx_dispatch(a, (hipStream_t)stream);
 }
 
 // workspace carve of hpmn_scan_fwd: [xp: B*T0*3H] [y0: B*(T0/p0)*H] [y1: same]

@@ -130,6 +130,9 @@ struct ReadSmem {
     float *t3;       // scratch [RS*K] / [RS]
     float *dq;       // [RS][H]
     float *drep;     // [RS][H+D0]
+    float *cmean;    // [RS*K]        slot means (covariance regulariser)
+    float *ccov;     // [RS*K*K]      off-diagonal covariance
+    float *cnorm;    // [RS]          Frobenius norms
 };
 
 __host__ __device__ inline size_t read_smem_floats(int K, int H, int D0, int hop, bool train) {
@@ -138,6 +141,7 @@ __host__ __device__ inline size_t read_smem_floats(int K, int H, int D0, int hop
                (size_t)RS * (H + D0) + (size_t)RS * (F1 + F2);
     if (train) n += RK * H + RK * (A1 + A2 + 1) + (size_t)RS * H + (size_t)RS * (H + D0) + 64;
     else n += 64;
+    n += RK + RK * K + RS + 16;
     return n + 64;
 }
 
@@ -156,6 +160,9 @@ __device__ inline void carve(ReadSmem &s, float *base, int K, int H, int D0, int
     s.h1 = take((size_t)RS * F1);
     s.h2 = take((size_t)RS * F2);
     s.t3 = take(64);
+    s.cmean = take((size_t)RK);
+    s.ccov = take((size_t)RK * K);
+    s.cnorm = take(RS);
     if (train) {
         s.dmem = take((size_t)RK * H);
         s.t1 = take((size_t)RK * A1 > (size_t)RS * F1 ? (size_t)RK * A1 : (size_t)RS * F1);
@@ -216,25 +223,32 @@ __device__ void read_forward_tile(const HpmnReadDesc &d, const float *P, const R
         }
         __syncthreads();
     }
-    // covariance regulariser (code/hpmn.py:161-170): per-sample Frobenius norm of the off-diagonal cov
-    if (tid < R) {
-        const float *m = s.mem + (size_t)tid * K * H;
-        float mean[MAXK];
-        for (int k = 0; k < K; ++k) {
-            float a = 0.f;
-            for (int i = 0; i < H; ++i) a += m[k * H + i];
-            mean[k] = a / H;
+    // covariance regulariser (code/hpmn.py:161-170): per-sample Frobenius norm of the off-diagonal cov.
+    // Parallel over (sample, slot[, slot]); means / covariances stay in LDS for the backward.
+    for (int o = tid; o < RK; o += RT) {
+        float a = 0.f;
+        for (int i = 0; i < H; ++i) a += s.mem[o * H + i];
+        s.cmean[o] = a / H;
+    }
+    __syncthreads();
+    for (int o = tid; o < RK * K; o += RT) {
+        const int rk = o / K, j = o - rk * K;       // rk = r*K + k
+        const int r = rk / K, k = rk - r * K;
+        float cv = 0.f;
+        if (j != k) {
+            const float *mk = s.mem + (size_t)rk * H, *mj = s.mem + (size_t)(r * K + j) * H;
+            const float ak = s.cmean[rk], aj = s.cmean[r * K + j];
+            for (int i = 0; i < H; ++i) cv = fmaf(mk[i] - ak, mj[i] - aj, cv);
+            cv /= H;
         }
+        s.ccov[o] = cv;
+    }
+    __syncthreads();
+    if (tid < R) {
         float ss = 0.f;
-        for (int k = 0; k < K; ++k)
-            for (int j = 0; j < K; ++j) {
-                if (j == k) continue;
-                float c = 0.f;
-                for (int i = 0; i < H; ++i) c = fmaf(m[k * H + i] - mean[k], m[j * H + i] - mean[j], c);
-                c /= H;
-                ss += c * c;
-            }
-        cov_sum[tid] = sqrtf(ss);
+        for (int o = 0; o < K * K; ++o) { const float cv = s.ccov[tid * K * K + o]; ss = fmaf(cv, cv, ss); }
+        s.cnorm[tid] = sqrtf(ss);
+        cov_sum[tid] = s.cnorm[tid];
     }
     // head (code/hpmn.py:190-199): repre = [q, last]; bn (inference affine); fc1 elu; dropout; fc2 elu; dropout; fc3
     const float *qf = s.q + (size_t)d.hop * RS * H;
@@ -385,35 +399,20 @@ __global__ __launch_bounds__(RT) void read_fwd_bwd_kernel(const HpmnReadDesc d, 
     // C = cc^T / H with c = m - mean_H(m):  d m = (2/(H*norm)) * (C_off c) projected off the mean
     for (int o = tid; o < RK * H; o += RT) s.dmem[o] = 0.f;
     __syncthreads();
-    if (tid < R && memory_reg != 0.f) {
-        const float *m = s.mem + (size_t)tid * K * H;
-        float *dm = s.dmem + (size_t)tid * K * H;
-        const float nrm = cov[tid];
-        if (nrm > 0.f) {
-            float mean[MAXK], C[MAXK][MAXK];
-            for (int k = 0; k < K; ++k) {
-                float a = 0.f;
-                for (int i = 0; i < H; ++i) a += m[k * H + i];
-                mean[k] = a / H;
+    if (memory_reg != 0.f) {
+        // dL/dC_kj = C_kj / nrm (off-diagonal); dL/dc_k = (2/H) sum_j dC_kj c_j; the mean subtraction is a
+        // projection that leaves it unchanged because sum_i c_j[i] = 0
+        for (int o = tid; o < RK * H; o += RT) {
+            const int rk = o / H, i = o - rk * H;
+            const int r = rk / K;
+            const float nrm = s.cnorm[r];
+            float acc = 0.f;
+            if (nrm > 0.f) {
+                for (int j = 0; j < K; ++j)
+                    acc = fmaf(s.ccov[rk * K + j], s.mem[(size_t)(r * K + j) * H + i] - s.cmean[r * K + j], acc);
+                acc *= memory_reg * 2.f / (H * nrm);
             }
-            for (int k = 0; k < K; ++k)
-                for (int j = 0; j < K; ++j) {
-                    float c = 0.f;
-                    if (j != k) {
-                        for (int i = 0; i < H; ++i) c = fmaf(m[k * H + i] - mean[k], m[j * H + i] - mean[j], c);
-                        c /= H;
-                    }
-                    C[k][j] = c;
-                }
-            // dL/dC_kj = C_kj / nrm (off-diagonal); dL/dc_k = (1/H) sum_j (dC_kj + dC_jk) c_j = (2/H) sum_j dC_kj c_j
-            // the mean subtraction projects: dm_k = dc_k - mean_i(dc_k); sum_i c_j[i] = 0 so the projection is a no-op
-            const float sc = memory_reg * 2.f / (H * nrm);
-            for (int k = 0; k < K; ++k)
-                for (int i = 0; i < H; ++i) {
-                    float a = 0.f;
-                    for (int j = 0; j < K; ++j) a = fmaf(C[k][j], m[j * H + i] - mean[j], a);
-                    dm[k * H + i] = sc * a;
-                }
+            s.dmem[o] = acc;
         }
     }
     __syncthreads();

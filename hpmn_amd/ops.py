@@ -171,8 +171,9 @@ def gru_scan_bwd(wg, wc, D, hs, gates, d_h_last, d_y, period):
     return d_act
 
 
-def gru_param_grads(x, hs, gates, d_act, wg, wc, d_wg, d_bg, d_wc, d_bc, want_dx=True):
-    """hpmn_gru_param_grads: accumulates into d_wg/d_bg/d_wc/d_bc (caller-zeroed), returns dx or None."""
+def gru_param_grads(x, hs, gates, d_act, wg, wc, d_wg, d_bg, d_wc, d_bc, want_dx=True, keep=None):
+    """hpmn_gru_param_grads: accumulates into d_wg/d_bg/d_wc/d_bc (caller-zeroed), returns dx or None.
+    ``keep``: list that receives the temporaries (workspace) when the call is issued on a side stream."""
     B, T, D = x.shape
     H = hs.shape[2]
     _chk_f32(x, hs, gates, d_act, wg, wc, d_wg, d_bg, d_wc, d_bc)
@@ -188,9 +189,22 @@ def gru_param_grads(x, hs, gates, d_act, wg, wc, d_wg, d_bg, d_wc, d_bc, want_dx
     lib = _lib.load()
     ws = torch.empty(lib.hpmn_gru_param_grads_workspace_bytes(B, T, D, H) // 4, device=x.device,
                      dtype=torch.float32)
+    if keep is not None:
+        keep.append(ws)
     a.workspace = ws.data_ptr()
     rc = lib.hpmn_gru_param_grads(C.byref(a), _stream())
     _lib.check(rc, "hpmn_gru_param_grads")
+    return d_x
+
+
+def gru_input_grad(d_act, wg, wc, D):
+    """hpmn_gru_input_grad: dx [B,T,D] = d_act [Wg[:D] | Wc[:D]]^T."""
+    B, T, H3 = d_act.shape
+    _chk_f32(d_act, wg, wc)
+    d_x = torch.empty(B, T, D, device=d_act.device, dtype=torch.float32)
+    rc = _lib.load().hpmn_gru_input_grad(d_act.data_ptr(), wg.data_ptr(), wc.data_ptr(), d_x.data_ptr(),
+                                          B, T, D, H3 // 3, _stream())
+    _lib.check(rc, "hpmn_gru_input_grad")
     return d_x
 
 
@@ -272,23 +286,46 @@ def scan_forward_train(spec: ScanSpec, ids, emb, weights: Sequence[torch.Tensor]
     return memory, last, saved
 
 
+_side_streams = {}
+
+
+def _side_stream(device) -> "torch.cuda.Stream":
+    key = str(device)
+    st = _side_streams.get(key)
+    if st is None:
+        st = _side_streams[key] = torch.cuda.Stream(device=device)
+    return st
+
+
 def scan_backward(spec: ScanSpec, ids, saved, weights: Sequence[torch.Tensor], d_memory, d_last, grad_out):
     """BPTT of scan_forward_train.  ``grad_out`` = [d_emb, d_wg0, d_bg0, d_wc0, d_bc0, d_wg1, ...]:
-    pre-zeroed buffers (views of the optimiser's flat gradient) that are accumulated into."""
+    pre-zeroed buffers (views of the optimiser's flat gradient) that are accumulated into.
+
+    The serial chain is scan_bwd(K-1) -> dx(K-1) -> scan_bwd(K-2) -> ... -> dx(0) -> scatter; the weight
+    gradient of a layer is off that chain, so it runs on a second HIP stream underneath the next layer's
+    reverse scan (which occupies one wave on half of the SIMDs)."""
     K = spec.K
     d_emb, gw = grad_out[0], list(grad_out[1:])
+    main = torch.cuda.current_stream()
+    side = _side_stream(d_memory.device)
+    keep = []                    # tensors the side stream still reads: freed only after the join below
     d_y = None
     for i in range(K - 1, -1, -1):
         wg, bg, wc, bc = weights[4 * i:4 * i + 4]
         x_in, hs, gates = saved[i]
         D = x_in.shape[2]
         d_act = gru_scan_bwd(wg, wc, D, hs, gates, d_memory[:, i, :], d_y, spec.periods[i])
-        d_y = gru_param_grads(x_in, hs, gates, d_act, wg, wc, gw[4 * i], gw[4 * i + 1], gw[4 * i + 2],
-                              gw[4 * i + 3], want_dx=True)
-        del d_act
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            gru_param_grads(x_in, hs, gates, d_act, wg, wc, gw[4 * i], gw[4 * i + 1], gw[4 * i + 2], gw[4 * i + 3],
+                            want_dx=False, keep=keep)
+        d_y = gru_input_grad(d_act, wg, wc, D)
+        keep.append(d_act)
     d_x0 = d_y
     d_x0[:, spec.last_index, :] += d_last
     embed_grad_scatter(ids, d_x0, d_emb, spec.front_zero, spec.mask_id0)
+    main.wait_stream(side)
+    del keep
 
 
 # ---------------------------------------------------------------------------------------

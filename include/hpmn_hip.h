@@ -157,6 +157,10 @@ typedef struct HpmnGruWgrad {
 
 size_t hpmn_gru_param_grads_workspace_bytes(int32_t B, int32_t T, int32_t D, int32_t H);
 int hpmn_gru_param_grads(const HpmnGruWgrad *args, void *stream);
+/* Only the input gradient d_x [B,T,D] = d_act [B,T,3H] [wg[0:D] | wc[0:D]]^T (the part of the above that
+ * is on BPTT's serial chain; the caller may run hpmn_gru_param_grads with d_x == NULL on another stream). */
+int hpmn_gru_input_grad(const float *d_act, const float *wg, const float *wc, float *d_x,
+                        int32_t B, int32_t T, int32_t D, int32_t H, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Whole build_memory forward (code/hpmn.py:113-129 without the covariance loss): K
