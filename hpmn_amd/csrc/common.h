@@ -38,6 +38,14 @@ __device__ __forceinline__ float fast_tanh(float x) {
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
+// Make a register-stationary value "defined here" for the compiler's s_waitcnt bookkeeping.  Weights
+// are loaded once before the time loop; without this the waitcnt pass keeps treating them as results of
+// still-pending loads on the loop back-edge and emits s_waitcnt vmcnt(0..2) in front of their uses in
+// EVERY step, which drains the step's own prefetch loads and output stores (an HBM round trip on the
+// serial chain; seen in the ISA of the scan kernels).
+__device__ __forceinline__ void settle(float &x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void settle(f2 &x) { asm volatile("" : "+v"(x)); }
+
 // acc0/acc1 += sum over NQ float4's of a wave-uniform LDS row (a broadcast) times the lane's packed
 // weights w[2*q], w[2*q+1] (pairs over consecutive k).  The LDS reads are software-pipelined in
 // groups of G float4 (G reads in flight while the previous group's packed FMAs issue) and fenced

@@ -43,6 +43,10 @@ __global__ __launch_bounds__(64, 1) void gru_scan_bwd_kernel(const HpmnGruBwd a)
     for (int n = 0; n < H / 2; ++n) wcT[n] = *reinterpret_cast<const f2 *>(a.wc + (long)(D + l) * H + 2 * n);
 #pragma unroll
     for (int n = 0; n < H; ++n) wgT[n] = *reinterpret_cast<const f2 *>(a.wg + (long)(D + l) * 2 * H + 2 * n);
+#pragma unroll
+    for (int n = 0; n < H / 2; ++n) settle(wcT[n]);
+#pragma unroll
+    for (int n = 0; n < H; ++n) settle(wgT[n]);
 
     const int period = a.period;
     const bool has_dy = a.d_y != nullptr;

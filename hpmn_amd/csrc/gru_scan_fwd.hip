@@ -19,6 +19,11 @@
 //     (v_pk_fma_f32 over two consecutive k: 3H/2 instructions per step instead of 3H) with
 //     the broadcast operands (h_{t-1}, r*h_{t-1}) read from LDS as wave-uniform 16-byte
 //     loads, each feeding two packed FMAs.
+//   * NOT splitting a sequence over several waves is deliberate: a 4-wave, K-split variant with DPP
+//     row broadcasts (no LDS broadcast reads, 48 weights per lane) was built and measured -- each
+//     cross-wave partial-sum exchange (ds_write, s_barrier, ds_read) costs ~380 cycles against ~110
+//     for the in-wave LDS round trip (tools/micro: "wg4" rows), and the step needs two of them:
+//     0.71 ms vs 0.67 ms for this kernel at layer 0 of C3.
 #include "common.h"
 
 namespace hpmn {
@@ -54,6 +59,8 @@ __global__ __launch_bounds__(64, 1) void gru_scan_fwd_kernel(const HpmnGruFwd a)
         whu[k] = f2{a.wg[(long)(D + 2 * k) * 2 * H + H + l], a.wg[(long)(D + 2 * k + 1) * 2 * H + H + l]};
         whc[k] = f2{a.wc[(long)(D + 2 * k) * H + l], a.wc[(long)(D + 2 * k + 1) * H + l]};
     }
+#pragma unroll
+    for (int k = 0; k < H / 2; ++k) { settle(whr[k]); settle(whu[k]); settle(whc[k]); }
 
     // chunk staging: float2 i of lane (s,l) covers elements e = 2*(i*H + l), e+1 of the sequence's
     // [CS x 3H] chunk image, i.e. row e / 3H, column e % 3H.  Rows past the end are clamped to T-1

@@ -131,6 +131,66 @@ __global__ void k_lat(float* out, long long* cyc, const float* in, int iters) {
     if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
+// 4-wave workgroup probes (the 4-waves-per-sequence scan): V=0 partial-sum exchange through LDS with a
+// barrier; V=1 the same + rep_row + 32 dpp fmacs (the gates half of a step); V=2 a full synthetic step
+template <int V>
+__global__ __launch_bounds__(256) void k_wg4(float* out, long long* cyc, const float* in, int iters) {
+    __shared__ __attribute__((aligned(16))) float pg[2][64][4];
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    float h = in[l];
+    float wr[16], wu[16];
+    for (int j = 0; j < 16; ++j) { wr[j] = in[64 + j] * (1 + w); wu[j] = in[128 + j]; }
+    for (int j = 0; j < 16; ++j) { asm volatile("" : "+v"(wr[j])); asm volatile("" : "+v"(wu[j])); }
+    long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+        float a = h, b2 = h;
+        if constexpr (V >= 1) {
+            unsigned x = __builtin_bit_cast(unsigned, h);
+            auto r32 = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+            unsigned src = (w & 2) ? r32[1] : r32[0];
+            auto r16 = __builtin_amdgcn_permlane16_swap(src, src, false, false);
+            float q = __builtin_bit_cast(float, (w & 1) ? r16[1] : r16[0]);
+            float a0 = 0, a1 = 0, c0 = 0, c1 = 0;
+#define D16(A0, A1, W) asm("s_nop 1\n" \
+            "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n v_fmac_f32_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
+            "v_fmac_f32_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n v_fmac_f32_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+            "v_fmac_f32_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n v_fmac_f32_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+            "v_fmac_f32_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n v_fmac_f32_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
+            "v_fmac_f32_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n v_fmac_f32_dpp %1, %2, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n" \
+            "v_fmac_f32_dpp %0, %2, %13 row_newbcast:10 row_mask:0xf bank_mask:0xf\n v_fmac_f32_dpp %1, %2, %14 row_newbcast:11 row_mask:0xf bank_mask:0xf\n" \
+            "v_fmac_f32_dpp %0, %2, %15 row_newbcast:12 row_mask:0xf bank_mask:0xf\n v_fmac_f32_dpp %1, %2, %16 row_newbcast:13 row_mask:0xf bank_mask:0xf\n" \
+            "v_fmac_f32_dpp %0, %2, %17 row_newbcast:14 row_mask:0xf bank_mask:0xf\n v_fmac_f32_dpp %1, %2, %18 row_newbcast:15 row_mask:0xf bank_mask:0xf\n" \
+            : "+v"(A0), "+v"(A1) : "v"(q), "v"(W[0]), "v"(W[1]), "v"(W[2]), "v"(W[3]), "v"(W[4]), "v"(W[5]), "v"(W[6]), "v"(W[7]), \
+              "v"(W[8]), "v"(W[9]), "v"(W[10]), "v"(W[11]), "v"(W[12]), "v"(W[13]), "v"(W[14]), "v"(W[15]))
+            D16(a0, a1, wr);
+            D16(c0, c1, wu);
+            a = a0 + a1; b2 = c0 + c1;
+        }
+        pg[0][l][w] = a;
+        pg[1][l][w] = b2;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const float4 sr = *reinterpret_cast<const float4*>(pg[0][l]);
+        const float4 su = *reinterpret_cast<const float4*>(pg[1][l]);
+        float r = (sr.x + sr.y) + (sr.z + sr.w), u = (su.x + su.y) + (su.z + su.w);
+        if constexpr (V >= 2) {
+            r = __builtin_amdgcn_rcpf(1.0f + __expf(-r));
+            u = __builtin_amdgcn_rcpf(1.0f + __expf(-u));
+        }
+        h = r * 0.25f + u * 0.125f;
+        // second barrier of the step (candidate partials)
+        if constexpr (V >= 2) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+    }
+    long long t1 = __builtin_amdgcn_s_memtime();
+    out[threadIdx.x + 256 * blockIdx.x] = h;
+    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
 template <typename F>
 static double run(F launch, long long* d_cyc, int blocks) {
     launch();
@@ -161,8 +221,8 @@ int main() {
     long long* d_cyc;
     const int blocks = 256;   // 1 wave per CU
     CK(hipMalloc(&d_in, 4096));
-    CK(hipMalloc(&d_out, 64 * blocks * 4 * 8));
-    CK(hipMalloc(&d_cyc, blocks * 8 * 8));
+    CK(hipMalloc(&d_out, 256 * 512 * 4 * 2));
+    CK(hipMalloc(&d_cyc, 512 * 8 * 8));
     std::vector<float> hin(1024, 0.001f);
     CK(hipMemcpy(d_in, hin.data(), 4096, hipMemcpyHostToDevice));
     const int iters = 2000;
@@ -185,6 +245,12 @@ int main() {
     LT(1, "4 x ds_bpermute");
     LT(2, "permlane32 + 2x permlane16");
     LT(3, "sigmoid (exp+rcp)");
+#define W4(V, nb, label) c = run([&] { hipLaunchKernelGGL((k_wg4<V>), dim3(nb), dim3(256), 0, 0, d_out, d_cyc, d_in, iters); }, d_cyc, nb); \
+    printf("wg4  %-34s: %.1f ticks/iter\n", label, c / iters);
+    W4(0, 250, "lds exchange + barrier (250 WG)");
+    W4(0, 500, "lds exchange + barrier (500 WG)");
+    W4(1, 500, "+rep_row + 32 dpp fmac (500 WG)");
+    W4(2, 500, "+2 sigmoid + 2nd barrier (500 WG)");
     // calibrate tick vs wall: time a known-length kernel with events
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
