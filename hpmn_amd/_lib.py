@@ -28,6 +28,7 @@ class HpmnInputProj(C.Structure):
         ("V", C.c_int64),
         ("wg", C.c_void_p), ("bg", C.c_void_p), ("wc", C.c_void_p), ("bc", C.c_void_p),
         ("xp", C.c_void_p), ("x_out", C.c_void_p),
+        ("t_begin", C.c_int32), ("t_len", C.c_int32),
     ]
 
 
@@ -38,6 +39,8 @@ class HpmnGruFwd(C.Structure):
         ("h_last", C.c_void_p), ("h_last_stride", C.c_int64),
         ("y", C.c_void_p), ("period", C.c_int32),
         ("hs", C.c_void_p), ("gates", C.c_void_p),
+        ("t_begin", C.c_int32), ("t_end", C.c_int32),
+        ("h_init", C.c_void_p), ("h_init_stride", C.c_int64),
     ]
 
 
@@ -49,6 +52,8 @@ class HpmnGruBwd(C.Structure):
         ("d_h_last", C.c_void_p), ("d_h_last_stride", C.c_int64),
         ("d_y", C.c_void_p), ("period", C.c_int32),
         ("d_act", C.c_void_p),
+        ("t_begin", C.c_int32), ("t_end", C.c_int32),
+        ("dh_carry", C.c_void_p),
     ]
 
 
@@ -61,6 +66,7 @@ class HpmnGruWgrad(C.Structure):
         ("d_x", C.c_void_p),
         ("workspace", C.c_void_p),
         ("seq_per_wg", C.c_int32),
+        ("t_begin", C.c_int32), ("t_len", C.c_int32),
     ]
 
 
@@ -99,7 +105,7 @@ SIGNATURES = {
     "hpmn_gru_param_grads_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "hpmn_gru_param_grads": (C.c_int, [C.POINTER(HpmnGruWgrad), C.c_void_p]),
     "hpmn_gru_input_grad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
-                                      C.c_int32, C.c_void_p]),
+                                      C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "hpmn_scan_workspace_bytes": (C.c_size_t, [C.POINTER(HpmnScanDesc)]),
     "hpmn_scan_fwd": (C.c_int, [C.POINTER(HpmnScanDesc), C.c_void_p, C.c_void_p,
                                 C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),

@@ -88,6 +88,7 @@ int hpmn_gru_input_proj(const HpmnInputProj *a, void *stream) {
             return HPMN_EINVAL;
         if (a->E % 4 != 0) return HPMN_EUNSUPPORTED;
     }
+    if (a->t_begin < 0 || a->t_len < 0 || a->t_begin + a->t_len > a->T) return HPMN_EINVAL;
     if (!input_proj_supported(a->H, a->D)) return HPMN_EUNSUPPORTED;
     if (a->B == 0) return HPMN_OK;
     return input_proj_dispatch(*a, (hipStream_t)stream);
@@ -99,6 +100,8 @@ int hpmn_gru_scan_fwd(const HpmnGruFwd *a, void *stream) {
     if (!a->xp || !a->wg || !a->wc || !a->h_last) return HPMN_EINVAL;
     if ((a->hs == nullptr) != (a->gates == nullptr)) return HPMN_EINVAL;
     if (a->y && (a->period < 1 || a->T % a->period != 0)) return HPMN_EINVAL;
+    if (a->t_begin < 0 || a->t_end < 0 || a->t_end > a->T || (a->t_end > 0 && a->t_end <= a->t_begin)) return HPMN_EINVAL;
+    if (a->t_begin % 2 != 0 || (a->period > 0 && a->t_begin % a->period != 0)) return HPMN_EINVAL;
     if (!gru_shape_supported(a->H, a->D)) return HPMN_EUNSUPPORTED;
     if (a->B == 0) return HPMN_OK;
     HpmnGruFwd k = *a;
@@ -111,6 +114,12 @@ int hpmn_gru_scan_bwd(const HpmnGruBwd *a, void *stream) {
     if (a->B < 0 || a->T < 1 || a->D < 1 || a->H < 1) return HPMN_EINVAL;
     if (!a->wg || !a->wc || !a->hs || !a->gates || !a->d_h_last || !a->d_act) return HPMN_EINVAL;
     if (a->d_y && (a->period < 1 || a->T % a->period != 0)) return HPMN_EINVAL;
+    {
+        const int t_hi = a->t_end > 0 ? a->t_end : a->T;
+        if (a->t_begin < 0 || t_hi > a->T || t_hi <= a->t_begin) return HPMN_EINVAL;
+        if ((t_hi < a->T || a->t_begin > 0) && !a->dh_carry) return HPMN_EINVAL;
+        if (a->d_y && t_hi % a->period != 0) return HPMN_EINVAL;
+    }
     if (!gru_shape_supported(a->H, a->D)) return HPMN_EUNSUPPORTED;
     if (a->B == 0) return HPMN_OK;
     HpmnGruBwd k = *a;
@@ -135,14 +144,15 @@ int hpmn_gru_param_grads(const HpmnGruWgrad *a, void *stream) {
 }
 
 int hpmn_gru_input_grad(const float *d_act, const float *wg, const float *wc, float *d_x, int32_t B, int32_t T,
-                        int32_t D, int32_t H, void *stream) {
-    if (B < 0 || T < 1 || D < 1 || H < 1) return HPMN_EINVAL;
+                        int32_t D, int32_t H, int32_t t_begin, int32_t t_len, void *stream) {
+    if (B < 0 || T < 1 || D < 1 || H < 1 || t_begin < 0 || t_len < 0 || t_begin + t_len > T) return HPMN_EINVAL;
     if (!gru_shape_supported(H, D) || !input_proj_supported(H, D)) return HPMN_EUNSUPPORTED;
     if (B == 0) return HPMN_OK;
     if (!d_act || !wg || !wc || !d_x) return HPMN_EINVAL;
     HpmnGruWgrad a = {};
     a.B = B; a.T = T; a.D = D; a.H = H;
     a.d_act = d_act; a.wg = wg; a.wc = wc; a.d_x = d_x;
+    a.t_begin = t_begin; a.t_len = t_len;
     return gru_dx_dispatch(a, (hipStream_t)stream);
 }
 

@@ -54,7 +54,11 @@ __global__ __launch_bounds__(64, 1) void gru_scan_bwd_kernel(const HpmnGruBwd a)
     const float *hsb = a.hs + b * (long)(T + 1) * H;
     const float *dyb = has_dy ? a.d_y + b * (long)(T / period) * H + l : nullptr;
 
-    // chunk q covers steps t in [T - BCS*(q+1), T - BCS*q); float2 i of lane (s,l) covers elements
+    // steps t_hi-1 .. t_lo0 of this launch, walking backwards (whole sequence unless time-chunked)
+    const int t_lo0 = a.t_begin;
+    const int t_hi = a.t_end > 0 ? a.t_end : T;
+
+    // chunk q covers steps t in [t_hi - BCS*(q+1), t_hi - BCS*q); float2 i of lane (s,l) covers elements
     // e = 2*(i*H + l), e+1 of the [BCS x 3H] gates image; the [BCS x H] h_prev image takes one float2.
     // Rows with t < 0 (tail chunk / run-ahead past the start) are clamped to 0: loaded, never consumed.
     int g_row[3], g_col[3];
@@ -67,11 +71,12 @@ __global__ __launch_bounds__(64, 1) void gru_scan_bwd_kernel(const HpmnGruBwd a)
     const int h_row = (2 * l) / H, h_col = 2 * l - h_row * H;
     // incoming output gradients: d_y row j belongs to step (j+1)*period - 1; walking backwards the
     // prefetch stream keeps "the next step that has one" instead of dividing every step
-    int pf_fire = T - 1, pf_row = T / period - 1;
+    // (t_hi is a multiple of period, so step t_hi-1 has one)
+    int pf_fire = t_hi - 1, pf_row = t_hi / period - 1;
 
     struct Pre { f2 g[3]; f2 hp; float dy[BCS]; };
     auto load_chunk = [&](int q, Pre &p) {
-        const int t_lo = T - BCS * (q + 1);
+        const int t_lo = t_hi - BCS * (q + 1);
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             int t = t_lo + g_row[i];
@@ -102,7 +107,7 @@ __global__ __launch_bounds__(64, 1) void gru_scan_bwd_kernel(const HpmnGruBwd a)
         for (int tt = 0; tt < BCS; ++tt) dring[q % BRING][tt * 64 + lane] = p.dy[tt];
     };
 
-    const int nchunk = (T + BCS - 1) / BCS;
+    const int nchunk = (t_hi - t_lo0 + BCS - 1) / BCS;
     {
         Pre p;
 #pragma unroll
@@ -111,13 +116,13 @@ __global__ __launch_bounds__(64, 1) void gru_scan_bwd_kernel(const HpmnGruBwd a)
             park_chunk(q, p);
         }
     }
-    float dh = a.d_h_last[b * a.d_h_last_stride + l];
+    float dh = (t_hi == T) ? a.d_h_last[b * a.d_h_last_stride + l] : a.dh_carry[b * H + l];
     wave_sync();
 
     for (int q = 0; q < nchunk; ++q) {
         Pre pre;
         load_chunk(q + BPD, pre);
-        const int t_lo = T - BCS * (q + 1);
+        const int t_lo = t_hi - BCS * (q + 1);
         const float *gc = &gring[q % BRING][s * GF + l];
         const float *hc = &hring[q % BRING][s * HF + l];
         const float *dc = &dring[q % BRING][lane];
@@ -125,7 +130,7 @@ __global__ __launch_bounds__(64, 1) void gru_scan_bwd_kernel(const HpmnGruBwd a)
         for (int jj = 0; jj < BCS; ++jj) {
             const int tt = BCS - 1 - jj;       // row inside the chunk, walking backwards in time
             const int t = t_lo + tt;
-            if (t >= 0) {
+            if (t >= t_lo0) {
                 const float r = gc[tt * 3 * H], u = gc[tt * 3 * H + H], c = gc[tt * 3 * H + 2 * H];
                 const float hp = hc[tt * H];
                 dh += dc[tt * 64];
@@ -156,6 +161,7 @@ __global__ __launch_bounds__(64, 1) void gru_scan_bwd_kernel(const HpmnGruBwd a)
         park_chunk(q + BPD, pre);
         wave_sync();
     }
+    if (live && t_lo0 > 0) a.dh_carry[b * H + l] = dh;
 }
 
 int gru_scan_bwd_dispatch(const HpmnGruBwd &a, hipStream_t st) {

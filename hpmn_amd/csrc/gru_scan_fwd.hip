@@ -87,39 +87,42 @@ __global__ __launch_bounds__(64, 1) void gru_scan_fwd_kernel(const HpmnGruFwd a)
         for (int i = 0; i < 3; ++i) *reinterpret_cast<f2 *>(dst + 2 * (i * H + l)) = v[i];
     };
 
-    const int nchunk = (T + CS - 1) / CS;
+    // steps [t0, t1) of this launch (whole sequence unless the caller pipelines layers in time chunks)
+    const int t0 = a.t_begin;
+    const int t1 = a.t_end > 0 ? a.t_end : T;
+    const int c_begin = t0 / CS, c_end = (t1 + CS - 1) / CS;
     {
         f2 v[3];
 #pragma unroll
         for (int c = 0; c < PD; ++c) {
-            load_chunk(c, v);
-            park_chunk(c, v);
+            load_chunk(c_begin + c, v);
+            park_chunk(c_begin + c, v);
         }
     }
 
-    float h = 0.f;
-    hb[lane] = 0.f;
+    float h = a.h_init != nullptr ? a.h_init[b * a.h_init_stride + l] : 0.f;
+    hb[lane] = h;
     if constexpr (TRAIN) {
-        if (live) a.hs[(b * (T + 1)) * H + l] = 0.f;
+        if (live && t0 == 0) a.hs[(b * (T + 1)) * H + l] = 0.f;
     }
     wave_sync();
 
     // subsampled outputs y[:, j] = outputs[:, (j+1)*period - 1]: running "next firing step" counter
     const int period = a.period;
     const bool has_y = a.y != nullptr;
-    int next_fire = period - 1;
-    float *yp = has_y ? a.y + (b * (long)(T / period)) * H + l : nullptr;
-    float *hsp = TRAIN ? a.hs + (b * (long)(T + 1) + 1) * H + l : nullptr;
-    float *gp = TRAIN ? a.gates + (b * (long)T) * 3 * H + l : nullptr;
+    int next_fire = t0 + period - 1;                                    // t0 is a multiple of period
+    float *yp = has_y ? a.y + (b * (long)(T / period) + t0 / period) * H + l : nullptr;
+    float *hsp = TRAIN ? a.hs + (b * (long)(T + 1) + t0 + 1) * H + l : nullptr;
+    float *gp = TRAIN ? a.gates + (b * (long)T + t0) * 3 * H + l : nullptr;
 
-    for (int c = 0; c < nchunk; ++c) {
+    for (int c = c_begin; c < c_end; ++c) {
         f2 pre[3];
         load_chunk(c + PD, pre);          // in flight for the steps below
         const float *xc = &ring[c % RING][s * CF + l];
 #pragma unroll
         for (int tt = 0; tt < CS; ++tt) {
             const int t = c * CS + tt;
-            if (t < T) {
+            if (t < t1) {
                 const float xr = xc[tt * 3 * H], xu = xc[tt * 3 * H + H], xcand = xc[tt * 3 * H + 2 * H];
                 f2 ar = {0.f, 0.f}, au = {0.f, 0.f};
                 bcast_matvec2<H / 4>(reinterpret_cast<const float4 *>(&hb[s * H]), whr, whu, ar, au);

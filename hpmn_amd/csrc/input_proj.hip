@@ -32,8 +32,11 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void input_proj_kernel(const Hpmn
     const int lane = threadIdx.x & 63;
     const int c = lane & 31, p = lane >> 5;
     const int H = a.H, N = 3 * H;
-    const long M = (long)a.B * a.T;
+    // rows of this launch: steps [t_begin, t_begin+TL) of every sequence; row r -> (b, t) -> flat row m = b*T + t
+    const int TL = a.t_len > 0 ? a.t_len : a.T;
+    const long M = (long)a.B * TL;
     const long ntile = (M + 31) / 32;
+    auto flat_row = [&](long r) -> long { const long b = r / TL; return b * a.T + a.t_begin + (r - b * TL); };
     const long gwave = (long)blockIdx.x * RW_WAVES + (threadIdx.x >> 6);
     const int ns = (int)(gwave % NS);              // which column group
     const long wave_id = gwave / NS;
@@ -55,8 +58,9 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void input_proj_kernel(const Hpmn
     }
 
     auto load_a = [&](long tile, float4 (&v)[Q]) {
-        const long m = tile * 32 + c;
-        const bool ok = m < M;
+        const long rr = tile * 32 + c;
+        const bool ok = rr < M;
+        const long m = ok ? flat_row(rr) : 0;
         if constexpr (GATHER) {
             const long b = ok ? m / a.T : 0;
             const int t = ok ? (int)(m - b * a.T) - a.front_zero : -1;
@@ -85,8 +89,9 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void input_proj_kernel(const Hpmn
     for (long tile = wave_id; tile < ntile; tile += nwave) {
         if (tile + nwave < ntile) load_a(tile + nwave, nxt);
         if constexpr (GATHER) {
-            const long m = tile * 32 + c;
-            if (ns == 0 && a.x_out != nullptr && m < M) {
+            const long rr = tile * 32 + c;
+            const long m = rr < M ? flat_row(rr) : 0;
+            if (ns == 0 && a.x_out != nullptr && rr < M) {
 #pragma unroll
                 for (int q = 0; q < Q; ++q) *reinterpret_cast<float4 *>(a.x_out + m * K + p * KH + 4 * q) = cur[q];
             }
@@ -108,8 +113,9 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void input_proj_kernel(const Hpmn
         // C/D layout: reg r -> row (r&3) + 8*(r>>2) + 4*p, col c
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const long m = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * p;
-            if (m < M) {
+            const long rr = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * p;
+            if (rr < M) {
+                const long m = flat_row(rr);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) a.xp[m * N + n_base + 32 * nt + c] = acc[nt][r];
             }
@@ -128,8 +134,10 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void gru_dx_kernel(const HpmnGruW
     const int lane = threadIdx.x & 63;
     const int c = lane & 31, p = lane >> 5;
     const int D = a.D;
-    const long M = (long)a.B * a.T;
+    const int TL = a.t_len > 0 ? a.t_len : a.T;
+    const long M = (long)a.B * TL;
     const long ntile = (M + 31) / 32;
+    auto flat_row = [&](long r) -> long { const long b = r / TL; return b * a.T + a.t_begin + (r - b * TL); };
     const long wave_id = (long)blockIdx.x * RW_WAVES + (threadIdx.x >> 6);
     const long nwave = (long)gridDim.x * RW_WAVES;
 
@@ -147,11 +155,12 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void gru_dx_kernel(const HpmnGruW
         }
     }
     auto load_a = [&](long tile, float4 (&v)[Q]) {
-        const long m = tile * 32 + c;
+        const long rr = tile * 32 + c;
+        const long m = rr < M ? flat_row(rr) : 0;
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
             v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m < M) v[q] = *reinterpret_cast<const float4 *>(a.d_act + m * K + p * KH + 4 * q);
+            if (rr < M) v[q] = *reinterpret_cast<const float4 *>(a.d_act + m * K + p * KH + 4 * q);
         }
     };
     float4 cur[Q], nxt[Q];
@@ -174,8 +183,9 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void gru_dx_kernel(const HpmnGruW
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const long m = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * p;
-            if (m < M) {
+            const long rr = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * p;
+            if (rr < M) {
+                const long m = flat_row(rr);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
                     if (32 * nt + c < D) a.d_x[m * D + 32 * nt + c] = acc[nt][r];
@@ -195,7 +205,7 @@ static unsigned rowwise_grid(long M) {
 
 template <int K, int NT, int NS>
 static int launch_proj(const HpmnInputProj &a, hipStream_t st) {
-    const long ntile = ((long)a.B * a.T + 31) / 32;
+    const long ntile = ((long)a.B * (a.t_len > 0 ? a.t_len : a.T) + 31) / 32;
     long wg = (ntile * NS + RW_WAVES - 1) / RW_WAVES;
     if (wg > 256) wg = 256;            // one persistent workgroup per CU, one wave per SIMD
     const unsigned grid = (unsigned)(wg < 1 ? 1 : wg);
@@ -219,7 +229,7 @@ int input_proj_dispatch(const HpmnInputProj &a, hipStream_t st) {
 }
 
 int gru_dx_dispatch(const HpmnGruWgrad &a, hipStream_t st) {
-    const unsigned grid = rowwise_grid((long)a.B * a.T);
+    const unsigned grid = rowwise_grid((long)a.B * (a.t_len > 0 ? a.t_len : a.T));
     const int DT = (a.D + 31) / 32;
     if (a.H == 32 && DT == 1) hipLaunchKernelGGL((gru_dx_kernel<96, 1>), dim3(grid), dim3(64 * RW_WAVES), 0, st, a);
     else if (a.H == 32 && DT == 2) hipLaunchKernelGGL((gru_dx_kernel<96, 2>), dim3(grid), dim3(64 * RW_WAVES), 0, st, a);

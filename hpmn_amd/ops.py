@@ -96,8 +96,9 @@ def embed_gather(ids: torch.Tensor, emb: torch.Tensor, mask_id0: bool) -> torch.
 
 
 def gru_input_proj(spec_or_none, *, x=None, ids=None, emb=None, wg, bg, wc, bc, H, T, front_zero=0,
-                   mask_id0=False, want_x_out=False):
-    """hpmn_gru_input_proj.  Returns (xp [B,T,3H], x_out or None)."""
+                   mask_id0=False, want_x_out=False, out=None, t_range=None):
+    """hpmn_gru_input_proj.  Returns (xp [B,T,3H], x_out or None).  ``out`` = (xp, x_out) preallocated
+    buffers and ``t_range`` = (t_begin, t_len) restrict the launch to a time chunk of every sequence."""
     a = HpmnInputProj()
     _chk_f32(wg, bg, wc, bc)
     if x is not None:
@@ -117,19 +118,24 @@ def gru_input_proj(spec_or_none, *, x=None, ids=None, emb=None, wg, bg, wc, bc, 
         dev = emb.device
     a.B, a.T, a.D, a.H = B, T, D, H
     a.wg, a.bg, a.wc, a.bc = wg.data_ptr(), bg.data_ptr(), wc.data_ptr(), bc.data_ptr()
-    xp = torch.empty(B, T, 3 * H, device=dev, dtype=torch.float32)
-    x_out = None
-    if want_x_out and x is None:
-        x_out = torch.empty(B, T, D, device=dev, dtype=torch.float32)
+    if out is not None:
+        xp, x_out = out
+    else:
+        xp = torch.empty(B, T, 3 * H, device=dev, dtype=torch.float32)
+        x_out = torch.empty(B, T, D, device=dev, dtype=torch.float32) if (want_x_out and x is None) else None
+    if x_out is not None and x is None:
         a.x_out = x_out.data_ptr()
+    if t_range is not None:
+        a.t_begin, a.t_len = t_range
     a.xp = xp.data_ptr()
     rc = _lib.load().hpmn_gru_input_proj(C.byref(a), _stream())
     _lib.check(rc, "hpmn_gru_input_proj")
     return xp, x_out
 
 
-def gru_scan_fwd(xp, wg, wc, D, h_last, period, want_y, train):
-    """hpmn_gru_scan_fwd.  h_last is a [B,H] strided view (e.g. memory[:, i, :])."""
+def gru_scan_fwd(xp, wg, wc, D, h_last, period, want_y, train, out=None, t_range=None, h_init=None):
+    """hpmn_gru_scan_fwd.  h_last is a [B,H] strided view (e.g. memory[:, i, :]).  ``out`` = (y, hs, gates)
+    preallocated; ``t_range`` = (t_begin, t_end) runs one time chunk from ``h_init`` ([B,H] strided view)."""
     B, T, H3 = xp.shape
     H = H3 // 3
     _chk_f32(xp, wg, wc)
@@ -140,20 +146,31 @@ def gru_scan_fwd(xp, wg, wc, D, h_last, period, want_y, train):
     a.h_last, a.h_last_stride = h_last.data_ptr(), h_last.stride(0)
     a.period = period
     y = hs = gates = None
-    if want_y:
-        y = torch.empty(B, T // period, H, device=xp.device, dtype=torch.float32)
+    if out is not None:
+        y, hs, gates = out
+    else:
+        if want_y:
+            y = torch.empty(B, T // period, H, device=xp.device, dtype=torch.float32)
+        if train:
+            hs = torch.empty(B, T + 1, H, device=xp.device, dtype=torch.float32)
+            gates = torch.empty(B, T, 3 * H, device=xp.device, dtype=torch.float32)
+    if y is not None:
         a.y = y.data_ptr()
-    if train:
-        hs = torch.empty(B, T + 1, H, device=xp.device, dtype=torch.float32)
-        gates = torch.empty(B, T, 3 * H, device=xp.device, dtype=torch.float32)
+    if hs is not None:
         a.hs, a.gates = hs.data_ptr(), gates.data_ptr()
+    if t_range is not None:
+        a.t_begin, a.t_end = t_range
+    if h_init is not None:
+        assert h_init.stride(1) == 1
+        a.h_init, a.h_init_stride = h_init.data_ptr(), h_init.stride(0)
     rc = _lib.load().hpmn_gru_scan_fwd(C.byref(a), _stream())
     _lib.check(rc, "hpmn_gru_scan_fwd")
     return y, hs, gates
 
 
-def gru_scan_bwd(wg, wc, D, hs, gates, d_h_last, d_y, period):
-    """hpmn_gru_scan_bwd -> d_act [B,T,3H]."""
+def gru_scan_bwd(wg, wc, D, hs, gates, d_h_last, d_y, period, out=None, t_range=None, dh_carry=None):
+    """hpmn_gru_scan_bwd -> d_act [B,T,3H].  ``out`` = preallocated d_act; ``t_range`` = (t_begin, t_end)
+    runs one time chunk (reverse) with the boundary gradient handed over through ``dh_carry`` [B,H]."""
     B, T1, H = hs.shape
     T = T1 - 1
     _chk_f32(wg, wc, hs, gates, d_y)
@@ -164,8 +181,12 @@ def gru_scan_bwd(wg, wc, D, hs, gates, d_h_last, d_y, period):
     a.d_h_last, a.d_h_last_stride = d_h_last.data_ptr(), d_h_last.stride(0)
     a.d_y = _ptr(d_y)
     a.period = period
-    d_act = torch.empty(B, T, 3 * H, device=hs.device, dtype=torch.float32)
+    d_act = out if out is not None else torch.empty(B, T, 3 * H, device=hs.device, dtype=torch.float32)
     a.d_act = d_act.data_ptr()
+    if t_range is not None:
+        a.t_begin, a.t_end = t_range
+    if dh_carry is not None:
+        a.dh_carry = dh_carry.data_ptr()
     rc = _lib.load().hpmn_gru_scan_bwd(C.byref(a), _stream())
     _lib.check(rc, "hpmn_gru_scan_bwd")
     return d_act
@@ -197,13 +218,14 @@ def gru_param_grads(x, hs, gates, d_act, wg, wc, d_wg, d_bg, d_wc, d_bc, want_dx
     return d_x
 
 
-def gru_input_grad(d_act, wg, wc, D):
-    """hpmn_gru_input_grad: dx [B,T,D] = d_act [Wg[:D] | Wc[:D]]^T."""
+def gru_input_grad(d_act, wg, wc, D, out=None, t_range=None):
+    """hpmn_gru_input_grad: dx [B,T,D] = d_act [Wg[:D] | Wc[:D]]^T (optionally one time chunk)."""
     B, T, H3 = d_act.shape
     _chk_f32(d_act, wg, wc)
-    d_x = torch.empty(B, T, D, device=d_act.device, dtype=torch.float32)
+    d_x = out if out is not None else torch.empty(B, T, D, device=d_act.device, dtype=torch.float32)
+    tb, tl = t_range if t_range is not None else (0, 0)
     rc = _lib.load().hpmn_gru_input_grad(d_act.data_ptr(), wg.data_ptr(), wc.data_ptr(), d_x.data_ptr(),
-                                          B, T, D, H3 // 3, _stream())
+                                          B, T, D, H3 // 3, tb, tl, _stream())
     _lib.check(rc, "hpmn_gru_input_grad")
     return d_x
 
@@ -259,73 +281,183 @@ def scan_forward_inference(spec: ScanSpec, ids, emb, weights: Sequence[torch.Ten
 # ---------------------------------------------------------------------------------------
 # build_memory with saved states (training) and its BPTT -- plain kernel sequences, no autograd
 # ---------------------------------------------------------------------------------------
+import os as _os
+
+# Time chunks for cross-layer pipelining over K HIP streams (1 = off, the default).  Measured on MI355X at
+# C3: a cross-stream event dependency costs ~40 us, a chunked scan launch ~15 us of prologue, so 2/4/8
+# chunks give 6.05/6.84/8.50 ms per step against 5.45 ms unpipelined -- kept (and tested) as an option.
+PIPELINE_CHUNKS = int(_os.environ.get("HPMN_PIPELINE_CHUNKS", "1"))
+
+_layer_streams = {}
+
+
+def _streams(device, n):
+    key = str(device)
+    lst = _layer_streams.setdefault(key, [])
+    while len(lst) < n:
+        lst.append(torch.cuda.Stream(device=device))
+    return lst[:n]
+
+
+def chunk_plan(spec: ScanSpec, nc: int):
+    """Per-layer chunk lengths for cross-layer pipelining, or None if the layer lengths do not split:
+    chunk c of layer i = steps [c*L_i, (c+1)*L_i) with L_{i+1} = L_i / period_i; every L_i must be even
+    (the kernels stage 2-step chunks) and a multiple of the layer's period."""
+    if nc <= 1 or spec.K < 2:
+        return None
+    lens = spec.layer_lengths()
+    if lens[0] % nc:
+        return None
+    L, out = lens[0] // nc, []
+    for i in range(spec.K):
+        if L < 2 or L % 2 or lens[i] != L * nc:
+            return None
+        out.append(L)
+        if i + 1 < spec.K:
+            if L % spec.periods[i]:
+                return None
+            L //= spec.periods[i]
+    return out
+
+
 def scan_forward_train(spec: ScanSpec, ids, emb, weights: Sequence[torch.Tensor]):
     """Training-mode build_memory (code/hpmn.py:113-129 on the embedded ids): per layer the input
-    projection + the serial scan with saved states.  Returns (memory [B,K,H], last [B,D0], saved)."""
+    projection + the serial scan with saved states.  Returns (memory [B,K,H], last [B,D0], saved).
+
+    Layer i+1 only needs every period-th output of layer i, so the layers are software-pipelined in time
+    chunks over K HIP streams: while layer 0 scans chunk c+1, layer 1 projects+scans chunk c, layer 2
+    chunk c-1, ...  The serial chain shrinks from sum_i T_i steps to about T_0 + T_1/nc + T_2/nc + ...
+    (at B ~ 2 sequences per CU a scan launch occupies one wave on half of the SIMDs)."""
     lens = spec.layer_lengths()
     B = ids.shape[0]
     H, K = spec.H, spec.K
-    memory = torch.empty(B, K, H, device=emb.device, dtype=torch.float32)
-    saved = []
-    x_in = x0 = None
-    for i in range(K):
-        wg, bg, wc, bc = weights[4 * i:4 * i + 4]
-        if i == 0:
-            xp, x0 = gru_input_proj(None, ids=ids, emb=emb, wg=wg, bg=bg, wc=wc, bc=bc, H=H, T=lens[0],
-                                    front_zero=spec.front_zero, mask_id0=spec.mask_id0, want_x_out=True)
-            D = spec.D0
-            x_in = x0
-        else:
-            xp, _ = gru_input_proj(None, x=x_in, wg=wg, bg=bg, wc=wc, bc=bc, H=H, T=lens[i])
-            D = H
-        y, hs, gates = gru_scan_fwd(xp, wg, wc, D, memory[:, i, :], spec.periods[i], want_y=(i + 1 < K), train=True)
-        del xp
-        saved.append((x_in, hs, gates))
-        x_in = y
+    dev = emb.device
+    f32 = dict(device=dev, dtype=torch.float32)
+    memory = torch.empty(B, K, H, **f32)
+    in_dims = [spec.D0] + [H] * (K - 1)
+    x0 = torch.empty(B, lens[0], spec.D0, **f32)
+    xp = [torch.empty(B, lens[i], 3 * H, **f32) for i in range(K)]
+    hs = [torch.empty(B, lens[i] + 1, H, **f32) for i in range(K)]
+    gates = [torch.empty(B, lens[i], 3 * H, **f32) for i in range(K)]
+    y = [torch.empty(B, lens[i] // spec.periods[i], H, **f32) if i + 1 < K else None for i in range(K)]
+    x_in = [x0] + y[:-1]
+
+    plan = chunk_plan(spec, PIPELINE_CHUNKS)
+    nc = PIPELINE_CHUNKS if plan is not None else 1
+    main = torch.cuda.current_stream()
+    streams = [main] + (_streams(dev, K - 1) if nc > 1 else [main] * (K - 1))
+    if nc > 1:
+        for st in streams[1:]:
+            st.wait_stream(main)
+    done = [[None] * nc for _ in range(K)]
+    for c in range(nc):
+        for i in range(K):
+            wg, bg, wc, bc = weights[4 * i:4 * i + 4]
+            L = plan[i] if plan is not None else lens[i]
+            t0, t1 = c * L, (c + 1) * L
+            with torch.cuda.stream(streams[i]):
+                if i > 0 and nc > 1:
+                    streams[i].wait_event(done[i - 1][c])
+                if i == 0:
+                    gru_input_proj(None, ids=ids, emb=emb, wg=wg, bg=bg, wc=wc, bc=bc, H=H, T=lens[0],
+                                   front_zero=spec.front_zero, mask_id0=spec.mask_id0, out=(xp[0], x0),
+                                   t_range=(t0, L) if nc > 1 else None)
+                else:
+                    gru_input_proj(None, x=x_in[i], wg=wg, bg=bg, wc=wc, bc=bc, H=H, T=lens[i], out=(xp[i], None),
+                                   t_range=(t0, L) if nc > 1 else None)
+                gru_scan_fwd(xp[i], wg, wc, in_dims[i], memory[:, i, :], spec.periods[i], want_y=(i + 1 < K),
+                             train=True, out=(y[i], hs[i], gates[i]),
+                             t_range=(t0, t1) if nc > 1 else None,
+                             h_init=hs[i][:, t0, :] if (nc > 1 and c > 0) else None)
+                if nc > 1:
+                    done[i][c] = torch.cuda.Event()
+                    done[i][c].record(streams[i])
+    if nc > 1:
+        for st in streams[1:]:
+            main.wait_stream(st)
     last = x0[:, spec.last_index, :].contiguous()
+    saved = [(x_in[i], hs[i], gates[i]) for i in range(K)]
+    del xp            # only now: the side streams are joined
     return memory, last, saved
-
-
-_side_streams = {}
-
-
-def _side_stream(device) -> "torch.cuda.Stream":
-    key = str(device)
-    st = _side_streams.get(key)
-    if st is None:
-        st = _side_streams[key] = torch.cuda.Stream(device=device)
-    return st
 
 
 def scan_backward(spec: ScanSpec, ids, saved, weights: Sequence[torch.Tensor], d_memory, d_last, grad_out):
     """BPTT of scan_forward_train.  ``grad_out`` = [d_emb, d_wg0, d_bg0, d_wc0, d_bc0, d_wg1, ...]:
     pre-zeroed buffers (views of the optimiser's flat gradient) that are accumulated into.
 
-    The serial chain is scan_bwd(K-1) -> dx(K-1) -> scan_bwd(K-2) -> ... -> dx(0) -> scatter; the weight
-    gradient of a layer is off that chain, so it runs on a second HIP stream underneath the next layer's
-    reverse scan (which occupies one wave on half of the SIMDs)."""
-    K = spec.K
+    Mirror image of the forward pipeline: layer K-1 runs its last time chunk first, its input gradient
+    feeds layer K-2's last chunk, ... and layer 0 works on chunk c while the layers above are already on
+    chunk c-1.  The weight gradient of a layer (an MFMA reduction over the whole d_act) is off the serial
+    chain and is issued on the layer's stream once its last chunk is done."""
+    K, H = spec.K, spec.H
+    lens = spec.layer_lengths()
     d_emb, gw = grad_out[0], list(grad_out[1:])
+    dev = d_memory.device
+    f32 = dict(device=dev, dtype=torch.float32)
+    B = d_memory.shape[0]
+    in_dims = [spec.D0] + [H] * (K - 1)
+    d_act = [torch.empty(B, lens[i], 3 * H, **f32) for i in range(K)]
+    d_x = [torch.empty(B, lens[i], in_dims[i], **f32) for i in range(K)]      # d_x[i+1] is layer i's d_y
+    carry = [torch.empty(B, H, **f32) for _ in range(K)]
+    plan = chunk_plan(spec, PIPELINE_CHUNKS)
+    nc = PIPELINE_CHUNKS if plan is not None else 1
     main = torch.cuda.current_stream()
-    side = _side_stream(d_memory.device)
-    keep = []                    # tensors the side stream still reads: freed only after the join below
-    d_y = None
-    for i in range(K - 1, -1, -1):
-        wg, bg, wc, bc = weights[4 * i:4 * i + 4]
-        x_in, hs, gates = saved[i]
-        D = x_in.shape[2]
-        d_act = gru_scan_bwd(wg, wc, D, hs, gates, d_memory[:, i, :], d_y, spec.periods[i])
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            gru_param_grads(x_in, hs, gates, d_act, wg, wc, gw[4 * i], gw[4 * i + 1], gw[4 * i + 2], gw[4 * i + 3],
-                            want_dx=False, keep=keep)
-        d_y = gru_input_grad(d_act, wg, wc, D)
-        keep.append(d_act)
-    d_x0 = d_y
+    keep = []
+    if nc == 1:
+        # unpipelined: the whole chain on the main stream, weight gradients underneath on one side stream
+        side = _streams(dev, 1)[0]
+        for i in range(K - 1, -1, -1):
+            wg, bg, wc, bc = weights[4 * i:4 * i + 4]
+            x_in, hs, gates = saved[i]
+            gru_scan_bwd(wg, wc, in_dims[i], hs, gates, d_memory[:, i, :], d_x[i + 1] if i + 1 < K else None,
+                         spec.periods[i], out=d_act[i])
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                gru_param_grads(x_in, hs, gates, d_act[i], wg, wc, gw[4 * i], gw[4 * i + 1], gw[4 * i + 2],
+                                gw[4 * i + 3], want_dx=False, keep=keep)
+            gru_input_grad(d_act[i], wg, wc, in_dims[i], out=d_x[i])
+        d_x0 = d_x[0]
+        d_x0[:, spec.last_index, :] += d_last
+        embed_grad_scatter(ids, d_x0, d_emb, spec.front_zero, spec.mask_id0)
+        main.wait_stream(side)
+        del keep, d_act, d_x
+        return
+    # layer 0 (the end of the chain, feeding the embedding scatter) stays on the main stream
+    streams = [main] + _streams(dev, K - 1)
+    for st in streams[1:]:
+        st.wait_stream(main)
+    done = [[None] * nc for _ in range(K)]
+    for c in range(nc - 1, -1, -1):
+        for i in range(K - 1, -1, -1):
+            wg, bg, wc, bc = weights[4 * i:4 * i + 4]
+            x_in, hs, gates = saved[i]
+            L = plan[i] if plan is not None else lens[i]
+            t0, t1 = c * L, (c + 1) * L
+            with torch.cuda.stream(streams[i]):
+                if i + 1 < K:
+                    streams[i].wait_event(done[i + 1][c])
+                gru_scan_bwd(wg, wc, in_dims[i], hs, gates, d_memory[:, i, :], d_x[i + 1] if i + 1 < K else None,
+                             spec.periods[i], out=d_act[i], t_range=(t0, t1) if nc > 1 else None,
+                             dh_carry=carry[i] if nc > 1 else None)
+                gru_input_grad(d_act[i], wg, wc, in_dims[i], out=d_x[i], t_range=(t0, L) if nc > 1 else None)
+                done[i][c] = torch.cuda.Event()
+                done[i][c].record(streams[i])
+                if c == 0 and i > 0:        # this layer is finished: its weight gradient, off the chain
+                    gru_param_grads(x_in, hs, gates, d_act[i], wg, wc, gw[4 * i], gw[4 * i + 1], gw[4 * i + 2],
+                                    gw[4 * i + 3], want_dx=False, keep=keep)
+    # layer 0's weight gradient overlaps the scatter on a side stream
+    side = streams[1] if K > 1 else _streams(dev, 1)[0]
+    side.wait_event(done[0][0])
+    with torch.cuda.stream(side):
+        wg, bg, wc, bc = weights[0:4]
+        gru_param_grads(saved[0][0], saved[0][1], saved[0][2], d_act[0], wg, wc, gw[0], gw[1], gw[2], gw[3],
+                        want_dx=False, keep=keep)
+    d_x0 = d_x[0]
     d_x0[:, spec.last_index, :] += d_last
     embed_grad_scatter(ids, d_x0, d_emb, spec.front_zero, spec.mask_id0)
-    main.wait_stream(side)
-    del keep
+    for st in set(streams[1:] + [side]):
+        main.wait_stream(st)
+    del keep, d_act, d_x
 
 
 # ---------------------------------------------------------------------------------------

@@ -92,6 +92,7 @@ typedef struct HpmnInputProj {
     const float *wg, *bg, *wc, *bc;
     float *xp;     /* [B, T, 3H] */
     float *x_out;  /* optional [B, T, D] (gather mode) */
+    int32_t t_begin, t_len;  /* only steps [t_begin, t_begin+t_len) of every sequence; t_len == 0: all T */
 } HpmnInputProj;
 
 int hpmn_gru_input_proj(const HpmnInputProj *args, void *stream);
@@ -106,6 +107,12 @@ typedef struct HpmnGruFwd {
     int32_t period;
     float *hs;
     float *gates;
+    /* time-chunked launches (cross-layer pipelining): run only steps [t_begin, t_end) (both multiples of 2
+     * and of period; t_end == 0: to T) starting from h_init[b*h_init_stride + 0..H) (NULL: zero state);
+     * h_last always receives the state after the last step run. */
+    int32_t t_begin, t_end;
+    const float *h_init;
+    int64_t h_init_stride;
 } HpmnGruFwd;
 
 int hpmn_gru_scan_fwd(const HpmnGruFwd *args, void *stream);
@@ -130,6 +137,11 @@ typedef struct HpmnGruBwd {
     const float *d_y;
     int32_t period;
     float *d_act;
+    /* time-chunked launches: reverse steps t_end-1 .. t_begin (t_end == 0: T).  The gradient flowing into
+     * step t_end-1 is d_h_last when t_end == T, else dh_carry[b*H + 0..H) left by the launch for the later
+     * chunk; when t_begin > 0 the gradient wrt the state before step t_begin is written to dh_carry. */
+    int32_t t_begin, t_end;
+    float *dh_carry;
 } HpmnGruBwd;
 
 int hpmn_gru_scan_bwd(const HpmnGruBwd *args, void *stream);
@@ -153,6 +165,7 @@ typedef struct HpmnGruWgrad {
     float *d_x;
     float *workspace;
     int32_t seq_per_wg;   /* set by the library */
+    int32_t t_begin, t_len;  /* d_x only: steps [t_begin, t_begin+t_len) of every sequence; 0,0: all */
 } HpmnGruWgrad;
 
 size_t hpmn_gru_param_grads_workspace_bytes(int32_t B, int32_t T, int32_t D, int32_t H);
@@ -160,7 +173,8 @@ int hpmn_gru_param_grads(const HpmnGruWgrad *args, void *stream);
 /* Only the input gradient d_x [B,T,D] = d_act [B,T,3H] [wg[0:D] | wc[0:D]]^T (the part of the above that
  * is on BPTT's serial chain; the caller may run hpmn_gru_param_grads with d_x == NULL on another stream). */
 int hpmn_gru_input_grad(const float *d_act, const float *wg, const float *wc, float *d_x,
-                        int32_t B, int32_t T, int32_t D, int32_t H, void *stream);
+                        int32_t B, int32_t T, int32_t D, int32_t H, int32_t t_begin, int32_t t_len,
+                        void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Whole build_memory forward (code/hpmn.py:113-129 without the covariance loss): K

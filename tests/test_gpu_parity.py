@@ -205,6 +205,24 @@ def test_gradients_match_float64_autograd(dev, tmp_path, name, cfg, B):
         assert float(m.grads["Embedding/emb_mtx"][0].abs().max()) == 0.0
 
 
+def test_time_chunked_pipelined_launches_match_unchunked(dev, tmp_path, monkeypatch):
+    """The optional cross-layer pipelining (time-chunked scan / projection / dx launches over K streams,
+    state and gradient carried across chunk boundaries) must reproduce the unchunked result."""
+    from hpmn_amd import ops
+    cfg = cfg_industry(H=64, K=4, T=105, V=150)          # 128 steps -> chunks of 32,16,8,4
+    p = f32_params(cfg, 91)
+    ids, label = rand_ids(cfg, 5, 92)
+    m = make_model(cfg, tmp_path, p)
+    ti, tl = torch.as_tensor(ids).to(dev), torch.as_tensor(label).to(dev)
+    out1, ce1 = m.compute_gradients(ti, tl, keep_prob=1.0)
+    g1 = m.flat_grad.clone()
+    assert ops.chunk_plan(m.spec, 4) == [32, 16, 8, 4]
+    monkeypatch.setattr(ops, "PIPELINE_CHUNKS", 4)
+    out2, ce2 = m.compute_gradients(ti, tl, keep_prob=1.0)
+    assert torch.equal(out1["memory"], out2["memory"]) and torch.equal(out1["prediction"], out2["prediction"])
+    np.testing.assert_allclose(m.flat_grad.cpu().numpy(), g1.cpu().numpy(), rtol=0, atol=1e-6 * float(g1.abs().max()))
+
+
 def test_dropout_masks_are_honoured(dev, tmp_path):
     cfg = cfg_amazon(K=3, T=100, V=120)
     p = f32_params(cfg, 51)
