@@ -292,7 +292,8 @@ _layer_streams = {}
 
 
 def _streams(device, n):
-    key = str(device)
+    """n helper streams private to the CURRENT stream (sub-batches run this code concurrently)."""
+    key = (str(device), torch.cuda.current_stream().cuda_stream)
     lst = _layer_streams.setdefault(key, [])
     while len(lst) < n:
         lst.append(torch.cuda.Stream(device=device))
@@ -469,7 +470,7 @@ _read_ws = {}
 def _read_workspace(desc, device):
     """Zero-initialised once, then reused: the kernel only rewrites parameter positions."""
     need = _lib.load().hpmn_read_workspace_bytes(C.byref(desc)) // 4
-    key = (str(device), int(desc.n_params))
+    key = (str(device), int(desc.n_params), torch.cuda.current_stream().cuda_stream)
     ws = _read_ws.get(key)
     if ws is None or ws.numel() < need:
         ws = _read_ws[key] = torch.zeros(need, device=device, dtype=torch.float32)
