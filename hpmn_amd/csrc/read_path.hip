@@ -47,8 +47,19 @@ __device__ __forceinline__ void dense_fwd(const float *X, int ldx, int R, int I,
         const float *xr[RB];
 #pragma unroll
         for (int j = 0; j < RB; ++j) xr[j] = X + ((r0 + j) < R ? (r0 + j) : (R - 1)) * ldx;
-#pragma unroll 4
-        for (int i = 0; i < I; ++i) {
+        // the weight column walk is a chain of L2 round trips: keep WU loads in flight
+        constexpr int WU = 8;
+        int i = 0;
+        for (; i + WU <= I; i += WU) {
+            float wv[WU];
+#pragma unroll
+            for (int q = 0; q < WU; ++q) wv[q] = W[(long)(i + q) * N + n];
+#pragma unroll
+            for (int q = 0; q < WU; ++q)
+#pragma unroll
+                for (int j = 0; j < RB; ++j) acc[j] = fmaf(xr[j][i + q], wv[q], acc[j]);
+        }
+        for (; i < I; ++i) {
             const float w = W[(long)i * N + n];
 #pragma unroll
             for (int j = 0; j < RB; ++j) acc[j] = fmaf(xr[j][i], w, acc[j]);
@@ -75,13 +86,29 @@ __device__ __forceinline__ void dense_bwd_x(const float *dY, int ldy, int R, int
             float acc[RB];
 #pragma unroll
             for (int j = 0; j < RB; ++j) acc[j] = 0.f;
-            for (int n = 0; n < N; ++n) {
+            const float *dr[RB];
+#pragma unroll
+            for (int j = 0; j < RB; ++j) dr[j] = dY + ((r0 + j) < R ? (r0 + j) : (R - 1)) * ldy;
+            int n = 0;
+            if ((N & 3) == 0) {              // weight rows are 16-byte aligned (N % 4 == 0): 4 columns per load
+                for (; n + 8 <= N; n += 8) {
+                    const float4 w0 = *reinterpret_cast<const float4 *>(w + n);
+                    const float4 w1 = *reinterpret_cast<const float4 *>(w + n + 4);
+#pragma unroll
+                    for (int j = 0; j < RB; ++j) {
+                        float a = acc[j];
+                        a = fmaf(dr[j][n + 0], w0.x, a); a = fmaf(dr[j][n + 1], w0.y, a);
+                        a = fmaf(dr[j][n + 2], w0.z, a); a = fmaf(dr[j][n + 3], w0.w, a);
+                        a = fmaf(dr[j][n + 4], w1.x, a); a = fmaf(dr[j][n + 5], w1.y, a);
+                        a = fmaf(dr[j][n + 6], w1.z, a); a = fmaf(dr[j][n + 7], w1.w, a);
+                        acc[j] = a;
+                    }
+                }
+            }
+            for (; n < N; ++n) {
                 const float wv = w[n];
 #pragma unroll
-                for (int j = 0; j < RB; ++j) {
-                    const int r = (r0 + j) < R ? (r0 + j) : (R - 1);
-                    acc[j] = fmaf(dY[r * ldy + n], wv, acc[j]);
-                }
+                for (int j = 0; j < RB; ++j) acc[j] = fmaf(dr[j][n], wv, acc[j]);
             }
 #pragma unroll
             for (int j = 0; j < RB; ++j)
