@@ -138,9 +138,21 @@ def roofline_probes(model, c, ids):
     gather_bytes = B * c["T"] * c["F"] * (4 + 2 * 16 * 4)      # id + row read + row write
     proj_bytes = B * c["T"] * c["F"] * (4 + 64) + B * T0 * 3 * H * 4
     dom_name, dom_t = ("gru_scan_bwd_kernel", t_bwd) if t_bwd >= t_fwd else ("gru_scan_fwd_kernel", t_fwd)
+    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; take the
+    # committed rocprofv3 --pmc passes of this same command/shape (profiles/r01_pmc_summary.json)
+    traffic, traffic_src = None, None
+    try:
+        if c.get("config_id") == "c3" and B == 500:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))["layer0_launch"]
+            key = "gru_scan_bwd_kernel<64>" if dom_name == "gru_scan_bwd_kernel" else "gru_scan_fwd_kernel<64,true>"
+            traffic = (2.0 * pmc[key]["FETCH_SIZE"] + pmc[key]["WRITE_SIZE"]) * 1024.0
+            traffic_src = "profiles/r01_pmc_summary.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x2 gfx950 correction)"
+    except Exception:
+        pass
     roof = {"kernel": dom_name + "<%d> layer 0 (T=%d)" % (H, T0), "bound": "mfma",
             "achieved": scan_flops / (dom_t * 1e-3) / 1e12, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-            "frac": scan_flops / (dom_t * 1e-3) / 1e12 / PEAK_F32_TFLOPS, "traffic": None,
+            "frac": scan_flops / (dom_t * 1e-3) / 1e12 / PEAK_F32_TFLOPS, "traffic": traffic,
+            "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
             "ms_per_launch": dom_t,
             "note": "fp32 FMA chain, latency-bound serial recurrence; peak = dense fp32 (vector == f32 MFMA)"}
     wgrad_flops = B * T0 * 2 * (D0 + H) * 3 * H
@@ -214,6 +226,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
     c = dict(CONFIGS[args.config])
+    c["config_id"] = args.config
     if args.batch:
         c["batch"] = args.batch
 
