@@ -30,6 +30,7 @@ __global__ __launch_bounds__(64, 1) void gru_scan_bwd_kernel(const HpmnGruBwd a)
     __shared__ __attribute__((aligned(16))) float bufA[SPW * H];
     __shared__ __attribute__((aligned(16))) float bufB[SPW * 2 * H];
 
+    __builtin_amdgcn_s_setprio(3);   // see gru_scan_fwd.hip
     const int lane = threadIdx.x;
     const int s = lane / H;
     const int l = lane % H;

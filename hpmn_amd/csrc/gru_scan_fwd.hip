@@ -41,6 +41,8 @@ __global__ __launch_bounds__(64, 1) void gru_scan_fwd_kernel(const HpmnGruFwd a)
     __shared__ __attribute__((aligned(16))) float ring[RING][SPW * CF];
     __shared__ __attribute__((aligned(16))) float hb[SPW * H];
     __shared__ __attribute__((aligned(16))) float rhb[SPW * H];
+    // the serial chain is latency-bound: win issue arbitration against co-resident waves of other kernels
+    __builtin_amdgcn_s_setprio(3);
 
     const int lane = threadIdx.x;
     const int s = lane / H;  // which of this wave's sequences
