@@ -162,6 +162,20 @@ def make_synthetic_xlong_arrays(n_lines, seed=SEED_BASE + 3, item_cnt=XLONG_ITEM
     return ids, label
 
 
+def make_synthetic_graph_emb(seed=SEED_BASE + 4, item_cnt=XLONG_ITEM_CNT, n_cluster=64, dim=16, spread=0.05):
+    """Stand-in for ``graph_emb.npy`` (code/hpmn.py:631-635: pre-trained item embeddings that
+    initialise the table): one centroid per id-block of ``make_synthetic_xlong_arrays`` plus
+    N(0, spread) noise, so the planted "target comes from the user's favourite block" signal is
+    visible to the model the way graph-trained embeddings make item similarity visible."""
+    rng = np.random.default_rng(seed)
+    cent = rng.standard_normal((n_cluster, dim)).astype(np.float32) * 0.3
+    block = item_cnt // n_cluster
+    cl = np.minimum(np.arange(item_cnt) // block, n_cluster - 1)
+    emb = cent[cl]
+    emb += rng.standard_normal((item_cnt, dim), dtype=np.float32) * spread
+    return emb
+
+
 def write_xlong_tsv(path, n_lines, seed=SEED_BASE + 3, item_cnt=XLONG_ITEM_CNT, users=XLONG_USERS,
                     hist_len=1000, user_part_len=184):
     """Write ``n_lines`` lines in the reference's TSV format (code/data_loader.py:59-73)."""
