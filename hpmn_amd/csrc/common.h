@@ -36,7 +36,32 @@ __device__ __forceinline__ float fast_tanh(float x) {
     return 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * x)) - 1.0f;
 }
 
+// The same with the exponent pre-scaled by the caller (z = -log2(e) * x, resp. -2 log2(e) * x): the scan
+// kernels fold the scale into their register-stationary weights, which takes two dependent
+// multiplies off the serial chain of every step.
+constexpr float NEG_LOG2E = -1.4426950408889634f;
+__device__ __forceinline__ float sigmoid_scaled(float z) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z));
+}
+__device__ __forceinline__ float tanh_scaled(float z2) {
+    return fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z2)), -1.0f);
+}
+
 typedef float f2 __attribute__((ext_vector_type(2)));
+
+// "Use" a whole group of just-loaded LDS values in one place: the compiler's waitcnt pass then emits ONE
+// s_waitcnt (for the newest of them) in front of this statement instead of one in front of each first
+// use.  Every s_waitcnt costs the single wave of a scan workgroup a 4-cycle issue slot
+// (tools/micro: pk_fma pairs separated by s_waitcnt/s_nop run at 7.5 instead of 5.5 cycles per pk_fma).
+typedef float v4f __attribute__((ext_vector_type(4)));
+// The two accumulators ride along so that the statement stays behind the previous group's FMAs (the
+// scheduler otherwise hoists it and the last group is waited for with nothing left to overlap).
+template <int G>
+__device__ __forceinline__ void land_group(v4f (&v)[G], f2 &a, f2 &b) {
+    static_assert(G == 2 || G == 4, "group sizes in use");
+    if constexpr (G == 4) asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(a), "+v"(b));
+    else                  asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(a), "+v"(b));
+}
 
 // Make a register-stationary value "defined here" for the compiler's s_waitcnt bookkeeping.  Weights
 // are loaded once before the time loop; without this the waitcnt pass keeps treating them as results of
@@ -52,9 +77,10 @@ __device__ __forceinline__ void settle(f2 &x) { asm volatile("" : "+v"(x)); }
 // with a compiler memory barrier so that not all NQ reads are hoisted at once -- with 3H weights resident
 // that costs 4*NQ VGPRs and pushes the weights into AGPRs (measured: +98 v_accvgpr_read per step).
 template <int NQ, int G = 4>
-__device__ __forceinline__ void bcast_matvec(const float4 *row, const f2 *w, f2 &acc0, f2 &acc1) {
+__device__ __forceinline__ void bcast_matvec(const float4 *row4, const f2 *w, f2 &acc0, f2 &acc1) {
     static_assert(NQ % G == 0, "groups");
-    float4 cur[G], nxt[G];
+    const v4f *row = reinterpret_cast<const v4f *>(row4);
+    v4f cur[G], nxt[G];
 #pragma unroll
     for (int i = 0; i < G; ++i) cur[i] = row[i];
 #pragma unroll
@@ -64,6 +90,7 @@ __device__ __forceinline__ void bcast_matvec(const float4 *row, const f2 *w, f2 
             for (int i = 0; i < G; ++i) nxt[i] = row[(g + 1) * G + i];
         }
         asm volatile("" ::: "memory");   // no later LDS read may be hoisted above this point
+        land_group<G>(cur, acc0, acc1);
 #pragma unroll
         for (int i = 0; i < G; ++i) {
             const int q = g * G + i;
@@ -77,9 +104,10 @@ __device__ __forceinline__ void bcast_matvec(const float4 *row, const f2 *w, f2 
 
 // Same row feeding two weight sets (the r and u columns of the gate kernel).
 template <int NQ, int G = 4>
-__device__ __forceinline__ void bcast_matvec2(const float4 *row, const f2 *wa, const f2 *wb, f2 &a0, f2 &b0) {
+__device__ __forceinline__ void bcast_matvec2(const float4 *row4, const f2 *wa, const f2 *wb, f2 &a0, f2 &b0) {
     static_assert(NQ % G == 0, "groups");
-    float4 cur[G], nxt[G];
+    const v4f *row = reinterpret_cast<const v4f *>(row4);
+    v4f cur[G], nxt[G];
 #pragma unroll
     for (int i = 0; i < G; ++i) cur[i] = row[i];
 #pragma unroll
@@ -89,6 +117,7 @@ __device__ __forceinline__ void bcast_matvec2(const float4 *row, const f2 *wa, c
             for (int i = 0; i < G; ++i) nxt[i] = row[(g + 1) * G + i];
         }
         asm volatile("" ::: "memory");
+        land_group<G>(cur, a0, b0);
 #pragma unroll
         for (int i = 0; i < G; ++i) {
             const int q = g * G + i;

@@ -51,7 +51,8 @@ __global__ __launch_bounds__(64, 1) void gru_scan_fwd_kernel(const HpmnGruFwd a)
     // SPW == 1: the sequence index is wave-uniform (addresses stay in SGPRs)
     const long b_raw = SPW == 1 ? (long)blockIdx.x : (long)blockIdx.x * SPW + s;
     const bool live = SPW == 1 ? true : (b_raw < B);
-    const long b = live ? b_raw : (long)B - 1;
+    if (!live) return;   // partial last wave at H=32: nothing below needs the dead half's lanes
+    const long b = b_raw;
 
     // register-stationary recurrent weights, packed over consecutive k (TF layout: rows [D, D+H))
     f2 whr[H / 2], whu[H / 2], whc[H / 2];
@@ -61,8 +62,16 @@ __global__ __launch_bounds__(64, 1) void gru_scan_fwd_kernel(const HpmnGruFwd a)
         whu[k] = f2{a.wg[(long)(D + 2 * k) * 2 * H + H + l], a.wg[(long)(D + 2 * k + 1) * 2 * H + H + l]};
         whc[k] = f2{a.wc[(long)(D + 2 * k) * H + l], a.wc[(long)(D + 2 * k + 1) * H + l]};
     }
+    // The exponent scale of sigmoid / tanh (exp(-x) = exp2(-log2e * x)) is folded into the stationary
+    // weights here and into the projected input by input_proj_kernel, so a step's serial chain is
+    // matvec -> v_exp -> +1 -> v_rcp with no multiply in front of the v_exp.
 #pragma unroll
-    for (int k = 0; k < H / 2; ++k) { settle(whr[k]); settle(whu[k]); settle(whc[k]); }
+    for (int k = 0; k < H / 2; ++k) {
+        whr[k] *= NEG_LOG2E;
+        whu[k] *= NEG_LOG2E;
+        whc[k] *= 2.0f * NEG_LOG2E;
+        settle(whr[k]); settle(whu[k]); settle(whc[k]);
+    }
 
     // chunk staging: float2 i of lane (s,l) covers elements e = 2*(i*H + l), e+1 of the sequence's
     // [CS x 3H] chunk image, i.e. row e / 3H, column e % 3H.  Rows past the end are clamped to T-1
@@ -105,62 +114,68 @@ __global__ __launch_bounds__(64, 1) void gru_scan_fwd_kernel(const HpmnGruFwd a)
     float h = a.h_init != nullptr ? a.h_init[b * a.h_init_stride + l] : 0.f;
     hb[lane] = h;
     if constexpr (TRAIN) {
-        if (live && t0 == 0) a.hs[(b * (T + 1)) * H + l] = 0.f;
+        if (t0 == 0) a.hs[(b * (T + 1)) * H + l] = 0.f;
     }
     wave_sync();
 
-    // subsampled outputs y[:, j] = outputs[:, (j+1)*period - 1]: running "next firing step" counter
+    // subsampled outputs y[:, j] = outputs[:, (j+1)*period - 1].  The store is UNCONDITIONAL: every step
+    // writes h to the current slot and the slot pointer advances after a firing step, so the slot ends up
+    // holding the firing step's state (same lane, same address: stores stay ordered).  Layers without y
+    // aim the pointer at their h_last slot.  Why: with a conditional store in the loop the compiler's
+    // s_waitcnt pass loses count of the stores in flight and waits vmcnt(0) for the prefetch loads at the
+    // end of each chunk, i.e. for every store of the chunk to reach memory -- measured 300 of the 1520
+    // cycles of a step (tools/micro/scan_ablate.py).  For the same reason the loop body has no branches:
+    // an odd last step is peeled, and the dead half of a partial H=32 wave has left the kernel above.
     const int period = a.period;
     const bool has_y = a.y != nullptr;
     int next_fire = t0 + period - 1;                                    // t0 is a multiple of period
-    float *yp = has_y ? a.y + (b * (long)(T / period) + t0 / period) * H + l : nullptr;
+    float *yp = has_y ? a.y + (b * (long)(T / period) + t0 / period) * H + l : a.h_last + b * a.h_last_stride + l;
+    const int y_adv = has_y ? H : 0;
     float *hsp = TRAIN ? a.hs + (b * (long)(T + 1) + t0 + 1) * H + l : nullptr;
     float *gp = TRAIN ? a.gates + (b * (long)T + t0) * 3 * H + l : nullptr;
 
-    for (int c = c_begin; c < c_end; ++c) {
+    auto step = [&](int t, const float *xc) {
+        // (xr, xu, xcand and the weights carry the exponent scale)
+        const float xr = xc[0], xu = xc[H], xcand = xc[2 * H];
+        f2 ar = {0.f, 0.f}, au = {0.f, 0.f};
+        bcast_matvec2<H / 4>(reinterpret_cast<const float4 *>(&hb[s * H]), whr, whu, ar, au);
+        const float r = sigmoid_scaled(xr + (ar.x + ar.y));
+        const float u = sigmoid_scaled(xu + (au.x + au.y));
+        rhb[lane] = r * h;
+        wave_sync();
+        f2 ac = {0.f, 0.f}, ac2 = {0.f, 0.f};
+        bcast_matvec<H / 4>(reinterpret_cast<const float4 *>(&rhb[s * H]), whc, ac, ac2);
+        ac += ac2;
+        const float cc = tanh_scaled(xcand + (ac.x + ac.y));
+        h = fmaf(u, h - cc, cc);  // u*h + (1-u)*c
+        hb[lane] = h;
+        wave_sync();
+        if constexpr (TRAIN) {
+            *hsp = h;
+            gp[0] = r;
+            gp[H] = u;
+            gp[2 * H] = cc;
+            hsp += H;
+            gp += 3 * H;
+        }
+        *yp = h;
+        const bool fire = t == next_fire;
+        next_fire += fire ? period : 0;
+        yp += fire ? y_adv : 0;
+    };
+
+    const int c_full = t1 / CS;            // chunks [c_begin, c_full) run all CS steps
+    for (int c = c_begin; c < c_full; ++c) {
         f2 pre[3];
         load_chunk(c + PD, pre);          // in flight for the steps below
         const float *xc = &ring[c % RING][s * CF + l];
 #pragma unroll
-        for (int tt = 0; tt < CS; ++tt) {
-            const int t = c * CS + tt;
-            if (t < t1) {
-                const float xr = xc[tt * 3 * H], xu = xc[tt * 3 * H + H], xcand = xc[tt * 3 * H + 2 * H];
-                f2 ar = {0.f, 0.f}, au = {0.f, 0.f};
-                bcast_matvec2<H / 4>(reinterpret_cast<const float4 *>(&hb[s * H]), whr, whu, ar, au);
-                const float r = fast_sigmoid(xr + (ar.x + ar.y));
-                const float u = fast_sigmoid(xu + (au.x + au.y));
-                rhb[lane] = r * h;
-                wave_sync();
-                f2 ac = {0.f, 0.f}, ac2 = {0.f, 0.f};
-                bcast_matvec<H / 4>(reinterpret_cast<const float4 *>(&rhb[s * H]), whc, ac, ac2);
-                const float cc = fast_tanh(xcand + ((ac.x + ac.y) + (ac2.x + ac2.y)));
-                h = fmaf(u, h - cc, cc);  // u*h + (1-u)*c
-                hb[lane] = h;
-                wave_sync();
-                if (live) {
-                    if constexpr (TRAIN) {
-                        *hsp = h;
-                        gp[0] = r;
-                        gp[H] = u;
-                        gp[2 * H] = cc;
-                    }
-                    if (has_y && t == next_fire) *yp = h;
-                }
-                if constexpr (TRAIN) {
-                    hsp += H;
-                    gp += 3 * H;
-                }
-                if (t == next_fire) {
-                    next_fire += period;
-                    yp += H;
-                }
-            }
-        }
+        for (int tt = 0; tt < CS; ++tt) step(c * CS + tt, xc + tt * 3 * H);
         park_chunk(c + PD, pre);
         wave_sync();
     }
-    if (live) a.h_last[b * a.h_last_stride + l] = h;
+    if (c_full < c_end) step(c_full * CS, &ring[c_full % RING][s * CF + l]);   // odd T: one step left
+    a.h_last[b * a.h_last_stride + l] = h;
 }
 
 template <int H>

@@ -49,11 +49,14 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void input_proj_kernel(const Hpmn
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int n = n_base + 32 * nt + c;
-        bias[nt] = n < 2 * H ? a.bg[n] : a.bc[n - 2 * H];
+        // xp is produced in the scan's exponent domain (hpmn_hip.h: HpmnInputProj.xp): gate columns times
+        // -log2(e), candidate columns times -2 log2(e), folded into the stationary operand for free
+        const float sc = n < 2 * H ? NEG_LOG2E : 2.0f * NEG_LOG2E;
+        bias[nt] = sc * (n < 2 * H ? a.bg[n] : a.bc[n - 2 * H]);
 #pragma unroll
         for (int ks = 0; ks < KH; ++ks) {
             const int j = p * KH + ks;
-            wb[nt][ks] = n < 2 * H ? a.wg[(long)j * 2 * H + n] : a.wc[(long)j * H + (n - 2 * H)];
+            wb[nt][ks] = sc * (n < 2 * H ? a.wg[(long)j * 2 * H + n] : a.wc[(long)j * H + (n - 2 * H)]);
         }
     }
 

@@ -66,7 +66,9 @@ int hpmn_embed_gather(const int32_t *ids, const float *emb, float *out,
  *
  * (1) hpmn_gru_input_proj -- the time-parallel half (the x rows of _Linear,
  *     code/util.py:88-95, 99-107):
- *        xp[b,t, 0:2H] = x[b,t] wg[0:D] + bg,    xp[b,t, 2H:3H] = x[b,t] wc[0:D] + bc.
+ *        xp[b,t, 0:2H] = s (x[b,t] wg[0:D] + bg),    xp[b,t, 2H:3H] = 2s (x[b,t] wc[0:D] + bc),
+ *     s = -log2(e): xp is an opaque hand-over buffer between (1) and (2), kept in the exponent
+ *     domain of the scan's exp2-based sigmoid/tanh so no multiply sits on the serial chain.
  *     Input is EITHER x [B,T,D] (layers >= 1: the subsampled outputs of the layer below)
  *     OR, when x == NULL, gathered on the fly from (ids [B,Tids,F], emb [V,E]) with
  *     `front_zero` all-zero steps in front (code/hpmn.py:288-289), T == front_zero+Tids,
@@ -75,7 +77,7 @@ int hpmn_embed_gather(const int32_t *ids, const float *emb, float *out,
  *        x_out : optional [B,T,D], the materialised gathered input (training only).
  *
  * (2) hpmn_gru_scan_fwd -- the serial half: for t in 0..T-1
- *        [r,u] = sigmoid(xp[:, t, 0:2H] + h wg[D:]);  c = tanh(xp[:, t, 2H:] + (r*h) wc[D:])
+ *        [r,u] = sigmoid(xp[:, t, 0:2H]/s + h wg[D:]);  c = tanh(xp[:, t, 2H:]/2s + (r*h) wc[D:])
  *        h = u*h + (1-u)*c
  *   h_last  : final state, written at h_last[b*h_last_stride + 0..H)   (memory[:, i, :])
  *   y       : optional [B, T/period, H]  = outputs[:, period-1::period, :]   (next layer's input)

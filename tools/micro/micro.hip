@@ -83,10 +83,36 @@ __global__ void k_tput(float* out, long long* cyc, const float* in, int iters) {
                                "v_fmac_f32_dpp %0, %2, %3 row_newbcast:3 row_mask:0xf bank_mask:0xf\n"
                                "v_fmac_f32_dpp %1, %2, %4 row_newbcast:4 row_mask:0xf bank_mask:0xf"
                                : "+v"(a0), "+v"(a1) : "v"(h), "v"(w0), "v"(w1));)
+        } else if constexpr (V == 8) {   // pk_fma pairs separated by a (satisfied) s_waitcnt
+            REP16(asm volatile("v_pk_fma_f32 %0, %2, %3, %0\n v_pk_fma_f32 %1, %2, %3, %1\n s_waitcnt lgkmcnt(0)\n"
+                               "v_pk_fma_f32 %0, %2, %3, %0\n v_pk_fma_f32 %1, %2, %3, %1\n s_waitcnt lgkmcnt(0)"
+                               : "+v"(p0), "+v"(p1) : "v"(ph), "v"(pw));)
+        } else if constexpr (V == 9) {   // pk_fma pairs separated by s_nop 0
+            REP16(asm volatile("v_pk_fma_f32 %0, %2, %3, %0\n v_pk_fma_f32 %1, %2, %3, %1\n s_nop 0\n"
+                               "v_pk_fma_f32 %0, %2, %3, %0\n v_pk_fma_f32 %1, %2, %3, %1\n s_nop 0"
+                               : "+v"(p0), "+v"(p1) : "v"(ph), "v"(pw));)
+        } else if constexpr (V == 10) {  // 6 pk_fma per wave-uniform ds_read_b128 (the scan's mix), waits every read
+            typedef float f4 __attribute__((ext_vector_type(4)));
+            f4 r0;
+            REP16(asm volatile("ds_read_b128 %2, %5\n"
+                               "v_pk_fma_f32 %0, %3, %4, %0\n v_pk_fma_f32 %1, %3, %4, %1\n"
+                               "v_pk_fma_f32 %0, %3, %4, %0\n v_pk_fma_f32 %1, %3, %4, %1\n"
+                               "v_pk_fma_f32 %0, %3, %4, %0\n v_pk_fma_f32 %1, %3, %4, %1\n s_waitcnt lgkmcnt(0)"
+                               : "+v"(p0), "+v"(p1), "=&v"(r0) : "v"(ph), "v"(pw), "v"(0));)
+        } else if constexpr (V == 11) {  // pk_fma with an SGPR pair as the broadcast operand
+            REP16(asm volatile("v_pk_fma_f32 %0, s[20:21], %2, %0\n v_pk_fma_f32 %1, s[22:23], %2, %1\n"
+                               "v_pk_fma_f32 %0, s[20:21], %2, %0\n v_pk_fma_f32 %1, s[22:23], %2, %1"
+                               : "+v"(p0), "+v"(p1) : "v"(pw) : "s20", "s21", "s22", "s23");)
+        } else if constexpr (V == 12) {  // 2 waves' worth of independent pk_fma chains (4 accumulators)
+            f2 p2 = p0, p3 = p1;
+            REP16(asm volatile("v_pk_fma_f32 %0, %4, %5, %0\n v_pk_fma_f32 %1, %4, %5, %1\n"
+                               "v_pk_fma_f32 %2, %4, %5, %2\n v_pk_fma_f32 %3, %4, %5, %3"
+                               : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(ph), "v"(pw));)
+            p0 += p2; p1 += p3;
         }
     }
     long long t1 = __builtin_amdgcn_s_memtime();
-    if constexpr (V == 2) { a0 = p0.x + p0.y; a1 = p1.x + p1.y; }
+    if constexpr (V == 2 || V >= 8) { a0 = p0.x + p0.y; a1 = p1.x + p1.y; }
     out[threadIdx.x + 64 * blockIdx.x] = a0 + a1 + a2 + a3;
     if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
@@ -238,6 +264,11 @@ int main() {
     TP(5, 64, "v_fmac dependent chain");
     TP(6, 64, "v_fmac_dpp dependent chain");
     TP(7, 64, "v_fmac_dpp 2 chains");
+    TP(8, 64, "pk_fma x2 + s_waitcnt (per pk)");
+    TP(9, 64, "pk_fma x2 + s_nop (per pk)");
+    TP(10, 96, "6 pk_fma + ds_read_b128 + wait (per pk)");
+    TP(11, 64, "pk_fma sgpr-pair operand");
+    TP(12, 64, "pk_fma x4 indep");
     // blocks = 1024: 1 wave per SIMD on every SIMD
 #define LT(V, label) c = run([&] { hipLaunchKernelGGL((k_lat<V>), dim3(blocks), dim3(64), 0, 0, d_out, d_cyc, d_in, iters); }, d_cyc, blocks); \
     printf("lat  %-28s: %.3f ticks/iter\n", label, c / iters);

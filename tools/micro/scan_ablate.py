@@ -1,0 +1,89 @@
+"""Where do the cycles of a scan step go?  Builds timing-only variants of the product forward/backward
+scan kernels by text substitution on the product sources (nothing here ships), one executable per
+variant, and prints a runner script.  Usage (GPU box): python tools/micro/scan_ablate.py && sh tools/micro/run_ablate.sh"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, "hpmn_amd", "csrc")
+
+MAIN_FWD = r'''
+#include <cstdio>
+#include <vector>
+namespace hpmn { void set_last_hip_error(int) {} }
+int main() {
+    const int B = 500, T = 1024, H = 64, D = 32;
+    float *xp, *wg, *wc, *hl, *y, *hs, *gates;
+    hipMalloc(&xp, (size_t)B * T * 3 * H * 4); hipMemset(xp, 0, (size_t)B * T * 3 * H * 4);
+    hipMalloc(&wg, (D + H) * 2 * H * 4); hipMalloc(&wc, (D + H) * H * 4);
+    std::vector<float> w((D + H) * 2 * H, 0.01f);
+    hipMemcpy(wg, w.data(), (D + H) * 2 * H * 4, hipMemcpyHostToDevice);
+    hipMemcpy(wc, w.data(), (D + H) * H * 4, hipMemcpyHostToDevice);
+    hipMalloc(&hl, B * H * 4); hipMalloc(&y, (size_t)B * T / 2 * H * 4);
+    hipMalloc(&hs, (size_t)B * (T + 1) * H * 4); hipMalloc(&gates, (size_t)B * T * 3 * H * 4);
+    HpmnGruFwd a = {};
+    a.B = B; a.T = T; a.D = D; a.H = H; a.xp = xp; a.wg = wg; a.wc = wc; a.h_last = hl; a.h_last_stride = H;
+    a.y = y; a.period = 2; a.hs = hs; a.gates = gates;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int i = 0; i < 2; ++i) hpmn::gru_scan_fwd_dispatch(a, 0);
+    hipEventRecord(e0);
+    for (int i = 0; i < 5; ++i) hpmn::gru_scan_fwd_dispatch(a, 0);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    printf("%-44s %.4f ms/launch  %.0f cycles/step @2.4GHz\n", VARIANT, ms / 5, ms / 5 * 2.4e6 / T);
+    return 0;
+}
+'''
+
+
+def sub(s, old, new, count=1):
+    assert old in s, old
+    return s.replace(old, new, count)
+
+
+def fwd_variants(src):
+    out = {"f0 baseline": src}
+    v1 = src
+    for old in ("*hsp = h;", "gp[0] = r;", "gp[H] = u;", "gp[2 * H] = cc;"):
+        v1 = sub(v1, old, "")
+    v1 = sub(v1, "if (has_y && t == next_fire) *yp = h;", "")
+    out["f1 no global stores"] = v1
+    v2 = sub(v1, "v[i] = *reinterpret_cast<const f2 *>(xpb + (long)t * 3 * H + c_col[i]);",
+             "v[i] = f2{(float)t * 1e-6f, 0.f};")
+    out["f2 f1 + no prefetch loads"] = v2
+    v3 = sub(v2, "const float r = sigmoid_scaled(", "const float r = 0.5f + 0.25f * (")
+    v3 = sub(v3, "const float u = sigmoid_scaled(", "const float u = 0.5f + 0.25f * (")
+    v3 = sub(v3, "const float cc = tanh_scaled(", "const float cc = 0.1f * (")
+    out["f3 f2 + linear activations"] = v3
+    v4 = sub(v3, "                rhb[lane] = r * h;\n                wave_sync();", "                rhb[lane] = r * h;")
+    v4 = sub(v4, "                hb[lane] = h;\n                wave_sync();", "                hb[lane] = h;")
+    out["f4 f3 + no fence between write and reads"] = v4
+    v5 = sub(src, "const float r = sigmoid_scaled(", "const float r = 0.5f + 0.25f * (")
+    v5 = sub(v5, "const float u = sigmoid_scaled(", "const float u = 0.5f + 0.25f * (")
+    v5 = sub(v5, "const float cc = tanh_scaled(", "const float cc = 0.1f * (")
+    out["f5 linear activations only"] = v5
+    return out
+
+
+def main():
+    src = open(os.path.join(CSRC, "gru_scan_fwd.hip")).read()
+    lines = ["#!/bin/sh"]
+    for name, text in fwd_variants(src).items():
+        tag = name.split()[0]
+        path = os.path.join(HERE, "ablate_%s.hip" % tag)
+        with open(path, "w") as f:
+            f.write("#include <hip/hip_runtime.h>\n#include \"hpmn_hip.h\"\n" + text +
+                    "\n#define VARIANT \"%s\"\n" % name + MAIN_FWD)
+        exe = os.path.join(HERE, "ablate_%s" % tag)
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-w",
+                               "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", exe, path])
+        os.remove(path)
+        lines.append("./tools/micro/ablate_%s" % tag)
+    with open(os.path.join(HERE, "run_ablate.sh"), "w") as f:
+        f.write("\n".join(lines) + "\n")
+
+
+if __name__ == "__main__":
+    sys.exit(main())
