@@ -36,8 +36,8 @@ __global__ __launch_bounds__(64, 1) void gru_scan_bwd_kernel(const HpmnGruBwd a)
     const int l = lane % H;
     const int B = a.B, T = a.T, D = a.D;
     const long b_raw = SPW == 1 ? (long)blockIdx.x : (long)blockIdx.x * SPW + s;
-    const bool live = SPW == 1 ? true : (b_raw < B);
-    const long b = live ? b_raw : (long)B - 1;
+    if (SPW != 1 && b_raw >= B) return;   // partial last wave at H=32: the dead half is not needed below
+    const long b = b_raw;
 
     f2 wcT[H / 2], wgT[H];
 #pragma unroll
@@ -53,7 +53,10 @@ __global__ __launch_bounds__(64, 1) void gru_scan_bwd_kernel(const HpmnGruBwd a)
     const bool has_dy = a.d_y != nullptr;
     const float *gb = a.gates + b * (long)T * 3 * H;
     const float *hsb = a.hs + b * (long)(T + 1) * H;
-    const float *dyb = has_dy ? a.d_y + b * (long)(T / period) * H + l : nullptr;
+    // (without d_y the stream below still loads -- from a valid dummy row -- and masks the value out: the
+    // time loop must stay free of branches, see the note at the loop)
+    const float *dyb = has_dy ? a.d_y + b * (long)(T / period) * H + l : a.d_h_last + b * a.d_h_last_stride + l;
+    const long dy_stride = has_dy ? H : 0;
 
     // steps t_hi-1 .. t_lo0 of this launch, walking backwards (whole sequence unless time-chunked)
     const int t_lo0 = a.t_begin;
@@ -75,7 +78,7 @@ __global__ __launch_bounds__(64, 1) void gru_scan_bwd_kernel(const HpmnGruBwd a)
     // (t_hi is a multiple of period, so step t_hi-1 has one)
     int pf_fire = t_hi - 1, pf_row = t_hi / period - 1;
 
-    struct Pre { f2 g[3]; f2 hp; float dy[BCS]; };
+    struct Pre { f2 g[3]; f2 hp; float dy[BCS]; bool m[BCS]; };
     auto load_chunk = [&](int q, Pre &p) {
         const int t_lo = t_hi - BCS * (q + 1);
 #pragma unroll
@@ -91,12 +94,13 @@ __global__ __launch_bounds__(64, 1) void gru_scan_bwd_kernel(const HpmnGruBwd a)
         }
 #pragma unroll
         for (int tt = BCS - 1; tt >= 0; --tt) {
-            p.dy[tt] = 0.f;
-            if (has_dy && t_lo + tt == pf_fire && pf_row >= 0) {
-                p.dy[tt] = dyb[(long)pf_row * H];
-                pf_row -= 1;
-                pf_fire -= period;
-            }
+            // unconditional load from a clamped row + a wave-uniform "this step has one" flag applied when
+            // the value is parked
+            const bool fire = has_dy && t_lo + tt == pf_fire && pf_row >= 0;
+            p.dy[tt] = dyb[(long)(pf_row > 0 ? pf_row : 0) * dy_stride];
+            p.m[tt] = fire;
+            pf_row -= fire ? 1 : 0;
+            pf_fire -= fire ? period : 0;
         }
     };
     auto park_chunk = [&](int q, const Pre &p) {
@@ -105,7 +109,7 @@ __global__ __launch_bounds__(64, 1) void gru_scan_bwd_kernel(const HpmnGruBwd a)
         for (int i = 0; i < 3; ++i) *reinterpret_cast<f2 *>(gd + 2 * (i * H + l)) = p.g[i];
         *reinterpret_cast<f2 *>(&hring[q % BRING][s * HF + 2 * l]) = p.hp;
 #pragma unroll
-        for (int tt = 0; tt < BCS; ++tt) dring[q % BRING][tt * 64 + lane] = p.dy[tt];
+        for (int tt = 0; tt < BCS; ++tt) dring[q % BRING][tt * 64 + lane] = p.m[tt] ? p.dy[tt] : 0.f;
     };
 
     const int nchunk = (t_hi - t_lo0 + BCS - 1) / BCS;
@@ -118,9 +122,42 @@ __global__ __launch_bounds__(64, 1) void gru_scan_bwd_kernel(const HpmnGruBwd a)
         }
     }
     float dh = (t_hi == T) ? a.d_h_last[b * a.d_h_last_stride + l] : a.dh_carry[b * H + l];
+    settle(dh);   // land the load here, not (per the waitcnt pass's loop merge) in every step
     wave_sync();
 
-    for (int q = 0; q < nchunk; ++q) {
+    // One step.  The loop around it has NO branches and every store is unconditional: with control flow
+    // in the body the compiler's s_waitcnt pass loses count of the stores in flight and the wait for the
+    // prefetched chunk becomes vmcnt(0), i.e. a wait for every store of the chunk to reach memory (and a
+    // conditional d_y load made each chunk wait out a full HBM round trip at the join); see
+    // tools/micro/scan_ablate.py and the note in gru_scan_fwd.hip.
+    auto step = [&](int t, int tt, const float *gc, const float *hc, const float *dc) {
+        const float r = gc[tt * 3 * H], u = gc[tt * 3 * H + H], c = gc[tt * 3 * H + 2 * H];
+        const float hp = hc[tt * H];
+        dh += dc[tt * 64];
+        const float omu = 1.f - u;
+        const float dcp = dh * omu * (1.f - c * c);
+        const float dau = dh * (hp - c) * u * omu;
+        bufA[lane] = dcp;
+        wave_sync();
+        f2 d0 = {0.f, 0.f}, d1 = {0.f, 0.f};
+        bcast_matvec<H / 4>(reinterpret_cast<const float4 *>(&bufA[s * H]), wcT, d0, d1);
+        const float drh = (d0.x + d0.y) + (d1.x + d1.y);
+        const float dar = drh * hp * r * (1.f - r);
+        bufB[s * 2 * H + l] = dar;
+        bufB[s * 2 * H + H + l] = dau;
+        wave_sync();
+        f2 e0 = {0.f, 0.f}, e1 = {0.f, 0.f};
+        bcast_matvec<2 * H / 4>(reinterpret_cast<const float4 *>(&bufB[s * 2 * H]), wgT, e0, e1);
+        float *da = a.d_act + (b * T + t) * 3 * H + l;
+        da[0] = dar;
+        da[H] = dau;
+        da[2 * H] = dcp;
+        dh = fmaf(dh, u, fmaf(drh, r, (e0.x + e0.y) + (e1.x + e1.y)));
+        wave_sync();
+    };
+
+    const int nfull = (t_hi - t_lo0) / BCS;    // chunks whose BCS steps all lie inside [t_lo0, t_hi)
+    for (int q = 0; q < nfull; ++q) {
         Pre pre;
         load_chunk(q + BPD, pre);
         const int t_lo = t_hi - BCS * (q + 1);
@@ -128,41 +165,15 @@ __global__ __launch_bounds__(64, 1) void gru_scan_bwd_kernel(const HpmnGruBwd a)
         const float *hc = &hring[q % BRING][s * HF + l];
         const float *dc = &dring[q % BRING][lane];
 #pragma unroll
-        for (int jj = 0; jj < BCS; ++jj) {
-            const int tt = BCS - 1 - jj;       // row inside the chunk, walking backwards in time
-            const int t = t_lo + tt;
-            if (t >= t_lo0) {
-                const float r = gc[tt * 3 * H], u = gc[tt * 3 * H + H], c = gc[tt * 3 * H + 2 * H];
-                const float hp = hc[tt * H];
-                dh += dc[tt * 64];
-                const float omu = 1.f - u;
-                const float dcp = dh * omu * (1.f - c * c);
-                const float dau = dh * (hp - c) * u * omu;
-                bufA[lane] = dcp;
-                wave_sync();
-                f2 d0 = {0.f, 0.f}, d1 = {0.f, 0.f};
-                bcast_matvec<H / 4>(reinterpret_cast<const float4 *>(&bufA[s * H]), wcT, d0, d1);
-                const float drh = (d0.x + d0.y) + (d1.x + d1.y);
-                const float dar = drh * hp * r * (1.f - r);
-                bufB[s * 2 * H + l] = dar;
-                bufB[s * 2 * H + H + l] = dau;
-                wave_sync();
-                f2 e0 = {0.f, 0.f}, e1 = {0.f, 0.f};
-                bcast_matvec<2 * H / 4>(reinterpret_cast<const float4 *>(&bufB[s * 2 * H]), wgT, e0, e1);
-                if (live) {
-                    float *da = a.d_act + (b * T + t) * 3 * H + l;
-                    da[0] = dar;
-                    da[H] = dau;
-                    da[2 * H] = dcp;
-                }
-                dh = fmaf(dh, u, fmaf(drh, r, (e0.x + e0.y) + (e1.x + e1.y)));
-                wave_sync();
-            }
-        }
+        for (int jj = 0; jj < BCS; ++jj) step(t_lo + BCS - 1 - jj, BCS - 1 - jj, gc, hc, dc);   // backwards in time
         park_chunk(q + BPD, pre);
         wave_sync();
     }
-    if (live && t_lo0 > 0) a.dh_carry[b * H + l] = dh;
+    if (nfull < nchunk) {   // odd number of steps: the oldest step sits alone in the last chunk's top row
+        const int q = nfull;
+        step(t_lo0, BCS - 1, &gring[q % BRING][s * GF + l], &hring[q % BRING][s * HF + l], &dring[q % BRING][lane]);
+    }
+    if (t_lo0 > 0) a.dh_carry[b * H + l] = dh;
 }
 
 int gru_scan_bwd_dispatch(const HpmnGruBwd &a, hipStream_t st) {
