@@ -10,9 +10,12 @@
 // reduction order is free we map half-wave p to the CONTIGUOUS half [p*K/2, (p+1)*K/2) of the row,
 // so each lane's A operands are simply 16-byte loads of its own row half (every fetched line is
 // fully used; a gathered 64-byte embedding row is exactly one lane's half row at D=32) and B is
-// W[p*K/2 + ks][n] kept register-stationary for the whole launch.  The C/D layout puts 32
-// consecutive n of one row in 32 consecutive lanes: stores are whole 128-byte lines.
-// Persistent waves walk 32-row tiles; the next tile's A is in flight under the current MFMAs.
+// W[p*K/2 + ks][n] kept register-stationary for the whole launch.  The product is computed
+// TRANSPOSED (the weights are the MFMA "A" operand, the rows the "B" operand): in the C/D layout a
+// lane then owns one output row and 4 consecutive output columns per register quad, so the
+// epilogue is 16-byte stores (4x fewer store instructions than the row-major product, whose
+// lanes hold 4 consecutive ROWS of one column).  The bias rides in as one extra k-step.
+// Persistent waves walk 32-row tiles; the next tile's rows are in flight under the current MFMAs.
 #include "common.h"
 
 namespace hpmn {
@@ -52,7 +55,7 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void input_proj_kernel(const Hpmn
         // xp is produced in the scan's exponent domain (hpmn_hip.h: HpmnInputProj.xp): gate columns times
         // -log2(e), candidate columns times -2 log2(e), folded into the stationary operand for free
         const float sc = n < 2 * H ? NEG_LOG2E : 2.0f * NEG_LOG2E;
-        bias[nt] = sc * (n < 2 * H ? a.bg[n] : a.bc[n - 2 * H]);
+        bias[nt] = p == 0 ? sc * (n < 2 * H ? a.bg[n] : a.bc[n - 2 * H]) : 0.f;   // k slot 0 of the bias step
 #pragma unroll
         for (int ks = 0; ks < KH; ++ks) {
             const int j = p * KH + ks;
@@ -99,11 +102,15 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void input_proj_kernel(const Hpmn
                 for (int q = 0; q < Q; ++q) *reinterpret_cast<float4 *>(a.x_out + m * K + p * KH + 4 * q) = cur[q];
             }
         }
+        // acc[nt] = (W^T tile)[n, k] (rows^T)[k, m]: D[i = n][j = m]; first k-step: bias[n] * 1
         f32x16 acc[NT];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+        for (int nt = 0; nt < NT; ++nt) {
+            f32x16 z;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[nt][r] = bias[nt];
+            for (int r = 0; r < 16; ++r) z[r] = 0.f;
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(bias[nt], 1.0f, z, 0, 0, 0);
+        }
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
             const float av[4] = {cur[q].x, cur[q].y, cur[q].z, cur[q].w};
@@ -111,16 +118,19 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void input_proj_kernel(const Hpmn
             for (int e = 0; e < 4; ++e)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], wb[nt][4 * q + e], acc[nt], 0, 0, 0);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[nt][4 * q + e], av[e], acc[nt], 0, 0, 0);
         }
-        // C/D layout: reg r -> row (r&3) + 8*(r>>2) + 4*p, col c
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const long rr = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * p;
+        // C/D layout: lane (c, p), reg r -> D row (r&3) + 8*(r>>2) + 4*p = column n of row m = tile*32 + c
+        {
+            const long rr = tile * 32 + c;
             if (rr < M) {
-                const long m = flat_row(rr);
+                float *dst = a.xp + flat_row(rr) * N + n_base + 4 * p;
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) a.xp[m * N + n_base + 32 * nt + c] = acc[nt][r];
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        *reinterpret_cast<float4 *>(dst + 32 * nt + 8 * g) =
+                            make_float4(acc[nt][4 * g], acc[nt][4 * g + 1], acc[nt][4 * g + 2], acc[nt][4 * g + 3]);
             }
         }
 #pragma unroll
@@ -182,16 +192,20 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void gru_dx_kernel(const HpmnGruW
             for (int e = 0; e < 4; ++e)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], wb[nt][4 * q + e], acc[nt], 0, 0, 0);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[nt][4 * q + e], av[e], acc[nt], 0, 0, 0);
         }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const long rr = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * p;
+        // transposed product (see the file header): lane (c, p) owns row tile*32 + c, columns 32nt + 8g + 4p + 0..3
+        {
+            const long rr = tile * 32 + c;
             if (rr < M) {
-                const long m = flat_row(rr);
+                float *dst = a.d_x + flat_row(rr) * D + 4 * p;
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    if (32 * nt + c < D) a.d_x[m * D + 32 * nt + c] = acc[nt][r];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        if (32 * nt + 8 * g + 4 * p < D)      // D is a multiple of 4: a quad is all in or all out
+                            *reinterpret_cast<float4 *>(dst + 32 * nt + 8 * g) =
+                                make_float4(acc[nt][4 * g], acc[nt][4 * g + 1], acc[nt][4 * g + 2], acc[nt][4 * g + 3]);
             }
         }
 #pragma unroll

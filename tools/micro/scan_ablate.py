@@ -38,6 +38,53 @@ int main() {
 '''
 
 
+MAIN_BWD = r'''
+#include <cstdio>
+#include <vector>
+namespace hpmn { void set_last_hip_error(int) {} }
+int main() {
+    const int B = 500, T = 1024, H = 64, D = 32;
+    float *wg, *wc, *dhl, *dy, *hs, *gates, *dact, *carry;
+    hipMalloc(&wg, (D + H) * 2 * H * 4); hipMalloc(&wc, (D + H) * H * 4);
+    std::vector<float> w((D + H) * 2 * H, 0.01f);
+    hipMemcpy(wg, w.data(), (D + H) * 2 * H * 4, hipMemcpyHostToDevice);
+    hipMemcpy(wc, w.data(), (D + H) * H * 4, hipMemcpyHostToDevice);
+    hipMalloc(&dhl, B * H * 4); hipMemset(dhl, 0, B * H * 4);
+    hipMalloc(&carry, B * H * 4);
+    hipMalloc(&dy, (size_t)B * T / 2 * H * 4); hipMemset(dy, 0, (size_t)B * T / 2 * H * 4);
+    hipMalloc(&hs, (size_t)B * (T + 1) * H * 4); hipMemset(hs, 0, (size_t)B * (T + 1) * H * 4);
+    hipMalloc(&gates, (size_t)B * T * 3 * H * 4); hipMemset(gates, 0, (size_t)B * T * 3 * H * 4);
+    hipMalloc(&dact, (size_t)B * T * 3 * H * 4);
+    HpmnGruBwd a = {};
+    a.B = B; a.T = T; a.D = D; a.H = H; a.wg = wg; a.wc = wc; a.hs = hs; a.gates = gates;
+    a.d_h_last = dhl; a.d_h_last_stride = H; a.d_y = dy; a.period = 2; a.d_act = dact; a.dh_carry = carry;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int i = 0; i < 2; ++i) hpmn::gru_scan_bwd_dispatch(a, 0);
+    hipEventRecord(e0);
+    for (int i = 0; i < 5; ++i) hpmn::gru_scan_bwd_dispatch(a, 0);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    printf("%-44s %.4f ms/launch  %.0f cycles/step @2.4GHz\n", VARIANT, ms / 5, ms / 5 * 2.4e6 / T);
+    return 0;
+}
+'''
+
+
+def bwd_variants(src):
+    out = {"b0 baseline": src}
+    v1 = src
+    for old in ("da[0] = dar;", "da[H] = dau;", "da[2 * H] = dcp;"):
+        v1 = sub(v1, old, "")
+    out["b1 no global stores"] = v1
+    v2 = sub(v1, "p.g[i] = *reinterpret_cast<const f2 *>(gb + (long)t * 3 * H + g_col[i]);", "p.g[i] = f2{(float)t * 1e-6f, 0.5f};")
+    v2 = sub(v2, "p.hp = *reinterpret_cast<const f2 *>(hsb + (long)t * H + h_col);", "p.hp = f2{(float)t * 1e-6f, 0.5f};")
+    v2 = sub(v2, "p.dy[tt] = dyb[(long)(pf_row > 0 ? pf_row : 0) * dy_stride];", "p.dy[tt] = (float)pf_row * 1e-6f;")
+    out["b2 b1 + no prefetch loads"] = v2
+    v3 = sub(src, "p.dy[tt] = dyb[(long)(pf_row > 0 ? pf_row : 0) * dy_stride];", "p.dy[tt] = (float)pf_row * 1e-6f;")
+    out["b3 no d_y loads only"] = v3
+    return out
+
+
 def sub(s, old, new, count=1):
     assert old in s, old
     return s.replace(old, new, count)
@@ -48,7 +95,7 @@ def fwd_variants(src):
     v1 = src
     for old in ("*hsp = h;", "gp[0] = r;", "gp[H] = u;", "gp[2 * H] = cc;"):
         v1 = sub(v1, old, "")
-    v1 = sub(v1, "if (has_y && t == next_fire) *yp = h;", "")
+    v1 = sub(v1, "        *yp = h;\n", "")
     out["f1 no global stores"] = v1
     v2 = sub(v1, "v[i] = *reinterpret_cast<const f2 *>(xpb + (long)t * 3 * H + c_col[i]);",
              "v[i] = f2{(float)t * 1e-6f, 0.f};")
@@ -57,8 +104,8 @@ def fwd_variants(src):
     v3 = sub(v3, "const float u = sigmoid_scaled(", "const float u = 0.5f + 0.25f * (")
     v3 = sub(v3, "const float cc = tanh_scaled(", "const float cc = 0.1f * (")
     out["f3 f2 + linear activations"] = v3
-    v4 = sub(v3, "                rhb[lane] = r * h;\n                wave_sync();", "                rhb[lane] = r * h;")
-    v4 = sub(v4, "                hb[lane] = h;\n                wave_sync();", "                hb[lane] = h;")
+    v4 = sub(v3, "        rhb[lane] = r * h;\n        wave_sync();", "        rhb[lane] = r * h;")
+    v4 = sub(v4, "        hb[lane] = h;\n        wave_sync();", "        hb[lane] = h;")
     out["f4 f3 + no fence between write and reads"] = v4
     v5 = sub(src, "const float r = sigmoid_scaled(", "const float r = 0.5f + 0.25f * (")
     v5 = sub(v5, "const float u = sigmoid_scaled(", "const float u = 0.5f + 0.25f * (")
@@ -76,6 +123,18 @@ def main():
         with open(path, "w") as f:
             f.write("#include <hip/hip_runtime.h>\n#include \"hpmn_hip.h\"\n" + text +
                     "\n#define VARIANT \"%s\"\n" % name + MAIN_FWD)
+        exe = os.path.join(HERE, "ablate_%s" % tag)
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-w",
+                               "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", exe, path])
+        os.remove(path)
+        lines.append("./tools/micro/ablate_%s" % tag)
+    srcb = open(os.path.join(CSRC, "gru_scan_bwd.hip")).read()
+    for name, text in bwd_variants(srcb).items():
+        tag = name.split()[0]
+        path = os.path.join(HERE, "ablate_%s.hip" % tag)
+        with open(path, "w") as f:
+            f.write("#include <hip/hip_runtime.h>\n#include \"hpmn_hip.h\"\n" + text +
+                    "\n#define VARIANT \"%s\"\n" % name + MAIN_BWD)
         exe = os.path.join(HERE, "ablate_%s" % tag)
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-w",
                                "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", exe, path])
