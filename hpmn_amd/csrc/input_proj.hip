@@ -27,7 +27,7 @@ constexpr int RW_WAVES = 4;     // waves per workgroup (each owns its own 32-row
 // K = reduction length; a wave computes NT 32-column output tiles, the NS column groups of a row tile
 // go to NS different waves (NT*NS*32 = 3H): at H=64 the 6 tiles are split 3+3 so the stationary
 // weights (NT*K/2 registers) + accumulators + double-buffered A fit without scratch.
-template <int K, int NT, int NS, bool GATHER>
+template <int K, int NT, int NS, bool GATHER, bool XOUT>
 __global__ __launch_bounds__(64 * RW_WAVES, 1) void input_proj_kernel(const HpmnInputProj a) {
     constexpr int KH = K / 2;        // k range of one half-wave
     constexpr int Q = KH / 4;        // float4 loads per lane per tile
@@ -37,13 +37,15 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void input_proj_kernel(const Hpmn
     const int H = a.H, N = 3 * H;
     // rows of this launch: steps [t_begin, t_begin+TL) of every sequence; row r -> (b, t) -> flat row m = b*T + t
     const int TL = a.t_len > 0 ? a.t_len : a.T;
-    const long M = (long)a.B * TL;
-    const long ntile = (M + 31) / 32;
-    auto flat_row = [&](long r) -> long { const long b = r / TL; return b * a.T + a.t_begin + (r - b * TL); };
-    const long gwave = (long)blockIdx.x * RW_WAVES + (threadIdx.x >> 6);
+    // row arithmetic is 32-bit (the dispatcher rejects B*T >= 2^31): 64-bit divisions compile to branchy
+    // code, and control flow inside the tile loop is what defeats the s_waitcnt bookkeeping (see below)
+    const unsigned M = (unsigned)a.B * (unsigned)TL;
+    const unsigned ntile = (M + 31u) / 32u;
+    auto flat_row = [&](unsigned r) -> unsigned { const unsigned b = r / (unsigned)TL; return b * a.T + a.t_begin + (r - b * TL); };
+    const unsigned gwave = blockIdx.x * RW_WAVES + (threadIdx.x >> 6);
     const int ns = (int)(gwave % NS);              // which column group
-    const long wave_id = gwave / NS;
-    const long nwave = (long)gridDim.x * RW_WAVES / NS;
+    const unsigned wave_id = gwave / NS;
+    const unsigned nwave = gridDim.x * RW_WAVES / NS;
     const int n_base = ns * NT * 32;
 
     // B operand: Wcat[p*KH + ks][n_base + 32*nt + c], Wcat = [wg[0:D] | wc[0:D]]
@@ -63,46 +65,100 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void input_proj_kernel(const Hpmn
         }
     }
 
-    auto load_a = [&](long tile, float4 (&v)[Q]) {
-        const long rr = tile * 32 + c;
-        const bool ok = rr < M;
-        const long m = ok ? flat_row(rr) : 0;
-        if constexpr (GATHER) {
-            const long b = ok ? m / a.T : 0;
-            const int t = ok ? (int)(m - b * a.T) - a.front_zero : -1;
+    // No lane is ever "out of range": lanes past the last row (and prefetches past the last tile) are CLAMPED
+    // to row M-1, so they load, compute and store exactly what that row's owner does (identical bytes to
+    // the same address).  That keeps every load and store of the tile loop unconditional -- with stores
+    // inside branches the s_waitcnt pass can no longer count them and turns the waits for the prefetched
+    // ids/rows into waits for the previous tile's stores (seen in the ISA as vmcnt(3) at the loop top).
+    auto tile_row = [&](unsigned tile) -> unsigned { const unsigned rr = tile * 32u + c; return rr < M ? rr : M - 1u; };
+
+    // GATHER: the row of a tile is two DEPENDENT HBM reads (id, then its embedding row).  One tile of
+    // MFMAs (~1.4 us) hides neither, so ids run three tiles ahead and rows two tiles ahead of the tile
+    // being multiplied (measured with tools/micro/scan_ablate.py: 183 -> ~120 us at C3 layer 0, where the
+    // kernel was latency-bound at 1.2 TB/s without its stores).
+    // (load_ids must not LOOK at the ids it loads -- a compare would wait for them on the spot: the address
+    // is clamped instead and "this row is all zero" travels in `live`; the id-0 mask is applied in load_rows)
+    auto load_ids = [&](unsigned tile, int (&id)[Q], bool &live) {
+        const unsigned m = flat_row(tile_row(tile));
+        const unsigned b = m / (unsigned)a.T;
+        const int t = (int)(m - b * a.T) - a.front_zero;
+        live = t >= 0;
+        const long base = ((long)b * a.Tids + (live ? t : 0)) * a.F;
 #pragma unroll
-            for (int q = 0; q < Q; ++q) {
-                const int j = p * KH + 4 * q;
-                const int f = j / a.E;
-                v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (t >= 0) {
-                    const int id = a.ids[(b * a.Tids + t) * a.F + f];
-                    if (!(a.mask_id0 && id == 0))
-                        v[q] = *reinterpret_cast<const float4 *>(a.emb + (long)id * a.E + (j - f * a.E));
-                }
-            }
-        } else {
+        for (int q = 0; q < Q; ++q) id[q] = a.ids[base + (p * KH + 4 * q) / a.E];
+    };
+    // rows are loaded UNCONDITIONALLY (every id read from the clamped address is a valid row) and zeroed by
+    // `keep` bits when they are consumed: conditional loads put branches and full vmcnt waits into the loop
+    auto load_rows = [&](const int (&id)[Q], bool live, float4 (&v)[Q], unsigned &keep) {
+        keep = 0;
 #pragma unroll
-            for (int q = 0; q < Q; ++q) {
-                v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ok) v[q] = *reinterpret_cast<const float4 *>(a.x + m * K + p * KH + 4 * q);
-            }
+        for (int q = 0; q < Q; ++q) {
+            const int j = p * KH + 4 * q;
+            const int f = j / a.E;
+            v[q] = *reinterpret_cast<const float4 *>(a.emb + (long)id[q] * a.E + (j - f * a.E));
+            keep |= (live && !(a.mask_id0 && id[q] == 0)) ? (1u << q) : 0u;
         }
     };
-
-    float4 cur[Q], nxt[Q];
-    if (wave_id < ntile) load_a(wave_id, cur);
-    for (long tile = wave_id; tile < ntile; tile += nwave) {
-        if (tile + nwave < ntile) load_a(tile + nwave, nxt);
-        if constexpr (GATHER) {
-            const long rr = tile * 32 + c;
-            const long m = rr < M ? flat_row(rr) : 0;
-            if (ns == 0 && a.x_out != nullptr && rr < M) {
+    auto load_x = [&](unsigned tile, float4 (&v)[Q]) {
+        const long m = flat_row(tile_row(tile));
 #pragma unroll
-                for (int q = 0; q < Q; ++q) *reinterpret_cast<float4 *>(a.x_out + m * K + p * KH + 4 * q) = cur[q];
+        for (int q = 0; q < Q; ++q) v[q] = *reinterpret_cast<const float4 *>(a.x + m * K + p * KH + 4 * q);
+    };
+
+    float4 cur[Q], nxt[Q], nx2[Q];
+    int idn[Q];                         // ids of the tile whose rows are fetched next
+    bool liven = false;
+    unsigned kcur = ~0u, knxt = ~0u, knx2 = ~0u;   // per-stage keep bits (GATHER only)
+    if constexpr (GATHER) {
+        int id0[Q];
+        bool live0;
+        load_ids(wave_id, id0, live0);
+        load_ids(wave_id + nwave, idn, liven);
+        load_rows(id0, live0, cur, kcur);
+        load_rows(idn, liven, nxt, knxt);
+        load_ids(wave_id + 2 * nwave, idn, liven);
+    } else {
+        load_x(wave_id, cur);
+    }
+    // Land the prologue's loads before entering the loop (one exposed latency per launch): the s_waitcnt
+    // pass merges the loop-entry state with the back-edge state, and loads still pending at entry (nothing
+    // issued after them yet) would make every in-loop wait for a prefetched value a wait for (almost) all
+    // outstanding memory operations, i.e. for the previous tile's stores.
+    auto land4 = [](float4 &v) { settle(v.x); settle(v.y); settle(v.z); settle(v.w); };
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        land4(cur[q]);
+        if constexpr (GATHER) {
+            land4(nxt[q]);
+            asm volatile("" : "+v"(idn[q]));
+        }
+    }
+    for (unsigned tile = wave_id; tile < ntile; tile += nwave) {
+        if constexpr (GATHER) {
+            load_rows(idn, liven, nx2, knx2);        // rows of tile + 2
+            load_ids(tile + 3 * nwave, idn, liven);
+        } else {
+            load_x(tile + nwave, nxt);
+        }
+        if constexpr (GATHER) {
+#pragma unroll
+            for (int q = 0; q < Q; ++q)
+                if (!((kcur >> q) & 1u)) cur[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (XOUT) {
+                // the NS waves that share this row tile each store 1/NS of the gathered row (selects, not
+                // a branch on ns)
+                static_assert(Q % NS == 0, "x_out pieces split evenly over the column groups");
+                float *xo = a.x_out + (long)flat_row(tile_row(tile)) * K + p * KH + 4 * (Q / NS) * ns;
+#pragma unroll
+                for (int i = 0; i < Q / NS; ++i) {
+                    float4 v = cur[i];
+#pragma unroll
+                    for (int g = 1; g < NS; ++g)
+                        if (ns == g) v = cur[g * (Q / NS) + i];
+                    *reinterpret_cast<float4 *>(xo + 4 * i) = v;
+                }
             }
         }
-        // acc[nt] = (W^T tile)[n, k] (rows^T)[k, m]: D[i = n][j = m]; first k-step: bias[n] * 1
         f32x16 acc[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -122,19 +178,21 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void input_proj_kernel(const Hpmn
         }
         // C/D layout: lane (c, p), reg r -> D row (r&3) + 8*(r>>2) + 4*p = column n of row m = tile*32 + c
         {
-            const long rr = tile * 32 + c;
-            if (rr < M) {
-                float *dst = a.xp + flat_row(rr) * N + n_base + 4 * p;
+            float *dst = a.xp + (long)flat_row(tile_row(tile)) * N + n_base + 4 * p;
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                        *reinterpret_cast<float4 *>(dst + 32 * nt + 8 * g) =
-                            make_float4(acc[nt][4 * g], acc[nt][4 * g + 1], acc[nt][4 * g + 2], acc[nt][4 * g + 3]);
-            }
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4 *>(dst + 32 * nt + 8 * g) =
+                        make_float4(acc[nt][4 * g], acc[nt][4 * g + 1], acc[nt][4 * g + 2], acc[nt][4 * g + 3]);
         }
 #pragma unroll
-        for (int q = 0; q < Q; ++q) cur[q] = nxt[q];
+        for (int q = 0; q < Q; ++q) {
+            cur[q] = nxt[q];
+            if constexpr (GATHER) nxt[q] = nx2[q];
+        }
+        kcur = knxt;
+        knxt = knx2;
     }
 }
 
@@ -148,11 +206,11 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void gru_dx_kernel(const HpmnGruW
     const int c = lane & 31, p = lane >> 5;
     const int D = a.D;
     const int TL = a.t_len > 0 ? a.t_len : a.T;
-    const long M = (long)a.B * TL;
-    const long ntile = (M + 31) / 32;
-    auto flat_row = [&](long r) -> long { const long b = r / TL; return b * a.T + a.t_begin + (r - b * TL); };
-    const long wave_id = (long)blockIdx.x * RW_WAVES + (threadIdx.x >> 6);
-    const long nwave = (long)gridDim.x * RW_WAVES;
+    const unsigned M = (unsigned)a.B * (unsigned)TL;          // 32-bit row arithmetic: see input_proj_kernel
+    const unsigned ntile = (M + 31u) / 32u;
+    auto flat_row = [&](unsigned r) -> unsigned { const unsigned b = r / (unsigned)TL; return b * a.T + a.t_begin + (r - b * TL); };
+    const unsigned wave_id = blockIdx.x * RW_WAVES + (threadIdx.x >> 6);
+    const unsigned nwave = gridDim.x * RW_WAVES;
 
     // B operand: B[k = j][n = d] = Wx[d][j], j = p*KH + ks;  row d of [wg[0:D] | wc[0:D]] is contiguous per source
     float wb[NT][KH];
@@ -167,19 +225,20 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void gru_dx_kernel(const HpmnGruW
             wb[nt][ks] = v;
         }
     }
-    auto load_a = [&](long tile, float4 (&v)[Q]) {
-        const long rr = tile * 32 + c;
-        const long m = rr < M ? flat_row(rr) : 0;
+    // rows past the end are clamped to M-1 (duplicate, identical work): no conditional loads or stores in
+    // the tile loop -- see input_proj_kernel
+    auto tile_row = [&](unsigned tile) -> unsigned { const unsigned rr = tile * 32u + c; return rr < M ? rr : M - 1u; };
+    auto load_a = [&](unsigned tile, float4 (&v)[Q]) {
+        const long m = flat_row(tile_row(tile));
 #pragma unroll
-        for (int q = 0; q < Q; ++q) {
-            v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (rr < M) v[q] = *reinterpret_cast<const float4 *>(a.d_act + m * K + p * KH + 4 * q);
-        }
+        for (int q = 0; q < Q; ++q) v[q] = *reinterpret_cast<const float4 *>(a.d_act + m * K + p * KH + 4 * q);
     };
     float4 cur[Q], nxt[Q];
-    if (wave_id < ntile) load_a(wave_id, cur);
-    for (long tile = wave_id; tile < ntile; tile += nwave) {
-        if (tile + nwave < ntile) load_a(tile + nwave, nxt);
+    load_a(wave_id, cur);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) { settle(cur[q].x); settle(cur[q].y); settle(cur[q].z); settle(cur[q].w); }   // see input_proj_kernel
+    for (unsigned tile = wave_id; tile < ntile; tile += nwave) {
+        load_a(tile + nwave, nxt);
         f32x16 acc[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
@@ -196,17 +255,14 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void gru_dx_kernel(const HpmnGruW
         }
         // transposed product (see the file header): lane (c, p) owns row tile*32 + c, columns 32nt + 8g + 4p + 0..3
         {
-            const long rr = tile * 32 + c;
-            if (rr < M) {
-                float *dst = a.d_x + flat_row(rr) * D + 4 * p;
+            float *dst = a.d_x + (long)flat_row(tile_row(tile)) * D + 4 * p;
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                        if (32 * nt + 8 * g + 4 * p < D)      // D is a multiple of 4: a quad is all in or all out
-                            *reinterpret_cast<float4 *>(dst + 32 * nt + 8 * g) =
-                                make_float4(acc[nt][4 * g], acc[nt][4 * g + 1], acc[nt][4 * g + 2], acc[nt][4 * g + 3]);
-            }
+                for (int g = 0; g < 4; ++g)
+                    if (32 * nt + 8 * g + 4 * p < D)      // D is a multiple of 4: a quad is all in or all out
+                        *reinterpret_cast<float4 *>(dst + 32 * nt + 8 * g) =
+                            make_float4(acc[nt][4 * g], acc[nt][4 * g + 1], acc[nt][4 * g + 2], acc[nt][4 * g + 3]);
         }
 #pragma unroll
         for (int q = 0; q < Q; ++q) cur[q] = nxt[q];
@@ -226,10 +282,13 @@ static int launch_proj(const HpmnInputProj &a, hipStream_t st) {
     long wg = (ntile * NS + RW_WAVES - 1) / RW_WAVES;
     if (wg > 256) wg = 256;            // one persistent workgroup per CU, one wave per SIMD
     const unsigned grid = (unsigned)(wg < 1 ? 1 : wg);
-    if (a.x == nullptr)
-        hipLaunchKernelGGL((input_proj_kernel<K, NT, NS, true>), dim3(grid), dim3(64 * RW_WAVES), 0, st, a);
+    if ((long)a.B * a.T >= (1L << 31) - 64) return HPMN_EUNSUPPORTED;   // 32-bit row arithmetic in the kernels
+    if (a.x == nullptr && a.x_out != nullptr)
+        hipLaunchKernelGGL((input_proj_kernel<K, NT, NS, true, true>), dim3(grid), dim3(64 * RW_WAVES), 0, st, a);
+    else if (a.x == nullptr)
+        hipLaunchKernelGGL((input_proj_kernel<K, NT, NS, true, false>), dim3(grid), dim3(64 * RW_WAVES), 0, st, a);
     else
-        hipLaunchKernelGGL((input_proj_kernel<K, NT, NS, false>), dim3(grid), dim3(64 * RW_WAVES), 0, st, a);
+        hipLaunchKernelGGL((input_proj_kernel<K, NT, NS, false, false>), dim3(grid), dim3(64 * RW_WAVES), 0, st, a);
     return check_launch();
 }
 
@@ -248,6 +307,7 @@ int input_proj_dispatch(const HpmnInputProj &a, hipStream_t st) {
 int gru_dx_dispatch(const HpmnGruWgrad &a, hipStream_t st) {
     const unsigned grid = rowwise_grid((long)a.B * (a.t_len > 0 ? a.t_len : a.T));
     const int DT = (a.D + 31) / 32;
+    if ((long)a.B * a.T >= (1L << 31) - 64) return HPMN_EUNSUPPORTED;   // 32-bit row arithmetic in the kernel
     if (a.H == 32 && DT == 1) hipLaunchKernelGGL((gru_dx_kernel<96, 1>), dim3(grid), dim3(64 * RW_WAVES), 0, st, a);
     else if (a.H == 32 && DT == 2) hipLaunchKernelGGL((gru_dx_kernel<96, 2>), dim3(grid), dim3(64 * RW_WAVES), 0, st, a);
     else if (a.H == 64 && DT == 1) hipLaunchKernelGGL((gru_dx_kernel<192, 1>), dim3(grid), dim3(64 * RW_WAVES), 0, st, a);

@@ -85,6 +85,63 @@ def bwd_variants(src):
     return out
 
 
+MAIN_PROJ = r'''
+#include <cstdio>
+#include <vector>
+#include <random>
+namespace hpmn { void set_last_hip_error(int) {} }
+int main() {
+    const int B = 500, T = 1024, Tids = 1001, H = 64, D = 32, F = 2, E = 16;
+    const long V = 3308019;
+    float *emb, *wg, *wc, *bg, *bc, *xp, *xo; int *ids;
+    hipMalloc(&emb, V * E * 4); hipMemset(emb, 0, V * E * 4);
+    hipMalloc(&wg, (D + H) * 2 * H * 4); hipMalloc(&wc, (D + H) * H * 4); hipMalloc(&bg, 2 * H * 4); hipMalloc(&bc, H * 4);
+    hipMemset(wg, 0, (D + H) * 2 * H * 4); hipMemset(wc, 0, (D + H) * H * 4); hipMemset(bg, 0, 2 * H * 4); hipMemset(bc, 0, H * 4);
+    hipMalloc(&xp, (size_t)B * T * 3 * H * 4); hipMalloc(&xo, (size_t)B * T * D * 4);
+    std::vector<int> h((size_t)B * Tids * F); std::mt19937 g(1);
+    for (auto &v : h) v = g() % V;
+    hipMalloc(&ids, h.size() * 4); hipMemcpy(ids, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+    HpmnInputProj a = {};
+    a.B = B; a.T = T; a.D = D; a.H = H; a.ids = ids; a.emb = emb; a.Tids = Tids; a.F = F; a.E = E; a.front_zero = 23;
+    a.V = V; a.wg = wg; a.bg = bg; a.wc = wc; a.bc = bc; a.xp = xp; a.x_out = xo;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int i = 0; i < 2; ++i) hpmn::input_proj_dispatch(a, 0);
+    hipEventRecord(e0);
+    for (int i = 0; i < 5; ++i) hpmn::input_proj_dispatch(a, 0);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    printf("%-44s %.4f ms/launch\n", VARIANT, ms / 5);
+    return 0;
+}
+'''
+
+
+def proj_variants(src):
+    out = {"p0 baseline (gather, L0)": src}
+    st = """            float *dst = a.xp + (long)flat_row(tile_row(tile)) * N + n_base + 4 * p;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4 *>(dst + 32 * nt + 8 * g) ="""
+    v1 = sub(src, st, st.replace("*reinterpret_cast<float4 *>(dst + 32 * nt + 8 * g) =",
+                                 "if (acc[nt][4 * g] == 123.f) *reinterpret_cast<float4 *>(dst + 32 * nt + 8 * g) ="))
+    out["p1 no xp stores"] = v1
+    v2 = sub(src, "*reinterpret_cast<float4 *>(xo + 4 * i) = v;", "if (v.x == 123.f) *reinterpret_cast<float4 *>(xo + 4 * i) = v;")
+    out["p2 no x_out stores"] = v2
+    v3 = sub(src, "v[q] = *reinterpret_cast<const float4 *>(a.emb + (long)id[q] * a.E + (j - f * a.E));",
+             "v[q] = make_float4((float)id[q], 0.f, 0.f, 0.f);")
+    out["p3 no embedding row loads (ids only)"] = v3
+    v4 = sub(src, "acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[nt][4 * q + e], av[e], acc[nt], 0, 0, 0);\n        }\n        // C/D layout: lane (c, p), reg r -> D row",
+             "acc[nt][e] += wb[nt][4 * q + e] * av[e];\n        }\n        // C/D layout: lane (c, p), reg r -> D row")
+    out["p4 no MFMA (4 fmas instead)"] = v4
+    v5 = sub(v1, "*reinterpret_cast<float4 *>(xo + 4 * i) = v;", "if (v.x == 123.f) *reinterpret_cast<float4 *>(xo + 4 * i) = v;")
+    v5 = sub(v5, "v[q] = *reinterpret_cast<const float4 *>(a.emb + (long)id[q] * a.E + (j - f * a.E));",
+             "v[q] = make_float4((float)id[q], 0.f, 0.f, 0.f);")
+    out["p5 only ids loads + MFMA"] = v5
+    return out
+
+
 def sub(s, old, new, count=1):
     assert old in s, old
     return s.replace(old, new, count)
@@ -135,6 +192,18 @@ def main():
         with open(path, "w") as f:
             f.write("#include <hip/hip_runtime.h>\n#include \"hpmn_hip.h\"\n" + text +
                     "\n#define VARIANT \"%s\"\n" % name + MAIN_BWD)
+        exe = os.path.join(HERE, "ablate_%s" % tag)
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-w",
+                               "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", exe, path])
+        os.remove(path)
+        lines.append("./tools/micro/ablate_%s" % tag)
+    srcp = open(os.path.join(CSRC, "input_proj.hip")).read()
+    for name, text in proj_variants(srcp).items():
+        tag = name.split()[0]
+        path = os.path.join(HERE, "ablate_%s.hip" % tag)
+        with open(path, "w") as f:
+            f.write("#include <hip/hip_runtime.h>\n#include \"hpmn_hip.h\"\n" + text +
+                    "\n#define VARIANT \"%s\"\n" % name + MAIN_PROJ)
         exe = os.path.join(HERE, "ablate_%s" % tag)
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-w",
                                "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", exe, path])
