@@ -219,10 +219,13 @@ class Hpmn_Basic(object):
 
     @torch.no_grad()
     def compute_gradients(self, ids: torch.Tensor, label: torch.Tensor, keep_prob=0.5, masks=None,
-                          global_batch: Optional[int] = None):
+                          global_batch: Optional[int] = None, defer_join: bool = False):
         """Forward + BPTT of cross_entropy (code/hpmn.py:202-207) for a (possibly sharded) batch into
         the flat gradient buffer: log-loss is a MEAN over the GLOBAL batch, the memory regulariser a
-        SUM.  Pure kernel sequence: scan fwd -> read fwd+loss+bwd -> scan bwd."""
+        SUM.  Pure kernel sequence: scan fwd -> read fwd+loss+bwd -> scan bwd.
+        With ``defer_join`` the GRU weight gradients may still be running on a side stream:
+        out["pending"].join() must be called before they (or anything after the table in the flat
+        gradient) are read; the embedding-table gradient is complete on the current stream."""
         B = ids.shape[0]
         if global_batch is None:
             global_batch = B * self.world
@@ -238,7 +241,9 @@ class Hpmn_Basic(object):
         out = ops.read_fwd_bwd(self._read_desc, self._read_params, self._read_grads, memory, last, label, masks,
                                keep_prob, 1.0 / float(global_batch), self.memory_reg)
         grad_out = [self.grads["Embedding/emb_mtx"]] + [self.grads[n] for names in self._gru_names for n in names]
-        ops.scan_backward(self.spec, ids, saved, weights, out["d_memory"], out["d_last"], grad_out)
+        pending = ops.scan_backward(self.spec, ids, saved, weights, out["d_memory"], out["d_last"], grad_out,
+                                    defer_join=defer_join and not self.l2_reg)
+        out["pending"] = pending
         if self.l2_reg:
             # l2_reg * tf.nn.l2_loss(v) for every trainable variable (code/hpmn.py:204-205); every rank holds
             # every variable, so each adds 1/world of it before the sum all-reduce
@@ -251,18 +256,34 @@ class Hpmn_Basic(object):
     def train_step(self, ids: torch.Tensor, label: torch.Tensor, keep_prob=0.5, masks=None,
                    global_batch: Optional[int] = None):
         """sess.run(train_step) of code/hpmn.py:482: forward, BPTT, clip, dense TF Adam."""
-        out, ce = self.compute_gradients(ids, label, keep_prob, masks, global_batch)
-        dist.allreduce_sum_(self.flat_grad)                     # RCCL sum; clip happens after (8e)
-        self.apply_gradients()
+        out, ce = self.compute_gradients(ids, label, keep_prob, masks, global_batch, defer_join=True)
+        pending = out.pop("pending", None)
+        if pending is None:
+            dist.allreduce_sum_(self.flat_grad)                 # RCCL sum; clip happens after (8e)
+            self.apply_gradients()
+            return out, ce
+        # The table gradient is final once the scatter is enqueued, the GRU weight gradients of layer 0
+        # are still being reduced on the side stream: exchange + update the table (99.5 % of the
+        # parameters, HBM-bound) underneath them, then join and do the dense rest.
+        n_emb = self.params["Embedding/emb_mtx"].numel()
+        dist.allreduce_sum_(self.flat_grad[:n_emb])
+        self.apply_gradients(0, n_emb, advance=True)
+        pending.join()
+        dist.allreduce_sum_(self.flat_grad[n_emb:])
+        self.apply_gradients(n_emb, self.flat_param.numel(), advance=False)
         return out, ce
 
-    def apply_gradients(self):
-        self.adam_t += 1
+    def apply_gradients(self, lo: int = 0, hi: Optional[int] = None, advance: bool = True):
+        """clip + TF-form Adam over elements [lo, hi) of the flat buffers (default: everything);
+        ``advance`` = this call starts a new optimiser step."""
+        if advance:
+            self.adam_t += 1
         t = self.adam_t
         lr_t = self.learning_rate * math.sqrt(1.0 - self.beta2 ** t) / (1.0 - self.beta1 ** t)
+        hi = self.flat_param.numel() if hi is None else hi
         with torch.no_grad():
-            ops.adam_step(self.flat_param, self.flat_grad, self.flat_m, self.flat_v, lr_t,
-                          self.beta1, self.beta2, self.adam_eps, clip=1.0)
+            ops.adam_step(self.flat_param[lo:hi], self.flat_grad[lo:hi], self.flat_m[lo:hi], self.flat_v[lo:hi],
+                          lr_t, self.beta1, self.beta2, self.adam_eps, clip=1.0)
 
     # ------------------------------------------------------------------ datasets
     def _dev(self, dataset) -> _DeviceDataset:

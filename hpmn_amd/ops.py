@@ -382,7 +382,23 @@ def scan_forward_train(spec: ScanSpec, ids, emb, weights: Sequence[torch.Tensor]
     return memory, last, saved
 
 
-def scan_backward(spec: ScanSpec, ids, saved, weights: Sequence[torch.Tensor], d_memory, d_last, grad_out):
+class PendingGrads:
+    """Weight-gradient work still running on a side stream when scan_backward(defer_join=True) returns:
+    the embedding gradient is complete on the current stream, the GRU weight gradients are not until
+    ``join()``.  Holds the buffers that work reads so the caching allocator cannot recycle them early."""
+
+    def __init__(self, streams, refs):
+        self._streams, self._refs = list(streams), refs
+
+    def join(self):
+        main = torch.cuda.current_stream()
+        for st in self._streams:
+            main.wait_stream(st)
+        self._streams, self._refs = [], None
+
+
+def scan_backward(spec: ScanSpec, ids, saved, weights: Sequence[torch.Tensor], d_memory, d_last, grad_out,
+                  defer_join: bool = False):
     """BPTT of scan_forward_train.  ``grad_out`` = [d_emb, d_wg0, d_bg0, d_wc0, d_bc0, d_wg1, ...]:
     pre-zeroed buffers (views of the optimiser's flat gradient) that are accumulated into.
 
@@ -420,9 +436,11 @@ def scan_backward(spec: ScanSpec, ids, saved, weights: Sequence[torch.Tensor], d
         d_x0 = d_x[0]
         d_x0[:, spec.last_index, :] += d_last
         embed_grad_scatter(ids, d_x0, d_emb, spec.front_zero, spec.mask_id0)
-        main.wait_stream(side)
-        del keep, d_act, d_x
-        return
+        pending = PendingGrads([side], (keep, d_act, d_x, saved))
+        if defer_join:
+            return pending
+        pending.join()
+        return None
     # layer 0 (the end of the chain, feeding the embedding scatter) stays on the main stream
     streams = [main] + _streams(dev, K - 1)
     for st in streams[1:]:
@@ -456,9 +474,11 @@ def scan_backward(spec: ScanSpec, ids, saved, weights: Sequence[torch.Tensor], d
     d_x0 = d_x[0]
     d_x0[:, spec.last_index, :] += d_last
     embed_grad_scatter(ids, d_x0, d_emb, spec.front_zero, spec.mask_id0)
-    for st in set(streams[1:] + [side]):
-        main.wait_stream(st)
-    del keep, d_act, d_x
+    pending = PendingGrads(set(streams[1:] + [side]), (keep, d_act, d_x, saved))
+    if defer_join:
+        return pending
+    pending.join()
+    return None
 
 
 # ---------------------------------------------------------------------------------------

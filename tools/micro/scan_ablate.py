@@ -135,6 +135,13 @@ def proj_variants(src):
     v4 = sub(src, "acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[nt][4 * q + e], av[e], acc[nt], 0, 0, 0);\n        }\n        // C/D layout: lane (c, p), reg r -> D row",
              "acc[nt][e] += wb[nt][4 * q + e] * av[e];\n        }\n        // C/D layout: lane (c, p), reg r -> D row")
     out["p4 no MFMA (4 fmas instead)"] = v4
+    v6 = sub(src, "float *dst = a.xp + (long)flat_row(tile_row(tile)) * N + n_base + 4 * p;",
+             "float *dst = a.xp + ((long)tile * NS + ns) * 32 * NT * 32 + lane * 4;")
+    v6 = sub(v6, "*reinterpret_cast<float4 *>(dst + 32 * nt + 8 * g) =", "*reinterpret_cast<float4 *>(dst + (nt * 4 + g) * 256) =")
+    out["p6 xp stores fully contiguous (wrong layout)"] = v6
+    v7 = sub(src, "float *dst = a.xp + (long)flat_row(tile_row(tile)) * N + n_base + 4 * p;",
+             "float *dst = a.xp + ((long)tile * NS + ns) * 32 * NT * 32 + c * 96 + 4 * p;")
+    out["p7 xp stores: 384-B row pieces packed (wrong layout)"] = v7
     v5 = sub(v1, "*reinterpret_cast<float4 *>(xo + 4 * i) = v;", "if (v.x == 123.f) *reinterpret_cast<float4 *>(xo + 4 * i) = v;")
     v5 = sub(v5, "v[q] = *reinterpret_cast<const float4 *>(a.emb + (long)id[q] * a.E + (j - f * a.E));",
              "v[q] = make_float4((float)id[q], 0.f, 0.f, 0.f);")

@@ -7,7 +7,12 @@ import sys
 def main(path):
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    # step boundary = the small (dense-parameter) Adam launch that ends a step; a step that is not split has
+    # one launch only
     adam = [i for i, r in enumerate(rows) if "adam" in r["Kernel_Name"]]
+    small = [i for i in adam if int(rows[i]["End_Timestamp"]) - int(rows[i]["Start_Timestamp"]) < 50000]
+    if len(small) >= 2:
+        adam = small
     a, b = adam[-2], adam[-1]
     t0 = int(rows[a]["End_Timestamp"])
     for r in rows[a + 1:b + 1]:
