@@ -1,0 +1,258 @@
+// Periodic-GRU layer scans for H = 128 on gfx950 (BASELINE.json configs[4]): forward and reverse.
+//
+// At H = 128 the recurrent kernels hold 3*128*128 floats -- 768 per lane of one wave, three times
+// the 256 architectural VGPRs -- so the one-wave-per-sequence design of gru_scan_fwd.hip /
+// gru_scan_bwd.hip cannot keep them stationary.  Here ONE WORKGROUP OF FOUR WAVES owns a sequence:
+//
+//   wave w, lane (c = lane & 31, p = lane >> 5)  <->  hidden unit u = 32 w + c, k-half p
+//
+// i.e. the output units are split over the waves (N-split) and the reduction index over the two
+// half-waves (K-split), which again gives 3 * 64 = 192 stationary weights per lane, packed in pairs
+// over consecutive k for v_pk_fma_f32.  The two halves of a dot product are joined with ONE
+// v_permlane32_swap + add (no LDS); the broadcast operand is read from LDS as half-wave-uniform
+// 16-byte loads through the same grouped pipeline as the H <= 64 kernels (bcast_matvec).  The price
+// of several waves per sequence is two workgroup barriers per step (raw s_barrier behind
+// lgkmcnt(0) only -- __syncthreads() would also drain the prefetch loads and the output stores).
+//
+// Streams that are known in advance (projected input; saved r,u,c,h_prev; incoming d_y) are
+// prefetched PF steps ahead straight into registers with unconditional, clamped loads; every store
+// is unconditional too (the halves of a wave split the output columns by select, not by branch), so
+// the time loop has no control flow for the s_waitcnt pass to lose count in (see gru_scan_fwd.hip).
+#include "common.h"
+
+namespace hpmn {
+
+constexpr int H128 = 128;
+constexpr int PF = 4;          // prefetch distance (steps) == unroll factor of the time loop
+
+__device__ __forceinline__ void wg_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// x[lane] + x[lane ^ 32] in every lane
+__device__ __forceinline__ float join_halves(float x) {
+    const unsigned v = __float_as_uint(x);
+    auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+template <bool TRAIN>
+__global__ __launch_bounds__(256, 1) void gru_scan_fwd128_kernel(const HpmnGruFwd a) {
+    constexpr int H = H128;
+    __shared__ __attribute__((aligned(16))) float hb[H];
+    __shared__ __attribute__((aligned(16))) float rhb[H];
+    __builtin_amdgcn_s_setprio(3);
+
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = lane & 31, p = lane >> 5;
+    const int u = 32 * w + c;
+    const int T = a.T, D = a.D;
+    const long b = blockIdx.x;
+
+    // stationary recurrent weights of unit u, k in [64p, 64p + 64), exponent scale folded in
+    f2 whr[32], whu[32], whc[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        const long k = D + 64 * p + 2 * i;
+        whr[i] = f2{a.wg[k * 2 * H + u], a.wg[(k + 1) * 2 * H + u]} * NEG_LOG2E;
+        whu[i] = f2{a.wg[k * 2 * H + H + u], a.wg[(k + 1) * 2 * H + H + u]} * NEG_LOG2E;
+        whc[i] = f2{a.wc[k * H + u], a.wc[(k + 1) * H + u]} * (2.0f * NEG_LOG2E);
+    }
+#pragma unroll
+    for (int i = 0; i < 32; ++i) { settle(whr[i]); settle(whu[i]); settle(whc[i]); }
+
+    const int t0 = a.t_begin;
+    const int t1 = a.t_end > 0 ? a.t_end : T;
+    const float *xpb = a.xp + b * (long)T * 3 * H + u;
+    float xr[PF], xu[PF], xc[PF];
+    auto fetch = [&](int t, int slot) {
+        const int tc = t < T ? t : T - 1;
+        const float *row = xpb + (long)tc * 3 * H;
+        xr[slot] = row[0];
+        xu[slot] = row[H];
+        xc[slot] = row[2 * H];
+    };
+#pragma unroll
+    for (int i = 0; i < PF; ++i) fetch(t0 + i, i);
+
+    float h = a.h_init != nullptr ? a.h_init[b * a.h_init_stride + u] : 0.f;
+    settle(h);
+#pragma unroll
+    for (int i = 0; i < PF; ++i) { settle(xr[i]); settle(xu[i]); settle(xc[i]); }
+    hb[u] = h;
+    if constexpr (TRAIN) {
+        if (t0 == 0 && p == 0) a.hs[(b * (T + 1)) * H + u] = 0.f;
+    }
+    wg_barrier();
+
+    const int period = a.period;
+    const bool has_y = a.y != nullptr;
+    int next_fire = t0 + period - 1;
+    float *yp = has_y ? a.y + (b * (long)(T / period) + t0 / period) * H + u : a.h_last + b * a.h_last_stride + u;
+    const int y_adv = has_y ? H : 0;
+    // TRAIN stores, split over the half-waves by select: p == 0 writes (hs, r), p == 1 writes (u, c)
+    float *s0 = nullptr, *s1 = nullptr;
+    long adv0 = 0, adv1 = 0;
+    if constexpr (TRAIN) {
+        float *hsp = a.hs + (b * (long)(T + 1) + t0 + 1) * H + u;
+        float *gp = a.gates + (b * (long)T + t0) * 3 * H + u;
+        s0 = p == 0 ? hsp : gp + H;
+        s1 = p == 0 ? gp : gp + 2 * H;
+        adv0 = p == 0 ? H : 3 * H;
+        adv1 = 3 * H;
+    }
+    const float4 *hrow = reinterpret_cast<const float4 *>(&hb[64 * p]);
+    const float4 *rrow = reinterpret_cast<const float4 *>(&rhb[64 * p]);
+
+    auto step = [&](int t, int slot) {
+        f2 ar = {0.f, 0.f}, au = {0.f, 0.f};
+        bcast_matvec2<16>(hrow, whr, whu, ar, au);
+        const float r = sigmoid_scaled(xr[slot] + join_halves(ar.x + ar.y));
+        const float ug = sigmoid_scaled(xu[slot] + join_halves(au.x + au.y));
+        rhb[u] = r * h;                     // both halves write the same value: no branch
+        wg_barrier();                       // every wave's r*h is in place; every wave is done reading hb
+        f2 ac = {0.f, 0.f}, ac2 = {0.f, 0.f};
+        bcast_matvec<16>(rrow, whc, ac, ac2);
+        ac += ac2;
+        const float cc = tanh_scaled(xc[slot] + join_halves(ac.x + ac.y));
+        h = fmaf(ug, h - cc, cc);
+        hb[u] = h;
+        fetch(t + PF, slot);
+        if constexpr (TRAIN) {
+            *s0 = p == 0 ? h : ug;
+            *s1 = p == 0 ? r : cc;
+            s0 += adv0;
+            s1 += adv1;
+        }
+        *yp = h;
+        const bool fire = t == next_fire;
+        next_fire += fire ? period : 0;
+        yp += fire ? y_adv : 0;
+        wg_barrier();                       // new h visible; every wave is done reading rhb
+    };
+
+    int t = t0;
+    for (; t + PF <= t1; t += PF) {
+#pragma unroll
+        for (int i = 0; i < PF; ++i) step(t + i, i);
+    }
+    // remainder (fewer than PF steps): slots were refilled in order, slot i holds step t + i
+#pragma unroll
+    for (int i = 0; i < PF - 1; ++i)
+        if (t + i < t1) step(t + i, i);
+    if (p == 0) a.h_last[b * a.h_last_stride + u] = h;
+}
+
+__global__ __launch_bounds__(256, 1) void gru_scan_bwd128_kernel(const HpmnGruBwd a) {
+    constexpr int H = H128;
+    __shared__ __attribute__((aligned(16))) float bufA[H];
+    __shared__ __attribute__((aligned(16))) float bufB[2 * H];
+    __builtin_amdgcn_s_setprio(3);
+
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = lane & 31, p = lane >> 5;
+    const int j = 32 * w + c;
+    const int T = a.T, D = a.D;
+    const long b = blockIdx.x;
+
+    // row D + j of the recurrent kernels (transposed products): wc columns [64p, 64p+64), wg columns [128p, 128p+128)
+    f2 wcT[32], wgT[64];
+#pragma unroll
+    for (int n = 0; n < 32; ++n) wcT[n] = *reinterpret_cast<const f2 *>(a.wc + (long)(D + j) * H + 64 * p + 2 * n);
+#pragma unroll
+    for (int n = 0; n < 64; ++n) wgT[n] = *reinterpret_cast<const f2 *>(a.wg + (long)(D + j) * 2 * H + 128 * p + 2 * n);
+#pragma unroll
+    for (int n = 0; n < 32; ++n) settle(wcT[n]);
+#pragma unroll
+    for (int n = 0; n < 64; ++n) settle(wgT[n]);
+
+    const int period = a.period;
+    const bool has_dy = a.d_y != nullptr;
+    const float *gb = a.gates + b * (long)T * 3 * H + j;
+    const float *hsb = a.hs + b * (long)(T + 1) * H + j;
+    const float *dyb = has_dy ? a.d_y + b * (long)(T / period) * H + j : a.d_h_last + b * a.d_h_last_stride + j;
+    const long dy_stride = has_dy ? H : 0;
+    const int t_lo0 = a.t_begin;
+    const int t_hi = a.t_end > 0 ? a.t_end : T;
+
+    // prefetch stream, walking backwards: slot i of the ring holds step (current - i)
+    int pf_fire = t_hi - 1, pf_row = t_hi / period - 1;       // t_hi is a multiple of period
+    float gr[PF], gu[PF], gc[PF], ghp[PF], gdy[PF];
+    bool gm[PF];
+    auto fetch = [&](int t, int slot) {
+        const int tc = t > 0 ? t : 0;
+        const float *row = gb + (long)tc * 3 * H;
+        gr[slot] = row[0];
+        gu[slot] = row[H];
+        gc[slot] = row[2 * H];
+        ghp[slot] = hsb[(long)tc * H];
+        const bool fire = has_dy && t == pf_fire && pf_row >= 0;
+        gdy[slot] = dyb[(long)(pf_row > 0 ? pf_row : 0) * dy_stride];
+        gm[slot] = fire;
+        pf_row -= fire ? 1 : 0;
+        pf_fire -= fire ? period : 0;
+    };
+#pragma unroll
+    for (int i = 0; i < PF; ++i) fetch(t_hi - 1 - i, i);
+    float dh = (t_hi == T) ? a.d_h_last[b * a.d_h_last_stride + j] : a.dh_carry[b * H + j];
+    settle(dh);
+#pragma unroll
+    for (int i = 0; i < PF; ++i) { settle(gr[i]); settle(gu[i]); settle(gc[i]); settle(ghp[i]); settle(gdy[i]); }
+
+    const float4 *arow = reinterpret_cast<const float4 *>(&bufA[64 * p]);
+    const float4 *brow = reinterpret_cast<const float4 *>(&bufB[128 * p]);
+    // d_act stores split over the half-waves by select: p == 0 writes (da_r, da_u), p == 1 writes (dc_pre, dc_pre)
+    float *da0 = a.d_act + (b * (long)T + (t_hi - 1)) * 3 * H + j + (p == 0 ? 0 : 2 * H);
+    float *da1 = a.d_act + (b * (long)T + (t_hi - 1)) * 3 * H + j + (p == 0 ? H : 2 * H);
+
+    auto step = [&](int t, int slot) {
+        const float r = gr[slot], ug = gu[slot], cc = gc[slot], hp = ghp[slot];
+        dh += gm[slot] ? gdy[slot] : 0.f;
+        const float omu = 1.f - ug;
+        const float dcp = dh * omu * (1.f - cc * cc);
+        const float dau = dh * (hp - cc) * ug * omu;
+        bufA[j] = dcp;                      // both halves write the same value: no branch
+        fetch(t - PF, slot);
+        wg_barrier();                       // dc_pre of all units in place; everyone is done reading bufB
+        f2 d0 = {0.f, 0.f}, d1 = {0.f, 0.f};
+        bcast_matvec<16>(arow, wcT, d0, d1);
+        d0 += d1;
+        const float drh = join_halves(d0.x + d0.y);
+        const float dar = drh * hp * r * (1.f - r);
+        bufB[j] = dar;
+        bufB[H + j] = dau;
+        wg_barrier();                       // [da_r | da_u] in place; everyone is done reading bufA
+        f2 e0 = {0.f, 0.f}, e1 = {0.f, 0.f};
+        bcast_matvec<32>(brow, wgT, e0, e1);
+        e0 += e1;
+        const float e = join_halves(e0.x + e0.y);
+        *da0 = p == 0 ? dar : dcp;
+        *da1 = p == 0 ? dau : dcp;
+        da0 -= 3 * H;
+        da1 -= 3 * H;
+        dh = fmaf(dh, ug, fmaf(drh, r, e));
+    };
+
+    int t = t_hi - 1;
+    for (; t - PF + 1 >= t_lo0; t -= PF) {
+#pragma unroll
+        for (int i = 0; i < PF; ++i) step(t - i, i);
+    }
+#pragma unroll
+    for (int i = 0; i < PF - 1; ++i)
+        if (t - i >= t_lo0) step(t - i, i);
+    if (t_lo0 > 0 && p == 0) a.dh_carry[b * H + j] = dh;
+}
+
+int gru_scan_fwd128_dispatch(const HpmnGruFwd &a, hipStream_t st) {
+    if (a.hs != nullptr) hipLaunchKernelGGL((gru_scan_fwd128_kernel<true>), dim3(a.B), dim3(256), 0, st, a);
+    else                 hipLaunchKernelGGL((gru_scan_fwd128_kernel<false>), dim3(a.B), dim3(256), 0, st, a);
+    return check_launch();
+}
+
+int gru_scan_bwd128_dispatch(const HpmnGruBwd &a, hipStream_t st) {
+    hipLaunchKernelGGL(gru_scan_bwd128_kernel, dim3(a.B), dim3(256), 0, st, a);
+    return check_launch();
+}
+
+}  // namespace hpmn

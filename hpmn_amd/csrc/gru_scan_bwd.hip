@@ -176,7 +176,10 @@ __global__ __launch_bounds__(64, 1) void gru_scan_bwd_kernel(const HpmnGruBwd a)
     if (t_lo0 > 0) a.dh_carry[b * H + l] = dh;
 }
 
+int gru_scan_bwd128_dispatch(const HpmnGruBwd &a, hipStream_t st);   // gru_scan128.hip
+
 int gru_scan_bwd_dispatch(const HpmnGruBwd &a, hipStream_t st) {
+    if (a.H == 128) return gru_scan_bwd128_dispatch(a, st);
     if (a.H == 32) {
         hipLaunchKernelGGL((gru_scan_bwd_kernel<32>), dim3((a.B + 1) / 2), dim3(64), 0, st, a);
     } else if (a.H == 64) {

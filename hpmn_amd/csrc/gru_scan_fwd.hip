@@ -187,13 +187,16 @@ static int launch_fwd(const HpmnGruFwd &a, hipStream_t st) {
     return check_launch();
 }
 
+int gru_scan_fwd128_dispatch(const HpmnGruFwd &a, hipStream_t st);   // gru_scan128.hip
+
 bool gru_shape_supported(int H, int D) {
-    return (H == 32 || H == 64) && D >= 4 && D <= 128 && D % 4 == 0;
+    return (H == 32 || H == 64 || H == 128) && D >= 4 && D <= 128 && D % 4 == 0;
 }
 
 int gru_scan_fwd_dispatch(const HpmnGruFwd &a, hipStream_t st) {
     if (a.H == 32) return launch_fwd<32>(a, st);
     if (a.H == 64) return launch_fwd<64>(a, st);
+    if (a.H == 128) return gru_scan_fwd128_dispatch(a, st);
     return HPMN_EUNSUPPORTED;
 }
 

@@ -34,7 +34,7 @@ constexpr int WG_MIN_ROWS = 128;  // a workgroup takes whole sequences, at least
 __host__ __device__ inline long wgrad_slab_floats(int D, int H) { return (long)(D + H) * 3 * H + 3 * H; }
 
 template <int HT, int DT>
-__global__ __launch_bounds__(64 * (HT + DT), 2) void gru_wgrad_kernel(const HpmnGruWgrad a) {
+__global__ __launch_bounds__(64 * (HT + DT), (HT + DT > 4 ? 1 : 2)) void gru_wgrad_kernel(const HpmnGruWgrad a) {
     constexpr int H = 32 * HT;
     constexpr int NJ = 3 * HT;            // 32-column tiles of d_act
     constexpr int NT = 64 * (HT + DT);    // threads
@@ -262,6 +262,8 @@ int gru_wgrad_dispatch(const HpmnGruWgrad &a, hipStream_t st) {
     else if (a.H == 32 && DT == 2) rc = launch_wgrad<1, 2>(a, st);
     else if (a.H == 64 && DT == 1) rc = launch_wgrad<2, 1>(a, st);
     else if (a.H == 64 && DT == 2) rc = launch_wgrad<2, 2>(a, st);
+    else if (a.H == 128 && DT == 1) rc = launch_wgrad<4, 1>(a, st);     // 12 accumulator tiles per wave, ~90 KB LDS:
+    else if (a.H == 128 && DT == 4) rc = launch_wgrad<4, 4>(a, st);     // one workgroup per CU
     if (rc != HPMN_OK || a.d_x == nullptr) return rc;
     return gru_dx_dispatch(a, st);
 }

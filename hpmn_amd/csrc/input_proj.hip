@@ -196,8 +196,10 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void input_proj_kernel(const Hpmn
     }
 }
 
-// dx[m, d] = sum_j d_act[m, j] Wx[d][j];  K = 3H (reduction), NT = ceil(D/32) output tiles (masked to D)
-template <int K, int NT>
+// dx[m, d] = sum_j d_act[m, j] Wx[d][j];  K = 3H (reduction); a wave computes NT 32-column output tiles
+// (masked to D) and the NS column groups of a row tile go to NS waves.  DB = prefetch the next tile's
+// rows under the MFMAs (two K/2-float row images in registers; off at K = 384 where one is 192 registers).
+template <int K, int NT, int NS, bool DB>
 __global__ __launch_bounds__(64 * RW_WAVES, 1) void gru_dx_kernel(const HpmnGruWgrad a) {
     constexpr int KH = K / 2;
     constexpr int Q = KH / 4;
@@ -209,14 +211,16 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void gru_dx_kernel(const HpmnGruW
     const unsigned M = (unsigned)a.B * (unsigned)TL;          // 32-bit row arithmetic: see input_proj_kernel
     const unsigned ntile = (M + 31u) / 32u;
     auto flat_row = [&](unsigned r) -> unsigned { const unsigned b = r / (unsigned)TL; return b * a.T + a.t_begin + (r - b * TL); };
-    const unsigned wave_id = blockIdx.x * RW_WAVES + (threadIdx.x >> 6);
-    const unsigned nwave = gridDim.x * RW_WAVES;
+    const unsigned gwave = blockIdx.x * RW_WAVES + (threadIdx.x >> 6);
+    const int n_base = (int)(gwave % NS) * NT * 32;
+    const unsigned wave_id = gwave / NS;
+    const unsigned nwave = gridDim.x * RW_WAVES / NS;
 
-    // B operand: B[k = j][n = d] = Wx[d][j], j = p*KH + ks;  row d of [wg[0:D] | wc[0:D]] is contiguous per source
+    // stationary operand: Wx[d][j], j = p*KH + ks;  row d of [wg[0:D] | wc[0:D]] is contiguous per source
     float wb[NT][KH];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        const int d = 32 * nt + c;
+        const int d = n_base + 32 * nt + c;
 #pragma unroll
         for (int ks = 0; ks < KH; ++ks) {
             const int j = p * KH + ks;
@@ -238,7 +242,7 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void gru_dx_kernel(const HpmnGruW
 #pragma unroll
     for (int q = 0; q < Q; ++q) { settle(cur[q].x); settle(cur[q].y); settle(cur[q].z); settle(cur[q].w); }   // see input_proj_kernel
     for (unsigned tile = wave_id; tile < ntile; tile += nwave) {
-        load_a(tile + nwave, nxt);
+        if constexpr (DB) load_a(tile + nwave, nxt);
         f32x16 acc[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
@@ -255,48 +259,71 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void gru_dx_kernel(const HpmnGruW
         }
         // transposed product (see the file header): lane (c, p) owns row tile*32 + c, columns 32nt + 8g + 4p + 0..3
         {
-            float *dst = a.d_x + (long)flat_row(tile_row(tile)) * D + 4 * p;
+            float *dst = a.d_x + (long)flat_row(tile_row(tile)) * D + n_base + 4 * p;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
-                    if (32 * nt + 8 * g + 4 * p < D)      // D is a multiple of 4: a quad is all in or all out
+                    if (n_base + 32 * nt + 8 * g + 4 * p < D)      // D is a multiple of 4: a quad is all in or all out
                         *reinterpret_cast<float4 *>(dst + 32 * nt + 8 * g) =
                             make_float4(acc[nt][4 * g], acc[nt][4 * g + 1], acc[nt][4 * g + 2], acc[nt][4 * g + 3]);
         }
+        if constexpr (DB) {
 #pragma unroll
-        for (int q = 0; q < Q; ++q) cur[q] = nxt[q];
+            for (int q = 0; q < Q; ++q) cur[q] = nxt[q];
+        } else {
+            load_a(tile + nwave, cur);
+        }
     }
 }
 
-static unsigned rowwise_grid(long M) {
+// persistent grid for a row-wise kernel whose row tile is shared by NS waves: one workgroup per CU at most,
+// (grid * RW_WAVES) a multiple of NS
+static unsigned rowwise_grid(long M, int NS) {
     const long ntile = (M + 31) / 32;
-    long wg = (ntile + RW_WAVES - 1) / RW_WAVES;
+    long wg = (ntile * NS + RW_WAVES - 1) / RW_WAVES;
     if (wg > 256) wg = 256;            // one persistent workgroup per CU (1 wave per SIMD: 3H..6H weight registers)
-    return (unsigned)(wg < 1 ? 1 : wg);
+    if (wg < 1) wg = 1;
+    int step = NS;                     // smallest s with (s * RW_WAVES) % NS == 0
+    for (int s2 = 1; s2 <= NS; ++s2)
+        if ((s2 * RW_WAVES) % NS == 0) { step = s2; break; }
+    wg = (wg + step - 1) / step * step;
+    if (wg > 256) wg -= step;
+    return (unsigned)wg;
 }
 
 template <int K, int NT, int NS>
 static int launch_proj(const HpmnInputProj &a, hipStream_t st) {
-    const long ntile = ((long)a.B * (a.t_len > 0 ? a.t_len : a.T) + 31) / 32;
-    long wg = (ntile * NS + RW_WAVES - 1) / RW_WAVES;
-    if (wg > 256) wg = 256;            // one persistent workgroup per CU, one wave per SIMD
-    const unsigned grid = (unsigned)(wg < 1 ? 1 : wg);
+    const unsigned grid = rowwise_grid((long)a.B * (a.t_len > 0 ? a.t_len : a.T), NS);
     if ((long)a.B * a.T >= (1L << 31) - 64) return HPMN_EUNSUPPORTED;   // 32-bit row arithmetic in the kernels
-    if (a.x == nullptr && a.x_out != nullptr)
-        hipLaunchKernelGGL((input_proj_kernel<K, NT, NS, true, true>), dim3(grid), dim3(64 * RW_WAVES), 0, st, a);
-    else if (a.x == nullptr)
-        hipLaunchKernelGGL((input_proj_kernel<K, NT, NS, true, false>), dim3(grid), dim3(64 * RW_WAVES), 0, st, a);
-    else
+    constexpr bool can_gather = (K / 8) % NS == 0;       // the x_out pieces split evenly over the column groups
+    if (a.x == nullptr) {
+        if constexpr (can_gather) {
+            if (a.x_out != nullptr)
+                hipLaunchKernelGGL((input_proj_kernel<K, NT, NS, true, true>), dim3(grid), dim3(64 * RW_WAVES), 0, st, a);
+            else
+                hipLaunchKernelGGL((input_proj_kernel<K, NT, NS, true, false>), dim3(grid), dim3(64 * RW_WAVES), 0, st, a);
+        } else {
+            return HPMN_EUNSUPPORTED;
+        }
+    } else {
         hipLaunchKernelGGL((input_proj_kernel<K, NT, NS, false, false>), dim3(grid), dim3(64 * RW_WAVES), 0, st, a);
+    }
     return check_launch();
 }
 
+// H = 128: 12 column tiles; D = 32 keeps 3 per wave over 4 waves, D = 128 (upper layers) one per wave
 bool input_proj_supported(int H, int D) {
+    if (H == 128) return D == 32 || D == 128;
     return (H == 32 || H == 64) && (D == 16 || D == 32 || D == 48 || D == 64);
 }
 
 int input_proj_dispatch(const HpmnInputProj &a, hipStream_t st) {
+    if (a.H == 128) {
+        if (a.D == 32) return launch_proj<32, 3, 4>(a, st);
+        if (a.D == 128) return launch_proj<128, 1, 12>(a, st);
+        return HPMN_EUNSUPPORTED;
+    }
 #define X(d) \
     if (a.D == d) return a.H == 32 ? launch_proj<d, 3, 1>(a, st) : launch_proj<d, 3, 2>(a, st);
     X(16) X(32) X(48) X(64)
@@ -305,13 +332,16 @@ int input_proj_dispatch(const HpmnInputProj &a, hipStream_t st) {
 }
 
 int gru_dx_dispatch(const HpmnGruWgrad &a, hipStream_t st) {
-    const unsigned grid = rowwise_grid((long)a.B * (a.t_len > 0 ? a.t_len : a.T));
+    const long rows = (long)a.B * (a.t_len > 0 ? a.t_len : a.T);
     const int DT = (a.D + 31) / 32;
     if ((long)a.B * a.T >= (1L << 31) - 64) return HPMN_EUNSUPPORTED;   // 32-bit row arithmetic in the kernel
-    if (a.H == 32 && DT == 1) hipLaunchKernelGGL((gru_dx_kernel<96, 1>), dim3(grid), dim3(64 * RW_WAVES), 0, st, a);
-    else if (a.H == 32 && DT == 2) hipLaunchKernelGGL((gru_dx_kernel<96, 2>), dim3(grid), dim3(64 * RW_WAVES), 0, st, a);
-    else if (a.H == 64 && DT == 1) hipLaunchKernelGGL((gru_dx_kernel<192, 1>), dim3(grid), dim3(64 * RW_WAVES), 0, st, a);
-    else if (a.H == 64 && DT == 2) hipLaunchKernelGGL((gru_dx_kernel<192, 2>), dim3(grid), dim3(64 * RW_WAVES), 0, st, a);
+    const dim3 blk(64 * RW_WAVES);
+    if (a.H == 32 && DT == 1) hipLaunchKernelGGL((gru_dx_kernel<96, 1, 1, true>), dim3(rowwise_grid(rows, 1)), blk, 0, st, a);
+    else if (a.H == 32 && DT == 2) hipLaunchKernelGGL((gru_dx_kernel<96, 2, 1, true>), dim3(rowwise_grid(rows, 1)), blk, 0, st, a);
+    else if (a.H == 64 && DT == 1) hipLaunchKernelGGL((gru_dx_kernel<192, 1, 1, true>), dim3(rowwise_grid(rows, 1)), blk, 0, st, a);
+    else if (a.H == 64 && DT == 2) hipLaunchKernelGGL((gru_dx_kernel<192, 2, 1, true>), dim3(rowwise_grid(rows, 1)), blk, 0, st, a);
+    else if (a.H == 128 && DT == 1) hipLaunchKernelGGL((gru_dx_kernel<384, 1, 1, false>), dim3(rowwise_grid(rows, 1)), blk, 0, st, a);
+    else if (a.H == 128 && DT == 4) hipLaunchKernelGGL((gru_dx_kernel<384, 1, 4, false>), dim3(rowwise_grid(rows, 4)), blk, 0, st, a);
     else return HPMN_EUNSUPPORTED;
     return check_launch();
 }

@@ -62,7 +62,9 @@ def test_error_codes_without_touching_a_device(lib):
     assert lib.hpmn_strerror(0) == b"ok"
     assert b"invalid" in lib.hpmn_strerror(-1)
     assert lib.hpmn_gru_shape_supported(32, 48) == 1 and lib.hpmn_gru_shape_supported(64, 64) == 1
-    assert lib.hpmn_gru_shape_supported(128, 32) == 0 and lib.hpmn_gru_shape_supported(64, 40) == 0
+    assert lib.hpmn_gru_shape_supported(128, 32) == 1 and lib.hpmn_gru_shape_supported(128, 128) == 1
+    assert lib.hpmn_gru_shape_supported(128, 48) == 0 and lib.hpmn_gru_shape_supported(96, 32) == 0
+    assert lib.hpmn_gru_shape_supported(64, 40) == 0
     # null struct / null pointers -> EINVAL before any launch
     assert lib.hpmn_gru_scan_fwd(None, None) == -1
     assert lib.hpmn_gru_input_proj(None, None) == -1

@@ -87,6 +87,10 @@ CASES = [
     ("industry_64", cfg_industry(), 5),
     ("industry_k7_1001", cfg_industry(H=64, K=7, T=1001, V=800), 3),   # XLong graph at full length
     ("industry_h32", cfg_industry(H=32, K=5, T=105), 4),
+    # BASELINE configs[4]: hidden 128 (four waves per sequence), XLong graph; T=41 -> 64,32,16 and an odd tail
+    ("industry_h128", cfg_industry(H=128, K=3, T=41, V=300), 3),
+    ("industry_h128_k7_1001", cfg_industry(H=128, K=7, T=1001, V=800), 2),
+    ("amazon_h128_d32", cfg_amazon(H=128, K=3, T=100, F=2), 3),           # layer 2 has 25 steps: remainder path
 ]
 
 
@@ -130,10 +134,10 @@ def test_empty_batch_is_a_noop(dev, tmp_path):
 
 def test_unsupported_shape_raises(dev):
     from hpmn_amd import _lib, ops
-    xp = torch.zeros(2, 4, 3 * 128, device=dev)
-    w = torch.zeros(160, 256, device=dev)
+    xp = torch.zeros(2, 4, 3 * 96, device=dev)
+    w = torch.zeros(128, 192, device=dev)
     with pytest.raises(_lib.HpmnLibraryError):
-        ops.gru_scan_fwd(xp, w, w, 32, torch.zeros(2, 128, device=dev), 1, False, False)
+        ops.gru_scan_fwd(xp, w, w, 32, torch.zeros(2, 96, device=dev), 1, False, False)
 
 
 # ------------------------------------------------------------------------------- properties at size
@@ -179,6 +183,7 @@ GRAD_CASES = [
     ("amazon_h64", cfg_amazon(H=64, K=2, T=20, V=120), 3),
     ("industry", cfg_industry(H=64, K=4, T=41, V=150), 4),
     ("industry_h32", cfg_industry(H=32, K=3, T=41, V=150), 3),
+    ("industry_h128", cfg_industry(H=128, K=3, T=41, V=150), 3),
 ]
 
 
