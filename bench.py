@@ -1,6 +1,6 @@
 """bench.py -- training sequences/sec of the HPMN hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3|c1|c2] [--batch B] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3|c4|c1|c2] [--batch B] [--no-cpu-baseline]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one full training pass of the hot path over one batch of synthetic input already
@@ -37,6 +37,9 @@ CONFIGS = {
     "c3": dict(industry=True, F=2, T=1001, H=64, K=7, periods=[2] * 10 + [1], batch=500,
                V=19002 + 3269017 + 20000, lr=0.001, memory_reg=5e-5,
                name="XLong synthetic, Hpmn_Industry 7-layer H=64 max_len=1000(+1)->1024"),
+    "c4": dict(industry=True, F=2, T=1001, H=128, K=7, periods=[2] * 10 + [1], batch=500,
+               V=19002 + 3269017 + 200000, lr=0.001, memory_reg=5e-5,
+               name="XLong synthetic x10 users, Hpmn_Industry 7-layer H=128 max_len=1000(+1)->1024"),
     "c2": dict(industry=False, F=4, T=300, H=64, K=5, periods=[2, 2, 3, 5, 5, 1], batch=128,
                V=4160000 + 990000 + 9400 + 5, lr=0.001, memory_reg=1e-5,
                name="Taobao synthetic, Hpmn 5-layer H=64 max_len=300"),
