@@ -12,8 +12,8 @@
 //     d_memory, d_last and the tile's contribution to every read-path weight gradient, written as a
 //     slab that mirrors the contiguous read-path range of the flat parameter buffer and summed over
 //     tiles by read_reduce_kernel (single writer per element, deterministic).
-// Dense layers are thread-per-output VALU loops with activations broadcast from LDS: the kernel is
-// latency/launch bound, not FLOP bound (all tiles run concurrently, one per CU).
+// Dense layers with at least 16 outputs run on f32 MFMA tiles (the tile's <= 24 rows fill one 32-row
+// tile; the four waves split the output columns); the single-column logit layers stay on VALU loops.
 #include "common.h"
 
 namespace hpmn {
@@ -35,8 +35,8 @@ __device__ __forceinline__ float elu(float x) { return x > 0.f ? x : __expf(x) -
 constexpr int RB = 8;
 
 template <int ACT>
-__device__ __forceinline__ void dense_fwd(const float *X, int ldx, int R, int I, const float *W, const float *b,
-                                          int N, float *Y, int ldy) {
+__device__ __forceinline__ void dense_fwd_valu(const float *X, int ldx, int R, int I, const float *W, const float *b,
+                                               int N, float *Y, int ldy) {
     const int nrb = (R + RB - 1) / RB;
     for (int o = threadIdx.x; o < nrb * N; o += RT) {
         const int rb = o / N, n = o - rb * N;
@@ -78,8 +78,8 @@ __device__ __forceinline__ void dense_fwd(const float *X, int ldx, int R, int I,
 
 // dX[r][i] (+)= sum_n dY[r][n] W[i][n]      thread = input unit i, walks its weight row once per RB rows
 template <bool ACCUM>
-__device__ __forceinline__ void dense_bwd_x(const float *dY, int ldy, int R, int N, const float *W, int I, float *dX,
-                                            int ldx) {
+__device__ __forceinline__ void dense_bwd_x_valu(const float *dY, int ldy, int R, int N, const float *W, int I, float *dX,
+                                                 int ldx) {
     for (int i = threadIdx.x; i < I; i += RT) {
         const float *w = W + (long)i * N;
         for (int r0 = 0; r0 < R; r0 += RB) {
@@ -122,14 +122,166 @@ __device__ __forceinline__ void dense_bwd_x(const float *dY, int ldy, int R, int
 
 // gW[i][n] (+)= sum_r X[r][i] dY[r][n];  gb[n] (+)= sum_r dY[r][n]   (slab in global, owned by this workgroup)
 template <bool ACCUM>
-__device__ __forceinline__ void dense_bwd_w(const float *X, int ldx, const float *dY, int ldy, int R, int I, int N,
-                                            float *gW, float *gb) {
+__device__ __forceinline__ void dense_bwd_w_valu(const float *X, int ldx, const float *dY, int ldy, int R, int I, int N,
+                                                 float *gW, float *gb) {
     for (int o = threadIdx.x; o < I * N; o += RT) {
         const int i = o / N, n = o - i * N;
         float acc = 0.f;
         for (int r = 0; r < R; ++r) acc = fmaf(X[r * ldx + i], dY[r * ldy + n], acc);
         if (ACCUM) gW[o] += acc;
         else gW[o] = acc;
+    }
+    for (int n = threadIdx.x; n < N; n += RT) {
+        float acc = 0.f;
+        for (int r = 0; r < R; ++r) acc += dY[r * ldy + n];
+        if (ACCUM) gb[n] += acc;
+        else gb[n] = acc;
+    }
+}
+
+// ---- MFMA versions (v_mfma_f32_32x32x2_f32) ---------------------------------------------------------
+// The tile has R <= RS*MAXK = 24 rows, so ONE 32-row MFMA tile holds all of them (lanes past R
+// repeat row R-1; their outputs are dropped) and the four waves of the workgroup split the output
+// column tiles.  As in input_proj.hip the MFMA k index goes to the half-waves and half-wave p takes
+// the contiguous half [p*Kd/2, (p+1)*Kd/2) of the reduction, so LDS / weight-row operands are
+// 16-byte reads.  Layers with a single output column (the logits) and reductions that are not a
+// multiple of 8 stay on the VALU loops above.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Y[r][n] = act(b[n] + sum_i X[r][i] W[i][n]):  A = X (LDS rows), B = W[k][n] (global, coalesced over n)
+template <int ACT>
+__device__ __forceinline__ void dense_fwd(const float *X, int ldx, int R, int I, const float *W, const float *b,
+                                          int N, float *Y, int ldy) {
+    if (N < 16 || (I & 7) != 0) { dense_fwd_valu<ACT>(X, ldx, R, I, W, b, N, Y, ldy); return; }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c = lane & 31, p = lane >> 5;
+    const int KH = I >> 1;
+    const float *xr = X + (c < R ? c : R - 1) * ldx + p * KH;
+    for (int nt = wave; nt * 32 < N; nt += RT / 64) {
+        const int n = nt * 32 + c, nc = n < N ? n : N - 1;
+        const float *wp = W + (long)(p * KH) * N + nc;
+        const float bn = b[nc];
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = bn;
+        float wv[8], wn[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) wv[e] = wp[(long)e * N];          // KH >= 8: I >= 16
+        for (int k0 = 0; k0 < KH; k0 += 8) {
+            const bool more = k0 + 8 < KH;
+            const int kn = more ? k0 + 8 : k0;                           // harmless reload on the last block
+            const int rem = KH - kn;                                     // >= 4 (KH % 4 == 0)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) wn[e] = wp[(long)(kn + (e < rem ? e : rem - 1)) * N];
+            const float4 x0 = *reinterpret_cast<const float4 *>(xr + k0);
+            const int k1 = k0 + 4 < KH ? k0 + 4 : k0;
+            const float4 x1 = *reinterpret_cast<const float4 *>(xr + k1);
+            const bool second = k0 + 4 < KH;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.x, wv[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.y, wv[1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.z, wv[2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.w, wv[3], acc, 0, 0, 0);
+            if (second) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.x, wv[4], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.y, wv[5], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.z, wv[6], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.w, wv[7], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) wv[e] = wn[e];
+        }
+        // C/D layout: lane (c, p), reg r -> row (r&3) + 8*(r>>2) + 4*p, column n
+        if (n < N) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * p;
+                if (row < R) {
+                    float v = acc[r];
+                    if (ACT == 1) v = fmaxf(v, 0.f);
+                    if (ACT == 2) v = elu(v);
+                    Y[row * ldy + n] = v;
+                }
+            }
+        }
+    }
+}
+
+// dX[r][i] (+)= sum_n dY[r][n] W[i][n]:  transposed product dX^T = W dY^T, A = W rows (global, 16-byte
+// pieces of the lane's own row), B = dY (LDS rows); a lane ends up with 4 consecutive i of row r = c.
+template <bool ACCUM>
+__device__ __forceinline__ void dense_bwd_x(const float *dY, int ldy, int R, int N, const float *W, int I, float *dX,
+                                            int ldx) {
+    if ((N & 7) != 0 || (I & 3) != 0 || I < 16) { dense_bwd_x_valu<ACCUM>(dY, ldy, R, N, W, I, dX, ldx); return; }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c = lane & 31, p = lane >> 5;
+    const int KH = N >> 1;
+    const float *yr = dY + (c < R ? c : R - 1) * ldy + p * KH;
+    for (int it = wave; it * 32 < I; it += RT / 64) {
+        const int i = it * 32 + c;
+        const float *wr = W + (long)(i < I ? i : I - 1) * N + p * KH;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        float4 wv = *reinterpret_cast<const float4 *>(wr);
+        for (int k0 = 0; k0 < KH; k0 += 4) {
+            const float4 wn = *reinterpret_cast<const float4 *>(wr + (k0 + 4 < KH ? k0 + 4 : k0));
+            const float4 y = *reinterpret_cast<const float4 *>(yr + k0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.x, y.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.y, y.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.z, y.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.w, y.w, acc, 0, 0, 0);
+            wv = wn;
+        }
+        // D[i_local][r]: lane (c = r, p), regs 4g..4g+3 -> i = it*32 + 8g + 4p + 0..3
+        if (c < R) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int i0 = it * 32 + 8 * g + 4 * p;
+                if (i0 < I) {                       // I % 4 == 0: a quad is all in or all out
+                    float4 *dst = reinterpret_cast<float4 *>(dX + c * ldx + i0);
+                    float4 v = make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+                    if (ACCUM) { const float4 o = *dst; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+                    *dst = v;
+                }
+            }
+        }
+    }
+}
+
+// gW[i][n] (+)= sum_r X[r][i] dY[r][n]; gb[n] (+)= sum_r dY[r][n]:  the reduction index (the tile's rows)
+// is the MFMA k, both operands are LDS row segments read by consecutive lanes
+template <bool ACCUM>
+__device__ __forceinline__ void dense_bwd_w(const float *X, int ldx, const float *dY, int ldy, int R, int I, int N,
+                                            float *gW, float *gb) {
+    if (N < 16 || I < 16) { dense_bwd_w_valu<ACCUM>(X, ldx, dY, ldy, R, I, N, gW, gb); return; }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c = lane & 31, p = lane >> 5;
+    const int nti = (I + 31) / 32, ntn = (N + 31) / 32;
+    for (int tl = wave; tl < nti * ntn; tl += RT / 64) {
+        const int ti = tl / ntn, tn = tl - ti * ntn;
+        const int i = ti * 32 + c, n = tn * 32 + c;
+        const float *xa = X + (i < I ? i : I - 1);
+        const float *yb = dY + (n < N ? n : N - 1);
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int r0 = 0; r0 < R; r0 += 2) {
+            const int row = r0 + p;
+            const bool in = row < R;
+            const float av = in ? xa[row * ldx] : 0.f;
+            const float bv = in ? yb[row * ldy] : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        }
+        if (n < N) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ii = ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * p;
+                if (ii < I) {
+                    if (ACCUM) gW[(long)ii * N + n] += acc[r];
+                    else gW[(long)ii * N + n] = acc[r];
+                }
+            }
+        }
     }
     for (int n = threadIdx.x; n < N; n += RT) {
         float acc = 0.f;
