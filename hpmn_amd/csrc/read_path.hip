@@ -149,9 +149,30 @@ __device__ __forceinline__ void dense_bwd_w_valu(const float *X, int ldx, const 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // Y[r][n] = act(b[n] + sum_i X[r][i] W[i][n]):  A = X (LDS rows), B = W[k][n] (global, coalesced over n)
+// N == 1 (the logit layers): wave per row, lanes over the reduction -- the weight column is ONE coalesced
+// L2 round trip instead of a serial chain of them in a single thread
+template <int ACT>
+__device__ __forceinline__ void dense_fwd_col(const float *X, int ldx, int R, int I, const float *W, const float *b,
+                                              float *Y, int ldy) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int r = wave; r < R; r += RT / 64) {
+        float acc = 0.f;
+        for (int i = lane; i < I; i += 64) acc = fmaf(X[r * ldx + i], W[i], acc);
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
+        if (lane == 0) {
+            float v = acc + b[0];
+            if (ACT == 1) v = fmaxf(v, 0.f);
+            if (ACT == 2) v = elu(v);
+            Y[r * ldy] = v;
+        }
+    }
+}
+
 template <int ACT>
 __device__ __forceinline__ void dense_fwd(const float *X, int ldx, int R, int I, const float *W, const float *b,
                                           int N, float *Y, int ldy) {
+    if (N == 1) { dense_fwd_col<ACT>(X, ldx, R, I, W, b, Y, ldy); return; }
     if (N < 16 || (I & 7) != 0) { dense_fwd_valu<ACT>(X, ldx, R, I, W, b, N, Y, ldy); return; }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int c = lane & 31, p = lane >> 5;
@@ -164,31 +185,29 @@ __device__ __forceinline__ void dense_fwd(const float *X, int ldx, int R, int I,
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = bn;
-        float wv[8], wn[8];
+        // weights stream from L2 one 16-step chunk ahead (a chunk of MFMAs ~ 1000 cycles covers the
+        // round trip; one 8-step block ahead did not: the kernel was waiting on every block)
+        constexpr int CH = 16;
+        float wv[CH], wn[CH];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) wv[e] = wp[(long)e * N];          // KH >= 8: I >= 16
-        for (int k0 = 0; k0 < KH; k0 += 8) {
-            const bool more = k0 + 8 < KH;
-            const int kn = more ? k0 + 8 : k0;                           // harmless reload on the last block
+        for (int e = 0; e < CH; ++e) wv[e] = wp[(long)(e < KH ? e : KH - 1) * N];
+        for (int k0 = 0; k0 < KH; k0 += CH) {
+            const int kn = k0 + CH < KH ? k0 + CH : k0;                  // harmless reload on the last chunk
             const int rem = KH - kn;                                     // >= 4 (KH % 4 == 0)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) wn[e] = wp[(long)(kn + (e < rem ? e : rem - 1)) * N];
-            const float4 x0 = *reinterpret_cast<const float4 *>(xr + k0);
-            const int k1 = k0 + 4 < KH ? k0 + 4 : k0;
-            const float4 x1 = *reinterpret_cast<const float4 *>(xr + k1);
-            const bool second = k0 + 4 < KH;
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.x, wv[0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.y, wv[1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.z, wv[2], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.w, wv[3], acc, 0, 0, 0);
-            if (second) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.x, wv[4], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.y, wv[5], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.z, wv[6], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.w, wv[7], acc, 0, 0, 0);
+            for (int e = 0; e < CH; ++e) wn[e] = wp[(long)(kn + (e < rem ? e : rem - 1)) * N];
+#pragma unroll
+            for (int j = 0; j < CH / 4; ++j) {
+                if (k0 + 4 * j < KH) {                                   // wave-uniform
+                    const float4 x = *reinterpret_cast<const float4 *>(xr + k0 + 4 * j);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x.x, wv[4 * j], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x.y, wv[4 * j + 1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x.z, wv[4 * j + 2], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x.w, wv[4 * j + 3], acc, 0, 0, 0);
+                }
             }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) wv[e] = wn[e];
+            for (int e = 0; e < CH; ++e) wv[e] = wn[e];
         }
         // C/D layout: lane (c, p), reg r -> row (r&3) + 8*(r>>2) + 4*p, column n
         if (n < N) {
@@ -222,15 +241,29 @@ __device__ __forceinline__ void dense_bwd_x(const float *dY, int ldy, int R, int
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        float4 wv = *reinterpret_cast<const float4 *>(wr);
-        for (int k0 = 0; k0 < KH; k0 += 4) {
-            const float4 wn = *reinterpret_cast<const float4 *>(wr + (k0 + 4 < KH ? k0 + 4 : k0));
-            const float4 y = *reinterpret_cast<const float4 *>(yr + k0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.x, y.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.y, y.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.z, y.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.w, y.w, acc, 0, 0, 0);
-            wv = wn;
+        // the lane's weight-row pieces stream from L2 four 16-byte pieces (16 k-steps) ahead
+        constexpr int PQ = 4;
+        float4 wv[PQ], wn[PQ];
+        const int nq = KH / 4;
+#pragma unroll
+        for (int e = 0; e < PQ; ++e) wv[e] = *reinterpret_cast<const float4 *>(wr + 4 * (e < nq ? e : nq - 1));
+        for (int q0 = 0; q0 < nq; q0 += PQ) {
+            const int qn = q0 + PQ < nq ? q0 + PQ : q0;
+            const int rem = nq - qn;
+#pragma unroll
+            for (int e = 0; e < PQ; ++e) wn[e] = *reinterpret_cast<const float4 *>(wr + 4 * (qn + (e < rem ? e : rem - 1)));
+#pragma unroll
+            for (int e = 0; e < PQ; ++e) {
+                if (q0 + e < nq) {                                       // wave-uniform
+                    const float4 y = *reinterpret_cast<const float4 *>(yr + 4 * (q0 + e));
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[e].x, y.x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[e].y, y.y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[e].z, y.z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[e].w, y.w, acc, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < PQ; ++e) wv[e] = wn[e];
         }
         // D[i_local][r]: lane (c = r, p), regs 4g..4g+3 -> i = it*32 + 8g + 4p + 0..3
         if (c < R) {
@@ -312,6 +345,7 @@ struct ReadSmem {
     float *cmean;    // [RS*K]        slot means (covariance regulariser)
     float *ccov;     // [RS*K*K]      off-diagonal covariance
     float *cnorm;    // [RS]          Frobenius norms
+    float *zero;     // [max(H, D0)] zeros (bias of the bias-free products)
 };
 
 __host__ __device__ inline size_t read_smem_floats(int K, int H, int D0, int hop, bool train) {
@@ -321,6 +355,7 @@ __host__ __device__ inline size_t read_smem_floats(int K, int H, int D0, int hop
     if (train) n += RK * H + RK * (A1 + A2 + 1) + (size_t)RS * H + (size_t)RS * (H + D0) + 64;
     else n += 64;
     n += RK + RK * K + RS + 16;
+    n += (size_t)(H > D0 ? H : D0) + 4;
     return n + 64;
 }
 
@@ -342,6 +377,8 @@ __device__ inline void carve(ReadSmem &s, float *base, int K, int H, int D0, int
     s.cmean = take((size_t)RK);
     s.ccov = take((size_t)RK * K);
     s.cnorm = take(RS);
+    s.zero = take((size_t)(H > D0 ? H : D0));
+    for (int o = threadIdx.x; o < (H > D0 ? H : D0); o += RT) s.zero[o] = 0.f;   // visible after the caller's first barrier
     if (train) {
         s.dmem = take((size_t)RK * H);
         s.t1 = take((size_t)RK * A1 > (size_t)RS * F1 ? (size_t)RK * A1 : (size_t)RS * F1);
@@ -393,10 +430,11 @@ __device__ void read_forward_tile(const HpmnReadDesc &d, const float *P, const R
         __syncthreads();
         // q' = q Hmap + sum_k score_k m_k   (code/hpmn.py:143-144, 179)
         float *qn = s.q + (size_t)(hop + 1) * RS * H;
+        dense_fwd<0>(q, H, R, H, P + d.off_map, s.zero, H, qn, H);        // q Hmap (no bias: a row of zeros)
+        __syncthreads();
         for (int o = tid; o < R * H; o += RT) {
             const int r = o / H, n = o - r * H;
-            float acc = 0.f;
-            for (int i = 0; i < H; ++i) acc = fmaf(q[r * H + i], P[d.off_map + (long)i * H + n], acc);
+            float acc = qn[o];
             for (int k = 0; k < K; ++k) acc = fmaf(sc[r * K + k], s.mem[(r * K + k) * H + n], acc);
             qn[o] = acc;
         }
@@ -657,10 +695,11 @@ __global__ __launch_bounds__(RT) void read_fwd_bwd_kernel(const HpmnReadDesc d, 
         // inp = [q, m, q-m, q*m]:  dq_row = d0 + d2 + d3*m ; dm += d1 - d2 + d3*q
         // new dq (gradient wrt the query entering the hop) = dq' Hmap^T + sum_k dq_row
         float *dqn = s.drep;        // [R][H] scratch: only columns [0,H) of each row are used here ...
+        dense_bwd_x<false>(s.dq, H, R, H, P + d.off_map, H, dqn, H + D0);     // dq' Hmap^T
+        __syncthreads();
         for (int o = tid; o < R * H; o += RT) {
             const int r = o / H, i = o - r * H;
-            float acc = 0.f;
-            for (int n = 0; n < H; ++n) acc = fmaf(s.dq[r * H + n], P[d.off_map + (long)i * H + n], acc);
+            float acc = dqn[r * (H + D0) + i];
             for (int k = 0; k < K; ++k) {
                 const float *di = s.inp + (size_t)(r * K + k) * 4 * H;
                 acc += di[i] + di[2 * H + i] + di[3 * H + i] * s.mem[(r * K + k) * H + i];
@@ -678,11 +717,11 @@ __global__ __launch_bounds__(RT) void read_fwd_bwd_kernel(const HpmnReadDesc d, 
     }
     // q0 = last Wq + bq
     dense_bwd_w<false>(s.last, D0, s.dq, H, R, D0, H, G + d.off_wq, G + d.off_bq);
+    dense_bwd_x<true>(s.dq, H, R, H, P + d.off_wq, D0, s.drep + H, H + D0);      // += dq Wq^T onto the head part
+    __syncthreads();
     for (int o = tid; o < R * D0; o += RT) {
         const int r = o / D0, i = o - r * D0;
-        float acc = s.drep[r * (H + D0) + H + i];                          // head part
-        for (int n = 0; n < H; ++n) acc = fmaf(s.dq[r * H + n], P[d.off_wq + (long)i * H + n], acc);
-        d_last[b0 * D0 + o] = acc;
+        d_last[b0 * D0 + o] = s.drep[r * (H + D0) + H + i];
     }
     for (int o = tid; o < RK * H; o += RT) d_memory[b0 * K * H + o] = s.dmem[o];
 }
