@@ -205,22 +205,34 @@ __global__ __launch_bounds__(64 * (HT + DT), (HT + DT > 4 ? 1 : 2)) void gru_wgr
     }
 }
 
-// dst[e] += sum over workgroups of slab[w][e]  (single writer per element: deterministic, no atomics)
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ ws, int nwg, long n,
-                                                           float *d_wg, float *d_bg, float *d_wc, float *d_bc,
-                                                           long n_wg, long n_bg, long n_wc) {
-    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n) return;
+// dst[e] += sum over workgroups of slab[w][e]  (single writer per element, fixed summation order:
+// deterministic, no atomics).  A block owns 32 consecutive elements; its 8 groups of 32 lanes each sum
+// every 8th slab (four independent partial sums per thread, 128-byte coalesced reads) and the groups are
+// combined through LDS in a fixed order -- an element's slab column is a few hundred values deep, one
+// thread per element left the launch latency-bound (60 us for 25 k elements).
+constexpr int RED_G = 8;
+__global__ __launch_bounds__(32 * RED_G) void wgrad_reduce_kernel(const float *__restrict__ ws, int nwg, long n,
+                                                                  float *d_wg, float *d_bg, float *d_wc, float *d_bc,
+                                                                  long n_wg, long n_bg, long n_wc) {
+    __shared__ float part[RED_G][32];
+    const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const long e = (long)blockIdx.x * 32 + c;
+    const long ec = e < n ? e : n - 1;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int w = 0;
-    for (; w + 3 < nwg; w += 4) {
-        s0 += ws[(long)w * n + e];
-        s1 += ws[(long)(w + 1) * n + e];
-        s2 += ws[(long)(w + 2) * n + e];
-        s3 += ws[(long)(w + 3) * n + e];
+    int w = g;
+    for (; w + 3 * RED_G < nwg; w += 4 * RED_G) {
+        s0 += ws[(long)w * n + ec];
+        s1 += ws[(long)(w + RED_G) * n + ec];
+        s2 += ws[(long)(w + 2 * RED_G) * n + ec];
+        s3 += ws[(long)(w + 3 * RED_G) * n + ec];
     }
-    for (; w < nwg; ++w) s0 += ws[(long)w * n + e];
-    const float tot = (s0 + s1) + (s2 + s3);
+    for (; w < nwg; w += RED_G) s0 += ws[(long)w * n + ec];
+    part[g][c] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (g != 0 || e >= n) return;
+    float tot = part[0][c];
+#pragma unroll
+    for (int k = 1; k < RED_G; ++k) tot += part[k][c];
     if (e < n_wg) d_wg[e] += tot;
     else if (e < n_wg + n_bg) d_bg[e - n_wg] += tot;
     else if (e < n_wg + n_bg + n_wc) d_wc[e - n_wg - n_bg] += tot;
@@ -250,7 +262,7 @@ static int launch_wgrad(const HpmnGruWgrad &a, hipStream_t st) {
     if (rc != HPMN_OK) return rc;
     const int H = a.H, D = a.D;
     const long n = wgrad_slab_floats(D, H);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a.workspace, nwg, n,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 31) / 32)), dim3(32 * RED_G), 0, st, a.workspace, nwg, n,
                        a.d_wg, a.d_bg, a.d_wc, a.d_bc, (long)(D + H) * 2 * H, (long)2 * H, (long)(D + H) * H);
     return check_launch();
 }
