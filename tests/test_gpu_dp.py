@@ -1,0 +1,46 @@
+"""Data parallel over two processes on the GPU: the product train step (kernels, sharded batch, the
+table / dense gradient exchange in two ranges, replicated clip + Adam) and the sharded eval must
+reproduce the single-process run.  Transport is gloo with both ranks on cuda:0 (see dp_worker.py)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def test_two_rank_training_matches_single_process(tmp_path):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    out = str(tmp_path / "dp.npz")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(HERE, "dp_worker.py"), out]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert r.returncode == 0, r.stdout.decode()[-3000:]
+    got = np.load(out)
+
+    sys.path.insert(0, HERE)
+    import dp_worker
+    m, tr, te = dp_worker.build(str(tmp_path / "single"))
+    assert m.world == 1
+    want = dp_worker.run(m, tr, te)
+    for k in want:
+        if k == "__eval__":
+            continue
+        # same kernels, but per-rank partial sums are added in a different order than one full batch
+        np.testing.assert_allclose(got[k], want[k], rtol=0, atol=2e-5, err_msg=k)
+    np.testing.assert_allclose(got["__eval__"], want["__eval__"], rtol=1e-4, atol=1e-4)
