@@ -18,6 +18,8 @@
 // prefetched PF steps ahead straight into registers with unconditional, clamped loads; every store
 // is unconditional too (the halves of a wave split the output columns by select, not by branch), so
 // the time loop has no control flow for the s_waitcnt pass to lose count in (see gru_scan_fwd.hip).
+// LDS reads go two (not four) 16-byte groups deep: with four the kernel needs ~275 registers and the
+// compiler parks ~50 stationary weights per lane in AGPRs (one v_accvgpr_read per use, every step).
 #include "common.h"
 
 namespace hpmn {
@@ -106,13 +108,13 @@ __global__ __launch_bounds__(256, 1) void gru_scan_fwd128_kernel(const HpmnGruFw
 
     auto step = [&](int t, int slot) {
         f2 ar = {0.f, 0.f}, au = {0.f, 0.f};
-        bcast_matvec2<16>(hrow, whr, whu, ar, au);
+        bcast_matvec2<16, 2>(hrow, whr, whu, ar, au);
         const float r = sigmoid_scaled(xr[slot] + join_halves(ar.x + ar.y));
         const float ug = sigmoid_scaled(xu[slot] + join_halves(au.x + au.y));
         rhb[u] = r * h;                     // both halves write the same value: no branch
         wg_barrier();                       // every wave's r*h is in place; every wave is done reading hb
         f2 ac = {0.f, 0.f}, ac2 = {0.f, 0.f};
-        bcast_matvec<16>(rrow, whc, ac, ac2);
+        bcast_matvec<16, 2>(rrow, whc, ac, ac2);
         ac += ac2;
         const float cc = tanh_scaled(xc[slot] + join_halves(ac.x + ac.y));
         h = fmaf(ug, h - cc, cc);
@@ -215,7 +217,7 @@ __global__ __launch_bounds__(256, 1) void gru_scan_bwd128_kernel(const HpmnGruBw
         fetch(t - PF, slot);
         wg_barrier();                       // dc_pre of all units in place; everyone is done reading bufB
         f2 d0 = {0.f, 0.f}, d1 = {0.f, 0.f};
-        bcast_matvec<16>(arow, wcT, d0, d1);
+        bcast_matvec<16, 2>(arow, wcT, d0, d1);
         d0 += d1;
         const float drh = join_halves(d0.x + d0.y);
         const float dar = drh * hp * r * (1.f - r);
@@ -223,7 +225,7 @@ __global__ __launch_bounds__(256, 1) void gru_scan_bwd128_kernel(const HpmnGruBw
         bufB[H + j] = dau;
         wg_barrier();                       // [da_r | da_u] in place; everyone is done reading bufA
         f2 e0 = {0.f, 0.f}, e1 = {0.f, 0.f};
-        bcast_matvec<32>(brow, wgT, e0, e1);
+        bcast_matvec<32, 2>(brow, wgT, e0, e1);
         e0 += e1;
         const float e = join_halves(e0.x + e0.y);
         *da0 = p == 0 ? dar : dcp;
