@@ -56,13 +56,15 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void input_proj_kernel(const Hpmn
         const int n = n_base + 32 * nt + c;
         // xp is produced in the scan's exponent domain (hpmn_hip.h: HpmnInputProj.xp): gate columns times
         // -log2(e), candidate columns times -2 log2(e), folded into the stationary operand for free
-        const float sc = n < 2 * H ? NEG_LOG2E : 2.0f * NEG_LOG2E;
-        bias[nt] = p == 0 ? sc * (n < 2 * H ? a.bg[n] : a.bc[n - 2 * H]) : 0.f;   // k slot 0 of the bias step
+        const bool gate = n < 2 * H;
+        const float sc = gate ? NEG_LOG2E : 2.0f * NEG_LOG2E;
+        // selected base / stride instead of a conditional per element (no branches, no waits at joins)
+        const float *wcol = gate ? a.wg + n : a.wc + (n - 2 * H);
+        const long ldw = gate ? 2 * H : H;
+        const float *bcol = gate ? a.bg + n : a.bc + (n - 2 * H);
+        bias[nt] = p == 0 ? sc * bcol[0] : 0.f;                                   // k slot 0 of the bias step
 #pragma unroll
-        for (int ks = 0; ks < KH; ++ks) {
-            const int j = p * KH + ks;
-            wb[nt][ks] = sc * (n < 2 * H ? a.wg[(long)j * 2 * H + n] : a.wc[(long)j * H + (n - 2 * H)]);
-        }
+        for (int ks = 0; ks < KH; ++ks) wb[nt][ks] = sc * wcol[(long)(p * KH + ks) * ldw];
     }
 
     // No lane is ever "out of range": lanes past the last row (and prefetches past the last tile) are CLAMPED
@@ -217,16 +219,25 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void gru_dx_kernel(const HpmnGruW
     const unsigned nwave = gridDim.x * RW_WAVES / NS;
 
     // stationary operand: Wx[d][j], j = p*KH + ks;  row d of [wg[0:D] | wc[0:D]] is contiguous per source
+    // Loaded as 16-byte pieces through SELECTED base pointers, no per-element conditionals (a branchy version
+    // of this prologue -- ~190 single-dword gathers behind ~190 branches -- was a fixed ~30 us per launch, most
+    // of the time of the small upper layers).  Half-wave p covers j in [p*KH, (p+1)*KH), KH = 1.5 H:
+    //   ks <  H/2 : j < 2H for both halves            -> wg row, offset p*KH + ks
+    //   ks >= H/2 : p = 0 still in the wg row; p = 1 is column ks - H/2 of the wc row
+    // Rows past D are clamped (their output columns are never stored).
     float wb[NT][KH];
+    static_assert(H % 8 == 0, "16-byte pieces");
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int d = n_base + 32 * nt + c;
+        const long dr = d < D ? d : D - 1;
+        const float *lo = a.wg + dr * 2 * H + p * KH;
+        const float *hi = p == 0 ? a.wg + dr * 2 * H + H / 2 : a.wc + dr * H;
 #pragma unroll
-        for (int ks = 0; ks < KH; ++ks) {
-            const int j = p * KH + ks;
-            float v = 0.f;
-            if (d < D) v = j < 2 * H ? a.wg[(long)d * 2 * H + j] : a.wc[(long)d * H + (j - 2 * H)];
-            wb[nt][ks] = v;
+        for (int q = 0; q < KH / 4; ++q) {
+            const float4 v = 4 * q < H / 2 ? *reinterpret_cast<const float4 *>(lo + 4 * q)
+                                           : *reinterpret_cast<const float4 *>(hi + (4 * q - H / 2));
+            wb[nt][4 * q] = v.x; wb[nt][4 * q + 1] = v.y; wb[nt][4 * q + 2] = v.z; wb[nt][4 * q + 3] = v.w;
         }
     }
     // rows past the end are clamped to M-1 (duplicate, identical work): no conditional loads or stores in
