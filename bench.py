@@ -339,6 +339,17 @@ def main():
     out = model.forward_inference(batches[0][0])
     finite = bool(torch.isfinite(out["prediction"]).all())
 
+    # forward-only (eval) throughput at the harness's eval batch = 4x the train batch (code/hpmn.py:485-486)
+    ev_ids = torch.cat([b[0] for b in batches[:4]], 0)
+    model.forward_inference(ev_ids)
+    torch.cuda.synchronize()
+    te0 = time.perf_counter()
+    for _ in range(5):
+        model.forward_inference(ev_ids)
+    torch.cuda.synchronize()
+    eval_seq_per_s = 5 * ev_ids.shape[0] * world / (time.perf_counter() - te0)
+    del ev_ids
+
     auc = None
     if args.config == "c3" and not args.no_auc:
         log("AUC leg: %d training steps on planted-signal rows" % args.auc_steps)
@@ -362,6 +373,7 @@ def main():
             "algorithmic": {"gru_flops_fwd_per_seq": algorithmic_flops_fwd(c),
                             "train_tflops_equiv": 3 * algorithmic_flops_fwd(c) * seqs / elapsed / 1e12},
         }
+        result["eval_sequences_per_s"] = eval_seq_per_s        # forward only, rank-0 clock (not barrier-bracketed)
         if auc is not None:
             result["auc"] = auc
         if not args.no_roofline:

@@ -34,6 +34,39 @@ def _glorot_uniform_(t: torch.Tensor, gen: torch.Generator):
     t.uniform_(-lim, lim, generator=gen)
 
 
+def device_auc(pred: torch.Tensor, label: torch.Tensor) -> torch.Tensor:
+    """ROC AUC = (sum of the positives' mid-ranks - n1 (n1 + 1) / 2) / (n1 n0), ties sharing their average
+    rank -- the Mann-Whitney form of the trapezoidal area sklearn.metrics.roc_auc_score integrates."""
+    pred = pred.double()
+    y = label.to(pred.device).double()
+    order = torch.argsort(pred)
+    ps = pred[order]
+    n = ps.numel()
+    # groups of equal predictions: every member gets the mean of the group's 1-based positions
+    new_group = torch.ones(n, dtype=torch.bool, device=pred.device)
+    new_group[1:] = ps[1:] != ps[:-1]
+    gid = torch.cumsum(new_group.long(), 0) - 1
+    pos = torch.arange(1, n + 1, device=pred.device, dtype=torch.float64)
+    ng = n                                     # at most n groups (sized without a host round trip)
+    gsum = torch.zeros(ng, dtype=torch.float64, device=pred.device).index_add_(0, gid, pos)
+    gcnt = torch.zeros(ng, dtype=torch.float64, device=pred.device).index_add_(0, gid, torch.ones_like(pos))
+    rank = (gsum / gcnt.clamp(min=1.0))[gid]
+    ys = y[order]
+    n1 = ys.sum()
+    n0 = n - n1
+    return ((rank * ys).sum() - n1 * (n1 + 1) / 2) / (n1 * n0)
+
+
+def device_log_loss(pred: torch.Tensor, label: torch.Tensor) -> torch.Tensor:
+    """sklearn.metrics.log_loss for binary labels: mean negative log-likelihood with the predictions
+    clipped to [eps, 1 - eps], eps = float64 machine epsilon."""
+    p = pred.double()
+    y = label.to(p.device).double()
+    eps = 2.220446049250313e-16
+    p = p.clamp(eps, 1.0 - eps)
+    return -(y * torch.log(p) + (1.0 - y) * torch.log1p(-p)).mean()
+
+
 class _DeviceDataset:
     """int32 device-resident copy of a dataset (list-of-samples or XLong TSV path), built once.
     Replaces the per-batch Python-list -> ndarray -> feed_dict conversion of
@@ -319,7 +352,6 @@ class Hpmn_Basic(object):
     def eval(self, dataset, batchsize):
         """-> (auc, log-loss, mean of per-batch memory_loss); code/hpmn.py:497-519.  With data
         parallel every rank scores a slice of each batch and predictions are all-gathered."""
-        from sklearn.metrics import log_loss, roc_auc_score
         ds = self._dev(dataset)
         preds, mem_losses = [], []
         for lo, hi in ds.batches(batchsize):
@@ -331,11 +363,13 @@ class Hpmn_Basic(object):
                 dist.allreduce_sum_(ml)
             preds.append(pred)
             mem_losses.append(ml)
-        preds = torch.cat(preds).cpu().numpy().astype(np.float64)
-        mem_loss = float(torch.cat(mem_losses).mean().item())
-        labels = ds.label_np
-        auc = roc_auc_score(labels, preds)
-        loss = log_loss(labels, preds)
+        # metrics on the device (the whole pass is enqueued without a host round trip; ONE sync for three
+        # scalars): same definitions as sklearn's roc_auc_score / log_loss used at code/hpmn.py:516-518
+        preds = torch.cat(preds).double()
+        auc = device_auc(preds, ds.label)
+        loss = device_log_loss(preds, ds.label)
+        mem_loss = torch.cat(mem_losses).mean().double()
+        auc, loss, mem_loss = torch.stack([auc, loss, mem_loss]).tolist()
         return auc, loss, mem_loss
 
     def get_weights(self):

@@ -97,3 +97,23 @@ def test_constructor_fails_loudly_without_gpu(tmp_path):
         assert "no CPU fallback" in str(e)
     else:
         raise AssertionError("constructing without a GPU must raise")
+
+
+def test_device_metrics_match_sklearn_with_ties():
+    """eval() computes AUC / log-loss with torch ops on the model's device; they must be sklearn's numbers
+    (code/hpmn.py:516-518), including tied and saturated predictions."""
+    import numpy as np
+    import torch
+    from sklearn.metrics import log_loss, roc_auc_score
+    from hpmn_amd.hpmn import device_auc, device_log_loss
+    rng = np.random.default_rng(0)
+    for n in (10, 1000, 5000):
+        p = rng.random(n).astype(np.float32)
+        p[rng.integers(0, n, n // 3)] = p[0]            # a big tie group
+        p[:3] = [0.0, 1.0, 0.5]                         # saturated predictions
+        y = rng.integers(0, 2, n)
+        y[0], y[1] = 0, 1
+        got_auc = float(device_auc(torch.as_tensor(p), torch.as_tensor(y)))
+        got_ll = float(device_log_loss(torch.as_tensor(p), torch.as_tensor(y)))
+        assert abs(got_auc - roc_auc_score(y, p.astype(np.float64))) < 1e-12
+        assert abs(got_ll - log_loss(y, p.astype(np.float64))) < 1e-9
