@@ -478,7 +478,7 @@ class Hpmn(Hpmn_Industry):
 # CLI (code/hpmn.py:563-667): same argv, same relative data paths, same hyper-parameters
 # ---------------------------------------------------------------------------------------
 def main(argv: Sequence[str]) -> int:
-    from .datasets import load_dataset_pkl
+    from .preprocess import load_dataset as load_dataset_pkl     # the pickle, through its int32 array cache
     if len(argv) != 2:
         print("Useage: python hpmn.py [dataset]")
         return 1

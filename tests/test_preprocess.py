@@ -1,0 +1,122 @@
+"""Raw logs -> dataset_hpmn.pkl (hpmn_amd/preprocess.py): schema invariants of the reference pipeline
+(code/preprocess_amazon.py:51-67,123-215; code/preprocess_taobao.py:26-48,104-186; code/util.py:152-159)
+on small synthetic raw files."""
+import json
+import os
+
+import numpy as np
+
+from hpmn_amd import datasets, preprocess as P
+
+
+def _write_amazon(tmp, n_user=40, n_item=25, n_cate=6, seed=3):
+    rng = np.random.default_rng(seed)
+    items = ["B%05d" % i for i in range(n_item)]
+    cate_of = {a: "cat%d" % rng.integers(0, n_cate) for a in items}
+    meta = os.path.join(tmp, "meta.json")
+    with open(meta, "w") as f:
+        for k, a in enumerate(items):
+            rec = {"asin": a, "categories": [["Electronics", "x"], ["Electronics", cate_of[a]]]}
+            f.write((json.dumps(rec) if k % 2 else repr(rec)) + "\n")       # JSON and python-literal lines
+        f.write(json.dumps({"asin": items[0], "categories": [["dup", "ignored"]]}) + "\n")   # first record wins
+    rev = os.path.join(tmp, "reviews.json")
+    events = []
+    with open(rev, "w") as f:
+        for u in range(n_user):
+            n = int(rng.integers(2, 9)) if u else 130                      # user 0 is longer than max_len
+            ts = np.sort(rng.choice(np.arange(1000, 100000), size=n, replace=False))
+            for t in ts:
+                a = items[int(rng.integers(0, n_item))]
+                events.append(("U%03d" % u, a, int(t)))
+                f.write(json.dumps({"reviewerID": "U%03d" % u, "asin": a, "unixReviewTime": int(t)}) + "\n")
+    return rev, meta, events, cate_of
+
+
+def test_amazon_pipeline_invariants(tmp_path):
+    rev, meta, events, cate_of = _write_amazon(str(tmp_path))
+    out = str(tmp_path / "amazon" / "dataset_hpmn.pkl")
+    ntr, nte, fs = P.preprocess_amazon(rev, meta, out)
+    users = sorted({e[0] for e in events})
+    items = sorted({e[1] for e in events})
+    cates = sorted({cate_of[a] for a in items})
+    assert ntr + nte == len(users)
+    assert fs == len(items) + len(cates) + len(users)                       # one id space: items, categories, users
+    item_id = {a: i for i, a in enumerate(items)}
+    cate_id = {c: len(items) + i for i, c in enumerate(cates)}
+    user_id = {u: len(items) + len(cates) + i for i, u in enumerate(users)}
+
+    train, test, fs2 = datasets.load_dataset_pkl(out)
+    assert fs2 == fs and len(train) == ntr and len(test) == nte
+    by_user = {}
+    for u, a, t in events:
+        by_user.setdefault(u, []).append((t, a))
+    last_touch = sorted(max(t for t, _ in v) for v in by_user.values())
+    split = last_touch[int(len(last_touch) * 0.7)]
+    seen = set()
+    n_neg = 0
+    for which, samples in (("train", train), ("test", test)):
+        for label, urows, ulen, irows, ilen in samples:
+            assert len(urows) == 100 and len(irows) == 100 and all(len(r) == 3 for r in urows) and all(len(r) == 2 for r in irows)
+            assert urows[:100 - ulen] == [[0, 0, 0]] * (100 - ulen) and irows[:100 - ilen] == [[0, 0]] * (100 - ilen)
+            uid = urows[-1][0]
+            uname = users[uid - len(items) - len(cates)]
+            seen.add(uname)
+            hist = sorted(by_user[uname])
+            assert ulen == min(len(hist), 100)
+            assert (max(t for t, _ in hist) > split) == (which == "test")
+            want_hist = [[uid, item_id[a], cate_id[cate_of[a]]] for _, a in hist[:-1]][-(ulen - 1):] if ulen > 1 else []
+            assert urows[100 - ulen:-1] == want_hist
+            target, tcate = urows[-1][1], urows[-1][2]
+            assert tcate == cate_id[cate_of[items[target]]]
+            if label == 1:
+                assert target == item_id[hist[-1][1]]
+            else:
+                n_neg += 1
+                assert target != item_id[hist[-1][1]]
+            t_target = hist[-1][0]
+            # item side: users who touched the target strictly earlier, in time order, then this user
+            earlier = sorted((t, user_id[u]) for u, a, t in events if item_id[a] == target and t < t_target)
+            want_item = ([[target, uu] for _, uu in earlier] + [[target, uid]])[-100:]
+            assert irows[100 - ilen:] == want_item and ilen == len(want_item)
+    assert seen == set(users) and 0 < n_neg < len(users)
+
+    # array cache: same samples, accepted as-is by the model's dataset wrapper
+    tr, te, fs3 = P.load_dataset(out)
+    assert fs3 == fs and tr["ids"].dtype == np.int32 and tr["ids"].shape == (ntr, 100, 3)
+    np.testing.assert_array_equal(tr["ids"], np.asarray([s[1] for s in train]))
+    np.testing.assert_array_equal(te["label"], np.asarray([s[0] for s in test]))
+    np.testing.assert_array_equal(tr["length"], np.asarray([s[2] for s in train]))
+    os.remove(os.path.splitext(out)[0] + ".npz")                             # cache gone: rebuilt from the pickle
+    tr2, _, _ = P.load_dataset(out)
+    np.testing.assert_array_equal(np.asarray([s[1] for s in tr2]), tr["ids"])
+    assert os.path.exists(os.path.splitext(out)[0] + ".npz")
+
+
+def test_taobao_pipeline_invariants(tmp_path):
+    rng = np.random.default_rng(5)
+    path = str(tmp_path / "taobao.csv")
+    rows = []
+    with open(path, "w") as f:
+        for u in range(30):
+            n = int(rng.integers(2, 12)) if u else 320                      # user 0 exceeds the 300-row window
+            ts = np.sort(rng.choice(np.arange(10, 10 ** 6), size=n, replace=False))
+            for t in ts:
+                iid = int(rng.integers(1000, 1012)) if u else int(rng.integers(1000, 1002))
+                r = (100 + u, iid, 7 + iid % 3, ["pv", "buy", "cart", "fav"][int(rng.integers(0, 4))], int(t))
+                rows.append(r)
+                f.write("%d,%d,%d,%s,%d\n" % r)
+    out = str(tmp_path / "taobao" / "dataset_hpmn.pkl")
+    ntr, nte, fs = P.preprocess_taobao(path, out)
+    n_item, n_user = len({r[1] for r in rows}), len({r[0] for r in rows})
+    n_cate, n_btag = len({r[2] for r in rows}), len({r[3] for r in rows})
+    assert fs == n_item + n_user + n_cate + n_btag + 1 and ntr + nte == n_user   # items, users, categories, btags, +1
+    train, test, _ = datasets.load_dataset_pkl(out)
+    for label, urows, ulen, irows, ilen in train + test:
+        assert len(urows) == 300 and len(irows) == 36 and len(urows[0]) == 4 and len(irows[0]) == 3
+        assert ilen <= 35 and irows[0] == [0, 0, 0]                          # 35 rows kept, padded to 36
+        assert urows[-1][3] == fs - 1 and irows[-1][2] == fs - 1             # unknown btag of the target row
+        assert 0 <= urows[-1][1] < n_item and n_item <= urows[-1][0] < n_item + n_user
+        assert n_item + n_user <= urows[-1][2] < n_item + n_user + n_cate
+        assert all(r == [0, 0, 0, 0] for r in urows[:300 - ulen]) and all(r[0] == urows[-1][0] for r in urows[300 - ulen:])
+        assert irows[-1][:2] == [urows[-1][1], urows[-1][0]]
+    assert max(s[2] for s in train + test) == 300                            # the long user was cropped to the window
