@@ -33,17 +33,25 @@ constexpr int WG_MIN_ROWS = 128;  // a workgroup takes whole sequences, at least
 // Slab layout of one workgroup's partial result (floats): [d_wg (D+H)x2H][d_bg 2H][d_wc (D+H)xH][d_bc H]
 __host__ __device__ inline long wgrad_slab_floats(int D, int H) { return (long)(D + H) * 3 * H + 3 * H; }
 
-template <int HT, int DT>
-__global__ __launch_bounds__(64 * (HT + DT), (HT + DT > 4 ? 1 : 2)) void gru_wgrad_kernel(const HpmnGruWgrad a) {
+// CS = column split: blockIdx.y picks one of CS groups of 3*HT/CS consecutive 32-column tiles of d_act, so a
+// wave holds 3*HT/CS accumulator tiles.  H = 128 uses CS = 3: twelve tiles are 192 accumulator registers,
+// and with 5..8 waves per workgroup a wave only has 256 -- the unsplit kernel spilled 124 registers to
+// scratch and ran at 27 TF/s; four tiles per wave also leave room for two workgroups per CU.  Each group
+// stages only ITS columns of d_act (plus x, h_prev, r).
+template <int HT, int DT, int CS>
+__global__ __launch_bounds__(64 * (HT + DT), 2) void gru_wgrad_kernel(const HpmnGruWgrad a) {
     constexpr int H = 32 * HT;
-    constexpr int NJ = 3 * HT;            // 32-column tiles of d_act
+    static_assert((3 * HT) % CS == 0, "column tiles split evenly");
+    constexpr int NJ = 3 * HT / CS;       // 32-column tiles of d_act held by this workgroup
+    constexpr int NC = 32 * NJ;           // ... = this many columns, starting at column jb*32
+    const int jb = blockIdx.y * NJ;       // first (global) column tile
     constexpr int NT = 64 * (HT + DT);    // threads
     constexpr int R = 2 * WU;             // rows per staged tile
     constexpr int XS = 32 * DT;           // row stride of the x image (zero-filled beyond D)
     // float4 items of one tile image and per-thread staging registers
-    constexpr int N_DA = R * 3 * H / 4, N_X = R * XS / 4, N_H = R * H / 4;
+    constexpr int N_DA = R * NC / 4, N_X = R * XS / 4, N_H = R * H / 4;
     constexpr int P_DA = (N_DA + NT - 1) / NT, P_X = (N_X + NT - 1) / NT, P_H = (N_H + NT - 1) / NT;
-    __shared__ __attribute__((aligned(16))) float l_da[2][R * 3 * H];
+    __shared__ __attribute__((aligned(16))) float l_da[2][R * NC];
     __shared__ __attribute__((aligned(16))) float l_x[2][R * XS];
     __shared__ __attribute__((aligned(16))) float l_h[2][R * H];
     __shared__ __attribute__((aligned(16))) float l_r[2][R * H];
@@ -81,10 +89,10 @@ __global__ __launch_bounds__(64 * (HT + DT), (HT + DT > 4 ? 1 : 2)) void gru_wgr
 #pragma unroll
         for (int p = 0; p < P_DA; ++p) {
             const int i = p * NT + tid;
-            const int row = i / (3 * H / 4), q = i % (3 * H / 4);
+            const int row = i / (NC / 4), q = i % (NC / 4);
             g.da[p] = z;
             if (i < N_DA && t0 + row < T)
-                g.da[p] = *reinterpret_cast<const float4 *>(a.d_act + ((long)b * T + t0 + row) * 3 * H + 4 * q);
+                g.da[p] = *reinterpret_cast<const float4 *>(a.d_act + ((long)b * T + t0 + row) * 3 * H + jb * 32 + 4 * q);
         }
 #pragma unroll
         for (int p = 0; p < P_X; ++p) {
@@ -136,7 +144,7 @@ __global__ __launch_bounds__(64 * (HT + DT), (HT + DT > 4 ? 1 : 2)) void gru_wgr
     for (int it = 0; it < niter; ++it) {
         const int buf = it & 1;
         if (it + 1 < niter) load_tile(it + 1, st);       // HBM loads in flight under this tile's MFMAs
-        const float *pda = &l_da[buf][rp * 3 * H + c];
+        const float *pda = &l_da[buf][rp * NC + c];
         if (role_x) {
             const float *px = &l_x[buf][rp * XS + 32 * tile + c];
 #pragma unroll
@@ -144,7 +152,7 @@ __global__ __launch_bounds__(64 * (HT + DT), (HT + DT > 4 ? 1 : 2)) void gru_wgr
                 const float av = px[2 * s * XS];
                 float bv[NJ];
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) bv[j] = pda[2 * s * 3 * H + 32 * j];
+                for (int j = 0; j < NJ; ++j) bv[j] = pda[2 * s * NC + 32 * j];
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[j], acc[j], 0, 0, 0);
                 if (tile == 0) {
@@ -162,11 +170,11 @@ __global__ __launch_bounds__(64 * (HT + DT), (HT + DT > 4 ? 1 : 2)) void gru_wgr
                 const float rh = pr[2 * s * H] * hv;      // r * h_prev (not stored by the forward)
                 float bv[NJ];
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) bv[j] = pda[2 * s * 3 * H + 32 * j];
+                for (int j = 0; j < NJ; ++j) bv[j] = pda[2 * s * NC + 32 * j];
+                // gate columns (global tile < 2 HT) pair with h_prev, candidate columns with r * h_prev
 #pragma unroll
-                for (int j = 0; j < 2 * HT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(hv, bv[j], acc[j], 0, 0, 0);
-#pragma unroll
-                for (int j = 2 * HT; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(rh, bv[j], acc[j], 0, 0, 0);
+                for (int j = 0; j < NJ; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32((jb + j) < 2 * HT ? hv : rh, bv[j], acc[j], 0, 0, 0);
                 if (s & 1) asm volatile("" ::: "memory");
             }
         }
@@ -182,10 +190,11 @@ __global__ __launch_bounds__(64 * (HT + DT), (HT + DT > 4 ? 1 : 2)) void gru_wgr
     const int row_base = role_x ? 32 * tile : D + 32 * tile;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        const bool gate_tile = j < 2 * HT;
+        const int jg = jb + j;
+        const bool gate_tile = jg < 2 * HT;
         float *dst = gate_tile ? s_wg : s_wc;
         const int ld = gate_tile ? 2 * H : H;
-        const int col = gate_tile ? 32 * j + c : 32 * (j - 2 * HT) + c;
+        const int col = gate_tile ? 32 * jg + c : 32 * (jg - 2 * HT) + c;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int i = (r & 3) + 8 * (r >> 2) + 4 * rp;
@@ -198,8 +207,9 @@ __global__ __launch_bounds__(64 * (HT + DT), (HT + DT > 4 ? 1 : 2)) void gru_wgr
             // the two half-waves hold the even / odd rows' sums of the same column
             const float tot = bsum[j] + __shfl_xor(bsum[j], 32);
             if (rp == 0) {
-                if (j < 2 * HT) s_bg[32 * j + c] = tot;
-                else            s_bc[32 * (j - 2 * HT) + c] = tot;
+                const int jg = jb + j;
+                if (jg < 2 * HT) s_bg[32 * jg + c] = tot;
+                else             s_bc[32 * (jg - 2 * HT) + c] = tot;
             }
         }
     }
@@ -252,12 +262,12 @@ size_t gru_wgrad_workspace_bytes(int B, int T, int D, int H) {
     return (size_t)nwg * (size_t)wgrad_slab_floats(D, H) * sizeof(float);
 }
 
-template <int HT, int DT>
+template <int HT, int DT, int CS = 1>
 static int launch_wgrad(const HpmnGruWgrad &a, hipStream_t st) {
     HpmnGruWgrad k = a;
     k.seq_per_wg = wgrad_seq_per_wg(a.T);
     const int nwg = (a.B + k.seq_per_wg - 1) / k.seq_per_wg;
-    hipLaunchKernelGGL((gru_wgrad_kernel<HT, DT>), dim3((unsigned)nwg), dim3(64 * (HT + DT)), 0, st, k);
+    hipLaunchKernelGGL((gru_wgrad_kernel<HT, DT, CS>), dim3((unsigned)nwg, CS), dim3(64 * (HT + DT)), 0, st, k);
     int rc = check_launch();
     if (rc != HPMN_OK) return rc;
     const int H = a.H, D = a.D;
@@ -274,8 +284,8 @@ int gru_wgrad_dispatch(const HpmnGruWgrad &a, hipStream_t st) {
     else if (a.H == 32 && DT == 2) rc = launch_wgrad<1, 2>(a, st);
     else if (a.H == 64 && DT == 1) rc = launch_wgrad<2, 1>(a, st);
     else if (a.H == 64 && DT == 2) rc = launch_wgrad<2, 2>(a, st);
-    else if (a.H == 128 && DT == 1) rc = launch_wgrad<4, 1>(a, st);     // 12 accumulator tiles per wave, ~90 KB LDS:
-    else if (a.H == 128 && DT == 4) rc = launch_wgrad<4, 4>(a, st);     // one workgroup per CU
+    else if (a.H == 128 && DT == 1) rc = launch_wgrad<4, 1, 3>(a, st);  // 3 column groups x 4 accumulator tiles,
+    else if (a.H == 128 && DT == 4) rc = launch_wgrad<4, 4, 3>(a, st);  // two workgroups per CU
     if (rc != HPMN_OK || a.d_x == nullptr) return rc;
     return gru_dx_dispatch(a, st);
 }

@@ -12,7 +12,7 @@ CSRC = os.path.join(ROOT, "hpmn_amd", "csrc")
 MAIN_FWD = r'''
 #include <cstdio>
 #include <vector>
-namespace hpmn { void set_last_hip_error(int) {} }
+namespace hpmn { void set_last_hip_error(int) {} int gru_scan_fwd128_dispatch(const HpmnGruFwd &, hipStream_t) { return -2; } }
 int main() {
     const int B = 500, T = 1024, H = 64, D = 32;
     float *xp, *wg, *wc, *hl, *y, *hs, *gates;
@@ -41,7 +41,7 @@ int main() {
 MAIN_BWD = r'''
 #include <cstdio>
 #include <vector>
-namespace hpmn { void set_last_hip_error(int) {} }
+namespace hpmn { void set_last_hip_error(int) {} int gru_scan_bwd128_dispatch(const HpmnGruBwd &, hipStream_t) { return -2; } }
 int main() {
     const int B = 500, T = 1024, H = 64, D = 32;
     float *wg, *wc, *dhl, *dy, *hs, *gates, *dact, *carry;
@@ -142,6 +142,18 @@ def proj_variants(src):
     v7 = sub(src, "float *dst = a.xp + (long)flat_row(tile_row(tile)) * N + n_base + 4 * p;",
              "float *dst = a.xp + ((long)tile * NS + ns) * 32 * NT * 32 + c * 96 + 4 * p;")
     out["p7 xp stores: 384-B row pieces packed (wrong layout)"] = v7
+    v8 = sub(src, """                    *reinterpret_cast<float4 *>(dst + 32 * nt + 8 * g) =
+                        make_float4(acc[nt][4 * g], acc[nt][4 * g + 1], acc[nt][4 * g + 2], acc[nt][4 * g + 3]);
+        }
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            cur[q] = nxt[q];""", """                    { typedef float v4 __attribute__((ext_vector_type(4))); v4 vv = {acc[nt][4 * g], acc[nt][4 * g + 1], acc[nt][4 * g + 2], acc[nt][4 * g + 3]};
+                      __builtin_nontemporal_store(vv, reinterpret_cast<v4 *>(dst + 32 * nt + 8 * g)); }
+        }
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            cur[q] = nxt[q];""")
+    out["p8 xp stores non-temporal"] = v8
     v5 = sub(v1, "*reinterpret_cast<float4 *>(xo + 4 * i) = v;", "if (v.x == 123.f) *reinterpret_cast<float4 *>(xo + 4 * i) = v;")
     v5 = sub(v5, "v[q] = *reinterpret_cast<const float4 *>(a.emb + (long)id[q] * a.E + (j - f * a.E));",
              "v[q] = make_float4((float)id[q], 0.f, 0.f, 0.f);")
@@ -171,6 +183,11 @@ def fwd_variants(src):
     v4 = sub(v3, "        rhb[lane] = r * h;\n        wave_sync();", "        rhb[lane] = r * h;")
     v4 = sub(v4, "        hb[lane] = h;\n        wave_sync();", "        hb[lane] = h;")
     out["f4 f3 + no fence between write and reads"] = v4
+    v6 = src
+    for old_, new_ in (("*hsp = h;", "__builtin_nontemporal_store(h, hsp);"), ("gp[0] = r;", "__builtin_nontemporal_store(r, gp);"),
+                       ("gp[H] = u;", "__builtin_nontemporal_store(u, gp + H);"), ("gp[2 * H] = cc;", "__builtin_nontemporal_store(cc, gp + 2 * H);")):
+        v6 = sub(v6, old_, new_)
+    out["f6 non-temporal hs/gates stores"] = v6
     v5 = sub(src, "const float r = sigmoid_scaled(", "const float r = 0.5f + 0.25f * (")
     v5 = sub(v5, "const float u = sigmoid_scaled(", "const float u = 0.5f + 0.25f * (")
     v5 = sub(v5, "const float cc = tanh_scaled(", "const float cc = 0.1f * (")
