@@ -323,7 +323,8 @@ static int launch_proj(const HpmnInputProj &a, hipStream_t st) {
     return check_launch();
 }
 
-// H = 128: 12 column tiles; D = 32 keeps 3 per wave over 4 waves, D = 128 (upper layers) one per wave
+// H = 128: 12 column tiles, 3 per wave over the 4 waves of a workgroup (D = 128: 192 stationary weights + two
+// 64-float row images + 48 accumulators per lane -- fits the 512-register budget of one wave per SIMD)
 bool input_proj_supported(int H, int D) {
     if (H == 128) return D == 32 || D == 128;
     return (H == 32 || H == 64) && (D == 16 || D == 32 || D == 48 || D == 64);
@@ -332,7 +333,7 @@ bool input_proj_supported(int H, int D) {
 int input_proj_dispatch(const HpmnInputProj &a, hipStream_t st) {
     if (a.H == 128) {
         if (a.D == 32) return launch_proj<32, 3, 4>(a, st);
-        if (a.D == 128) return launch_proj<128, 1, 12>(a, st);
+        if (a.D == 128) return launch_proj<128, 3, 4>(a, st);
         return HPMN_EUNSUPPORTED;
     }
 #define X(d) \
