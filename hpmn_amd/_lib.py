@@ -140,6 +140,11 @@ def load(path: Optional[str] = None) -> C.CDLL:
         raise HpmnLibraryError(
             "%s not found: the HIP extension is not built.  Run `python -c \"import __graft_entry__ as g; "
             "g.build()\"` (or hpmn_amd.build.build_library()).  There is no CPU fallback." % p)
+    # PyTorch-ROCm bundles its own libamdhip64; streams and device pointers handed to this library come from
+    # THAT runtime.  Import torch first so the library's libamdhip64 dependency resolves to the copy torch has
+    # already loaded -- loaded the other way round the process ends up with two HIP runtimes and every launch
+    # on a torch stream fails with hipErrorNoDevice (100).
+    import torch  # noqa: F401
     lib = C.CDLL(p)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)       # AttributeError if the export is missing

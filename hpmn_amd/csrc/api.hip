@@ -47,6 +47,11 @@ static bool layer_lengths(const HpmnScanDesc &d, int32_t *len) {
 
 using namespace hpmn;
 
+// hipGetLastError() is sticky per thread: an error left behind by an unrelated earlier HIP call of the
+// host application (seen: 100 from a device probe made before the runtime was initialised) would be
+// reported by the first launch check of this library.  Every launching entry point drops it first.
+static inline void drop_stale_hip_error() { (void)hipGetLastError(); }
+
 extern "C" {
 
 int hpmn_abi_version(void) { return HPMN_ABI_VERSION; }
@@ -70,6 +75,7 @@ int hpmn_gru_shape_supported(int32_t H, int32_t D) {
 
 int hpmn_embed_gather(const int32_t *ids, const float *emb, float *out, int64_t N, int32_t F, int32_t E,
                       int64_t V, int32_t mask_id0, void *stream) {
+    drop_stale_hip_error();
     if (N < 0 || F < 1 || E < 4 || V < 1) return HPMN_EINVAL;
     if (E % 4 != 0) return HPMN_EUNSUPPORTED;
     if (N == 0) return HPMN_OK;
@@ -78,6 +84,7 @@ int hpmn_embed_gather(const int32_t *ids, const float *emb, float *out, int64_t 
 }
 
 int hpmn_gru_input_proj(const HpmnInputProj *a, void *stream) {
+    drop_stale_hip_error();
     if (!a) return HPMN_EINVAL;
     if (a->B < 0 || a->T < 1 || a->D < 1 || a->H < 1) return HPMN_EINVAL;
     if (!a->wg || !a->bg || !a->wc || !a->bc || !a->xp) return HPMN_EINVAL;
@@ -95,6 +102,7 @@ int hpmn_gru_input_proj(const HpmnInputProj *a, void *stream) {
 }
 
 int hpmn_gru_scan_fwd(const HpmnGruFwd *a, void *stream) {
+    drop_stale_hip_error();
     if (!a) return HPMN_EINVAL;
     if (a->B < 0 || a->T < 1 || a->D < 1 || a->H < 1) return HPMN_EINVAL;
     if (!a->xp || !a->wg || !a->wc || !a->h_last) return HPMN_EINVAL;
@@ -110,6 +118,7 @@ int hpmn_gru_scan_fwd(const HpmnGruFwd *a, void *stream) {
 }
 
 int hpmn_gru_scan_bwd(const HpmnGruBwd *a, void *stream) {
+    drop_stale_hip_error();
     if (!a) return HPMN_EINVAL;
     if (a->B < 0 || a->T < 1 || a->D < 1 || a->H < 1) return HPMN_EINVAL;
     if (!a->wg || !a->wc || !a->hs || !a->gates || !a->d_h_last || !a->d_act) return HPMN_EINVAL;
@@ -133,6 +142,7 @@ size_t hpmn_gru_param_grads_workspace_bytes(int32_t B, int32_t T, int32_t D, int
 }
 
 int hpmn_gru_param_grads(const HpmnGruWgrad *a, void *stream) {
+    drop_stale_hip_error();
     if (!a) return HPMN_EINVAL;
     if (a->B < 0 || a->T < 1 || a->D < 1 || a->H < 1) return HPMN_EINVAL;
     if (!gru_shape_supported(a->H, a->D) || !input_proj_supported(a->H, a->D)) return HPMN_EUNSUPPORTED;
@@ -145,6 +155,7 @@ int hpmn_gru_param_grads(const HpmnGruWgrad *a, void *stream) {
 
 int hpmn_gru_input_grad(const float *d_act, const float *wg, const float *wc, float *d_x, int32_t B, int32_t T,
                         int32_t D, int32_t H, int32_t t_begin, int32_t t_len, void *stream) {
+    drop_stale_hip_error();
     if (B < 0 || T < 1 || D < 1 || H < 1 || t_begin < 0 || t_len < 0 || t_begin + t_len > T) return HPMN_EINVAL;
     if (!gru_shape_supported(H, D) || !input_proj_supported(H, D)) return HPMN_EUNSUPPORTED;
     if (B == 0) return HPMN_OK;
@@ -173,6 +184,7 @@ size_t hpmn_scan_workspace_bytes(const HpmnScanDesc *d) {
 int hpmn_scan_fwd(const HpmnScanDesc *d, const int32_t *ids, const float *emb, const float *const *wg,
                   const float *const *bg, const float *const *wc, const float *const *bc, float *memory,
                   float *last, void *workspace, void *stream) {
+    drop_stale_hip_error();
     int32_t len[HPMN_MAX_LAYERS];
     if (!d || !ids || !emb || !wg || !bg || !wc || !bc || !memory || !workspace) return HPMN_EINVAL;
     if (d->B < 0 || d->T < 1 || d->F < 1 || d->E < 4 || d->H < 1 || d->V < 1) return HPMN_EINVAL;
@@ -237,6 +249,7 @@ size_t hpmn_read_workspace_bytes(const HpmnReadDesc *d) {
 
 int hpmn_read_fwd(const HpmnReadDesc *d, const float *params, const float *memory, const float *last, float *pred,
                   float *logit, float *att_w0, float *mem_loss, void *stream) {
+    drop_stale_hip_error();
     if (!d) return HPMN_EINVAL;
     if (d->B < 0) return HPMN_EINVAL;
     if (d->B == 0) return HPMN_OK;
@@ -248,6 +261,7 @@ int hpmn_read_fwd_bwd(const HpmnReadDesc *d, const float *params, const float *m
                       const int32_t *label, const float *mask1, const float *mask2, float keep_prob,
                       float inv_global_batch, float memory_reg, float *pred, float *loss_out, float *d_memory,
                       float *d_last, float *d_params, float *workspace, void *stream) {
+    drop_stale_hip_error();
     if (!d) return HPMN_EINVAL;
     if (d->B < 0 || !(keep_prob > 0.f)) return HPMN_EINVAL;
     if (d->B == 0) return HPMN_OK;
@@ -263,6 +277,7 @@ int hpmn_read_fwd_bwd(const HpmnReadDesc *d, const float *params, const float *m
 int hpmn_embed_grad_scatter(const int32_t *ids, const float *d_x, float *d_emb, int32_t B, int32_t T,
                             int32_t F, int32_t E, int32_t front_zero, int64_t V, int32_t mask_id0,
                             void *stream) {
+    drop_stale_hip_error();
     if (B < 0 || T < 1 || F < 1 || E < 1 || front_zero < 0 || V < 1) return HPMN_EINVAL;
     if (64 % E != 0) return HPMN_EUNSUPPORTED;
     if (B == 0) return HPMN_OK;
@@ -272,6 +287,7 @@ int hpmn_embed_grad_scatter(const int32_t *ids, const float *d_x, float *d_emb, 
 
 int hpmn_adam_step(float *param, const float *grad, float *m, float *v, int64_t n, float lr_t, float beta1,
                    float beta2, float eps, float clip, float grad_scale, void *stream) {
+    drop_stale_hip_error();
     if (n < 0) return HPMN_EINVAL;
     if (n == 0) return HPMN_OK;
     if (!param || !grad || !m || !v) return HPMN_EINVAL;
