@@ -44,6 +44,22 @@ def allreduce_sum_(flat: torch.Tensor) -> torch.Tensor:
     return flat
 
 
+def allreduce_sum_async(flat: torch.Tensor):
+    """Start a sum all-reduce of a contiguous range; ``.wait()`` on the result orders the current stream
+    after it (world > 1 only)."""
+    return td.all_reduce(flat, op=td.ReduceOp.SUM, async_op=True)
+
+
+def chunk_bounds(n: int, chunks: int, align: int = 1) -> List[Tuple[int, int]]:
+    """[0, n) cut into at most ``chunks`` contiguous ranges whose interior boundaries are multiples of
+    ``align``; never returns an empty range."""
+    if n <= 0:
+        return []
+    step = -(-n // max(1, chunks))
+    step = -(-step // align) * align
+    return [(a, min(n, a + step)) for a in range(0, n, step)]
+
+
 def gather_predictions(pred: torch.Tensor, n_global: int) -> torch.Tensor:
     """All-gather per-rank prediction slices (sizes from ``shard_sizes``) into the global order.
     Uses one equal-size all_gather_into_tensor (slices padded to the largest)."""

@@ -135,6 +135,7 @@ class Hpmn_Basic(object):
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
         assert self.user_num_layers <= len(self.user_layers)     # code/hpmn.py:115
         self.rank, self.world = dist.rank_world()
+        self.table_exchange_chunks = 4
         self._save_path = None
         self._datasets: Dict[int, _DeviceDataset] = {}
         self.spec = self._make_spec()
@@ -299,8 +300,16 @@ class Hpmn_Basic(object):
         # are still being reduced on the side stream: exchange + update the table (99.5 % of the
         # parameters, HBM-bound) underneath them, then join and do the dense rest.
         n_emb = self.params["Embedding/emb_mtx"].numel()
-        dist.allreduce_sum_(self.flat_grad[:n_emb])
-        self.apply_gradients(0, n_emb, advance=True)
+        if self.world > 1:
+            # the table exchange is the one big collective of the step (212 MB at C3): cut it into a few
+            # ranges so that clip + Adam of range i run while RCCL is still reducing range i+1
+            bounds = dist.chunk_bounds(n_emb, self.table_exchange_chunks, align=1024)
+            works = [dist.allreduce_sum_async(self.flat_grad[a:b]) for a, b in bounds]
+            for i, ((a, b), w) in enumerate(zip(bounds, works)):
+                w.wait()                                     # orders the current stream after the collective
+                self.apply_gradients(a, b, advance=(i == 0))
+        else:
+            self.apply_gradients(0, n_emb, advance=True)
         pending.join()
         dist.allreduce_sum_(self.flat_grad[n_emb:])
         self.apply_gradients(n_emb, self.flat_param.numel(), advance=False)

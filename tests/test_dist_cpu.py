@@ -91,3 +91,13 @@ def test_shard_bounds_cover_batch_without_overlap():
             assert all(cuts[i][1] == cuts[i + 1][0] for i in range(world - 1))
             assert [b - a for a, b in cuts] == dist.shard_sizes(n, world)
             assert max(dist.shard_sizes(n, world)) - min(dist.shard_sizes(n, world)) <= 1
+
+
+def test_chunk_bounds_cover_the_range_with_aligned_cuts():
+    for n, k, al in ((10, 4, 1), (52928304, 4, 1024), (1000, 4, 1024), (4096, 3, 1024), (5, 8, 2), (0, 4, 16)):
+        b = dist.chunk_bounds(n, k, al)
+        assert len(b) <= max(1, k) and (not b) == (n == 0)
+        if b:
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(x[1] == y[0] for x, y in zip(b, b[1:])) and all(lo < hi for lo, hi in b)
+            assert all(lo % al == 0 for lo, _ in b)
