@@ -91,6 +91,16 @@ class HpmnScanDesc(C.Structure):
     ]
 
 
+class HpmnOnlineUpdate(C.Structure):
+    _fields_ = [
+        ("B", C.c_int32), ("D", C.c_int32), ("H", C.c_int32), ("K", C.c_int32),
+        ("periods", C.c_int32 * HPMN_MAX_LAYERS),
+        ("user", C.c_void_p), ("x", C.c_void_p), ("state", C.c_void_p), ("count", C.c_void_p),
+        ("wg", C.c_void_p * HPMN_MAX_LAYERS), ("bg", C.c_void_p * HPMN_MAX_LAYERS),
+        ("wc", C.c_void_p * HPMN_MAX_LAYERS), ("bc", C.c_void_p * HPMN_MAX_LAYERS),
+    ]
+
+
 # every symbol include/hpmn_hip.h declares: (restype, argtypes)
 SIGNATURES = {
     "hpmn_abi_version": (C.c_int, []),
@@ -117,6 +127,7 @@ SIGNATURES = {
                           [C.c_float, C.c_float, C.c_float] + [C.c_void_p] * 7),
     "hpmn_embed_grad_scatter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                           C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_void_p]),
+    "hpmn_memory_update": (C.c_int, [C.POINTER(HpmnOnlineUpdate), C.c_void_p]),
     "hpmn_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                  C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                  C.c_void_p]),

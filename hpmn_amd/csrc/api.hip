@@ -11,6 +11,7 @@ bool gru_shape_supported(int H, int D);
 int gru_scan_fwd_dispatch(const HpmnGruFwd &a, hipStream_t st);
 int gru_scan_bwd_dispatch(const HpmnGruBwd &a, hipStream_t st);
 bool input_proj_supported(int H, int D);
+int memory_update_launch(const HpmnOnlineUpdate &a, hipStream_t st);
 int input_proj_dispatch(const HpmnInputProj &a, hipStream_t st);
 int gru_wgrad_dispatch(const HpmnGruWgrad &a, hipStream_t st);
 int gru_dx_dispatch(const HpmnGruWgrad &a, hipStream_t st);
@@ -292,6 +293,19 @@ int hpmn_adam_step(float *param, const float *grad, float *m, float *v, int64_t 
     if (n == 0) return HPMN_OK;
     if (!param || !grad || !m || !v) return HPMN_EINVAL;
     return adam_launch(param, grad, m, v, n, lr_t, beta1, beta2, eps, clip, grad_scale, (hipStream_t)stream);
+}
+
+int hpmn_memory_update(const HpmnOnlineUpdate *a, void *stream) {
+    drop_stale_hip_error();
+    if (a == nullptr || a->B < 0 || a->K < 1 || a->K > HPMN_MAX_LAYERS || a->D < 1 || a->D > 128) return HPMN_EINVAL;
+    if (a->B == 0) return HPMN_OK;
+    if (a->user == nullptr || a->x == nullptr || a->state == nullptr || a->count == nullptr) return HPMN_EINVAL;
+    for (int i = 0; i < a->K; ++i) {
+        if (a->wg[i] == nullptr || a->bg[i] == nullptr || a->wc[i] == nullptr || a->bc[i] == nullptr) return HPMN_EINVAL;
+        if (i + 1 < a->K && a->periods[i] < 1) return HPMN_EINVAL;
+    }
+    if (a->H != 32 && a->H != 64 && a->H != 128) return HPMN_EUNSUPPORTED;
+    return memory_update_launch(*a, (hipStream_t)stream);
 }
 
 }  // extern "C"

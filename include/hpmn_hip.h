@@ -264,6 +264,37 @@ int hpmn_adam_step(float *param, const float *grad, float *m, float *v, int64_t 
                    float lr_t, float beta1, float beta2, float eps, float clip,
                    float grad_scale, void *stream);
 
+/* ------------------------------------------------------------------------------------
+ * Online incremental memory update -- the serving-time form of build_memory: ONE new event per
+ * user and call, against a persisted per-user state store.  Reference: the "incremental_update"
+ * cascade of code/srnn.py:727-748 (layer i is updated iff index % 2^i == 0, its input being the
+ * state layer i-1 has just produced) and its state store / scatter update (:790-796), generalised
+ * to the periods of code/hpmn.py:113-129:
+ *
+ *   n = ++count[u]                                   events of user u so far (1-based)
+ *   s_0 = GRU_0(x, s_0)                              every event
+ *   for i = 1..K-1 while n % (p_0 p_1 .. p_{i-1}) == 0:   s_i = GRU_i(s_{i-1}, s_i)
+ *
+ * After T events the store holds exactly the `memory` hpmn_scan_fwd computes over those T steps
+ * (every layer's last firing), so a user's lifelong sequence never has to be replayed.
+ *   user  [B] int32   row of the store touched by event b (distinct within one call)
+ *   x     [B, D]      the event's input row (embedding gather: hpmn_embed_gather)
+ *   state [U, K, H]   in/out;   count [U] int32 in/out
+ *   wg/bg/wc/bc       K pointers each, TF layout; layer 0 has D input rows, layers >= 1 have H
+ * H in {32, 64, 128}; D <= 128.
+ * ---------------------------------------------------------------------------------- */
+typedef struct HpmnOnlineUpdate {
+    int32_t B, D, H, K;
+    int32_t periods[HPMN_MAX_LAYERS];
+    const int32_t *user;
+    const float *x;
+    float *state;
+    int32_t *count;
+    const float *wg[HPMN_MAX_LAYERS], *bg[HPMN_MAX_LAYERS], *wc[HPMN_MAX_LAYERS], *bc[HPMN_MAX_LAYERS];
+} HpmnOnlineUpdate;
+
+int hpmn_memory_update(const HpmnOnlineUpdate *args, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

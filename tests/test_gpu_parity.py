@@ -237,6 +237,34 @@ def test_tiny_and_odd_lengths_forward_and_gradients(dev, tmp_path, H, T):
                                    err_msg=k)
 
 
+@pytest.mark.parametrize("H", [32, 64, 128])
+def test_online_update_event_by_event_equals_the_batch_scan(dev, tmp_path, H):
+    """hpmn_memory_update (the serving-time cascade, code/srnn.py:727-748): feeding a sequence one event at a
+    time into the persisted store must land on the memory the batch scan computes -- after the full sequence
+    and at every prefix whose length the periods divide -- and score like the batch forward."""
+    from hpmn_amd.online import OnlineMemory
+    T, B = 40, 5
+    cfg = O.HpmnConfig(120, 2, T, H, 16, 3, (2, 2, 5, 1), 3, False, 1e-5)      # firing every 1 / 2 / 4 events
+    p = f32_params(cfg, 61)
+    ids, label = rand_ids(cfg, B, 62, ragged=False)
+    m = make_model(cfg, tmp_path, p)
+    store = OnlineMemory(m, n_users=9)
+    users = torch.as_tensor([7, 0, 3, 8, 2], dtype=torch.int32, device=dev)
+    t_ids = torch.as_tensor(ids).to(dev)
+    for t in range(T):
+        store.update(users, t_ids[:, t, :].contiguous())
+        if (t + 1) in (20, 40):                     # 20 = 2*2*5: every layer's length divides at this prefix
+            pre = O.HpmnConfig(120, 2, t + 1, H, 16, 3, (2, 2, 5, 1), 3, False, 1e-5)
+            want = O.forward(pre, p, ids[:, :t + 1], label)
+            np.testing.assert_allclose(store.memory(users).cpu().numpy(), want["memory"], rtol=0, atol=TOL)
+    assert store.count.cpu().tolist() == [T if u in (7, 0, 3, 8, 2) else 0 for u in range(9)]
+    assert float(store.state[[1, 4, 5, 6]].abs().max()) == 0.0        # untouched users stay untouched
+    # scoring a stored user == the batch forward whose last row is the candidate (Hpmn: last = row -1)
+    want = O.forward(cfg, p, ids, label)
+    got = store.predict(users, t_ids[:, -1, :].contiguous())
+    np.testing.assert_allclose(got["logit"].cpu().numpy(), want["logit"], rtol=0, atol=TOL)
+
+
 def test_time_chunked_pipelined_launches_match_unchunked(dev, tmp_path, monkeypatch):
     """The optional cross-layer pipelining (time-chunked scan / projection / dx launches over K streams,
     state and gradient carried across chunk boundaries) must reproduce the unchunked result."""
