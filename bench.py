@@ -22,8 +22,11 @@ import sys
 import tempfile
 import time
 
-import numpy as np
-import torch
+# dmabuf IPC is the only mode the host driver supports: RCCL / cross-process tensor sharing fail without it
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -274,6 +277,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-auc", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend for N > 1 (nccl == RCCL; gloo lets several ranks share one GPU for a dry run)")
     ap.add_argument("--auc-steps", type=int, default=300)
     args = ap.parse_args()
     c = dict(CONFIGS[args.config])
@@ -287,11 +292,16 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    if args.backend == "gloo":
+        local_rank = local_rank % max(1, torch.cuda.device_count())      # dry run: ranks may share a device
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.backend == "nccl":
+            torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
 
     from hpmn_amd import build
     if rank == 0:
