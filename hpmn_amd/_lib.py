@@ -91,6 +91,20 @@ class HpmnScanDesc(C.Structure):
     ]
 
 
+class HpmnGruFusedFwd(C.Structure):
+    _fields_ = [
+        ("B", C.c_int32), ("T", C.c_int32), ("D", C.c_int32), ("H", C.c_int32),
+        ("x", C.c_void_p), ("ids", C.c_void_p), ("emb", C.c_void_p),
+        ("Tids", C.c_int32), ("F", C.c_int32), ("E", C.c_int32), ("front_zero", C.c_int32), ("mask_id0", C.c_int32),
+        ("V", C.c_int64),
+        ("wg", C.c_void_p), ("bg", C.c_void_p), ("wc", C.c_void_p), ("bc", C.c_void_p),
+        ("x_out", C.c_void_p),
+        ("h_last", C.c_void_p), ("h_last_stride", C.c_int64),
+        ("y", C.c_void_p), ("period", C.c_int32),
+        ("hs", C.c_void_p), ("gates", C.c_void_p),
+    ]
+
+
 class HpmnOnlineUpdate(C.Structure):
     _fields_ = [
         ("B", C.c_int32), ("D", C.c_int32), ("H", C.c_int32), ("K", C.c_int32),
@@ -127,6 +141,8 @@ SIGNATURES = {
                           [C.c_float, C.c_float, C.c_float] + [C.c_void_p] * 7),
     "hpmn_embed_grad_scatter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                           C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_void_p]),
+    "hpmn_gru_fused_fwd_supported": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),
+    "hpmn_gru_fused_fwd": (C.c_int, [C.POINTER(HpmnGruFusedFwd), C.c_void_p]),
     "hpmn_memory_update": (C.c_int, [C.POINTER(HpmnOnlineUpdate), C.c_void_p]),
     "hpmn_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                  C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,

@@ -12,6 +12,8 @@ int gru_scan_fwd_dispatch(const HpmnGruFwd &a, hipStream_t st);
 int gru_scan_bwd_dispatch(const HpmnGruBwd &a, hipStream_t st);
 bool input_proj_supported(int H, int D);
 int memory_update_launch(const HpmnOnlineUpdate &a, hipStream_t st);
+bool gru_fused_fwd_supported(int H, int D, int gather);
+int gru_fused_fwd_dispatch(const HpmnGruFusedFwd &a, hipStream_t st);
 int input_proj_dispatch(const HpmnInputProj &a, hipStream_t st);
 int gru_wgrad_dispatch(const HpmnGruWgrad &a, hipStream_t st);
 int gru_dx_dispatch(const HpmnGruWgrad &a, hipStream_t st);
@@ -204,6 +206,25 @@ int hpmn_scan_fwd(const HpmnScanDesc *d, const int32_t *ids, const float *emb, c
     float *ybuf[2] = {reinterpret_cast<float *>(ws + xp_bytes), reinterpret_cast<float *>(ws + xp_bytes + y_bytes)};
 
     for (int i = 0; i < d->K; ++i) {
+        const int Di = i == 0 ? D0 : d->H;
+        if (gru_fused_fwd_supported(d->H, Di, i == 0) && (i > 0 || (64 % d->E == 0 && Di <= 64))) {
+            HpmnGruFusedFwd f = {};
+            f.B = d->B; f.T = len[i]; f.D = Di; f.H = d->H;
+            f.wg = wg[i]; f.bg = bg[i]; f.wc = wc[i]; f.bc = bc[i];
+            if (i == 0) {
+                f.ids = ids; f.emb = emb; f.Tids = d->T; f.F = d->F; f.E = d->E; f.front_zero = d->front_zero;
+                f.mask_id0 = d->mask_id0; f.V = d->V;
+            } else {
+                f.x = ybuf[(i - 1) & 1];
+            }
+            f.h_last = memory + (size_t)i * d->H;
+            f.h_last_stride = (int64_t)d->K * d->H;
+            f.period = d->periods[i];
+            f.y = (i + 1 < d->K) ? ybuf[i & 1] : nullptr;
+            int rc = hpmn_gru_fused_fwd(&f, stream);
+            if (rc != HPMN_OK) return rc;
+            continue;
+        }
         HpmnInputProj p = {};
         p.B = d->B; p.T = len[i]; p.H = d->H;
         p.wg = wg[i]; p.bg = bg[i]; p.wc = wc[i]; p.bc = bc[i];
@@ -293,6 +314,26 @@ int hpmn_adam_step(float *param, const float *grad, float *m, float *v, int64_t 
     if (n == 0) return HPMN_OK;
     if (!param || !grad || !m || !v) return HPMN_EINVAL;
     return adam_launch(param, grad, m, v, n, lr_t, beta1, beta2, eps, clip, grad_scale, (hipStream_t)stream);
+}
+
+int hpmn_gru_fused_fwd_supported(int32_t H, int32_t D, int32_t gather) {
+    return gru_fused_fwd_supported(H, D, gather) ? 1 : 0;
+}
+
+int hpmn_gru_fused_fwd(const HpmnGruFusedFwd *a, void *stream) {
+    drop_stale_hip_error();
+    if (a == nullptr || a->B < 0 || a->T < 1 || a->period < 1) return HPMN_EINVAL;
+    if (!a->wg || !a->bg || !a->wc || !a->bc || !a->h_last) return HPMN_EINVAL;
+    if ((a->hs == nullptr) != (a->gates == nullptr)) return HPMN_EINVAL;
+    if (a->x == nullptr) {
+        if (!a->ids || !a->emb || a->F < 1 || a->E < 1 || a->F * a->E != a->D || a->Tids + a->front_zero != a->T ||
+            a->front_zero < 0)
+            return HPMN_EINVAL;
+    }
+    if (a->y != nullptr && a->T % a->period != 0) return HPMN_EINVAL;
+    if (!gru_fused_fwd_supported(a->H, a->D, a->x == nullptr)) return HPMN_EUNSUPPORTED;
+    if (a->B == 0) return HPMN_OK;
+    return gru_fused_fwd_dispatch(*a, (hipStream_t)stream);
 }
 
 int hpmn_memory_update(const HpmnOnlineUpdate *a, void *stream) {

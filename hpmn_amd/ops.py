@@ -11,6 +11,7 @@ path stay in ``hpmn_amd.model``).
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
 
@@ -131,6 +132,43 @@ def gru_input_proj(spec_or_none, *, x=None, ids=None, emb=None, wg, bg, wc, bc, 
     rc = _lib.load().hpmn_gru_input_proj(C.byref(a), _stream())
     _lib.check(rc, "hpmn_gru_input_proj")
     return xp, x_out
+
+
+FUSED_FWD = int(os.environ.get("HPMN_FUSED_FWD", "1")) != 0
+
+
+def fused_fwd_supported(H: int, D: int, gather: bool) -> bool:
+    return FUSED_FWD and bool(_lib.load().hpmn_gru_fused_fwd_supported(H, D, int(gather)))
+
+
+def gru_fused_fwd(*, x=None, ids=None, emb=None, wg, bg, wc, bc, H, T, front_zero=0, mask_id0=False, h_last, period,
+                  out):
+    """hpmn_gru_fused_fwd: input projection + recurrence of one layer in one launch (two specialised waves per
+    sequence).  ``out`` = (y, hs, gates, x_out), any of them None."""
+    a = _lib.HpmnGruFusedFwd()
+    _chk_f32(wg, bg, wc, bc)
+    if x is not None:
+        _chk_f32(x)
+        B, Tx, D = x.shape
+        assert Tx == T
+        a.x = x.data_ptr()
+    else:
+        _chk_ids(ids)
+        _chk_f32(emb)
+        B, Tids, F = ids.shape
+        V, E = emb.shape
+        D = F * E
+        a.ids, a.emb = ids.data_ptr(), emb.data_ptr()
+        a.Tids, a.F, a.E, a.front_zero, a.mask_id0, a.V = Tids, F, E, front_zero, int(mask_id0), V
+    a.B, a.T, a.D, a.H = B, T, D, H
+    a.wg, a.bg, a.wc, a.bc = wg.data_ptr(), bg.data_ptr(), wc.data_ptr(), bc.data_ptr()
+    assert h_last.stride(1) == 1 and h_last.shape == (B, H)
+    a.h_last, a.h_last_stride = h_last.data_ptr(), h_last.stride(0)
+    a.period = period
+    y, hs, gates, x_out = out
+    a.y, a.hs, a.gates, a.x_out = _ptr(y), _ptr(hs), _ptr(gates), _ptr(x_out)
+    rc = _lib.load().hpmn_gru_fused_fwd(C.byref(a), _stream())
+    _lib.check(rc, "hpmn_gru_fused_fwd")
 
 
 def gru_scan_fwd(xp, wg, wc, D, h_last, period, want_y, train, out=None, t_range=None, h_init=None):
@@ -337,7 +375,9 @@ def scan_forward_train(spec: ScanSpec, ids, emb, weights: Sequence[torch.Tensor]
     memory = torch.empty(B, K, H, **f32)
     in_dims = [spec.D0] + [H] * (K - 1)
     x0 = torch.empty(B, lens[0], spec.D0, **f32)
-    xp = [torch.empty(B, lens[i], 3 * H, **f32) for i in range(K)]
+    fused = [PIPELINE_CHUNKS <= 1 and fused_fwd_supported(H, in_dims[i], i == 0) and (i > 0 or 64 % spec.E == 0)
+             for i in range(K)]
+    xp = [None if fused[i] else torch.empty(B, lens[i], 3 * H, **f32) for i in range(K)]
     hs = [torch.empty(B, lens[i] + 1, H, **f32) for i in range(K)]
     gates = [torch.empty(B, lens[i], 3 * H, **f32) for i in range(K)]
     y = [torch.empty(B, lens[i] // spec.periods[i], H, **f32) if i + 1 < K else None for i in range(K)]
@@ -359,6 +399,15 @@ def scan_forward_train(spec: ScanSpec, ids, emb, weights: Sequence[torch.Tensor]
             with torch.cuda.stream(streams[i]):
                 if i > 0 and nc > 1:
                     streams[i].wait_event(done[i - 1][c])
+                if fused[i] and nc == 1:
+                    if i == 0:
+                        gru_fused_fwd(ids=ids, emb=emb, wg=wg, bg=bg, wc=wc, bc=bc, H=H, T=lens[0],
+                                      front_zero=spec.front_zero, mask_id0=spec.mask_id0, h_last=memory[:, 0, :],
+                                      period=spec.periods[0], out=(y[0], hs[0], gates[0], x0))
+                    else:
+                        gru_fused_fwd(x=x_in[i], wg=wg, bg=bg, wc=wc, bc=bc, H=H, T=lens[i], h_last=memory[:, i, :],
+                                      period=spec.periods[i], out=(y[i], hs[i], gates[i], None))
+                    continue
                 if i == 0:
                     gru_input_proj(None, ids=ids, emb=emb, wg=wg, bg=bg, wc=wc, bc=bc, H=H, T=lens[0],
                                    front_zero=spec.front_zero, mask_id0=spec.mask_id0, out=(xp[0], x0),

@@ -120,6 +120,36 @@ typedef struct HpmnGruFwd {
 int hpmn_gru_scan_fwd(const HpmnGruFwd *args, void *stream);
 
 /* ------------------------------------------------------------------------------------
+ * (1)+(2) fused: the forward of one GRU layer in ONE launch, without the xp hand-over buffer.
+ * A workgroup owns a sequence and runs two specialised waves on two SIMDs of its CU: a
+ * projection wave computes the input half x_t W[0:D] + b (gathering x_t from (ids, emb) for
+ * layer 0) a few steps AHEAD of the recurrence and hands it over through an LDS ring; the
+ * scan wave runs the serial recurrence exactly as hpmn_gru_scan_fwd does.  Same arguments as
+ * HpmnInputProj + HpmnGruFwd (whole sequences only: no t_begin/t_end), same results.
+ * hpmn_gru_fused_fwd_supported(H, D, gather) tells which shapes have this path (others:
+ * HPMN_EUNSUPPORTED -- call (1) then (2)).
+ * ---------------------------------------------------------------------------------- */
+typedef struct HpmnGruFusedFwd {
+    int32_t B, T, D, H;
+    const float *x;            /* [B,T,D], or NULL: gather from (ids, emb) as in HpmnInputProj */
+    const int32_t *ids;
+    const float *emb;
+    int32_t Tids, F, E, front_zero, mask_id0;
+    int64_t V;
+    const float *wg, *bg, *wc, *bc;
+    float *x_out;              /* optional [B,T,D]: the gathered input (training, gather mode)   */
+    float *h_last;
+    int64_t h_last_stride;
+    float *y;                  /* optional [B, T/period, H] */
+    int32_t period;
+    float *hs;                 /* optional [B,T+1,H]  (training) */
+    float *gates;              /* optional [B,T,3H]   (training) */
+} HpmnGruFusedFwd;
+
+int hpmn_gru_fused_fwd_supported(int32_t H, int32_t D, int32_t gather);
+int hpmn_gru_fused_fwd(const HpmnGruFusedFwd *args, void *stream);
+
+/* ------------------------------------------------------------------------------------
  * One GRU layer, reverse scan (BPTT) -- the serial part of the gradient of
  * hpmn_gru_scan_fwd (TF autodiff through the while_loop of code/hpmn.py:119-120).
  *   d_h_last [B] rows at d_h_last[b*stride + 0..H) : gradient wrt the final state

@@ -40,7 +40,8 @@ def test_struct_layout_matches_c_compiler(tmp_path):
     """sizeof/offsetof from gcc on the real header vs the ctypes mirror."""
     structs = {"HpmnInputProj": _lib.HpmnInputProj, "HpmnGruFwd": _lib.HpmnGruFwd,
                "HpmnGruBwd": _lib.HpmnGruBwd, "HpmnGruWgrad": _lib.HpmnGruWgrad, "HpmnReadDesc": _lib.HpmnReadDesc,
-               "HpmnScanDesc": _lib.HpmnScanDesc, "HpmnOnlineUpdate": _lib.HpmnOnlineUpdate}
+               "HpmnScanDesc": _lib.HpmnScanDesc, "HpmnOnlineUpdate": _lib.HpmnOnlineUpdate,
+               "HpmnGruFusedFwd": _lib.HpmnGruFusedFwd}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "hpmn_hip.h"', "int main(void){"]
     for name, st in structs.items():
         lines.append('printf("%s %%zu\\n", sizeof(%s));' % (name, name))

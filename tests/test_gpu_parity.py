@@ -274,6 +274,7 @@ def test_time_chunked_pipelined_launches_match_unchunked(dev, tmp_path, monkeypa
     ids, label = rand_ids(cfg, 5, 92)
     m = make_model(cfg, tmp_path, p)
     ti, tl = torch.as_tensor(ids).to(dev), torch.as_tensor(label).to(dev)
+    monkeypatch.setattr(ops, "FUSED_FWD", False)         # same (two-kernel) forward on both sides: bit-exact
     out1, ce1 = m.compute_gradients(ti, tl, keep_prob=1.0)
     g1 = m.flat_grad.clone()
     assert ops.chunk_plan(m.spec, 4) == [32, 16, 8, 4]
@@ -281,6 +282,35 @@ def test_time_chunked_pipelined_launches_match_unchunked(dev, tmp_path, monkeypa
     out2, ce2 = m.compute_gradients(ti, tl, keep_prob=1.0)
     assert torch.equal(out1["memory"], out2["memory"]) and torch.equal(out1["prediction"], out2["prediction"])
     np.testing.assert_allclose(m.flat_grad.cpu().numpy(), g1.cpu().numpy(), rtol=0, atol=1e-6 * float(g1.abs().max()))
+
+
+def test_fused_forward_matches_the_two_kernel_forward(dev, tmp_path, monkeypatch):
+    """hpmn_gru_fused_fwd (projection wave + scan wave per sequence, LDS ring hand-over) against
+    hpmn_gru_input_proj + hpmn_gru_scan_fwd: same saved states, gates and gradients up to the summation
+    order of the projection; at the full XLong length, batch > the number of CUs, and with an odd tail."""
+    from hpmn_amd import ops
+    for cfg, B in ((cfg_industry(H=64, K=7, T=1001, V=900), 3), (cfg_industry(H=64, K=3, T=41, V=150), 600),
+                   (cfg_amazon(H=64, K=3, T=100, F=2), 5), (cfg_amazon(H=64, K=3, T=100, F=4), 4)):
+        p = f32_params(cfg, 93)
+        ids, label = rand_ids(cfg, B, 94)
+        m = make_model(cfg, tmp_path, p)
+        ti, tl = torch.as_tensor(ids).to(dev), torch.as_tensor(label).to(dev)
+        monkeypatch.setattr(ops, "FUSED_FWD", True)
+        assert ops.fused_fwd_supported(64, cfg.user_dim * 16, True)
+        mem_f, last_f, saved_f = ops.scan_forward_train(m.spec, ti, m.params["Embedding/emb_mtx"], m._gru_weights())
+        m.compute_gradients(ti, tl, keep_prob=1.0)
+        g_f = m.flat_grad.clone()
+        monkeypatch.setattr(ops, "FUSED_FWD", False)
+        mem_u, last_u, saved_u = ops.scan_forward_train(m.spec, ti, m.params["Embedding/emb_mtx"], m._gru_weights())
+        m.compute_gradients(ti, tl, keep_prob=1.0)
+        g_u = m.flat_grad.clone()
+        np.testing.assert_allclose(mem_f.cpu().numpy(), mem_u.cpu().numpy(), rtol=0, atol=2e-6)
+        assert torch.equal(last_f, last_u)
+        for (x_f, hs_f, ga_f), (x_u, hs_u, ga_u) in zip(saved_f, saved_u):
+            np.testing.assert_allclose(hs_f.cpu().numpy(), hs_u.cpu().numpy(), rtol=0, atol=2e-6)
+            np.testing.assert_allclose(ga_f.cpu().numpy(), ga_u.cpu().numpy(), rtol=0, atol=2e-6)
+        assert torch.equal(saved_f[0][0], saved_u[0][0])                     # the materialised gather
+        np.testing.assert_allclose(g_f.cpu().numpy(), g_u.cpu().numpy(), rtol=0, atol=2e-5 * float(g_u.abs().max()))
 
 
 def test_dropout_masks_are_honoured(dev, tmp_path):
