@@ -206,25 +206,9 @@ int hpmn_scan_fwd(const HpmnScanDesc *d, const int32_t *ids, const float *emb, c
     float *ybuf[2] = {reinterpret_cast<float *>(ws + xp_bytes), reinterpret_cast<float *>(ws + xp_bytes + y_bytes)};
 
     for (int i = 0; i < d->K; ++i) {
-        const int Di = i == 0 ? D0 : d->H;
-        if (gru_fused_fwd_supported(d->H, Di, i == 0) && (i > 0 || (64 % d->E == 0 && Di <= 64))) {
-            HpmnGruFusedFwd f = {};
-            f.B = d->B; f.T = len[i]; f.D = Di; f.H = d->H;
-            f.wg = wg[i]; f.bg = bg[i]; f.wc = wc[i]; f.bc = bc[i];
-            if (i == 0) {
-                f.ids = ids; f.emb = emb; f.Tids = d->T; f.F = d->F; f.E = d->E; f.front_zero = d->front_zero;
-                f.mask_id0 = d->mask_id0; f.V = d->V;
-            } else {
-                f.x = ybuf[(i - 1) & 1];
-            }
-            f.h_last = memory + (size_t)i * d->H;
-            f.h_last_stride = (int64_t)d->K * d->H;
-            f.period = d->periods[i];
-            f.y = (i + 1 < d->K) ? ybuf[i & 1] : nullptr;
-            int rc = hpmn_gru_fused_fwd(&f, stream);
-            if (rc != HPMN_OK) return rc;
-            continue;
-        }
+        // (inference keeps the two-kernel layer: without the saved-state stores the fused layer's scan wave,
+        //  slowed by sharing its CU's LDS pipe with the projection wave, gains nothing -- measured 473 k vs
+        //  534 k sequences/s forward-only at C3)
         HpmnInputProj p = {};
         p.B = d->B; p.T = len[i]; p.H = d->H;
         p.wg = wg[i]; p.bg = bg[i]; p.wc = wc[i]; p.bc = bc[i];
