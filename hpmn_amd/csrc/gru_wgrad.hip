@@ -77,21 +77,24 @@ __global__ __launch_bounds__(64 * (HT + DT), 2) void gru_wgrad_kernel(const Hpmn
 
     const int b_begin = blockIdx.x * a.seq_per_wg;
     const int b_end = (b_begin + a.seq_per_wg) < a.B ? (b_begin + a.seq_per_wg) : a.B;
-    const int ipt = (T + R - 1) / R;                      // tiles per sequence
+    // rows of this launch: steps [tb, te) of every sequence (the whole sequence unless the caller splits the
+    // reduction in time to start it before the reverse scan has finished)
+    const int tb = a.t_begin, te = a.t_len > 0 ? a.t_begin + a.t_len : T;
+    const int ipt = (te - tb + R - 1) / R;                // tiles per sequence
     const int niter = (b_end - b_begin) * ipt;
 
     struct Stage { float4 da[P_DA], x[P_X], h[P_H], r[P_H]; };
     // tile `it` = rows t0..t0+R-1 of sequence b; rows >= T are zero.  All loads are 16-byte, coalesced.
     auto load_tile = [&](int it, Stage &g) {
         const int b = b_begin + it / ipt;
-        const int t0 = (it % ipt) * R;
+        const int t0 = tb + (it % ipt) * R;
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int p = 0; p < P_DA; ++p) {
             const int i = p * NT + tid;
             const int row = i / (NC / 4), q = i % (NC / 4);
             g.da[p] = z;
-            if (i < N_DA && t0 + row < T)
+            if (i < N_DA && t0 + row < te)
                 g.da[p] = *reinterpret_cast<const float4 *>(a.d_act + ((long)b * T + t0 + row) * 3 * H + jb * 32 + 4 * q);
         }
 #pragma unroll
@@ -99,7 +102,7 @@ __global__ __launch_bounds__(64 * (HT + DT), 2) void gru_wgrad_kernel(const Hpmn
             const int i = p * NT + tid;
             const int row = i / (XS / 4), q = i % (XS / 4);
             g.x[p] = z;
-            if (i < N_X && t0 + row < T && 4 * q < D)
+            if (i < N_X && t0 + row < te && 4 * q < D)
                 g.x[p] = *reinterpret_cast<const float4 *>(a.x + ((long)b * T + t0 + row) * D + 4 * q);
         }
 #pragma unroll
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(64 * (HT + DT), 2) void gru_wgrad_kernel(const Hpmn
             const int row = i / (H / 4), q = i % (H / 4);
             g.h[p] = z;
             g.r[p] = z;
-            if (i < N_H && t0 + row < T) {
+            if (i < N_H && t0 + row < te) {
                 g.h[p] = *reinterpret_cast<const float4 *>(a.hs + ((long)b * (T + 1) + t0 + row) * H + 4 * q);
                 g.r[p] = *reinterpret_cast<const float4 *>(a.gates + ((long)b * T + t0 + row) * 3 * H + 4 * q);
             }
@@ -251,7 +254,7 @@ __global__ __launch_bounds__(32 * RED_G) void wgrad_reduce_kernel(const float *_
 
 int gru_dx_dispatch(const HpmnGruWgrad &a, hipStream_t st);   // input_proj.hip (row-wise MFMA)
 
-static int wgrad_seq_per_wg(int T) {
+static int wgrad_seq_per_wg(int T) {   // T = steps per sequence in this launch
     int spw = (WG_MIN_ROWS + T - 1) / T;
     return spw < 1 ? 1 : spw;
 }
@@ -265,7 +268,7 @@ size_t gru_wgrad_workspace_bytes(int B, int T, int D, int H) {
 template <int HT, int DT, int CS = 1>
 static int launch_wgrad(const HpmnGruWgrad &a, hipStream_t st) {
     HpmnGruWgrad k = a;
-    k.seq_per_wg = wgrad_seq_per_wg(a.T);
+    k.seq_per_wg = wgrad_seq_per_wg(a.t_len > 0 ? a.t_len : a.T);
     const int nwg = (a.B + k.seq_per_wg - 1) / k.seq_per_wg;
     hipLaunchKernelGGL((gru_wgrad_kernel<HT, DT, CS>), dim3((unsigned)nwg, CS), dim3(64 * (HT + DT)), 0, st, k);
     int rc = check_launch();

@@ -11,6 +11,7 @@ path stay in ``hpmn_amd.model``).
 from __future__ import annotations
 
 import ctypes as C
+import math
 import os
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
@@ -230,9 +231,10 @@ def gru_scan_bwd(wg, wc, D, hs, gates, d_h_last, d_y, period, out=None, t_range=
     return d_act
 
 
-def gru_param_grads(x, hs, gates, d_act, wg, wc, d_wg, d_bg, d_wc, d_bc, want_dx=True, keep=None):
+def gru_param_grads(x, hs, gates, d_act, wg, wc, d_wg, d_bg, d_wc, d_bc, want_dx=True, keep=None, t_range=None):
     """hpmn_gru_param_grads: accumulates into d_wg/d_bg/d_wc/d_bc (caller-zeroed), returns dx or None.
-    ``keep``: list that receives the temporaries (workspace) when the call is issued on a side stream."""
+    ``keep``: list that receives the temporaries (workspace) when the call is issued on a side stream;
+    ``t_range`` = (t_begin, t_len) restricts the reduction to those steps of every sequence."""
     B, T, D = x.shape
     H = hs.shape[2]
     _chk_f32(x, hs, gates, d_act, wg, wc, d_wg, d_bg, d_wc, d_bc)
@@ -241,6 +243,8 @@ def gru_param_grads(x, hs, gates, d_act, wg, wc, d_wg, d_bg, d_wc, d_bc, want_dx
     a.x, a.hs, a.gates, a.d_act = x.data_ptr(), hs.data_ptr(), gates.data_ptr(), d_act.data_ptr()
     a.wg, a.wc = wg.data_ptr(), wc.data_ptr()
     a.d_wg, a.d_bg, a.d_wc, a.d_bc = d_wg.data_ptr(), d_bg.data_ptr(), d_wc.data_ptr(), d_bc.data_ptr()
+    if t_range is not None:
+        a.t_begin, a.t_len = t_range
     d_x = None
     if want_dx:
         d_x = torch.empty(B, T, D, device=x.device, dtype=torch.float32)
@@ -431,6 +435,20 @@ def scan_forward_train(spec: ScanSpec, ids, emb, weights: Sequence[torch.Tensor]
     return memory, last, saved
 
 
+# measured neutral (C3 4.143 vs 4.169 ms/step, C4 10.48 vs 10.33): off by default, kept as an option
+SPLIT_LAYER0_BWD = int(os.environ.get("HPMN_SPLIT_LAYER0_BWD", "0")) != 0
+
+
+def _time_cut(T: int, period: int) -> int:
+    """Step at which a long reverse scan is cut in two launches (a multiple of 2 and of the period, about the
+    middle); 0 = do not cut (short sequences: the extra launch costs more than it hides)."""
+    if T < 256:
+        return 0
+    q = 2 * period // math.gcd(2, period)
+    cut = (T // 2) // q * q
+    return cut if 0 < cut < T else 0
+
+
 class PendingGrads:
     """Weight-gradient work still running on a side stream when scan_backward(defer_join=True) returns:
     the embedding gradient is complete on the current stream, the GRU weight gradients are not until
@@ -475,12 +493,30 @@ def scan_backward(spec: ScanSpec, ids, saved, weights: Sequence[torch.Tensor], d
         for i in range(K - 1, -1, -1):
             wg, bg, wc, bc = weights[4 * i:4 * i + 4]
             x_in, hs, gates = saved[i]
-            gru_scan_bwd(wg, wc, in_dims[i], hs, gates, d_memory[:, i, :], d_x[i + 1] if i + 1 < K else None,
-                         spec.periods[i], out=d_act[i])
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                gru_param_grads(x_in, hs, gates, d_act[i], wg, wc, gw[4 * i], gw[4 * i + 1], gw[4 * i + 2],
-                                gw[4 * i + 3], want_dx=False, keep=keep)
+            d_y = d_x[i + 1] if i + 1 < K else None
+            # Layer 0 is the end of the chain: nothing runs under ITS weight-gradient reduction except the
+            # scatter, so the reverse scan is cut in two time halves and the reduction over the late half starts
+            # (on the side stream) while the scan works on the early half.
+            cut = _time_cut(lens[i], spec.periods[i]) if (i == 0 and SPLIT_LAYER0_BWD) else 0
+            if cut:
+                gru_scan_bwd(wg, wc, in_dims[i], hs, gates, d_memory[:, i, :], d_y, spec.periods[i], out=d_act[i],
+                             t_range=(cut, lens[i]), dh_carry=carry[i])
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    gru_param_grads(x_in, hs, gates, d_act[i], wg, wc, gw[4 * i], gw[4 * i + 1], gw[4 * i + 2],
+                                    gw[4 * i + 3], want_dx=False, keep=keep, t_range=(cut, lens[i] - cut))
+                gru_scan_bwd(wg, wc, in_dims[i], hs, gates, d_memory[:, i, :], d_y, spec.periods[i], out=d_act[i],
+                             t_range=(0, cut), dh_carry=carry[i])
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    gru_param_grads(x_in, hs, gates, d_act[i], wg, wc, gw[4 * i], gw[4 * i + 1], gw[4 * i + 2],
+                                    gw[4 * i + 3], want_dx=False, keep=keep, t_range=(0, cut))
+            else:
+                gru_scan_bwd(wg, wc, in_dims[i], hs, gates, d_memory[:, i, :], d_y, spec.periods[i], out=d_act[i])
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    gru_param_grads(x_in, hs, gates, d_act[i], wg, wc, gw[4 * i], gw[4 * i + 1], gw[4 * i + 2],
+                                    gw[4 * i + 3], want_dx=False, keep=keep)
             gru_input_grad(d_act[i], wg, wc, in_dims[i], out=d_x[i])
         d_x0 = d_x[0]
         d_x0[:, spec.last_index, :] += d_last

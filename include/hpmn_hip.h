@@ -197,7 +197,9 @@ typedef struct HpmnGruWgrad {
     float *d_x;
     float *workspace;
     int32_t seq_per_wg;   /* set by the library */
-    int32_t t_begin, t_len;  /* d_x only: steps [t_begin, t_begin+t_len) of every sequence; 0,0: all */
+    int32_t t_begin, t_len;  /* steps [t_begin, t_begin+t_len) of every sequence (the reduction of the parameter
+                              * gradients and d_x alike); 0,0: all.  Lets the caller start the reduction of the
+                              * late steps while the reverse scan is still working on the early ones. */
 } HpmnGruWgrad;
 
 size_t hpmn_gru_param_grads_workspace_bytes(int32_t B, int32_t T, int32_t D, int32_t H);

@@ -284,6 +284,24 @@ def test_time_chunked_pipelined_launches_match_unchunked(dev, tmp_path, monkeypa
     np.testing.assert_allclose(m.flat_grad.cpu().numpy(), g1.cpu().numpy(), rtol=0, atol=1e-6 * float(g1.abs().max()))
 
 
+def test_layer0_backward_split_in_time_matches_unsplit(dev, tmp_path, monkeypatch):
+    """Optional: layer 0's reverse scan as two launches (late half first) with the weight-gradient reduction of
+    the late half started in between (hpmn_gru_param_grads with a time range)."""
+    from hpmn_amd import ops
+    cfg = cfg_industry(H=64, K=3, T=489, V=300)           # 512 steps at layer 0 -> cut at 256
+    p = f32_params(cfg, 95)
+    ids, label = rand_ids(cfg, 4, 96)
+    m = make_model(cfg, tmp_path, p)
+    ti, tl = torch.as_tensor(ids).to(dev), torch.as_tensor(label).to(dev)
+    monkeypatch.setattr(ops, "SPLIT_LAYER0_BWD", False)
+    m.compute_gradients(ti, tl, keep_prob=1.0)
+    g0 = m.flat_grad.clone()
+    monkeypatch.setattr(ops, "SPLIT_LAYER0_BWD", True)
+    assert ops._time_cut(512, 2) == 256
+    m.compute_gradients(ti, tl, keep_prob=1.0)
+    np.testing.assert_allclose(m.flat_grad.cpu().numpy(), g0.cpu().numpy(), rtol=0, atol=2e-6 * float(g0.abs().max()))
+
+
 def test_fused_forward_matches_the_two_kernel_forward(dev, tmp_path, monkeypatch):
     """hpmn_gru_fused_fwd (projection wave + scan wave per sequence, LDS ring hand-over) against
     hpmn_gru_input_proj + hpmn_gru_scan_fwd: same saved states, gates and gradients up to the summation
