@@ -10,7 +10,7 @@ import os
 from typing import Optional
 
 HPMN_MAX_LAYERS = 12
-HPMN_ABI_VERSION = 1
+HPMN_ABI_VERSION = 2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libhpmn_hip.so")
@@ -78,6 +78,7 @@ class HpmnReadDesc(C.Structure):
         ("off_gamma", C.c_int32), ("off_beta", C.c_int32),
         ("off_fc", C.c_int32 * 6),
         ("n_params", C.c_int32),
+        ("dropout_seed", C.c_uint64),
     ]
 
 

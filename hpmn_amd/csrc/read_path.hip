@@ -27,6 +27,23 @@ constexpr int MAXHOP = 4;
 
 __device__ __forceinline__ float elu(float x) { return x > 0.f ? x : __expf(x) - 1.f; }
 
+// Dropout keep factor (0 or 1) of unit j of sample b in head layer `layer`: the caller's mask when one is
+// given, else a counter-based draw -- splitmix64 of (seed, layer, b, j) -- so forward and backward of the
+// same launch see the same mask without materialising it (saves six framework launches per step).
+__device__ __forceinline__ float keep_factor(const float *mask, uint64_t seed, int layer, long b, int j, int width,
+                                             float keep_prob) {
+    if (mask != nullptr) return mask[b * width + j];
+    if (seed == 0) return 1.f;
+    // distinct odd multipliers per coordinate (the caller's seed is itself a mixed value, not a counter)
+    uint64_t z = seed + (uint64_t)(b + 1) * 0x9E3779B97F4A7C15ull + (uint64_t)(j + 1) * 0xC2B2AE3D27D4EB4Full +
+                 (uint64_t)layer * 0xD1B54A32D192ED03ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    const float u = (float)(z >> 40) * (1.0f / 16777216.0f);          // [0, 1)
+    return u < keep_prob ? 1.f : 0.f;
+}
+
 // Y[r][n] = act(b[n] + sum_i X[r][i] W[i][n]) for r < R, n < N.  X, Y in LDS; W [I,N] row-major in
 // global (coalesced over n).  ACT: 0 none, 1 relu, 2 elu.
 // Register blocking: a work item = (column n, block of RB rows) carries RB accumulators, so one
@@ -478,14 +495,17 @@ __device__ void read_forward_tile(const HpmnReadDesc &d, const float *P, const R
     __syncthreads();
     dense_fwd<2>(s.rep, H + D0, R, H + D0, P + d.off_fc[0], P + d.off_fc[1], F1, s.h1, F1);
     __syncthreads();
-    if (mask1 != nullptr) {
-        for (int o = tid; o < R * F1; o += RT) s.h1[o] *= mask1[(b0 + o / F1) * F1 + o % F1] / keep_prob;
+    const bool drop = mask1 != nullptr || mask2 != nullptr || (d.dropout_seed != 0 && keep_prob < 1.f);
+    if (drop) {
+        for (int o = tid; o < R * F1; o += RT)
+            s.h1[o] *= keep_factor(mask1, d.dropout_seed, 1, b0 + o / F1, o % F1, F1, keep_prob) / keep_prob;
         __syncthreads();
     }
     dense_fwd<2>(s.h1, F1, R, F1, P + d.off_fc[2], P + d.off_fc[3], F2, s.h2, F2);
     __syncthreads();
-    if (mask2 != nullptr) {
-        for (int o = tid; o < R * F2; o += RT) s.h2[o] *= mask2[(b0 + o / F2) * F2 + o % F2] / keep_prob;
+    if (drop) {
+        for (int o = tid; o < R * F2; o += RT)
+            s.h2[o] *= keep_factor(mask2, d.dropout_seed, 2, b0 + o / F2, o % F2, F2, keep_prob) / keep_prob;
         __syncthreads();
     }
     dense_fwd<0>(s.h2, F2, R, F2, P + d.off_fc[4], P + d.off_fc[5], 1, s.t3, 1);
@@ -547,6 +567,7 @@ __global__ __launch_bounds__(RT) void read_fwd_bwd_kernel(const HpmnReadDesc d, 
     load_tile_inputs(d, s, memory, last, b0, R);
     float *cov = s.t3 + 32;
     read_forward_tile(d, P, s, R, mask1, mask2, keep_prob, b0, cov);
+    const bool drop = mask1 != nullptr || mask2 != nullptr || (d.dropout_seed != 0 && keep_prob < 1.f);
 
     // ---- loss and d logit -------------------------------------------------------------------
     float *dlg = s.t3 + 48;       // [R]
@@ -572,7 +593,7 @@ __global__ __launch_bounds__(RT) void read_fwd_bwd_kernel(const HpmnReadDesc d, 
     // through dropout2 and elu2: h2 = elu(a2) * mask/keep.  elu'(a) = a>0 ? 1 : elu(a)+1; recover from h2.
     for (int o = tid; o < R * F2; o += RT) {
         float mk = 1.f;
-        if (mask2 != nullptr) mk = mask2[(b0 + o / F2) * F2 + o % F2] / keep_prob;
+        if (drop) mk = keep_factor(mask2, d.dropout_seed, 2, b0 + o / F2, o % F2, F2, keep_prob) / keep_prob;
         const float hv = mk != 0.f ? s.h2[o] / mk : 0.f;                    // elu(a2); irrelevant where mask==0
         s.t2[o] = s.t2[o] * mk * (hv > 0.f ? 1.f : hv + 1.f);
     }
@@ -582,7 +603,7 @@ __global__ __launch_bounds__(RT) void read_fwd_bwd_kernel(const HpmnReadDesc d, 
     __syncthreads();
     for (int o = tid; o < R * F1; o += RT) {
         float mk = 1.f;
-        if (mask1 != nullptr) mk = mask1[(b0 + o / F1) * F1 + o % F1] / keep_prob;
+        if (drop) mk = keep_factor(mask1, d.dropout_seed, 1, b0 + o / F1, o % F1, F1, keep_prob) / keep_prob;
         const float hv = mk != 0.f ? s.h1[o] / mk : 0.f;
         s.t1[o] = s.t1[o] * mk * (hv > 0.f ? 1.f : hv + 1.f);
     }

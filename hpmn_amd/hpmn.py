@@ -34,6 +34,17 @@ def _glorot_uniform_(t: torch.Tensor, gen: torch.Generator):
     t.uniform_(-lim, lim, generator=gen)
 
 
+def _splitmix64(x: int) -> int:
+    """One splitmix64 step: a well-mixed 64-bit value per counter value.  The per-step dropout seed must not be
+    an arithmetic progression: the kernel adds sample/unit offsets to it, and with a linear seed the mask of
+    (step, sample) would recur as that of (step-1, sample+4) -- always on a sample of the same label parity in
+    alternating pos/neg data, which is a label leak the head learns within 50 steps."""
+    x = (x + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    return x ^ (x >> 31)
+
+
 def device_auc(pred: torch.Tensor, label: torch.Tensor) -> torch.Tensor:
     """ROC AUC = (sum of the positives' mid-ranks - n1 (n1 + 1) / 2) / (n1 n0), ties sharing their average
     rank -- the Mann-Whitney form of the trapezoidal area sklearn.metrics.roc_auc_score integrates."""
@@ -136,6 +147,7 @@ class Hpmn_Basic(object):
         assert self.user_num_layers <= len(self.user_layers)     # code/hpmn.py:115
         self.rank, self.world = dist.rank_world()
         self.table_exchange_chunks = 4
+        self._dropout_base, self._dropout_step = (int(seed or 0) * 0x632BE59BD9B4E019 + 0x1234567) & (2 ** 63 - 1), 0
         self._save_path = None
         self._datasets: Dict[int, _DeviceDataset] = {}
         self.spec = self._make_spec()
@@ -269,11 +281,13 @@ class Hpmn_Basic(object):
         emb = self.params["Embedding/emb_mtx"]
         weights = self._gru_weights()
         memory, last, saved = ops.scan_forward_train(self.spec, ids, emb, weights)
+        seed = 0
         if masks is None and keep_prob < 1.0:
-            masks = ((torch.rand(B, 200, device=self.device) < keep_prob).float(),
-                     (torch.rand(B, 80, device=self.device) < keep_prob).float())
+            # masks are drawn inside the read kernel (counter-based): a fresh 64-bit seed per step and rank
+            self._dropout_step += 1
+            seed = _splitmix64(_splitmix64(self._dropout_base + self._dropout_step) ^ (self.rank + 1)) | 1
         out = ops.read_fwd_bwd(self._read_desc, self._read_params, self._read_grads, memory, last, label, masks,
-                               keep_prob, 1.0 / float(global_batch), self.memory_reg)
+                               keep_prob, 1.0 / float(global_batch), self.memory_reg, dropout_seed=seed)
         grad_out = [self.grads["Embedding/emb_mtx"]] + [self.grads[n] for names in self._gru_names for n in names]
         pending = ops.scan_backward(self.spec, ids, saved, weights, out["d_memory"], out["d_last"], grad_out,
                                     defer_join=defer_join and not self.l2_reg)

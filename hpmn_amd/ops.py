@@ -598,11 +598,15 @@ def read_fwd(desc, params, memory, last, want_logit=False, want_att=False):
     return dict(prediction=pred, logit=logit, user_weights=att, memory_loss=mem_loss[0], memory=memory)
 
 
-def read_fwd_bwd(desc, params, d_params, memory, last, label, masks, keep_prob, inv_global_batch, memory_reg):
-    """hpmn_read_fwd_bwd: forward + loss + backward of the read path; accumulates into d_params."""
+def read_fwd_bwd(desc, params, d_params, memory, last, label, masks, keep_prob, inv_global_batch, memory_reg,
+                 dropout_seed: int = 0):
+    """hpmn_read_fwd_bwd: forward + loss + backward of the read path; accumulates into d_params.
+    ``masks`` = (mask1 [B,200], mask2 [B,80]) or None; with None and keep_prob < 1 a non-zero ``dropout_seed``
+    makes the kernel draw the masks itself."""
     _chk_f32(params, d_params, memory, last)
     B, K, H = memory.shape
     desc.B = B
+    desc.dropout_seed = int(dropout_seed) & 0xFFFFFFFFFFFFFFFF
     dev = memory.device
     assert label.dtype == torch.int32 and label.is_contiguous()
     pred = torch.empty(B, device=dev)

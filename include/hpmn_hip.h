@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define HPMN_ABI_VERSION 1
+#define HPMN_ABI_VERSION 2
 #define HPMN_MAX_LAYERS 12
 
 enum {
@@ -261,6 +261,10 @@ typedef struct HpmnReadDesc {
     int32_t off_gamma, off_beta;
     int32_t off_fc[6];
     int32_t n_params;
+    /* Dropout masks generated IN the kernel (hpmn_read_fwd_bwd with mask1 == mask2 == NULL, keep_prob < 1 and
+     * dropout_seed != 0): unit j of sample b of layer l is kept iff a splitmix64 hash of (seed, l, b, j) maps
+     * below keep_prob.  Callers that need TF-reproducible or externally supplied masks pass mask1/mask2. */
+    uint64_t dropout_seed;
 } HpmnReadDesc;
 
 size_t hpmn_read_workspace_bytes(const HpmnReadDesc *desc);

@@ -357,6 +357,50 @@ def test_dropout_masks_are_honoured(dev, tmp_path):
 
 
 # ------------------------------------------------------------------------------- optimiser + steps
+def test_in_kernel_dropout_is_bernoulli_and_consistent(dev, tmp_path):
+    """Without explicit masks the read kernel draws them itself (counter-based hash of seed / layer / sample /
+    unit): the keep rate must be keep_prob, masks must differ between steps, and forward and backward of one
+    launch must see the SAME mask -- checked through the gradient of fc3's kernel, which is exactly
+    sum_b dlogit_b * h2_b and vanishes on the columns a mask zeroed for every sample."""
+    cfg = cfg_amazon(K=3, T=100, V=120)
+    p = f32_params(cfg, 71)
+    m = make_model(cfg, tmp_path, p)
+    ids, label = rand_ids(cfg, 1, 72)
+    ti, tl = torch.as_tensor(ids).to(dev), torch.as_tensor(label).to(dev)
+    zero_sets, kept = [], 0
+    for _ in range(40):
+        m.compute_gradients(ti, tl, keep_prob=0.5)
+        g = m.grads["output/fc3/kernel"].cpu().numpy().reshape(-1)        # [80]: one sample -> zero iff dropped
+        zero_sets.append(tuple(np.flatnonzero(g == 0.0)))
+        kept += int((g != 0.0).sum())
+    rate = kept / (40 * 80)
+    assert 0.42 < rate < 0.58, rate
+    assert len(set(zero_sets)) > 30                      # a fresh mask nearly every step
+    # keep_prob == 1 -> no dropout at all
+    m.compute_gradients(ti, tl, keep_prob=1.0)
+    assert int((m.grads["output/fc3/kernel"] == 0).sum()) == 0
+
+
+def test_in_kernel_dropout_does_not_leak_the_label(dev, tmp_path):
+    """Regression: with a per-step seed that was an arithmetic progression, the mask of (step, sample) recurred
+    as that of (step-1, sample+4) -- always on a sample of the same parity -- and on data whose labels alternate
+    1,0,1,0 (the XLong loader's layout, code/data_loader.py:75-80) the head learned the label from the mask:
+    training loss 0.13 after 60 steps, test AUC 0.50.  Pure-noise inputs with alternating labels must stay at
+    chance."""
+    cfg = cfg_amazon(H=32, K=3, T=20, V=5000)
+    m = make_model(cfg, tmp_path, None, lr=0.003)
+    rng = np.random.default_rng(77)
+    B = 128
+    label = torch.as_tensor(np.tile([1, 0], B // 2).astype(np.int32)).to(dev)
+    tail = []
+    for step in range(120):
+        ids = torch.as_tensor(rng.integers(1, 5000, size=(B, 20, 3)).astype(np.int32)).to(dev)
+        _, ce = m.train_step(ids, label, keep_prob=0.5)
+        if step >= 100:
+            tail.append(float(ce))
+    assert np.mean(tail) > 0.62, np.mean(tail)       # log 2 = 0.693; the leak drove this below 0.2
+
+
 def test_adam_kernel_matches_tf_form(dev):
     from hpmn_amd import ops
     rng = np.random.default_rng(61)
