@@ -84,7 +84,7 @@ class _DeviceDataset:
     code/data_loader.py:283-296 / code/hpmn.py:474-481; batches are slices in stored order,
     exactly the batches ``DataLoader`` would yield."""
 
-    def __init__(self, dataset, device, industry: bool):
+    def __init__(self, dataset, device, industry: bool, feature_size: Optional[int] = None):
         if isinstance(dataset, dict):
             ids, label = dataset["ids"], dataset["label"]
             length = dataset.get("length")
@@ -101,6 +101,12 @@ class _DeviceDataset:
             ids = np.asarray([s[1] for s in dataset], dtype=np.int32)
             length = np.asarray([s[2] for s in dataset], dtype=np.int32)
         self.n = int(ids.shape[0])
+        # tf.nn.embedding_lookup on the CPU raises on an out-of-range id; the kernels index the table unchecked,
+        # so the range is checked once here, on the host, when the dataset is staged
+        if feature_size is not None and self.n:
+            lo, hi = int(np.min(ids)), int(np.max(ids))
+            if lo < 0 or hi >= feature_size:
+                raise ValueError("dataset ids span [%d, %d] but the embedding table has %d rows" % (lo, hi, feature_size))
         self.ids = torch.as_tensor(np.ascontiguousarray(ids, dtype=np.int32)).to(device)
         self.label_np = np.asarray(label, dtype=np.int32)
         self.label = torch.as_tensor(self.label_np).to(device)
@@ -346,7 +352,7 @@ class Hpmn_Basic(object):
         key = id(dataset)
         ds = self._datasets.get(key)
         if ds is None:
-            ds = self._datasets[key] = _DeviceDataset(dataset, self.device, self.industry)
+            ds = self._datasets[key] = _DeviceDataset(dataset, self.device, self.industry, getattr(self, "feature_size", None))
         return ds
 
     # ------------------------------------------------------------------ harness (code/hpmn.py:467-519)

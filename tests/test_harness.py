@@ -117,3 +117,20 @@ def test_device_metrics_match_sklearn_with_ties():
         got_ll = float(device_log_loss(torch.as_tensor(p), torch.as_tensor(y)))
         assert abs(got_auc - roc_auc_score(y, p.astype(np.float64))) < 1e-12
         assert abs(got_ll - log_loss(y, p.astype(np.float64))) < 1e-9
+
+
+def test_out_of_range_ids_are_rejected_when_a_dataset_is_staged():
+    """tf.nn.embedding_lookup raises on an id >= feature_size on the CPU; the kernels index unchecked, so the
+    check happens once on the host when a dataset is moved to the device."""
+    import numpy as np
+    import pytest
+    import torch
+    from hpmn_amd.hpmn import _DeviceDataset
+    ok = dict(ids=np.array([[[0, 4]]], dtype=np.int32), label=np.array([1], dtype=np.int32))
+    _DeviceDataset(ok, torch.device("cpu"), False, feature_size=5)
+    bad = dict(ids=np.array([[[0, 5]]], dtype=np.int32), label=np.array([1], dtype=np.int32))
+    with pytest.raises(ValueError):
+        _DeviceDataset(bad, torch.device("cpu"), False, feature_size=5)
+    neg = dict(ids=np.array([[[-1, 2]]], dtype=np.int32), label=np.array([1], dtype=np.int32))
+    with pytest.raises(ValueError):
+        _DeviceDataset(neg, torch.device("cpu"), False, feature_size=5)
