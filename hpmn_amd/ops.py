@@ -379,8 +379,11 @@ def scan_forward_train(spec: ScanSpec, ids, emb, weights: Sequence[torch.Tensor]
     memory = torch.empty(B, K, H, **f32)
     in_dims = [spec.D0] + [H] * (K - 1)
     x0 = torch.empty(B, lens[0], spec.D0, **f32)
-    fused = [PIPELINE_CHUNKS <= 1 and fused_fwd_supported(H, in_dims[i], i == 0) and (i > 0 or 64 % spec.E == 0)
-             for i in range(K)]
+    # the fused layer spends a second wave per sequence on a SIMD that would otherwise idle: a win while
+    # 2 B waves still find (about) a SIMD each -- measured at C3: +3.7 % at B=500, -6.6 % at B=750 / 1000
+    room = 2 * B <= 1.1 * 4 * torch.cuda.get_device_properties(dev).multi_processor_count
+    fused = [room and PIPELINE_CHUNKS <= 1 and fused_fwd_supported(H, in_dims[i], i == 0) and
+             (i > 0 or 64 % spec.E == 0) for i in range(K)]
     xp = [None if fused[i] else torch.empty(B, lens[i], 3 * H, **f32) for i in range(K)]
     hs = [torch.empty(B, lens[i] + 1, H, **f32) for i in range(K)]
     gates = [torch.empty(B, lens[i], 3 * H, **f32) for i in range(K)]
