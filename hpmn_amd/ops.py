@@ -1,12 +1,13 @@
 """Host-side operators over the C ABI of libhpmn_hip.so.
 
-Everything numerical on the hot path runs in the HIP library; PyTorch supplies device
-memory, the current stream, autograd plumbing and the plain library GEMMs that turn the
-reverse scan's pre-activation gradients into weight/input gradients.
+Everything numerical on the hot path runs in the HIP library; PyTorch supplies device memory, streams
+and events.  There is no autograd here: a training step is a fixed sequence of library calls
+(``scan_forward_train`` -> ``read_fwd_bwd`` -> ``scan_backward``), each wrapper below is one entry
+point of include/hpmn_hip.h.
 
-Reference being replaced: ``Hpmn.embedding`` + ``Hpmn_Basic.build_memory`` of
-/root/reference/code/hpmn.py:414-430, :113-129 (the covariance loss of :130 and the read
-path stay in ``hpmn_amd.model``).
+Reference being replaced: ``Hpmn.embedding`` + ``Hpmn_Basic.build_memory`` (code/hpmn.py:414-430,
+:113-129), the read path ``get_covreg`` / ``query_memory`` / ``attention`` / ``build_fc_net``
+(:161-207) and TF's autodiff of all of it.
 """
 from __future__ import annotations
 
