@@ -156,8 +156,7 @@ def test_batch_composition_independence_and_determinism_full_xlong_shape(dev, tm
     assert torch.equal(a["logit"], b["logit"]) and torch.equal(a["memory"], b["memory"])
     assert torch.equal(a["memory"][7], a["memory"][3])
     sub = m.forward_inference(t[[3, 250, 499]].contiguous())
-    # the HIP scan is batch-independent bit for bit; the read path tiles samples in pairs, so a sample's
-    # partner (and with it the MFMA tile contents) changes with the batch: a (tiny) tolerance on the logits only
+    # the scan is batch-independent bit for bit (asserted); the logits are only required to agree to 2e-5
     assert torch.equal(sub["memory"], a["memory"][[3, 250, 499]])
     np.testing.assert_allclose(sub["logit"].cpu().numpy(), a["logit"][[3, 250, 499]].cpu().numpy(), atol=2e-5)
     want = O.forward(cfg, p, ids[[3, 250, 499]])
