@@ -312,10 +312,13 @@ class Hpmn_Basic(object):
         """sess.run(train_step) of code/hpmn.py:482: forward, BPTT, clip, dense TF Adam."""
         out, ce = self.compute_gradients(ids, label, keep_prob, masks, global_batch, defer_join=True)
         pending = out.pop("pending", None)
-        if pending is None:
+        if self.l2_reg:
+            # (same on every rank) the l2 term touched the whole buffer after the join: one exchange, one update
             dist.allreduce_sum_(self.flat_grad)                 # RCCL sum; clip happens after (8e)
             self.apply_gradients()
             return out, ce
+        # From here on EVERY rank issues the same collectives in the same order, whatever its shard looked like
+        # (a rank whose slice of a short last batch is empty has pending == None and a zero gradient).
         # The table gradient is final once the scatter is enqueued, the GRU weight gradients of layer 0
         # are still being reduced on the side stream: exchange + update the table (99.5 % of the
         # parameters, HBM-bound) underneath them, then join and do the dense rest.
@@ -330,7 +333,8 @@ class Hpmn_Basic(object):
                 self.apply_gradients(a, b, advance=(i == 0))
         else:
             self.apply_gradients(0, n_emb, advance=True)
-        pending.join()
+        if pending is not None:
+            pending.join()
         dist.allreduce_sum_(self.flat_grad[n_emb:])
         self.apply_gradients(n_emb, self.flat_param.numel(), advance=False)
         return out, ce

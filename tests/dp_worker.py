@@ -33,6 +33,10 @@ def run(m, tr, te, steps=5, batch=50):
         step += 1
         if step == steps:
             break
+    # a "last batch" of ONE sample: with two ranks one shard is empty, and that rank must still take part in
+    # every collective of the step
+    a, b = dist.shard_bounds(0, 1, m.rank, m.world)
+    m.train_step(ds.ids[a:b], ds.label[a:b], keep_prob=1.0, global_batch=1)
     auc, ll, mem = m.eval(te, 64)
     out = {k: v.detach().cpu().numpy() for k, v in m.params.items()}
     out["__eval__"] = np.array([auc, ll, mem])
