@@ -30,8 +30,8 @@ __device__ __forceinline__ float elu(float x) { return x > 0.f ? x : __expf(x) -
 // Dropout keep factor (0 or 1) of unit j of sample b in head layer `layer`: the caller's mask when one is
 // given, else a counter-based draw -- splitmix64 of (seed, layer, b, j) -- so forward and backward of the
 // same launch see the same mask without materialising it (saves six framework launches per step).
-__device__ __forceinline__ float keep_factor(const float *mask, uint64_t seed, int layer, long b, int j, int width,
-                                             float keep_prob) {
+__device__ __noinline__ float keep_factor(const float *mask, uint64_t seed, int layer, long b, int j, int width,
+                                          float keep_prob) {
     if (mask != nullptr) return mask[b * width + j];
     if (seed == 0) return 1.f;
     // distinct odd multipliers per coordinate (the caller's seed is itself a mixed value, not a counter)
@@ -363,6 +363,8 @@ struct ReadSmem {
     float *ccov;     // [RS*K*K]      off-diagonal covariance
     float *cnorm;    // [RS]          Frobenius norms
     float *zero;     // [max(H, D0)] zeros (bias of the bias-free products)
+    float *mk1;      // [RS][F1]  dropout factor mask/keep_prob of the tile (training)
+    float *mk2;      // [RS][F2]
 };
 
 __host__ __device__ inline size_t read_smem_floats(int K, int H, int D0, int hop, bool train) {
@@ -373,6 +375,7 @@ __host__ __device__ inline size_t read_smem_floats(int K, int H, int D0, int hop
     else n += 64;
     n += RK + RK * K + RS + 16;
     n += (size_t)(H > D0 ? H : D0) + 4;
+    n += (size_t)RS * (F1 + F2) + 8;
     return n + 64;
 }
 
@@ -396,6 +399,8 @@ __device__ inline void carve(ReadSmem &s, float *base, int K, int H, int D0, int
     s.cnorm = take(RS);
     s.zero = take((size_t)(H > D0 ? H : D0));
     for (int o = threadIdx.x; o < (H > D0 ? H : D0); o += RT) s.zero[o] = 0.f;   // visible after the caller's first barrier
+    s.mk1 = take((size_t)RS * F1);
+    s.mk2 = take((size_t)RS * F2);
     if (train) {
         s.dmem = take((size_t)RK * H);
         s.t1 = take((size_t)RK * A1 > (size_t)RS * F1 ? (size_t)RK * A1 : (size_t)RS * F1);
@@ -497,15 +502,22 @@ __device__ void read_forward_tile(const HpmnReadDesc &d, const float *P, const R
     __syncthreads();
     const bool drop = mask1 != nullptr || mask2 != nullptr || (d.dropout_seed != 0 && keep_prob < 1.f);
     if (drop) {
+        // the tile's dropout factors, once, into LDS (the hash is 64-bit integer math: kept out of line and out
+        // of the layer loops -- inlined at its four use sites it doubled the kernel's registers and spilled)
+#pragma unroll 1
         for (int o = tid; o < R * F1; o += RT)
-            s.h1[o] *= keep_factor(mask1, d.dropout_seed, 1, b0 + o / F1, o % F1, F1, keep_prob) / keep_prob;
+            s.mk1[o] = keep_factor(mask1, d.dropout_seed, 1, b0 + o / F1, o % F1, F1, keep_prob) / keep_prob;
+#pragma unroll 1
+        for (int o = tid; o < R * F2; o += RT)
+            s.mk2[o] = keep_factor(mask2, d.dropout_seed, 2, b0 + o / F2, o % F2, F2, keep_prob) / keep_prob;
+        __syncthreads();
+        for (int o = tid; o < R * F1; o += RT) s.h1[o] *= s.mk1[o];
         __syncthreads();
     }
     dense_fwd<2>(s.h1, F1, R, F1, P + d.off_fc[2], P + d.off_fc[3], F2, s.h2, F2);
     __syncthreads();
     if (drop) {
-        for (int o = tid; o < R * F2; o += RT)
-            s.h2[o] *= keep_factor(mask2, d.dropout_seed, 2, b0 + o / F2, o % F2, F2, keep_prob) / keep_prob;
+        for (int o = tid; o < R * F2; o += RT) s.h2[o] *= s.mk2[o];
         __syncthreads();
     }
     dense_fwd<0>(s.h2, F2, R, F2, P + d.off_fc[4], P + d.off_fc[5], 1, s.t3, 1);
@@ -593,7 +605,7 @@ __global__ __launch_bounds__(RT) void read_fwd_bwd_kernel(const HpmnReadDesc d, 
     // through dropout2 and elu2: h2 = elu(a2) * mask/keep.  elu'(a) = a>0 ? 1 : elu(a)+1; recover from h2.
     for (int o = tid; o < R * F2; o += RT) {
         float mk = 1.f;
-        if (drop) mk = keep_factor(mask2, d.dropout_seed, 2, b0 + o / F2, o % F2, F2, keep_prob) / keep_prob;
+        if (drop) mk = s.mk2[o];
         const float hv = mk != 0.f ? s.h2[o] / mk : 0.f;                    // elu(a2); irrelevant where mask==0
         s.t2[o] = s.t2[o] * mk * (hv > 0.f ? 1.f : hv + 1.f);
     }
@@ -603,7 +615,7 @@ __global__ __launch_bounds__(RT) void read_fwd_bwd_kernel(const HpmnReadDesc d, 
     __syncthreads();
     for (int o = tid; o < R * F1; o += RT) {
         float mk = 1.f;
-        if (drop) mk = keep_factor(mask1, d.dropout_seed, 1, b0 + o / F1, o % F1, F1, keep_prob) / keep_prob;
+        if (drop) mk = s.mk1[o];
         const float hv = mk != 0.f ? s.h1[o] / mk : 0.f;
         s.t1[o] = s.t1[o] * mk * (hv > 0.f ? 1.f : hv + 1.f);
     }
@@ -747,18 +759,33 @@ __global__ __launch_bounds__(RT) void read_fwd_bwd_kernel(const HpmnReadDesc d, 
     for (int o = tid; o < RK * H; o += RT) d_memory[b0 * K * H + o] = s.dmem[o];
 }
 
-// grad[e] += sum over tiles of slabs[w][e]
-__global__ __launch_bounds__(256) void read_reduce_kernel(const float *__restrict__ slabs, int ntile, int n, float *grad) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n) return;
-    float s0 = 0.f, s1 = 0.f;
-    int w = 0;
-    for (; w + 1 < ntile; w += 2) {
-        s0 += slabs[(long)w * n + e];
-        s1 += slabs[(long)(w + 1) * n + e];
+// grad[e] += sum over tiles of slabs[w][e].  A block owns 32 consecutive elements; its 8 groups of 32 lanes
+// each sum every 8th slab (4 independent partial sums, 128-byte coalesced reads) and are combined through LDS
+// in a fixed order (deterministic) -- same scheme as wgrad_reduce_kernel: one thread walking 250 slabs per
+// element was latency-bound.
+constexpr int RRED_G = 8;
+__global__ __launch_bounds__(32 * RRED_G) void read_reduce_kernel(const float *__restrict__ slabs, int ntile, int n,
+                                                                  float *grad) {
+    __shared__ float part[RRED_G][32];
+    const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int e = blockIdx.x * 32 + c;
+    const int ec = e < n ? e : n - 1;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int w = g;
+    for (; w + 3 * RRED_G < ntile; w += 4 * RRED_G) {
+        s0 += slabs[(long)w * n + ec];
+        s1 += slabs[(long)(w + RRED_G) * n + ec];
+        s2 += slabs[(long)(w + 2 * RRED_G) * n + ec];
+        s3 += slabs[(long)(w + 3 * RRED_G) * n + ec];
     }
-    if (w < ntile) s0 += slabs[(long)w * n + e];
-    grad[e] += s0 + s1;
+    for (; w < ntile; w += RRED_G) s0 += slabs[(long)w * n + ec];
+    part[g][c] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (g != 0 || e >= n) return;
+    float tot = part[0][c];
+#pragma unroll
+    for (int k = 1; k < RRED_G; ++k) tot += part[k][c];
+    grad[e] += tot;
 }
 
 static bool read_desc_ok(const HpmnReadDesc &d) {
@@ -797,7 +824,7 @@ int read_fwd_bwd_launch(const HpmnReadDesc &d, const float *P, const float *memo
                        keep_prob, inv_global_batch, memory_reg, pred, loss_out, d_memory, d_last, workspace);
     int rc = check_launch();
     if (rc != HPMN_OK) return rc;
-    hipLaunchKernelGGL(read_reduce_kernel, dim3((unsigned)((d.n_params + 255) / 256)), dim3(256), 0, st, workspace,
+    hipLaunchKernelGGL(read_reduce_kernel, dim3((unsigned)((d.n_params + 31) / 32)), dim3(32 * RRED_G), 0, st, workspace,
                        (int)grid, d.n_params, d_params);
     return check_launch();
 }
