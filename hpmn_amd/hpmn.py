@@ -65,6 +65,7 @@ def device_auc(pred: torch.Tensor, label: torch.Tensor) -> torch.Tensor:
     ys = y[order]
     n1 = ys.sum()
     n0 = n - n1
+    # (one class only: n1 * n0 == 0 -> NaN here; eval() turns that into sklearn's ValueError on the host)
     return ((rank * ys).sum() - n1 * (n1 + 1) / 2) / (n1 * n0)
 
 
@@ -155,7 +156,7 @@ class Hpmn_Basic(object):
         self.table_exchange_chunks = 4
         self._dropout_base, self._dropout_step = (int(seed or 0) * 0x632BE59BD9B4E019 + 0x1234567) & (2 ** 63 - 1), 0
         self._save_path = None
-        self._datasets: Dict[int, _DeviceDataset] = {}
+        self._datasets: Dict[int, Tuple[object, _DeviceDataset]] = {}
         self.spec = self._make_spec()
         self._build_variables(emb_initializer, seed)
         self.adam_t = 0
@@ -303,6 +304,10 @@ class Hpmn_Basic(object):
             # every variable, so each adds 1/world of it before the sum all-reduce
             self.flat_grad.add_(self.flat_param, alpha=self.l2_reg / self.world)
         ce = out["log_loss_sum"] / float(global_batch) + self.memory_reg * out["memory_loss"]
+        if self.l2_reg:
+            # cross_entropy includes sum_v l2_reg * tf.nn.l2_loss(v) = l2_reg/2 * |v|^2 (code/hpmn.py:203-205);
+            # every rank holds every variable, so each reports 1/world of it like the other (sharded) terms
+            ce = ce + (0.5 * self.l2_reg / self.world) * sum((v * v).sum() for v in self.params.values())
         out["memory"] = memory
         return out, ce
 
@@ -353,11 +358,33 @@ class Hpmn_Basic(object):
 
     # ------------------------------------------------------------------ datasets
     def _dev(self, dataset) -> _DeviceDataset:
+        """Device-resident copy of ``dataset``, staged once per object.  The cache entry keeps a reference to the
+        dataset it was built from and is only used for that very object (an ``id`` can be recycled once a
+        temporary dataset is collected).  A list mutated in place after staging (e.g. shuffled between epochs)
+        must be re-staged with ``invalidate_dataset``; at most ``max_cached_datasets`` stay resident."""
         key = id(dataset)
-        ds = self._datasets.get(key)
-        if ds is None:
-            ds = self._datasets[key] = _DeviceDataset(dataset, self.device, self.industry, getattr(self, "feature_size", None))
+        hit = self._datasets.get(key)
+        if hit is not None and hit[0] is dataset:
+            return hit[1]
+        ds = _DeviceDataset(dataset, self.device, self.industry, getattr(self, "feature_size", None))
+        while len(self._datasets) >= self.max_cached_datasets:
+            # evict the oldest entry that is not the model's own train / test set
+            victim = next((k for k, (d, _) in self._datasets.items()
+                           if d is not self.trainset and d is not self.testset), None)
+            if victim is None:
+                break
+            del self._datasets[victim]
+        self._datasets[key] = (dataset, ds)
         return ds
+
+    max_cached_datasets = 8
+
+    def invalidate_dataset(self, dataset=None):
+        """Drop the device copy of ``dataset`` (all copies when None): the next use re-stages it."""
+        if dataset is None:
+            self._datasets.clear()
+        else:
+            self._datasets.pop(id(dataset), None)
 
     # ------------------------------------------------------------------ harness (code/hpmn.py:467-519)
     def train(self, epochs, batchsize):
@@ -373,7 +400,7 @@ class Hpmn_Basic(object):
                     result = list(self.eval(self.trainset, 4 * batchsize))
                     result += list(self.eval(self.testset, 4 * batchsize))
                     self.log(step, result)
-                    if result[3] <= best:
+                    if not (result[3] > best):
                         count += 1
                         if count > 3:
                             return best
@@ -403,10 +430,16 @@ class Hpmn_Basic(object):
         loss = device_log_loss(preds, ds.label)
         mem_loss = torch.cat(mem_losses).mean().double()
         auc, loss, mem_loss = torch.stack([auc, loss, mem_loss]).tolist()
+        if math.isnan(auc):
+            # sklearn.metrics.roc_auc_score (code/hpmn.py:516) raises this; a NaN would also poison train()'s
+            # early-stopping comparisons silently
+            raise ValueError("Only one class present in y_true. ROC AUC score is not defined in that case.")
         return auc, loss, mem_loss
 
     def get_weights(self):
         """code/hpmn.py:521-560: first-hop attention weights over train+test at batch 512."""
+        if self.rank != 0:          # unsharded forward + file writes: one rank does it (like save_model / log)
+            return
         weights, lengths, labels = [], [], []
         for dataset in (self.trainset, self.testset):
             ds = self._dev(dataset)
@@ -482,6 +515,8 @@ class Hpmn_Industry(Hpmn_Basic):
 
     def get_weights(self):
         """code/hpmn.py:375-410."""
+        if self.rank != 0:
+            return
         weights, ids = [], []
         for dataset in (self.trainset, self.testset):
             ds = self._dev(dataset)

@@ -44,8 +44,15 @@ def run(m, tr, te, steps=5, batch=50):
 
 
 def main():
-    td.init_process_group("gloo")
-    torch.cuda.set_device(0)
+    # HPMN_DP_BACKEND=nccl: one GPU per rank over RCCL (needs >= 2 devices); default: gloo, both ranks on cuda:0
+    backend = os.environ.get("HPMN_DP_BACKEND", "gloo")
+    if backend == "nccl":
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        td.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        td.init_process_group("gloo")
+        torch.cuda.set_device(0)
     m, tr, te = build(sys.argv[1] + ".model%d" % td.get_rank())
     assert m.world == 2
     out = run(m, tr, te)

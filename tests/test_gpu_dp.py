@@ -23,10 +23,23 @@ def _free_port():
 
 
 def test_two_rank_training_matches_single_process(tmp_path):
+    _run_two_ranks(tmp_path, "gloo")
+
+
+def test_two_rank_training_over_rccl_matches_single_process(tmp_path):
+    """The same run with one GPU per rank and backend "nccl" (= RCCL over xGMI): the asynchronous chunked table
+    all-reduce, wait() as a stream dependency (not a host block as with gloo), Adam of range i under the reduce
+    of range i+1, against the caching allocator and the side stream.  Needs two devices; the 1-GPU boxes skip."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (RCCL refuses two ranks on one device)")
+    _run_two_ranks(tmp_path, "nccl")
+
+
+def _run_two_ranks(tmp_path, backend):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     out = str(tmp_path / "dp.npz")
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", HPMN_DP_BACKEND=backend)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(HERE, "dp_worker.py"), out]
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)

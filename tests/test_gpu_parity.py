@@ -141,10 +141,11 @@ def test_unsupported_shape_raises(dev):
 
 
 # ------------------------------------------------------------------------------- properties at size
-def test_batch_composition_independence_and_determinism_full_xlong_shape(dev, tmp_path):
-    """At BASELINE's XLong shape (B=500, T=1001, H=64, K=7) the oracle is too slow to run in full;
-    check size-independent properties: a sample's result does not depend on its batch, equal inputs
-    give equal outputs, two runs are bit-identical, and a 3-sample subset matches the oracle."""
+def test_full_xlong_batch_matches_oracle_and_is_batch_independent(dev, tmp_path):
+    """BASELINE's XLong shape in full (B=500, T=1001, H=64, K=7): EVERY sample's memory, logit, prediction and
+    first-hop attention weights against the float64 oracle (~10 s of NumPy), plus the size-independent
+    properties: a sample's result does not depend on its batch, equal inputs give equal outputs, two runs
+    are bit-identical."""
     cfg = cfg_industry(H=64, K=7, T=1001, V=5000)
     p = f32_params(cfg, 21)
     m = make_model(cfg, tmp_path, p)
@@ -159,10 +160,26 @@ def test_batch_composition_independence_and_determinism_full_xlong_shape(dev, tm
     # the scan is batch-independent bit for bit (asserted); the logits are only required to agree to 2e-5
     assert torch.equal(sub["memory"], a["memory"][[3, 250, 499]])
     np.testing.assert_allclose(sub["logit"].cpu().numpy(), a["logit"][[3, 250, 499]].cpu().numpy(), atol=2e-5)
-    want = O.forward(cfg, p, ids[[3, 250, 499]])
-    np.testing.assert_allclose(sub["logit"].cpu().numpy(), want["logit"], atol=TOL)
-    np.testing.assert_allclose(sub["memory"].cpu().numpy(), want["memory"], atol=TOL)
-    assert bool(torch.isfinite(a["logit"]).all())
+    want = O.forward(cfg, p, ids)
+    for k in ("memory", "logit", "prediction", "user_weights"):
+        np.testing.assert_allclose(a[k].cpu().numpy(), want[k], rtol=0, atol=TOL, err_msg=k)
+    # ... and through the training path (saved-state kernels), whole batch
+    label = (want["prediction"] > 0.5).astype(np.int32)
+    out_t, _ = m.compute_gradients(t, torch.as_tensor(label).to(dev), keep_prob=1.0)
+    np.testing.assert_allclose(out_t["memory"].cpu().numpy(), want["memory"], rtol=0, atol=TOL)
+    np.testing.assert_allclose(out_t["prediction"].cpu().numpy(), want["prediction"], rtol=0, atol=TOL)
+
+
+def test_full_taobao_and_amazon_batches_match_oracle(dev, tmp_path):
+    """configs[1] / configs[2] at their reference batch (128) and full length, ragged front padding."""
+    for cfg in (cfg_amazon(K=4, V=4000), O.HpmnConfig(4000, 4, 300, 64, 16, 3, (2, 2, 3, 5, 5, 1), 5, False, 1e-5)):
+        p = f32_params(cfg, 23)
+        ids, label = rand_ids(cfg, 128, 24)
+        want = O.forward(cfg, p, ids, label)
+        m = make_model(cfg, tmp_path, p)
+        out = m.forward_inference(torch.as_tensor(ids).to(dev))
+        for k in ("memory", "logit", "prediction", "user_weights"):
+            np.testing.assert_allclose(out[k].cpu().numpy(), want[k], rtol=0, atol=TOL, err_msg=k)
 
 
 def test_padding_prefix_property_on_device(dev, tmp_path):
@@ -183,6 +200,14 @@ GRAD_CASES = [
     ("industry", cfg_industry(H=64, K=4, T=41, V=150), 4),
     ("industry_h32", cfg_industry(H=32, K=3, T=41, V=150), 3),
     ("industry_h128", cfg_industry(H=128, K=3, T=41, V=150), 3),
+    # the shapes the throughput numbers are quoted on (BASELINE configs[1..4]), not miniatures of them:
+    # C3 -- 1024-step fp32 reverse scan, 7 layers, T=1001 scatter; C4's hidden size at the same length;
+    # C2 -- four id columns (F=4, D0=64: gather + x_out split, 4-column scatter) with periods 2,2,3,5,5;
+    # C1 -- the reference batch of 128 at K=4
+    ("xlong_c3_shape", cfg_industry(H=64, K=7, T=1001, V=2000), 5),
+    ("xlong_c4_h128", cfg_industry(H=128, K=7, T=1001, V=2000), 2),
+    ("taobao_c2_shape", O.HpmnConfig(600, 4, 300, 64, 16, 3, (2, 2, 3, 5, 5, 1), 5, False, 1e-5), 4),
+    ("amazon_c1_b128", cfg_amazon(K=4, V=3000), 128),
 ]
 
 
@@ -256,12 +281,33 @@ def test_online_update_event_by_event_equals_the_batch_scan(dev, tmp_path, H):
             pre = O.HpmnConfig(120, 2, t + 1, H, 16, 3, (2, 2, 5, 1), 3, False, 1e-5)
             want = O.forward(pre, p, ids[:, :t + 1], label)
             np.testing.assert_allclose(store.memory(users).cpu().numpy(), want["memory"], rtol=0, atol=TOL)
-    assert store.count.cpu().tolist() == [T if u in (7, 0, 3, 8, 2) else 0 for u in range(9)]
+    assert store.events().cpu().tolist() == [T if u in (7, 0, 3, 8, 2) else 0 for u in range(9)]
     assert float(store.state[[1, 4, 5, 6]].abs().max()) == 0.0        # untouched users stay untouched
     # scoring a stored user == the batch forward whose last row is the candidate (Hpmn: last = row -1)
     want = O.forward(cfg, p, ids, label)
     got = store.predict(users, t_ids[:, -1, :].contiguous())
     np.testing.assert_allclose(got["logit"].cpu().numpy(), want["logit"], rtol=0, atol=TOL)
+
+
+def test_online_update_industry_graph_prefix_and_query_row(dev, tmp_path):
+    """Hpmn_Industry: 23 all-zero steps in front (state != 0 after them, firing phase shifted by an odd count)
+    and query row -2.  A store fed the 41 real events must land on the batch graph's memory AND logit."""
+    from hpmn_amd.online import OnlineMemory
+    cfg = cfg_industry(H=64, K=4, T=41, V=300)            # 23 + 41 = 64 steps: 64, 32, 16, 8
+    p = f32_params(cfg, 63)
+    ids, label = rand_ids(cfg, 4, 64)
+    m = make_model(cfg, tmp_path, p)
+    store = OnlineMemory(m, n_users=6)
+    assert store.count.cpu().tolist() == [23] * 6 and float(store.state.abs().max()) > 1e-3
+    users = torch.as_tensor([5, 1, 2, 0], dtype=torch.int32, device=dev)
+    t_ids = torch.as_tensor(ids).to(dev)
+    for t in range(cfg.user_maxlen):
+        store.update(users, t_ids[:, t, :].contiguous())
+    want = O.forward(cfg, p, ids, label)
+    np.testing.assert_allclose(store.memory(users).cpu().numpy(), want["memory"], rtol=0, atol=TOL)
+    got = store.predict(users)
+    np.testing.assert_allclose(got["logit"].cpu().numpy(), want["logit"], rtol=0, atol=TOL)
+    assert store.events(users).cpu().tolist() == [41] * 4 and store.events().cpu().tolist()[3:5] == [0, 0]
 
 
 def test_time_chunked_pipelined_launches_match_unchunked(dev, tmp_path, monkeypatch):
@@ -498,3 +544,45 @@ def test_training_learns_planted_signal_and_save_load(dev, tmp_path):
     assert torch.equal(before, m.forward_inference(m._dev(te).ids[:16])["prediction"])
     m.log(5, [auc1, loss1, mem1, auc1, loss1, mem1])
     assert open(str(tmp_path / "m") + "/result.log").read().count("\t") == 6
+
+
+# ------------------------------------------------------------------------------- get_weights (code/hpmn.py:521-560, :375-410)
+def test_get_weights_dumps_first_hop_attention_of_both_classes(dev, tmp_path):
+    """Hpmn.get_weights -> weights.npy / lengths.npy / labels.npy; Hpmn_Industry.get_weights -> weights_new.npy /
+    ids.npy: first-hop attention weights of train+test in stored order at batch 512, checked against the oracle's
+    user_weights."""
+    from hpmn_amd.hpmn import Hpmn, Hpmn_Industry
+    # Hpmn
+    cfg = cfg_amazon(K=3, T=100, V=400)
+    p = f32_params(cfg, 101)
+    ids_tr, lab_tr = rand_ids(cfg, 530, 102)             # > 512: two batches
+    ids_te, lab_te = rand_ids(cfg, 7, 103)
+    mk = lambda ids, lab: [(int(l), x.tolist(), int((x[:, 1] != 0).sum()), [[0, 0]], 1) for x, l in zip(ids, lab)]
+    tr, te = mk(ids_tr, lab_tr), mk(ids_te, lab_te)
+    m = Hpmn(str(tmp_path / "a"), tr, te, cfg.feature_size, 3, 2, 100, 1, 0.003, 32, 16, 3, [2, 2, 5, 5, 1], [1], 3, 1,
+             True, False, verbose=False)
+    m.set_params(p)
+    m.get_weights()
+    w = np.load(str(tmp_path / "a") + "/weights.npy")
+    want = O.forward(cfg, p, np.concatenate([ids_tr, ids_te]))["user_weights"]
+    assert w.shape == (537, 3)
+    np.testing.assert_allclose(w, want, rtol=0, atol=TOL)
+    np.testing.assert_allclose(w.sum(1), 1.0, atol=1e-5)
+    np.testing.assert_array_equal(np.load(str(tmp_path / "a") + "/labels.npy"), np.concatenate([lab_tr, lab_te]))
+    np.testing.assert_array_equal(np.load(str(tmp_path / "a") + "/lengths.npy"),
+                                  [s[2] for s in tr] + [s[2] for s in te])
+    # Hpmn_Industry
+    cfg = cfg_industry(H=64, K=4, T=41, V=300)
+    p = f32_params(cfg, 104)
+    ids_tr, lab_tr = rand_ids(cfg, 9, 105)
+    ids_te, lab_te = rand_ids(cfg, 4, 106)
+    m = Hpmn_Industry(str(tmp_path / "i"), dict(ids=ids_tr, label=lab_tr), dict(ids=ids_te, label=lab_te),
+                      cfg.feature_size, 2, 1, 41, 1, 0.001, 64, 16, 3, [2] * 10 + [1], [1], 4, 1, True, False,
+                      verbose=False)
+    m.set_params(p)
+    m.get_weights()
+    w = np.load(str(tmp_path / "i") + "/weights_new.npy")
+    want = O.forward(cfg, p, np.concatenate([ids_tr, ids_te]))["user_weights"]
+    np.testing.assert_allclose(w, want, rtol=0, atol=TOL)
+    np.testing.assert_array_equal(np.load(str(tmp_path / "i") + "/ids.npy"),
+                                  np.concatenate([ids_tr, ids_te])[:, :, 1])        # code/hpmn.py:399

@@ -134,3 +134,49 @@ def test_out_of_range_ids_are_rejected_when_a_dataset_is_staged():
     neg = dict(ids=np.array([[[-1, 2]]], dtype=np.int32), label=np.array([1], dtype=np.int32))
     with pytest.raises(ValueError):
         _DeviceDataset(neg, torch.device("cpu"), False, feature_size=5)
+
+
+def test_device_dataset_cache_is_identity_checked_and_bounded(tmp_path):
+    """_dev() must not hand the tensors of a collected temporary dataset to a new object that happens to get
+    the same id(), must re-stage after invalidate_dataset(), and must not grow without bound."""
+    m, _ = _stub(Hpmn, tmp_path, n_train=4, aucs=[])
+    m.industry, m.feature_size = False, 100
+    a = dict(ids=np.ones((3, 4, 3), np.int32), label=np.zeros(3, np.int32))
+    da = m._dev(a)
+    assert m._dev(a) is da
+    # simulate id() reuse: a different object filed under the same key must not hit
+    b = dict(ids=np.full((2, 4, 3), 7, np.int32), label=np.ones(2, np.int32))
+    m._datasets[id(b)] = m._datasets[id(a)]
+    db = m._dev(b)
+    assert db is not da and int(db.ids[0, 0, 0]) == 7 and db.n == 2
+    # in-place mutation is only seen after an explicit invalidate
+    # (on the CPU device of this stub the staged tensor aliases the numpy array; on the GPU it is a copy)
+    a["ids"][:] = 5
+    assert m._dev(a) is da
+    m.invalidate_dataset(a)
+    assert m._dev(a) is not da and int(m._dev(a).ids[0, 0, 0]) == 5
+    # bounded: temporaries are evicted, the model's own train/test sets never are
+    m._dev(m.trainset), m._dev(m.testset)
+    for i in range(3 * m.max_cached_datasets):
+        m._dev(dict(ids=np.zeros((1, 4, 3), np.int32), label=np.zeros(1, np.int32)))
+    assert len(m._datasets) <= m.max_cached_datasets
+    assert id(m.trainset) in m._datasets and id(m.testset) in m._datasets
+
+
+def test_single_class_eval_raises_like_sklearn(tmp_path):
+    """roc_auc_score (code/hpmn.py:516) raises ValueError on a one-class split; a silent NaN would disable
+    early stopping."""
+    import pytest
+    m = object.__new__(Hpmn)
+    m.rank, m.world, m.device = 0, 1, torch.device("cpu")
+    m._datasets, m.industry, m.feature_size = {}, False, 10
+    m.trainset = m.testset = None
+    m.forward_inference = lambda ids: dict(prediction=torch.linspace(0.1, 0.9, ids.shape[0]),
+                                           memory_loss=torch.zeros(()))
+    one = dict(ids=np.ones((6, 4, 3), np.int32), label=np.ones(6, np.int32))
+    with pytest.raises(ValueError, match="Only one class"):
+        m.eval(one, 4)
+    two = dict(ids=np.ones((6, 4, 3), np.int32), label=np.array([0, 0, 1, 0, 1, 1], np.int32))
+    auc, ll, mem = m.eval(two, 4)
+    from sklearn.metrics import roc_auc_score
+    assert abs(auc - roc_auc_score(two["label"], np.linspace(0.1, 0.9, 4).tolist() + np.linspace(0.1, 0.9, 2).tolist())) < 1e-12
