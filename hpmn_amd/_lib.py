@@ -10,7 +10,7 @@ import os
 from typing import Optional
 
 HPMN_MAX_LAYERS = 12
-HPMN_ABI_VERSION = 2
+HPMN_ABI_VERSION = 3
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libhpmn_hip.so")
@@ -106,6 +106,21 @@ class HpmnGruFusedFwd(C.Structure):
     ]
 
 
+class HpmnPipe(C.Structure):
+    _fields_ = [
+        ("B", C.c_int32), ("K", C.c_int32), ("H", C.c_int32), ("train", C.c_int32),
+        ("T", C.c_int32 * HPMN_MAX_LAYERS), ("D", C.c_int32 * HPMN_MAX_LAYERS), ("period", C.c_int32 * HPMN_MAX_LAYERS),
+        ("wg", C.c_void_p * HPMN_MAX_LAYERS), ("bg", C.c_void_p * HPMN_MAX_LAYERS),
+        ("wc", C.c_void_p * HPMN_MAX_LAYERS), ("bc", C.c_void_p * HPMN_MAX_LAYERS),
+        ("x0", C.c_void_p),
+        ("y", C.c_void_p * HPMN_MAX_LAYERS), ("hs", C.c_void_p * HPMN_MAX_LAYERS), ("gates", C.c_void_p * HPMN_MAX_LAYERS),
+        ("memory", C.c_void_p), ("d_memory", C.c_void_p),
+        ("d_act", C.c_void_p * HPMN_MAX_LAYERS), ("d_x", C.c_void_p * HPMN_MAX_LAYERS),
+        ("sync", C.c_void_p),
+        ("mem_stride", C.c_int64),
+    ]
+
+
 class HpmnOnlineUpdate(C.Structure):
     _fields_ = [
         ("B", C.c_int32), ("D", C.c_int32), ("H", C.c_int32), ("K", C.c_int32),
@@ -145,6 +160,12 @@ SIGNATURES = {
     "hpmn_gru_fused_fwd_supported": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),
     "hpmn_gru_fused_fwd": (C.c_int, [C.POINTER(HpmnGruFusedFwd), C.c_void_p]),
     "hpmn_memory_update": (C.c_int, [C.POINTER(HpmnOnlineUpdate), C.c_void_p]),
+    "hpmn_pipe_supported": (C.c_int, [C.c_int32, C.c_int32]),
+    "hpmn_pipe_sync_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
+    "hpmn_pipe_fwd": (C.c_int, [C.POINTER(HpmnPipe), C.c_void_p]),
+    "hpmn_pipe_bwd": (C.c_int, [C.POINTER(HpmnPipe), C.c_void_p]),
+    "hpmn_embed_gather_seq": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                        C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_void_p]),
     "hpmn_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                  C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                  C.c_void_p]),
@@ -163,7 +184,7 @@ def load(path: Optional[str] = None) -> C.CDLL:
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("HPMN_LIB_PATH") or LIB_PATH      # (HPMN_LIB_PATH: developer builds, tools/)
     if not os.path.exists(p):
         raise HpmnLibraryError(
             "%s not found: the HIP extension is not built.  Run `python -c \"import __graft_entry__ as g; "

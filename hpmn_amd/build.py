@@ -39,7 +39,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-I" + INCLUDE, "-I" + CSRC, "-o", OUT + ".tmp"] + sources()
+           "-I" + INCLUDE, "-I" + CSRC, "-o", OUT + ".tmp"] + os.environ.get("HPMN_HIPCC_FLAGS", "").split() + sources()
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     proc = subprocess.run(cmd, capture_output=True, text=True)

@@ -364,7 +364,249 @@ def chunk_plan(spec: ScanSpec, nc: int):
     return out
 
 
+# ---------------------------------------------------------------------------------------
+# all layers in one launch (H = 64): hpmn_pipe_fwd / hpmn_pipe_bwd
+# ---------------------------------------------------------------------------------------
+# HPMN_PIPE = "0" (default): per-layer, per-sequence kernels; "all": every layer in ONE pipelined, batch-tiled MFMA
+# launch (hpmn_pipe_fwd / hpmn_pipe_bwd); "upper": layer 0 on the per-sequence kernels, layers 1..K-1 pipelined.
+# The pipelined launches are parity-green but measured SLOWER at the reference batch (C3, B=500: forward 1.61 /
+# 1.50 / 1.25 ms, backward 2.27 / 2.15 / 2.29 ms for all / upper / 0) -- a tile of 16 sequences concentrates on
+# one CU the LDS traffic, transcendental work and stores that one-sequence-per-wave spreads over eight;
+# DESIGN.md section 3.7 has the per-step cycle accounting.
+PIPE = os.environ.get("HPMN_PIPE", "0")
+if PIPE in ("1", "true"):
+    PIPE = "all"
+_pipe_sync = {}
+
+
+def pipe_mode(spec: ScanSpec) -> str:
+    """"all" / "upper" / "" (per-layer kernels) for this graph."""
+    if PIPE in (False, None, "0", "", "off") or spec.H != 64 or spec.E % 4:
+        return ""
+    lib = _lib.load()
+    if PIPE in (True, "all") and lib.hpmn_pipe_supported(spec.H, spec.D0):
+        return "all"
+    if spec.K >= 3 and lib.hpmn_pipe_supported(spec.H, spec.H):
+        return "upper" if PIPE == "upper" else ("upper" if not lib.hpmn_pipe_supported(spec.H, spec.D0) else "all")
+    return ""
+
+
+def pipe_supported(spec: ScanSpec) -> bool:
+    return pipe_mode(spec) == "all"
+
+
+def _pipe_sync_buffer(K: int, B: int, device) -> torch.Tensor:
+    """Progress words of the in-launch hand-offs, private to the current stream (re-zeroed by every call)."""
+    need = _lib.load().hpmn_pipe_sync_bytes(K, B)
+    key = (str(device), torch.cuda.current_stream().cuda_stream)
+    buf = _pipe_sync.get(key)
+    if buf is None or buf.numel() < need:
+        buf = _pipe_sync[key] = torch.zeros(need, device=device, dtype=torch.uint8)
+    return buf
+
+
+def embed_gather_seq(ids, emb, front_zero: int, mask_id0: bool, out=None):
+    """hpmn_embed_gather_seq: ids [B,T,F] -> x0 [B, front_zero+T, F*E] (zero prefix, id-0 mask)."""
+    _chk_ids(ids)
+    _chk_f32(emb)
+    B, T, F = ids.shape
+    V, E = emb.shape
+    if out is None:
+        out = torch.empty(B, front_zero + T, F * E, device=emb.device, dtype=torch.float32)
+    rc = _lib.load().hpmn_embed_gather_seq(ids.data_ptr(), emb.data_ptr(), out.data_ptr(), B, T, F, E, front_zero, V,
+                                            int(mask_id0), _stream())
+    _lib.check(rc, "hpmn_embed_gather_seq")
+    return out
+
+
+def _pipe_desc(spec: ScanSpec, B: int, weights, train: bool, first: int = 0):
+    """HpmnPipe for layers first..K-1 of the graph (pipe layer j = graph layer first + j)."""
+    p = _lib.HpmnPipe()
+    lens = spec.layer_lengths()
+    p.B, p.K, p.H, p.train = B, spec.K - first, spec.H, int(train)
+    p.mem_stride = spec.K * spec.H
+    for j, i in enumerate(range(first, spec.K)):
+        p.T[j], p.D[j], p.period[j] = lens[i], (spec.D0 if i == 0 else spec.H), spec.periods[i]
+        p.wg[j], p.bg[j], p.wc[j], p.bc[j] = (t.data_ptr() for t in weights[4 * i:4 * i + 4])
+    return p, lens
+
+
+def pipe_forward(spec: ScanSpec, ids, emb, weights: Sequence[torch.Tensor], train: bool):
+    """build_memory forward with all K layers in ONE launch (hpmn_embed_gather_seq + hpmn_pipe_fwd).
+    Returns (memory, last, saved) with saved = [(x_in, hs, gates)] per layer (hs/gates None for inference)."""
+    _chk_ids(ids)
+    _chk_f32(emb, *weights)
+    B = ids.shape[0]
+    H, K = spec.H, spec.K
+    dev = emb.device
+    f32 = dict(device=dev, dtype=torch.float32)
+    p, lens = _pipe_desc(spec, B, weights, train)
+    x0 = embed_gather_seq(ids, emb, spec.front_zero, spec.mask_id0)
+    memory = torch.empty(B, K, H, **f32)
+    y = [torch.empty(B, lens[i] // spec.periods[i], H, **f32) if i + 1 < K else None for i in range(K)]
+    hs = [torch.empty(B, lens[i] + 1, H, **f32) if train else None for i in range(K)]
+    gates = [torch.empty(B, lens[i], 3 * H, **f32) if train else None for i in range(K)]
+    p.x0, p.memory = x0.data_ptr(), memory.data_ptr()
+    for i in range(K):
+        p.y[i], p.hs[i], p.gates[i] = _ptr(y[i]), _ptr(hs[i]), _ptr(gates[i])
+    sync = _pipe_sync_buffer(K, B, dev)
+    p.sync = sync.data_ptr()
+    rc = _lib.load().hpmn_pipe_fwd(C.byref(p), _stream())
+    _lib.check(rc, "hpmn_pipe_fwd")
+    last = x0[:, spec.last_index, :].contiguous()
+    x_in = [x0] + y[:-1]
+    return memory, last, [(x_in[i], hs[i], gates[i]) for i in range(K)]
+
+
+def pipe_error_word(K: int, B: int, device) -> int:
+    """Hand-off error word of the last forward pipe launch on the current stream (0 = no lost hand-off: a wait
+    that exceeds its spin bound gives up, records 1 + layer here and lets the launch finish); synchronises."""
+    buf = _pipe_sync_buffer(K, B, device)
+    torch.cuda.current_stream().synchronize()
+    return int(buf.view(torch.int32)[1])
+
+
+def pipe_backward(spec: ScanSpec, ids, saved, weights, d_memory, d_last, grad_out, defer_join: bool = False):
+    """BPTT of pipe_forward: hpmn_pipe_bwd (every layer's reverse scan + the inter-layer input gradients in one
+    launch), then layer 0's input gradient + the embedding scatter on the current stream and the weight
+    gradients (MFMA reductions over d_act) on a side stream."""
+    K, H = spec.K, spec.H
+    B = d_memory.shape[0]
+    dev = d_memory.device
+    f32 = dict(device=dev, dtype=torch.float32)
+    d_emb, gw = grad_out[0], list(grad_out[1:])
+    p, lens = _pipe_desc(spec, B, weights, True)
+    in_dims = [spec.D0] + [H] * (K - 1)
+    d_act = [torch.empty(B, lens[i], 3 * H, **f32) for i in range(K)]
+    d_x = [torch.empty(B, lens[i], in_dims[i], **f32) for i in range(K)]
+    _chk_f32(d_memory)
+    p.x0, p.d_memory = saved[0][0].data_ptr(), d_memory.data_ptr()
+    for i in range(K):
+        p.hs[i], p.gates[i] = saved[i][1].data_ptr(), saved[i][2].data_ptr()
+        p.d_act[i], p.d_x[i] = d_act[i].data_ptr(), d_x[i].data_ptr()
+        if i + 1 < K:
+            p.y[i] = saved[i + 1][0].data_ptr()
+    sync = _pipe_sync_buffer(K, B, dev)
+    p.sync = sync.data_ptr()
+    rc = _lib.load().hpmn_pipe_bwd(C.byref(p), _stream())
+    _lib.check(rc, "hpmn_pipe_bwd")
+    main = torch.cuda.current_stream()
+    side = _streams(dev, 1)[0]
+    keep = []
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        for i in range(K):
+            x_in, hs, gates = saved[i]
+            gru_param_grads(x_in, hs, gates, d_act[i], weights[4 * i], weights[4 * i + 2], gw[4 * i], gw[4 * i + 1],
+                            gw[4 * i + 2], gw[4 * i + 3], want_dx=False, keep=keep)
+    gru_input_grad(d_act[0], weights[0], weights[2], in_dims[0], out=d_x[0])
+    d_x0 = d_x[0]
+    d_x0[:, spec.last_index, :] += d_last
+    embed_grad_scatter(ids, d_x0, d_emb, spec.front_zero, spec.mask_id0)
+    pending = PendingGrads([side], (keep, d_act, d_x, saved))
+    if defer_join:
+        return pending
+    pending.join()
+    return None
+
+
+def upper_forward(spec: ScanSpec, ids, emb, weights: Sequence[torch.Tensor]):
+    """Layer 0 on the per-sequence kernels (fused projection + scan), layers 1..K-1 in one pipelined launch."""
+    lens = spec.layer_lengths()
+    B, H, K = ids.shape[0], spec.H, spec.K
+    dev = emb.device
+    f32 = dict(device=dev, dtype=torch.float32)
+    memory = torch.empty(B, K, H, **f32)
+    y = [torch.empty(B, lens[i] // spec.periods[i], H, **f32) if i + 1 < K else None for i in range(K)]
+    hs = [torch.empty(B, lens[i] + 1, H, **f32) for i in range(K)]
+    gates = [torch.empty(B, lens[i], 3 * H, **f32) for i in range(K)]
+    x0 = torch.empty(B, lens[0], spec.D0, **f32)
+    wg, bg, wc, bc = weights[0:4]
+    if fused_fwd_supported(H, spec.D0, True) and 64 % spec.E == 0:
+        gru_fused_fwd(ids=ids, emb=emb, wg=wg, bg=bg, wc=wc, bc=bc, H=H, T=lens[0], front_zero=spec.front_zero,
+                      mask_id0=spec.mask_id0, h_last=memory[:, 0, :], period=spec.periods[0],
+                      out=(y[0], hs[0], gates[0], x0))
+    else:
+        xp, _ = gru_input_proj(None, ids=ids, emb=emb, wg=wg, bg=bg, wc=wc, bc=bc, H=H, T=lens[0],
+                               front_zero=spec.front_zero, mask_id0=spec.mask_id0,
+                               out=(torch.empty(B, lens[0], 3 * H, **f32), x0))
+        gru_scan_fwd(xp, wg, wc, spec.D0, memory[:, 0, :], spec.periods[0], True, True, out=(y[0], hs[0], gates[0]))
+    p, _ = _pipe_desc(spec, B, weights, True, first=1)
+    p.x0, p.memory = y[0].data_ptr(), memory[:, 1, :].data_ptr()
+    for j, i in enumerate(range(1, K)):
+        p.y[j], p.hs[j], p.gates[j] = _ptr(y[i]), hs[i].data_ptr(), gates[i].data_ptr()
+    p.sync = _pipe_sync_buffer(K, B, dev).data_ptr()
+    _lib.check(_lib.load().hpmn_pipe_fwd(C.byref(p), _stream()), "hpmn_pipe_fwd")
+    last = x0[:, spec.last_index, :].contiguous()
+    x_in = [x0] + y[:-1]
+    return memory, last, [(x_in[i], hs[i], gates[i]) for i in range(K)]
+
+
+def upper_backward(spec: ScanSpec, ids, saved, weights, d_memory, d_last, grad_out, defer_join: bool = False):
+    """BPTT of upper_forward: layers K-1..1 in one pipelined launch, then layer 0's reverse scan on the
+    per-sequence kernel; weight gradients on a side stream as their d_act completes."""
+    K, H = spec.K, spec.H
+    B = d_memory.shape[0]
+    dev = d_memory.device
+    f32 = dict(device=dev, dtype=torch.float32)
+    d_emb, gw = grad_out[0], list(grad_out[1:])
+    lens = spec.layer_lengths()
+    in_dims = [spec.D0] + [H] * (K - 1)
+    d_act = [torch.empty(B, lens[i], 3 * H, **f32) for i in range(K)]
+    d_x = [torch.empty(B, lens[i], in_dims[i], **f32) for i in range(K)]
+    _chk_f32(d_memory)
+    p, _ = _pipe_desc(spec, B, weights, True, first=1)
+    p.x0, p.d_memory = saved[1][0].data_ptr(), d_memory[:, 1, :].data_ptr()
+    for j, i in enumerate(range(1, K)):
+        p.hs[j], p.gates[j] = saved[i][1].data_ptr(), saved[i][2].data_ptr()
+        p.d_act[j], p.d_x[j] = d_act[i].data_ptr(), d_x[i].data_ptr()
+        if i + 1 < K:
+            p.y[j] = saved[i + 1][0].data_ptr()
+    p.sync = _pipe_sync_buffer(K, B, dev).data_ptr()
+    _lib.check(_lib.load().hpmn_pipe_bwd(C.byref(p), _stream()), "hpmn_pipe_bwd")
+    main = torch.cuda.current_stream()
+    side = _streams(dev, 1)[0]
+    keep = []
+
+    def wgrad(i):
+        x_in, hs, gates = saved[i]
+        gru_param_grads(x_in, hs, gates, d_act[i], weights[4 * i], weights[4 * i + 2], gw[4 * i], gw[4 * i + 1],
+                        gw[4 * i + 2], gw[4 * i + 3], want_dx=False, keep=keep)
+
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        for i in range(K - 1, 0, -1):
+            wgrad(i)
+    # the gradient wrt layer 0's subsampled outputs, then its reverse scan (the end of the chain)
+    gru_input_grad(d_act[1], weights[4], weights[6], H, out=d_x[1])
+    gru_scan_bwd(weights[0], weights[2], in_dims[0], saved[0][1], saved[0][2], d_memory[:, 0, :], d_x[1],
+                 spec.periods[0], out=d_act[0])
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        wgrad(0)
+    gru_input_grad(d_act[0], weights[0], weights[2], in_dims[0], out=d_x[0])
+    d_x0 = d_x[0]
+    d_x0[:, spec.last_index, :] += d_last
+    embed_grad_scatter(ids, d_x0, d_emb, spec.front_zero, spec.mask_id0)
+    pending = PendingGrads([side], (keep, d_act, d_x, saved))
+    if defer_join:
+        return pending
+    pending.join()
+    return None
+
+
 def scan_forward_train(spec: ScanSpec, ids, emb, weights: Sequence[torch.Tensor]):
+    """Training-mode build_memory: pipelined launches where the shape has them (pipe_mode), else the per-layer
+    kernels below."""
+    mode = pipe_mode(spec) if ids.shape[0] > 0 else ""
+    if mode == "all":
+        return pipe_forward(spec, ids, emb, weights, train=True)
+    if mode == "upper":
+        return upper_forward(spec, ids, emb, weights)
+    return scan_forward_train_layers(spec, ids, emb, weights)
+
+
+def scan_forward_train_layers(spec: ScanSpec, ids, emb, weights: Sequence[torch.Tensor]):
     """Training-mode build_memory (code/hpmn.py:113-129 on the embedded ids): per layer the input
     projection + the serial scan with saved states.  Returns (memory [B,K,H], last [B,D0], saved).
 
@@ -470,7 +712,18 @@ class PendingGrads:
 
 def scan_backward(spec: ScanSpec, ids, saved, weights: Sequence[torch.Tensor], d_memory, d_last, grad_out,
                   defer_join: bool = False):
-    """BPTT of scan_forward_train.  ``grad_out`` = [d_emb, d_wg0, d_bg0, d_wc0, d_bc0, d_wg1, ...]:
+    """BPTT of scan_forward_train (every forward path leaves the same saved states)."""
+    mode = pipe_mode(spec) if d_memory.shape[0] > 0 else ""
+    if mode == "all":
+        return pipe_backward(spec, ids, saved, weights, d_memory, d_last, grad_out, defer_join)
+    if mode == "upper":
+        return upper_backward(spec, ids, saved, weights, d_memory, d_last, grad_out, defer_join)
+    return scan_backward_layers(spec, ids, saved, weights, d_memory, d_last, grad_out, defer_join)
+
+
+def scan_backward_layers(spec: ScanSpec, ids, saved, weights: Sequence[torch.Tensor], d_memory, d_last, grad_out,
+                         defer_join: bool = False):
+    """BPTT of scan_forward_train_layers.  ``grad_out`` = [d_emb, d_wg0, d_bg0, d_wc0, d_bc0, d_wg1, ...]:
     pre-zeroed buffers (views of the optimiser's flat gradient) that are accumulated into.
 
     Mirror image of the forward pipeline: layer K-1 runs its last time chunk first, its input gradient

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define HPMN_ABI_VERSION 2
+#define HPMN_ABI_VERSION 3
 #define HPMN_MAX_LAYERS 12
 
 enum {
@@ -230,6 +230,50 @@ int hpmn_scan_fwd(const HpmnScanDesc *desc, const int32_t *ids, const float *emb
                   const float *const *wg, const float *const *bg,
                   const float *const *wc, const float *const *bc,
                   float *memory, float *last, void *workspace, void *stream);
+
+
+/* ------------------------------------------------------------------------------------
+ * build_memory with ALL K layers in ONE launch (H = 64): forward hpmn_pipe_fwd, BPTT hpmn_pipe_bwd.
+ * Replaces the whole loop of code/hpmn.py:116-128 (and TF's autodiff of it) at once: a workgroup owns a
+ * tile of 16 sequences of ONE layer and runs that layer's recurrence on the matrix cores (the [3H x H] x
+ * [H x 16] product of a step as 16x16x32 f16 MFMAs on operands split x = hi + lo, three products per tile,
+ * fp32 accumulate: fp32-class results at 3/16 of the f32-MFMA time); the workgroups of layer i+1 consume
+ * every period-th state of layer i while layer i is still running (hand-off through the y rows in memory +
+ * per-wave progress words), so all K layers -- "fire every 2^k steps" -- advance concurrently.
+ *
+ *   x0      [B, T[0], D[0]]   layer-0 input rows (hpmn_embed_gather_seq: gather + zero prefix)
+ *   y[i]    [B, T[i]/period[i], H]  every period-th output of layer i, i < K-1 (= the input rows of layer
+ *                             i+1: T[i+1] == T[i]/period[i], D[i+1] == H)
+ *   hs[i]   [B, T[i]+1, H], gates[i] [B, T[i], 3H]   saved states as in hpmn_gru_scan_fwd (train != 0, and bwd)
+ *   memory  [B, K, H] out (fwd);  d_memory [B, K, H] in (bwd): gradient wrt memory (row stride mem_stride)
+ *   d_act[i] [B, T[i], 3H] out (bwd);  d_x[i] [B, T[i], H] out for i >= 1 (the gradient wrt y[i-1]; layer 0's
+ *   input gradient is hpmn_gru_input_grad(d_act[0]) as before).  Weight gradients: hpmn_gru_param_grads.
+ *   sync    scratch of hpmn_pipe_sync_bytes(K, B) bytes (progress words, re-zeroed on the stream by every call)
+ * D[0] in {16, 32, 48, 64}; other shapes: HPMN_EUNSUPPORTED (use the per-layer entry points above).
+ * ---------------------------------------------------------------------------------- */
+typedef struct HpmnPipe {
+    int32_t B, K, H, train;
+    int32_t T[HPMN_MAX_LAYERS], D[HPMN_MAX_LAYERS], period[HPMN_MAX_LAYERS];
+    const float *wg[HPMN_MAX_LAYERS], *bg[HPMN_MAX_LAYERS], *wc[HPMN_MAX_LAYERS], *bc[HPMN_MAX_LAYERS];
+    const float *x0;
+    float *y[HPMN_MAX_LAYERS], *hs[HPMN_MAX_LAYERS], *gates[HPMN_MAX_LAYERS];
+    float *memory;
+    const float *d_memory;
+    float *d_act[HPMN_MAX_LAYERS], *d_x[HPMN_MAX_LAYERS];
+    void *sync;
+    int64_t mem_stride;   /* floats between consecutive sequences' rows of memory / d_memory; 0: K*H.  Lets the K
+                           * layers of this call be layers j..j+K-1 of a taller stack (memory + j*H, stride K_all*H) */
+} HpmnPipe;
+
+int hpmn_pipe_supported(int32_t H, int32_t D0);
+size_t hpmn_pipe_sync_bytes(int32_t K, int32_t B);
+int hpmn_pipe_fwd(const HpmnPipe *args, void *stream);
+int hpmn_pipe_bwd(const HpmnPipe *args, void *stream);
+/* out[b, t, f*E:(f+1)*E] = t < front_zero ? 0 : emb[ids[b, t-front_zero, f]] * (mask_id0 ? id != 0 : 1):
+ * Hpmn.embedding (code/hpmn.py:414-423 / :266-276) with the zero prefix of code/hpmn.py:288-289.
+ *   ids [B, Tids, F] int32, emb [V, E], out [B, front_zero+Tids, F*E] */
+int hpmn_embed_gather_seq(const int32_t *ids, const float *emb, float *out, int32_t B, int32_t Tids, int32_t F,
+                          int32_t E, int32_t front_zero, int64_t V, int32_t mask_id0, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Memory read path: covariance regulariser (code/hpmn.py:161-170), multi-hop attention over
