@@ -1,6 +1,7 @@
 """bench.py -- training sequences/sec of the HPMN hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3|c4|c1|c2] [--batch B] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3|c4|c4big|c1|c2] [--batch B]
+                    [--scaling weak|strong] [--no-cpu-baseline] [--no-roofline] [--no-auc]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one full training pass of the hot path over one batch of synthetic input already
@@ -43,6 +44,11 @@ CONFIGS = {
     "c4": dict(industry=True, F=2, T=1001, H=128, K=7, periods=[2] * 10 + [1], batch=500,
                V=19002 + 3269017 + 200000, lr=0.001, memory_reg=5e-5,
                name="XLong synthetic x10 users, Hpmn_Industry 7-layer H=128 max_len=1000(+1)->1024"),
+    # configs[4] with a table far beyond the 256 MiB Infinity Cache: 256 M rows x 16 = 16 GiB, dense TF-Adam
+    # semantics (param + grad + m + v = 64 GiB of flat buffers); int32 row ids (2.1 G rows is the id limit)
+    "c4big": dict(industry=True, F=2, T=1001, H=128, K=7, periods=[2] * 10 + [1], batch=500,
+                  V=256 * 1024 * 1024, lr=0.001, memory_reg=5e-5, device_init=True,
+                  name="XLong synthetic, 256 M-row table (16 GiB), Hpmn_Industry 7-layer H=128 max_len=1000(+1)->1024"),
     "c2": dict(industry=False, F=4, T=300, H=64, K=5, periods=[2, 2, 3, 5, 5, 1], batch=128,
                V=4160000 + 990000 + 9400 + 5, lr=0.001, memory_reg=1e-5,
                name="Taobao synthetic, Hpmn 5-layer H=64 max_len=300"),
@@ -75,11 +81,15 @@ def build_model(c, tmp, device, seed=0):
     cls = Hpmn_Industry if c["industry"] else Hpmn
     gen = np.random.default_rng(1234)
     emb_init = None
-    if c["industry"]:
+    if c["industry"] and not c.get("device_init"):
         # graph_emb.npy stand-in: N(0, 0.1) rows
         emb_init = (gen.standard_normal((c["V"], 16), dtype=np.float32) * 0.1)
-    return cls(tmp, [], [], c["V"], c["F"], 1, c["T"], 1, c["lr"], c["H"], 16, 3, c["periods"], [1], c["K"], 1,
-               True, False, emb_initializer=emb_init, l2_reg=0, memory_reg=c["memory_reg"], verbose=False, seed=seed)
+    m = cls(tmp, [], [], c["V"], c["F"], 1, c["T"], 1, c["lr"], c["H"], 16, 3, c["periods"], [1], c["K"], 1,
+            True, False, emb_initializer=emb_init, l2_reg=0, memory_reg=c["memory_reg"], verbose=False, seed=seed)
+    if c.get("device_init"):     # tables of many GiB: N(0, 0.1) drawn on the device
+        g = torch.Generator(device=device).manual_seed(1234)
+        m.params["Embedding/emb_mtx"].normal_(0.0, 0.1, generator=g)
+    return m
 
 
 def layer_lengths(c):
@@ -110,73 +120,183 @@ def time_kernel(fn, iters, stream):
     return e0.elapsed_time(e1) / iters
 
 
-def roofline_probes(model, c, ids):
-    """Per-kernel live timings of the dominant kernels on the stream they are launched on (torch's
-    current stream -- every HIP entry point takes it explicitly)."""
+def source_sha():
+    """sha1 over the kernel sources: PMC digests under profiles/ are only quoted while they still describe THIS code."""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    for f in sorted(glob.glob(os.path.join(ROOT, "hpmn_amd", "csrc", "*"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_digest(c, B):
+    """profiles/r02_pmc_summary.json (tools/pmc_digest.py: two separate rocprofv3 --pmc passes of this command,
+    FETCH x2 gfx950 correction) -- used only if it was taken on the current kernel sources, config and batch."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")))
+        if d.get("source_sha") == source_sha() and d.get("config_id") == c.get("config_id") and d.get("batch") == B:
+            return d
+    except Exception:
+        pass
+    return None
+
+
+def roofline_probes(model, c, batches, step_fn):
+    """Live timings on the stream the kernels are launched on (torch's current stream -- every HIP entry point
+    takes it explicitly).  The DOMINANT kernel (layer-0 reverse scan) is timed INSIDE real training steps, with the
+    weight-gradient kernels live on the side stream; the others stand-alone."""
     from hpmn_amd import ops
     st = torch.cuda.current_stream()
+    ids = batches[0][0]
     H, B = c["H"], ids.shape[0]
     T0 = layer_lengths(c)[0]
     D0 = c["F"] * 16
     w = [t.detach() for t in model._gru_weights()]
     emb = model.params["Embedding/emb_mtx"].detach()
     spec = model.spec
+
+    # -- dominant kernel, in-step
+    in_step_ms = None
+    if ops.pipe_mode(spec) == "":
+        ops.PROBE = []
+        for i in range(24):
+            step_fn(i)
+        torch.cuda.synchronize()
+        ts = sorted(e0.elapsed_time(e1) for e0, e1 in ops.PROBE[4:])
+        ops.PROBE = None
+        in_step_ms = ts[len(ts) // 2]
+
     xp, x0 = ops.gru_input_proj(None, ids=ids, emb=emb, wg=w[0], bg=w[1], wc=w[2], bc=w[3], H=H, T=T0,
                                 front_zero=spec.front_zero, mask_id0=spec.mask_id0, want_x_out=True)
     mem = torch.empty(B, H, device=ids.device)
     y, hs, gates = ops.gru_scan_fwd(xp, w[0], w[2], D0, mem, spec.periods[0], True, True)
     dmem = torch.randn(B, H, device=ids.device) * 0.01
-
     t_fwd = time_kernel(lambda: ops.gru_scan_fwd(xp, w[0], w[2], D0, mem, spec.periods[0], True, True), 5, st)
     t_bwd = time_kernel(lambda: ops.gru_scan_bwd(w[0], w[2], D0, hs, gates, dmem, None, spec.periods[0]), 5, st)
     t_proj = time_kernel(lambda: ops.gru_input_proj(None, ids=ids, emb=emb, wg=w[0], bg=w[1], wc=w[2], bc=w[3],
                                                     H=H, T=T0, front_zero=spec.front_zero,
                                                     mask_id0=spec.mask_id0), 5, st)
-    t_gather = time_kernel(lambda: ops.embed_gather(ids, emb, spec.mask_id0), 10, st)
     d_act = ops.gru_scan_bwd(w[0], w[2], D0, hs, gates, dmem, None, spec.periods[0])
     gw = [torch.zeros_like(t) for t in w[:4]]
     t_wgrad = time_kernel(lambda: ops.gru_param_grads(x0, hs, gates, d_act, w[0], w[2], gw[0], gw[1], gw[2], gw[3],
                                                       want_dx=False), 5, st)
-    t_wgrad_dx = time_kernel(lambda: ops.gru_param_grads(x0, hs, gates, d_act, w[0], w[2], gw[0], gw[1], gw[2],
-                                                         gw[3], want_dx=True), 5, st)
-    # serial-scan flops per launch (recurrent half only; the input half lives in input_proj)
-    scan_flops = B * T0 * 2 * H * 3 * H
-    gather_bytes = B * c["T"] * c["F"] * (4 + 2 * 16 * 4)      # id + row read + row write
-    proj_bytes = B * c["T"] * c["F"] * (4 + 64) + B * T0 * 3 * H * 4
-    dom_name, dom_t = ("gru_scan_bwd_kernel", t_bwd) if t_bwd >= t_fwd else ("gru_scan_fwd_kernel", t_fwd)
-    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; take the
-    # committed rocprofv3 --pmc passes of this same command/shape (profiles/r01_pmc_summary.json)
-    traffic, traffic_src = None, None
-    try:
-        if c.get("config_id") == "c3" and B == 500:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))["layer0_launch"]
-            key = "gru_scan_bwd_kernel<64>" if dom_name == "gru_scan_bwd_kernel" else "gru_scan_fwd_kernel<64,true>"
-            traffic = (2.0 * pmc[key]["FETCH_SIZE"] + pmc[key]["WRITE_SIZE"]) * 1024.0
-            traffic_src = "profiles/r01_pmc_summary.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x2 gfx950 correction)"
-    except Exception:
-        pass
-    roof = {"kernel": dom_name + "<%d> layer 0 (T=%d)" % (H, T0), "bound": "mfma",
+    t_dx = time_kernel(lambda: ops.gru_input_grad(d_act, w[0], w[2], D0), 5, st)
+    del xp, x0, y, hs, gates, d_act
+
+    # -- gather, cold: a table far beyond the 256 MiB Infinity Cache (unless the model's own already is), EIGHT
+    #    distinct id batches rotated inside the timed loop, SURVEY 8d's algorithmic bytes (4 B id + 64 B row)
+    n_ids = B * c["T"] * c["F"]
+    if emb.numel() * 4 >= (2 << 30):
+        gtab, gV = emb, emb.shape[0]
+    else:
+        gV = 64 * 1024 * 1024                                   # 4 GiB
+        gtab = torch.empty(gV, 16, device=ids.device).normal_(0.0, 0.1)
+    gen = torch.Generator(device=ids.device).manual_seed(99)
+    gids = [torch.randint(0, gV, (B, c["T"], c["F"]), device=ids.device, dtype=torch.int32, generator=gen)
+            for _ in range(8)]
+    gout = torch.empty(B, c["T"] + spec.front_zero, D0, device=ids.device)
+    k = [0]
+
+    def gather_once():
+        ops.embed_gather_seq(gids[k[0] % 8], gtab, spec.front_zero, spec.mask_id0, out=gout)
+        k[0] += 1
+    t_gather = time_kernel(gather_once, 16, st)
+    gather_alg = n_ids * (4 + 64)
+    gather_moved = n_ids * (4 + 128)                              # incl. the materialised row write
+    del gids, gout
+    if gtab is not emb:
+        del gtab
+
+    scan_flops = B * T0 * 2 * H * 3 * H           # recurrent half; the input half is accounted to input_proj
+    dom_t = in_step_ms if in_step_ms is not None else max(t_bwd, t_fwd)
+    pmc = pmc_digest(c, B)
+    traffic = None
+    step_bytes = None
+    if pmc is not None:
+        kk = pmc["kernels"].get("gru_scan_bwd_kernel<%d>" % H)
+        if kk:
+            traffic = kk["hbm_bytes_max_launch"]
+        step_bytes = pmc.get("hbm_bytes_per_step")
+    roof = {"kernel": "gru_scan_bwd_kernel<%d> layer 0 (T=%d)" % (H, T0), "bound": "mfma",
             "achieved": scan_flops / (dom_t * 1e-3) / 1e12, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-            "frac": scan_flops / (dom_t * 1e-3) / 1e12 / PEAK_F32_TFLOPS, "traffic": traffic,
-            "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
+            "frac": scan_flops / (dom_t * 1e-3) / 1e12 / PEAK_F32_TFLOPS,
+            "traffic": traffic, "traffic_unit": "bytes/launch",
+            "traffic_source": None if pmc is None else "profiles/r02_pmc_summary.json taken at source sha %s "
+                              "(separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x2 gfx950 correction)"
+                              % pmc["source_sha"],
             "ms_per_launch": dom_t,
+            "timing": "median of 20 launches INSIDE training steps (HIP events on the launch stream, weight-gradient "
+                      "kernels live on the side stream)" if in_step_ms is not None else "stand-alone launches",
+            "ms_per_launch_standalone": t_bwd,
+            "algorithmic_flops_per_launch": scan_flops,
             "note": "fp32 FMA chain, latency-bound serial recurrence; peak = dense fp32 (vector == f32 MFMA)"}
     wgrad_flops = B * T0 * 2 * (D0 + H) * 3 * H
+    proj_bytes = n_ids * (4 + 64) + B * T0 * 3 * H * 4
+    alg_train = B * bytes_train_per_seq(c)
     extra = {
-        "scan_fwd_ms": t_fwd, "scan_bwd_ms": t_bwd,
+        "scan_fwd_ms": t_fwd, "scan_bwd_ms_standalone": t_bwd, "scan_bwd_ms_in_step": in_step_ms,
         "wgrad": {"ms": t_wgrad, "bound": "mfma", "achieved": wgrad_flops / (t_wgrad * 1e-3) / 1e12,
                   "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
                   "frac": wgrad_flops / (t_wgrad * 1e-3) / 1e12 / PEAK_F32_TFLOPS},
-        "dx_ms": t_wgrad_dx - t_wgrad,
-        "scan_fwd_tflops": scan_flops / (t_fwd * 1e-3) / 1e12,
-        "scan_bwd_tflops": scan_flops / (t_bwd * 1e-3) / 1e12,
+        "dx_ms": t_dx,
         "input_proj": {"ms": t_proj, "bound": "hbm", "achieved": proj_bytes / (t_proj * 1e-3) / 1e9,
                        "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": proj_bytes / (t_proj * 1e-3) / 1e9 / PEAK_HBM_GBS},
-        "gather": {"ms": t_gather, "bound": "hbm", "achieved": gather_bytes / (t_gather * 1e-3) / 1e9,
-                   "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                   "frac": gather_bytes / (t_gather * 1e-3) / 1e9 / PEAK_HBM_GBS},
+        "gather": {"kernel": "embed_gather_seq_kernel", "ms": t_gather, "bound": "hbm",
+                   "achieved": gather_alg / (t_gather * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                   "frac": gather_alg / (t_gather * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                   "bytes": "SURVEY 8d algorithmic: 4 B id + 64 B row per id (the row WRITE is not counted)",
+                   "moved_GBs_incl_row_write": gather_moved / (t_gather * 1e-3) / 1e9,
+                   "table_rows": int(gV), "table_bytes": int(gV) * 64,
+                   "protocol": "8 distinct random id batches rotated inside the timed loop, table >> 256 MiB L3"},
+        "hbm_bytes_per_step": step_bytes,
+        "algorithmic_bytes_train_per_step": alg_train,
+        "hbm_over_algorithmic": None if step_bytes is None else step_bytes / alg_train,
     }
     return roof, extra
+
+
+def bytes_train_per_seq(c):
+    """T*F*(4 + 3*4*E) + 4*K*H + 4 (ids, row read + gradient read-modify-write, memory, prediction)."""
+    return c["T"] * c["F"] * (4 + 3 * 4 * 16) + 4 * c["K"] * c["H"] + 4
+
+
+def parity_gate(device, tmp):
+    """fixed weights + one fixed batch, max-abs difference of the HIP path against the float64 oracle's
+    COMMITTED outputs (tests/golden/*.npz: data, generated by oracle/ in the build container) -- in the same
+    process as the timing.  Both graphs: Hpmn (C0 shape) and Hpmn_Industry; inference AND training-path forward."""
+    from hpmn_amd.hpmn import Hpmn, Hpmn_Industry
+    out = {"tolerance": 1e-4, "cases": {}}
+    ok = True
+    for fname, industry in (("oracle_c0.npz", False), ("oracle_industry.npz", True)):
+        z = np.load(os.path.join(ROOT, "tests", "golden", fname))
+        p = {k[len("param:"):]: z[k] for k in z.files if k.startswith("param:")}
+        V = p["Embedding/emb_mtx"].shape[0]
+        ids = z["ids"]
+        if industry:
+            m = Hpmn_Industry(tmp + "/pg_i", [], [], V, 2, 1, ids.shape[1], 1, 0.001, 64, 16, 3, [2] * 10 + [1], [1], 4, 1,
+                              True, False, memory_reg=5e-5, verbose=False)
+        else:
+            m = Hpmn(tmp + "/pg_a", [], [], V, 3, 2, ids.shape[1], 1, 0.003, 32, 16, 3, [2, 2, 5, 5, 1], [1], 3, 1,
+                     True, False, memory_reg=1e-5, verbose=False)
+        m.set_params(p)
+        t = torch.as_tensor(ids).to(device)
+        o = m.forward_inference(t)
+        ot, _ = m.compute_gradients(t, torch.as_tensor(z["label"]).to(device), keep_prob=1.0)
+        d = {}
+        for k in ("memory", "logit", "prediction", "user_weights"):
+            d["max_abs_" + k] = float(np.abs(o[k].cpu().numpy().astype(np.float64) - z[k]).max())
+        d["max_abs_memory_train_path"] = float(np.abs(ot["memory"].cpu().numpy().astype(np.float64) - z["memory"]).max())
+        d["max_abs_prediction_train_path"] = float(np.abs(ot["prediction"].cpu().numpy().astype(np.float64)
+                                                           - z["prediction"]).max())
+        d["batch"] = int(ids.shape[0])
+        ok = ok and all(v <= out["tolerance"] for k, v in d.items() if k.startswith("max_abs"))
+        out["cases"][fname] = d
+    out["pass"] = bool(ok)
+    out["max_abs_logit"] = max(v["max_abs_logit"] for v in out["cases"].values())
+    out["max_abs_memory"] = max(v["max_abs_memory"] for v in out["cases"].values())
+    out["max_abs_prediction"] = max(v["max_abs_prediction"] for v in out["cases"].values())
+    return out
 
 
 def auc_leg(c, device, rank, world, steps, tmp):
@@ -223,15 +343,14 @@ def log(msg):
 T_START = time.perf_counter()
 
 
-def cpu_baseline(c, seed=0, budget_s=20.0):
-    """The oracle's PyTorch-CPU eager restatement (per-timestep small ops like the TF graph, dense
-    TF-form Adam over the whole table), float32, timed on this host on a bounded sample of the same
-    workload: full sequence length / layers / vocabulary, a batch sized by a calibration step so the
-    timed step costs about `budget_s` seconds."""
+def cpu_baseline(c, seed=0):
+    """The oracle's PyTorch-CPU eager restatement (per-timestep small ops like the TF graph, dense TF-form Adam
+    over the whole table), float32, timed on this host's cores at the FULL shape of the workload (sequence length,
+    layers, vocabulary, the reference batch): median of 3 training steps and of 3 forward-only passes on all
+    useful threads, plus a 1-thread figure on a smaller batch (a 1-thread step at batch 500 takes minutes)."""
     from oracle import hpmn_oracle as O
     from oracle import torch_restatement as R
     threads = min(os.cpu_count() or 1, 32)      # tiny per-step ops: more threads only add sync cost
-    torch.set_num_threads(threads)
     cfg = O.HpmnConfig(feature_size=c["V"], user_dim=c["F"], user_maxlen=c["T"], hidden_size=c["H"],
                        embedding_size=16, hop=3, user_layers=tuple(c["periods"]), user_num_layers=c["K"],
                        industry=c["industry"], memory_reg=c["memory_reg"])
@@ -239,39 +358,62 @@ def cpu_baseline(c, seed=0, budget_s=20.0):
     opt = R.TFAdam(p, c["lr"])
     rng = np.random.default_rng(seed + 1)
 
-    def run(bs):
-        ids = torch.as_tensor(rng.integers(1, c["V"], size=(bs, c["T"], c["F"])))
-        label = torch.as_tensor(rng.integers(0, 2, size=bs))
+    def batch(bs):
+        return (torch.as_tensor(rng.integers(1, c["V"], size=(bs, c["T"], c["F"]))),
+                torch.as_tensor(rng.integers(0, 2, size=bs)))
+
+    def train(bs):
+        ids, label = batch(bs)
         t0 = time.perf_counter()
         R.train_step(cfg, p, opt, ids, label)
         return time.perf_counter() - t0
 
-    run(8)                                   # warm-up (allocator, thread pool, first-touch of the table)
-    t_cal = run(16)
+    def fwd(bs):
+        ids, label = batch(bs)
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            R.forward(cfg, p, ids, label)
+        return time.perf_counter() - t0
+
+    torch.set_num_threads(threads)
+    train(8)                                   # warm-up (allocator, thread pool, first-touch of the table)
+    t_cal = train(16)
     log("cpu baseline calibration: batch 16 step %.2fs on %d threads" % (t_cal, threads))
-    # cost is sub-linear in the batch (per-timestep dispatch overhead dominates small batches), so the
-    # linear extrapolation from batch 16 is a generous upper bound: take the full batch when even that
-    # bound stays within 4x the budget, then repeat whole steps until about half the budget is used
-    lin = t_cal / 16.0
-    bs = c["batch"] if lin * c["batch"] <= 4 * budget_s else int(max(16, budget_s / lin))
-    times = []
-    while sum(times) < 0.5 * budget_s and len(times) < 4:
-        times.append(run(bs))
-        log("cpu baseline: batch %d step %.2fs" % (bs, times[-1]))
-        if times[-1] > budget_s:
+    # per-timestep dispatch overhead dominates small batches: linear extrapolation from batch 16 is an upper bound
+    bs = c["batch"] if t_cal / 16.0 * c["batch"] <= 120.0 else int(max(16, 30.0 / (t_cal / 16.0)))
+    tt = []
+    for _ in range(3):
+        tt.append(train(bs))
+        log("cpu baseline: train step batch %d %.2fs" % (bs, tt[-1]))
+        if sum(tt) > 90.0:
             break
-    t = sum(times)
-    return {"value": bs * len(times) / t, "unit": "sequences/s", "cores": threads, "kind": "port",
-            "sample": "%d train step(s) (fwd+BPTT+clip+dense Adam) of batch %d at the full %s shape, fp32 "
-                      "PyTorch-CPU eager restatement (oracle/torch_restatement.py), %.2fs in total; calibration "
-                      "step of batch 16 took %.2fs" % (len(times), bs, c["name"], t, t_cal)}
+    tf = [fwd(bs) for _ in range(3 if sum(tt) < 60.0 else 1)]
+    log("cpu baseline: forward batch %d %s" % (bs, " ".join("%.2fs" % x for x in tf)))
+    torch.set_num_threads(1)
+    b1 = 16
+    t1 = train(b1)
+    log("cpu baseline: 1 thread, train step batch %d %.2fs" % (b1, t1))
+    torch.set_num_threads(threads)
+    med = sorted(tt)[len(tt) // 2]
+    medf = sorted(tf)[len(tf) // 2]
+    return {"value": bs / med, "unit": "sequences/s", "cores": threads, "kind": "port",
+            "train_step_seconds": tt, "forward_only": {"value": bs / medf, "unit": "sequences/s", "seconds": tf},
+            "one_thread": {"value": b1 / t1, "unit": "sequences/s", "cores": 1, "batch": b1, "seconds": t1},
+            "sample": "median of %d train step(s) (fwd+BPTT+clip+dense Adam) of batch %d at the full %s shape, fp32 "
+                      "PyTorch-CPU eager restatement (oracle/torch_restatement.py), %.1fs in total; forward-only: median "
+                      "of %d passes of the same batch; 1 thread: one train step of batch %d"
+                      % (len(tt), bs, c["name"], sum(tt), len(tf), b1)}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: the per-GPU batch is the reference batch (global = N x); strong: the GLOBAL batch is")
+    ap.add_argument("--no-parity-gate", action="store_true")
+    ap.add_argument("--no-eval", action="store_true", help="skip the forward-only throughput leg (clean PMC profiles)")
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the reference literal)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -312,9 +454,14 @@ def main():
     tmp = tempfile.mkdtemp(prefix="hpmn_bench_")
     log("building model %s" % c["name"])
     model = build_model(c, tmp, device, seed=0)          # same seed -> identical replicas
-    n_distinct = 4
-    batches = synth_batches(c, n_distinct, c["batch"], 20190521 + 3 + 1000 * rank, device)
-    global_batch = c["batch"] * world
+    n_distinct = 8
+    if args.scaling == "strong":
+        global_batch = c["batch"]
+        lo, hi = (global_batch * rank) // world, (global_batch * (rank + 1)) // world
+        per_gpu = hi - lo
+    else:
+        per_gpu, global_batch = c["batch"], c["batch"] * world
+    batches = synth_batches(c, n_distinct, per_gpu, 20190521 + 3 + 1000 * rank, device)
 
     def step(i):
         ids, label = batches[i % n_distinct]
@@ -346,24 +493,27 @@ def main():
 
     log("timed region done: %.1f ms/step" % (elapsed / args.steps * 1e3))
     # quick quality signal on the bench batches (not a trained AUC: weights saw only W+K steps)
-    out = model.forward_inference(batches[0][0])
-    finite = bool(torch.isfinite(out["prediction"]).all())
+    finite = True
+    if not args.no_eval:
+        out = model.forward_inference(batches[0][0])
+        finite = bool(torch.isfinite(out["prediction"]).all())
 
     # forward-only (eval) throughput at the harness's eval batch = 4x the train batch (code/hpmn.py:485-486)
-    ev_ids = torch.cat([b[0] for b in batches[:4]], 0)
-    model.forward_inference(ev_ids)
-    torch.cuda.synchronize()
-    te0 = time.perf_counter()
-    for _ in range(5):
+    eval_seq_per_s = None
+    if not args.no_eval:
+        ev_ids = torch.cat([b[0] for b in batches[:4]], 0)[:4 * c["batch"]]
         model.forward_inference(ev_ids)
-    torch.cuda.synchronize()
-    eval_seq_per_s = 5 * ev_ids.shape[0] * world / (time.perf_counter() - te0)
-    del ev_ids
+        torch.cuda.synchronize()
+        te0 = time.perf_counter()
+        for _ in range(5):
+            model.forward_inference(ev_ids)
+        torch.cuda.synchronize()
+        eval_seq_per_s = 5 * ev_ids.shape[0] * world / (time.perf_counter() - te0)
+        del ev_ids
 
     auc = None
     if args.config == "c3" and not args.no_auc:
         log("AUC leg: %d training steps on planted-signal rows" % args.auc_steps)
-        del batches[1:]
         auc = auc_leg(c, device, rank, world, args.auc_steps, tmp)
         log("AUC leg done: test AUC %.4f" % auc["test_auc"])
 
@@ -375,8 +525,8 @@ def main():
                       else "training sequences/sec (fwd+BPTT+clip+dense Adam)",
             "value": seqs / elapsed, "unit": "sequences/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": c["name"], "config_id": args.config, "per_gpu_batch": c["batch"],
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": c["name"], "config_id": args.config, "per_gpu_batch": per_gpu,
                        "global_batch": global_batch, "max_len": c["T"], "scan_steps": layer_lengths(c),
                        "hidden": c["H"], "layers": c["K"], "vocab_rows": c["V"], "keep_prob": 0.5,
                        "parallelism": "dp%d" % world, "predictions_finite": finite},
@@ -386,9 +536,13 @@ def main():
         result["eval_sequences_per_s"] = eval_seq_per_s        # forward only, rank-0 clock (not barrier-bracketed)
         if auc is not None:
             result["auc"] = auc
+        if not args.no_parity_gate:
+            log("parity gate (golden vectors)")
+            result["parity_gate"] = parity_gate(device, tmp)
+            log("parity gate: pass=%s max|dlogit| %.2e" % (result["parity_gate"]["pass"], result["parity_gate"]["max_abs_logit"]))
         if not args.no_roofline:
             log("roofline probes")
-            roof, extra = roofline_probes(model, c, batches[0][0])
+            roof, extra = roofline_probes(model, c, batches, step)
             result["roofline"] = roof
             result["kernels"] = extra
         if not args.no_cpu_baseline and world == 1:

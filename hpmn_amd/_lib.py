@@ -121,6 +121,18 @@ class HpmnPipe(C.Structure):
     ]
 
 
+class HpmnTrainLayout(C.Structure):
+    _fields_ = [
+        ("K", C.c_int32), ("pad", C.c_int32),
+        ("T", C.c_int32 * HPMN_MAX_LAYERS),
+        ("x0", C.c_uint64),
+        ("xp", C.c_uint64 * HPMN_MAX_LAYERS), ("hs", C.c_uint64 * HPMN_MAX_LAYERS),
+        ("gates", C.c_uint64 * HPMN_MAX_LAYERS), ("y", C.c_uint64 * HPMN_MAX_LAYERS),
+        ("d_act", C.c_uint64 * HPMN_MAX_LAYERS), ("d_x", C.c_uint64 * HPMN_MAX_LAYERS),
+        ("wgrad_ws", C.c_uint64), ("total_bytes", C.c_uint64),
+    ]
+
+
 class HpmnOnlineUpdate(C.Structure):
     _fields_ = [
         ("B", C.c_int32), ("D", C.c_int32), ("H", C.c_int32), ("K", C.c_int32),
@@ -160,6 +172,18 @@ SIGNATURES = {
     "hpmn_gru_fused_fwd_supported": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),
     "hpmn_gru_fused_fwd": (C.c_int, [C.POINTER(HpmnGruFusedFwd), C.c_void_p]),
     "hpmn_memory_update": (C.c_int, [C.POINTER(HpmnOnlineUpdate), C.c_void_p]),
+    "hpmn_train_ctx_create": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "hpmn_train_ctx_destroy": (None, [C.c_void_p]),
+    "hpmn_scan_train_workspace_bytes": (C.c_size_t, [C.POINTER(HpmnScanDesc)]),
+    "hpmn_scan_train_layout": (C.c_int, [C.POINTER(HpmnScanDesc), C.POINTER(HpmnTrainLayout)]),
+    "hpmn_scan_fwd_train": (C.c_int, [C.c_void_p, C.POINTER(HpmnScanDesc), C.c_void_p, C.c_void_p,
+                                      C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                      C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hpmn_scan_bwd": (C.c_int, [C.c_void_p, C.POINTER(HpmnScanDesc), C.c_void_p, C.POINTER(C.c_void_p),
+                                C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p),
+                                C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p,
+                                C.c_void_p, C.c_int32, C.c_void_p]),
+    "hpmn_train_join": (C.c_int, [C.c_void_p, C.c_void_p]),
     "hpmn_pipe_supported": (C.c_int, [C.c_int32, C.c_int32]),
     "hpmn_pipe_sync_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "hpmn_pipe_fwd": (C.c_int, [C.POINTER(HpmnPipe), C.c_void_p]),

@@ -409,21 +409,36 @@ __global__ __launch_bounds__(256) void embed_gather_seq_kernel(const int32_t *__
                                                                const float *__restrict__ emb, float *__restrict__ out,
                                                                long total4, int E4, int F, int Tids, int front_zero,
                                                                int mask_id0) {
+    // Four items per thread and pass: the four ids first, then the four (dependent) row loads, then the stores --
+    // a cold table (rows are 64-byte random HBM reads) is latency-bound unless many rows are in flight per wave.
+    constexpr int U = 4;
     const long stride = (long)gridDim.x * blockDim.x;
     const int T0 = Tids + front_zero;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += stride) {
-        const long row = i / E4;                 // (b, t, f)
-        const int e4 = (int)(i - row * E4);
-        const long bt = row / F;
-        const int f = (int)(row - bt * F);
-        const long bb = bt / T0;
-        const int t = (int)(bt - bb * T0) - front_zero;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (t >= 0) {
-            const int id = ids[(bb * Tids + t) * F + f];
-            if (!(mask_id0 && id == 0)) v = reinterpret_cast<const float4 *>(emb)[(long)id * E4 + e4];
+    for (long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x; i0 < total4; i0 += U * stride) {
+        int id[U], e4[U];
+        bool real[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long i = i0 + u * stride;
+            const long ic = i < total4 ? i : total4 - 1;
+            const long row = ic / E4;                 // (b, t, f)
+            e4[u] = (int)(ic - row * E4);
+            const long bt = row / F;
+            const int f = (int)(row - bt * F);
+            const long bb = bt / T0;
+            const int t = (int)(bt - bb * T0) - front_zero;
+            real[u] = t >= 0;
+            id[u] = ids[(bb * Tids + (t >= 0 ? t : 0)) * F + f];
         }
-        reinterpret_cast<float4 *>(out)[i] = v;
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = reinterpret_cast<const float4 *>(emb)[(long)id[u] * E4 + e4[u]];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long i = i0 + u * stride;
+            if (!real[u] || (mask_id0 && id[u] == 0)) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < total4) reinterpret_cast<float4 *>(out)[i] = v[u];
+        }
     }
 }
 
@@ -431,8 +446,8 @@ int embed_gather_seq_launch(const int32_t *ids, const float *emb, float *out, in
                             int front_zero, int mask_id0, hipStream_t st) {
     const long total4 = (long)B * (Tids + front_zero) * F * E / 4;
     if (total4 == 0) return HPMN_OK;
-    long blocks = (total4 + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
+    long blocks = (total4 + 4 * 256 - 1) / (4 * 256);
+    if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(embed_gather_seq_kernel, dim3((unsigned)blocks), dim3(256), 0, st, ids, emb, out, total4, E / 4,
                        F, Tids, front_zero, mask_id0);
     return check_launch();

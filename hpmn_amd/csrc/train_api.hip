@@ -1,0 +1,249 @@
+// Whole-graph TRAINING entry points of the C ABI: build_memory with saved states and its BPTT as two
+// calls, hpmn_scan_fwd_train / hpmn_scan_bwd, over one caller-provided workspace.  Everything the Python host used
+// to orchestrate -- the per-layer launches, the weight-gradient reductions running on a helper stream underneath
+// the serial chain (fork / join with events on the caller's stream), the row add of d_last, the embedding scatter
+// -- happens inside the library, so a non-Python host can run a training step through the ABI alone.
+#include <mutex>
+
+#include "common.h"
+
+namespace hpmn {
+int embed_gather_launch(const int32_t *ids, int64_t ids_stride, const float *emb, float *out, int64_t N, int32_t F,
+                        int32_t E, int32_t mask_id0, hipStream_t st);
+bool gru_fused_fwd_supported(int H, int D, int gather);
+size_t gru_wgrad_workspace_bytes(int B, int T, int D, int H);
+
+struct TrainCtx {
+    int device = -1, cus = 256;
+    hipStream_t side = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+    bool pending = false;
+};
+
+static size_t up256(size_t x) { return (x + 255) / 256 * 256; }
+
+static bool lengths(const HpmnScanDesc &d, int32_t *len) {
+    if (d.K < 1 || d.K > HPMN_MAX_LAYERS) return false;
+    long t = (long)d.T + d.front_zero;
+    for (int i = 0; i < d.K; ++i) {
+        len[i] = (int32_t)t;
+        if (d.periods[i] < 1 || t % d.periods[i] != 0) return false;
+        t /= d.periods[i];
+    }
+    return true;
+}
+
+static bool layout(const HpmnScanDesc &d, HpmnTrainLayout &L) {
+    int32_t len[HPMN_MAX_LAYERS];
+    if (d.B < 1 || d.H < 1 || d.F < 1 || d.E < 1 || !lengths(d, len)) return false;
+    const size_t B = d.B, H = d.H, D0 = (size_t)d.F * d.E;
+    size_t off = 0, wmax = 0;
+    auto take = [&](size_t floats) { const size_t o = off; off += up256(floats * sizeof(float)); return o; };
+    L = HpmnTrainLayout{};
+    L.K = d.K;
+    L.x0 = take(B * len[0] * D0);
+    for (int i = 0; i < d.K; ++i) {
+        const size_t T = len[i], D = i == 0 ? D0 : H;
+        L.T[i] = len[i];
+        L.xp[i] = take(B * T * 3 * H);
+        L.hs[i] = take(B * (T + 1) * H);
+        L.gates[i] = take(B * T * 3 * H);
+        L.y[i] = i + 1 < d.K ? take(B * (T / d.periods[i]) * H) : 0;
+        L.d_act[i] = take(B * T * 3 * H);
+        L.d_x[i] = take(B * T * D);
+        const size_t w = gru_wgrad_workspace_bytes(d.B, len[i], (int)D, d.H);
+        wmax = w > wmax ? w : wmax;
+    }
+    L.wgrad_ws = off;
+    off += up256(wmax);
+    L.total_bytes = off + 256;
+    return true;
+}
+
+__global__ void add_rows_kernel(float *dst, long dst_stride, const float *src, int B, int D) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (long)B * D) {
+        const long b = i / D;
+        dst[b * dst_stride + (i - b * D)] += src[i];
+    }
+}
+}  // namespace hpmn
+
+using namespace hpmn;
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_last_hip_error((int)e_); return HPMN_EHIP; } } while (0)
+
+extern "C" {
+
+int hpmn_train_ctx_create(HpmnTrainCtx **out) {
+    (void)hipGetLastError();
+    if (!out) return HPMN_EINVAL;
+    TrainCtx *c = new TrainCtx();
+    if (hipGetDevice(&c->device) != hipSuccess) { delete c; return HPMN_ENODEVICE; }
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && n > 0) c->cus = n;
+    if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->join, hipEventDisableTiming) != hipSuccess) {
+        set_last_hip_error((int)hipGetLastError());
+        delete c;
+        return HPMN_EHIP;
+    }
+    *out = reinterpret_cast<HpmnTrainCtx *>(c);
+    return HPMN_OK;
+}
+
+void hpmn_train_ctx_destroy(HpmnTrainCtx *ctx) {
+    TrainCtx *c = reinterpret_cast<TrainCtx *>(ctx);
+    if (!c) return;
+    if (c->side) (void)hipStreamSynchronize(c->side);
+    if (c->fork) (void)hipEventDestroy(c->fork);
+    if (c->join) (void)hipEventDestroy(c->join);
+    if (c->side) (void)hipStreamDestroy(c->side);
+    delete c;
+}
+
+int hpmn_scan_train_layout(const HpmnScanDesc *d, HpmnTrainLayout *out) {
+    if (!d || !out) return HPMN_EINVAL;
+    return layout(*d, *out) ? HPMN_OK : HPMN_EINVAL;
+}
+
+size_t hpmn_scan_train_workspace_bytes(const HpmnScanDesc *d) {
+    HpmnTrainLayout L;
+    if (!d || !layout(*d, L)) return 0;
+    return L.total_bytes;
+}
+
+int hpmn_scan_fwd_train(HpmnTrainCtx *ctx, const HpmnScanDesc *d, const int32_t *ids, const float *emb,
+                        const float *const *wg, const float *const *bg, const float *const *wc,
+                        const float *const *bc, float *memory, float *last, void *workspace, void *stream) {
+    (void)hipGetLastError();
+    TrainCtx *c = reinterpret_cast<TrainCtx *>(ctx);
+    if (!c || !d || !ids || !emb || !wg || !bg || !wc || !bc || !memory || !workspace) return HPMN_EINVAL;
+    if (d->B < 0 || d->T < 1 || d->F < 1 || d->E < 4 || d->H < 1 || d->V < 1) return HPMN_EINVAL;
+    if (d->B == 0) return HPMN_OK;
+    HpmnTrainLayout L;
+    if (!layout(*d, L)) return HPMN_EINVAL;
+    if (d->last_index >= 0 || -d->last_index > L.T[0]) return HPMN_EINVAL;
+    const int D0 = d->F * d->E;
+    if (!hpmn_gru_shape_supported(d->H, D0) || (d->K > 1 && !hpmn_gru_shape_supported(d->H, d->H))) return HPMN_EUNSUPPORTED;
+    char *ws = reinterpret_cast<char *>((reinterpret_cast<size_t>(workspace) + 255) / 256 * 256);
+    auto F = [&](size_t off) { return reinterpret_cast<float *>(ws + off); };
+    // the fused layer spends a second wave per sequence on a SIMD that would otherwise idle: a win while 2 B waves
+    // still find (about) a SIMD each (measured at C3: +3.7 % at B=500, -6.6 % at B=750 / 1000)
+    const bool room = 2.0 * d->B <= 1.1 * 4 * c->cus;
+    for (int i = 0; i < d->K; ++i) {
+        const int D = i == 0 ? D0 : d->H;
+        const bool fused = room && gru_fused_fwd_supported(d->H, D, i == 0) && (i > 0 || 64 % d->E == 0);
+        float *y = i + 1 < d->K ? F(L.y[i]) : nullptr;
+        int rc;
+        if (fused) {
+            HpmnGruFusedFwd a = {};
+            a.B = d->B; a.T = L.T[i]; a.D = D; a.H = d->H;
+            if (i == 0) {
+                a.ids = ids; a.emb = emb; a.Tids = d->T; a.F = d->F; a.E = d->E; a.front_zero = d->front_zero;
+                a.mask_id0 = d->mask_id0; a.V = d->V; a.x_out = F(L.x0);
+            } else {
+                a.x = F(L.y[i - 1]);
+            }
+            a.wg = wg[i]; a.bg = bg[i]; a.wc = wc[i]; a.bc = bc[i];
+            a.h_last = memory + (size_t)i * d->H; a.h_last_stride = (int64_t)d->K * d->H;
+            a.y = y; a.period = d->periods[i]; a.hs = F(L.hs[i]); a.gates = F(L.gates[i]);
+            rc = hpmn_gru_fused_fwd(&a, stream);
+        } else {
+            HpmnInputProj p = {};
+            p.B = d->B; p.T = L.T[i]; p.D = D; p.H = d->H;
+            if (i == 0) {
+                p.ids = ids; p.emb = emb; p.Tids = d->T; p.F = d->F; p.E = d->E; p.front_zero = d->front_zero;
+                p.mask_id0 = d->mask_id0; p.V = d->V; p.x_out = F(L.x0);
+            } else {
+                p.x = F(L.y[i - 1]);
+            }
+            p.wg = wg[i]; p.bg = bg[i]; p.wc = wc[i]; p.bc = bc[i]; p.xp = F(L.xp[i]);
+            rc = hpmn_gru_input_proj(&p, stream);
+            if (rc != HPMN_OK) return rc;
+            HpmnGruFwd a = {};
+            a.B = d->B; a.T = L.T[i]; a.D = D; a.H = d->H;
+            a.xp = F(L.xp[i]); a.wg = wg[i]; a.wc = wc[i];
+            a.h_last = memory + (size_t)i * d->H; a.h_last_stride = (int64_t)d->K * d->H;
+            a.y = y; a.period = d->periods[i]; a.hs = F(L.hs[i]); a.gates = F(L.gates[i]);
+            rc = hpmn_gru_scan_fwd(&a, stream);
+        }
+        if (rc != HPMN_OK) return rc;
+    }
+    if (last) {
+        // uinp[:, last_index, :] (code/hpmn.py:439 / :292): a row of the materialised layer-0 input
+        const size_t row = (size_t)(L.T[0] + d->last_index) * D0;
+        HIPCHK(hipMemcpy2DAsync(last, (size_t)D0 * sizeof(float), F(L.x0) + row, (size_t)L.T[0] * D0 * sizeof(float),
+                                (size_t)D0 * sizeof(float), d->B, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    }
+    return HPMN_OK;
+}
+
+int hpmn_scan_bwd(HpmnTrainCtx *ctx, const HpmnScanDesc *d, const int32_t *ids, const float *const *wg,
+                  const float *const *wc, const float *d_memory, const float *d_last, float *const *d_wg,
+                  float *const *d_bg, float *const *d_wc, float *const *d_bc, float *d_emb, void *workspace,
+                  int32_t defer_join, void *stream) {
+    (void)hipGetLastError();
+    TrainCtx *c = reinterpret_cast<TrainCtx *>(ctx);
+    if (!c || !d || !ids || !wg || !wc || !d_memory || !d_wg || !d_bg || !d_wc || !d_bc || !d_emb || !workspace)
+        return HPMN_EINVAL;
+    if (d->B == 0) return HPMN_OK;
+    HpmnTrainLayout L;
+    if (!layout(*d, L)) return HPMN_EINVAL;
+    const int D0 = d->F * d->E;
+    char *ws = reinterpret_cast<char *>((reinterpret_cast<size_t>(workspace) + 255) / 256 * 256);
+    auto F = [&](size_t off) { return reinterpret_cast<float *>(ws + off); };
+    hipStream_t st = (hipStream_t)stream;
+    for (int i = d->K - 1; i >= 0; --i) {
+        const int D = i == 0 ? D0 : d->H;
+        HpmnGruBwd a = {};
+        a.B = d->B; a.T = L.T[i]; a.D = D; a.H = d->H;
+        a.wg = wg[i]; a.wc = wc[i]; a.hs = F(L.hs[i]); a.gates = F(L.gates[i]);
+        a.d_h_last = d_memory + (size_t)i * d->H; a.d_h_last_stride = (int64_t)d->K * d->H;
+        a.d_y = i + 1 < d->K ? F(L.d_x[i + 1]) : nullptr;
+        a.period = d->periods[i];
+        a.d_act = F(L.d_act[i]);
+        int rc = hpmn_gru_scan_bwd(&a, stream);
+        if (rc != HPMN_OK) return rc;
+        // the weight gradient of this layer: an MFMA reduction over d_act, off the serial chain, on the helper stream
+        HIPCHK(hipEventRecord(c->fork, st));
+        HIPCHK(hipStreamWaitEvent(c->side, c->fork, 0));
+        HpmnGruWgrad w = {};
+        w.B = d->B; w.T = L.T[i]; w.D = D; w.H = d->H;
+        w.x = i == 0 ? F(L.x0) : F(L.y[i - 1]);
+        w.hs = F(L.hs[i]); w.gates = F(L.gates[i]); w.d_act = F(L.d_act[i]);
+        w.wg = wg[i]; w.wc = wc[i];
+        w.d_wg = d_wg[i]; w.d_bg = d_bg[i]; w.d_wc = d_wc[i]; w.d_bc = d_bc[i];
+        w.workspace = F(L.wgrad_ws);
+        rc = hpmn_gru_param_grads(&w, c->side);
+        if (rc != HPMN_OK) return rc;
+        c->pending = true;
+        rc = hpmn_gru_input_grad(F(L.d_act[i]), wg[i], wc[i], F(L.d_x[i]), d->B, L.T[i], D, d->H, 0, 0, stream);
+        if (rc != HPMN_OK) return rc;
+    }
+    if (d_last) {
+        const long n = (long)d->B * D0;
+        hipLaunchKernelGGL(add_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                           F(L.d_x[0]) + (size_t)(L.T[0] + d->last_index) * D0, (long)L.T[0] * D0, d_last, d->B, D0);
+        int rc = check_launch();
+        if (rc != HPMN_OK) return rc;
+    }
+    int rc = hpmn_embed_grad_scatter(ids, F(L.d_x[0]), d_emb, d->B, d->T, d->F, d->E, d->front_zero, d->V, d->mask_id0,
+                                     stream);
+    if (rc != HPMN_OK) return rc;
+    if (!defer_join) return hpmn_train_join(ctx, stream);
+    return HPMN_OK;
+}
+
+int hpmn_train_join(HpmnTrainCtx *ctx, void *stream) {
+    TrainCtx *c = reinterpret_cast<TrainCtx *>(ctx);
+    if (!c) return HPMN_EINVAL;
+    if (!c->pending) return HPMN_OK;
+    HIPCHK(hipEventRecord(c->join, c->side));
+    HIPCHK(hipStreamWaitEvent((hipStream_t)stream, c->join, 0));
+    c->pending = false;
+    return HPMN_OK;
+}
+
+}  // extern "C"

@@ -595,14 +595,120 @@ def upper_backward(spec: ScanSpec, ids, saved, weights, d_memory, d_last, grad_o
     return None
 
 
+# ---------------------------------------------------------------------------------------
+# the whole training graph behind two C entry points (hpmn_scan_fwd_train / hpmn_scan_bwd): the default
+# ---------------------------------------------------------------------------------------
+TRAIN_ABI = int(os.environ.get("HPMN_TRAIN_ABI", "1")) != 0
+_train_ctx = {}
+
+
+def _ctx(device) -> int:
+    """One HpmnTrainCtx (helper stream + events) per (device, launch stream)."""
+    key = (str(device), torch.cuda.current_stream().cuda_stream)
+    h = _train_ctx.get(key)
+    if h is None:
+        out = C.c_void_p()
+        _lib.check(_lib.load().hpmn_train_ctx_create(C.byref(out)), "hpmn_train_ctx_create")
+        h = _train_ctx[key] = out.value
+    return h
+
+
+class AbiSaved:
+    """Saved states of hpmn_scan_fwd_train: one workspace + its layout.  Iterating yields the per-layer
+    (x_in, hs, gates) views the per-layer Python path returns, for inspection."""
+
+    def __init__(self, spec, B, V, workspace, layout, desc):
+        self.spec, self.B, self.V, self.workspace, self.layout, self.desc = spec, B, V, workspace, layout, desc
+
+    def _view(self, off, shape):
+        base = (-self.workspace.data_ptr()) % 256
+        n = 1
+        for d_ in shape:
+            n *= d_
+        return self.workspace[base + off: base + off + 4 * n].view(torch.float32).view(*shape)
+
+    def tensor(self, name, i=0):
+        L, H, B = self.layout, self.spec.H, self.B
+        T = L.T[i]
+        D = self.spec.D0 if i == 0 else H
+        if name == "x0":
+            return self._view(L.x0, (B, L.T[0], self.spec.D0))
+        shape = {"hs": (B, T + 1, H), "gates": (B, T, 3 * H), "y": (B, T // self.spec.periods[i], H),
+                 "d_act": (B, T, 3 * H), "d_x": (B, T, D)}[name]
+        return self._view(getattr(L, name)[i], shape)
+
+    def __iter__(self):
+        for i in range(self.spec.K):
+            x_in = self.tensor("x0") if i == 0 else self.tensor("y", i - 1)
+            yield (x_in, self.tensor("hs", i), self.tensor("gates", i))
+
+    def __getitem__(self, i):
+        return list(self)[i]
+
+
+def _wptrs(weights, K, j):
+    return (C.c_void_p * K)(*[weights[4 * i + j].data_ptr() for i in range(K)])
+
+
+def abi_forward_train(spec: ScanSpec, ids, emb, weights: Sequence[torch.Tensor]):
+    """hpmn_scan_fwd_train: the training forward of build_memory in ONE library call."""
+    _chk_ids(ids)
+    _chk_f32(emb, *weights)
+    B, K, H = ids.shape[0], spec.K, spec.H
+    V = emb.shape[0]
+    lib = _lib.load()
+    d = spec.desc(B, V)
+    lay = _lib.HpmnTrainLayout()
+    _lib.check(lib.hpmn_scan_train_layout(C.byref(d), C.byref(lay)), "hpmn_scan_train_layout")
+    ws = torch.empty(int(lay.total_bytes), device=emb.device, dtype=torch.uint8)
+    memory = torch.empty(B, K, H, device=emb.device, dtype=torch.float32)
+    last = torch.empty(B, spec.D0, device=emb.device, dtype=torch.float32)
+    rc = lib.hpmn_scan_fwd_train(_ctx(emb.device), C.byref(d), ids.data_ptr(), emb.data_ptr(), _wptrs(weights, K, 0),
+                                 _wptrs(weights, K, 1), _wptrs(weights, K, 2), _wptrs(weights, K, 3),
+                                 memory.data_ptr(), last.data_ptr(), ws.data_ptr(), _stream())
+    _lib.check(rc, "hpmn_scan_fwd_train")
+    return memory, last, AbiSaved(spec, B, V, ws, lay, d)
+
+
+class _AbiPending:
+    def __init__(self, ctx, refs):
+        self._ctx, self._refs = ctx, refs
+
+    def join(self):
+        if self._ctx is not None:
+            _lib.check(_lib.load().hpmn_train_join(self._ctx, _stream()), "hpmn_train_join")
+            self._ctx, self._refs = None, None
+
+
+def abi_backward(spec: ScanSpec, ids, saved: "AbiSaved", weights, d_memory, d_last, grad_out, defer_join=False):
+    """hpmn_scan_bwd: BPTT of abi_forward_train in ONE library call (weight gradients on the context's helper
+    stream; with ``defer_join`` they may still be running when this returns -- see PendingGrads)."""
+    K = spec.K
+    _chk_f32(d_memory, d_last, *grad_out)
+    assert d_memory.is_contiguous() and d_last.is_contiguous()
+    gw = list(grad_out[1:])
+    arr = lambda j: (C.c_void_p * K)(*[gw[4 * i + j].data_ptr() for i in range(K)])
+    ctx = _ctx(d_memory.device)
+    rc = _lib.load().hpmn_scan_bwd(ctx, C.byref(saved.desc), ids.data_ptr(), _wptrs(weights, K, 0),
+                                   _wptrs(weights, K, 2), d_memory.data_ptr(), d_last.data_ptr(), arr(0), arr(1),
+                                   arr(2), arr(3), grad_out[0].data_ptr(), saved.workspace.data_ptr(),
+                                   int(defer_join), _stream())
+    _lib.check(rc, "hpmn_scan_bwd")
+    if defer_join:
+        return _AbiPending(ctx, (saved, weights))
+    return None
+
+
 def scan_forward_train(spec: ScanSpec, ids, emb, weights: Sequence[torch.Tensor]):
-    """Training-mode build_memory: pipelined launches where the shape has them (pipe_mode), else the per-layer
-    kernels below."""
+    """Training-mode build_memory.  Default: the whole graph in one library call (hpmn_scan_fwd_train); the
+    pipelined launches (pipe_mode) and the per-layer Python orchestration below are options."""
     mode = pipe_mode(spec) if ids.shape[0] > 0 else ""
     if mode == "all":
         return pipe_forward(spec, ids, emb, weights, train=True)
     if mode == "upper":
         return upper_forward(spec, ids, emb, weights)
+    if TRAIN_ABI and PIPELINE_CHUNKS <= 1 and FUSED_FWD and not SPLIT_LAYER0_BWD and ids.shape[0] > 0:
+        return abi_forward_train(spec, ids, emb, weights)
     return scan_forward_train_layers(spec, ids, emb, weights)
 
 
@@ -681,6 +787,10 @@ def scan_forward_train_layers(spec: ScanSpec, ids, emb, weights: Sequence[torch.
     return memory, last, saved
 
 
+# bench.py sets this to a list: the layer-0 reverse scan of every step is then bracketed by HIP events on the launch
+# stream (the weight-gradient kernels of the layer above are live on the side stream, as in any step)
+PROBE = None
+
 # measured neutral (C3 4.143 vs 4.169 ms/step, C4 10.48 vs 10.33): off by default, kept as an option
 SPLIT_LAYER0_BWD = int(os.environ.get("HPMN_SPLIT_LAYER0_BWD", "0")) != 0
 
@@ -713,6 +823,11 @@ class PendingGrads:
 def scan_backward(spec: ScanSpec, ids, saved, weights: Sequence[torch.Tensor], d_memory, d_last, grad_out,
                   defer_join: bool = False):
     """BPTT of scan_forward_train (every forward path leaves the same saved states)."""
+    if isinstance(saved, AbiSaved):
+        if PROBE is None:
+            return abi_backward(spec, ids, saved, weights, d_memory, d_last, grad_out, defer_join)
+        saved = list(saved)            # bench.py's in-step probe brackets a launch: per-layer path over the same states
+        return scan_backward_layers(spec, ids, saved, weights, d_memory, d_last, grad_out, defer_join)
     mode = pipe_mode(spec) if d_memory.shape[0] > 0 else ""
     if mode == "all":
         return pipe_backward(spec, ids, saved, weights, d_memory, d_last, grad_out, defer_join)
@@ -769,7 +884,13 @@ def scan_backward_layers(spec: ScanSpec, ids, saved, weights: Sequence[torch.Ten
                     gru_param_grads(x_in, hs, gates, d_act[i], wg, wc, gw[4 * i], gw[4 * i + 1], gw[4 * i + 2],
                                     gw[4 * i + 3], want_dx=False, keep=keep, t_range=(0, cut))
             else:
+                if PROBE is not None and i == 0:      # bench.py: the dominant kernel timed INSIDE a real step
+                    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                    ev[0].record(main)
                 gru_scan_bwd(wg, wc, in_dims[i], hs, gates, d_memory[:, i, :], d_y, spec.periods[i], out=d_act[i])
+                if PROBE is not None and i == 0:
+                    ev[1].record(main)
+                    PROBE.append(ev)
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
                     gru_param_grads(x_in, hs, gates, d_act[i], wg, wc, gw[4 * i], gw[4 * i + 1], gw[4 * i + 2],

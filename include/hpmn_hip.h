@@ -10,7 +10,8 @@
  *
  * Conventions
  *  - every pointer is a DEVICE pointer borrowed from the caller (PyTorch tensors in
- *    this repo); the library never allocates, frees or synchronises;
+ *    this repo); the library never allocates device memory, frees or synchronises (the only objects it
+ *    creates are the helper stream + two events of an HpmnTrainCtx);
  *  - all work is enqueued on `stream` (a hipStream_t passed as void*); no host sync;
  *  - all tensors are dense row-major, fp32 unless stated, ids are int32;
  *  - return value: 0 (HPMN_OK) or a negative HPMN_E* code; a failing HIP runtime call
@@ -231,6 +232,53 @@ int hpmn_scan_fwd(const HpmnScanDesc *desc, const int32_t *ids, const float *emb
                   const float *const *wc, const float *const *bc,
                   float *memory, float *last, void *workspace, void *stream);
 
+
+/* ------------------------------------------------------------------------------------
+ * Whole build_memory in TRAINING form and its BPTT, as two calls over one workspace (the
+ * hpmn_scan_fwd(..., saved, ...) / hpmn_scan_bwd(...) pair).  Replaces, for the "User" branch, everything TF
+ * executes for code/hpmn.py:113-129 in sess.run(train_step) (code/hpmn.py:482, :336) and TF's autodiff of it,
+ * including the densified embedding gradient (code/hpmn.py:204-205).
+ *
+ *   hpmn_scan_fwd_train : ids [B,T,F], emb [V,E], K layers' (wg, bg, wc, bc)  ->  memory [B,K,H],
+ *                         last [B,F*E] (= uinp[:, last_index, :], may be NULL); saved states stay in `workspace`
+ *   hpmn_scan_bwd       : d_memory [B,K,H], d_last [B,F*E] (may be NULL) + the workspace of the forward call
+ *                         ->  d_wg/d_bg/d_wc/d_bc[i] += (K pointers each, the optimiser's pre-zeroed buffers),
+ *                             d_emb [V,E] += scatter of the input gradient (pre-zeroed by the caller)
+ *
+ * The serial chain (reverse scans, input gradients, scatter) runs on `stream`; the weight-gradient reductions run
+ * on a helper stream owned by the context, forked and joined with events on `stream`.  With defer_join != 0
+ * hpmn_scan_bwd returns with the helper stream still busy: d_emb is complete on `stream`, the d_w* buffers are not
+ * until hpmn_train_join(ctx, stream) -- lets the caller update the (large) table underneath them.
+ * A context serves one stream at a time; contexts are cheap (one stream, two events) and device-bound.
+ * workspace: hpmn_scan_train_workspace_bytes(desc) bytes; hpmn_scan_train_layout gives the byte offsets (from
+ * the 256-byte-aligned base) of the saved tensors for hosts that want to inspect them.
+ * ---------------------------------------------------------------------------------- */
+typedef struct HpmnTrainCtx HpmnTrainCtx;
+typedef struct HpmnTrainLayout {
+    int32_t K, pad;
+    int32_t T[HPMN_MAX_LAYERS];
+    uint64_t x0;                           /* [B, T[0], F*E] materialised layer-0 input                     */
+    uint64_t xp[HPMN_MAX_LAYERS];          /* [B, T[i], 3H]  (only used by the two-kernel layers)          */
+    uint64_t hs[HPMN_MAX_LAYERS];          /* [B, T[i]+1, H]                                               */
+    uint64_t gates[HPMN_MAX_LAYERS];       /* [B, T[i], 3H]                                                */
+    uint64_t y[HPMN_MAX_LAYERS];           /* [B, T[i]/period[i], H]  (i < K-1)                            */
+    uint64_t d_act[HPMN_MAX_LAYERS];       /* [B, T[i], 3H]                                                */
+    uint64_t d_x[HPMN_MAX_LAYERS];         /* [B, T[i], D_i]                                               */
+    uint64_t wgrad_ws, total_bytes;
+} HpmnTrainLayout;
+
+int hpmn_train_ctx_create(HpmnTrainCtx **ctx);
+void hpmn_train_ctx_destroy(HpmnTrainCtx *ctx);
+size_t hpmn_scan_train_workspace_bytes(const HpmnScanDesc *desc);
+int hpmn_scan_train_layout(const HpmnScanDesc *desc, HpmnTrainLayout *out);
+int hpmn_scan_fwd_train(HpmnTrainCtx *ctx, const HpmnScanDesc *desc, const int32_t *ids, const float *emb,
+                        const float *const *wg, const float *const *bg, const float *const *wc,
+                        const float *const *bc, float *memory, float *last, void *workspace, void *stream);
+int hpmn_scan_bwd(HpmnTrainCtx *ctx, const HpmnScanDesc *desc, const int32_t *ids, const float *const *wg,
+                  const float *const *wc, const float *d_memory, const float *d_last, float *const *d_wg,
+                  float *const *d_bg, float *const *d_wc, float *const *d_bc, float *d_emb, void *workspace,
+                  int32_t defer_join, void *stream);
+int hpmn_train_join(HpmnTrainCtx *ctx, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * build_memory with ALL K layers in ONE launch (H = 64): forward hpmn_pipe_fwd, BPTT hpmn_pipe_bwd.

@@ -634,3 +634,61 @@ def test_pipelined_mfma_scan_matches_oracle_and_per_layer_kernels(dev, tmp_path,
         np.testing.assert_allclose(out["memory"].cpu().numpy(), out0["memory"].cpu().numpy(), rtol=0, atol=TOL)
         np.testing.assert_allclose(g_pipe.cpu().numpy(), m.flat_grad.cpu().numpy(), rtol=0,
                                    atol=5e-4 * float(m.flat_grad.abs().max()))
+
+
+# ------------------------------------------------------------------------------- training graph through the C ABI
+def test_training_step_through_the_c_abi_alone(dev, tmp_path):
+    """hpmn_scan_fwd_train -> hpmn_read_fwd_bwd -> hpmn_scan_bwd (+ hpmn_train_join) -> hpmn_adam_step called
+    directly through ctypes -- no Python orchestration of layers, streams or events, torch only lends the device
+    memory: gradients vs float64 autograd, the parameter update vs the oracle's TF-form Adam."""
+    import ctypes as C
+    from hpmn_amd import _lib
+    lib = _lib.load()
+    cfg = cfg_industry(H=64, K=4, T=41, V=150)
+    B = 6
+    p = f32_params(cfg, 121)
+    ids, label = rand_ids(cfg, B, 122)
+    m = make_model(cfg, tmp_path, p)            # only used as the owner of the flat parameter / gradient buffers
+    spec, K, H, D0 = m.spec, cfg.user_num_layers, 64, 32
+    st = torch.cuda.current_stream().cuda_stream
+    t_ids, t_lab = torch.as_tensor(ids).to(dev), torch.as_tensor(label).to(dev)
+    ctx = C.c_void_p()
+    assert lib.hpmn_train_ctx_create(C.byref(ctx)) == 0
+    d = spec.desc(B, cfg.feature_size)
+    ws = torch.empty(lib.hpmn_scan_train_workspace_bytes(C.byref(d)), device=dev, dtype=torch.uint8)
+    w = m._gru_weights()
+    arr = lambda ts: (C.c_void_p * K)(*[t.data_ptr() for t in ts])
+    memory, last = torch.empty(B, K, H, device=dev), torch.empty(B, D0, device=dev)
+    m.flat_grad.zero_()
+    emb = m.params["Embedding/emb_mtx"]
+    assert lib.hpmn_scan_fwd_train(ctx, C.byref(d), t_ids.data_ptr(), emb.data_ptr(), arr(w[0::4]), arr(w[1::4]),
+                                   arr(w[2::4]), arr(w[3::4]), memory.data_ptr(), last.data_ptr(), ws.data_ptr(), st) == 0
+    rd = m._read_desc
+    rd.B = B
+    rws = torch.zeros(lib.hpmn_read_workspace_bytes(C.byref(rd)) // 4, device=dev)
+    pred, loss = torch.empty(B, device=dev), torch.zeros(2, device=dev)
+    d_mem, d_last = torch.empty_like(memory), torch.empty_like(last)
+    assert lib.hpmn_read_fwd_bwd(C.byref(rd), m._read_params.data_ptr(), memory.data_ptr(), last.data_ptr(),
+                                 t_lab.data_ptr(), None, None, 1.0, 1.0 / B, cfg.memory_reg, pred.data_ptr(),
+                                 loss.data_ptr(), d_mem.data_ptr(), d_last.data_ptr(), m._read_grads.data_ptr(),
+                                 rws.data_ptr(), st) == 0
+    g = [m.grads[n] for names in m._gru_names for n in names]
+    assert lib.hpmn_scan_bwd(ctx, C.byref(d), t_ids.data_ptr(), arr(w[0::4]), arr(w[2::4]), d_mem.data_ptr(),
+                             d_last.data_ptr(), arr(g[0::4]), arr(g[1::4]), arr(g[2::4]), arr(g[3::4]),
+                             m.grads["Embedding/emb_mtx"].data_ptr(), ws.data_ptr(), 1, st) == 0
+    assert lib.hpmn_train_join(ctx, st) == 0
+    tp = R.to_torch(p, torch.float64, requires_grad=True)
+    ref = R.forward(cfg, tp, torch.as_tensor(ids.astype(np.int64)), torch.as_tensor(label.astype(np.int64)))
+    ref["cross_entropy"].backward()
+    for k in p:
+        wnt = tp[k].grad.numpy()
+        np.testing.assert_allclose(m.grads[k].cpu().numpy(), wnt, rtol=0, atol=2e-4 * max(1e-6, np.abs(wnt).max()) + 1e-6,
+                                   err_msg=k)
+    np.testing.assert_allclose(pred.cpu().numpy(), ref["prediction"].detach().numpy(), rtol=0, atol=TOL)
+    lr_t = 0.001 * math.sqrt(1 - 0.999) / (1 - 0.9)
+    before = m.flat_param.clone()
+    assert lib.hpmn_adam_step(m.flat_param.data_ptr(), m.flat_grad.data_ptr(), m.flat_m.data_ptr(), m.flat_v.data_ptr(),
+                              m.flat_param.numel(), lr_t, 0.9, 0.999, 1e-8, 1.0, 1.0, st) == 0
+    moved = (m.flat_param - before).abs()
+    assert float(moved.max()) <= 0.001 * 1.01 and float(moved.max()) > 1e-4      # first Adam step: |dp| ~ lr
+    lib.hpmn_train_ctx_destroy(ctx)
