@@ -49,5 +49,24 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     return OUT
 
 
+HOST_OUT = os.path.join(_HERE, "lib", "libhpmn_host.so")
+HOST_SRC = os.path.join(CSRC, "host", "crc32c.c")
+
+
+def build_host_library(force: bool = False) -> str:
+    """Host-only helpers (crc32c for the TF checkpoint files): plain C, gcc, no HIP."""
+    if not force and os.path.exists(HOST_OUT) and os.path.getmtime(HOST_OUT) >= os.path.getmtime(HOST_SRC):
+        return HOST_OUT
+    os.makedirs(os.path.dirname(HOST_OUT), exist_ok=True)
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if cc is None:
+        raise RuntimeError("no C compiler for the host helper library")
+    proc = subprocess.run([cc, "-O2", "-shared", "-fPIC", "-o", HOST_OUT + ".tmp", HOST_SRC], capture_output=True, text=True)
+    if proc.returncode != 0:
+        raise RuntimeError("host helper build failed:\n%s" % proc.stderr)
+    os.replace(HOST_OUT + ".tmp", HOST_OUT)
+    return HOST_OUT
+
+
 if __name__ == "__main__":
     print(build_library(force="--force" in sys.argv, verbose=True))

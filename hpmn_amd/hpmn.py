@@ -463,22 +463,42 @@ class Hpmn_Basic(object):
         return self._save_path
 
     def save_model(self, global_step=None):
+        """code/hpmn.py:91-92: ``saver.save(sess, save_path)`` -- written as the TensorFlow-1 tensor bundle the
+        reference's Saver produces (``model.ckpt.index`` + ``model.ckpt.data-00000-of-00001`` + ``checkpoint``),
+        under the variable names of the TF 1.4 graph, Adam slots and beta powers included
+        (hpmn_amd/tf_checkpoint.py), so that either implementation can restore the other's checkpoint."""
         if self.rank != 0:
             return
+        from . import tf_checkpoint as tfc
         path = self.save_path if global_step is None else "%s-%s" % (self.save_path, global_step)
-        torch.save({"variables": {k: v.detach().cpu() for k, v in self.params.items()},
-                    "adam_m": self.flat_m.cpu(), "adam_v": self.flat_v.cpu(), "adam_t": self.adam_t}, path)
+        torch.cuda.synchronize(self.device)
+        host = lambda flat: {k: flat[self._offs[k]:self._offs[k] + v.numel()].view(v.shape).cpu().numpy()
+                             for k, v in self.params.items()}
+        tfc.export_model(path, host(self.flat_param), host(self.flat_m), host(self.flat_v), self.adam_t, self.beta1,
+                         self.beta2, mask_table_rows=self.feature_size if self.spec.mask_id0 else None)
 
-    def load_model(self):
+    def load_model(self, path: Optional[str] = None):
+        """code/hpmn.py:105-111: ``saver.restore``; raises IOError like the reference when it fails.  Restores a
+        checkpoint written by ``save_model`` or by the reference's TF 1.4 Saver (variables the User branch does not
+        have -- the never-executed item branch -- are ignored; Adam state is taken when present)."""
+        from . import tf_checkpoint as tfc
+        path = self.save_path if path is None else path
         try:
-            ck = torch.load(self.save_path, map_location="cpu")
-            self.set_params({k: v.numpy() for k, v in ck["variables"].items()})
-            self.flat_m.copy_(ck["adam_m"])
-            self.flat_v.copy_(ck["adam_v"])
-            self.adam_t = int(ck["adam_t"])
+            params, m, v, t = tfc.import_model(path, {k: tuple(p.shape) for k, p in self.params.items()}, self.beta1)
+            self.set_params(params)
+            with torch.no_grad():
+                if m is not None:
+                    for k in params:
+                        o, n = self._offs[k], self.params[k].numel()
+                        self.flat_m[o:o + n].copy_(torch.as_tensor(m[k]).reshape(-1))
+                        self.flat_v[o:o + n].copy_(torch.as_tensor(v[k]).reshape(-1))
+                else:
+                    self.flat_m.zero_()
+                    self.flat_v.zero_()
+            self.adam_t = int(t)
         except Exception:
-            raise IOError("Failed to load model from save path: %s" % self.save_path)
-        print("Successfully load model from save path: %s" % self.save_path)
+            raise IOError("Failed to load model from save path: %s" % path)
+        print("Successfully load model from save path: %s" % path)
 
     def log(self, step, result):
         if self.rank != 0:
