@@ -85,22 +85,31 @@ class _DeviceDataset:
     code/data_loader.py:283-296 / code/hpmn.py:474-481; batches are slices in stored order,
     exactly the batches ``DataLoader`` would yield."""
 
-    def __init__(self, dataset, device, industry: bool, feature_size: Optional[int] = None):
+    def __init__(self, dataset, device, industry: bool, feature_size: Optional[int] = None, want_item: bool = False):
+        item_ids = None
         if isinstance(dataset, dict):
             ids, label = dataset["ids"], dataset["label"]
             length = dataset.get("length")
+            item_ids = dataset.get("item_ids")
         elif isinstance(dataset, str):
-            chunks, labels = [], []
+            chunks, ichunks, labels = [], [], []
             for _, data in DataLoader_Mul(dataset, 512):
                 labels += data[0]
                 chunks.append(np.asarray(data[1], dtype=np.int32))
+                if want_item:
+                    ichunks.append(np.asarray(data[3], dtype=np.int32))     # item_inp <- data[3] (code/hpmn.py:330)
             ids = np.concatenate(chunks, axis=0)
+            item_ids = np.concatenate(ichunks, axis=0) if want_item else None
             label = np.asarray(labels, dtype=np.int32)
             length = None
         else:
             label = np.asarray([s[0] for s in dataset], dtype=np.int32)
             ids = np.asarray([s[1] for s in dataset], dtype=np.int32)
             length = np.asarray([s[2] for s in dataset], dtype=np.int32)
+            if want_item:
+                item_ids = np.asarray([s[3] for s in dataset], dtype=np.int32)   # item_inp <- data[3] (:477)
+        if want_item and item_ids is None:
+            raise ValueError("item=True needs the item-side sequences (sample[3] / dataset['item_ids'])")
         self.n = int(ids.shape[0])
         # tf.nn.embedding_lookup on the CPU raises on an out-of-range id; the kernels index the table unchecked,
         # so the range is checked once here, on the host, when the dataset is staged
@@ -109,6 +118,11 @@ class _DeviceDataset:
             if lo < 0 or hi >= feature_size:
                 raise ValueError("dataset ids span [%d, %d] but the embedding table has %d rows" % (lo, hi, feature_size))
         self.ids = torch.as_tensor(np.ascontiguousarray(ids, dtype=np.int32)).to(device)
+        self.item_ids = None
+        if want_item:
+            if feature_size is not None and self.n and (int(np.min(item_ids)) < 0 or int(np.max(item_ids)) >= feature_size):
+                raise ValueError("item-side ids out of the embedding table's range")
+            self.item_ids = torch.as_tensor(np.ascontiguousarray(item_ids, dtype=np.int32)).to(device)
         self.label_np = np.asarray(label, dtype=np.int32)
         self.label = torch.as_tensor(self.label_np).to(device)
         self.length_np = None if length is None else np.asarray(length)
@@ -133,11 +147,8 @@ class Hpmn_Basic(object):
             raise RuntimeError("hpmn_amd needs an MI355X (ROCm) device: the hot path is HIP-only, "
                                "there is no CPU fallback")
         ops._lib.load()       # raises loudly if libhpmn_hip.so is not built
-        if not user:
-            raise NotImplementedError("item-only mode (user=False) is not built yet; every reference "
-                                      "configuration uses user=True, item=False (code/hpmn.py:591-592)")
-        if item:
-            raise NotImplementedError("dual mode (item=True) is not built yet (SURVEY.md 8f rank 3)")
+        if not user and not item:
+            raise ValueError("at least one of user / item must be set (code/hpmn.py:452-462)")
         self._path = path
         self.trainset, self.testset = trainset, testset
         self.feature_size = int(feature_size)
@@ -152,12 +163,19 @@ class Hpmn_Basic(object):
         self.verbose = verbose
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
         assert self.user_num_layers <= len(self.user_layers)     # code/hpmn.py:115
+        assert not item or self.item_num_layers <= len(self.item_layers)
         self.rank, self.world = dist.rank_world()
         self.table_exchange_chunks = 4
         self._dropout_base, self._dropout_step = (int(seed or 0) * 0x632BE59BD9B4E019 + 0x1234567) & (2 ** 63 - 1), 0
         self._save_path = None
         self._datasets: Dict[int, Tuple[object, _DeviceDataset]] = {}
         self.spec = self._make_spec()
+        self.item_spec = self._make_item_spec() if item else None
+        # scope names of the two branches in the TF graph (code/hpmn.py:436, :444 "item"; :286, :297 "Item")
+        self.item_scope = "Item" if self.industry else "item"
+        self._branches = ([("User", self.spec, self.user_num_layers)] if user else []) + \
+                         ([(self.item_scope, self.item_spec, self.item_num_layers)] if item else [])
+        self._hip_read = bool(user and not item)     # the fused HIP read kernel serves the user-only graph
         self._build_variables(emb_initializer, seed)
         self.adam_t = 0
         self.beta1, self.beta2, self.adam_eps = 0.9, 0.999, 1e-8   # tf.train.AdamOptimizer defaults
@@ -167,22 +185,30 @@ class Hpmn_Basic(object):
     def _make_spec(self) -> ScanSpec:
         raise NotImplementedError
 
+    def _make_item_spec(self) -> ScanSpec:
+        raise NotImplementedError
+
     # ------------------------------------------------------------------ variables
     def _param_shapes(self) -> List[Tuple[str, Tuple[int, ...]]]:
-        H, D0 = self.hidden_size, self.spec.D0
+        """The variables the graph EXECUTES (TF also creates the other branch's, which no fetch ever reaches)."""
+        H = self.hidden_size
         shp = [("Embedding/emb_mtx", (self.feature_size, self.embedding_size))]
-        for i in range(self.user_num_layers):
-            d = D0 if i == 0 else H
-            shp += [("User/GRU%d/gates/kernel" % i, (d + H, 2 * H)), ("User/GRU%d/gates/bias" % i, (2 * H,)),
-                    ("User/GRU%d/candidate/kernel" % i, (d + H, H)), ("User/GRU%d/candidate/bias" % i, (H,))]
-        shp += [("User/dense/kernel", (D0, H)), ("User/dense/bias", (H,)), ("User/map", (H, H))]
-        n = 1
-        for _ in range(self.hop):
-            for fin, fout in ((4 * H, 80), (80, 40), (40, 1)):      # code/hpmn.py:137-139
-                shp += [("User/dense_%d/kernel" % n, (fin, fout)), ("User/dense_%d/bias" % n, (fout,))]
-                n += 1
-        shp += [("output/bn1/gamma", (H + D0,)), ("output/bn1/beta", (H + D0,))]
-        for name, fin, fout in (("fc1", H + D0, 200), ("fc2", 200, 80), ("fc3", 80, 1)):   # :191-195
+        width = 0
+        for scope, spec, K in self._branches:
+            D0 = spec.D0
+            for i in range(K):
+                d = D0 if i == 0 else H
+                shp += [("%s/GRU%d/gates/kernel" % (scope, i), (d + H, 2 * H)), ("%s/GRU%d/gates/bias" % (scope, i), (2 * H,)),
+                        ("%s/GRU%d/candidate/kernel" % (scope, i), (d + H, H)), ("%s/GRU%d/candidate/bias" % (scope, i), (H,))]
+            shp += [(scope + "/dense/kernel", (D0, H)), (scope + "/dense/bias", (H,)), (scope + "/map", (H, H))]
+            n = 1
+            for _ in range(self.hop):
+                for fin, fout in ((4 * H, 80), (80, 40), (40, 1)):      # code/hpmn.py:137-139
+                    shp += [("%s/dense_%d/kernel" % (scope, n), (fin, fout)), ("%s/dense_%d/bias" % (scope, n), (fout,))]
+                    n += 1
+            width += H + D0
+        shp += [("output/bn1/gamma", (width,)), ("output/bn1/beta", (width,))]
+        for name, fin, fout in (("fc1", width, 200), ("fc2", 200, 80), ("fc3", 80, 1)):   # :191-195
             shp += [("output/%s/kernel" % name, (fin, fout)), ("output/%s/bias" % name, (fout,))]
         return shp
 
@@ -219,10 +245,14 @@ class Hpmn_Basic(object):
             self.params[name] = p
             self.grads[name] = g
         self._emb_numel_padded = offs[shapes[1][0]]     # emb is first; dense part starts here
-        self._gru_names = [["User/GRU%d/%s" % (i, s) for s in
-                            ("gates/kernel", "gates/bias", "candidate/kernel", "candidate/bias")]
-                           for i in range(self.user_num_layers)]
-        self._make_read_desc()
+        self._gru_names_of = {scope: [["%s/GRU%d/%s" % (scope, i, s) for s in
+                                       ("gates/kernel", "gates/bias", "candidate/kernel", "candidate/bias")]
+                                      for i in range(K)] for scope, _, K in self._branches}
+        self._gru_names = self._gru_names_of[self._branches[0][0]]
+        if self._hip_read:
+            self._make_read_desc()
+        else:
+            self._read_names = [n for n, _ in shapes if "/GRU" not in n and n != "Embedding/emb_mtx"]
 
     def set_params(self, values: Dict[str, np.ndarray]):
         """Inject weights (parity tests: identical weights => identical logits)."""
@@ -233,8 +263,9 @@ class Hpmn_Basic(object):
     def get_params(self) -> Dict[str, np.ndarray]:
         return {k: v.detach().cpu().numpy().copy() for k, v in self.params.items()}
 
-    def _gru_weights(self) -> List[torch.Tensor]:
-        return [self.params[n] for names in self._gru_names for n in names]
+    def _gru_weights(self, scope: Optional[str] = None) -> List[torch.Tensor]:
+        names = self._gru_names if scope is None else self._gru_names_of[scope]
+        return [self.params[n] for ns in names for n in ns]
 
     # ------------------------------------------------------------------ read path (code/hpmn.py:133-207)
     def _make_read_desc(self):
@@ -260,8 +291,10 @@ class Hpmn_Basic(object):
 
     # ------------------------------------------------------------------ forward passes
     @torch.no_grad()
-    def forward_inference(self, ids: torch.Tensor, want_logit=True, want_att=True):
+    def forward_inference(self, ids: torch.Tensor, want_logit=True, want_att=True, item_ids: Optional[torch.Tensor] = None):
         """Eval-mode forward (keep_prob 1): hpmn_scan_fwd chain + hpmn_read_fwd."""
+        if not self._hip_read:
+            return self._forward_inference_branches(ids, item_ids)
         memory, last = ops.scan_forward_inference(self.spec, ids, self.params["Embedding/emb_mtx"],
                                                   self._gru_weights())
         if ids.shape[0] == 0:
@@ -270,9 +303,86 @@ class Hpmn_Basic(object):
                         memory_loss=torch.zeros((), device=self.device))
         return ops.read_fwd(self._read_desc, self._read_params, memory, last, want_logit, want_att)
 
+    # ------------------------------------------------------------------ graphs that execute the item branch
+    def _branch_inputs(self, ids, item_ids):
+        out = []
+        for scope, spec, _ in self._branches:
+            x = ids if scope == "User" else item_ids
+            if x is None:
+                raise ValueError("this graph executes the %s branch: pass its id tensor" % scope)
+            out.append((scope, spec, x))
+        return out
+
+    @torch.no_grad()
+    def _forward_inference_branches(self, ids, item_ids):
+        """item=True graphs, eval mode: both scans on the HIP inference chain, the joint read on device ops."""
+        from . import read_torch as RT
+        emb = self.params["Embedding/emb_mtx"]
+        br, mems = [], {}
+        for scope, spec, x in self._branch_inputs(ids, item_ids):
+            memory, last = ops.scan_forward_inference(spec, x, emb, self._gru_weights(scope))
+            br.append((scope, self.hop, memory, last))
+            mems[scope] = memory
+        B = br[0][2].shape[0]
+        if B == 0:
+            z = torch.empty(0, device=self.device)
+            return dict(prediction=z, logit=z, memory_loss=torch.zeros((), device=self.device), memory=br[0][2],
+                        user_weights=torch.empty(0, self._branches[0][2], device=self.device))
+        out = RT.read(self.params, br, 1.0)
+        first = self._branches[0][0]
+        return dict(prediction=out["prediction"], logit=out["logit"], memory_loss=out["memory_loss"],
+                    memory=mems[first], memories=mems, user_weights=out["weights"].get("User"),
+                    item_weights=out["weights"].get(self.item_scope))
+
+    def _compute_gradients_branches(self, ids, item_ids, label, keep_prob, masks, global_batch, defer_join):
+        """item=True graphs: scan forward (HIP, per branch) -> joint read path + loss under autograd (device ops)
+        -> scan BPTT + embedding scatter (HIP, per branch) into the flat gradient."""
+        from . import read_torch as RT
+        emb = self.params["Embedding/emb_mtx"]
+        fw = []
+        with torch.no_grad():
+            for scope, spec, x in self._branch_inputs(ids, item_ids):
+                memory, last, saved = ops.scan_forward_train(spec, x, emb, self._gru_weights(scope))
+                fw.append((scope, spec, x, memory, last, saved))
+        with torch.enable_grad():
+            leaves = [(m.detach().requires_grad_(True), l.detach().requires_grad_(True)) for _, _, _, m, l, _ in fw]
+            rp = {n: self.params[n].detach().requires_grad_(True) for n in self._read_names}
+            gen = None
+            if masks is None and keep_prob < 1.0:
+                self._dropout_step += 1
+                gen = torch.Generator(device=self.device)
+                gen.manual_seed(_splitmix64(_splitmix64(self._dropout_base + self._dropout_step) ^ (self.rank + 1)) & (2 ** 62 - 1))
+            out = RT.read(rp, [(f[0], self.hop, mm, ll) for f, (mm, ll) in zip(fw, leaves)], keep_prob, masks, gen)
+            ll_sum = RT.log_loss_sum(out["prediction"], label)
+            loss = ll_sum / float(global_batch) + self.memory_reg * out["memory_loss"]
+            wrt = [t for pair in leaves for t in pair] + list(rp.values())
+            grads = torch.autograd.grad(loss, wrt, allow_unused=True)
+        with torch.no_grad():
+            for n, g in zip(rp, grads[2 * len(leaves):]):
+                if g is not None:
+                    self.grads[n].add_(g)
+            pendings = []
+            for j, (scope, spec, x, memory, last, saved) in enumerate(fw):
+                gm, gl = grads[2 * j], grads[2 * j + 1]
+                gm = torch.zeros_like(memory) if gm is None else gm.contiguous()
+                gl = torch.zeros_like(last) if gl is None else gl.contiguous()
+                grad_out = [self.grads["Embedding/emb_mtx"]] + [self.grads[n] for ns in self._gru_names_of[scope] for n in ns]
+                pend = ops.scan_backward(spec, x, saved, self._gru_weights(scope), gm, gl, grad_out, defer_join=False)
+                if pend is not None:
+                    pend.join()
+            res = dict(prediction=out["prediction"].detach(), log_loss_sum=ll_sum.detach(),
+                       memory_loss=out["memory_loss"].detach(), memory=fw[0][3], pending=None)
+            if self.l2_reg:
+                self.flat_grad.add_(self.flat_param, alpha=self.l2_reg / self.world)
+            ce = res["log_loss_sum"] / float(global_batch) + self.memory_reg * res["memory_loss"]
+            if self.l2_reg:
+                ce = ce + (0.5 * self.l2_reg / self.world) * sum((v * v).sum() for v in self.params.values())
+        return res, ce
+
     @torch.no_grad()
     def compute_gradients(self, ids: torch.Tensor, label: torch.Tensor, keep_prob=0.5, masks=None,
-                          global_batch: Optional[int] = None, defer_join: bool = False):
+                          global_batch: Optional[int] = None, defer_join: bool = False,
+                          item_ids: Optional[torch.Tensor] = None):
         """Forward + BPTT of cross_entropy (code/hpmn.py:202-207) for a (possibly sharded) batch into
         the flat gradient buffer: log-loss is a MEAN over the GLOBAL batch, the memory regulariser a
         SUM.  Pure kernel sequence: scan fwd -> read fwd+loss+bwd -> scan bwd.
@@ -285,6 +395,8 @@ class Hpmn_Basic(object):
         self.flat_grad.zero_()
         if B == 0:
             return dict(prediction=torch.empty(0, device=self.device)), torch.zeros((), device=self.device)
+        if not self._hip_read:
+            return self._compute_gradients_branches(ids, item_ids, label, keep_prob, masks, global_batch, defer_join)
         emb = self.params["Embedding/emb_mtx"]
         weights = self._gru_weights()
         memory, last, saved = ops.scan_forward_train(self.spec, ids, emb, weights)
@@ -313,9 +425,9 @@ class Hpmn_Basic(object):
 
     # ------------------------------------------------------------------ one training step
     def train_step(self, ids: torch.Tensor, label: torch.Tensor, keep_prob=0.5, masks=None,
-                   global_batch: Optional[int] = None):
+                   global_batch: Optional[int] = None, item_ids: Optional[torch.Tensor] = None):
         """sess.run(train_step) of code/hpmn.py:482: forward, BPTT, clip, dense TF Adam."""
-        out, ce = self.compute_gradients(ids, label, keep_prob, masks, global_batch, defer_join=True)
+        out, ce = self.compute_gradients(ids, label, keep_prob, masks, global_batch, defer_join=True, item_ids=item_ids)
         pending = out.pop("pending", None)
         if self.l2_reg:
             # (same on every rank) the l2 term touched the whole buffer after the join: one exchange, one update
@@ -366,7 +478,8 @@ class Hpmn_Basic(object):
         hit = self._datasets.get(key)
         if hit is not None and hit[0] is dataset:
             return hit[1]
-        ds = _DeviceDataset(dataset, self.device, self.industry, getattr(self, "feature_size", None))
+        ds = _DeviceDataset(dataset, self.device, self.industry, getattr(self, "feature_size", None),
+                            want_item=bool(getattr(self, "item", False)))
         while len(self._datasets) >= self.max_cached_datasets:
             # evict the oldest entry that is not the model's own train / test set
             victim = next((k for k, (d, _) in self._datasets.items()
@@ -395,7 +508,8 @@ class Hpmn_Basic(object):
                 step += 1
                 # data parallel: every rank takes a contiguous slice of the global batch
                 a, b = dist.shard_bounds(lo, hi, self.rank, self.world)
-                self.train_step(ds.ids[a:b], ds.label[a:b], keep_prob=0.5, global_batch=hi - lo)
+                self.train_step(ds.ids[a:b], ds.label[a:b], keep_prob=0.5, global_batch=hi - lo,
+                                item_ids=None if ds.item_ids is None else ds.item_ids[a:b])
                 if step % self.eval_every == 0:
                     result = list(self.eval(self.trainset, 4 * batchsize))
                     result += list(self.eval(self.testset, 4 * batchsize))
@@ -416,7 +530,7 @@ class Hpmn_Basic(object):
         preds, mem_losses = [], []
         for lo, hi in ds.batches(batchsize):
             a, b = dist.shard_bounds(lo, hi, self.rank, self.world)
-            out = self.forward_inference(ds.ids[a:b])
+            out = self.forward_inference(ds.ids[a:b], item_ids=None if ds.item_ids is None else ds.item_ids[a:b])
             pred, ml = out["prediction"], out["memory_loss"].reshape(1)
             if self.world > 1:
                 pred = dist.gather_predictions(pred.contiguous(), hi - lo)
@@ -436,6 +550,12 @@ class Hpmn_Basic(object):
             raise ValueError("Only one class present in y_true. ROC AUC score is not defined in that case.")
         return auc, loss, mem_loss
 
+    def _first_hop_weights(self, ds, lo, hi):
+        """self.user_weights of code/hpmn.py:534-537 (the item branch's weights when only that branch runs)."""
+        out = self.forward_inference(ds.ids[lo:hi], item_ids=None if ds.item_ids is None else ds.item_ids[lo:hi])
+        w = out["user_weights"] if out.get("user_weights") is not None else out["item_weights"]
+        return w.cpu().numpy()
+
     def get_weights(self):
         """code/hpmn.py:521-560: first-hop attention weights over train+test at batch 512."""
         if self.rank != 0:          # unsharded forward + file writes: one rank does it (like save_model / log)
@@ -444,7 +564,7 @@ class Hpmn_Basic(object):
         for dataset in (self.trainset, self.testset):
             ds = self._dev(dataset)
             for lo, hi in ds.batches(512):
-                weights.append(self.forward_inference(ds.ids[lo:hi])["user_weights"].cpu().numpy())
+                weights.append(self._first_hop_weights(ds, lo, hi))
             if ds.length_np is not None:
                 lengths.append(ds.length_np)
             labels.append(ds.label_np)
@@ -533,6 +653,13 @@ class Hpmn_Industry(Hpmn_Basic):
                         front_zero=23,     # literal of code/hpmn.py:288 (1001 + 23 = 1024 = the literal of :290)
                         mask_id0=False, last_index=-2)
 
+    def _make_item_spec(self) -> ScanSpec:
+        # code/hpmn.py:297-302: 192 - 184 = 8 zero steps in front, build_memory(iinp, item_layers, 192, ...),
+        # last = iinp[:, -1, :]
+        return ScanSpec(F=self.item_dim, E=self.embedding_size, H=self.hidden_size, K=self.item_num_layers,
+                        T=self.item_maxlen, periods=tuple(self.item_layers[:self.item_num_layers]),
+                        front_zero=192 - 184, mask_id0=False, last_index=-1)
+
     def get_weights(self):
         """code/hpmn.py:375-410."""
         if self.rank != 0:
@@ -541,7 +668,7 @@ class Hpmn_Industry(Hpmn_Basic):
         for dataset in (self.trainset, self.testset):
             ds = self._dev(dataset)
             for lo, hi in ds.batches(512):
-                weights.append(self.forward_inference(ds.ids[lo:hi])["user_weights"].cpu().numpy())
+                weights.append(self._first_hop_weights(ds, lo, hi))
                 ids.append(ds.ids[lo:hi, :, 1].cpu().numpy())
         np.save(self._path + "/weights_new.npy", np.concatenate(weights))
         np.save(self._path + "/ids.npy", np.concatenate(ids))
@@ -557,6 +684,12 @@ class Hpmn(Hpmn_Industry):
     def _make_spec(self) -> ScanSpec:
         return ScanSpec(F=self.user_dim, E=self.embedding_size, H=self.hidden_size, K=self.user_num_layers,
                         T=self.user_maxlen, periods=tuple(self.user_layers[:self.user_num_layers]),
+                        front_zero=0, mask_id0=True, last_index=-1)
+
+    def _make_item_spec(self) -> ScanSpec:
+        # code/hpmn.py:444-447 (the same masked embedding, :424-428)
+        return ScanSpec(F=self.item_dim, E=self.embedding_size, H=self.hidden_size, K=self.item_num_layers,
+                        T=self.item_maxlen, periods=tuple(self.item_layers[:self.item_num_layers]),
                         front_zero=0, mask_id0=True, last_index=-1)
 
     get_weights = Hpmn_Basic.get_weights

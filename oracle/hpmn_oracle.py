@@ -51,11 +51,18 @@ class HpmnConfig:
     industry: bool = False       # Hpmn_Industry graph (code/hpmn.py:284-320) vs Hpmn (:432-465)
     memory_reg: float = 1e-5
     l2_reg: float = 0.0
+    # the same container describes an ITEM-side branch (code/hpmn.py:444-450 scope "item", :297-305 scope "Item"):
+    # user_dim/user_maxlen/user_layers/user_num_layers then hold item_dim/item_maxlen/item_layers/item_num_layers
+    scope: str = "User"
+    front_zero: int = -1         # override; Hpmn_Industry's item side pads 192 - 184 = 8 zero steps (:298-299)
+    last_idx: int = 0            # override; every item side reads iinp[:, -1, :] (:302, :447)
 
     # --- derived -----------------------------------------------------------
     @property
     def front_zero_steps(self) -> int:
         # code/hpmn.py:288-290: 23 zero steps in front, build_memory(..., 1024, ...)
+        if self.front_zero >= 0:
+            return self.front_zero
         return 23 if self.industry else 0
 
     @property
@@ -71,6 +78,8 @@ class HpmnConfig:
     @property
     def last_index(self) -> int:
         # code/hpmn.py:439 (uinp[:, -1, :]) vs :292 (uinp[:, -2, :])
+        if self.last_idx:
+            return self.last_idx
         return -2 if self.industry else -1
 
     @property
@@ -95,40 +104,59 @@ class HpmnConfig:
 # ---------------------------------------------------------------------------
 # parameter container
 # ---------------------------------------------------------------------------
-def param_shapes(cfg: HpmnConfig) -> Dict[str, Tuple[int, ...]]:
-    H, D0 = cfg.hidden_size, cfg.d0
-    shp: Dict[str, Tuple[int, ...]] = {"Embedding/emb_mtx": (cfg.feature_size, cfg.embedding_size)}
+def branch_shapes(cfg: HpmnConfig) -> Dict[str, Tuple[int, ...]]:
+    """Variables of one branch (scope ``cfg.scope``): its GRU stack, query projection, map, attention MLPs."""
+    H, D0, sc = cfg.hidden_size, cfg.d0, cfg.scope
+    shp: Dict[str, Tuple[int, ...]] = {}
     for i, d in enumerate(cfg.layer_in_dims()):
-        shp["User/GRU%d/gates/kernel" % i] = (d + H, 2 * H)
-        shp["User/GRU%d/gates/bias" % i] = (2 * H,)
-        shp["User/GRU%d/candidate/kernel" % i] = (d + H, H)
-        shp["User/GRU%d/candidate/bias" % i] = (H,)
-    shp["User/dense/kernel"] = (D0, H)
-    shp["User/dense/bias"] = (H,)
-    shp["User/map"] = (H, H)
+        shp["%s/GRU%d/gates/kernel" % (sc, i)] = (d + H, 2 * H)
+        shp["%s/GRU%d/gates/bias" % (sc, i)] = (2 * H,)
+        shp["%s/GRU%d/candidate/kernel" % (sc, i)] = (d + H, H)
+        shp["%s/GRU%d/candidate/bias" % (sc, i)] = (H,)
+    shp[sc + "/dense/kernel"] = (D0, H)
+    shp[sc + "/dense/bias"] = (H,)
+    shp[sc + "/map"] = (H, H)
     n = 1
     for _ in range(cfg.hop):
         for fin, fout in ((4 * H, ATT_FC1), (ATT_FC1, ATT_FC2), (ATT_FC2, 1)):
-            shp["User/dense_%d/kernel" % n] = (fin, fout)
-            shp["User/dense_%d/bias" % n] = (fout,)
+            shp["%s/dense_%d/kernel" % (sc, n)] = (fin, fout)
+            shp["%s/dense_%d/bias" % (sc, n)] = (fout,)
             n += 1
-    shp["output/bn1/gamma"] = (H + D0,)
-    shp["output/bn1/beta"] = (H + D0,)
-    for name, fin, fout in (("fc1", H + D0, HEAD_FC1), ("fc2", HEAD_FC1, HEAD_FC2), ("fc3", HEAD_FC2, 1)):
+    return shp
+
+
+def head_shapes(width: int) -> Dict[str, Tuple[int, ...]]:
+    shp = {"output/bn1/gamma": (width,), "output/bn1/beta": (width,)}
+    for name, fin, fout in (("fc1", width, HEAD_FC1), ("fc2", HEAD_FC1, HEAD_FC2), ("fc3", HEAD_FC2, 1)):
         shp["output/%s/kernel" % name] = (fin, fout)
         shp["output/%s/bias" % name] = (fout,)
     return shp
 
 
+def param_shapes(cfg: HpmnConfig, item_cfg: "HpmnConfig | None" = None, user: bool = True) -> Dict[str, Tuple[int, ...]]:
+    """Variables that are EXECUTED: the user branch (default), the item branch, or both (code/hpmn.py:452-462:
+    repre = [user_repre, item_repre] / user_repre / item_repre)."""
+    shp: Dict[str, Tuple[int, ...]] = {"Embedding/emb_mtx": (cfg.feature_size, cfg.embedding_size)}
+    width = 0
+    if user:
+        shp.update(branch_shapes(cfg))
+        width += cfg.hidden_size + cfg.d0
+    if item_cfg is not None:
+        shp.update(branch_shapes(item_cfg))
+        width += item_cfg.hidden_size + item_cfg.d0
+    shp.update(head_shapes(width))
+    return shp
+
+
 def init_params(cfg: HpmnConfig, seed: int = 0, emb_init: np.ndarray | None = None,
-                dtype=np.float64) -> Dict[str, np.ndarray]:
+                dtype=np.float64, item_cfg: "HpmnConfig | None" = None, user: bool = True) -> Dict[str, np.ndarray]:
     """TF1.4 default initialisers: glorot-uniform for kernels / get_variable without
     initializer, zeros for dense biases, ones for the GRU gate bias (code/util.py:84-86),
     gamma=1 / beta=0 for batch-norm.  The RNG stream is ours (TF's is unseeded,
     code/hpmn.py:13 seeds only ``random``)."""
     rng = np.random.default_rng(seed)
     out: Dict[str, np.ndarray] = {}
-    for name, shape in param_shapes(cfg).items():
+    for name, shape in param_shapes(cfg, item_cfg, user).items():
         if name == "Embedding/emb_mtx" and emb_init is not None:
             assert tuple(emb_init.shape) == shape
             out[name] = np.array(emb_init, dtype=dtype)

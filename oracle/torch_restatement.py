@@ -78,7 +78,7 @@ def build_memory(cfg: HpmnConfig, p, inp):
     # code/hpmn.py:113-131
     mem = []
     for i in range(cfg.user_num_layers):
-        pre = "User/GRU%d/" % i
+        pre = "%s/GRU%d/" % (cfg.scope, i)
         outs, state = dynamic_rnn(inp, p[pre + "gates/kernel"], p[pre + "gates/bias"],
                                   p[pre + "candidate/kernel"], p[pre + "candidate/bias"])
         mem.append(state.unsqueeze(1))
@@ -89,26 +89,28 @@ def build_memory(cfg: HpmnConfig, p, inp):
     return memory, get_covreg(memory)
 
 
-def attention(p, first_dense, memory, query):
+def attention(p, first_dense, memory, query, scope="User"):
     # code/hpmn.py:133-146
     B, K, H = memory.shape
     q = query.unsqueeze(1).expand(B, K, H)
     inp = torch.cat([q, memory, q - memory, q * memory], dim=-1)
     n = first_dense
-    fc1 = torch.relu(inp @ p["User/dense_%d/kernel" % n] + p["User/dense_%d/bias" % n])
-    fc2 = torch.relu(fc1 @ p["User/dense_%d/kernel" % (n + 1)] + p["User/dense_%d/bias" % (n + 1)])
-    fc3 = fc2 @ p["User/dense_%d/kernel" % (n + 2)] + p["User/dense_%d/bias" % (n + 2)]
+    d = scope + "/dense_%d/"
+    fc1 = torch.relu(inp @ p[d % n + "kernel"] + p[d % n + "bias"])
+    fc2 = torch.relu(fc1 @ p[d % (n + 1) + "kernel"] + p[d % (n + 1) + "bias"])
+    fc3 = fc2 @ p[d % (n + 2) + "kernel"] + p[d % (n + 2) + "bias"]
     score = torch.softmax(fc3.reshape(B, K), dim=1)
     return (memory * score.unsqueeze(2)).sum(dim=1), score
 
 
 def query_memory(cfg, p, last, memory):
     # code/hpmn.py:172-182
-    q = last @ p["User/dense/kernel"] + p["User/dense/bias"]
+    sc = cfg.scope
+    q = last @ p[sc + "/dense/kernel"] + p[sc + "/dense/bias"]
     w0 = None
     for hop in range(cfg.hop):
-        read, w = attention(p, 3 * hop + 1, memory, q)
-        q = q @ p["User/map"] + read
+        read, w = attention(p, 3 * hop + 1, memory, q, sc)
+        q = q @ p[sc + "/map"] + read
         if hop == 0:
             w0 = w
     return q, w0
@@ -144,6 +146,31 @@ def forward(cfg: HpmnConfig, p, user_inp, label=None, mask1=None, mask2=None, ke
         if cfg.l2_reg:
             ce = ce + cfg.l2_reg * sum(0.5 * (v * v).sum() for v in p.values())
         out["cross_entropy"] = ce
+    return out
+
+
+def forward_dual(ucfg: HpmnConfig, icfg: HpmnConfig, p, user_inp, item_inp, label=None, user=True, item=True,
+                 mask1=None, mask2=None, keep_prob=1.0):
+    """build_graph with the item side executed (code/hpmn.py:444-462 / :297-317): both branches share the embedding
+    table, repre = [user_repre, item_repre] (dual) or item_repre alone, memory_loss = imloss + umloss / imloss."""
+    parts, mem_loss, out = [], 0.0, {}
+    for on, cfg, inp, tag in ((user, ucfg, user_inp, "user"), (item, icfg, item_inp, "item")):
+        if not on:
+            continue
+        x = embedding(cfg, p, inp)
+        memory, ml = build_memory(cfg, p, x)
+        last = x[:, cfg.last_index, :]
+        q, w0 = query_memory(cfg, p, last, memory)
+        parts += [q, last]
+        mem_loss = mem_loss + ml
+        out[tag + "_memory"], out[tag + "_weights"] = memory, w0
+    logit, pred = fc_net(p, torch.cat(parts, dim=-1), mask1, mask2, keep_prob)
+    out.update(memory_loss=mem_loss, logit=logit, prediction=pred)
+    if label is not None:
+        y = label.to(pred.dtype)
+        ll = torch.mean(-y * torch.log(pred + LOGLOSS_EPS) - (1.0 - y) * torch.log(1.0 - pred + LOGLOSS_EPS))
+        out["log_loss"] = ll
+        out["cross_entropy"] = ll + ucfg.memory_reg * mem_loss
     return out
 
 

@@ -692,3 +692,68 @@ def test_training_step_through_the_c_abi_alone(dev, tmp_path):
     moved = (m.flat_param - before).abs()
     assert float(moved.max()) <= 0.001 * 1.01 and float(moved.max()) > 1e-4      # first Adam step: |dp| ~ lr
     lib.hpmn_train_ctx_destroy(ctx)
+
+
+# ------------------------------------------------------------------------------- item branch / dual mode (code/hpmn.py:444-462, :297-317)
+def _dual_case(industry, H):
+    if industry:
+        # the XLong literals: item side 184 steps + 8 zero steps = 192, periods [3,2,2,2,2,2,2,1], 8 layers
+        u = cfg_industry(H=H, K=4, T=41, V=400)
+        i = O.HpmnConfig(400, 1, 184, H, 16, 3, (3, 2, 2, 2, 2, 2, 2, 1), 8, True, 5e-5, scope="Item", front_zero=8, last_idx=-1)
+    else:
+        u = cfg_amazon(H=H, K=3, T=100, V=400)
+        i = O.HpmnConfig(400, 2, 36, H, 16, 3, (2, 2, 3, 3, 1), 5, False, 1e-5, scope="item", last_idx=-1)   # Taobao's item side
+    return u, i
+
+
+@pytest.mark.parametrize("industry,H,user", [(False, 32, True), (True, 64, True), (False, 64, False), (True, 32, False)])
+def test_item_branch_and_dual_mode_match_oracle(dev, tmp_path, industry, H, user):
+    """item=True: repre = [user_repre, item_repre] (or item_repre alone), memory_loss = imloss + umloss; both scans
+    and their BPTT on the HIP kernels (the item side brings period 3 at layer 0, D0 = 16 and 1-step layers), the
+    joint read path under autograd on the device.  Forward and every gradient against float64 autograd."""
+    from hpmn_amd.hpmn import Hpmn, Hpmn_Industry
+    ucfg, icfg = _dual_case(industry, H)
+    B = 5
+    p = O.randomize_params(O.init_params(ucfg, seed=131, item_cfg=icfg, user=user), seed=132)
+    p = {k: v.astype(np.float32).astype(np.float64) for k, v in p.items()}
+    rng = np.random.default_rng(133)
+    uids, label = rand_ids(ucfg, B, 134)
+    iids = rng.integers(0 if industry else 1, 400, size=(B, icfg.user_maxlen, icfg.user_dim)).astype(np.int32)
+    if not industry:
+        iids[1, :20] = 0
+    cls = Hpmn_Industry if industry else Hpmn
+    m = cls(str(tmp_path), [], [], 400, ucfg.user_dim, icfg.user_dim, ucfg.user_maxlen, icfg.user_maxlen, 0.001, H, 16, 3,
+            list(ucfg.user_layers), list(icfg.user_layers), ucfg.user_num_layers, icfg.user_num_layers, user, True,
+            memory_reg=ucfg.memory_reg, verbose=False)
+    assert sorted(m.params) == sorted(p)
+    m.set_params(p)
+    tp = R.to_torch(p, torch.float64, requires_grad=True)
+    ref = R.forward_dual(ucfg, icfg, tp, torch.as_tensor(uids.astype(np.int64)), torch.as_tensor(iids.astype(np.int64)),
+                         torch.as_tensor(label.astype(np.int64)), user=user, item=True)
+    ref["cross_entropy"].backward()
+    tu, ti, tl = torch.as_tensor(uids).to(dev), torch.as_tensor(iids).to(dev), torch.as_tensor(label).to(dev)
+    out = m.forward_inference(tu, item_ids=ti)
+    np.testing.assert_allclose(out["logit"].cpu().numpy(), ref["logit"].detach().numpy(), rtol=0, atol=TOL)
+    np.testing.assert_allclose(out["prediction"].cpu().numpy(), ref["prediction"].detach().numpy(), rtol=0, atol=TOL)
+    np.testing.assert_allclose(out["item_weights"].cpu().numpy(), ref["item_weights"].detach().numpy(), rtol=0, atol=TOL)
+    np.testing.assert_allclose(out["memories"][m.item_scope].cpu().numpy(), ref["item_memory"].detach().numpy(), rtol=0, atol=TOL)
+    if user:
+        np.testing.assert_allclose(out["user_weights"].cpu().numpy(), ref["user_weights"].detach().numpy(), rtol=0, atol=TOL)
+    np.testing.assert_allclose(float(out["memory_loss"]), float(ref["memory_loss"]), rtol=1e-4, atol=1e-5)
+    _, ce = m.compute_gradients(tu, tl, keep_prob=1.0, global_batch=B, item_ids=ti)
+    np.testing.assert_allclose(float(ce), float(ref["cross_entropy"]), rtol=2e-4, atol=1e-5)
+    for k in p:
+        w = tp[k].grad.numpy()
+        np.testing.assert_allclose(m.grads[k].cpu().numpy(), w, rtol=0, atol=2e-4 * max(1e-6, np.abs(w).max()) + 1e-6,
+                                   err_msg=k)
+    # a training step runs, eval through the harness stages the item side from the samples' 4th field
+    m.train_step(tu, tl, keep_prob=0.5, item_ids=ti)
+    samples = [(int(l), u.tolist(), 1, i.tolist(), 1) for l, u, i in zip(label, uids, iids)]
+    if len(set(label.tolist())) == 2:
+        auc, ll, ml = m.eval(samples, 3)
+        assert 0.0 <= auc <= 1.0 and np.isfinite(ll)
+    m.save_model()
+    before = m.forward_inference(tu, item_ids=ti)["prediction"].clone()
+    m.set_params({k: np.zeros_like(v) for k, v in m.get_params().items()})
+    m.load_model()
+    assert torch.equal(before, m.forward_inference(tu, item_ids=ti)["prediction"])

@@ -22,7 +22,7 @@ def _stub(cls, tmp_path, n_train, aucs, eval_every=None):
     calls = dict(steps=[], evals=0)
     script = iter(aucs)
 
-    def train_step(ids, label, keep_prob=0.5, masks=None, global_batch=None):
+    def train_step(ids, label, keep_prob=0.5, masks=None, global_batch=None, item_ids=None):
         calls["steps"].append((ids.shape[0], keep_prob, global_batch))
 
     def fake_eval(dataset, batchsize):
@@ -171,7 +171,7 @@ def test_single_class_eval_raises_like_sklearn(tmp_path):
     m.rank, m.world, m.device = 0, 1, torch.device("cpu")
     m._datasets, m.industry, m.feature_size = {}, False, 10
     m.trainset = m.testset = None
-    m.forward_inference = lambda ids: dict(prediction=torch.linspace(0.1, 0.9, ids.shape[0]),
+    m.forward_inference = lambda ids, item_ids=None: dict(prediction=torch.linspace(0.1, 0.9, ids.shape[0]),
                                            memory_loss=torch.zeros(()))
     one = dict(ids=np.ones((6, 4, 3), np.int32), label=np.ones(6, np.int32))
     with pytest.raises(ValueError, match="Only one class"):
