@@ -413,6 +413,8 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: the per-GPU batch is the reference batch (global = N x); strong: the GLOBAL batch is")
     ap.add_argument("--no-parity-gate", action="store_true")
+    ap.add_argument("--lazy-table-adam", action="store_true",
+                    help="row-wise (lazy) Adam on the table: a labelled DEVIATION from the reference's dense update")
     ap.add_argument("--no-eval", action="store_true", help="skip the forward-only throughput leg (clean PMC profiles)")
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the reference literal)")
@@ -453,6 +455,8 @@ def main():
 
     tmp = tempfile.mkdtemp(prefix="hpmn_bench_")
     log("building model %s" % c["name"])
+    if args.lazy_table_adam:
+        os.environ["HPMN_LAZY_TABLE_ADAM"] = "1"
     model = build_model(c, tmp, device, seed=0)          # same seed -> identical replicas
     n_distinct = 8
     if args.scaling == "strong":
@@ -529,7 +533,9 @@ def main():
             "config": {"workload": c["name"], "config_id": args.config, "per_gpu_batch": per_gpu,
                        "global_batch": global_batch, "max_len": c["T"], "scan_steps": layer_lengths(c),
                        "hidden": c["H"], "layers": c["K"], "vocab_rows": c["V"], "keep_prob": 0.5,
-                       "parallelism": "dp%d" % world, "predictions_finite": finite},
+                       "parallelism": "dp%d" % world, "predictions_finite": finite,
+                       "table_optimizer": "lazy (row-wise) Adam -- DEVIATION from the reference's dense TF Adam"
+                                          if args.lazy_table_adam else "dense TF Adam over every row (reference semantics)"},
             "algorithmic": {"gru_flops_fwd_per_seq": algorithmic_flops_fwd(c),
                             "train_tflops_equiv": 3 * algorithmic_flops_fwd(c) * seqs / elapsed / 1e12},
         }

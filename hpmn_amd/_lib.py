@@ -172,6 +172,8 @@ SIGNATURES = {
     "hpmn_gru_fused_fwd_supported": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),
     "hpmn_gru_fused_fwd": (C.c_int, [C.POINTER(HpmnGruFusedFwd), C.c_void_p]),
     "hpmn_memory_update": (C.c_int, [C.POINTER(HpmnOnlineUpdate), C.c_void_p]),
+    "hpmn_adam_step_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
+                                      C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "hpmn_train_ctx_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "hpmn_train_ctx_destroy": (None, [C.c_void_p]),
     "hpmn_scan_train_workspace_bytes": (C.c_size_t, [C.POINTER(HpmnScanDesc)]),

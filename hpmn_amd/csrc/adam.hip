@@ -41,6 +41,40 @@ __global__ __launch_bounds__(256) void adam_kernel_v1(float *__restrict__ p, con
     }
 }
 
+// Row-wise ("lazy") variant for tables too large for the dense update: only the rows listed in row_ids are
+// touched; their gradients come from a COMPACT buffer g[u, :] (row u of it belongs to table row row_ids[u]).
+// One float4 per thread, E/4 adjacent lanes per row.  A DEVIATION from the reference's dense TF Adam (rows with
+// a zero gradient but non-zero moments do not move) -- the semantics of tf.contrib.opt.LazyAdamOptimizer.
+__global__ __launch_bounds__(256) void adam_rows_kernel(float4 *__restrict__ p, const float4 *__restrict__ g,
+                                                        float4 *__restrict__ m, float4 *__restrict__ v,
+                                                        const int64_t *__restrict__ row_ids, long n_rows, int E4,
+                                                        float lr_t, float b1, float b2, float eps, float clip,
+                                                        float gs) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n_rows * E4; i += stride) {
+        const long u = i / E4;
+        const long j = row_ids[u] * E4 + (i - u * E4);
+        float4 pp = p[j], mm = m[j], vv = v[j];
+        const float4 gg = g[i];
+        adam_elem(pp.x, gg.x, mm.x, vv.x, lr_t, b1, b2, eps, clip, gs);
+        adam_elem(pp.y, gg.y, mm.y, vv.y, lr_t, b1, b2, eps, clip, gs);
+        adam_elem(pp.z, gg.z, mm.z, vv.z, lr_t, b1, b2, eps, clip, gs);
+        adam_elem(pp.w, gg.w, mm.w, vv.w, lr_t, b1, b2, eps, clip, gs);
+        p[j] = pp; m[j] = mm; v[j] = vv;
+    }
+}
+
+int adam_rows_launch(float *p, const float *g, float *m, float *v, const int64_t *row_ids, int64_t n_rows, int E,
+                     float lr_t, float b1, float b2, float eps, float clip, float gs, hipStream_t st) {
+    if (n_rows == 0) return HPMN_OK;
+    const long n4 = n_rows * (E / 4);
+    long blocks = (n4 + 255) / 256;
+    if (blocks > 256L * 16) blocks = 256L * 16;
+    hipLaunchKernelGGL(adam_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (float4 *)p, (const float4 *)g,
+                       (float4 *)m, (float4 *)v, row_ids, (long)n_rows, E / 4, lr_t, b1, b2, eps, clip, gs);
+    return check_launch();
+}
+
 int adam_launch(float *p, const float *g, float *m, float *v, int64_t n, float lr_t, float b1, float b2,
                 float eps, float clip, float gs, hipStream_t st) {
     if (n == 0) return HPMN_OK;

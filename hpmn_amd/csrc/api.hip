@@ -31,6 +31,8 @@ int embed_grad_scatter_launch(const int32_t *ids, const float *d_x, float *d_emb
                               int32_t F, int32_t E, int32_t front_zero, int32_t mask_id0, hipStream_t st);
 int adam_launch(float *p, const float *g, float *m, float *v, int64_t n, float lr_t, float b1, float b2,
                 float eps, float clip, float gs, hipStream_t st);
+int adam_rows_launch(float *p, const float *g, float *m, float *v, const int64_t *row_ids, int64_t n_rows, int E,
+                     float lr_t, float b1, float b2, float eps, float clip, float gs, hipStream_t st);
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
@@ -298,6 +300,18 @@ int hpmn_adam_step(float *param, const float *grad, float *m, float *v, int64_t 
     if (n == 0) return HPMN_OK;
     if (!param || !grad || !m || !v) return HPMN_EINVAL;
     return adam_launch(param, grad, m, v, n, lr_t, beta1, beta2, eps, clip, grad_scale, (hipStream_t)stream);
+}
+
+int hpmn_adam_step_rows(float *param, const float *grad_rows, float *m, float *v, const int64_t *row_ids,
+                        int64_t n_rows, int32_t E, float lr_t, float beta1, float beta2, float eps, float clip,
+                        float grad_scale, void *stream) {
+    drop_stale_hip_error();
+    if (n_rows < 0 || E < 4) return HPMN_EINVAL;
+    if (E % 4 != 0) return HPMN_EUNSUPPORTED;
+    if (n_rows == 0) return HPMN_OK;
+    if (!param || !grad_rows || !m || !v || !row_ids) return HPMN_EINVAL;
+    return adam_rows_launch(param, grad_rows, m, v, row_ids, n_rows, E, lr_t, beta1, beta2, eps, clip, grad_scale,
+                            (hipStream_t)stream);
 }
 
 int hpmn_gru_fused_fwd_supported(int32_t H, int32_t D, int32_t gather) {

@@ -142,7 +142,7 @@ class Hpmn_Basic(object):
     def __init__(self, path, trainset, testset, feature_size, user_dim, item_dim, learning_rate,
                  hidden_size, embedding_size, hop, user_layers, item_layers, user_num_layers,
                  item_num_layers, user, item, emb_initializer=None, l2_reg=0, memory_reg=1e-5,
-                 device=None, seed: Optional[int] = None, verbose: bool = True):
+                 device=None, seed: Optional[int] = None, verbose: bool = True, lazy_table_adam: Optional[bool] = None):
         if not torch.cuda.is_available():
             raise RuntimeError("hpmn_amd needs an MI355X (ROCm) device: the hot path is HIP-only, "
                                "there is no CPU fallback")
@@ -165,6 +165,12 @@ class Hpmn_Basic(object):
         assert self.user_num_layers <= len(self.user_layers)     # code/hpmn.py:115
         assert not item or self.item_num_layers <= len(self.item_layers)
         self.rank, self.world = dist.rank_world()
+        # Row-wise ("lazy") Adam on the embedding table: ONLY for tables that cannot afford the reference's dense
+        # update (BASELINE configs[4]); a labelled deviation from code/hpmn.py:209-214, off unless asked for.
+        self.lazy_table_adam = bool(int(os.environ.get("HPMN_LAZY_TABLE_ADAM", "0"))) if lazy_table_adam is None \
+            else bool(lazy_table_adam)
+        if self.lazy_table_adam and (self.world > 1 or item or l2_reg):
+            raise NotImplementedError("lazy_table_adam: single process, user-only graph, l2_reg == 0")
         self.table_exchange_chunks = 4
         self._dropout_base, self._dropout_step = (int(seed or 0) * 0x632BE59BD9B4E019 + 0x1234567) & (2 ** 63 - 1), 0
         self._save_path = None
@@ -225,7 +231,9 @@ class Hpmn_Basic(object):
         self._offs = offs
         dev = self.device
         self.flat_param = torch.zeros(n, device=dev, dtype=torch.float32)
-        self.flat_grad = torch.zeros(n, device=dev, dtype=torch.float32)
+        # lazy table Adam: no dense table gradient exists; the flat gradient then covers the dense variables only
+        self._goff = offs[shapes[1][0]] if self.lazy_table_adam else 0
+        self.flat_grad = torch.zeros(n - self._goff, device=dev, dtype=torch.float32)
         self.flat_m = torch.zeros(n, device=dev, dtype=torch.float32)
         self.flat_v = torch.zeros(n, device=dev, dtype=torch.float32)
         self.params: Dict[str, torch.Tensor] = {}
@@ -235,7 +243,8 @@ class Hpmn_Basic(object):
         for name, shape in shapes:
             k = int(np.prod(shape))
             p = self.flat_param[offs[name]:offs[name] + k].view(shape)
-            g = self.flat_grad[offs[name]:offs[name] + k].view(shape)
+            g = None if (self.lazy_table_adam and name == "Embedding/emb_mtx") else \
+                self.flat_grad[offs[name] - self._goff:offs[name] - self._goff + k].view(shape)
             if name == "Embedding/emb_mtx" and emb_initializer is not None:
                 p.copy_(torch.as_tensor(np.asarray(emb_initializer, dtype=np.float32)))
             elif name.endswith("gates/bias") or name.endswith("gamma"):
@@ -287,7 +296,7 @@ class Hpmn_Basic(object):
         d.n_params = self._n_flat - start
         self._read_desc = d
         self._read_params = self.flat_param[start:]
-        self._read_grads = self.flat_grad[start:]
+        self._read_grads = self.flat_grad[start - self._goff:]
 
     # ------------------------------------------------------------------ forward passes
     @torch.no_grad()
@@ -407,8 +416,22 @@ class Hpmn_Basic(object):
             seed = _splitmix64(_splitmix64(self._dropout_base + self._dropout_step) ^ (self.rank + 1)) | 1
         out = ops.read_fwd_bwd(self._read_desc, self._read_params, self._read_grads, memory, last, label, masks,
                                keep_prob, 1.0 / float(global_batch), self.memory_reg, dropout_seed=seed)
-        grad_out = [self.grads["Embedding/emb_mtx"]] + [self.grads[n] for names in self._gru_names for n in names]
-        pending = ops.scan_backward(self.spec, ids, saved, weights, out["d_memory"], out["d_last"], grad_out,
+        if self.lazy_table_adam:
+            # touched rows only: the scatter goes to a COMPACT [U, E] buffer through ids remapped to 0..U-1 (row 0 of
+            # it stays original id 0, so the id-0 mask of the Hpmn graph keeps working on the remapped ids)
+            flat = ids.reshape(-1).long()
+            if self.spec.mask_id0:
+                flat = torch.cat([flat.new_zeros(1), flat])
+            uniq, inv = torch.unique(flat, return_inverse=True)
+            if self.spec.mask_id0:
+                inv = inv[1:]
+            d_emb = torch.zeros(uniq.numel(), self.embedding_size, device=self.device, dtype=torch.float32)
+            scatter_ids = inv.to(torch.int32).view_as(ids).contiguous()
+            out["table_rows"], out["table_row_grads"] = uniq, d_emb
+        else:
+            d_emb, scatter_ids = self.grads["Embedding/emb_mtx"], ids
+        grad_out = [d_emb] + [self.grads[n] for names in self._gru_names for n in names]
+        pending = ops.scan_backward(self.spec, scatter_ids, saved, weights, out["d_memory"], out["d_last"], grad_out,
                                     defer_join=defer_join and not self.l2_reg)
         out["pending"] = pending
         if self.l2_reg:
@@ -440,6 +463,21 @@ class Hpmn_Basic(object):
         # are still being reduced on the side stream: exchange + update the table (99.5 % of the
         # parameters, HBM-bound) underneath them, then join and do the dense rest.
         n_emb = self.params["Embedding/emb_mtx"].numel()
+        if self.lazy_table_adam:
+            self.adam_t += 1
+            t = self.adam_t
+            lr_t = self.learning_rate * math.sqrt(1.0 - self.beta2 ** t) / (1.0 - self.beta1 ** t)
+            V, E = self.feature_size, self.embedding_size
+            if "table_rows" in out:
+                ops.adam_step_rows(self.flat_param[:n_emb].view(V, E), out.pop("table_row_grads"),
+                                   self.flat_m[:n_emb].view(V, E), self.flat_v[:n_emb].view(V, E), out.pop("table_rows"),
+                                   lr_t, self.beta1, self.beta2, self.adam_eps, clip=1.0)
+            if pending is not None:
+                pending.join()
+            lo = self._goff
+            ops.adam_step(self.flat_param[lo:], self.flat_grad, self.flat_m[lo:], self.flat_v[lo:], lr_t, self.beta1,
+                          self.beta2, self.adam_eps, clip=1.0)
+            return out, ce
         if self.world > 1:
             # the table exchange is the one big collective of the step (212 MB at C3): cut it into a few
             # ranges so that clip + Adam of range i run while RCCL is still reducing range i+1

@@ -295,6 +295,18 @@ def adam_step(param, grad, m, v, lr_t, beta1=0.9, beta2=0.999, eps=1e-8, clip=1.
     _lib.check(rc, "hpmn_adam_step")
 
 
+def adam_step_rows(param, grad_rows, m, v, row_ids, lr_t, beta1=0.9, beta2=0.999, eps=1e-8, clip=1.0, grad_scale=1.0):
+    """hpmn_adam_step_rows: the update of ``adam_step`` on the table rows ``row_ids`` [U] int64 only, gradients
+    from the compact ``grad_rows`` [U, E] (lazy / sparse Adam -- a labelled deviation, see include/hpmn_hip.h)."""
+    _chk_f32(param, grad_rows, m, v)
+    assert row_ids.dtype == torch.int64 and row_ids.is_cuda and row_ids.is_contiguous()
+    U, E = grad_rows.shape
+    assert row_ids.numel() == U and param.shape[1] == E
+    rc = _lib.load().hpmn_adam_step_rows(param.data_ptr(), grad_rows.data_ptr(), m.data_ptr(), v.data_ptr(),
+                                          row_ids.data_ptr(), U, E, lr_t, beta1, beta2, eps, clip, grad_scale, _stream())
+    _lib.check(rc, "hpmn_adam_step_rows")
+
+
 def scan_forward_inference(spec: ScanSpec, ids, emb, weights: Sequence[torch.Tensor], workspace=None):
     """hpmn_scan_fwd: whole build_memory forward (no saved states).  weights = [wg0,bg0,wc0,bc0, wg1,...].
     Returns (memory [B,K,H], last [B,D0])."""

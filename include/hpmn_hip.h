@@ -391,6 +391,15 @@ int hpmn_embed_grad_scatter(const int32_t *ids, const float *d_x, float *d_emb,
 int hpmn_adam_step(float *param, const float *grad, float *m, float *v, int64_t n,
                    float lr_t, float beta1, float beta2, float eps, float clip,
                    float grad_scale, void *stream);
+/* Row-wise ("lazy") form for embedding tables too large for the dense sweep (BASELINE configs[4]: a table
+ * sized to HBM cannot also hold a dense gradient, and 28 B/element of dense Adam traffic over 10^9+ rows is the
+ * whole step): the same update applied only to the n_rows table rows row_ids[u] (distinct), whose clipped
+ * gradients are the rows of the COMPACT buffer grad_rows [n_rows, E].  A documented DEVIATION from
+ * code/hpmn.py:209-214 (TF's dense Adam keeps moving a row whose moments are non-zero even when its gradient is
+ * zero) -- the semantics of TF's LazyAdamOptimizer.  param / m / v: [V, E]; E % 4 == 0. */
+int hpmn_adam_step_rows(float *param, const float *grad_rows, float *m, float *v, const int64_t *row_ids,
+                        int64_t n_rows, int32_t E, float lr_t, float beta1, float beta2, float eps, float clip,
+                        float grad_scale, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Online incremental memory update -- the serving-time form of build_memory: ONE new event per

@@ -757,3 +757,38 @@ def test_item_branch_and_dual_mode_match_oracle(dev, tmp_path, industry, H, user
     m.set_params({k: np.zeros_like(v) for k, v in m.get_params().items()})
     m.load_model()
     assert torch.equal(before, m.forward_inference(tu, item_ids=ti)["prediction"])
+
+
+def test_lazy_table_adam_touches_only_the_batch_rows_and_matches_dense_on_them(dev, tmp_path):
+    """lazy_table_adam=True (the labelled deviation for tables too large for the dense sweep): on the FIRST step
+    (all moments zero) the rows a batch touches must end exactly where the dense update puts them, every other
+    row must not move, and the dense variables must be identical; later steps differ from dense only on rows whose
+    moments are non-zero but whose gradient is zero (that IS the deviation) -- checked as: untouched rows never move."""
+    for cfg in (cfg_industry(H=64, K=3, T=41, V=600), cfg_amazon(K=3, T=100, V=600)):
+        p = f32_params(cfg, 141)
+        ids, label = rand_ids(cfg, 6, 142)
+        ids = np.minimum(ids, 299)                                # rows 300.. are never touched
+        md = make_model(cfg, tmp_path, p)
+        from hpmn_amd.hpmn import Hpmn, Hpmn_Industry
+        cls = Hpmn_Industry if cfg.industry else Hpmn
+        ml = cls(str(tmp_path / "lazy"), [], [], cfg.feature_size, cfg.user_dim, 2, cfg.user_maxlen, 10, 0.003, cfg.hidden_size,
+                 16, 3, list(cfg.user_layers), [2, 1], cfg.user_num_layers, 1, True, False, memory_reg=cfg.memory_reg,
+                 verbose=False, lazy_table_adam=True)
+        ml.set_params(p)
+        assert ml.flat_grad.numel() == md.flat_grad.numel() - 600 * 16
+        ti, tl = torch.as_tensor(ids).to(dev), torch.as_tensor(label).to(dev)
+        md.train_step(ti, tl, keep_prob=1.0)
+        ml.train_step(ti, tl, keep_prob=1.0)
+        for k in p:
+            a, b = ml.params[k].cpu().numpy(), md.params[k].cpu().numpy()
+            np.testing.assert_allclose(a, b, rtol=0, atol=1e-6, err_msg=k)            # step 1: identical everywhere
+        e0 = p["Embedding/emb_mtx"].astype(np.float32)
+        for _ in range(3):
+            ml.train_step(ti, tl, keep_prob=1.0)
+        e = ml.params["Embedding/emb_mtx"].cpu().numpy()
+        np.testing.assert_array_equal(e[300:], e0[300:])
+        touched = np.unique(ids)
+        touched = touched[touched != 0] if not cfg.industry else touched
+        assert float(np.abs(e[touched] - e0[touched]).max()) > 1e-4
+        if not cfg.industry:
+            np.testing.assert_array_equal(e[0], e0[0])            # the masked row 0 never gets a gradient
