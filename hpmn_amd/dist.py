@@ -73,3 +73,21 @@ def gather_predictions(pred: torch.Tensor, n_global: int) -> torch.Tensor:
     allp = torch.empty(world * cap, device=pred.device, dtype=pred.dtype)
     td.all_gather_into_tensor(allp, mine)
     return torch.cat([allp[r * cap:r * cap + sizes[r]] for r in range(world)])
+
+
+def reduce_scatter_sum(flat: torch.Tensor, rank: int, world: int) -> torch.Tensor:
+    """Sum over the ranks of ``flat`` (numel divisible by world); returns THIS rank's 1/world slice of the result.
+    RCCL: one reduce-scatter; backends without it (gloo): all-reduce, then the local slice."""
+    shard = flat.numel() // world
+    if td.get_backend() == "nccl":
+        out = torch.empty(shard, device=flat.device, dtype=flat.dtype)
+        td.reduce_scatter_tensor(out, flat, op=td.ReduceOp.SUM)
+        return out
+    td.all_reduce(flat, op=td.ReduceOp.SUM)
+    return flat[rank * shard:(rank + 1) * shard]
+
+
+def all_gather_shards_(flat: torch.Tensor, lo: int, shard: int) -> None:
+    """Every rank contributes flat[lo:lo+shard] (its own slice); afterwards ``flat`` holds all slices in rank order."""
+    mine = flat[lo:lo + shard].clone()
+    td.all_gather_into_tensor(flat, mine)

@@ -101,3 +101,40 @@ def test_chunk_bounds_cover_the_range_with_aligned_cuts():
             assert b[0][0] == 0 and b[-1][1] == n
             assert all(x[1] == y[0] for x, y in zip(b, b[1:])) and all(lo < hi for lo, hi in b)
             assert all(lo % al == 0 for lo, _ in b)
+
+
+def _rs_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n = 4 * 256 * world
+        g = torch.arange(n, dtype=torch.float32) * (rank + 1)
+        mine = dist.reduce_scatter_sum(g.clone(), rank, world).clone()
+        flat = torch.zeros(n)
+        shard = n // world
+        flat[rank * shard:(rank + 1) * shard] = mine + 1000.0 * rank
+        dist.all_gather_shards_(flat, rank * shard, shard)
+        q.put((rank, mine.numpy(), flat.numpy()))
+    finally:
+        td.destroy_process_group()
+
+
+def test_reduce_scatter_and_shard_all_gather_helpers():
+    """The collectives of the "sharded" table update: this rank's slice of the summed gradient, and the updated
+    slices gathered back in rank order (gloo has no reduce-scatter: all-reduce + slice; RCCL uses the real one)."""
+    world = 2
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_rs_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in ps]
+    got = dict((r, (a, b)) for r, a, b in (q.get(timeout=120) for _ in range(world)))
+    [p.join(60) for p in ps]
+    n = 4 * 256 * world
+    total = np.arange(n, dtype=np.float32) * 3.0
+    shard = n // world
+    for r in range(world):
+        np.testing.assert_array_equal(got[r][0], total[r * shard:(r + 1) * shard])
+        want = np.concatenate([total[k * shard:(k + 1) * shard] + 1000.0 * k for k in range(world)])
+        np.testing.assert_array_equal(got[r][1], want)

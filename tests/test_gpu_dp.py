@@ -22,8 +22,11 @@ def _free_port():
     return port
 
 
-def test_two_rank_training_matches_single_process(tmp_path):
-    _run_two_ranks(tmp_path, "gloo")
+@pytest.mark.parametrize("exchange", ["allreduce", "sharded"])
+def test_two_rank_training_matches_single_process(tmp_path, exchange):
+    """exchange = how the replicated table is kept in step: all-reduce + replicated Adam, or reduce-scatter +
+    Adam on 1/world of the rows + all-gather of the updated rows (same arithmetic, 1/world of the Adam traffic)."""
+    _run_two_ranks(tmp_path, "gloo", exchange)
 
 
 def test_two_rank_training_over_rccl_matches_single_process(tmp_path):
@@ -33,13 +36,14 @@ def test_two_rank_training_over_rccl_matches_single_process(tmp_path):
     if torch.cuda.device_count() < 2:
         pytest.skip("needs >= 2 GPUs (RCCL refuses two ranks on one device)")
     _run_two_ranks(tmp_path, "nccl")
+    _run_two_ranks(tmp_path, "nccl", "sharded")
 
 
-def _run_two_ranks(tmp_path, backend):
+def _run_two_ranks(tmp_path, backend, exchange="allreduce"):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     out = str(tmp_path / "dp.npz")
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", HPMN_DP_BACKEND=backend)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", HPMN_DP_BACKEND=backend, HPMN_TABLE_EXCHANGE=exchange)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(HERE, "dp_worker.py"), out]
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
@@ -53,6 +57,11 @@ def _run_two_ranks(tmp_path, backend):
     want = dp_worker.run(m, tr, te)
     for k in want:
         if k == "__eval__":
+            continue
+        if k.endswith(("dense_3/bias", "dense_6/bias", "dense_9/bias")):
+            # the bias in front of a softmax shifts every score alike: its exact gradient is 0, what arrives is
+            # rounding noise, and Adam normalises noise to +-lr steps -- within the trust region is all one can ask
+            np.testing.assert_allclose(got[k], want[k], rtol=0, atol=0.003 * 6 * 1.05, err_msg=k)
             continue
         # same kernels, but per-rank partial sums are added in a different order than one full batch
         np.testing.assert_allclose(got[k], want[k], rtol=0, atol=2e-5, err_msg=k)
