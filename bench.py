@@ -125,8 +125,9 @@ def source_sha():
     import glob
     import hashlib
     h = hashlib.sha1()
-    for f in sorted(glob.glob(os.path.join(ROOT, "hpmn_amd", "csrc", "*"))):
-        h.update(open(f, "rb").read())
+    for f in sorted(glob.glob(os.path.join(ROOT, "hpmn_amd", "csrc", "**", "*"), recursive=True)):
+        if os.path.isfile(f):
+            h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
 
 

@@ -49,6 +49,18 @@ __device__ __forceinline__ float tanh_scaled(float z2) {
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
+// Progress counters between the waves of a workgroup live in LDS and MUST be accessed as LDS: a `volatile int *`
+// parameter is a GENERIC pointer, for which hipcc emits flat_load/flat_store ... sc0 sc1 followed by
+// s_waitcnt vmcnt(0) lgkmcnt(0) -- every poll then drains every outstanding global store of the wave (seen in the
+// ISA of the fused forward kernel: a full store drain every ~8 steps of the scan wave).  These two go through an
+// address_space(3) pointer: plain ds_read_b32 / ds_write_b32, lgkmcnt only.
+typedef __attribute__((address_space(3))) volatile int lds_int;
+__device__ __forceinline__ int lds_counter_peek(int *p) { return *(lds_int *)p; }
+__device__ __forceinline__ void lds_counter_set(int *p, int v) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the data written before must have landed in LDS
+    *(lds_int *)p = v;
+}
+
 // "Use" a whole group of just-loaded LDS values in one place: the compiler's waitcnt pass then emits ONE
 // s_waitcnt (for the newest of them) in front of this statement instead of one in front of each first
 // use.  Every s_waitcnt costs the single wave of a scan workgroup a 4-cycle issue slot

@@ -29,11 +29,8 @@ constexpr int FH = 64;        // hidden size of this kernel
 constexpr int FRING = 8;      // ring slots (steps the producer may run ahead)
 constexpr int FBLK = 8;       // producer prefetch block (steps)
 
-__device__ __forceinline__ int lds_peek(const volatile int *p) { return *p; }
-__device__ __forceinline__ void lds_publish(volatile int *p, int v) {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the data written before must have landed in LDS
-    *p = v;
-}
+__device__ __forceinline__ int lds_peek(int *p) { return lds_counter_peek(p); }
+__device__ __forceinline__ void lds_publish(int *p, int v) { lds_counter_set(p, v); }
 
 // acc_c += sum over NQ float4 of a wave-uniform LDS row times three packed weight sets (bcast_matvec, x3)
 template <int NQ, int G>

@@ -10,6 +10,8 @@
 // chunk in HBM: they are fetched three 2-step chunks ahead (4 x 8 B per lane), parked in an LDS ring
 // and read back per step, so the only HBM access on the serial chain is the fire-and-forget
 // store of d_act.  Weight/input gradients are MFMA reductions over d_act (gru_wgrad.hip).
+#include <cstdlib>
+
 #include "common.h"
 
 namespace hpmn {
@@ -176,6 +178,188 @@ __global__ __launch_bounds__(64, 1) void gru_scan_bwd_kernel(const HpmnGruBwd a)
     if (t_lo0 > 0) a.dh_carry[b * H + l] = dh;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// H = 64 with a HELPER wave.  A single wave issues one instruction per ~5.3 cycles whatever it is, and the reverse
+// step is ~300 of them, so its length is issue time.  The update-gate half of the second product,
+//     e_u[k] = sum_n da_u[n] Wg[D+k][H+n]                       (16 broadcast reads + 32 packed FMAs per step),
+// needs nothing but da_u, which the main wave knows at the very START of the step: a second wave of the sequence's
+// workgroup (on another SIMD of the CU -- at the reference batch half of them idle) computes it while the main
+// wave is busy with d(rh) and da_r, and hands it back through LDS.  No barrier: the main wave publishes "da_u of
+// iteration k is in LDS" (data, then a counter: LDS operations of a wave execute in order), the helper publishes
+// "e_u of iteration k is in LDS"; the main wave cannot overwrite da_u before it has consumed e_u, which the helper
+// only produces after reading all of da_u.  Everything else is gru_scan_bwd_kernel<64>.
+__device__ __forceinline__ int bw_peek(int *p) { return lds_counter_peek(p); }
+
+__global__ __launch_bounds__(128, 1) void gru_scan_bwd_helper_kernel(const HpmnGruBwd a) {
+    constexpr int H = 64;
+    constexpr int GF = BCS * 3 * H, HF = BCS * H;
+    __shared__ __attribute__((aligned(16))) float gring[BRING][GF];
+    __shared__ __attribute__((aligned(16))) float hring[BRING][HF];
+    __shared__ float dring[BRING][BCS * 64];
+    __shared__ __attribute__((aligned(16))) float bufA[H];
+    __shared__ __attribute__((aligned(16))) float bufB[2 * H];
+    __shared__ float eU[2][H];
+    __shared__ int dau_pub, eu_pub;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l = lane;
+    const int T = a.T, D = a.D;
+    const long b = blockIdx.x;
+    const int t_lo0 = a.t_begin;
+    const int t_hi = a.t_end > 0 ? a.t_end : T;
+    const int nsteps = t_hi - t_lo0;
+    if (threadIdx.x == 0) { dau_pub = 0; eu_pub = 0; }
+    __syncthreads();
+
+    if (wave == 1) {
+        // ------------------------------------------------------------------ helper: e_u of every iteration
+        __builtin_amdgcn_s_setprio(2);
+        f2 wuT[H / 2];       // row D+l of the update-gate block, packed over consecutive n
+#pragma unroll
+        for (int n = 0; n < H / 2; ++n) wuT[n] = *reinterpret_cast<const f2 *>(a.wg + (long)(D + l) * 2 * H + H + 2 * n);
+#pragma unroll
+        for (int n = 0; n < H / 2; ++n) settle(wuT[n]);
+        int seen = 0;
+        for (int k = 0; k < nsteps; ++k) {
+            while (seen <= k) {
+                seen = bw_peek(&dau_pub);
+                if (seen <= k) __builtin_amdgcn_s_sleep(1);
+            }
+            asm volatile("" ::: "memory");
+            f2 e0 = {0.f, 0.f}, e1 = {0.f, 0.f};
+            bcast_matvec<H / 4>(reinterpret_cast<const float4 *>(&bufB[H]), wuT, e0, e1);
+            eU[k & 1][l] = (e0.x + e0.y) + (e1.x + e1.y);
+            lds_counter_set(&eu_pub, k + 1);
+        }
+        return;
+    }
+
+    __builtin_amdgcn_s_setprio(3);
+    f2 wcT[H / 2], wrT[H / 2];
+#pragma unroll
+    for (int n = 0; n < H / 2; ++n) wcT[n] = *reinterpret_cast<const f2 *>(a.wc + (long)(D + l) * H + 2 * n);
+#pragma unroll
+    for (int n = 0; n < H / 2; ++n) wrT[n] = *reinterpret_cast<const f2 *>(a.wg + (long)(D + l) * 2 * H + 2 * n);
+#pragma unroll
+    for (int n = 0; n < H / 2; ++n) { settle(wcT[n]); settle(wrT[n]); }
+
+    const int period = a.period;
+    const bool has_dy = a.d_y != nullptr;
+    const float *gb = a.gates + b * (long)T * 3 * H;
+    const float *hsb = a.hs + b * (long)(T + 1) * H;
+    const float *dyb = has_dy ? a.d_y + b * (long)(T / period) * H + l : a.d_h_last + b * a.d_h_last_stride + l;
+    const long dy_stride = has_dy ? H : 0;
+
+    int g_row[3], g_col[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int e = 2 * (i * H + l);
+        g_row[i] = e / (3 * H);
+        g_col[i] = e - g_row[i] * 3 * H;
+    }
+    const int h_row = (2 * l) / H, h_col = 2 * l - h_row * H;
+    int pf_fire = t_hi - 1, pf_row = t_hi / period - 1;
+
+    struct Pre { f2 g[3]; f2 hp; float dy[BCS]; bool m[BCS]; };
+    auto load_chunk = [&](int q, Pre &p) {
+        const int t_lo = t_hi - BCS * (q + 1);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            int t = t_lo + g_row[i];
+            t = t > 0 ? t : 0;
+            p.g[i] = *reinterpret_cast<const f2 *>(gb + (long)t * 3 * H + g_col[i]);
+        }
+        {
+            int t = t_lo + h_row;
+            t = t > 0 ? t : 0;
+            p.hp = *reinterpret_cast<const f2 *>(hsb + (long)t * H + h_col);
+        }
+#pragma unroll
+        for (int tt = BCS - 1; tt >= 0; --tt) {
+            const bool fire = has_dy && t_lo + tt == pf_fire && pf_row >= 0;
+            p.dy[tt] = dyb[(long)(pf_row > 0 ? pf_row : 0) * dy_stride];
+            p.m[tt] = fire;
+            pf_row -= fire ? 1 : 0;
+            pf_fire -= fire ? period : 0;
+        }
+    };
+    auto park_chunk = [&](int q, const Pre &p) {
+        float *gd = &gring[q % BRING][0];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) *reinterpret_cast<f2 *>(gd + 2 * (i * H + l)) = p.g[i];
+        *reinterpret_cast<f2 *>(&hring[q % BRING][2 * l]) = p.hp;
+#pragma unroll
+        for (int tt = 0; tt < BCS; ++tt) dring[q % BRING][tt * 64 + lane] = p.m[tt] ? p.dy[tt] : 0.f;
+    };
+
+    const int nchunk = (nsteps + BCS - 1) / BCS;
+    {
+        Pre p;
+#pragma unroll
+        for (int q = 0; q < BPD; ++q) {
+            load_chunk(q, p);
+            park_chunk(q, p);
+        }
+    }
+    float dh = (t_hi == T) ? a.d_h_last[b * a.d_h_last_stride + l] : a.dh_carry[b * H + l];
+    settle(dh);
+    wave_sync();
+
+    int kk = 0, eu_seen = 0;       // iteration count of this launch
+    auto step = [&](int t, int tt, const float *gc, const float *hc, const float *dc) {
+        const float r = gc[tt * 3 * H], u = gc[tt * 3 * H + H], c = gc[tt * 3 * H + 2 * H];
+        const float hp = hc[tt * H];
+        dh += dc[tt * 64];
+        const float omu = 1.f - u;
+        const float dcp = dh * omu * (1.f - c * c);
+        const float dau = dh * (hp - c) * u * omu;
+        bufB[H + l] = dau;
+        bufA[lane] = dcp;
+        lds_counter_set(&dau_pub, kk + 1);                           // the helper may start on da_u
+        wave_sync();
+        f2 d0 = {0.f, 0.f}, d1 = {0.f, 0.f};
+        bcast_matvec<H / 4>(reinterpret_cast<const float4 *>(&bufA[0]), wcT, d0, d1);
+        const float drh = (d0.x + d0.y) + (d1.x + d1.y);
+        const float dar = drh * hp * r * (1.f - r);
+        bufB[l] = dar;
+        wave_sync();
+        f2 e0 = {0.f, 0.f}, e1 = {0.f, 0.f};
+        bcast_matvec<H / 4>(reinterpret_cast<const float4 *>(&bufB[0]), wrT, e0, e1);
+        float *da = a.d_act + (b * T + t) * 3 * H + l;
+        da[0] = dar;
+        da[H] = dau;
+        da[2 * H] = dcp;
+        while (eu_seen <= kk) {
+            eu_seen = bw_peek(&eu_pub);
+            if (eu_seen <= kk) __builtin_amdgcn_s_sleep(1);
+        }
+        asm volatile("" ::: "memory");
+        const float eu = eU[kk & 1][l];
+        dh = fmaf(dh, u, fmaf(drh, r, ((e0.x + e0.y) + (e1.x + e1.y)) + eu));
+        kk += 1;
+        wave_sync();
+    };
+
+    const int nfull = nsteps / BCS;
+    for (int q = 0; q < nfull; ++q) {
+        Pre pre;
+        load_chunk(q + BPD, pre);
+        const int t_lo = t_hi - BCS * (q + 1);
+        const float *gc = &gring[q % BRING][l];
+        const float *hc = &hring[q % BRING][l];
+        const float *dc = &dring[q % BRING][lane];
+#pragma unroll
+        for (int jj = 0; jj < BCS; ++jj) step(t_lo + BCS - 1 - jj, BCS - 1 - jj, gc, hc, dc);
+        park_chunk(q + BPD, pre);
+        wave_sync();
+    }
+    if (nfull < nchunk) {
+        const int q = nfull;
+        step(t_lo0, BCS - 1, &gring[q % BRING][l], &hring[q % BRING][l], &dring[q % BRING][lane]);
+    }
+    if (t_lo0 > 0) a.dh_carry[b * H + l] = dh;
+}
+
 int gru_scan_bwd128_dispatch(const HpmnGruBwd &a, hipStream_t st);   // gru_scan128.hip
 
 int gru_scan_bwd_dispatch(const HpmnGruBwd &a, hipStream_t st) {
@@ -183,7 +367,12 @@ int gru_scan_bwd_dispatch(const HpmnGruBwd &a, hipStream_t st) {
     if (a.H == 32) {
         hipLaunchKernelGGL((gru_scan_bwd_kernel<32>), dim3((a.B + 1) / 2), dim3(64), 0, st, a);
     } else if (a.H == 64) {
-        hipLaunchKernelGGL((gru_scan_bwd_kernel<64>), dim3(a.B), dim3(64), 0, st, a);
+        // helper-wave variant (HPMN_BWD_HELPER=1): 4 % faster alone (0.651 vs 0.678 ms at C3 layer 0) but 7 % SLOWER
+        // inside the step (0.873 vs 0.815 ms), where the weight-gradient kernels of the layer above share the chip
+        // with it -- measured, default off
+        static const int helper = [] { const char *e = getenv("HPMN_BWD_HELPER"); return e ? atoi(e) : 0; }();
+        if (helper && a.B <= 640) hipLaunchKernelGGL(gru_scan_bwd_helper_kernel, dim3(a.B), dim3(128), 0, st, a);
+        else                     hipLaunchKernelGGL((gru_scan_bwd_kernel<64>), dim3(a.B), dim3(64), 0, st, a);
     } else {
         return HPMN_EUNSUPPORTED;
     }
