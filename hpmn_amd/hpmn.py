@@ -175,7 +175,8 @@ class Hpmn_Basic(object):
         # how the replicas keep the (replicated) table in step: "allreduce" = sum all-reduce of the table gradient in
         # a few ranges + replicated dense Adam (every rank sweeps the whole table); "sharded" = reduce-scatter of the
         # gradient, Adam on this rank's 1/world of the rows only, all-gather of the updated rows -- the same bytes
-        # on the wire, 1/world of the 28 B/element optimiser traffic per GPU (identical arithmetic)
+        # on the wire, 1/world of the 28 B/element optimiser traffic per GPU (identical arithmetic); "single" = one
+        # blocking all-reduce over the whole flat gradient, then one update (no overlap: the fallback switch)
         self.table_exchange = os.environ.get("HPMN_TABLE_EXCHANGE", "allreduce")
         self._dropout_base, self._dropout_step = (int(seed or 0) * 0x632BE59BD9B4E019 + 0x1234567) & (2 ** 63 - 1), 0
         self._save_path = None
@@ -485,6 +486,13 @@ class Hpmn_Basic(object):
             lo = self._goff
             ops.adam_step(self.flat_param[lo:], self.flat_grad, self.flat_m[lo:], self.flat_v[lo:], lr_t, self.beta1,
                           self.beta2, self.adam_eps, clip=1.0)
+            return out, ce
+        if self.world > 1 and self.table_exchange == "single":
+            # the plainest scheme (fallback switch): join, ONE all-reduce over the whole flat gradient, one update
+            if pending is not None:
+                pending.join()
+            dist.allreduce_sum_(self.flat_grad)
+            self.apply_gradients()
             return out, ce
         if self.world > 1 and self.table_exchange == "sharded":
             n_pad = self._emb_numel_padded

@@ -22,7 +22,7 @@ def _free_port():
     return port
 
 
-@pytest.mark.parametrize("exchange", ["allreduce", "sharded"])
+@pytest.mark.parametrize("exchange", ["allreduce", "sharded", "single"])
 def test_two_rank_training_matches_single_process(tmp_path, exchange):
     """exchange = how the replicated table is kept in step: all-reduce + replicated Adam, or reduce-scatter +
     Adam on 1/world of the rows + all-gather of the updated rows (same arithmetic, 1/world of the Adam traffic)."""
