@@ -792,3 +792,40 @@ def test_lazy_table_adam_touches_only_the_batch_rows_and_matches_dense_on_them(d
         assert float(np.abs(e[touched] - e0[touched]).max()) > 1e-4
         if not cfg.industry:
             np.testing.assert_array_equal(e[0], e0[0])            # the masked row 0 never gets a gradient
+
+
+def test_table_rows_beyond_2_gib_give_identical_results(dev, tmp_path):
+    """BASELINE configs[4] is about tables far larger than any cache: every kernel that indexes the table (gather in
+    the projection / fused forward / inference chain, gradient scatter, dense and row-wise Adam) must do its row
+    arithmetic in 64 bits.  A 40 M-row table (2.4 GiB per buffer) whose top 600 rows hold a small model's table, ids
+    shifted to match: outputs, the gradient rows and the updated rows must be bit-identical to the small model's."""
+    from hpmn_amd.hpmn import Hpmn_Industry
+    cfg = cfg_industry(H=64, K=3, T=41, V=600)
+    p = f32_params(cfg, 151)
+    ids, label = rand_ids(cfg, 6, 152)
+    base = 40_000_000 - 600
+    small = make_model(cfg, tmp_path, p)
+    big = Hpmn_Industry(str(tmp_path / "big"), [], [], 40_000_000, 2, 1, 41, 1, 0.003, 64, 16, 3, [2] * 10 + [1], [1], 3, 1,
+                        True, False, memory_reg=cfg.memory_reg, verbose=False)
+    big.set_params({k: v for k, v in p.items() if k != "Embedding/emb_mtx"})
+    with torch.no_grad():
+        big.params["Embedding/emb_mtx"].zero_()
+        big.params["Embedding/emb_mtx"][base:].copy_(small.params["Embedding/emb_mtx"])
+    ts, tb = torch.as_tensor(ids).to(dev), torch.as_tensor(ids + base).to(dev)
+    tl = torch.as_tensor(label).to(dev)
+    a, b = small.forward_inference(ts), big.forward_inference(tb)
+    assert torch.equal(a["logit"], b["logit"]) and torch.equal(a["memory"], b["memory"])
+    small.compute_gradients(ts, tl, keep_prob=1.0)
+    big.compute_gradients(tb, tl, keep_prob=1.0)
+    gs, gb = small.grads["Embedding/emb_mtx"], big.grads["Embedding/emb_mtx"]
+    np.testing.assert_allclose(gb[base:].cpu().numpy(), gs.cpu().numpy(), rtol=0, atol=1e-7)   # (atomics: last-bit order)
+    assert float(gb[:base].abs().max()) == 0.0
+    for k in p:
+        if k != "Embedding/emb_mtx":
+            np.testing.assert_allclose(big.grads[k].cpu().numpy(), small.grads[k].cpu().numpy(), rtol=0,
+                                       atol=1e-6 * float(small.grads[k].abs().max()) + 1e-12, err_msg=k)
+    small.train_step(ts, tl, keep_prob=1.0)
+    big.train_step(tb, tl, keep_prob=1.0)
+    np.testing.assert_allclose(big.params["Embedding/emb_mtx"][base:].cpu().numpy(),
+                               small.params["Embedding/emb_mtx"].cpu().numpy(), rtol=0, atol=2e-6)
+    assert float(big.params["Embedding/emb_mtx"][:base].abs().max()) == 0.0

@@ -31,7 +31,13 @@ def main():
             subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-w",
                                    "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-S", "--cuda-device-only",
                                    "-o", out, src])
-            rows = PAT.findall(open(out).read())
+            text = open(out).read()
+            nflat = len(re.findall(r"^\s+flat_(?:load|store|atomic)", text, flags=re.M))
+            if nflat:
+                # an LDS or global access through a GENERIC pointer: flat_* counts in vmcnt AND lgkmcnt, so waiting for
+                # it drains the wave's global stores (progress counters of the fused forward kernel)
+                print("%-58s %d flat_load/store/atomic instruction(s)  <-- generic-pointer access" % (os.path.basename(src), nflat))
+            rows = PAT.findall(text)
             names = demangle([r[0] for r in rows])
             for name, r in zip(names, rows):
                 scratch, sgpr, sspill, vgpr, vspill = map(int, r[1:])
