@@ -381,8 +381,8 @@ def chunk_plan(spec: ScanSpec, nc: int):
 # ---------------------------------------------------------------------------------------
 # HPMN_PIPE = "0" (default): per-layer, per-sequence kernels; "all": every layer in ONE pipelined, batch-tiled MFMA
 # launch (hpmn_pipe_fwd / hpmn_pipe_bwd); "upper": layer 0 on the per-sequence kernels, layers 1..K-1 pipelined.
-# The pipelined launches are parity-green but measured SLOWER at the reference batch (C3, B=500: forward 1.61 /
-# 1.50 / 1.25 ms, backward 2.27 / 2.15 / 2.29 ms for all / upper / 0) -- a tile of 16 sequences concentrates on
+# The pipelined launches are parity-green but measured SLOWER at the reference batch (C3, B=500: forward 1.52 /
+# 1.42 / 1.14 ms, backward 2.31 / 2.29 / 2.29 ms for all / upper / 0) -- a tile of 16 sequences concentrates on
 # one CU the LDS traffic, transcendental work and stores that one-sequence-per-wave spreads over eight;
 # DESIGN.md section 3.7 has the per-step cycle accounting.
 PIPE = os.environ.get("HPMN_PIPE", "0")
