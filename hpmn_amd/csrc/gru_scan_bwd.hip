@@ -367,10 +367,10 @@ int gru_scan_bwd_dispatch(const HpmnGruBwd &a, hipStream_t st) {
     if (a.H == 32) {
         hipLaunchKernelGGL((gru_scan_bwd_kernel<32>), dim3((a.B + 1) / 2), dim3(64), 0, st, a);
     } else if (a.H == 64) {
-        // helper-wave variant (HPMN_BWD_HELPER=1): 4 % faster alone (0.651 vs 0.678 ms at C3 layer 0) but 7 % SLOWER
-        // inside the step (0.873 vs 0.815 ms), where the weight-gradient kernels of the layer above share the chip
-        // with it -- measured, default off
-        static const int helper = [] { const char *e = getenv("HPMN_BWD_HELPER"); return e ? atoi(e) : 0; }();
+        // helper-wave variant (default; HPMN_BWD_HELPER=0 selects the one-wave kernel): 0.651 vs 0.678 ms alone at C3
+        // layer 0, and 0.683 vs 0.744 ms inside the step now that the weight-gradient launches leave room on every
+        // CU (gru_wgrad.hip: one workgroup per CU; before that change the variant LOST in-step, 0.873 vs 0.815)
+        static const int helper = [] { const char *e = getenv("HPMN_BWD_HELPER"); return e ? atoi(e) : 1; }();
         if (helper && a.B <= 640) hipLaunchKernelGGL(gru_scan_bwd_helper_kernel, dim3(a.B), dim3(128), 0, st, a);
         else                     hipLaunchKernelGGL((gru_scan_bwd_kernel<64>), dim3(a.B), dim3(64), 0, st, a);
     } else {

@@ -21,6 +21,8 @@
 //     partial result as a slab in a caller-provided workspace and wgrad_reduce_kernel adds the
 //     slabs into dW (single writer per element: deterministic, no atomics).
 // (2) dx = d_act Wx^T is a row-wise transform: gru_dx_kernel in input_proj.hip.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace hpmn {
@@ -270,7 +272,26 @@ static int launch_wgrad(const HpmnGruWgrad &a, hipStream_t st) {
     HpmnGruWgrad k = a;
     k.seq_per_wg = wgrad_seq_per_wg(a.t_len > 0 ? a.t_len : a.T);
     const int nwg = (a.B + k.seq_per_wg - 1) / k.seq_per_wg;
-    hipLaunchKernelGGL((gru_wgrad_kernel<HT, DT, CS>), dim3((unsigned)nwg, CS), dim3(64 * (HT + DT)), 0, st, k);
+    // One weight-gradient workgroup per CU while the launch shares the chip with a reverse scan (every layer but the
+    // longest): two of them take every register of a CU, and the single-wave workgroups of the next reverse scan --
+    // the serial chain -- then cannot even be dispatched until they retire.  Asking for > 80 KiB of (unused) dynamic
+    // LDS caps the occupancy at one per CU; HPMN_WGRAD_SOLO_ROWS = largest B*T that gets this treatment (0 = never).
+    // Measured (C3 / C2 / C4 steps, ms): 3.985 -> 3.846 / 1.655 -> 1.591 / 10.29 -> 10.47: on for H <= 64 (the H = 128
+    // kernels are already shaped for two workgroups per CU around their column split).
+    static const long solo_env = [] { const char *e = getenv("HPMN_WGRAD_SOLO_ROWS"); return e ? atol(e) : -1L; }();
+    const long solo_rows = solo_env >= 0 ? solo_env : (a.H <= 64 ? (1L << 62) : 0L);
+    const long rows = (long)a.B * (a.t_len > 0 ? a.t_len : a.T);
+    size_t lds_pad = 0;
+    if (rows <= solo_rows) {
+        lds_pad = 72 * 1024;
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gru_wgrad_kernel<HT, DT, CS>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
+            attr = true;
+        }
+    }
+    hipLaunchKernelGGL((gru_wgrad_kernel<HT, DT, CS>), dim3((unsigned)nwg, CS), dim3(64 * (HT + DT)), lds_pad, st, k);
     int rc = check_launch();
     if (rc != HPMN_OK) return rc;
     const int H = a.H, D = a.D;
