@@ -210,16 +210,19 @@ def roofline_probes(model, c, batches, step_fn):
         del gtab
 
     scan_flops = B * T0 * 2 * H * 3 * H           # recurrent half; the input half is accounted to input_proj
+    # (H = 64 at the reference batch runs the helper-wave variant of the reverse scan, gru_scan_bwd.hip)
+    helper = H == 64 and B <= 640 and os.environ.get("HPMN_BWD_HELPER", "1") != "0"
+    dom_kernel = "gru_scan_bwd_helper_kernel<false>" if helper else "gru_scan_bwd_kernel<%d>" % H
     dom_t = in_step_ms if in_step_ms is not None else max(t_bwd, t_fwd)
     pmc = pmc_digest(c, B)
     traffic = None
     step_bytes = None
     if pmc is not None:
-        kk = pmc["kernels"].get("gru_scan_bwd_kernel<%d>" % H)
+        kk = pmc["kernels"].get(dom_kernel)
         if kk:
             traffic = kk["hbm_bytes_max_launch"]
         step_bytes = pmc.get("hbm_bytes_per_step")
-    roof = {"kernel": "gru_scan_bwd_kernel<%d> layer 0 (T=%d)" % (H, T0), "bound": "mfma",
+    roof = {"kernel": "%s layer 0 (T=%d)" % (dom_kernel, T0), "bound": "mfma",
             "achieved": scan_flops / (dom_t * 1e-3) / 1e12, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
             "frac": scan_flops / (dom_t * 1e-3) / 1e12 / PEAK_F32_TFLOPS,
             "traffic": traffic, "traffic_unit": "bytes/launch",

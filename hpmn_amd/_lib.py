@@ -10,7 +10,7 @@ import os
 from typing import Optional
 
 HPMN_MAX_LAYERS = 12
-HPMN_ABI_VERSION = 3
+HPMN_ABI_VERSION = 4
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libhpmn_hip.so")
@@ -54,6 +54,7 @@ class HpmnGruBwd(C.Structure):
         ("d_act", C.c_void_p),
         ("t_begin", C.c_int32), ("t_end", C.c_int32),
         ("dh_carry", C.c_void_p),
+        ("d_x", C.c_void_p),
     ]
 
 
@@ -154,6 +155,7 @@ SIGNATURES = {
     "hpmn_gru_input_proj": (C.c_int, [C.POINTER(HpmnInputProj), C.c_void_p]),
     "hpmn_gru_scan_fwd": (C.c_int, [C.POINTER(HpmnGruFwd), C.c_void_p]),
     "hpmn_gru_scan_bwd": (C.c_int, [C.POINTER(HpmnGruBwd), C.c_void_p]),
+    "hpmn_gru_scan_bwd_fuses_dx": (C.c_int, [C.c_int32, C.c_int32]),
     "hpmn_gru_param_grads_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "hpmn_gru_param_grads": (C.c_int, [C.POINTER(HpmnGruWgrad), C.c_void_p]),
     "hpmn_gru_input_grad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,

@@ -10,6 +10,7 @@ void set_last_hip_error(int e) { g_last_hip_error = e; }
 bool gru_shape_supported(int H, int D);
 int gru_scan_fwd_dispatch(const HpmnGruFwd &a, hipStream_t st);
 int gru_scan_bwd_dispatch(const HpmnGruBwd &a, hipStream_t st);
+bool gru_scan_bwd_fuses_dx(int H, int B);
 bool input_proj_supported(int H, int D);
 int memory_update_launch(const HpmnOnlineUpdate &a, hipStream_t st);
 bool gru_fused_fwd_supported(int H, int D, int gather);
@@ -135,11 +136,14 @@ int hpmn_gru_scan_bwd(const HpmnGruBwd *a, void *stream) {
         if (a->d_y && t_hi % a->period != 0) return HPMN_EINVAL;
     }
     if (!gru_shape_supported(a->H, a->D)) return HPMN_EUNSUPPORTED;
+    if (a->d_x && (!gru_scan_bwd_fuses_dx(a->H, a->B) || a->D > 64)) return HPMN_EUNSUPPORTED;
     if (a->B == 0) return HPMN_OK;
     HpmnGruBwd k = *a;
     if (k.period < 1) k.period = 1;
     return gru_scan_bwd_dispatch(k, (hipStream_t)stream);
 }
+
+int hpmn_gru_scan_bwd_fuses_dx(int32_t H, int32_t B) { return gru_scan_bwd_fuses_dx(H, B) ? 1 : 0; }
 
 size_t hpmn_gru_param_grads_workspace_bytes(int32_t B, int32_t T, int32_t D, int32_t H) {
     if (B < 1 || T < 1 || D < 1 || H < 1) return 0;

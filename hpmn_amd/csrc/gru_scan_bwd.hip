@@ -190,16 +190,23 @@ __global__ __launch_bounds__(64, 1) void gru_scan_bwd_kernel(const HpmnGruBwd a)
 // only produces after reading all of da_u.  Everything else is gru_scan_bwd_kernel<64>.
 __device__ __forceinline__ int bw_peek(int *p) { return lds_counter_peek(p); }
 
-__global__ __launch_bounds__(128, 1) void gru_scan_bwd_helper_kernel(const HpmnGruBwd a) {
+// DX = true adds a THIRD wave: the gradient wrt the layer's input rows, d_x[t] = [da_r | da_u | dc_pre] [Wg[:D] | Wc[:D]]^T
+// (row d of the input blocks register-stationary in lane d, the three operand rows are already in LDS for the main
+// wave's own products).  That is the whole gru_dx launch of this layer -- for layers >= 1 the d_y the next reverse
+// scan waits for, a kernel on the serial chain -- done underneath the scan.  The operand buffers are double-buffered
+// by step parity so that wave has a full step to read them; it reports what it has read (dx_read) and the main wave
+// checks that (a cached counter) before it reuses a buffer.
+template <bool DX>
+__global__ __launch_bounds__(DX ? 192 : 128, DX ? 2 : 1) void gru_scan_bwd_helper_kernel(const HpmnGruBwd a) {
     constexpr int H = 64;
     constexpr int GF = BCS * 3 * H, HF = BCS * H;
     __shared__ __attribute__((aligned(16))) float gring[BRING][GF];
     __shared__ __attribute__((aligned(16))) float hring[BRING][HF];
     __shared__ float dring[BRING][BCS * 64];
-    __shared__ __attribute__((aligned(16))) float bufA[H];
-    __shared__ __attribute__((aligned(16))) float bufB[2 * H];
+    __shared__ __attribute__((aligned(16))) float bufA[2][H];
+    __shared__ __attribute__((aligned(16))) float bufB[2][2 * H];
     __shared__ float eU[2][H];
-    __shared__ int dau_pub, eu_pub;
+    __shared__ int dau_pub, eu_pub, dar_pub, dx_read;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l = lane;
@@ -208,7 +215,7 @@ __global__ __launch_bounds__(128, 1) void gru_scan_bwd_helper_kernel(const HpmnG
     const int t_lo0 = a.t_begin;
     const int t_hi = a.t_end > 0 ? a.t_end : T;
     const int nsteps = t_hi - t_lo0;
-    if (threadIdx.x == 0) { dau_pub = 0; eu_pub = 0; }
+    if (threadIdx.x == 0) { dau_pub = 0; eu_pub = 0; dar_pub = 0; dx_read = 0; }
     __syncthreads();
 
     if (wave == 1) {
@@ -227,11 +234,45 @@ __global__ __launch_bounds__(128, 1) void gru_scan_bwd_helper_kernel(const HpmnG
             }
             asm volatile("" ::: "memory");
             f2 e0 = {0.f, 0.f}, e1 = {0.f, 0.f};
-            bcast_matvec<H / 4>(reinterpret_cast<const float4 *>(&bufB[H]), wuT, e0, e1);
+            bcast_matvec<H / 4>(reinterpret_cast<const float4 *>(&bufB[k & 1][H]), wuT, e0, e1);
             eU[k & 1][l] = (e0.x + e0.y) + (e1.x + e1.y);
             lds_counter_set(&eu_pub, k + 1);
         }
         return;
+    }
+    if constexpr (DX) {
+        if (wave == 2) {
+            // -------------------------------------------------------------- input gradient of every iteration
+            const int d = lane < D ? lane : D - 1;     // lanes past D repeat the last row (never stored)
+            f2 wxg[H], wxc[H / 2];                     // row d of Wg[:D] (r | u columns) and of Wc[:D]
+#pragma unroll
+            for (int n = 0; n < H; ++n) wxg[n] = *reinterpret_cast<const f2 *>(a.wg + (long)d * 2 * H + 2 * n);
+#pragma unroll
+            for (int n = 0; n < H / 2; ++n) wxc[n] = *reinterpret_cast<const f2 *>(a.wc + (long)d * H + 2 * n);
+#pragma unroll
+            for (int n = 0; n < H; ++n) settle(wxg[n]);
+#pragma unroll
+            for (int n = 0; n < H / 2; ++n) settle(wxc[n]);
+            float *dxp = a.d_x + (b * (long)T + (t_hi - 1)) * D + d;
+            int seen = 0;
+            for (int k = 0; k < nsteps; ++k) {
+                while (seen <= k) {
+                    seen = bw_peek(&dar_pub);
+                    if (seen <= k) __builtin_amdgcn_s_sleep(2);
+                }
+                asm volatile("" ::: "memory");
+                f2 x0 = {0.f, 0.f}, x1 = {0.f, 0.f}, x2 = {0.f, 0.f}, x3 = {0.f, 0.f};
+                // (two reads in flight instead of four: this wave holds 192 stationary weights and must stay under
+                //  256 registers so that two workgroups fit a CU)
+                bcast_matvec<2 * H / 4, 2>(reinterpret_cast<const float4 *>(&bufB[k & 1][0]), wxg, x0, x1);
+                bcast_matvec<H / 4, 2>(reinterpret_cast<const float4 *>(&bufA[k & 1][0]), wxc, x2, x3);
+                lds_counter_set(&dx_read, k + 1);            // (every read above has been consumed)
+                const float v = ((x0.x + x0.y) + (x1.x + x1.y)) + ((x2.x + x2.y) + (x3.x + x3.y));
+                if (lane < D) *dxp = v;
+                dxp -= D;
+            }
+            return;
+        }
     }
 
     __builtin_amdgcn_s_setprio(3);
@@ -305,26 +346,36 @@ __global__ __launch_bounds__(128, 1) void gru_scan_bwd_helper_kernel(const HpmnG
     settle(dh);
     wave_sync();
 
-    int kk = 0, eu_seen = 0;       // iteration count of this launch
+    int kk = 0, eu_seen = 0, dxr_seen = 0;       // iteration count of this launch
     auto step = [&](int t, int tt, const float *gc, const float *hc, const float *dc) {
+        const int p = kk & 1;
         const float r = gc[tt * 3 * H], u = gc[tt * 3 * H + H], c = gc[tt * 3 * H + 2 * H];
         const float hp = hc[tt * H];
         dh += dc[tt * 64];
         const float omu = 1.f - u;
         const float dcp = dh * omu * (1.f - c * c);
         const float dau = dh * (hp - c) * u * omu;
-        bufB[H + l] = dau;
-        bufA[lane] = dcp;
+        if constexpr (DX) {
+            // buffer p was last used in iteration kk-2: the dx wave must have read it
+            while (dxr_seen < kk - 1) {
+                dxr_seen = bw_peek(&dx_read);
+                if (dxr_seen < kk - 1) __builtin_amdgcn_s_sleep(1);
+            }
+            asm volatile("" ::: "memory");
+        }
+        bufB[p][H + l] = dau;
+        bufA[p][lane] = dcp;
         lds_counter_set(&dau_pub, kk + 1);                           // the helper may start on da_u
         wave_sync();
         f2 d0 = {0.f, 0.f}, d1 = {0.f, 0.f};
-        bcast_matvec<H / 4>(reinterpret_cast<const float4 *>(&bufA[0]), wcT, d0, d1);
+        bcast_matvec<H / 4>(reinterpret_cast<const float4 *>(&bufA[p][0]), wcT, d0, d1);
         const float drh = (d0.x + d0.y) + (d1.x + d1.y);
         const float dar = drh * hp * r * (1.f - r);
-        bufB[l] = dar;
+        bufB[p][l] = dar;
+        if constexpr (DX) lds_counter_set(&dar_pub, kk + 1);         // all three operand rows of this step are in LDS
         wave_sync();
         f2 e0 = {0.f, 0.f}, e1 = {0.f, 0.f};
-        bcast_matvec<H / 4>(reinterpret_cast<const float4 *>(&bufB[0]), wrT, e0, e1);
+        bcast_matvec<H / 4>(reinterpret_cast<const float4 *>(&bufB[p][0]), wrT, e0, e1);
         float *da = a.d_act + (b * T + t) * 3 * H + l;
         da[0] = dar;
         da[H] = dau;
@@ -334,7 +385,7 @@ __global__ __launch_bounds__(128, 1) void gru_scan_bwd_helper_kernel(const HpmnG
             if (eu_seen <= kk) __builtin_amdgcn_s_sleep(1);
         }
         asm volatile("" ::: "memory");
-        const float eu = eU[kk & 1][l];
+        const float eu = eU[p][l];
         dh = fmaf(dh, u, fmaf(drh, r, ((e0.x + e0.y) + (e1.x + e1.y)) + eu));
         kk += 1;
         wave_sync();
@@ -360,6 +411,19 @@ __global__ __launch_bounds__(128, 1) void gru_scan_bwd_helper_kernel(const HpmnG
     if (t_lo0 > 0) a.dh_carry[b * H + l] = dh;
 }
 
+static int bwd_helper_enabled() {
+    static const int helper = [] { const char *e = getenv("HPMN_BWD_HELPER"); return e ? atoi(e) : 1; }();
+    return helper;
+}
+// does hpmn_gru_scan_bwd produce d_x itself (HpmnGruBwd.d_x) for this shape?
+bool gru_scan_bwd_fuses_dx(int H, int B) {
+    // measured at C3: step 4.12 ms with the dx wave against 3.78 without (layer-0 scan 0.948 vs 0.688 ms in the step:
+    // three waves per sequence crowd the LDS pipe and the SIMDs the scan wave lives on, and leave the weight
+    // gradients no room beside the scan) -- parity-tested, default OFF, HPMN_BWD_DX_WAVE=1 turns it on
+    static const int dxw = [] { const char *e = getenv("HPMN_BWD_DX_WAVE"); return e ? atoi(e) : 0; }();
+    return H == 64 && B <= 640 && bwd_helper_enabled() && dxw;
+}
+
 int gru_scan_bwd128_dispatch(const HpmnGruBwd &a, hipStream_t st);   // gru_scan128.hip
 
 int gru_scan_bwd_dispatch(const HpmnGruBwd &a, hipStream_t st) {
@@ -370,9 +434,14 @@ int gru_scan_bwd_dispatch(const HpmnGruBwd &a, hipStream_t st) {
         // helper-wave variant (default; HPMN_BWD_HELPER=0 selects the one-wave kernel): 0.651 vs 0.678 ms alone at C3
         // layer 0, and 0.683 vs 0.744 ms inside the step now that the weight-gradient launches leave room on every
         // CU (gru_wgrad.hip: one workgroup per CU; before that change the variant LOST in-step, 0.873 vs 0.815)
-        static const int helper = [] { const char *e = getenv("HPMN_BWD_HELPER"); return e ? atoi(e) : 1; }();
-        if (helper && a.B <= 640) hipLaunchKernelGGL(gru_scan_bwd_helper_kernel, dim3(a.B), dim3(128), 0, st, a);
-        else                     hipLaunchKernelGGL((gru_scan_bwd_kernel<64>), dim3(a.B), dim3(64), 0, st, a);
+        if (bwd_helper_enabled() && a.B <= 640) {
+            if (a.d_x != nullptr && gru_scan_bwd_fuses_dx(a.H, a.B))
+                hipLaunchKernelGGL(gru_scan_bwd_helper_kernel<true>, dim3(a.B), dim3(192), 0, st, a);
+            else
+                hipLaunchKernelGGL(gru_scan_bwd_helper_kernel<false>, dim3(a.B), dim3(128), 0, st, a);
+        } else {
+            hipLaunchKernelGGL((gru_scan_bwd_kernel<64>), dim3(a.B), dim3(64), 0, st, a);
+        }
     } else {
         return HPMN_EUNSUPPORTED;
     }

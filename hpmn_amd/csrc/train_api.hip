@@ -12,6 +12,7 @@ int embed_gather_launch(const int32_t *ids, int64_t ids_stride, const float *emb
                         int32_t E, int32_t mask_id0, hipStream_t st);
 bool gru_fused_fwd_supported(int H, int D, int gather);
 size_t gru_wgrad_workspace_bytes(int B, int T, int D, int H);
+bool gru_scan_bwd_fuses_dx(int H, int B);
 
 struct TrainCtx {
     int device = -1, cus = 256;
@@ -204,6 +205,8 @@ int hpmn_scan_bwd(HpmnTrainCtx *ctx, const HpmnScanDesc *d, const int32_t *ids, 
         a.d_y = i + 1 < d->K ? F(L.d_x[i + 1]) : nullptr;
         a.period = d->periods[i];
         a.d_act = F(L.d_act[i]);
+        const bool fused_dx = gru_scan_bwd_fuses_dx(d->H, d->B) && D <= 64;
+        if (fused_dx) a.d_x = F(L.d_x[i]);       // the input gradient comes out of the scan launch itself
         int rc = hpmn_gru_scan_bwd(&a, stream);
         if (rc != HPMN_OK) return rc;
         // the weight gradient of this layer: an MFMA reduction over d_act, off the serial chain, on the helper stream
@@ -219,8 +222,10 @@ int hpmn_scan_bwd(HpmnTrainCtx *ctx, const HpmnScanDesc *d, const int32_t *ids, 
         rc = hpmn_gru_param_grads(&w, c->side);
         if (rc != HPMN_OK) return rc;
         c->pending = true;
-        rc = hpmn_gru_input_grad(F(L.d_act[i]), wg[i], wc[i], F(L.d_x[i]), d->B, L.T[i], D, d->H, 0, 0, stream);
-        if (rc != HPMN_OK) return rc;
+        if (!fused_dx) {
+            rc = hpmn_gru_input_grad(F(L.d_act[i]), wg[i], wc[i], F(L.d_x[i]), d->B, L.T[i], D, d->H, 0, 0, stream);
+            if (rc != HPMN_OK) return rc;
+        }
     }
     if (d_last) {
         const long n = (long)d->B * D0;

@@ -208,7 +208,11 @@ def gru_scan_fwd(xp, wg, wc, D, h_last, period, want_y, train, out=None, t_range
     return y, hs, gates
 
 
-def gru_scan_bwd(wg, wc, D, hs, gates, d_h_last, d_y, period, out=None, t_range=None, dh_carry=None):
+def scan_bwd_fuses_dx(H: int, B: int) -> bool:
+    return bool(_lib.load().hpmn_gru_scan_bwd_fuses_dx(H, B))
+
+
+def gru_scan_bwd(wg, wc, D, hs, gates, d_h_last, d_y, period, out=None, t_range=None, dh_carry=None, d_x=None):
     """hpmn_gru_scan_bwd -> d_act [B,T,3H].  ``out`` = preallocated d_act; ``t_range`` = (t_begin, t_end)
     runs one time chunk (reverse) with the boundary gradient handed over through ``dh_carry`` [B,H]."""
     B, T1, H = hs.shape
@@ -227,6 +231,8 @@ def gru_scan_bwd(wg, wc, D, hs, gates, d_h_last, d_y, period, out=None, t_range=
         a.t_begin, a.t_end = t_range
     if dh_carry is not None:
         a.dh_carry = dh_carry.data_ptr()
+    if d_x is not None:             # the input gradient from the scan launch itself (scan_bwd_fuses_dx)
+        a.d_x = d_x.data_ptr()
     rc = _lib.load().hpmn_gru_scan_bwd(C.byref(a), _stream())
     _lib.check(rc, "hpmn_gru_scan_bwd")
     return d_act
@@ -896,10 +902,12 @@ def scan_backward_layers(spec: ScanSpec, ids, saved, weights: Sequence[torch.Ten
                     gru_param_grads(x_in, hs, gates, d_act[i], wg, wc, gw[4 * i], gw[4 * i + 1], gw[4 * i + 2],
                                     gw[4 * i + 3], want_dx=False, keep=keep, t_range=(0, cut))
             else:
+                fdx = scan_bwd_fuses_dx(H, B) and in_dims[i] <= 64
                 if PROBE is not None and i == 0:      # bench.py: the dominant kernel timed INSIDE a real step
                     ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                     ev[0].record(main)
-                gru_scan_bwd(wg, wc, in_dims[i], hs, gates, d_memory[:, i, :], d_y, spec.periods[i], out=d_act[i])
+                gru_scan_bwd(wg, wc, in_dims[i], hs, gates, d_memory[:, i, :], d_y, spec.periods[i], out=d_act[i],
+                             d_x=d_x[i] if fdx else None)
                 if PROBE is not None and i == 0:
                     ev[1].record(main)
                     PROBE.append(ev)
@@ -907,7 +915,8 @@ def scan_backward_layers(spec: ScanSpec, ids, saved, weights: Sequence[torch.Ten
                 with torch.cuda.stream(side):
                     gru_param_grads(x_in, hs, gates, d_act[i], wg, wc, gw[4 * i], gw[4 * i + 1], gw[4 * i + 2],
                                     gw[4 * i + 3], want_dx=False, keep=keep)
-            gru_input_grad(d_act[i], wg, wc, in_dims[i], out=d_x[i])
+            if cut or not (scan_bwd_fuses_dx(H, B) and in_dims[i] <= 64):
+                gru_input_grad(d_act[i], wg, wc, in_dims[i], out=d_x[i])
         d_x0 = d_x[0]
         d_x0[:, spec.last_index, :] += d_last
         embed_grad_scatter(ids, d_x0, d_emb, spec.front_zero, spec.mask_id0)

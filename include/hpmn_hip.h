@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define HPMN_ABI_VERSION 3
+#define HPMN_ABI_VERSION 4
 #define HPMN_MAX_LAYERS 12
 
 enum {
@@ -175,9 +175,14 @@ typedef struct HpmnGruBwd {
      * chunk; when t_begin > 0 the gradient wrt the state before step t_begin is written to dh_carry. */
     int32_t t_begin, t_end;
     float *dh_carry;
+    /* optional [B, T, D]: the gradient wrt the layer's input rows, d_act [wg[0:D] | wc[0:D]]^T, produced by a third
+     * wave of the scan's workgroups underneath the scan (what hpmn_gru_input_grad computes as a launch of its own).
+     * Only where hpmn_gru_scan_bwd_fuses_dx(H, B) != 0; elsewhere it must be NULL (HPMN_EUNSUPPORTED otherwise). */
+    float *d_x;
 } HpmnGruBwd;
 
 int hpmn_gru_scan_bwd(const HpmnGruBwd *args, void *stream);
+int hpmn_gru_scan_bwd_fuses_dx(int32_t H, int32_t B);
 
 /* ------------------------------------------------------------------------------------
  * One GRU layer, parameter and input gradients -- the time-parallel half of BPTT (TF
