@@ -21,6 +21,8 @@
 // consumer re-reads about once per RING steps.  Everything else (exp2-domain weights, branch-free
 // stores, unconditional y slot) is as in gru_scan_fwd.hip; results are bit-identical to the two-kernel
 // path up to the summation order of the projection.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace hpmn {
@@ -65,21 +67,67 @@ __device__ __forceinline__ void bcast_matvec3(const float4 *row4, const f2 *wa, 
     }
 }
 
-template <int D, bool GATHER, bool TRAIN>
-__global__ __launch_bounds__(128, 1) void gru_fused_fwd_kernel(const HpmnGruFusedFwd a) {
+// HELP = true adds a third wave: the UPDATE gate u_t = sigmoid(xu_t + h_{t-1} Wg[D:, H:2H]) needs nothing the scan
+// wave computes within the step, so a helper wave forms it (16 broadcast reads + 32 packed FMAs + one sigmoid, and
+// the u store of the saved gates) while the scan wave does r, r*h and the candidate; the scan wave picks u_t up from
+// LDS just before the state update.  No barrier: h_pub ("h_{t-1} is in hb") and u_pub ("u_t is in ubuf") are LDS
+// counters; the scan wave cannot overwrite hb before it has consumed u_t, which exists only once the helper has
+// read all of hb.
+template <int D, bool GATHER, bool TRAIN, bool HELP>
+__global__ __launch_bounds__(HELP ? 192 : 128, 1) void gru_fused_fwd_kernel(const HpmnGruFusedFwd a) {
     constexpr int H = FH;
     __shared__ __attribute__((aligned(16))) float ring[FRING][3 * H];
     __shared__ __attribute__((aligned(16))) float xb[D];
     __shared__ __attribute__((aligned(16))) float hb[H];
     __shared__ __attribute__((aligned(16))) float rhb[H];
-    __shared__ int produced, consumed;
+    __shared__ float ubuf[2][H];
+    __shared__ int produced, consumed, h_pub, u_pub;
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int T = a.T;
     const long b = blockIdx.x;
-    if (threadIdx.x == 0) { produced = 0; consumed = 0; }
-    __syncthreads();                       // the only barrier: the counters start at zero for both waves
+    if (threadIdx.x == 0) { produced = 0; consumed = 0; h_pub = 0; u_pub = 0; }
+    if (threadIdx.x < H) hb[threadIdx.x] = 0.f;
+    __syncthreads();                       // the only barrier: the counters start at zero for every wave
+
+    if constexpr (HELP) {
+        if (wave == 2) {
+            // -------------------------------------------------------------- helper: the update gate of every step
+            __builtin_amdgcn_s_setprio(2);
+            const int l = lane;
+            f2 whu[H / 2];
+#pragma unroll
+            for (int k = 0; k < H / 2; ++k)
+                whu[k] = f2{a.wg[(long)(D + 2 * k) * 2 * H + H + l], a.wg[(long)(D + 2 * k + 1) * 2 * H + H + l]} * NEG_LOG2E;
+#pragma unroll
+            for (int k = 0; k < H / 2; ++k) settle(whu[k]);
+            float *gpu = TRAIN ? a.gates + (b * (long)T) * 3 * H + H + l : nullptr;
+            int p_seen = 0, h_seen = 0;
+            for (int t = 0; t < T; ++t) {
+                while (p_seen <= t) {
+                    p_seen = lds_peek(&produced);
+                    if (p_seen <= t) __builtin_amdgcn_s_sleep(1);
+                }
+                while (h_seen < t) {                     // h_{t-1} is in hb once the scan wave has finished step t-1
+                    h_seen = lds_peek(&h_pub);
+                    if (h_seen < t) __builtin_amdgcn_s_sleep(1);
+                }
+                asm volatile("" ::: "memory");
+                const float xu = ring[t % FRING][H + l];
+                f2 au = {0.f, 0.f}, au2 = {0.f, 0.f};
+                bcast_matvec<H / 4>(reinterpret_cast<const float4 *>(hb), whu, au, au2);
+                const float u = sigmoid_scaled(xu + ((au.x + au.y) + (au2.x + au2.y)));
+                ubuf[t & 1][l] = u;
+                lds_publish(&u_pub, t + 1);
+                if constexpr (TRAIN) {
+                    *gpu = u;
+                    gpu += 3 * H;
+                }
+            }
+            return;
+        }
+    }
 
     if (wave == 1) {
         // ------------------------------------------------------------------ producer: x_t -> xp_t
@@ -175,20 +223,24 @@ __global__ __launch_bounds__(128, 1) void gru_fused_fwd_kernel(const HpmnGruFuse
     // ---------------------------------------------------------------------- consumer: the recurrence
     __builtin_amdgcn_s_setprio(3);
     const int l = lane;
-    f2 whr[H / 2], whu[H / 2], whc[H / 2];
+    f2 whr[H / 2], whu[HELP ? 1 : H / 2], whc[H / 2];
 #pragma unroll
     for (int k = 0; k < H / 2; ++k) {
         whr[k] = f2{a.wg[(long)(D + 2 * k) * 2 * H + l], a.wg[(long)(D + 2 * k + 1) * 2 * H + l]} * NEG_LOG2E;
-        whu[k] = f2{a.wg[(long)(D + 2 * k) * 2 * H + H + l], a.wg[(long)(D + 2 * k + 1) * 2 * H + H + l]} * NEG_LOG2E;
+        if constexpr (!HELP)
+            whu[k] = f2{a.wg[(long)(D + 2 * k) * 2 * H + H + l], a.wg[(long)(D + 2 * k + 1) * 2 * H + H + l]} * NEG_LOG2E;
         whc[k] = f2{a.wc[(long)(D + 2 * k) * H + l], a.wc[(long)(D + 2 * k + 1) * H + l]} * (2.0f * NEG_LOG2E);
     }
 #pragma unroll
-    for (int k = 0; k < H / 2; ++k) { settle(whr[k]); settle(whu[k]); settle(whc[k]); }
+    for (int k = 0; k < H / 2; ++k) {
+        settle(whr[k]); settle(whc[k]);
+        if constexpr (!HELP) settle(whu[k]);
+    }
 
     float h = 0.f;
-    hb[lane] = h;
     if constexpr (TRAIN) a.hs[(b * (T + 1)) * H + l] = 0.f;
     wave_sync();
+    int u_seen = 0;
 
     const int period = a.period;
     const bool has_y = a.y != nullptr;
@@ -206,25 +258,42 @@ __global__ __launch_bounds__(128, 1) void gru_fused_fwd_kernel(const HpmnGruFuse
         }
         asm volatile("" ::: "memory");                       // ring reads stay behind the counter check
         const float *xc = &ring[t % FRING][l];
-        const float xr = xc[0], xu = xc[H], xcand = xc[2 * H];
-        f2 ar = {0.f, 0.f}, au = {0.f, 0.f};
-        bcast_matvec2<H / 4>(reinterpret_cast<const float4 *>(hb), whr, whu, ar, au);
-        const float r = sigmoid_scaled(xr + (ar.x + ar.y));
-        const float u = sigmoid_scaled(xu + (au.x + au.y));
+        const float xr = xc[0], xcand = xc[2 * H];
+        float r, u = 0.f;
+        if constexpr (HELP) {
+            f2 ar = {0.f, 0.f}, ar2 = {0.f, 0.f};
+            bcast_matvec<H / 4>(reinterpret_cast<const float4 *>(hb), whr, ar, ar2);
+            r = sigmoid_scaled(xr + ((ar.x + ar.y) + (ar2.x + ar2.y)));
+        } else {
+            const float xu = xc[H];
+            f2 ar = {0.f, 0.f}, au = {0.f, 0.f};
+            bcast_matvec2<H / 4>(reinterpret_cast<const float4 *>(hb), whr, whu, ar, au);
+            r = sigmoid_scaled(xr + (ar.x + ar.y));
+            u = sigmoid_scaled(xu + (au.x + au.y));
+        }
         rhb[lane] = r * h;
         wave_sync();
         f2 ac = {0.f, 0.f}, ac2 = {0.f, 0.f};
         bcast_matvec<H / 4>(reinterpret_cast<const float4 *>(rhb), whc, ac, ac2);
         ac += ac2;
         const float cc = tanh_scaled(xcand + (ac.x + ac.y));
+        if constexpr (HELP) {
+            while (u_seen <= t) {
+                u_seen = lds_peek(&u_pub);
+                if (u_seen <= t) __builtin_amdgcn_s_sleep(1);
+            }
+            asm volatile("" ::: "memory");
+            u = ubuf[t & 1][l];
+        }
         h = fmaf(u, h - cc, cc);
         hb[lane] = h;
+        if constexpr (HELP) lds_publish(&h_pub, t + 1);       // the helper may start on u_{t+1}
         if ((t & 1) == 1) lds_publish(&consumed, t + 1);     // slot t (and t-1) may be refilled
         wave_sync();
         if constexpr (TRAIN) {
             *hsp = h;
             gp[0] = r;
-            gp[H] = u;
+            if constexpr (!HELP) gp[H] = u;
             gp[2 * H] = cc;
             hsp += H;
             gp += 3 * H;
@@ -242,18 +311,27 @@ bool gru_fused_fwd_supported(int H, int D, int gather) {
     return H == FH && (D == 32 || D == 64);
 }
 
-template <int D>
-static int launch_fused(const HpmnGruFusedFwd &a, hipStream_t st) {
+template <int D, bool HELP>
+static int launch_fused_h(const HpmnGruFusedFwd &a, hipStream_t st) {
     const bool train = a.hs != nullptr;
-    const dim3 grid(a.B), blk(128);
+    const dim3 grid(a.B), blk(HELP ? 192 : 128);
     if (a.x == nullptr) {
-        if (train) hipLaunchKernelGGL((gru_fused_fwd_kernel<D, true, true>), grid, blk, 0, st, a);
-        else       hipLaunchKernelGGL((gru_fused_fwd_kernel<D, true, false>), grid, blk, 0, st, a);
+        if (train) hipLaunchKernelGGL((gru_fused_fwd_kernel<D, true, true, HELP>), grid, blk, 0, st, a);
+        else       hipLaunchKernelGGL((gru_fused_fwd_kernel<D, true, false, HELP>), grid, blk, 0, st, a);
     } else {
-        if (train) hipLaunchKernelGGL((gru_fused_fwd_kernel<D, false, true>), grid, blk, 0, st, a);
-        else       hipLaunchKernelGGL((gru_fused_fwd_kernel<D, false, false>), grid, blk, 0, st, a);
+        if (train) hipLaunchKernelGGL((gru_fused_fwd_kernel<D, false, true, HELP>), grid, blk, 0, st, a);
+        else       hipLaunchKernelGGL((gru_fused_fwd_kernel<D, false, false, HELP>), grid, blk, 0, st, a);
     }
     return check_launch();
+}
+
+template <int D>
+static int launch_fused(const HpmnGruFusedFwd &a, hipStream_t st) {
+    static const int help = [] { const char *e = getenv("HPMN_FWD_HELPER"); return e ? atoi(e) : 0; }();
+    // (D = 64: the projection wave alone needs ~290 registers, so a three-wave workgroup would take three SIMDs to
+    //  itself and only half the sequences would be resident: D = 32 only)
+    if constexpr (D == 32) return help ? launch_fused_h<D, true>(a, st) : launch_fused_h<D, false>(a, st);
+    else                   return launch_fused_h<D, false>(a, st);
 }
 
 int gru_fused_fwd_dispatch(const HpmnGruFusedFwd &a, hipStream_t st) {
