@@ -114,6 +114,130 @@ __device__ __forceinline__ void bcast_matvec(const float4 *row4, const f2 *w, f2
     }
 }
 
+// bcast_matvec whose accumulators START here (first products are multiplies: no zero-initialising moves, which cost
+// the single wave of a scan an issue slot each).  OFF: first float4 of the row (the caller may split a product in two).
+template <int NQ, int G = 4>
+__device__ __forceinline__ void bcast_matvec_first(const float4 *row4, const f2 *w, f2 &acc0, f2 &acc1) {
+    static_assert(NQ % G == 0, "groups");
+    const v4f *row = reinterpret_cast<const v4f *>(row4);
+    v4f cur[G], nxt[G];
+#pragma unroll
+    for (int i = 0; i < G; ++i) cur[i] = row[i];
+#pragma unroll
+    for (int g = 0; g < NQ / G; ++g) {
+        if (g + 1 < NQ / G) {
+#pragma unroll
+            for (int i = 0; i < G; ++i) nxt[i] = row[(g + 1) * G + i];
+        }
+        asm volatile("" ::: "memory");
+        if (g == 0) asm volatile("" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]));
+        else        land_group<G>(cur, acc0, acc1);
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const int q = g * G + i;
+            if (q == 0) {
+                acc0 = f2{cur[i].x, cur[i].y} * w[0];
+                acc1 = f2{cur[i].z, cur[i].w} * w[1];
+            } else {
+                acc0 = __builtin_elementwise_fma(f2{cur[i].x, cur[i].y}, w[2 * q], acc0);
+                acc1 = __builtin_elementwise_fma(f2{cur[i].z, cur[i].w}, w[2 * q + 1], acc1);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < G; ++i) cur[i] = nxt[i];
+    }
+}
+
+// K-SPLIT mat-vec, y[unit] = sum_k x[k] W[unit][k] over 64 k with lane == unit on both sides, for the scan waves that
+// share a CU's LDS pipe.  A broadcast ds_read_b128 returns 1 KB to the wave (8 cycles of the CU's 128 B/clk return
+// path) however few distinct bytes it carries, and bcast_matvec needs 16 of them: with two sequences (four waves) per
+// CU the pipe is busy ~60 % of a step and every round trip on the serial chain queues behind the neighbours' reads
+// (measured: the same kernel runs 18 % faster with one sequence per CU).  Here KS adjacent lanes share KS units: lane
+// (g = lane / KS, s = lane % KS) multiplies the KS rows of units KS g .. KS g + KS-1 over its own 64/KS-wide slice of
+// k -- 16/KS reads instead of 16, the same 32 packed FMAs -- and the slices are summed with quad_perm DPP adds
+// (full-rate VALU, no LDS), after which the lane keeps the sum of unit KS g + s == lane.
+//   w[j][i]: row of unit KS*(lane/KS) + j, k = (64/KS)*(lane%KS) + 2i, 2i+1      (loaded by split_matvec_weights)
+template <int KS>
+__device__ __forceinline__ void split_matvec_weights(const float *wrows, long row_stride, int lane, f2 (&w)[KS][32 / KS]) {
+    const int g = lane / KS, s = lane % KS;
+#pragma unroll
+    for (int j = 0; j < KS; ++j)
+#pragma unroll
+        for (int i = 0; i < 32 / KS; ++i)
+            w[j][i] = *reinterpret_cast<const f2 *>(wrows + (long)(KS * g + j) * row_stride + (64 / KS) * s + 2 * i);
+#pragma unroll
+    for (int j = 0; j < KS; ++j)
+#pragma unroll
+        for (int i = 0; i < 32 / KS; ++i) settle(w[j][i]);
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_quad(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+
+// x: the 64-float operand row in LDS (16-byte aligned); returns y[lane]
+template <int KS>
+__device__ __forceinline__ float split_matvec(const float *x, const f2 (&w)[KS][32 / KS], int lane) {
+    static_assert(KS == 2 || KS == 4, "quad_perm reductions");
+    constexpr int NQ = 16 / KS;          // float4s of this lane's k slice
+    constexpr int G = 4;
+    const v4f *row = reinterpret_cast<const v4f *>(x + (64 / KS) * (lane % KS));
+    f2 acc[KS][2];
+    v4f cur[G], nxt[G];
+#pragma unroll
+    for (int i = 0; i < G; ++i) cur[i] = row[i];
+#pragma unroll
+    for (int g = 0; g < NQ / G; ++g) {
+        if (g + 1 < NQ / G) {
+#pragma unroll
+            for (int i = 0; i < G; ++i) nxt[i] = row[(g + 1) * G + i];
+        }
+        asm volatile("" ::: "memory");
+        if (g == 0) asm volatile("" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]));
+        else        asm volatile("" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(acc[0][0]), "+v"(acc[0][1]));
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const int q = g * G + i;
+            const f2 lo = {cur[i].x, cur[i].y}, hi = {cur[i].z, cur[i].w};
+#pragma unroll
+            for (int j = 0; j < KS; ++j) {
+                if (q == 0) {
+                    acc[j][0] = lo * w[j][0];
+                    acc[j][1] = hi * w[j][1];
+                } else {
+                    acc[j][0] = __builtin_elementwise_fma(lo, w[j][2 * q], acc[j][0]);
+                    acc[j][1] = __builtin_elementwise_fma(hi, w[j][2 * q + 1], acc[j][1]);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < G; ++i) cur[i] = nxt[i];
+    }
+    float sj[KS];
+#pragma unroll
+    for (int j = 0; j < KS; ++j) {
+        const f2 t = acc[j][0] + acc[j][1];
+        sj[j] = t.x + t.y;
+    }
+    if constexpr (KS == 2) {
+        // lane keeps unit (lane & 1): add the partner's slice of that unit
+        const float mine = (lane & 1) ? sj[1] : sj[0];
+        const float give = (lane & 1) ? sj[0] : sj[1];
+        return mine + dpp_quad<0xB1>(give);                      // quad_perm [1,0,3,2]
+    } else {
+        const bool b0 = lane & 1, b1 = lane & 2;
+        // stage 1 (xor 1): of each unit pair keep the one with my low bit, hand the other to the neighbour
+        const float k01 = b0 ? sj[1] : sj[0], g01 = b0 ? sj[0] : sj[1];
+        const float k23 = b0 ? sj[3] : sj[2], g23 = b0 ? sj[2] : sj[3];
+        const float r01 = k01 + dpp_quad<0xB1>(g01);
+        const float r23 = k23 + dpp_quad<0xB1>(g23);
+        // stage 2 (xor 2): keep the pair with my high bit
+        const float kk = b1 ? r23 : r01, gg = b1 ? r01 : r23;
+        return kk + dpp_quad<0x4E>(gg);                          // quad_perm [2,3,0,1]
+    }
+}
+
 // Same row feeding two weight sets (the r and u columns of the gate kernel).
 template <int NQ, int G = 4>
 __device__ __forceinline__ void bcast_matvec2(const float4 *row4, const f2 *wa, const f2 *wb, f2 &a0, f2 &b0) {

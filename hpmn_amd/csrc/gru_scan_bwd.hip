@@ -411,10 +411,12 @@ __global__ __launch_bounds__(DX ? 192 : 128, DX ? 2 : 1) void gru_scan_bwd_helpe
     if (t_lo0 > 0) a.dh_carry[b * H + l] = dh;
 }
 
+// HPMN_BWD_HELPER: 2 (default) chain + feeder wave (gru_scan_bwd_feed.hip), 1 the e_u helper wave above, 0 one wave
 static int bwd_helper_enabled() {
-    static const int helper = [] { const char *e = getenv("HPMN_BWD_HELPER"); return e ? atoi(e) : 1; }();
+    static const int helper = [] { const char *e = getenv("HPMN_BWD_HELPER"); return e ? atoi(e) : 2; }();
     return helper;
 }
+int gru_scan_bwd_feed_launch(const HpmnGruBwd &a, hipStream_t st);   // gru_scan_bwd_feed.hip
 // does hpmn_gru_scan_bwd produce d_x itself (HpmnGruBwd.d_x) for this shape?
 bool gru_scan_bwd_fuses_dx(int H, int B) {
     // measured at C3: step 4.12 ms with the dx wave against 3.78 without (layer-0 scan 0.948 vs 0.688 ms in the step:
@@ -437,6 +439,8 @@ int gru_scan_bwd_dispatch(const HpmnGruBwd &a, hipStream_t st) {
         if (bwd_helper_enabled() && a.B <= 640) {
             if (a.d_x != nullptr && gru_scan_bwd_fuses_dx(a.H, a.B))
                 hipLaunchKernelGGL(gru_scan_bwd_helper_kernel<true>, dim3(a.B), dim3(192), 0, st, a);
+            else if (bwd_helper_enabled() >= 2)
+                return gru_scan_bwd_feed_launch(a, st);
             else
                 hipLaunchKernelGGL(gru_scan_bwd_helper_kernel<false>, dim3(a.B), dim3(128), 0, st, a);
         } else {
