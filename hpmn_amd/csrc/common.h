@@ -170,6 +170,22 @@ __device__ __forceinline__ void split_matvec_weights(const float *wrows, long ro
 #pragma unroll
         for (int i = 0; i < 32 / KS; ++i) settle(w[j][i]);
 }
+// the same from a [k][unit] matrix (the forward's layout: element (unit, k) at wk[k * k_stride + unit]), times scale
+template <int KS>
+__device__ __forceinline__ void split_matvec_weights_t(const float *wk, long k_stride, float scale, int lane, f2 (&w)[KS][32 / KS]) {
+    const int g = lane / KS, s = lane % KS;
+#pragma unroll
+    for (int j = 0; j < KS; ++j)
+#pragma unroll
+        for (int i = 0; i < 32 / KS; ++i) {
+            const long k = (64 / KS) * s + 2 * i;
+            w[j][i] = f2{wk[k * k_stride + KS * g + j], wk[(k + 1) * k_stride + KS * g + j]} * scale;
+        }
+#pragma unroll
+    for (int j = 0; j < KS; ++j)
+#pragma unroll
+        for (int i = 0; i < 32 / KS; ++i) settle(w[j][i]);
+}
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_quad(float v) {
@@ -236,6 +252,56 @@ __device__ __forceinline__ float split_matvec(const float *x, const f2 (&w)[KS][
         const float kk = b1 ? r23 : r01, gg = b1 ? r01 : r23;
         return kk + dpp_quad<0x4E>(gg);                          // quad_perm [2,3,0,1]
     }
+}
+
+// Two weight sets over the same operand row (the forward's reset and update gates), KS = 2.
+__device__ __forceinline__ void split_matvec2x(const float *x, const f2 (&wa)[2][16], const f2 (&wb)[2][16], int lane,
+                                               float &ya, float &yb) {
+    constexpr int NQ = 8, G = 4;
+    const v4f *row = reinterpret_cast<const v4f *>(x + 32 * (lane & 1));
+    f2 a[2][2], b[2][2];
+    v4f cur[G], nxt[G];
+#pragma unroll
+    for (int i = 0; i < G; ++i) cur[i] = row[i];
+#pragma unroll
+    for (int g = 0; g < NQ / G; ++g) {
+        if (g + 1 < NQ / G) {
+#pragma unroll
+            for (int i = 0; i < G; ++i) nxt[i] = row[(g + 1) * G + i];
+        }
+        asm volatile("" ::: "memory");
+        if (g == 0) asm volatile("" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]));
+        else        asm volatile("" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(a[0][0]), "+v"(b[0][0]));
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const int q = g * G + i;
+            const f2 lo = {cur[i].x, cur[i].y}, hi = {cur[i].z, cur[i].w};
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (q == 0) {
+                    a[j][0] = lo * wa[j][0]; a[j][1] = hi * wa[j][1];
+                    b[j][0] = lo * wb[j][0]; b[j][1] = hi * wb[j][1];
+                } else {
+                    a[j][0] = __builtin_elementwise_fma(lo, wa[j][2 * q], a[j][0]);
+                    a[j][1] = __builtin_elementwise_fma(hi, wa[j][2 * q + 1], a[j][1]);
+                    b[j][0] = __builtin_elementwise_fma(lo, wb[j][2 * q], b[j][0]);
+                    b[j][1] = __builtin_elementwise_fma(hi, wb[j][2 * q + 1], b[j][1]);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < G; ++i) cur[i] = nxt[i];
+    }
+    float sa[2], sb[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const f2 ta = a[j][0] + a[j][1], tb = b[j][0] + b[j][1];
+        sa[j] = ta.x + ta.y;
+        sb[j] = tb.x + tb.y;
+    }
+    const bool odd = lane & 1;
+    ya = (odd ? sa[1] : sa[0]) + dpp_quad<0xB1>(odd ? sa[0] : sa[1]);
+    yb = (odd ? sb[1] : sb[0]) + dpp_quad<0xB1>(odd ? sb[0] : sb[1]);
 }
 
 // Same row feeding two weight sets (the r and u columns of the gate kernel).
