@@ -334,13 +334,13 @@ static int launch_fused(const HpmnGruFusedFwd &a, hipStream_t st) {
     else                   return launch_fused_h<D, false>(a, st);
 }
 
-int gru_fwd_duo_dispatch(const HpmnGruFusedFwd &a, hipStream_t st);   // gru_fused_fwd2.hip
+int gru_fwd_mfma_dispatch(const HpmnGruFusedFwd &a, hipStream_t st);  // gru_fused_fwd3.hip
 
 int gru_fused_fwd_dispatch(const HpmnGruFusedFwd &a, hipStream_t st) {
-    // HPMN_FUSED_FWD_GEN: 2 (default) chain + producer waves, two sequences per workgroup (gru_fused_fwd2.hip); 1 the
+    // HPMN_FUSED_FWD_GEN: 3 (default) chain + MFMA-producer waves, two sequences per workgroup (gru_fused_fwd3.hip); 1 the
     // first generation below
-    static const int gen = [] { const char *e = getenv("HPMN_FUSED_FWD_GEN"); return e ? atoi(e) : 2; }();
-    if (gen >= 2) return gru_fwd_duo_dispatch(a, st);
+    static const int gen = [] { const char *e = getenv("HPMN_FUSED_FWD_GEN"); return e ? atoi(e) : 3; }();
+    if (gen >= 3) return gru_fwd_mfma_dispatch(a, st);
     if (a.B == 0) return HPMN_OK;
     if (a.H != FH) return HPMN_EUNSUPPORTED;
     if (a.D == 32) return launch_fused<32>(a, st);

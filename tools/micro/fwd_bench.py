@@ -1,5 +1,6 @@
 """Stand-alone timing of the fused forward layer kernels at the C3 shapes: layer 0 (gather, D=32, T=1024) and layer 1
-(D=64, T=512), generation 1 (gru_fused_fwd.hip) against generation 2 (gru_fused_fwd2.hip) and its -D knob sets.
+(D=64, T=512), generation 1 (gru_fused_fwd.hip) against generation 3 (gru_fused_fwd3.hip) and its -D knob sets
+(e.g. "u=-DMF_UPROD32=1,-DMF_UPROD64=1").
 Nothing here ships.  Usage (GPU box):  python tools/micro/fwd_bench.py [name=-DX=1,...] && sh tools/micro/run_fwd.sh"""
 import os
 import subprocess
@@ -54,10 +55,10 @@ int main(int argc, char **argv) {
 
 
 def main():
-    variants = {"gen1": ("1", []), "gen2": ("2", [])}
+    variants = {"gen1": ("1", []), "gen3": ("3", [])}
     for arg in sys.argv[1:]:
         name, flags = arg.split("=", 1)
-        variants[name] = ("2", flags.split(","))
+        variants[name] = ("3", flags.split(","))
     main_cc = os.path.join(HERE, "fwd_main.hip")
     open(main_cc, "w").write(MAIN)
     lines = ["#!/bin/sh"]
@@ -65,7 +66,7 @@ def main():
         exe = os.path.join(HERE, "feedb_fwd_%d" % i)
         cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-w", "-I" + os.path.join(ROOT, "include"),
                "-I" + CSRC, '-DVARIANT="%s"' % name] + flags + [main_cc, os.path.join(CSRC, "gru_fused_fwd.hip"),
-               os.path.join(CSRC, "gru_fused_fwd2.hip"), "-o", exe]
+               os.path.join(CSRC, "gru_fused_fwd3.hip"), "-o", exe]
         subprocess.check_call(cmd)
         for B in (500, 250):
             for layer in (0, 1):
