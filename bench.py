@@ -210,9 +210,12 @@ def roofline_probes(model, c, batches, step_fn):
         del gtab
 
     scan_flops = B * T0 * 2 * H * 3 * H           # recurrent half; the input half is accounted to input_proj
-    # (H = 64 at the reference batch runs the helper-wave variant of the reverse scan, gru_scan_bwd.hip)
-    helper = H == 64 and B <= 640 and os.environ.get("HPMN_BWD_HELPER", "1") != "0"
-    dom_kernel = "gru_scan_bwd_helper_kernel<false>" if helper else "gru_scan_bwd_kernel<%d>" % H
+    # (H = 64 at the reference batch runs the chain + feeder variant of the reverse scan, gru_scan_bwd_feed.hip)
+    mode = os.environ.get("HPMN_BWD_HELPER", "2")
+    if H == 64 and B <= 640 and mode != "0":
+        dom_kernel = "gru_scan_bwd_feed_kernel<2>" if mode != "1" else "gru_scan_bwd_helper_kernel<false>"
+    else:
+        dom_kernel = "gru_scan_bwd_kernel<%d>" % H
     dom_t = in_step_ms if in_step_ms is not None else max(t_bwd, t_fwd)
     pmc = pmc_digest(c, B)
     traffic = None

@@ -29,7 +29,8 @@ int read_fwd_bwd_launch(const HpmnReadDesc &d, const float *P, const float *memo
 int embed_gather_launch(const int32_t *ids, int64_t ids_stride, const float *emb, float *out, int64_t N,
                         int32_t F, int32_t E, int32_t mask_id0, hipStream_t st);
 int embed_grad_scatter_launch(const int32_t *ids, const float *d_x, float *d_emb, int32_t B, int32_t T,
-                              int32_t F, int32_t E, int32_t front_zero, int32_t mask_id0, hipStream_t st);
+                              int32_t F, int32_t E, int32_t front_zero, int32_t mask_id0, int32_t t_lo, int32_t t_hi,
+                              hipStream_t st);
 int adam_launch(float *p, const float *g, float *m, float *v, int64_t n, float lr_t, float b1, float b2,
                 float eps, float clip, float gs, hipStream_t st);
 int adam_rows_launch(float *p, const float *g, float *m, float *v, const int64_t *row_ids, int64_t n_rows, int E,
@@ -294,7 +295,7 @@ int hpmn_embed_grad_scatter(const int32_t *ids, const float *d_x, float *d_emb, 
     if (64 % E != 0) return HPMN_EUNSUPPORTED;
     if (B == 0) return HPMN_OK;
     if (!ids || !d_x || !d_emb) return HPMN_EINVAL;
-    return embed_grad_scatter_launch(ids, d_x, d_emb, B, T, F, E, front_zero, mask_id0, (hipStream_t)stream);
+    return embed_grad_scatter_launch(ids, d_x, d_emb, B, T, F, E, front_zero, mask_id0, 0, T, (hipStream_t)stream);
 }
 
 int hpmn_adam_step(float *param, const float *grad, float *m, float *v, int64_t n, float lr_t, float beta1,

@@ -38,7 +38,7 @@ constexpr int SCU = 8;      // steps per load chunk
 constexpr int SSEG = 128;   // steps per wave
 __global__ __launch_bounds__(64) void embed_grad_scatter_kernel(
     const int32_t *__restrict__ ids, const float *__restrict__ d_x, float *__restrict__ d_emb, int B,
-    int T, int F, int E, int front_zero, int mask_id0, int groups, int nseg) {
+    int T, int F, int E, int front_zero, int mask_id0, int groups, int nseg, int t_lo, int t_hi) {
     const int cpw = 64 / E;                          // id columns per wave
     const int seg = blockIdx.x % nseg;
     const int grp = (blockIdx.x / nseg) % groups;
@@ -48,8 +48,8 @@ __global__ __launch_bounds__(64) void embed_grad_scatter_kernel(
     const int e = lane % E;
     if (f >= F) return;
     const int Dx = F * E;
-    const int t_begin = seg * SSEG;
-    const int t_end = (t_begin + SSEG) < T ? (t_begin + SSEG) : T;
+    const int t_begin = t_lo + seg * SSEG;
+    const int t_end = (t_begin + SSEG) < t_hi ? (t_begin + SSEG) : t_hi;
     const int32_t *idp = ids + (b * T) * F + f;
     const float *gp = d_x + (b * (long)(front_zero + T) + front_zero) * Dx + f * E + e;
     int run_id = -1;
@@ -93,14 +93,18 @@ int embed_gather_launch(const int32_t *ids, int64_t ids_stride, const float *emb
     return check_launch();
 }
 
+// steps [t_lo, t_hi) of every sequence (ids time; t_hi == 0: T)
 int embed_grad_scatter_launch(const int32_t *ids, const float *d_x, float *d_emb, int32_t B, int32_t T,
-                              int32_t F, int32_t E, int32_t front_zero, int32_t mask_id0, hipStream_t st) {
-    if (B == 0 || T == 0) return HPMN_OK;
+                              int32_t F, int32_t E, int32_t front_zero, int32_t mask_id0, int32_t t_lo, int32_t t_hi,
+                              hipStream_t st) {
+    if (t_hi <= 0 || t_hi > T) t_hi = T;
+    if (t_lo < 0) t_lo = 0;
+    if (B == 0 || t_hi <= t_lo) return HPMN_OK;
     const int cpw = 64 / E;
     const int groups = (F + cpw - 1) / cpw;
-    const int nseg = (T + SSEG - 1) / SSEG;
+    const int nseg = (t_hi - t_lo + SSEG - 1) / SSEG;
     hipLaunchKernelGGL(embed_grad_scatter_kernel, dim3((unsigned)(B * groups * nseg)), dim3(64), 0, st, ids,
-                       d_x, d_emb, B, T, F, E, front_zero, mask_id0, groups, nseg);
+                       d_x, d_emb, B, T, F, E, front_zero, mask_id0, groups, nseg, t_lo, t_hi);
     return check_launch();
 }
 

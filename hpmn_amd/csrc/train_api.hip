@@ -3,6 +3,7 @@
 // to orchestrate -- the per-layer launches, the weight-gradient reductions running on a helper stream underneath
 // the serial chain (fork / join with events on the caller's stream), the row add of d_last, the embedding scatter
 // -- happens inside the library, so a non-Python host can run a training step through the ABI alone.
+#include <cstdlib>
 #include <mutex>
 
 #include "common.h"
@@ -13,11 +14,14 @@ int embed_gather_launch(const int32_t *ids, int64_t ids_stride, const float *emb
 bool gru_fused_fwd_supported(int H, int D, int gather);
 size_t gru_wgrad_workspace_bytes(int B, int T, int D, int H);
 bool gru_scan_bwd_fuses_dx(int H, int B);
+int embed_grad_scatter_launch(const int32_t *ids, const float *d_x, float *d_emb, int32_t B, int32_t T,
+                              int32_t F, int32_t E, int32_t front_zero, int32_t mask_id0, int32_t t_lo, int32_t t_hi,
+                              hipStream_t st);
 
 struct TrainCtx {
     int device = -1, cus = 256;
     hipStream_t side = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr, scat = nullptr;
     bool pending = false;
 };
 
@@ -85,7 +89,8 @@ int hpmn_train_ctx_create(HpmnTrainCtx **out) {
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && n > 0) c->cus = n;
     if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->join, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&c->join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->scat, hipEventDisableTiming) != hipSuccess) {
         set_last_hip_error((int)hipGetLastError());
         delete c;
         return HPMN_EHIP;
@@ -100,6 +105,7 @@ void hpmn_train_ctx_destroy(HpmnTrainCtx *ctx) {
     if (c->side) (void)hipStreamSynchronize(c->side);
     if (c->fork) (void)hipEventDestroy(c->fork);
     if (c->join) (void)hipEventDestroy(c->join);
+    if (c->scat) (void)hipEventDestroy(c->scat);
     if (c->side) (void)hipStreamDestroy(c->side);
     delete c;
 }
@@ -192,10 +198,26 @@ int hpmn_scan_bwd(HpmnTrainCtx *ctx, const HpmnScanDesc *d, const int32_t *ids, 
     if (d->B == 0) return HPMN_OK;
     HpmnTrainLayout L;
     if (!layout(*d, L)) return HPMN_EINVAL;
+    if (64 % d->E != 0) return HPMN_EUNSUPPORTED;     // (the scatter's lane mapping)
     const int D0 = d->F * d->E;
     char *ws = reinterpret_cast<char *>((reinterpret_cast<size_t>(workspace) + 255) / 256 * 256);
     auto F = [&](size_t off) { return reinterpret_cast<float *>(ws + off); };
     hipStream_t st = (hipStream_t)stream;
+    // Layer 0 in two time halves (HPMN_L0_SPLIT=1; built, parity-green, measured NEUTRAL at C3 -- 3.282 vs 3.272 ms/step:
+    // the early half of the scan runs 340 instead of 262 us beside the late half's gradient kernels, which is what the
+    // shorter tail gains -- default off).  Everything behind the layer-0
+    // reverse scan -- its input gradient, the scatter into the table gradient, the dense table Adam of the caller --
+    // is serial, and half of it does not need the early steps: the late half's input gradient, the d_last row add and
+    // its scatter run on the helper stream underneath the scan of the early half, together with the late half's
+    // weight gradient.  (The scatter is an atomic row add, so the two halves commute.)
+    static const int split_env = [] { const char *e = getenv("HPMN_L0_SPLIT"); return e ? atoi(e) : 0; }();
+    int cut = 0;
+    if (split_env && L.T[0] >= 256 && !gru_scan_bwd_fuses_dx(d->H, d->B)) {
+        const int p0 = d->periods[0], q = (p0 % 2 == 0) ? p0 : 2 * p0;
+        cut = (L.T[0] / 2) / q * q;
+        if (cut <= d->front_zero || cut >= L.T[0] + d->last_index) cut = 0;
+    }
+    bool scatter_pending = false;
     for (int i = d->K - 1; i >= 0; --i) {
         const int D = i == 0 ? D0 : d->H;
         HpmnGruBwd a = {};
@@ -205,13 +227,6 @@ int hpmn_scan_bwd(HpmnTrainCtx *ctx, const HpmnScanDesc *d, const int32_t *ids, 
         a.d_y = i + 1 < d->K ? F(L.d_x[i + 1]) : nullptr;
         a.period = d->periods[i];
         a.d_act = F(L.d_act[i]);
-        const bool fused_dx = gru_scan_bwd_fuses_dx(d->H, d->B) && D <= 64;
-        if (fused_dx) a.d_x = F(L.d_x[i]);       // the input gradient comes out of the scan launch itself
-        int rc = hpmn_gru_scan_bwd(&a, stream);
-        if (rc != HPMN_OK) return rc;
-        // the weight gradient of this layer: an MFMA reduction over d_act, off the serial chain, on the helper stream
-        HIPCHK(hipEventRecord(c->fork, st));
-        HIPCHK(hipStreamWaitEvent(c->side, c->fork, 0));
         HpmnGruWgrad w = {};
         w.B = d->B; w.T = L.T[i]; w.D = D; w.H = d->H;
         w.x = i == 0 ? F(L.x0) : F(L.y[i - 1]);
@@ -219,6 +234,50 @@ int hpmn_scan_bwd(HpmnTrainCtx *ctx, const HpmnScanDesc *d, const int32_t *ids, 
         w.wg = wg[i]; w.wc = wc[i];
         w.d_wg = d_wg[i]; w.d_bg = d_bg[i]; w.d_wc = d_wc[i]; w.d_bc = d_bc[i];
         w.workspace = F(L.wgrad_ws);
+        if (i == 0 && cut > 0) {
+            const int T0 = L.T[0];
+            a.t_begin = cut; a.t_end = T0; a.dh_carry = F(L.xp[0]);      // (xp is free once the forward is done)
+            int rc = hpmn_gru_scan_bwd(&a, stream);
+            if (rc != HPMN_OK) return rc;
+            HIPCHK(hipEventRecord(c->fork, st));
+            HIPCHK(hipStreamWaitEvent(c->side, c->fork, 0));
+            rc = hpmn_gru_input_grad(F(L.d_act[0]), wg[0], wc[0], F(L.d_x[0]), d->B, T0, D, d->H, cut, T0 - cut, c->side);
+            if (rc != HPMN_OK) return rc;
+            if (d_last) {
+                const long n = (long)d->B * D0;
+                hipLaunchKernelGGL(add_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->side,
+                                   F(L.d_x[0]) + (size_t)(T0 + d->last_index) * D0, (long)T0 * D0, d_last, d->B, D0);
+                rc = check_launch();
+                if (rc != HPMN_OK) return rc;
+            }
+            rc = embed_grad_scatter_launch(ids, F(L.d_x[0]), d_emb, d->B, d->T, d->F, d->E, d->front_zero, d->mask_id0,
+                                           cut - d->front_zero, d->T, c->side);
+            if (rc != HPMN_OK) return rc;
+            HIPCHK(hipEventRecord(c->scat, c->side));
+            scatter_pending = true;
+            w.t_begin = cut; w.t_len = T0 - cut;
+            rc = hpmn_gru_param_grads(&w, c->side);
+            if (rc != HPMN_OK) return rc;
+            c->pending = true;
+            a.t_begin = 0; a.t_end = cut;
+            rc = hpmn_gru_scan_bwd(&a, stream);
+            if (rc != HPMN_OK) return rc;
+            HIPCHK(hipEventRecord(c->fork, st));
+            HIPCHK(hipStreamWaitEvent(c->side, c->fork, 0));
+            w.t_begin = 0; w.t_len = cut;
+            rc = hpmn_gru_param_grads(&w, c->side);
+            if (rc != HPMN_OK) return rc;
+            rc = hpmn_gru_input_grad(F(L.d_act[0]), wg[0], wc[0], F(L.d_x[0]), d->B, T0, D, d->H, 0, cut, stream);
+            if (rc != HPMN_OK) return rc;
+            continue;
+        }
+        const bool fused_dx = gru_scan_bwd_fuses_dx(d->H, d->B) && D <= 64;
+        if (fused_dx) a.d_x = F(L.d_x[i]);       // the input gradient comes out of the scan launch itself
+        int rc = hpmn_gru_scan_bwd(&a, stream);
+        if (rc != HPMN_OK) return rc;
+        // the weight gradient of this layer: an MFMA reduction over d_act, off the serial chain, on the helper stream
+        HIPCHK(hipEventRecord(c->fork, st));
+        HIPCHK(hipStreamWaitEvent(c->side, c->fork, 0));
         rc = hpmn_gru_param_grads(&w, c->side);
         if (rc != HPMN_OK) return rc;
         c->pending = true;
@@ -227,16 +286,17 @@ int hpmn_scan_bwd(HpmnTrainCtx *ctx, const HpmnScanDesc *d, const int32_t *ids, 
             if (rc != HPMN_OK) return rc;
         }
     }
-    if (d_last) {
+    if (d_last && !scatter_pending) {
         const long n = (long)d->B * D0;
         hipLaunchKernelGGL(add_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
                            F(L.d_x[0]) + (size_t)(L.T[0] + d->last_index) * D0, (long)L.T[0] * D0, d_last, d->B, D0);
         int rc = check_launch();
         if (rc != HPMN_OK) return rc;
     }
-    int rc = hpmn_embed_grad_scatter(ids, F(L.d_x[0]), d_emb, d->B, d->T, d->F, d->E, d->front_zero, d->V, d->mask_id0,
-                                     stream);
+    int rc = embed_grad_scatter_launch(ids, F(L.d_x[0]), d_emb, d->B, d->T, d->F, d->E, d->front_zero, d->mask_id0, 0,
+                                       scatter_pending ? cut - d->front_zero : d->T, st);
     if (rc != HPMN_OK) return rc;
+    if (scatter_pending) HIPCHK(hipStreamWaitEvent(st, c->scat, 0));   // the caller's table update needs both halves
     if (!defer_join) return hpmn_train_join(ctx, stream);
     return HPMN_OK;
 }

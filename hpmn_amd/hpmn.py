@@ -243,6 +243,8 @@ class Hpmn_Basic(object):
         # lazy table Adam: no dense table gradient exists; the flat gradient then covers the dense variables only
         self._goff = offs[shapes[1][0]] if self.lazy_table_adam else 0
         self.flat_grad = torch.zeros(n - self._goff, device=dev, dtype=torch.float32)
+        self._loss_acc = torch.zeros(2, device=dev, dtype=torch.float32)      # log-loss sum, memory-loss sum of a step
+        self._aux_stream = torch.cuda.Stream(device=dev)                      # housekeeping off the serial chain
         self.flat_m = torch.zeros(n, device=dev, dtype=torch.float32)
         self.flat_v = torch.zeros(n, device=dev, dtype=torch.float32)
         self.params: Dict[str, torch.Tensor] = {}
@@ -410,21 +412,40 @@ class Hpmn_Basic(object):
         B = ids.shape[0]
         if global_batch is None:
             global_batch = B * self.world
-        self.flat_grad.zero_()
+        if B == 0 or not self._hip_read:
+            self.flat_grad.zero_()
         if B == 0:
             return dict(prediction=torch.empty(0, device=self.device)), torch.zeros((), device=self.device)
         if not self._hip_read:
             return self._compute_gradients_branches(ids, item_ids, label, keep_prob, masks, global_batch, defer_join)
+        # Housekeeping that nothing on the serial chain waits for goes to an auxiliary stream: clearing the flat
+        # gradient (213 MB at C3, 28 us) runs underneath the forward scans, which do not touch it, and the three
+        # scalar kernels that form cross_entropy run underneath BPTT instead of in front of the table update.
+        main = torch.cuda.current_stream()
+        aux = self._aux_stream
+        aux.wait_stream(main)                                # (after the previous step's optimiser, which read it)
+        with torch.cuda.stream(aux):
+            self.flat_grad.zero_()
+            self._loss_acc.zero_()
         emb = self.params["Embedding/emb_mtx"]
         weights = self._gru_weights()
         memory, last, saved = ops.scan_forward_train(self.spec, ids, emb, weights)
+        main.wait_stream(aux)
         seed = 0
         if masks is None and keep_prob < 1.0:
             # masks are drawn inside the read kernel (counter-based): a fresh 64-bit seed per step and rank
             self._dropout_step += 1
             seed = _splitmix64(_splitmix64(self._dropout_base + self._dropout_step) ^ (self.rank + 1)) | 1
         out = ops.read_fwd_bwd(self._read_desc, self._read_params, self._read_grads, memory, last, label, masks,
-                               keep_prob, 1.0 / float(global_batch), self.memory_reg, dropout_seed=seed)
+                               keep_prob, 1.0 / float(global_batch), self.memory_reg, dropout_seed=seed,
+                               loss_out=self._loss_acc)
+        aux.wait_stream(main)
+        with torch.cuda.stream(aux):
+            sums = self._loss_acc.clone()                    # (the accumulator is cleared again next step)
+            out["log_loss_sum"], out["memory_loss"] = sums[0], sums[1]
+            ce = sums[0] / float(global_batch) + self.memory_reg * sums[1]
+            sums.record_stream(main)
+            ce.record_stream(main)
         if self.lazy_table_adam:
             # touched rows only: the scatter goes to a COMPACT [U, E] buffer through ids remapped to 0..U-1 (row 0 of
             # it stays original id 0, so the id-0 mask of the Hpmn graph keeps working on the remapped ids)
@@ -443,11 +464,11 @@ class Hpmn_Basic(object):
         pending = ops.scan_backward(self.spec, scatter_ids, saved, weights, out["d_memory"], out["d_last"], grad_out,
                                     defer_join=defer_join and not self.l2_reg)
         out["pending"] = pending
+        main.wait_stream(aux)                                # the loss scalars belong to the caller's stream again
         if self.l2_reg:
             # l2_reg * tf.nn.l2_loss(v) for every trainable variable (code/hpmn.py:204-205); every rank holds
             # every variable, so each adds 1/world of it before the sum all-reduce
             self.flat_grad.add_(self.flat_param, alpha=self.l2_reg / self.world)
-        ce = out["log_loss_sum"] / float(global_batch) + self.memory_reg * out["memory_loss"]
         if self.l2_reg:
             # cross_entropy includes sum_v l2_reg * tf.nn.l2_loss(v) = l2_reg/2 * |v|^2 (code/hpmn.py:203-205);
             # every rank holds every variable, so each reports 1/world of it like the other (sharded) terms

@@ -998,10 +998,11 @@ def read_fwd(desc, params, memory, last, want_logit=False, want_att=False):
 
 
 def read_fwd_bwd(desc, params, d_params, memory, last, label, masks, keep_prob, inv_global_batch, memory_reg,
-                 dropout_seed: int = 0):
+                 dropout_seed: int = 0, loss_out: Optional[torch.Tensor] = None):
     """hpmn_read_fwd_bwd: forward + loss + backward of the read path; accumulates into d_params.
     ``masks`` = (mask1 [B,200], mask2 [B,80]) or None; with None and keep_prob < 1 a non-zero ``dropout_seed``
-    makes the kernel draw the masks itself."""
+    makes the kernel draw the masks itself.  ``loss_out``: a ZEROED [2] buffer to accumulate the two loss sums into
+    (the training step keeps one and clears it off the critical path); default: a fresh one."""
     _chk_f32(params, d_params, memory, last)
     B, K, H = memory.shape
     desc.B = B
@@ -1009,7 +1010,8 @@ def read_fwd_bwd(desc, params, d_params, memory, last, label, masks, keep_prob, 
     dev = memory.device
     assert label.dtype == torch.int32 and label.is_contiguous()
     pred = torch.empty(B, device=dev)
-    loss_out = torch.zeros(2, device=dev)
+    if loss_out is None:
+        loss_out = torch.zeros(2, device=dev)
     d_memory = torch.empty_like(memory)
     d_last = torch.empty_like(last)
     m1 = m2 = None
