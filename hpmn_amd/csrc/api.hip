@@ -11,6 +11,7 @@ bool gru_shape_supported(int H, int D);
 int gru_scan_fwd_dispatch(const HpmnGruFwd &a, hipStream_t st);
 int gru_scan_bwd_dispatch(const HpmnGruBwd &a, hipStream_t st);
 bool gru_scan_bwd_fuses_dx(int H, int B);
+bool gru_scan_bwd_dx_width_ok(int D);
 bool input_proj_supported(int H, int D);
 int memory_update_launch(const HpmnOnlineUpdate &a, hipStream_t st);
 bool gru_fused_fwd_supported(int H, int D, int gather);
@@ -137,7 +138,7 @@ int hpmn_gru_scan_bwd(const HpmnGruBwd *a, void *stream) {
         if (a->d_y && t_hi % a->period != 0) return HPMN_EINVAL;
     }
     if (!gru_shape_supported(a->H, a->D)) return HPMN_EUNSUPPORTED;
-    if (a->d_x && (!gru_scan_bwd_fuses_dx(a->H, a->B) || a->D > 64)) return HPMN_EUNSUPPORTED;
+    if (a->d_x && (!gru_scan_bwd_fuses_dx(a->H, a->B) || !gru_scan_bwd_dx_width_ok(a->D))) return HPMN_EUNSUPPORTED;
     if (a->B == 0) return HPMN_OK;
     HpmnGruBwd k = *a;
     if (k.period < 1) k.period = 1;

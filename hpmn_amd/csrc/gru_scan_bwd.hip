@@ -417,14 +417,19 @@ static int bwd_helper_enabled() {
     return helper;
 }
 int gru_scan_bwd_feed_launch(const HpmnGruBwd &a, hipStream_t st);   // gru_scan_bwd_feed.hip
-// does hpmn_gru_scan_bwd produce d_x itself (HpmnGruBwd.d_x) for this shape?
+bool gru_scan_bwd_feed_dx_width(int D);
+// does hpmn_gru_scan_bwd produce d_x itself (HpmnGruBwd.d_x) for this shape?  (and input widths 16, 32, 64)
 bool gru_scan_bwd_fuses_dx(int H, int B) {
-    // measured at C3: step 4.12 ms with the dx wave against 3.78 without (layer-0 scan 0.948 vs 0.688 ms in the step:
-    // three waves per sequence crowd the LDS pipe and the SIMDs the scan wave lives on, and leave the weight
-    // gradients no room beside the scan) -- parity-tested, default OFF, HPMN_BWD_DX_WAVE=1 turns it on
+    // HPMN_BWD_DX_WAVE=1 (default 0): built twice, parity-green twice, measured slower twice.  With the e_u helper
+    // kernel above (HPMN_BWD_HELPER=1) a third wave did the product with packed FMAs: 4.12 vs 3.78 ms/step at C3.  With
+    // the chain + feeder kernel (gru_scan_bwd_feed.hip) the third role runs on the matrix cores out of an LDS operand
+    // ring: 3.62 vs 3.36 ms/step, layer-0 launch 0.562 vs 0.458 ms alone (D = 64: 0.641) -- the slowdown equals the
+    // MFMA pipe time (96 / 192 x 32 cycles per 16 steps): a SIMD does not issue its other wave's VALU instructions
+    // while an fp32 MFMA is passing, and every SIMD of the CU hosts a latency-critical wave.
     static const int dxw = [] { const char *e = getenv("HPMN_BWD_DX_WAVE"); return e ? atoi(e) : 0; }();
     return H == 64 && B <= 640 && bwd_helper_enabled() && dxw;
 }
+bool gru_scan_bwd_dx_width_ok(int D) { return bwd_helper_enabled() >= 2 ? gru_scan_bwd_feed_dx_width(D) : D <= 64; }
 
 int gru_scan_bwd128_dispatch(const HpmnGruBwd &a, hipStream_t st);   // gru_scan128.hip
 
@@ -437,10 +442,10 @@ int gru_scan_bwd_dispatch(const HpmnGruBwd &a, hipStream_t st) {
         // layer 0, and 0.683 vs 0.744 ms inside the step now that the weight-gradient launches leave room on every
         // CU (gru_wgrad.hip: one workgroup per CU; before that change the variant LOST in-step, 0.873 vs 0.815)
         if (bwd_helper_enabled() && a.B <= 640) {
-            if (a.d_x != nullptr && gru_scan_bwd_fuses_dx(a.H, a.B))
-                hipLaunchKernelGGL(gru_scan_bwd_helper_kernel<true>, dim3(a.B), dim3(192), 0, st, a);
-            else if (bwd_helper_enabled() >= 2)
+            if (bwd_helper_enabled() >= 2)
                 return gru_scan_bwd_feed_launch(a, st);
+            else if (a.d_x != nullptr && gru_scan_bwd_fuses_dx(a.H, a.B))
+                hipLaunchKernelGGL(gru_scan_bwd_helper_kernel<true>, dim3(a.B), dim3(192), 0, st, a);
             else
                 hipLaunchKernelGGL(gru_scan_bwd_helper_kernel<false>, dim3(a.B), dim3(128), 0, st, a);
         } else {

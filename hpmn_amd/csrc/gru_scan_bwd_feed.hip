@@ -19,6 +19,17 @@
 //   chain (wave 0), per step:   dh += dy; dc_pre, da_u (2 multiplies) -> LDS; d(rh) = dc_pre Wc^T; da_r -> LDS;
 //       e_r = da_r Wg_r^T; dh = dh u + d(rh) r + e_r + e_u.   No global memory access, no address arithmetic, no vmcnt.
 //
+// DXD > 0 adds a third role, the layer's INPUT GRADIENT d_x[t] = d_act[t] [Wg[:D] | Wc[:D]]^T (what hpmn_gru_input_grad
+// computes as a launch of its own -- for layers >= 1 the d_y the next reverse scan waits for, i.e. a kernel on the serial
+// chain, and for layer 0 the first kernel of the step's tail): over a block of 16 steps it is a real [D x 192] x
+// [192 x 16] product, so a wave per sequence issues it on the MATRIX cores (v_mfma_f32_16x16x4_f32, true fp32; 96 / 192
+// MFMAs per block = 6 / 12 instructions per step) out of the operand rows the chain wave writes to LDS anyway -- they now
+// go into a 32-step ring instead of a 2-step buffer -- with the input-block weights stationary as A operands.  Its waves
+// are the 5th and 6th of the workgroup, which the hardware places on the feeders' SIMDs (tools/micro/where.hip).
+// MEASURED SLOWER, default off (gru_scan_bwd.hip, HPMN_BWD_DX_WAVE): the scan slows down by the MFMA pipe time -- a SIMD
+// does not issue the feeder's VALU instructions while the other wave's fp32 MFMA is passing -- which is more than the
+// stand-alone input-gradient launch costs.
+//
 // Hand-offs are LDS progress counters (common.h: data, lgkmcnt(0), counter; cached copies, re-read only when the
 // cached value says "wait"); no barrier in the loop.  Buffers are double-buffered by step parity: the feeder reads
 // step k-1's operands at the start of its step k, before it publishes e_u(k), and the chain wave cannot reach step
@@ -29,42 +40,34 @@
 
 namespace hpmn {
 
-constexpr int FR_STEPS = 8;     // ring depth in steps (4 chunks of 2)
+constexpr int FR_STEPS = 8;     // coefficient ring depth in steps (4 chunks of 2)
 constexpr int FR_AHEAD = 3;     // chunks the feeder parks ahead of the chunk the chain wave is on
+constexpr int DROW = 196;       // floats per operand row [da_r | da_u | dc_pre] + 4 pad: rows 784 B apart, so that the 16
+                                // lanes of a quarter-wave reading 16 B of 16 different rows hit 64 different banks
+constexpr int DXB = 16;         // steps per input-gradient block (= MFMA N)
 
-// tuning knobs (tools/micro/feed_bench.py builds variants with -D; the defaults are the measured best)
-#ifndef FEED_DAU_SLEEP
-#define FEED_DAU_SLEEP 0        // s_sleep argument of the feeder's poll for da_u (0: spin)
-#endif
-#ifndef FEED_EU_MID
-#define FEED_EU_MID 0           // chain wave picks e_u up in the middle of its second product (0: at its end)
-#endif
-#ifndef FEED_KS
-#define FEED_KS 2               // k-split of the three 64x64 products (common.h split_matvec; 1: broadcast reads)
-#endif
-#ifndef FEED_CHAIN_EU
-#define FEED_CHAIN_EU 0         // float4s (of 16) of the e_u product the chain wave computes itself
-#endif
-constexpr int CEU = FEED_CHAIN_EU;
+typedef float f4m __attribute__((ext_vector_type(4)));
 
 // TWO sequences per workgroup: the hardware places the waves of a workgroup on consecutive SIMDs of its rotation,
 // but starts the next workgroup of the CU on the SIMD the previous one ended on (tools/micro/where.hip: with 2-wave
 // workgroups every CU had the chain wave of one sequence and the feeder of the other on ONE SIMD and a SIMD idle;
-// 4-wave workgroups land on four distinct SIMDs).  Waves 0,1 are the chain waves of sequences 2 blockIdx.x + 0,1,
-// waves 2,3 their feeders; the two halves share nothing but the launch.
-template <int KS>
-__global__ __launch_bounds__(256, 1) void gru_scan_bwd_feed_kernel(const HpmnGruBwd a) {
+// 4-wave workgroups land on four distinct SIMDs, the 5th and 6th wave of a 6-wave workgroup on the SIMDs of the 1st
+// and 2nd).  DXD == 0: waves 0,1 chain, 2,3 feeder.  DXD > 0: waves 0,1 feeder, 2,3 chain, 4,5 input gradient.
+template <int DXD>
+__global__ __launch_bounds__(DXD ? 384 : 256, 1) void gru_scan_bwd_feed_kernel(const HpmnGruBwd a) {
     constexpr int H = 64;
-    constexpr int KSS = KS == 1 ? 2 : KS;     // array extents of the unused form stay legal
+    constexpr bool DX = DXD > 0;
+    constexpr int NSLOT = DX ? 2 * DXB : 2;                                // operand rows kept in LDS
     __shared__ __attribute__((aligned(16))) v4f ringA_[2][FR_STEPS][H];    // dy, k1, k2, k3
     __shared__ __attribute__((aligned(16))) f2 ringB_[2][FR_STEPS][H];     // r, u
-    __shared__ __attribute__((aligned(16))) float bufA_[2][2][H];          // dc_pre
-    __shared__ __attribute__((aligned(16))) float bufB_[2][2][2 * H];      // da_r | da_u
+    __shared__ __attribute__((aligned(16))) float dact_[2][NSLOT][DROW];   // da_r | da_u | dc_pre of iteration k in row k % NSLOT
     __shared__ float eU_[2][2][H];
     __shared__ int ctr_[2][4];
 
     const int lane = threadIdx.x & 63;
-    const int seq = (threadIdx.x >> 6) & 1, wave = threadIdx.x >> 7;     // wave: 0 chain, 1 feeder
+    const int w = threadIdx.x >> 6;
+    const int seq = w & 1;
+    const int role = DX ? (w < 2 ? 1 : (w < 4 ? 0 : 2)) : (w >> 1);       // 0 chain, 1 feeder, 2 input gradient
     const int l = lane;
     const int T = a.T, D = a.D;
     const long b = 2 * (long)blockIdx.x + seq;
@@ -72,30 +75,78 @@ __global__ __launch_bounds__(256, 1) void gru_scan_bwd_feed_kernel(const HpmnGru
                                                  // ended waves do not take part in it)
     v4f (&ringA)[FR_STEPS][H] = ringA_[seq];
     f2 (&ringB)[FR_STEPS][H] = ringB_[seq];
-    float (&bufA)[2][H] = bufA_[seq];
-    float (&bufB)[2][2 * H] = bufB_[seq];
+    float (&dact)[NSLOT][DROW] = dact_[seq];
     float (&eU)[2][H] = eU_[seq];
-    int &dau_pub = ctr_[seq][0], &eu_pub = ctr_[seq][1], &fed = ctr_[seq][2];
+    int &dau_pub = ctr_[seq][0], &eu_pub = ctr_[seq][1], &fed = ctr_[seq][2], &dx_done = ctr_[seq][3];
     const int t_lo0 = a.t_begin;
     const int t_hi = a.t_end > 0 ? a.t_end : T;
     const int nsteps = t_hi - t_lo0;
     const int nfull = nsteps >> 1;               // 2-step chunks; an odd last step is peeled
-    if (lane == 0 && wave == 0) { dau_pub = 0; eu_pub = 0; fed = 0; }
+    if (lane == 0 && role == 0) { dau_pub = 0; eu_pub = 0; fed = 0; dx_done = 0; }
     __syncthreads();
 
-    if (wave == 1) {
+    if constexpr (DX) {
+        if (role == 2) {
+            // ============================================================== input gradient, 16 steps per block
+            const int j = lane & 15, g = lane >> 4;
+            constexpr int NCT = DXD / 16;
+            // A operands: W[col = 16 ct + j][f = 16 kq + 4 g + c], W = [wg[0:D] | wc[0:D]] (input rows x 3H gate columns)
+            float wx[NCT][12][4];
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                for (int kq = 0; kq < 12; ++kq) {
+                    const long col = 16 * ct + j;
+                    const v4f v = kq < 8 ? *reinterpret_cast<const v4f *>(a.wg + col * 2 * H + 16 * kq + 4 * g)
+                                         : *reinterpret_cast<const v4f *>(a.wc + col * H + 16 * (kq - 8) + 4 * g);
+                    wx[ct][kq][0] = v.x; wx[ct][kq][1] = v.y; wx[ct][kq][2] = v.z; wx[ct][kq][3] = v.w;
+                }
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                for (int kq = 0; kq < 12; ++kq)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) settle(wx[ct][kq][c]);
+            const int nblk = (nsteps + DXB - 1) / DXB;
+            int seen = 0;
+            for (int q = 0; q < nblk; ++q) {
+                // rows of iterations 16 q .. are complete once the chain wave has STARTED iteration 16 q + 16 (it
+                // reports nsteps + 1 when the last one is done)
+                const int last = DXB * (q + 1) < nsteps ? DXB * (q + 1) : nsteps;
+                while (seen <= last) {
+                    seen = lds_counter_peek(&dau_pub);
+                    if (seen <= last) __builtin_amdgcn_s_sleep(8);
+                }
+                asm volatile("" ::: "memory");
+                const int k = DXB * q + j;
+                const float *row = &dact[k & (NSLOT - 1)][4 * g];
+                v4f v[12];
+#pragma unroll
+                for (int kq = 0; kq < 12; ++kq) v[kq] = *reinterpret_cast<const v4f *>(row + 16 * kq);
+#pragma unroll
+                for (int kq = 0; kq < 12; ++kq) asm volatile("" : "+v"(v[kq]));
+                lds_counter_set(&dx_done, q + 1);                      // (the reads above have landed)
+                float *dst = a.d_x + (b * (long)T + (t_hi - 1 - k)) * DXD + 4 * g;
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) {
+                    f4m acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int kq = 0; kq < 12; ++kq)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wx[ct][kq][c], v[kq][c], acc, 0, 0, 0);
+                    if (k < nsteps) *reinterpret_cast<f4m *>(dst + 16 * ct) = acc;
+                }
+            }
+            return;
+        }
+    }
+
+    if (role == 1) {
         // ================================================================== feeder
         __builtin_amdgcn_s_setprio(2);
-        f2 wuT[KS == 1 ? H / 2 : 1];       // row D+l of the update-gate block, packed over consecutive n
-        f2 wuS[KSS][32 / KSS];
-        if constexpr (KS == 1) {
-#pragma unroll
-            for (int n = 0; n < H / 2; ++n) wuT[n] = *reinterpret_cast<const f2 *>(a.wg + (long)(D + l) * 2 * H + H + 2 * n);
-#pragma unroll
-            for (int n = 0; n < H / 2; ++n) settle(wuT[n]);
-        } else {
-            split_matvec_weights<KSS>(a.wg + (long)D * 2 * H + H, 2 * H, lane, wuS);
-        }
+        f2 wuS[2][16];                       // rows of the update-gate block, k-split (common.h)
+        split_matvec_weights<2>(a.wg + (long)D * 2 * H + H, 2 * H, lane, wuS);
 
         const int period = a.period;
         const bool has_dy = a.d_y != nullptr;
@@ -156,20 +207,12 @@ __global__ __launch_bounds__(256, 1) void gru_scan_bwd_feed_kernel(const HpmnGru
         int seen = 0;
         // one iteration: e_u(k); the d_act row of iteration k-1 goes out behind it
         auto iter = [&](int k, int p, bool store_prev) {
-            while (seen <= k) {
-                seen = lds_counter_peek(&dau_pub);
-                if (FEED_DAU_SLEEP && seen <= k) __builtin_amdgcn_s_sleep(FEED_DAU_SLEEP);
-            }
+            while (seen <= k) seen = lds_counter_peek(&dau_pub);
             asm volatile("" ::: "memory");
-            float euv;
-            if constexpr (KS == 1) {
-                f2 e0, e1;
-                bcast_matvec_first<H / 4 - CEU>(reinterpret_cast<const float4 *>(&bufB[p][H + 4 * CEU]), wuT + 2 * CEU, e0, e1);
-                euv = (e0.x + e0.y) + (e1.x + e1.y);
-            } else {
-                euv = split_matvec<KSS>(&bufB[p][H], wuS, lane);
-            }
-            const float o_dar = bufB[p ^ 1][l], o_dau = bufB[p ^ 1][H + l], o_dcp = bufA[p ^ 1][l];
+            const float *row = dact[DX ? (k & (NSLOT - 1)) : p];
+            const float *old = dact[DX ? ((k - 1) & (NSLOT - 1)) : (p ^ 1)];
+            const float euv = split_matvec<2>(row + H, wuS, lane);
+            const float o_dar = old[l], o_dau = old[H + l], o_dcp = old[2 * H + l];
             eU[p][l] = euv;
             lds_counter_set(&eu_pub, k + 1);
             if (store_prev) {
@@ -213,41 +256,24 @@ __global__ __launch_bounds__(256, 1) void gru_scan_bwd_feed_kernel(const HpmnGru
                 if (seen <= nsteps) __builtin_amdgcn_s_sleep(1);
             }
             asm volatile("" ::: "memory");
-            const int p = (nsteps - 1) & 1;
-            dap[0] = bufB[p][l];
-            dap[H] = bufB[p][H + l];
-            dap[2 * H] = bufA[p][l];
+            const float *row = dact[(nsteps - 1) & (NSLOT - 1)];
+            dap[0] = row[l];
+            dap[H] = row[H + l];
+            dap[2 * H] = row[2 * H + l];
         }
         return;
     }
 
     // ====================================================================== chain wave
     __builtin_amdgcn_s_setprio(3);
-    f2 wcT[KS == 1 ? H / 2 : 1], wrT[KS == 1 ? H / 2 : 1];
-    f2 wcS[KSS][32 / KSS], wrS[KSS][32 / KSS];
-    if constexpr (KS == 1) {
-#pragma unroll
-        for (int n = 0; n < H / 2; ++n) wcT[n] = *reinterpret_cast<const f2 *>(a.wc + (long)(D + l) * H + 2 * n);
-#pragma unroll
-        for (int n = 0; n < H / 2; ++n) wrT[n] = *reinterpret_cast<const f2 *>(a.wg + (long)(D + l) * 2 * H + 2 * n);
-#pragma unroll
-        for (int n = 0; n < H / 2; ++n) { settle(wcT[n]); settle(wrT[n]); }
-    } else {
-        split_matvec_weights<KSS>(a.wc + (long)D * H, H, lane, wcS);
-        split_matvec_weights<KSS>(a.wg + (long)D * 2 * H, 2 * H, lane, wrS);
-    }
-    f2 wuC[CEU > 0 ? 2 * CEU : 1];       // the chain wave's share of the update-gate rows
-    if constexpr (CEU > 0) {
-#pragma unroll
-        for (int n = 0; n < 2 * CEU; ++n) wuC[n] = *reinterpret_cast<const f2 *>(a.wg + (long)(D + l) * 2 * H + H + 2 * n);
-#pragma unroll
-        for (int n = 0; n < 2 * CEU; ++n) settle(wuC[n]);
-    }
+    f2 wcS[2][16], wrS[2][16];
+    split_matvec_weights<2>(a.wc + (long)D * H, H, lane, wcS);
+    split_matvec_weights<2>(a.wg + (long)D * 2 * H, 2 * H, lane, wrS);
 
     float dh = (t_hi == T) ? a.d_h_last[b * a.d_h_last_stride + l] : a.dh_carry[b * H + l];
     settle(dh);
 
-    int fed_seen = 0, eu_seen = 0;
+    int fed_seen = 0, eu_seen = 0, dxd_seen = 0;
     auto wait_fed = [&](int need) {
         while (fed_seen < need) {
             fed_seen = lds_counter_peek(&fed);
@@ -260,69 +286,74 @@ __global__ __launch_bounds__(256, 1) void gru_scan_bwd_feed_kernel(const HpmnGru
     f2 cb = ringB[0][l];
 
     auto step = [&](int k, int p) {
+        float *row = dact[DX ? (k & (NSLOT - 1)) : p];
         const float dhin = dh + ca.x;
         const float dcp = dhin * ca.y;
         const float dau = dhin * ca.z;
         const float k3 = ca.w, r = cb.x, u = cb.y;
-        bufB[p][H + l] = dau;
-        bufA[p][l] = dcp;
+        row[H + l] = dau;
+        row[2 * H + l] = dcp;
         lds_counter_set(&dau_pub, k + 1);                            // the feeder may start on e_u(k)
         wave_sync();
-        float drh;
-        if constexpr (KS == 1) {
-            f2 d0, d1;
-            bcast_matvec_first<H / 4>(reinterpret_cast<const float4 *>(&bufA[p][0]), wcT, d0, d1);
-            drh = (d0.x + d0.y) + (d1.x + d1.y);
-        } else {
-            drh = split_matvec<KSS>(&bufA[p][0], wcS, lane);
-        }
-        bufB[p][l] = drh * k3;
+        const float drh = split_matvec<2>(row + 2 * H, wcS, lane);
+        row[l] = drh * k3;
         wave_sync();
-        // e_r in two halves; between them -- i.e. underneath the second half -- the reads whose latency would
-        // otherwise sit on the chain: e_u (the feeder has normally published it by now) and the next step's
-        // coefficients (parked several steps ago; the feeder parks past the end as well)
-        f2 e0, e1;
-        float er = 0.f;
-        if constexpr (KS == 1) {
-            bcast_matvec_first<H / 8>(reinterpret_cast<const float4 *>(&bufB[p][0]), wrT, e0, e1);
-            if constexpr (CEU > 0) bcast_matvec<CEU>(reinterpret_cast<const float4 *>(&bufB[p][H]), wuC, e0, e1);
-        }
-        auto wait_eu = [&]() {
-            while (eu_seen <= k) {
-                eu_seen = lds_counter_peek(&eu_pub);
-                if (eu_seen <= k) __builtin_amdgcn_s_sleep(1);
-            }
-            asm volatile("" ::: "memory");
-        };
-        float eu = 0.f;
-        if (FEED_EU_MID) { wait_eu(); eu = eU[p][l]; }
+        // the next step's coefficients (parked several steps ago; the feeder parks past the end as well): issued
+        // here so that their latency lies underneath the second product
         wait_fed(k + 2);
         const int slot = (k + 1) & (FR_STEPS - 1);
         ca = ringA[slot][l];
         cb = ringB[slot][l];
-        if constexpr (KS == 1) {
-            bcast_matvec<H / 8>(reinterpret_cast<const float4 *>(&bufB[p][H / 2]), wrT + H / 4, e0, e1);
-            er = (e0.x + e0.y) + (e1.x + e1.y);
-        } else {
-            er = split_matvec<KSS>(&bufB[p][0], wrS, lane);
-        }
+        const float er = split_matvec<2>(row, wrS, lane);
         const float part = fmaf(dhin, u, fmaf(drh, r, er));
-        if (!FEED_EU_MID) { wait_eu(); eu = eU[p][l]; }
-        dh = part + eu;
+        while (eu_seen <= k) {
+            eu_seen = lds_counter_peek(&eu_pub);
+            if (eu_seen <= k) __builtin_amdgcn_s_sleep(1);
+        }
+        asm volatile("" ::: "memory");
+        dh = part + eU[p][l];
         wave_sync();
     };
 
     for (int q = 0; q < nfull; ++q) {
+        if constexpr (DX) {
+            // entering a new 16-step block: its rows were last used two blocks ago, which the input-gradient wave
+            // must have read (it does so while this wave is on the block in between)
+            if (((2 * q) & (DXB - 1)) == 0) {
+                const int need = (2 * q) / DXB - 1;
+                while (dxd_seen < need) {
+                    dxd_seen = lds_counter_peek(&dx_done);
+                    if (dxd_seen < need) __builtin_amdgcn_s_sleep(1);
+                }
+                asm volatile("" ::: "memory");
+            }
+        }
         step(2 * q, 0);
         step(2 * q + 1, 1);
     }
-    if (nsteps & 1) step(nsteps - 1, 0);
+    if (nsteps & 1) {
+        if constexpr (DX) {
+            if (((nsteps - 1) & (DXB - 1)) == 0) {
+                const int need = (nsteps - 1) / DXB - 1;
+                while (dxd_seen < need) dxd_seen = lds_counter_peek(&dx_done);
+                asm volatile("" ::: "memory");
+            }
+        }
+        step(nsteps - 1, 0);
+    }
     lds_counter_set(&dau_pub, nsteps + 1);                           // da_r of the last step is in LDS
     if (t_lo0 > 0) a.dh_carry[b * H + l] = dh;
 }
 
+bool gru_scan_bwd_feed_dx_width(int D) { return D == 16 || D == 32 || D == 64; }
+
 int gru_scan_bwd_feed_launch(const HpmnGruBwd &a, hipStream_t st) {
-    hipLaunchKernelGGL(gru_scan_bwd_feed_kernel<FEED_KS>, dim3((a.B + 1) / 2), dim3(256), 0, st, a);
+    const dim3 grid((a.B + 1) / 2);
+    if (a.d_x == nullptr) hipLaunchKernelGGL(gru_scan_bwd_feed_kernel<0>, grid, dim3(256), 0, st, a);
+    else if (a.D == 16) hipLaunchKernelGGL(gru_scan_bwd_feed_kernel<16>, grid, dim3(384), 0, st, a);
+    else if (a.D == 32) hipLaunchKernelGGL(gru_scan_bwd_feed_kernel<32>, grid, dim3(384), 0, st, a);
+    else if (a.D == 64) hipLaunchKernelGGL(gru_scan_bwd_feed_kernel<64>, grid, dim3(384), 0, st, a);
+    else return HPMN_EUNSUPPORTED;
     return check_launch();
 }
 

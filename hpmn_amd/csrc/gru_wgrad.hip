@@ -274,8 +274,9 @@ static int launch_wgrad(const HpmnGruWgrad &a, hipStream_t st) {
     const int nwg = (a.B + k.seq_per_wg - 1) / k.seq_per_wg;
     // One weight-gradient workgroup per CU while the launch shares the chip with a reverse scan (every layer but the
     // longest): two of them take every register of a CU, and the single-wave workgroups of the next reverse scan --
-    // the serial chain -- then cannot even be dispatched until they retire.  Asking for > 80 KiB of (unused) dynamic
-    // LDS caps the occupancy at one per CU; HPMN_WGRAD_SOLO_ROWS = largest B*T that gets this treatment (0 = never).
+    // the serial chain -- then cannot even be dispatched until they retire.  Padding the workgroup's LDS to 82 KiB with
+    // (unused) dynamic LDS caps the occupancy at one per CU and still leaves the 76 KiB a reverse-scan workgroup with
+    // its input-gradient ring needs beside it; HPMN_WGRAD_SOLO_ROWS = largest B*T that gets this treatment (0 = never).
     // Measured (C3 / C2 / C4 steps, ms): 3.985 -> 3.846 / 1.655 -> 1.591 / 10.29 -> 10.47: on for H <= 64 (the H = 128
     // kernels are already shaped for two workgroups per CU around their column split).
     static const long solo_env = [] { const char *e = getenv("HPMN_WGRAD_SOLO_ROWS"); return e ? atol(e) : -1L; }();
@@ -283,13 +284,16 @@ static int launch_wgrad(const HpmnGruWgrad &a, hipStream_t st) {
     const long rows = (long)a.B * (a.t_len > 0 ? a.t_len : a.T);
     size_t lds_pad = 0;
     if (rows <= solo_rows) {
-        lds_pad = 72 * 1024;
-        static bool attr = false;
-        if (!attr) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gru_wgrad_kernel<HT, DT, CS>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
-            attr = true;
-        }
+        static const size_t pad = [] {
+            hipFuncAttributes fa = {};
+            const void *fn = reinterpret_cast<const void *>(gru_wgrad_kernel<HT, DT, CS>);
+            if (hipFuncGetAttributes(&fa, fn) != hipSuccess) return (size_t)0;
+            const size_t want = 82 * 1024;
+            const size_t p = fa.sharedSizeBytes < want ? want - fa.sharedSizeBytes : 0;
+            (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p);
+            return p;
+        }();
+        lds_pad = pad;
     }
     hipLaunchKernelGGL((gru_wgrad_kernel<HT, DT, CS>), dim3((unsigned)nwg, CS), dim3(64 * (HT + DT)), lds_pad, st, k);
     int rc = check_launch();

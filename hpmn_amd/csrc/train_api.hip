@@ -14,6 +14,7 @@ int embed_gather_launch(const int32_t *ids, int64_t ids_stride, const float *emb
 bool gru_fused_fwd_supported(int H, int D, int gather);
 size_t gru_wgrad_workspace_bytes(int B, int T, int D, int H);
 bool gru_scan_bwd_fuses_dx(int H, int B);
+bool gru_scan_bwd_dx_width_ok(int D);
 int embed_grad_scatter_launch(const int32_t *ids, const float *d_x, float *d_emb, int32_t B, int32_t T,
                               int32_t F, int32_t E, int32_t front_zero, int32_t mask_id0, int32_t t_lo, int32_t t_hi,
                               hipStream_t st);
@@ -271,7 +272,7 @@ int hpmn_scan_bwd(HpmnTrainCtx *ctx, const HpmnScanDesc *d, const int32_t *ids, 
             if (rc != HPMN_OK) return rc;
             continue;
         }
-        const bool fused_dx = gru_scan_bwd_fuses_dx(d->H, d->B) && D <= 64;
+        const bool fused_dx = gru_scan_bwd_fuses_dx(d->H, d->B) && gru_scan_bwd_dx_width_ok(D);
         if (fused_dx) a.d_x = F(L.d_x[i]);       // the input gradient comes out of the scan launch itself
         int rc = hpmn_gru_scan_bwd(&a, stream);
         if (rc != HPMN_OK) return rc;

@@ -902,7 +902,7 @@ def scan_backward_layers(spec: ScanSpec, ids, saved, weights: Sequence[torch.Ten
                     gru_param_grads(x_in, hs, gates, d_act[i], wg, wc, gw[4 * i], gw[4 * i + 1], gw[4 * i + 2],
                                     gw[4 * i + 3], want_dx=False, keep=keep, t_range=(0, cut))
             else:
-                fdx = scan_bwd_fuses_dx(H, B) and in_dims[i] <= 64
+                fdx = scan_bwd_fuses_dx(H, B) and in_dims[i] in (16, 32, 64)
                 if PROBE is not None and i == 0:      # bench.py: the dominant kernel timed INSIDE a real step
                     ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                     ev[0].record(main)
@@ -915,7 +915,7 @@ def scan_backward_layers(spec: ScanSpec, ids, saved, weights: Sequence[torch.Ten
                 with torch.cuda.stream(side):
                     gru_param_grads(x_in, hs, gates, d_act[i], wg, wc, gw[4 * i], gw[4 * i + 1], gw[4 * i + 2],
                                     gw[4 * i + 3], want_dx=False, keep=keep)
-            if cut or not (scan_bwd_fuses_dx(H, B) and in_dims[i] <= 64):
+            if cut or not (scan_bwd_fuses_dx(H, B) and in_dims[i] in (16, 32, 64)):
                 gru_input_grad(d_act[i], wg, wc, in_dims[i], out=d_x[i])
         d_x0 = d_x[0]
         d_x0[:, spec.last_index, :] += d_last

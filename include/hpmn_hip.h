@@ -177,7 +177,8 @@ typedef struct HpmnGruBwd {
     float *dh_carry;
     /* optional [B, T, D]: the gradient wrt the layer's input rows, d_act [wg[0:D] | wc[0:D]]^T, produced by a third
      * wave of the scan's workgroups underneath the scan (what hpmn_gru_input_grad computes as a launch of its own).
-     * Only where hpmn_gru_scan_bwd_fuses_dx(H, B) != 0; elsewhere it must be NULL (HPMN_EUNSUPPORTED otherwise). */
+     * Only where hpmn_gru_scan_bwd_fuses_dx(H, B) != 0 and D is 16, 32 or 64; elsewhere it must be NULL
+     * (HPMN_EUNSUPPORTED otherwise). */
     float *d_x;
 } HpmnGruBwd;
 

@@ -17,7 +17,7 @@ MAIN = r'''
 namespace hpmn { void set_last_hip_error(int) {} int gru_scan_bwd128_dispatch(const HpmnGruBwd &, hipStream_t) { return -2; }
                  int gru_scan_bwd_dispatch(const HpmnGruBwd &a, hipStream_t st); }
 int main(int argc, char **argv) {
-    const int B = argc > 1 ? atoi(argv[1]) : 500, T = 1024, H = 64, D = 32;
+    const int B = argc > 1 ? atoi(argv[1]) : 500, T = 1024, H = 64, D = argc > 2 ? atoi(argv[2]) : 32, dx = argc > 3 ? atoi(argv[3]) : 0;
     float *wg, *wc, *dhl, *dy, *hs, *gates, *dact, *carry;
     hipMalloc(&wg, (D + H) * 2 * H * 4); hipMalloc(&wc, (D + H) * H * 4);
     std::vector<float> w((D + H) * 2 * H, 0.01f);
@@ -29,16 +29,17 @@ int main(int argc, char **argv) {
     hipMalloc(&hs, (size_t)B * (T + 1) * H * 4); hipMemset(hs, 0, (size_t)B * (T + 1) * H * 4);
     hipMalloc(&gates, (size_t)B * T * 3 * H * 4); hipMemset(gates, 0, (size_t)B * T * 3 * H * 4);
     hipMalloc(&dact, (size_t)B * T * 3 * H * 4);
+    float *dxb; hipMalloc(&dxb, (size_t)B * T * D * 4);
     HpmnGruBwd a = {};
     a.B = B; a.T = T; a.D = D; a.H = H; a.wg = wg; a.wc = wc; a.hs = hs; a.gates = gates;
-    a.d_h_last = dhl; a.d_h_last_stride = H; a.d_y = dy; a.period = 2; a.d_act = dact; a.dh_carry = carry;
+    a.d_h_last = dhl; a.d_h_last_stride = H; a.d_y = dy; a.period = 2; a.d_act = dact; a.dh_carry = carry; if (dx) a.d_x = dxb;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int i = 0; i < 2; ++i) hpmn::gru_scan_bwd_dispatch(a, 0);
     hipEventRecord(e0);
     for (int i = 0; i < 5; ++i) hpmn::gru_scan_bwd_dispatch(a, 0);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
-    printf("%-52s B=%d %.4f ms/launch  %.0f ns/step\n", VARIANT, B, ms / 5, ms / 5 * 1e6 / T);
+    printf("%-52s B=%d D=%d dx=%d %.4f ms/launch  %.0f ns/step\n", VARIANT, B, D, dx, ms / 5, ms / 5 * 1e6 / T);
     return 0;
 }
 '''
@@ -67,8 +68,10 @@ def main():
                "-I" + CSRC, '-DVARIANT="%s"' % name] + flags + [main_cc, os.path.join(CSRC, "gru_scan_bwd.hip"),
                os.path.join(CSRC, "gru_scan_bwd_feed.hip"), "-o", exe]
         subprocess.check_call(cmd)
-        for B in (500, 250):
-            lines.append("HPMN_BWD_HELPER=%s ./tools/micro/feedb_%d %d" % (mode, i, B))
+        for args in ("500 32 0", "500 32 1", "500 64 0", "500 64 1", "250 64 1"):
+            if mode == "1" and args.endswith("1"):
+                continue
+            lines.append("HPMN_BWD_HELPER=%s ./tools/micro/feedb_%d %s" % (mode, i, args))
     os.remove(main_cc)
     open(os.path.join(HERE, "run_feed.sh"), "w").write("\n".join(lines) + "\n")
 

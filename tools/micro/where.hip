@@ -35,7 +35,7 @@ void run(int B) {
     }
     int n = 0, share_chain = 0, share_any = 0, two = 0;
     for (auto &kv : cu) {
-        if (n++ < 6) printf("cu %05x:%s\n", kv.first, kv.second.c_str());
+        if (n++ < 8) printf("cu %05x:%s\n", kv.first, kv.second.c_str());
         auto &v = simds[kv.first];
         int cnt[4] = {0, 0, 0, 0};
         for (int x : v) cnt[x]++;
@@ -47,6 +47,6 @@ void run(int B) {
     hipFree(d);
 }
 int main(int argc, char **argv) {
-    run<2>(500); run<4>(250); run<3>(256); run<3>(500); run<2>(250); run<1>(500); run<1>(1000);
+    run<2>(500); run<4>(250); run<6>(250); run<8>(250); run<6>(320);
     return 0;
 }
