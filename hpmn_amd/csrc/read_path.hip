@@ -18,7 +18,10 @@
 
 namespace hpmn {
 
-constexpr int RS = 2;          // samples per workgroup
+#ifndef HPMN_READ_RS
+#define HPMN_READ_RS 2
+#endif
+constexpr int RS = HPMN_READ_RS;          // samples per workgroup
 constexpr int RT = 256;        // threads
 constexpr int A1 = 80, A2 = 40;      // attention MLP widths (code/hpmn.py:137-138)
 constexpr int F1 = 200, F2 = 80;     // head widths (code/hpmn.py:191,193)

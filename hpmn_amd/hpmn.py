@@ -421,16 +421,20 @@ class Hpmn_Basic(object):
         # Housekeeping that nothing on the serial chain waits for goes to an auxiliary stream: clearing the flat
         # gradient (213 MB at C3, 28 us) runs underneath the forward scans, which do not touch it, and the three
         # scalar kernels that form cross_entropy run underneath BPTT instead of in front of the table update.
+        # (Each hand-over between streams costs a few microseconds of queue processing: only worth it where the
+        # gradient buffer is big -- C3: 213 MB -- not for the 0.5 ms steps of the small-table configurations.)
         main = torch.cuda.current_stream()
-        aux = self._aux_stream
-        aux.wait_stream(main)                                # (after the previous step's optimiser, which read it)
+        aux = self._aux_stream if self.flat_grad.numel() >= (1 << 24) else main
+        if aux is not main:
+            aux.wait_stream(main)                            # (after the previous step's optimiser, which read it)
         with torch.cuda.stream(aux):
             self.flat_grad.zero_()
             self._loss_acc.zero_()
         emb = self.params["Embedding/emb_mtx"]
         weights = self._gru_weights()
         memory, last, saved = ops.scan_forward_train(self.spec, ids, emb, weights)
-        main.wait_stream(aux)
+        if aux is not main:
+            main.wait_stream(aux)
         seed = 0
         if masks is None and keep_prob < 1.0:
             # masks are drawn inside the read kernel (counter-based): a fresh 64-bit seed per step and rank
@@ -439,13 +443,15 @@ class Hpmn_Basic(object):
         out = ops.read_fwd_bwd(self._read_desc, self._read_params, self._read_grads, memory, last, label, masks,
                                keep_prob, 1.0 / float(global_batch), self.memory_reg, dropout_seed=seed,
                                loss_out=self._loss_acc)
-        aux.wait_stream(main)
+        if aux is not main:
+            aux.wait_stream(main)
         with torch.cuda.stream(aux):
             sums = self._loss_acc.clone()                    # (the accumulator is cleared again next step)
             out["log_loss_sum"], out["memory_loss"] = sums[0], sums[1]
             ce = sums[0] / float(global_batch) + self.memory_reg * sums[1]
-            sums.record_stream(main)
-            ce.record_stream(main)
+            if aux is not main:
+                sums.record_stream(main)
+                ce.record_stream(main)
         if self.lazy_table_adam:
             # touched rows only: the scatter goes to a COMPACT [U, E] buffer through ids remapped to 0..U-1 (row 0 of
             # it stays original id 0, so the id-0 mask of the Hpmn graph keeps working on the remapped ids)
@@ -464,7 +470,8 @@ class Hpmn_Basic(object):
         pending = ops.scan_backward(self.spec, scatter_ids, saved, weights, out["d_memory"], out["d_last"], grad_out,
                                     defer_join=defer_join and not self.l2_reg)
         out["pending"] = pending
-        main.wait_stream(aux)                                # the loss scalars belong to the caller's stream again
+        if aux is not main:
+            main.wait_stream(aux)                            # the loss scalars belong to the caller's stream again
         if self.l2_reg:
             # l2_reg * tf.nn.l2_loss(v) for every trainable variable (code/hpmn.py:204-205); every rank holds
             # every variable, so each adds 1/world of it before the sum all-reduce
