@@ -213,7 +213,7 @@ def roofline_probes(model, c, batches, step_fn):
     # (H = 64 at the reference batch runs the chain + feeder variant of the reverse scan, gru_scan_bwd_feed.hip)
     mode = os.environ.get("HPMN_BWD_HELPER", "2")
     if H == 64 and B <= 640 and mode != "0":
-        dom_kernel = "gru_scan_bwd_feed_kernel<2>" if mode != "1" else "gru_scan_bwd_helper_kernel<false>"
+        dom_kernel = "gru_scan_bwd_feed_kernel<0>" if mode != "1" else "gru_scan_bwd_helper_kernel<false>"
     else:
         dom_kernel = "gru_scan_bwd_kernel<%d>" % H
     dom_t = in_step_ms if in_step_ms is not None else max(t_bwd, t_fwd)
