@@ -219,6 +219,8 @@ int hpmn_scan_bwd(HpmnTrainCtx *ctx, const HpmnScanDesc *d, const int32_t *ids, 
         if (cut <= d->front_zero || cut >= L.T[0] + d->last_index) cut = 0;
     }
     bool scatter_pending = false;
+    HpmnGruWgrad held[4];
+    int nheld = 0;
     for (int i = d->K - 1; i >= 0; --i) {
         const int D = i == 0 ? D0 : d->H;
         HpmnGruBwd a = {};
@@ -237,6 +239,16 @@ int hpmn_scan_bwd(HpmnTrainCtx *ctx, const HpmnScanDesc *d, const int32_t *ids, 
         w.workspace = F(L.wgrad_ws);
         if (i == 0 && cut > 0) {
             const int T0 = L.T[0];
+            if (nheld) {                                   // (weight gradients of short layers still waiting for a fork)
+                HIPCHK(hipEventRecord(c->fork, st));
+                HIPCHK(hipStreamWaitEvent(c->side, c->fork, 0));
+                for (int h = 0; h < nheld; ++h) {
+                    const int rc0 = hpmn_gru_param_grads(&held[h], c->side);
+                    if (rc0 != HPMN_OK) return rc0;
+                }
+                nheld = 0;
+                c->pending = true;
+            }
             a.t_begin = cut; a.t_end = T0; a.dh_carry = F(L.xp[0]);      // (xp is free once the forward is done)
             int rc = hpmn_gru_scan_bwd(&a, stream);
             if (rc != HPMN_OK) return rc;
@@ -276,12 +288,20 @@ int hpmn_scan_bwd(HpmnTrainCtx *ctx, const HpmnScanDesc *d, const int32_t *ids, 
         if (fused_dx) a.d_x = F(L.d_x[i]);       // the input gradient comes out of the scan launch itself
         int rc = hpmn_gru_scan_bwd(&a, stream);
         if (rc != HPMN_OK) return rc;
-        // the weight gradient of this layer: an MFMA reduction over d_act, off the serial chain, on the helper stream
-        HIPCHK(hipEventRecord(c->fork, st));
-        HIPCHK(hipStreamWaitEvent(c->side, c->fork, 0));
-        rc = hpmn_gru_param_grads(&w, c->side);
-        if (rc != HPMN_OK) return rc;
-        c->pending = true;
+        // the weight gradient of this layer: an MFMA reduction over d_act, off the serial chain, on the helper stream.
+        // Every fork (event record on the launch stream) costs the chain ~6 us of queue processing, so the short top
+        // layers (<= 128 steps: 30-80 us of weight-gradient work each) share the fork of the layer below them.
+        held[nheld++] = w;
+        if (L.T[i] > 128 || i == 0 || nheld == 4) {
+            HIPCHK(hipEventRecord(c->fork, st));
+            HIPCHK(hipStreamWaitEvent(c->side, c->fork, 0));
+            for (int h = 0; h < nheld; ++h) {
+                rc = hpmn_gru_param_grads(&held[h], c->side);
+                if (rc != HPMN_OK) return rc;
+            }
+            nheld = 0;
+            c->pending = true;
+        }
         if (!fused_dx) {
             rc = hpmn_gru_input_grad(F(L.d_act[i]), wg[i], wc[i], F(L.d_x[i]), d->B, L.T[i], D, d->H, 0, 0, stream);
             if (rc != HPMN_OK) return rc;
