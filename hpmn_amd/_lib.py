@@ -10,7 +10,7 @@ import os
 from typing import Optional
 
 HPMN_MAX_LAYERS = 12
-HPMN_ABI_VERSION = 4
+HPMN_ABI_VERSION = 5
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libhpmn_hip.so")
@@ -176,6 +176,10 @@ SIGNATURES = {
     "hpmn_memory_update": (C.c_int, [C.POINTER(HpmnOnlineUpdate), C.c_void_p]),
     "hpmn_adam_step_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
                                       C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    "hpmn_table_mark_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
+    "hpmn_adam_step_table": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
+                                       C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                       C.c_void_p]),
     "hpmn_train_ctx_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "hpmn_train_ctx_destroy": (None, [C.c_void_p]),
     "hpmn_scan_train_workspace_bytes": (C.c_size_t, [C.POINTER(HpmnScanDesc)]),

@@ -64,6 +64,68 @@ __global__ __launch_bounds__(256) void adam_rows_kernel(float4 *__restrict__ p, 
     }
 }
 
+// Dense table Adam in TWO passes with identical arithmetic (include/hpmn_hip.h, hpmn_adam_step_table): the rows a batch
+// does not touch have an exactly-zero gradient, so their update (m = b1 m, v = b2 v, p -= lr_t m / (sqrt v + eps)) needs
+// nothing of the step and runs early on another stream; the touched rows follow behind the scatter.
+__global__ __launch_bounds__(256) void table_mark_kernel(const int32_t *__restrict__ ids, long n, uint8_t *__restrict__ flags) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) flags[ids[i]] = 1;
+}
+
+// PASS 0: rows with flag == 0 (gradient taken as zero, not read).  PASS 1: rows with flag != 0: the gradient row is
+// consumed and CLEARED and so is the flag, which leaves the gradient table and the flags all-zero for the next step.
+// One float4 per thread, E4 = E/4 adjacent lanes per row (256 % E4 == 0: a row never straddles a wave, so every lane
+// of a row has read the flag before one of them clears it).
+template <int PASS>
+__global__ __launch_bounds__(256) void adam_table_kernel(float4 *__restrict__ p, float4 *__restrict__ g,
+                                                         float4 *__restrict__ m, float4 *__restrict__ v,
+                                                         uint8_t *__restrict__ flags, long n4, int e4_shift, float lr_t,
+                                                         float b1, float b2, float eps, float clip, float gs) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const long row = i >> e4_shift;
+        const bool marked = flags[row] != 0;
+        if (marked != (PASS == 1)) continue;
+        float4 pp = p[i], mm = m[i], vv = v[i];
+        float4 gg = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (PASS == 1) {
+            gg = g[i];
+            g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        adam_elem(pp.x, gg.x, mm.x, vv.x, lr_t, b1, b2, eps, clip, gs);
+        adam_elem(pp.y, gg.y, mm.y, vv.y, lr_t, b1, b2, eps, clip, gs);
+        adam_elem(pp.z, gg.z, mm.z, vv.z, lr_t, b1, b2, eps, clip, gs);
+        adam_elem(pp.w, gg.w, mm.w, vv.w, lr_t, b1, b2, eps, clip, gs);
+        p[i] = pp; m[i] = mm; v[i] = vv;
+        if (PASS == 1 && (i & ((1L << e4_shift) - 1)) == 0) flags[row] = 0;
+    }
+}
+
+int table_mark_launch(const int32_t *ids, int64_t n, uint8_t *flags, hipStream_t st) {
+    if (n == 0) return HPMN_OK;
+    long blocks = (n + 255) / 256;
+    if (blocks > 256L * 8) blocks = 256L * 8;
+    hipLaunchKernelGGL(table_mark_kernel, dim3((unsigned)blocks), dim3(256), 0, st, ids, (long)n, flags);
+    return check_launch();
+}
+
+int adam_table_launch(float *p, float *g, float *m, float *v, uint8_t *flags, int64_t V, int E, int pass, float lr_t,
+                      float b1, float b2, float eps, float clip, float gs, hipStream_t st) {
+    if (V == 0) return HPMN_OK;
+    int shift = 0;
+    while ((1 << shift) < E / 4) ++shift;
+    const long n4 = V * (long)(E / 4);
+    long blocks = (n4 + 255) / 256;
+    if (blocks > 256L * 16) blocks = 256L * 16;
+    if (pass == 0)
+        hipLaunchKernelGGL(adam_table_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, st, (float4 *)p, (float4 *)g,
+                           (float4 *)m, (float4 *)v, flags, n4, shift, lr_t, b1, b2, eps, clip, gs);
+    else
+        hipLaunchKernelGGL(adam_table_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, (float4 *)p, (float4 *)g,
+                           (float4 *)m, (float4 *)v, flags, n4, shift, lr_t, b1, b2, eps, clip, gs);
+    return check_launch();
+}
+
 int adam_rows_launch(float *p, const float *g, float *m, float *v, const int64_t *row_ids, int64_t n_rows, int E,
                      float lr_t, float b1, float b2, float eps, float clip, float gs, hipStream_t st) {
     if (n_rows == 0) return HPMN_OK;

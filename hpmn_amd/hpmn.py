@@ -244,6 +244,9 @@ class Hpmn_Basic(object):
         self._goff = offs[shapes[1][0]] if self.lazy_table_adam else 0
         self.flat_grad = torch.zeros(n - self._goff, device=dev, dtype=torch.float32)
         self._loss_acc = torch.zeros(2, device=dev, dtype=torch.float32)      # log-loss sum, memory-loss sum of a step
+        # two-pass dense table Adam (train_step): rows the batch points at / whether the table gradient is all-zero
+        self._row_flags: Optional[torch.Tensor] = None
+        self._table_grad_clean = True
         self._aux_stream = torch.cuda.Stream(device=dev)                      # housekeeping off the serial chain
         self.flat_m = torch.zeros(n, device=dev, dtype=torch.float32)
         self.flat_v = torch.zeros(n, device=dev, dtype=torch.float32)
@@ -402,7 +405,7 @@ class Hpmn_Basic(object):
     @torch.no_grad()
     def compute_gradients(self, ids: torch.Tensor, label: torch.Tensor, keep_prob=0.5, masks=None,
                           global_batch: Optional[int] = None, defer_join: bool = False,
-                          item_ids: Optional[torch.Tensor] = None):
+                          item_ids: Optional[torch.Tensor] = None, _clear_grads=None):
         """Forward + BPTT of cross_entropy (code/hpmn.py:202-207) for a (possibly sharded) batch into
         the flat gradient buffer: log-loss is a MEAN over the GLOBAL batch, the memory regulariser a
         SUM.  Pure kernel sequence: scan fwd -> read fwd+loss+bwd -> scan bwd.
@@ -414,6 +417,7 @@ class Hpmn_Basic(object):
             global_batch = B * self.world
         if B == 0 or not self._hip_read:
             self.flat_grad.zero_()
+            self._table_grad_clean = True
         if B == 0:
             return dict(prediction=torch.empty(0, device=self.device)), torch.zeros((), device=self.device)
         if not self._hip_read:
@@ -428,8 +432,12 @@ class Hpmn_Basic(object):
         if aux is not main:
             aux.wait_stream(main)                            # (after the previous step's optimiser, which read it)
         with torch.cuda.stream(aux):
-            self.flat_grad.zero_()
+            if _clear_grads is not None:
+                _clear_grads()                               # train_step's two-pass table update (see there)
+            else:
+                self.flat_grad.zero_()
             self._loss_acc.zero_()
+        self._table_grad_clean = False                       # (until something consumes or clears the table gradient)
         emb = self.params["Embedding/emb_mtx"]
         weights = self._gru_weights()
         memory, last, saved = ops.scan_forward_train(self.spec, ids, emb, weights)
@@ -487,6 +495,8 @@ class Hpmn_Basic(object):
     def train_step(self, ids: torch.Tensor, label: torch.Tensor, keep_prob=0.5, masks=None,
                    global_batch: Optional[int] = None, item_ids: Optional[torch.Tensor] = None):
         """sess.run(train_step) of code/hpmn.py:482: forward, BPTT, clip, dense TF Adam."""
+        if self._two_pass_table_adam(ids):
+            return self._train_step_two_pass(ids, label, keep_prob, masks, global_batch)
         out, ce = self.compute_gradients(ids, label, keep_prob, masks, global_batch, defer_join=True, item_ids=item_ids)
         pending = out.pop("pending", None)
         if self.l2_reg:
@@ -547,6 +557,53 @@ class Hpmn_Basic(object):
         if pending is not None:
             pending.join()
         dist.allreduce_sum_(self.flat_grad[n_emb:])
+        self.apply_gradients(n_emb, self.flat_param.numel(), advance=False)
+        return out, ce
+
+    # ------------------------------------------------------------------ dense table Adam in two passes
+    TWO_PASS_TABLE_ADAM = int(os.environ.get("HPMN_TWO_PASS_ADAM", "1")) != 0
+    TWO_PASS_MIN_NUMEL = 1 << 24          # below this the dense sweep is a few microseconds: not worth two launches
+
+    def _two_pass_table_adam(self, ids) -> bool:
+        """Single process, user-only graph, no densifying l2 term, a table big enough for the dense sweep to matter."""
+        return bool(self.TWO_PASS_TABLE_ADAM and self.world == 1 and self._hip_read and not self.l2_reg
+                    and not self.lazy_table_adam and ids.shape[0] > 0 and self.flat_grad.numel() >= self.TWO_PASS_MIN_NUMEL
+                    and self.embedding_size % 4 == 0)
+
+    def _train_step_two_pass(self, ids, label, keep_prob, masks, global_batch):
+        """The same step with the dense table update (99.5 % of the parameters, 1.5 GB of HBM traffic, the longest kernel
+        of the step's serial tail) split by what it depends on.  A row no id of the batch points at has an exactly-zero
+        gradient: its update -- m = b1 m, v = b2 v, p -= lr_t m / (sqrt(v) + eps), the SAME arithmetic the dense sweep
+        would do with g = 0 -- needs nothing this step computes, and nothing this step computes reads it (the gather and
+        the scatter only touch the batch's rows).  So: mark the batch's rows, update all OTHER rows on the auxiliary
+        stream underneath the forward scans (which leave HBM nearly idle), and behind the scatter update only the marked
+        rows; that pass also clears the gradient rows and flags it consumed, so the table gradient is never cleared
+        densely either.  Results are identical to the one-sweep path (tests/test_gpu_parity.py)."""
+        n_emb = self.params["Embedding/emb_mtx"].numel()
+        V, E = self.feature_size, self.embedding_size
+        if self._row_flags is None:
+            self._row_flags = torch.zeros(V, device=self.device, dtype=torch.uint8)
+        flags = self._row_flags
+        t = self.adam_t + 1
+        lr_t = self.learning_rate * math.sqrt(1.0 - self.beta2 ** t) / (1.0 - self.beta1 ** t)
+        views = [b[:n_emb].view(V, E) for b in (self.flat_param, self.flat_grad, self.flat_m, self.flat_v)]
+
+        def early():                                          # runs on the auxiliary stream
+            if not self._table_grad_clean:
+                self.flat_grad.zero_()                        # (a stand-alone compute_gradients left a gradient behind)
+            else:
+                self.flat_grad[n_emb:].zero_()
+            ops.table_mark_rows(ids, flags)
+            ops.adam_step_table(*views, flags, 0, lr_t, self.beta1, self.beta2, self.adam_eps, clip=1.0)
+
+        out, ce = self.compute_gradients(ids, label, keep_prob, masks, global_batch, defer_join=True, _clear_grads=early)
+        pending = out.pop("pending", None)
+        self.adam_t = t
+        # (compute_gradients has ordered this stream behind the auxiliary one: pass 0 is complete)
+        ops.adam_step_table(*views, flags, 1, lr_t, self.beta1, self.beta2, self.adam_eps, clip=1.0)
+        self._table_grad_clean = True
+        if pending is not None:
+            pending.join()
         self.apply_gradients(n_emb, self.flat_param.numel(), advance=False)
         return out, ce
 

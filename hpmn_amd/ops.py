@@ -313,6 +313,26 @@ def adam_step_rows(param, grad_rows, m, v, row_ids, lr_t, beta1=0.9, beta2=0.999
     _lib.check(rc, "hpmn_adam_step_rows")
 
 
+def table_mark_rows(ids: torch.Tensor, flags: torch.Tensor):
+    """hpmn_table_mark_rows: flags[id] = 1 for every id of the batch (flags: uint8 [V], all zero before)."""
+    _chk_ids(ids)
+    assert flags.dtype == torch.uint8 and flags.is_cuda and flags.is_contiguous()
+    rc = _lib.load().hpmn_table_mark_rows(ids.data_ptr(), ids.numel(), flags.data_ptr(), flags.numel(), _stream())
+    _lib.check(rc, "hpmn_table_mark_rows")
+
+
+def adam_step_table(param, grad, m, v, flags, pass_: int, lr_t, beta1=0.9, beta2=0.999, eps=1e-8, clip=1.0,
+                    grad_scale=1.0):
+    """hpmn_adam_step_table: the dense table update of ``adam_step`` in two passes (0: rows no id of the batch points
+    at, gradient taken as zero; 1: the marked rows, whose gradient rows and flags it clears).  [V, E] views."""
+    _chk_f32(param, grad, m, v)
+    V, E = param.shape
+    assert grad.shape == param.shape and flags.numel() == V and flags.dtype == torch.uint8
+    rc = _lib.load().hpmn_adam_step_table(param.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(), flags.data_ptr(),
+                                           V, E, int(pass_), lr_t, beta1, beta2, eps, clip, grad_scale, _stream())
+    _lib.check(rc, "hpmn_adam_step_table")
+
+
 def scan_forward_inference(spec: ScanSpec, ids, emb, weights: Sequence[torch.Tensor], workspace=None):
     """hpmn_scan_fwd: whole build_memory forward (no saved states).  weights = [wg0,bg0,wc0,bc0, wg1,...].
     Returns (memory [B,K,H], last [B,D0])."""

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define HPMN_ABI_VERSION 4
+#define HPMN_ABI_VERSION 5
 #define HPMN_MAX_LAYERS 12
 
 enum {
@@ -406,6 +406,20 @@ int hpmn_adam_step(float *param, const float *grad, float *m, float *v, int64_t 
 int hpmn_adam_step_rows(float *param, const float *grad_rows, float *m, float *v, const int64_t *row_ids,
                         int64_t n_rows, int32_t E, float lr_t, float beta1, float beta2, float eps, float clip,
                         float grad_scale, void *stream);
+/* The DENSE table update of hpmn_adam_step (same arithmetic, same result) in two passes, so that most of it leaves
+ * the serial tail of the step: a row no id of the batch points at has an exactly-zero gradient, and its update
+ * (m = b1 m, v = b2 v, p -= lr_t m / (sqrt(v) + eps)) depends on nothing the step computes.
+ *   hpmn_table_mark_rows : flags[id] = 1 for the n_ids ids of the batch (flags: V bytes, all zero before)
+ *   pass 0               : every row with flag == 0, gradient taken as zero (not read) -- any time after the marking,
+ *                          on any stream: the step's gather and scatter only touch marked rows
+ *   pass 1               : every row with flag != 0, behind the scatter; consumes AND CLEARS the row's gradient and
+ *                          its flag, leaving grad [V,E] and flags all-zero for the next step (the caller must not
+ *                          clear the table gradient densely any more, only make sure it starts all-zero)
+ * param / grad / m / v: [V, E], 16-byte aligned; E/4 a power of two. */
+int hpmn_table_mark_rows(const int32_t *ids, int64_t n_ids, uint8_t *flags, int64_t V, void *stream);
+int hpmn_adam_step_table(float *param, float *grad, float *m, float *v, uint8_t *flags, int64_t V, int32_t E,
+                         int32_t pass, float lr_t, float beta1, float beta2, float eps, float clip, float grad_scale,
+                         void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Online incremental memory update -- the serving-time form of build_memory: ONE new event per

@@ -829,3 +829,37 @@ def test_table_rows_beyond_2_gib_give_identical_results(dev, tmp_path):
     np.testing.assert_allclose(big.params["Embedding/emb_mtx"][base:].cpu().numpy(),
                                small.params["Embedding/emb_mtx"].cpu().numpy(), rtol=0, atol=2e-6)
     assert float(big.params["Embedding/emb_mtx"][:base].abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+def test_two_pass_table_adam_equals_the_dense_sweep(dev, tmp_path, monkeypatch):
+    """train_step's dense table update split in two passes (rows the batch does not point at early, on the auxiliary
+    stream; the batch's rows behind the scatter) must leave every buffer exactly where the one-sweep path leaves it:
+    parameters and both moment buffers after several steps, gradient table and row flags all-zero in between, and a
+    stand-alone compute_gradients in the middle must not confuse it."""
+    from hpmn_amd import hpmn as H
+    cfg = O.HpmnConfig(4000, 2, 41, 64, 16, 3, (2, 2, 2), 3, True, 1e-5)
+    p = f32_params(cfg, 71)
+    rng = np.random.default_rng(72)
+    batches = [rand_ids(cfg, 6, 100 + i, ragged=True) for i in range(4)]
+    results = []
+    for two_pass in (True, False):
+        monkeypatch.setattr(H.Hpmn_Basic, "TWO_PASS_TABLE_ADAM", two_pass)
+        monkeypatch.setattr(H.Hpmn_Basic, "TWO_PASS_MIN_NUMEL", 0)
+        m = make_model(cfg, tmp_path, p)
+        masks = (torch.ones(6, 200, device=dev), torch.ones(6, 80, device=dev))
+        for i, (ids, label) in enumerate(batches):
+            ti, tl = torch.as_tensor(ids).to(dev), torch.as_tensor(label).to(dev)
+            if i == 2:
+                m.compute_gradients(ti, tl, keep_prob=1.0)            # leaves a table gradient behind
+            assert m._two_pass_table_adam(ti) == two_pass
+            m.train_step(ti, tl, keep_prob=1.0, masks=masks)
+            if two_pass:
+                n_emb = m.params["Embedding/emb_mtx"].numel()
+                assert float(m.flat_grad[:n_emb].abs().max()) == 0.0
+                assert int(m._row_flags.max()) == 0
+        torch.cuda.synchronize()
+        results.append([b.clone() for b in (m.flat_param, m.flat_m, m.flat_v)])
+    for a, b, name in zip(results[0], results[1], ("param", "m", "v")):
+        # (the scatter's fp32 atomics may order differently run to run: last-bit differences in touched rows)
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-5, atol=1e-7, err_msg=name)
