@@ -1,5 +1,7 @@
 // TF-form Adam with per-element gradient clip, one launch over a flat parameter buffer.
 // HBM-bound: 16 B read (p,g,m,v) + 12 B written (p,m,v) per element, float4-vectorised.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace hpmn {
@@ -116,7 +118,13 @@ int adam_table_launch(float *p, float *g, float *m, float *v, uint8_t *flags, in
     while ((1 << shift) < E / 4) ++shift;
     const long n4 = V * (long)(E / 4);
     long blocks = (n4 + 255) / 256;
-    if (blocks > 256L * 16) blocks = 256L * 16;
+    // Pass 0 has the whole forward and BPTT to finish in and shares the chip with their latency-critical waves: a
+    // THIN grid (HPMN_ADAM_EARLY_WGS workgroups, default 192 -- less than one per CU) trickles through the table instead
+    // of flooding every SIMD and the memory system at once (measured: with 4096 workgroups the layer-0 forward beside
+    // it took 585 instead of 483 us).  Pass 1 is on the serial tail: full width.
+    static const long early = [] { const char *e = getenv("HPMN_ADAM_EARLY_WGS"); return e ? atol(e) : 192L; }();
+    const long cap = pass == 0 ? (early > 0 ? early : 256L * 16) : 256L * 16;
+    if (blocks > cap) blocks = cap;
     if (pass == 0)
         hipLaunchKernelGGL(adam_table_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, st, (float4 *)p, (float4 *)g,
                            (float4 *)m, (float4 *)v, flags, n4, shift, lr_t, b1, b2, eps, clip, gs);
