@@ -174,7 +174,10 @@ def roofline_probes(model, c, batches, step_fn):
     y, hs, gates = ops.gru_scan_fwd(xp, w[0], w[2], D0, mem, spec.periods[0], True, True)
     dmem = torch.randn(B, H, device=ids.device) * 0.01
     t_fwd = time_kernel(lambda: ops.gru_scan_fwd(xp, w[0], w[2], D0, mem, spec.periods[0], True, True), 5, st)
-    t_bwd = time_kernel(lambda: ops.gru_scan_bwd(w[0], w[2], D0, hs, gates, dmem, None, spec.periods[0]), 5, st)
+    # (where the product path lets the scan launch produce the layer's input gradient too, time it the same way)
+    dx_buf = (torch.empty(B, T0, D0, device=ids.device)
+              if H == 64 and ops.scan_bwd_fuses_dx(H, B) and D0 in (16, 32, 64) else None)
+    t_bwd = time_kernel(lambda: ops.gru_scan_bwd(w[0], w[2], D0, hs, gates, dmem, None, spec.periods[0], d_x=dx_buf), 5, st)
     t_proj = time_kernel(lambda: ops.gru_input_proj(None, ids=ids, emb=emb, wg=w[0], bg=w[1], wc=w[2], bc=w[3],
                                                     H=H, T=T0, front_zero=spec.front_zero,
                                                     mask_id0=spec.mask_id0), 5, st)
@@ -212,8 +215,15 @@ def roofline_probes(model, c, batches, step_fn):
     scan_flops = B * T0 * 2 * H * 3 * H           # recurrent half; the input half is accounted to input_proj
     # (H = 64 at the reference batch runs the chain + feeder variant of the reverse scan, gru_scan_bwd_feed.hip)
     mode = os.environ.get("HPMN_BWD_HELPER", "2")
+    dx_in_scan = False
     if H == 64 and B <= 640 and mode != "0":
         dom_kernel = "gru_scan_bwd_feed_kernel<0>" if mode != "1" else "gru_scan_bwd_helper_kernel<false>"
+        if mode != "1" and ops.scan_bwd_fuses_dx(H, B) and D0 in (16, 32, 64):
+            # the launch also produces the layer's input gradient (MFMA epilogue, gru_scan_bwd_feed.hip): its
+            # 2*3H*D0 flops per step belong to the launch's algorithmic work
+            dom_kernel = "gru_scan_bwd_feed_kernel<%d>" % D0
+            dx_in_scan = True
+            scan_flops += B * T0 * 2 * 3 * H * D0
     else:
         dom_kernel = "gru_scan_bwd_kernel<%d>" % H
     dom_t = in_step_ms if in_step_ms is not None else max(t_bwd, t_fwd)
@@ -237,7 +247,8 @@ def roofline_probes(model, c, batches, step_fn):
                       "kernels live on the side stream)" if in_step_ms is not None else "stand-alone launches",
             "ms_per_launch_standalone": t_bwd,
             "algorithmic_flops_per_launch": scan_flops,
-            "note": "fp32 FMA chain, latency-bound serial recurrence; peak = dense fp32 (vector == f32 MFMA)"}
+            "note": "fp32 FMA chain, latency-bound serial recurrence; peak = dense fp32 (vector == f32 MFMA)"
+                    + ("; the launch includes the layer's input gradient (MFMA epilogue) and its flops" if dx_in_scan else "")}
     wgrad_flops = B * T0 * 2 * (D0 + H) * 3 * H
     proj_bytes = n_ids * (4 + 64) + B * T0 * 3 * H * 4
     alg_train = B * bytes_train_per_seq(c)

@@ -420,14 +420,15 @@ int gru_scan_bwd_feed_launch(const HpmnGruBwd &a, hipStream_t st);   // gru_scan
 bool gru_scan_bwd_feed_dx_width(int D);
 // does hpmn_gru_scan_bwd produce d_x itself (HpmnGruBwd.d_x) for this shape?  (and input widths 16, 32, 64)
 bool gru_scan_bwd_fuses_dx(int H, int B) {
-    // HPMN_BWD_DX_WAVE=1 (default 0): built twice, parity-green twice, measured slower twice.  With the e_u helper
-    // kernel above (HPMN_BWD_HELPER=1) a third wave did the product with packed FMAs: 4.12 vs 3.78 ms/step at C3.  With
-    // the chain + feeder kernel (gru_scan_bwd_feed.hip) the third role runs on the matrix cores out of an LDS operand
-    // ring: 3.62 vs 3.36 ms/step, layer-0 launch 0.562 vs 0.458 ms alone (D = 64: 0.641) -- the slowdown equals the
-    // MFMA pipe time (96 / 192 x 32 cycles per 16 steps): a SIMD does not issue its other wave's VALU instructions
-    // while an fp32 MFMA is passing, and every SIMD of the CU hosts a latency-critical wave.
-    static const int dxw = [] { const char *e = getenv("HPMN_BWD_DX_WAVE"); return e ? atoi(e) : 0; }();
-    return H == 64 && B <= 640 && bwd_helper_enabled() && dxw;
+    // HPMN_BWD_DX_WAVE: does the scan launch produce d_x itself?  Default 1 with the chain + feeder kernel, whose waves
+    // compute it on the matrix cores as an EPILOGUE, once their scan is done (gru_scan_bwd_feed.hip).  The same product
+    // CONCURRENT with the scan was built twice and lost twice: with the e_u helper kernel above (HPMN_BWD_HELPER=1; a
+    // third wave, packed FMAs) 4.12 vs 3.78 ms/step at C3; with the chain + feeder kernel as a third MFMA role out of an
+    // LDS operand ring 3.62 vs 3.36 (a SIMD does not issue its other wave's VALU instructions while an fp32 MFMA is
+    // passing, and every SIMD of the CU hosts a latency-critical wave).
+    static const int dxw = [] { const char *e = getenv("HPMN_BWD_DX_WAVE"); return e ? atoi(e) : -1; }();
+    if (dxw >= 0) return H == 64 && B <= 640 && bwd_helper_enabled() && dxw;
+    return H == 64 && B <= 640 && bwd_helper_enabled() >= 2;
 }
 bool gru_scan_bwd_dx_width_ok(int D) { return bwd_helper_enabled() >= 2 ? gru_scan_bwd_feed_dx_width(D) : D <= 64; }
 

@@ -19,16 +19,16 @@
 //   chain (wave 0), per step:   dh += dy; dc_pre, da_u (2 multiplies) -> LDS; d(rh) = dc_pre Wc^T; da_r -> LDS;
 //       e_r = da_r Wg_r^T; dh = dh u + d(rh) r + e_r + e_u.   No global memory access, no address arithmetic, no vmcnt.
 //
-// DXD > 0 adds a third role, the layer's INPUT GRADIENT d_x[t] = d_act[t] [Wg[:D] | Wc[:D]]^T (what hpmn_gru_input_grad
-// computes as a launch of its own -- for layers >= 1 the d_y the next reverse scan waits for, i.e. a kernel on the serial
-// chain, and for layer 0 the first kernel of the step's tail): over a block of 16 steps it is a real [D x 192] x
-// [192 x 16] product, so a wave per sequence issues it on the MATRIX cores (v_mfma_f32_16x16x4_f32, true fp32; 96 / 192
-// MFMAs per block = 6 / 12 instructions per step) out of the operand rows the chain wave writes to LDS anyway -- they now
-// go into a 32-step ring instead of a 2-step buffer -- with the input-block weights stationary as A operands.  Its waves
-// are the 5th and 6th of the workgroup, which the hardware places on the feeders' SIMDs (tools/micro/where.hip).
-// MEASURED SLOWER, default off (gru_scan_bwd.hip, HPMN_BWD_DX_WAVE): the scan slows down by the MFMA pipe time -- a SIMD
-// does not issue the feeder's VALU instructions while the other wave's fp32 MFMA is passing -- which is more than the
-// stand-alone input-gradient launch costs.
+// DXD > 0: the layer's INPUT GRADIENT d_x[t] = d_act[t] [Wg[:D] | Wc[:D]]^T (what hpmn_gru_input_grad computes as a launch
+// of its own -- for layers >= 1 the d_y the next reverse scan waits for, i.e. a kernel on the serial chain, 17-90 us each
+// and ~10 us of launch latency even for the 16-step top layer; for layer 0 the first kernel of the step's tail) comes out
+// of THIS launch, as an epilogue: once a sequence's chain and feeder waves have finished the scan, their SIMDs are idle
+// until the launch ends, so the two waves split the sequence's 16-step blocks between them and issue the product on the
+// matrix cores (v_mfma_f32_16x16x4_f32, true fp32, 96 / 192 per block), reading the d_act rows back from memory (they are
+// the feeder's own stores, ordered by a barrier) 16 bytes per lane straight into operand layout.  Nobody is
+// latency-critical any more at that point -- which is what sank the same product as a CONCURRENT third role (waves on the
+// feeders' SIMDs, operands from a 32-step LDS ring): 3.62 vs 3.36 ms/step, because a SIMD does not issue its other wave's
+// VALU instructions while an fp32 MFMA is passing.
 //
 // Hand-offs are LDS progress counters (common.h: data, lgkmcnt(0), counter; cached copies, re-read only when the
 // cached value says "wait"); no barrier in the loop.  Buffers are double-buffered by step parity: the feeder reads
@@ -42,8 +42,7 @@ namespace hpmn {
 
 constexpr int FR_STEPS = 8;     // coefficient ring depth in steps (4 chunks of 2)
 constexpr int FR_AHEAD = 3;     // chunks the feeder parks ahead of the chunk the chain wave is on
-constexpr int DROW = 196;       // floats per operand row [da_r | da_u | dc_pre] + 4 pad: rows 784 B apart, so that the 16
-                                // lanes of a quarter-wave reading 16 B of 16 different rows hit 64 different banks
+constexpr int DROW = 192;       // floats per operand row [da_r | da_u | dc_pre]
 constexpr int DXB = 16;         // steps per input-gradient block (= MFMA N)
 
 typedef float f4m __attribute__((ext_vector_type(4)));
@@ -52,12 +51,12 @@ typedef float f4m __attribute__((ext_vector_type(4)));
 // but starts the next workgroup of the CU on the SIMD the previous one ended on (tools/micro/where.hip: with 2-wave
 // workgroups every CU had the chain wave of one sequence and the feeder of the other on ONE SIMD and a SIMD idle;
 // 4-wave workgroups land on four distinct SIMDs, the 5th and 6th wave of a 6-wave workgroup on the SIMDs of the 1st
-// and 2nd).  DXD == 0: waves 0,1 chain, 2,3 feeder.  DXD > 0: waves 0,1 feeder, 2,3 chain, 4,5 input gradient.
+// and 2nd).  Waves 0,1: chain waves of sequences 2 blockIdx.x + 0,1; waves 2,3: their feeders.
 template <int DXD>
-__global__ __launch_bounds__(DXD ? 384 : 256, 1) void gru_scan_bwd_feed_kernel(const HpmnGruBwd a) {
+__global__ __launch_bounds__(256, 1) void gru_scan_bwd_feed_kernel(const HpmnGruBwd a) {
     constexpr int H = 64;
     constexpr bool DX = DXD > 0;
-    constexpr int NSLOT = DX ? 2 * DXB : 2;                                // operand rows kept in LDS
+    constexpr int NSLOT = 2;                                               // operand rows kept in LDS (step parity)
     __shared__ __attribute__((aligned(16))) v4f ringA_[2][FR_STEPS][H];    // dy, k1, k2, k3
     __shared__ __attribute__((aligned(16))) f2 ringB_[2][FR_STEPS][H];     // r, u
     __shared__ __attribute__((aligned(16))) float dact_[2][NSLOT][DROW];   // da_r | da_u | dc_pre of iteration k in row k % NSLOT
@@ -67,7 +66,7 @@ __global__ __launch_bounds__(DXD ? 384 : 256, 1) void gru_scan_bwd_feed_kernel(c
     const int lane = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;
     const int seq = w & 1;
-    const int role = DX ? (w < 2 ? 1 : (w < 4 ? 0 : 2)) : (w >> 1);       // 0 chain, 1 feeder, 2 input gradient
+    const int role = w >> 1;                                              // 0 chain, 1 feeder
     const int l = lane;
     const int T = a.T, D = a.D;
     const long b = 2 * (long)blockIdx.x + seq;
@@ -77,70 +76,13 @@ __global__ __launch_bounds__(DXD ? 384 : 256, 1) void gru_scan_bwd_feed_kernel(c
     f2 (&ringB)[FR_STEPS][H] = ringB_[seq];
     float (&dact)[NSLOT][DROW] = dact_[seq];
     float (&eU)[2][H] = eU_[seq];
-    int &dau_pub = ctr_[seq][0], &eu_pub = ctr_[seq][1], &fed = ctr_[seq][2], &dx_done = ctr_[seq][3];
+    int &dau_pub = ctr_[seq][0], &eu_pub = ctr_[seq][1], &fed = ctr_[seq][2];
     const int t_lo0 = a.t_begin;
     const int t_hi = a.t_end > 0 ? a.t_end : T;
     const int nsteps = t_hi - t_lo0;
     const int nfull = nsteps >> 1;               // 2-step chunks; an odd last step is peeled
-    if (lane == 0 && role == 0) { dau_pub = 0; eu_pub = 0; fed = 0; dx_done = 0; }
+    if (lane == 0 && role == 0) { dau_pub = 0; eu_pub = 0; fed = 0; }
     __syncthreads();
-
-    if constexpr (DX) {
-        if (role == 2) {
-            // ============================================================== input gradient, 16 steps per block
-            const int j = lane & 15, g = lane >> 4;
-            constexpr int NCT = DXD / 16;
-            // A operands: W[col = 16 ct + j][f = 16 kq + 4 g + c], W = [wg[0:D] | wc[0:D]] (input rows x 3H gate columns)
-            float wx[NCT][12][4];
-#pragma unroll
-            for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-                for (int kq = 0; kq < 12; ++kq) {
-                    const long col = 16 * ct + j;
-                    const v4f v = kq < 8 ? *reinterpret_cast<const v4f *>(a.wg + col * 2 * H + 16 * kq + 4 * g)
-                                         : *reinterpret_cast<const v4f *>(a.wc + col * H + 16 * (kq - 8) + 4 * g);
-                    wx[ct][kq][0] = v.x; wx[ct][kq][1] = v.y; wx[ct][kq][2] = v.z; wx[ct][kq][3] = v.w;
-                }
-#pragma unroll
-            for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-                for (int kq = 0; kq < 12; ++kq)
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) settle(wx[ct][kq][c]);
-            const int nblk = (nsteps + DXB - 1) / DXB;
-            int seen = 0;
-            for (int q = 0; q < nblk; ++q) {
-                // rows of iterations 16 q .. are complete once the chain wave has STARTED iteration 16 q + 16 (it
-                // reports nsteps + 1 when the last one is done)
-                const int last = DXB * (q + 1) < nsteps ? DXB * (q + 1) : nsteps;
-                while (seen <= last) {
-                    seen = lds_counter_peek(&dau_pub);
-                    if (seen <= last) __builtin_amdgcn_s_sleep(8);
-                }
-                asm volatile("" ::: "memory");
-                const int k = DXB * q + j;
-                const float *row = &dact[k & (NSLOT - 1)][4 * g];
-                v4f v[12];
-#pragma unroll
-                for (int kq = 0; kq < 12; ++kq) v[kq] = *reinterpret_cast<const v4f *>(row + 16 * kq);
-#pragma unroll
-                for (int kq = 0; kq < 12; ++kq) asm volatile("" : "+v"(v[kq]));
-                lds_counter_set(&dx_done, q + 1);                      // (the reads above have landed)
-                float *dst = a.d_x + (b * (long)T + (t_hi - 1 - k)) * DXD + 4 * g;
-#pragma unroll
-                for (int ct = 0; ct < NCT; ++ct) {
-                    f4m acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int kq = 0; kq < 12; ++kq)
-#pragma unroll
-                        for (int c = 0; c < 4; ++c)
-                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wx[ct][kq][c], v[kq][c], acc, 0, 0, 0);
-                    if (k < nsteps) *reinterpret_cast<f4m *>(dst + 16 * ct) = acc;
-                }
-            }
-            return;
-        }
-    }
 
     if (role == 1) {
         // ================================================================== feeder
@@ -209,8 +151,8 @@ __global__ __launch_bounds__(DXD ? 384 : 256, 1) void gru_scan_bwd_feed_kernel(c
         auto iter = [&](int k, int p, bool store_prev) {
             while (seen <= k) seen = lds_counter_peek(&dau_pub);
             asm volatile("" ::: "memory");
-            const float *row = dact[DX ? (k & (NSLOT - 1)) : p];
-            const float *old = dact[DX ? ((k - 1) & (NSLOT - 1)) : (p ^ 1)];
+            const float *row = dact[p];
+            const float *old = dact[p ^ 1];
             const float euv = split_matvec<2>(row + H, wuS, lane);
             const float o_dar = old[l], o_dau = old[H + l], o_dcp = old[2 * H + l];
             eU[p][l] = euv;
@@ -261,9 +203,7 @@ __global__ __launch_bounds__(DXD ? 384 : 256, 1) void gru_scan_bwd_feed_kernel(c
             dap[H] = row[H + l];
             dap[2 * H] = row[2 * H + l];
         }
-        return;
-    }
-
+    } else {
     // ====================================================================== chain wave
     __builtin_amdgcn_s_setprio(3);
     f2 wcS[2][16], wrS[2][16];
@@ -273,7 +213,7 @@ __global__ __launch_bounds__(DXD ? 384 : 256, 1) void gru_scan_bwd_feed_kernel(c
     float dh = (t_hi == T) ? a.d_h_last[b * a.d_h_last_stride + l] : a.dh_carry[b * H + l];
     settle(dh);
 
-    int fed_seen = 0, eu_seen = 0, dxd_seen = 0;
+    int fed_seen = 0, eu_seen = 0;
     auto wait_fed = [&](int need) {
         while (fed_seen < need) {
             fed_seen = lds_counter_peek(&fed);
@@ -286,7 +226,7 @@ __global__ __launch_bounds__(DXD ? 384 : 256, 1) void gru_scan_bwd_feed_kernel(c
     f2 cb = ringB[0][l];
 
     auto step = [&](int k, int p) {
-        float *row = dact[DX ? (k & (NSLOT - 1)) : p];
+        float *row = dact[p];
         const float dhin = dh + ca.x;
         const float dcp = dhin * ca.y;
         const float dau = dhin * ca.z;
@@ -316,33 +256,61 @@ __global__ __launch_bounds__(DXD ? 384 : 256, 1) void gru_scan_bwd_feed_kernel(c
     };
 
     for (int q = 0; q < nfull; ++q) {
-        if constexpr (DX) {
-            // entering a new 16-step block: its rows were last used two blocks ago, which the input-gradient wave
-            // must have read (it does so while this wave is on the block in between)
-            if (((2 * q) & (DXB - 1)) == 0) {
-                const int need = (2 * q) / DXB - 1;
-                while (dxd_seen < need) {
-                    dxd_seen = lds_counter_peek(&dx_done);
-                    if (dxd_seen < need) __builtin_amdgcn_s_sleep(1);
-                }
-                asm volatile("" ::: "memory");
-            }
-        }
         step(2 * q, 0);
         step(2 * q + 1, 1);
     }
-    if (nsteps & 1) {
-        if constexpr (DX) {
-            if (((nsteps - 1) & (DXB - 1)) == 0) {
-                const int need = (nsteps - 1) / DXB - 1;
-                while (dxd_seen < need) dxd_seen = lds_counter_peek(&dx_done);
-                asm volatile("" ::: "memory");
-            }
-        }
-        step(nsteps - 1, 0);
-    }
+    if (nsteps & 1) step(nsteps - 1, 0);
     lds_counter_set(&dau_pub, nsteps + 1);                           // da_r of the last step is in LDS
     if (t_lo0 > 0) a.dh_carry[b * H + l] = dh;
+    }
+
+    if constexpr (DX) {
+        // ================================================================== epilogue: the input gradient of this launch's steps
+        __builtin_amdgcn_s_setprio(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the feeders' d_act rows have reached memory
+        __syncthreads();                                              // (waves of a sequence that does not exist left before the first barrier)
+        const int j = lane & 15, g = lane >> 4;
+        constexpr int NCT = DXD / 16;
+        // A operands: W[col = 16 ct + j][f = 16 kq + 4 g + c], W = [wg[0:D] | wc[0:D]] (input rows x 3H gate columns)
+        float wx[NCT][12][4];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int kq = 0; kq < 12; ++kq) {
+                const long col = 16 * ct + j;
+                const v4f v = kq < 8 ? *reinterpret_cast<const v4f *>(a.wg + col * 2 * H + 16 * kq + 4 * g)
+                                     : *reinterpret_cast<const v4f *>(a.wc + col * H + 16 * (kq - 8) + 4 * g);
+                wx[ct][kq][0] = v.x; wx[ct][kq][1] = v.y; wx[ct][kq][2] = v.z; wx[ct][kq][3] = v.w;
+            }
+        // blocks of 16 steps [t_lo0 + 16 q, ...), q = role, role + 2, ...: B operand of lane (j, g) = d_act[t][16 kq + 4 g ..+3]
+        const int nblk = (nsteps + DXB - 1) / DXB;
+        const float *src = a.d_act + (b * (long)T + t_lo0) * 3 * H + 4 * g;
+        float *dst = a.d_x + (b * (long)T + t_lo0) * DXD + 4 * g;
+        auto fetch = [&](int q, v4f (&v)[12]) {
+            int tr = DXB * q + j;
+            tr = tr < nsteps ? tr : nsteps - 1;                       // (clamped: loaded, computed, not stored)
+#pragma unroll
+            for (int kq = 0; kq < 12; ++kq) v[kq] = *reinterpret_cast<const v4f *>(src + (long)tr * 3 * H + 16 * kq);
+        };
+        v4f cur[12], nxt[12];
+        if (role < nblk) fetch(role, cur);
+        for (int q = role; q < nblk; q += 2) {
+            if (q + 2 < nblk) fetch(q + 2, nxt);
+            const int tr = DXB * q + j;
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                f4m acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kq = 0; kq < 12; ++kq)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wx[ct][kq][c], cur[kq][c], acc, 0, 0, 0);
+                if (tr < nsteps) *reinterpret_cast<f4m *>(dst + (long)tr * DXD + 16 * ct) = acc;
+            }
+#pragma unroll
+            for (int kq = 0; kq < 12; ++kq) cur[kq] = nxt[kq];
+        }
+    }
 }
 
 bool gru_scan_bwd_feed_dx_width(int D) { return D == 16 || D == 32 || D == 64; }
@@ -350,9 +318,9 @@ bool gru_scan_bwd_feed_dx_width(int D) { return D == 16 || D == 32 || D == 64; }
 int gru_scan_bwd_feed_launch(const HpmnGruBwd &a, hipStream_t st) {
     const dim3 grid((a.B + 1) / 2);
     if (a.d_x == nullptr) hipLaunchKernelGGL(gru_scan_bwd_feed_kernel<0>, grid, dim3(256), 0, st, a);
-    else if (a.D == 16) hipLaunchKernelGGL(gru_scan_bwd_feed_kernel<16>, grid, dim3(384), 0, st, a);
-    else if (a.D == 32) hipLaunchKernelGGL(gru_scan_bwd_feed_kernel<32>, grid, dim3(384), 0, st, a);
-    else if (a.D == 64) hipLaunchKernelGGL(gru_scan_bwd_feed_kernel<64>, grid, dim3(384), 0, st, a);
+    else if (a.D == 16) hipLaunchKernelGGL(gru_scan_bwd_feed_kernel<16>, grid, dim3(256), 0, st, a);
+    else if (a.D == 32) hipLaunchKernelGGL(gru_scan_bwd_feed_kernel<32>, grid, dim3(256), 0, st, a);
+    else if (a.D == 64) hipLaunchKernelGGL(gru_scan_bwd_feed_kernel<64>, grid, dim3(256), 0, st, a);
     else return HPMN_EUNSUPPORTED;
     return check_launch();
 }
