@@ -291,8 +291,10 @@ int hpmn_scan_bwd(HpmnTrainCtx *ctx, const HpmnScanDesc *d, const int32_t *ids, 
         // the weight gradient of this layer: an MFMA reduction over d_act, off the serial chain, on the helper stream.
         // Every fork (event record on the launch stream) costs the chain ~6 us of queue processing, so the short top
         // layers (<= 128 steps: 30-80 us of weight-gradient work each) share the fork of the layer below them.
+        // (Only where a long chain is still ahead to hide them under: with short sequences -- Amazon: 100 steps -- holding
+        // them back just moves them into the tail.)
         held[nheld++] = w;
-        if (L.T[i] > 128 || i == 0 || nheld == 4) {
+        if (L.T[i] > 128 || L.T[0] < 512 || i == 0 || nheld == 4) {
             HIPCHK(hipEventRecord(c->fork, st));
             HIPCHK(hipStreamWaitEvent(c->side, c->fork, 0));
             for (int h = 0; h < nheld; ++h) {
