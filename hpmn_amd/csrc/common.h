@@ -55,7 +55,9 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 // ISA of the fused forward kernel: a full store drain every ~8 steps of the scan wave).  These two go through an
 // address_space(3) pointer: plain ds_read_b32 / ds_write_b32, lgkmcnt only.
 typedef __attribute__((address_space(3))) volatile int lds_int;
-__device__ __forceinline__ int lds_counter_peek(int *p) { return *(lds_int *)p; }
+// (every lane reads the same word: handing the value back through v_readfirstlane makes it -- and every comparison and
+//  loop on it -- wave-uniform, i.e. s_cmp + s_cbranch instead of v_cmp + exec-mask bookkeeping around the poll loops)
+__device__ __forceinline__ int lds_counter_peek(int *p) { return __builtin_amdgcn_readfirstlane(*(lds_int *)p); }
 __device__ __forceinline__ void lds_counter_set(int *p, int v) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the data written before must have landed in LDS
     *(lds_int *)p = v;

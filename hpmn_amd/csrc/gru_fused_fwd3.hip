@@ -41,6 +41,9 @@ constexpr int MH = 64;        // hidden size of this kernel
 constexpr int MB = 16;        // steps per projection block (= MFMA N)
 constexpr int MRING = 32;     // ring slots: the block the chain wave is on + the block being projected
 constexpr int MNT = 12;       // 16-column tiles of [r | u | c]
+constexpr int MSL = 4;        // slots of the state / gate hand-off buffers (h_{t-1} in slot t % MSL): the chain wave may run
+                              // MSL - 2 steps ahead of the producer's reads, so its check of the producer's counter is
+                              // almost always answered by the cached copy
 
 typedef float f4v __attribute__((ext_vector_type(4)));
 
@@ -50,10 +53,10 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_mfma_kernel(const HpmnGruFused
     constexpr int H = MH;
     constexpr int NJ = D / 16;                                              // 16-byte pieces of an input row per lane
     __shared__ __attribute__((aligned(16))) float ring_[2][MRING][3 * H];   // xp (r | u | c)
-    __shared__ __attribute__((aligned(16))) float hb_[2][2][H];            // h_{t-1} lives in hb[t & 1]
+    __shared__ __attribute__((aligned(16))) float hb_[2][MSL][H];          // h_{t-1} lives in hb[t % MSL]
     __shared__ __attribute__((aligned(16))) float rhb_[2][H];
     __shared__ float ubuf_[2][2][H];
-    __shared__ __attribute__((aligned(16))) v4f rcb_[2][2][H];             // r, u, c of step t in rcb[t & 1]
+    __shared__ __attribute__((aligned(16))) v4f rcb_[2][MSL][H];           // r, u, c of step t in rcb[t % MSL]
     __shared__ int ctr_[2][4];
 
     const int lane = threadIdx.x & 63;
@@ -63,10 +66,10 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_mfma_kernel(const HpmnGruFused
     const long b = 2 * (long)blockIdx.x + seq;
     if (b >= a.B) return;        // odd batch (before the barrier: ended waves do not take part in it)
     float (&ring)[MRING][3 * H] = ring_[seq];
-    float (&hb)[2][H] = hb_[seq];
+    float (&hb)[MSL][H] = hb_[seq];
     float (&rhb)[H] = rhb_[seq];
     float (&ubuf)[2][H] = ubuf_[seq];
-    v4f (&rcb)[2][H] = rcb_[seq];
+    v4f (&rcb)[MSL][H] = rcb_[seq];
     int &produced = ctr_[seq][0], &h_pub = ctr_[seq][1], &u_pub = ctr_[seq][2];
     if (role == 0) {
         hb[0][l] = 0.f;
@@ -190,7 +193,7 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_mfma_kernel(const HpmnGruFused
                 h_seen = lds_counter_peek(&h_pub);
             }
             asm volatile("" ::: "memory");
-            const int p = t & 1;
+            const int p = t & (MSL - 1), pm = (t - 1) & (MSL - 1);
             f4v acc = {0.f, 0.f, 0.f, 0.f};
             if constexpr (TILE >= 0) {
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wBias[TILE], one, acc, 0, 0, 0);
@@ -202,21 +205,21 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_mfma_kernel(const HpmnGruFused
             }
             float u_now = 0.f;
             // everything this iteration reads of the chain wave's buffers is read BEFORE the counter that lets the
-            // chain wave move on (LDS operations of a wave complete in order): hb[p] and rcb[p^1] are rewritten at
-            // the end of step t+1
+            // chain wave move on (LDS operations of a wave complete in order): hb[t % MSL] and rcb[(t-1) % MSL] are
+            // rewritten MSL - 1 steps later
             float hprev;
             v4f rc = {0.f, 0.f, 0.f, 0.f};
             if constexpr (UPROD) {
                 const float xu = ring[t & (MRING - 1)][H + l];
                 const float su = split_matvec<2>(&hb[p][0], whu, lane);
                 hprev = hb[p][l];
-                if constexpr (TRAIN) rc = rcb[p ^ 1][l];
+                if constexpr (TRAIN) rc = rcb[pm][l];
                 u_now = sigmoid_scaled(xu + su);
-                ubuf[p][l] = u_now;
+                ubuf[t & 1][l] = u_now;
                 lds_counter_set(&u_pub, t + 1);
             } else {
                 hprev = hb[p][l];
-                if constexpr (TRAIN) rc = rcb[p ^ 1][l];
+                if constexpr (TRAIN) rc = rcb[pm][l];
                 asm volatile("" : "+v"(hprev), "+v"(rc));          // (the reads have landed)
                 lds_counter_set(&u_pub, t + 1);                    // here: "iteration t has read its inputs"
             }
@@ -268,10 +271,9 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_mfma_kernel(const HpmnGruFused
         while (h_seen < T) h_seen = lds_counter_peek(&h_pub);
         asm volatile("" ::: "memory");
         {
-            const int p = T & 1;
-            const float hlast = hb[p][l];
+            const float hlast = hb[T & (MSL - 1)][l];
             if constexpr (TRAIN) {
-                const v4f rc = rcb[p ^ 1][l];
+                const v4f rc = rcb[(T - 1) & (MSL - 1)][l];
                 *hsp = hlast;
                 gp[0] = rc.x;
                 gp[H] = UPROD ? u_prev : rc.y;
@@ -318,28 +320,35 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_mfma_kernel(const HpmnGruFused
         xr = nx[l];
         if constexpr (!UPROD) xu = nx[H + l];
         xcand = nx[2 * H + l];
-        // UPROD: u_t from the producer.  Otherwise the same counter says "the producer has read h_{t-2}, r,u,c of
-        // step t-2" (= its iteration t-1), the buffers this step is about to overwrite
+        // UPROD: u_t from the producer.  Otherwise the same counter says "the producer's iteration i has read its
+        // inputs": the slots this step is about to overwrite (h_{t-4}, gates of step t-4) were read by iteration t-3.
+        // With MSL = 4 slots the cached copy of the counter answers that almost every time -- with 2 slots it was by
+        // construction one step too old, and the forced re-read (an LDS round trip on the chain) cost 50 ns per step.
         if constexpr (UPROD) {
             while (u_seen <= t) u_seen = lds_counter_peek(&u_pub);
             asm volatile("" ::: "memory");
-            u = ubuf[p][l];
+            u = ubuf[p & 1][l];
         } else {
-            while (u_seen < t) u_seen = lds_counter_peek(&u_pub);
+            while (u_seen < t - (MSL - 2)) u_seen = lds_counter_peek(&u_pub);
             asm volatile("" ::: "memory");
         }
         h = fmaf(u, h - cc, cc);
-        hb[p ^ 1][lane] = h;
+        hb[(p + 1) & (MSL - 1)][lane] = h;
         if constexpr (TRAIN) rcb[p][l] = v4f{r, u, cc, 0.f};
         lds_counter_set(&h_pub, t + 1);
         wave_sync();
     };
-    const int nfull = T >> 1;
+    static_assert(MSL == 4, "the loop below is unrolled by the slot count");
+    const int nfull = T >> 2;
     for (int q = 0; q < nfull; ++q) {
-        step(2 * q, 0);
-        step(2 * q + 1, 1);
+        step(4 * q, 0);
+        step(4 * q + 1, 1);
+        step(4 * q + 2, 2);
+        step(4 * q + 3, 3);
     }
-    if (T & 1) step(T - 1, 0);
+    if ((T & 3) > 0) step(4 * nfull, 0);
+    if ((T & 3) > 1) step(4 * nfull + 1, 1);
+    if ((T & 3) > 2) step(4 * nfull + 2, 2);
 }
 
 template <int D, bool UPROD>
