@@ -58,9 +58,18 @@ typedef __attribute__((address_space(3))) volatile int lds_int;
 // (every lane reads the same word: handing the value back through v_readfirstlane makes it -- and every comparison and
 //  loop on it -- wave-uniform, i.e. s_cmp + s_cbranch instead of v_cmp + exec-mask bookkeeping around the poll loops)
 __device__ __forceinline__ int lds_counter_peek(int *p) { return __builtin_amdgcn_readfirstlane(*(lds_int *)p); }
+// Publishing: data first, then the counter.  The LDS unit executes the DS instructions of one wave in the order they
+// were issued, so the counter write cannot overtake the data writes in front of it and no s_waitcnt is needed in
+// between (with one, every publish stalled its wave for an LDS write latency -- on the serial chain, once per step);
+// the compiler barrier keeps the program order.  HPMN_LDS_PUBLISH_WAIT restores the wait (tools, bisecting).
 __device__ __forceinline__ void lds_counter_set(int *p, int v) {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the data written before must have landed in LDS
+#ifdef HPMN_LDS_PUBLISH_WAIT
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
+    asm volatile("" ::: "memory");
+#endif
     *(lds_int *)p = v;
+    asm volatile("" ::: "memory");
 }
 
 // "Use" a whole group of just-loaded LDS values in one place: the compiler's waitcnt pass then emits ONE

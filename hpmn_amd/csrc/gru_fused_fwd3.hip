@@ -315,7 +315,15 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_mfma_kernel(const HpmnGruFused
         rhb[lane] = r * h;
         wave_sync();
         const float cc = tanh_scaled(xcand + split_matvec<2>(&rhb[0], whc, lane));
-        // next step's projected input (the producer is MB steps ahead; past the end: a stale slot, unused)
+        // next step's projected input (the producer is MB steps ahead; past the end: a stale slot, unused).  Crossing
+        // into the next 16-step block, its last tile must be in the ring: the producer writes tile i at the END of
+        // iteration 16 q + i, i < 12, so "iteration 16 q + 12 has started" (u_pub >= 16 q + 13 = t - 2) is the condition
+        // -- the end-of-step check below only guarantees one iteration less.  (Found by running the forward beside an
+        // unrelated 2.5 GB fill, tools/dbg_fwd_race.py: without this wait 5 of 20 such runs read a stale last tile.)
+        if (((t + 1) & (MB - 1)) == 0) {
+            while (u_seen < t - 2) u_seen = lds_counter_peek(&u_pub);
+            asm volatile("" ::: "memory");
+        }
         const float *nx = ring[(t + 1) & (MRING - 1)];
         xr = nx[l];
         if constexpr (!UPROD) xu = nx[H + l];

@@ -863,3 +863,41 @@ def test_two_pass_table_adam_equals_the_dense_sweep(dev, tmp_path, monkeypatch):
     for a, b, name in zip(results[0], results[1], ("param", "m", "v")):
         # (the scatter's fp32 atomics may order differently run to run: last-bit differences in touched rows)
         np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-5, atol=1e-7, err_msg=name)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [6, 75])
+def test_scans_give_the_same_result_beside_an_unrelated_kernel(dev, tmp_path, B):
+    """The two-wave scan kernels hand data between waves through LDS behind progress counters; a missing condition
+    there only shows when one wave is slowed down.  A 2.5 GB fill on another stream beside the step does that (it is
+    how a stale projection tile in the fused forward was found): forward outputs, saved states and every gradient must
+    not depend on it."""
+    from hpmn_amd import ops
+    cfg = cfg_industry(H=64, K=3, T=41, V=600)
+    p = f32_params(cfg, 151)
+    ids, label = rand_ids(cfg, B, 152)
+    m = make_model(cfg, tmp_path, p)
+    ti, tl = torch.as_tensor(ids).to(dev), torch.as_tensor(label).to(dev)
+    junk = torch.empty(640_000_000, device=dev)
+    side = torch.cuda.Stream()
+
+    def run(concurrent):
+        if concurrent:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                junk.zero_()
+        memory, last, saved = ops.scan_forward_train(m.spec, ti, m.params["Embedding/emb_mtx"], m._gru_weights())
+        states = [s[1].clone() for s in saved] + [s[2].clone() for s in saved]
+        out, _ = m.compute_gradients(ti, tl, keep_prob=1.0)
+        torch.cuda.synchronize()
+        return [memory.clone(), last.clone()] + states, {k: v.clone() for k, v in m.grads.items()}
+
+    ref_f, ref_g = run(False)
+    for it in range(24):
+        f, g = run(it % 3 != 2)
+        for i, (a, b) in enumerate(zip(ref_f, f)):
+            assert torch.equal(a, b), "forward tensor %d differs in run %d" % (i, it)
+        for k in ref_g:
+            # (the scatter's fp32 atomics may order differently run to run)
+            tol = 1e-6 if k == "Embedding/emb_mtx" else 0.0
+            assert float((ref_g[k] - g[k]).abs().max()) <= tol, "%s differs in run %d" % (k, it)
