@@ -122,8 +122,15 @@ int adam_table_launch(float *p, float *g, float *m, float *v, uint8_t *flags, in
     // THIN grid (HPMN_ADAM_EARLY_WGS workgroups, default 192 -- less than one per CU) trickles through the table instead
     // of flooding every SIMD and the memory system at once (measured: with 4096 workgroups the layer-0 forward beside
     // it took 585 instead of 483 us).  Pass 1 is on the serial tail: full width.
+    // The thin grid moves ~2.2 TB/s: right for the 1.2 GB of the reference tables (0.54 ms, the forward takes 1 ms),
+    // hopeless for a table sized to HBM (256 M rows = 98 GB of optimiser traffic: 45 ms against a 10 ms chain --
+    // measured 43 vs 33 ms/step) -- so it widens in proportion, up to the full width.
     static const long early = [] { const char *e = getenv("HPMN_ADAM_EARLY_WGS"); return e ? atol(e) : 192L; }();
-    const long cap = pass == 0 ? (early > 0 ? early : 256L * 16) : 256L * 16;
+    long thin = early > 0 ? early : 256L * 16;
+    const double gb = (double)V * E * 24.0 / 1.2e9;
+    if (gb > 1.0) thin = (long)(thin * gb);
+    if (thin > 256L * 16) thin = 256L * 16;
+    const long cap = pass == 0 ? thin : 256L * 16;
     if (blocks > cap) blocks = cap;
     if (pass == 0)
         hipLaunchKernelGGL(adam_table_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, st, (float4 *)p, (float4 *)g,
