@@ -471,6 +471,34 @@ def test_adam_kernel_matches_tf_form(dev):
         np.testing.assert_allclose(tv.cpu().numpy(), st.v["w"], atol=1e-6)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("E", [4, 16, 32])
+def test_table_adam_in_two_passes_is_bit_identical_to_the_dense_kernel(dev, E):
+    """hpmn_table_mark_rows + hpmn_adam_step_table (pass 0: unmarked rows with a zero gradient, pass 1: marked rows)
+    against hpmn_adam_step over the same buffers: identical bits in p, m, v; gradient rows and flags cleared."""
+    from hpmn_amd import ops
+    g = torch.Generator(device=dev).manual_seed(5)
+    V = 5003
+    p = torch.randn(V, E, device=dev, generator=g)
+    m = torch.randn(V, E, device=dev, generator=g) * 0.1
+    v = torch.rand(V, E, device=dev, generator=g) * 0.01
+    ids = torch.randint(0, V, (7, 33, 3), device=dev, dtype=torch.int32, generator=g)
+    grad = torch.zeros(V, E, device=dev)
+    rows = ids.reshape(-1).long().unique()
+    grad[rows] = torch.randn(rows.numel(), E, device=dev, generator=g) * 2.0          # (exercises the clip)
+    ref = [t.clone() for t in (p, m, v)]
+    ops.adam_step(ref[0].view(-1), grad.view(-1), ref[1].view(-1), ref[2].view(-1), 0.0021)
+    flags = torch.zeros(V, device=dev, dtype=torch.uint8)
+    ops.table_mark_rows(ids, flags)
+    assert int(flags.sum()) == rows.numel()
+    ops.adam_step_table(p, grad, m, v, flags, 0, 0.0021)
+    assert int(flags.sum()) == rows.numel() and float(grad.abs().sum()) > 0          # pass 0 consumes nothing
+    ops.adam_step_table(p, grad, m, v, flags, 1, 0.0021)
+    for a, b in zip((p, m, v), ref):
+        assert torch.equal(a, b)
+    assert float(grad.abs().max()) == 0.0 and int(flags.max()) == 0
+
+
 @pytest.mark.parametrize("industry", [False, True])
 def test_three_training_steps_track_the_restatement(dev, tmp_path, industry):
     """sess.run(train_step) x3 with keep_prob 1 (dropout RNG cannot be matched): parameters after
