@@ -10,7 +10,7 @@ import os
 from typing import Optional
 
 HPMN_MAX_LAYERS = 12
-HPMN_ABI_VERSION = 5
+HPMN_ABI_VERSION = 6
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libhpmn_hip.so")
@@ -169,6 +169,7 @@ SIGNATURES = {
     "hpmn_read_fwd": (C.c_int, [C.POINTER(HpmnReadDesc)] + [C.c_void_p] * 8),
     "hpmn_read_fwd_bwd": (C.c_int, [C.POINTER(HpmnReadDesc)] + [C.c_void_p] * 6 +
                           [C.c_float, C.c_float, C.c_float] + [C.c_void_p] * 7),
+    "hpmn_read_param_grads": (C.c_int, [C.POINTER(HpmnReadDesc), C.c_void_p, C.c_void_p, C.c_void_p]),
     "hpmn_embed_grad_scatter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                           C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_void_p]),
     "hpmn_gru_fused_fwd_supported": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),

@@ -27,6 +27,7 @@ int read_fwd_bwd_launch(const HpmnReadDesc &d, const float *P, const float *memo
                         const int32_t *label, const float *mask1, const float *mask2, float keep_prob,
                         float inv_global_batch, float memory_reg, float *pred, float *loss_out, float *d_memory,
                         float *d_last, float *d_params, float *workspace, hipStream_t st);
+int read_reduce_launch(const HpmnReadDesc &d, float *d_params, const float *workspace, hipStream_t st);
 int embed_gather_launch(const int32_t *ids, int64_t ids_stride, const float *emb, float *out, int64_t N,
                         int32_t F, int32_t E, int32_t mask_id0, hipStream_t st);
 int embed_grad_scatter_launch(const int32_t *ids, const float *d_x, float *d_emb, int32_t B, int32_t T,
@@ -282,13 +283,20 @@ int hpmn_read_fwd_bwd(const HpmnReadDesc *d, const float *params, const float *m
     if (!d) return HPMN_EINVAL;
     if (d->B < 0 || !(keep_prob > 0.f)) return HPMN_EINVAL;
     if (d->B == 0) return HPMN_OK;
-    if (!params || !memory || !last || !label || !pred || !loss_out || !d_memory || !d_last || !d_params ||
-        !workspace)
-        return HPMN_EINVAL;
+    if (!params || !memory || !last || !label || !pred || !loss_out || !d_memory || !d_last || !workspace)
+        return HPMN_EINVAL;                       // (d_params may be NULL: see hpmn_read_param_grads)
     if ((mask1 == nullptr) != (mask2 == nullptr)) return HPMN_EINVAL;
     return read_fwd_bwd_launch(*d, params, memory, last, label, mask1, mask2, keep_prob, inv_global_batch,
                                memory_reg, pred, loss_out, d_memory, d_last, d_params, workspace,
                                (hipStream_t)stream);
+}
+
+int hpmn_read_param_grads(const HpmnReadDesc *d, float *d_params, const float *workspace, void *stream) {
+    drop_stale_hip_error();
+    if (!d || d->B < 0) return HPMN_EINVAL;
+    if (d->B == 0) return HPMN_OK;
+    if (!d_params || !workspace) return HPMN_EINVAL;
+    return read_reduce_launch(*d, d_params, workspace, (hipStream_t)stream);
 }
 
 int hpmn_embed_grad_scatter(const int32_t *ids, const float *d_x, float *d_emb, int32_t B, int32_t T,

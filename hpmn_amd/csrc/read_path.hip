@@ -826,7 +826,16 @@ int read_fwd_bwd_launch(const HpmnReadDesc &d, const float *P, const float *memo
     hipLaunchKernelGGL(read_fwd_bwd_kernel, dim3(grid), dim3(RT), lds, st, d, P, memory, last, label, mask1, mask2,
                        keep_prob, inv_global_batch, memory_reg, pred, loss_out, d_memory, d_last, workspace);
     int rc = check_launch();
-    if (rc != HPMN_OK) return rc;
+    if (rc != HPMN_OK || d_params == nullptr) return rc;      // (NULL: the caller reduces the slabs itself, read_reduce_launch)
+    hipLaunchKernelGGL(read_reduce_kernel, dim3((unsigned)((d.n_params + 31) / 32)), dim3(32 * RRED_G), 0, st, workspace,
+                       (int)grid, d.n_params, d_params);
+    return check_launch();
+}
+
+// the second half of read_fwd_bwd_launch on its own: d_params += the per-workgroup slabs the kernel left in `workspace`
+int read_reduce_launch(const HpmnReadDesc &d, float *d_params, const float *workspace, hipStream_t st) {
+    if (!read_desc_ok(d)) return HPMN_EUNSUPPORTED;
+    const unsigned grid = (unsigned)((d.B + RS - 1) / RS);
     hipLaunchKernelGGL(read_reduce_kernel, dim3((unsigned)((d.n_params + 31) / 32)), dim3(32 * RRED_G), 0, st, workspace,
                        (int)grid, d.n_params, d_params);
     return check_launch();

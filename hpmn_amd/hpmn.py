@@ -450,10 +450,12 @@ class Hpmn_Basic(object):
             seed = _splitmix64(_splitmix64(self._dropout_base + self._dropout_step) ^ (self.rank + 1)) | 1
         out = ops.read_fwd_bwd(self._read_desc, self._read_params, self._read_grads, memory, last, label, masks,
                                keep_prob, 1.0 / float(global_batch), self.memory_reg, dropout_seed=seed,
-                               loss_out=self._loss_acc)
+                               loss_out=self._loss_acc, defer_param_grads=aux is not main)
         if aux is not main:
             aux.wait_stream(main)
         with torch.cuda.stream(aux):
+            if aux is not main:
+                out.pop("reduce_param_grads")()              # (only the optimiser needs them: off the serial chain too)
             sums = self._loss_acc.clone()                    # (the accumulator is cleared again next step)
             out["log_loss_sum"], out["memory_loss"] = sums[0], sums[1]
             ce = sums[0] / float(global_batch) + self.memory_reg * sums[1]

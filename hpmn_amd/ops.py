@@ -1018,11 +1018,13 @@ def read_fwd(desc, params, memory, last, want_logit=False, want_att=False):
 
 
 def read_fwd_bwd(desc, params, d_params, memory, last, label, masks, keep_prob, inv_global_batch, memory_reg,
-                 dropout_seed: int = 0, loss_out: Optional[torch.Tensor] = None):
+                 dropout_seed: int = 0, loss_out: Optional[torch.Tensor] = None, defer_param_grads: bool = False):
     """hpmn_read_fwd_bwd: forward + loss + backward of the read path; accumulates into d_params.
     ``masks`` = (mask1 [B,200], mask2 [B,80]) or None; with None and keep_prob < 1 a non-zero ``dropout_seed``
     makes the kernel draw the masks itself.  ``loss_out``: a ZEROED [2] buffer to accumulate the two loss sums into
-    (the training step keeps one and clears it off the critical path); default: a fresh one."""
+    (the training step keeps one and clears it off the critical path); default: a fresh one.
+    ``defer_param_grads``: leave the parameter gradients as partial sums in the workspace; the returned dict then holds
+    ``reduce_param_grads``, a callable that adds them to ``d_params`` on whatever stream is current when it is called."""
     _chk_f32(params, d_params, memory, last)
     B, K, H = memory.shape
     desc.B = B
@@ -1043,6 +1045,12 @@ def read_fwd_bwd(desc, params, d_params, memory, last, label, masks, keep_prob, 
                                         label.data_ptr(), _ptr(m1), _ptr(m2), float(keep_prob),
                                         float(inv_global_batch), float(memory_reg), pred.data_ptr(),
                                         loss_out.data_ptr(), d_memory.data_ptr(), d_last.data_ptr(),
-                                        d_params.data_ptr(), ws.data_ptr(), _stream())
+                                        None if defer_param_grads else d_params.data_ptr(), ws.data_ptr(), _stream())
     _lib.check(rc, "hpmn_read_fwd_bwd")
-    return dict(prediction=pred, log_loss_sum=loss_out[0], memory_loss=loss_out[1], d_memory=d_memory, d_last=d_last)
+    out = dict(prediction=pred, log_loss_sum=loss_out[0], memory_loss=loss_out[1], d_memory=d_memory, d_last=d_last)
+    if defer_param_grads:
+        def reduce_param_grads():
+            _lib.check(_lib.load().hpmn_read_param_grads(C.byref(desc), d_params.data_ptr(), ws.data_ptr(), _stream()),
+                       "hpmn_read_param_grads")
+        out["reduce_param_grads"] = reduce_param_grads
+    return out

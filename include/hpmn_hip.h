@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define HPMN_ABI_VERSION 5
+#define HPMN_ABI_VERSION 6
 #define HPMN_MAX_LAYERS 12
 
 enum {
@@ -372,6 +372,10 @@ int hpmn_read_fwd_bwd(const HpmnReadDesc *desc, const float *params, const float
                       const int32_t *label, const float *mask1, const float *mask2, float keep_prob,
                       float inv_global_batch, float memory_reg, float *pred, float *loss_out,
                       float *d_memory, float *d_last, float *d_params, float *workspace, void *stream);
+/* BPTT only waits for d_memory / d_last.  With d_params == NULL hpmn_read_fwd_bwd leaves the parameter gradients as
+ * per-workgroup partial sums in `workspace`, and this call (any stream ordered behind it, before `workspace` is used
+ * again) adds them to d_params -- the reduction (30 us at the reference batch) then need not sit on the serial chain. */
+int hpmn_read_param_grads(const HpmnReadDesc *desc, float *d_params, const float *workspace, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Embedding-gradient scatter-add: gradient of hpmn_embed_gather / the gather inside the
