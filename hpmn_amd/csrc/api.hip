@@ -32,7 +32,7 @@ int embed_gather_launch(const int32_t *ids, int64_t ids_stride, const float *emb
                         int32_t F, int32_t E, int32_t mask_id0, hipStream_t st);
 int embed_grad_scatter_launch(const int32_t *ids, const float *d_x, float *d_emb, int32_t B, int32_t T,
                               int32_t F, int32_t E, int32_t front_zero, int32_t mask_id0, int32_t t_lo, int32_t t_hi,
-                              hipStream_t st);
+                              hipStream_t st, const float *d_last = nullptr, int32_t t_last = 0);
 int adam_launch(float *p, const float *g, float *m, float *v, int64_t n, float lr_t, float b1, float b2,
                 float eps, float clip, float gs, hipStream_t st);
 int table_mark_launch(const int32_t *ids, int64_t n, uint8_t *flags, hipStream_t st);

@@ -38,7 +38,8 @@ constexpr int SCU = 8;      // steps per load chunk
 constexpr int SSEG = 128;   // steps per wave
 __global__ __launch_bounds__(64) void embed_grad_scatter_kernel(
     const int32_t *__restrict__ ids, const float *__restrict__ d_x, float *__restrict__ d_emb, int B,
-    int T, int F, int E, int front_zero, int mask_id0, int groups, int nseg, int t_lo, int t_hi) {
+    int T, int F, int E, int front_zero, int mask_id0, int groups, int nseg, int t_lo, int t_hi,
+    const float *__restrict__ d_last, int t_last) {
     const int cpw = 64 / E;                          // id columns per wave
     const int seg = blockIdx.x % nseg;
     const int grp = (blockIdx.x / nseg) % groups;
@@ -65,6 +66,9 @@ __global__ __launch_bounds__(64) void embed_grad_scatter_kernel(
             if (t < t_end) {
                 idv[i] = idp[(long)t * F];
                 gv[i] = gp[(long)t * Dx];
+                // the read path's gradient wrt uinp[:, last_index, :] joins the scan's at that step (instead of a
+                // row-add launch of its own in front of this one)
+                if (d_last != nullptr && t == t_last) gv[i] += d_last[b * Dx + f * E + e];
             }
         }
 #pragma unroll
@@ -94,9 +98,10 @@ int embed_gather_launch(const int32_t *ids, int64_t ids_stride, const float *emb
 }
 
 // steps [t_lo, t_hi) of every sequence (ids time; t_hi == 0: T)
+// d_last [B, F*E] (optional): added to the gradient rows of ids step t_last
 int embed_grad_scatter_launch(const int32_t *ids, const float *d_x, float *d_emb, int32_t B, int32_t T,
                               int32_t F, int32_t E, int32_t front_zero, int32_t mask_id0, int32_t t_lo, int32_t t_hi,
-                              hipStream_t st) {
+                              hipStream_t st, const float *d_last, int32_t t_last) {
     if (t_hi <= 0 || t_hi > T) t_hi = T;
     if (t_lo < 0) t_lo = 0;
     if (B == 0 || t_hi <= t_lo) return HPMN_OK;
@@ -104,7 +109,7 @@ int embed_grad_scatter_launch(const int32_t *ids, const float *d_x, float *d_emb
     const int groups = (F + cpw - 1) / cpw;
     const int nseg = (t_hi - t_lo + SSEG - 1) / SSEG;
     hipLaunchKernelGGL(embed_grad_scatter_kernel, dim3((unsigned)(B * groups * nseg)), dim3(64), 0, st, ids,
-                       d_x, d_emb, B, T, F, E, front_zero, mask_id0, groups, nseg, t_lo, t_hi);
+                       d_x, d_emb, B, T, F, E, front_zero, mask_id0, groups, nseg, t_lo, t_hi, d_last, t_last);
     return check_launch();
 }
 

@@ -17,7 +17,7 @@ bool gru_scan_bwd_fuses_dx(int H, int B);
 bool gru_scan_bwd_dx_width_ok(int D);
 int embed_grad_scatter_launch(const int32_t *ids, const float *d_x, float *d_emb, int32_t B, int32_t T,
                               int32_t F, int32_t E, int32_t front_zero, int32_t mask_id0, int32_t t_lo, int32_t t_hi,
-                              hipStream_t st);
+                              hipStream_t st, const float *d_last = nullptr, int32_t t_last = 0);
 
 struct TrainCtx {
     int device = -1, cus = 256;
@@ -309,7 +309,9 @@ int hpmn_scan_bwd(HpmnTrainCtx *ctx, const HpmnScanDesc *d, const int32_t *ids, 
             if (rc != HPMN_OK) return rc;
         }
     }
-    if (d_last && !scatter_pending) {
+    // (d_last, the read path's gradient wrt uinp[:, last_index, :], rides into the scatter: ids step T + last_index)
+    const bool last_in_scatter = d_last && !scatter_pending && d->T + d->last_index >= 0;
+    if (d_last && !scatter_pending && !last_in_scatter) {
         const long n = (long)d->B * D0;
         hipLaunchKernelGGL(add_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
                            F(L.d_x[0]) + (size_t)(L.T[0] + d->last_index) * D0, (long)L.T[0] * D0, d_last, d->B, D0);
@@ -317,7 +319,8 @@ int hpmn_scan_bwd(HpmnTrainCtx *ctx, const HpmnScanDesc *d, const int32_t *ids, 
         if (rc != HPMN_OK) return rc;
     }
     int rc = embed_grad_scatter_launch(ids, F(L.d_x[0]), d_emb, d->B, d->T, d->F, d->E, d->front_zero, d->mask_id0, 0,
-                                       scatter_pending ? cut - d->front_zero : d->T, st);
+                                       scatter_pending ? cut - d->front_zero : d->T, st,
+                                       last_in_scatter ? d_last : nullptr, d->T + d->last_index);
     if (rc != HPMN_OK) return rc;
     if (scatter_pending) HIPCHK(hipStreamWaitEvent(st, c->scat, 0));   // the caller's table update needs both halves
     if (!defer_join) return hpmn_train_join(ctx, stream);
