@@ -4,6 +4,7 @@ against the committed golden vectors.  Tolerances: 1e-4 absolute on logits/predi
 (the north_star bar), tighter where the arithmetic allows; integer paths exact."""
 import math
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -930,3 +931,22 @@ def test_scans_give_the_same_result_beside_an_unrelated_kernel(dev, tmp_path, B,
             # (the scatter's fp32 atomics may order differently run to run)
             tol = 1e-6 if k == "Embedding/emb_mtx" else 0.0
             assert float((ref_g[k] - g[k]).abs().max()) <= tol, "%s differs in run %d" % (k, it)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [
+    {"HPMN_BWD_HELPER": "1", "HPMN_FUSED_FWD_GEN": "1"},                       # the first-generation two-wave kernels
+    {"HPMN_BWD_HELPER": "0", "HPMN_FUSED_FWD": "0", "HPMN_TWO_PASS_ADAM": "0"},  # one wave per sequence, two-kernel forward
+    {"HPMN_BWD_DX_WAVE": "0", "HPMN_L0_SPLIT": "1"},                           # separate input-gradient launches, layer 0 split in time
+], ids=["gen1", "one-wave", "dx-launches+split"])
+def test_fallback_kernel_paths_still_match_the_oracle(env):
+    """The switches of DESIGN.md 3.11 select kernels at library load, so each set runs a slice of this file in a
+    process of its own: H = 64 forward/gradient parity at the tiny and odd lengths and at the XLong length."""
+    import subprocess
+    e = dict(os.environ)
+    e.update(env)
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", here, "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider",
+                        "-k", "(tiny_and_odd and 64) or xlong_c3_shape or c_abi_alone"],
+                       env=e, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
