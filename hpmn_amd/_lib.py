@@ -10,7 +10,7 @@ import os
 from typing import Optional
 
 HPMN_MAX_LAYERS = 12
-HPMN_ABI_VERSION = 6
+HPMN_ABI_VERSION = 7
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libhpmn_hip.so")
@@ -104,6 +104,7 @@ class HpmnGruFusedFwd(C.Structure):
         ("h_last", C.c_void_p), ("h_last_stride", C.c_int64),
         ("y", C.c_void_p), ("period", C.c_int32),
         ("hs", C.c_void_p), ("gates", C.c_void_p),
+        ("last", C.c_void_p), ("last_t", C.c_int32), ("pad_", C.c_int32),
     ]
 
 
@@ -173,6 +174,7 @@ SIGNATURES = {
     "hpmn_embed_grad_scatter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                           C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_void_p]),
     "hpmn_gru_fused_fwd_supported": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),
+    "hpmn_gru_fused_fwd_writes_last": (C.c_int, []),
     "hpmn_gru_fused_fwd": (C.c_int, [C.POINTER(HpmnGruFusedFwd), C.c_void_p]),
     "hpmn_memory_update": (C.c_int, [C.POINTER(HpmnOnlineUpdate), C.c_void_p]),
     "hpmn_adam_step_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,

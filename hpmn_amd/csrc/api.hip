@@ -15,6 +15,7 @@ bool gru_scan_bwd_dx_width_ok(int D);
 bool input_proj_supported(int H, int D);
 int memory_update_launch(const HpmnOnlineUpdate &a, hipStream_t st);
 bool gru_fused_fwd_supported(int H, int D, int gather);
+bool gru_fused_fwd_writes_last();
 int gru_fused_fwd_dispatch(const HpmnGruFusedFwd &a, hipStream_t st);
 int input_proj_dispatch(const HpmnInputProj &a, hipStream_t st);
 int gru_wgrad_dispatch(const HpmnGruWgrad &a, hipStream_t st);
@@ -353,6 +354,8 @@ int hpmn_adam_step_table(float *param, float *grad, float *m, float *v, uint8_t 
     return adam_table_launch(param, grad, m, v, flags, V, E, pass, lr_t, beta1, beta2, eps, clip, grad_scale,
                              (hipStream_t)stream);
 }
+
+int hpmn_gru_fused_fwd_writes_last(void) { return gru_fused_fwd_writes_last() ? 1 : 0; }
 
 int hpmn_gru_fused_fwd_supported(int32_t H, int32_t D, int32_t gather) {
     return gru_fused_fwd_supported(H, D, gather) ? 1 : 0;

@@ -336,11 +336,19 @@ static int launch_fused(const HpmnGruFusedFwd &a, hipStream_t st) {
 
 int gru_fwd_mfma_dispatch(const HpmnGruFusedFwd &a, hipStream_t st);  // gru_fused_fwd3.hip
 
+static int fused_gen() {
+    static const int gen = [] { const char *e = getenv("HPMN_FUSED_FWD_GEN"); return e ? atoi(e) : 3; }();
+    return gen;
+}
+// does the launch write HpmnGruFusedFwd.last itself?
+bool gru_fused_fwd_writes_last() { return fused_gen() >= 3; }
+
 int gru_fused_fwd_dispatch(const HpmnGruFusedFwd &a, hipStream_t st) {
     // HPMN_FUSED_FWD_GEN: 3 (default) chain + MFMA-producer waves, two sequences per workgroup (gru_fused_fwd3.hip); 1 the
     // first generation below
-    static const int gen = [] { const char *e = getenv("HPMN_FUSED_FWD_GEN"); return e ? atoi(e) : 3; }();
+    const int gen = fused_gen();
     if (gen >= 3) return gru_fwd_mfma_dispatch(a, st);
+    if (a.last != nullptr) return HPMN_EUNSUPPORTED;
     if (a.B == 0) return HPMN_OK;
     if (a.H != FH) return HPMN_EUNSUPPORTED;
     if (a.D == 32) return launch_fused<32>(a, st);

@@ -144,6 +144,8 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_mfma_kernel(const HpmnGruFused
                 if constexpr (GATHER) {
                     if (a.x_out != nullptr && s0 + n16 < T)
                         *reinterpret_cast<v4f *>(a.x_out + (b * (long)T + s0 + n16) * D + 16 * kq + 4 * g) = r.v[kq];
+                    if (a.last != nullptr && s0 + n16 == a.last_t)      // the read path's uinp[:, last_index, :]
+                        *reinterpret_cast<v4f *>(a.last + b * (long)D + 16 * kq + 4 * g) = r.v[kq];
                 }
             }
         };

@@ -12,6 +12,7 @@ namespace hpmn {
 int embed_gather_launch(const int32_t *ids, int64_t ids_stride, const float *emb, float *out, int64_t N, int32_t F,
                         int32_t E, int32_t mask_id0, hipStream_t st);
 bool gru_fused_fwd_supported(int H, int D, int gather);
+bool gru_fused_fwd_writes_last();
 size_t gru_wgrad_workspace_bytes(int B, int T, int D, int H);
 bool gru_scan_bwd_fuses_dx(int H, int B);
 bool gru_scan_bwd_dx_width_ok(int D);
@@ -140,6 +141,7 @@ int hpmn_scan_fwd_train(HpmnTrainCtx *ctx, const HpmnScanDesc *d, const int32_t 
     // the fused layer spends a second wave per sequence on a SIMD that would otherwise idle: a win while 2 B waves
     // still find (about) a SIMD each (measured at C3: +3.7 % at B=500, -6.6 % at B=750 / 1000)
     const bool room = 2.0 * d->B <= 1.1 * 4 * c->cus;
+    bool last_done = false;
     for (int i = 0; i < d->K; ++i) {
         const int D = i == 0 ? D0 : d->H;
         const bool fused = room && gru_fused_fwd_supported(d->H, D, i == 0) && (i > 0 || 64 % d->E == 0);
@@ -149,6 +151,10 @@ int hpmn_scan_fwd_train(HpmnTrainCtx *ctx, const HpmnScanDesc *d, const int32_t 
             HpmnGruFusedFwd a = {};
             a.B = d->B; a.T = L.T[i]; a.D = D; a.H = d->H;
             if (i == 0) {
+                if (last && gru_fused_fwd_writes_last()) {      // uinp[:, last_index, :] straight out of the launch
+                    a.last = last; a.last_t = L.T[0] + d->last_index;
+                    last_done = true;
+                }
                 a.ids = ids; a.emb = emb; a.Tids = d->T; a.F = d->F; a.E = d->E; a.front_zero = d->front_zero;
                 a.mask_id0 = d->mask_id0; a.V = d->V; a.x_out = F(L.x0);
             } else {
@@ -179,7 +185,7 @@ int hpmn_scan_fwd_train(HpmnTrainCtx *ctx, const HpmnScanDesc *d, const int32_t 
         }
         if (rc != HPMN_OK) return rc;
     }
-    if (last) {
+    if (last && !last_done) {
         // uinp[:, last_index, :] (code/hpmn.py:439 / :292): a row of the materialised layer-0 input
         const size_t row = (size_t)(L.T[0] + d->last_index) * D0;
         HIPCHK(hipMemcpy2DAsync(last, (size_t)D0 * sizeof(float), F(L.x0) + row, (size_t)L.T[0] * D0 * sizeof(float),

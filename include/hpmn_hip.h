@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define HPMN_ABI_VERSION 6
+#define HPMN_ABI_VERSION 7
 #define HPMN_MAX_LAYERS 12
 
 enum {
@@ -145,9 +145,14 @@ typedef struct HpmnGruFusedFwd {
     int32_t period;
     float *hs;                 /* optional [B,T+1,H]  (training) */
     float *gates;              /* optional [B,T,3H]   (training) */
+    float *last;               /* optional [B,D]: a copy of the (gathered, masked) input row of step last_t -- the read
+                                * path's uinp[:, last_index, :] -- written by the launch itself.  Only where
+                                * hpmn_gru_fused_fwd_writes_last() != 0 (HPMN_EUNSUPPORTED otherwise); NULL: none */
+    int32_t last_t, pad_;
 } HpmnGruFusedFwd;
 
 int hpmn_gru_fused_fwd_supported(int32_t H, int32_t D, int32_t gather);
+int hpmn_gru_fused_fwd_writes_last(void);
 int hpmn_gru_fused_fwd(const HpmnGruFusedFwd *args, void *stream);
 
 /* ------------------------------------------------------------------------------------
