@@ -68,6 +68,7 @@ class HpmnGruWgrad(C.Structure):
         ("workspace", C.c_void_p),
         ("seq_per_wg", C.c_int32),
         ("t_begin", C.c_int32), ("t_len", C.c_int32),
+        ("whole_cu", C.c_int32),
     ]
 
 

@@ -283,7 +283,7 @@ static int launch_wgrad(const HpmnGruWgrad &a, hipStream_t st) {
     const long solo_rows = solo_env >= 0 ? solo_env : (a.H <= 64 ? (1L << 62) : 0L);
     const long rows = (long)a.B * (a.t_len > 0 ? a.t_len : a.T);
     size_t lds_pad = 0;
-    if (rows <= solo_rows) {
+    if (rows <= solo_rows && !a.whole_cu) {
         static const size_t pad = [] {
             hipFuncAttributes fa = {};
             const void *fn = reinterpret_cast<const void *>(gru_wgrad_kernel<HT, DT, CS>);

@@ -243,6 +243,9 @@ int hpmn_scan_bwd(HpmnTrainCtx *ctx, const HpmnScanDesc *d, const int32_t *ids, 
         w.wg = wg[i]; w.wc = wc[i];
         w.d_wg = d_wg[i]; w.d_bg = d_bg[i]; w.d_wc = d_wc[i]; w.d_bc = d_bc[i];
         w.workspace = F(L.wgrad_ws);
+        // (layer 0's weight gradient runs beside the scatter and the table update, which are bandwidth kernels, and
+        //  bounds the step's tail: it may fill the CUs -- 2.985 -> 2.905 ms/step at C3)
+        w.whole_cu = i == 0 && d->H <= 64 ? 1 : 0;
         if (i == 0 && cut > 0) {
             const int T0 = L.T[0];
             if (nheld) {                                   // (weight gradients of short layers still waiting for a fork)
@@ -274,7 +277,7 @@ int hpmn_scan_bwd(HpmnTrainCtx *ctx, const HpmnScanDesc *d, const int32_t *ids, 
             if (rc != HPMN_OK) return rc;
             HIPCHK(hipEventRecord(c->scat, c->side));
             scatter_pending = true;
-            w.t_begin = cut; w.t_len = T0 - cut;
+            w.t_begin = cut; w.t_len = T0 - cut; w.whole_cu = 0;      // (beside the early half's scan)
             rc = hpmn_gru_param_grads(&w, c->side);
             if (rc != HPMN_OK) return rc;
             c->pending = true;
@@ -283,7 +286,7 @@ int hpmn_scan_bwd(HpmnTrainCtx *ctx, const HpmnScanDesc *d, const int32_t *ids, 
             if (rc != HPMN_OK) return rc;
             HIPCHK(hipEventRecord(c->fork, st));
             HIPCHK(hipStreamWaitEvent(c->side, c->fork, 0));
-            w.t_begin = 0; w.t_len = cut;
+            w.t_begin = 0; w.t_len = cut; w.whole_cu = d->H <= 64 ? 1 : 0;
             rc = hpmn_gru_param_grads(&w, c->side);
             if (rc != HPMN_OK) return rc;
             rc = hpmn_gru_input_grad(F(L.d_act[0]), wg[0], wc[0], F(L.d_x[0]), d->B, T0, D, d->H, 0, cut, stream);

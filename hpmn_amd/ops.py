@@ -238,7 +238,8 @@ def gru_scan_bwd(wg, wc, D, hs, gates, d_h_last, d_y, period, out=None, t_range=
     return d_act
 
 
-def gru_param_grads(x, hs, gates, d_act, wg, wc, d_wg, d_bg, d_wc, d_bc, want_dx=True, keep=None, t_range=None):
+def gru_param_grads(x, hs, gates, d_act, wg, wc, d_wg, d_bg, d_wc, d_bc, want_dx=True, keep=None, t_range=None,
+                    whole_cu=False):
     """hpmn_gru_param_grads: accumulates into d_wg/d_bg/d_wc/d_bc (caller-zeroed), returns dx or None.
     ``keep``: list that receives the temporaries (workspace) when the call is issued on a side stream;
     ``t_range`` = (t_begin, t_len) restricts the reduction to those steps of every sequence."""
@@ -252,6 +253,7 @@ def gru_param_grads(x, hs, gates, d_act, wg, wc, d_wg, d_bg, d_wc, d_bc, want_dx
     a.d_wg, a.d_bg, a.d_wc, a.d_bc = d_wg.data_ptr(), d_bg.data_ptr(), d_wc.data_ptr(), d_bc.data_ptr()
     if t_range is not None:
         a.t_begin, a.t_len = t_range
+    a.whole_cu = 1 if whole_cu else 0          # (layer 0 at the end of BPTT: nothing latency-critical beside it)
     d_x = None
     if want_dx:
         d_x = torch.empty(B, T, D, device=x.device, dtype=torch.float32)
@@ -934,7 +936,7 @@ def scan_backward_layers(spec: ScanSpec, ids, saved, weights: Sequence[torch.Ten
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
                     gru_param_grads(x_in, hs, gates, d_act[i], wg, wc, gw[4 * i], gw[4 * i + 1], gw[4 * i + 2],
-                                    gw[4 * i + 3], want_dx=False, keep=keep)
+                                    gw[4 * i + 3], want_dx=False, keep=keep, whole_cu=(i == 0 and H <= 64))
             if cut or not (scan_bwd_fuses_dx(H, B) and in_dims[i] in (16, 32, 64)):
                 gru_input_grad(d_act[i], wg, wc, in_dims[i], out=d_x[i])
         d_x0 = d_x[0]
