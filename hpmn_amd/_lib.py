@@ -10,7 +10,7 @@ import os
 from typing import Optional
 
 HPMN_MAX_LAYERS = 12
-HPMN_ABI_VERSION = 7
+HPMN_ABI_VERSION = 8
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libhpmn_hip.so")
@@ -109,6 +109,11 @@ class HpmnGruFusedFwd(C.Structure):
     ]
 
 
+class HpmnGruPairFwd(C.Structure):
+    _fields_ = [("lo", HpmnGruFusedFwd), ("up", HpmnGruFusedFwd), ("scratch", C.c_void_p),
+                ("flags", C.c_int32), ("pad_", C.c_int32)]
+
+
 class HpmnPipe(C.Structure):
     _fields_ = [
         ("B", C.c_int32), ("K", C.c_int32), ("H", C.c_int32), ("train", C.c_int32),
@@ -133,6 +138,7 @@ class HpmnTrainLayout(C.Structure):
         ("gates", C.c_uint64 * HPMN_MAX_LAYERS), ("y", C.c_uint64 * HPMN_MAX_LAYERS),
         ("d_act", C.c_uint64 * HPMN_MAX_LAYERS), ("d_x", C.c_uint64 * HPMN_MAX_LAYERS),
         ("wgrad_ws", C.c_uint64), ("total_bytes", C.c_uint64),
+        ("pair_ws", C.c_uint64),
     ]
 
 
@@ -177,6 +183,9 @@ SIGNATURES = {
     "hpmn_gru_fused_fwd_supported": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),
     "hpmn_gru_fused_fwd_writes_last": (C.c_int, []),
     "hpmn_gru_fused_fwd": (C.c_int, [C.POINTER(HpmnGruFusedFwd), C.c_void_p]),
+    "hpmn_gru_pair_fwd_supported": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),
+    "hpmn_gru_pair_fwd_scratch_bytes": (C.c_size_t, []),
+    "hpmn_gru_pair_fwd": (C.c_int, [C.POINTER(HpmnGruPairFwd), C.c_void_p]),
     "hpmn_memory_update": (C.c_int, [C.POINTER(HpmnOnlineUpdate), C.c_void_p]),
     "hpmn_adam_step_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
                                       C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),

@@ -17,6 +17,9 @@ int memory_update_launch(const HpmnOnlineUpdate &a, hipStream_t st);
 bool gru_fused_fwd_supported(int H, int D, int gather);
 bool gru_fused_fwd_writes_last();
 int gru_fused_fwd_dispatch(const HpmnGruFusedFwd &a, hipStream_t st);
+bool gru_pair_fwd_supported(int H, int D_lo, int gather);
+size_t gru_pair_fwd_scratch_bytes();
+int gru_pair_fwd_launch(const HpmnGruFusedFwd &lo, const HpmnGruFusedFwd &up, int flags, float *scratch, hipStream_t st);
 int input_proj_dispatch(const HpmnInputProj &a, hipStream_t st);
 int gru_wgrad_dispatch(const HpmnGruWgrad &a, hipStream_t st);
 int gru_dx_dispatch(const HpmnGruWgrad &a, hipStream_t st);
@@ -375,6 +378,41 @@ int hpmn_gru_fused_fwd(const HpmnGruFusedFwd *a, void *stream) {
     if (!gru_fused_fwd_supported(a->H, a->D, a->x == nullptr)) return HPMN_EUNSUPPORTED;
     if (a->B == 0) return HPMN_OK;
     return gru_fused_fwd_dispatch(*a, (hipStream_t)stream);
+}
+
+int hpmn_gru_pair_fwd_supported(int32_t H, int32_t D_lo, int32_t gather) {
+    return gru_pair_fwd_supported(H, D_lo, gather) ? 1 : 0;
+}
+
+size_t hpmn_gru_pair_fwd_scratch_bytes(void) { return gru_pair_fwd_scratch_bytes(); }
+
+static int fused_args_ok(const HpmnGruFusedFwd *a, bool needs_input) {
+    if (a->B < 0 || a->T < 1 || a->period < 1) return HPMN_EINVAL;
+    if (!a->wg || !a->bg || !a->wc || !a->bc || !a->h_last) return HPMN_EINVAL;
+    if ((a->hs == nullptr) != (a->gates == nullptr)) return HPMN_EINVAL;
+    if (needs_input && a->x == nullptr) {
+        if (!a->ids || !a->emb || a->F < 1 || a->E < 1 || a->F * a->E != a->D || a->Tids + a->front_zero != a->T ||
+            a->front_zero < 0)
+            return HPMN_EINVAL;
+    }
+    if (a->y != nullptr && a->T % a->period != 0) return HPMN_EINVAL;
+    return HPMN_OK;
+}
+
+int hpmn_gru_pair_fwd(const HpmnGruPairFwd *p, void *stream) {
+    drop_stale_hip_error();
+    if (p == nullptr || p->scratch == nullptr || (reinterpret_cast<size_t>(p->scratch) & 15) != 0) return HPMN_EINVAL;
+    int rc = fused_args_ok(&p->lo, true);
+    if (rc != HPMN_OK) return rc;
+    rc = fused_args_ok(&p->up, false);
+    if (rc != HPMN_OK) return rc;
+    if (p->lo.T % p->lo.period != 0 || p->up.T != p->lo.T / p->lo.period || p->up.B != p->lo.B) return HPMN_EINVAL;
+    if ((p->lo.hs == nullptr) != (p->up.hs == nullptr)) return HPMN_EINVAL;
+    if (p->up.D != p->lo.H || p->up.H != p->lo.H || p->up.last != nullptr) return HPMN_EINVAL;
+    if (!gru_pair_fwd_supported(p->lo.H, p->lo.D, p->lo.x == nullptr)) return HPMN_EUNSUPPORTED;
+    if (p->lo.x == nullptr && p->lo.E % 4 != 0) return HPMN_EUNSUPPORTED;
+    if (p->lo.B == 0) return HPMN_OK;
+    return gru_pair_fwd_launch(p->lo, p->up, p->flags, reinterpret_cast<float *>(p->scratch), (hipStream_t)stream);
 }
 
 int hpmn_memory_update(const HpmnOnlineUpdate *a, void *stream) {

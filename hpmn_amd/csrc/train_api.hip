@@ -13,6 +13,8 @@ int embed_gather_launch(const int32_t *ids, int64_t ids_stride, const float *emb
                         int32_t E, int32_t mask_id0, hipStream_t st);
 bool gru_fused_fwd_supported(int H, int D, int gather);
 bool gru_fused_fwd_writes_last();
+bool gru_pair_fwd_supported(int H, int D_lo, int gather);
+size_t gru_pair_fwd_scratch_bytes();
 size_t gru_wgrad_workspace_bytes(int B, int T, int D, int H);
 bool gru_scan_bwd_fuses_dx(int H, int B);
 bool gru_scan_bwd_dx_width_ok(int D);
@@ -63,6 +65,8 @@ static bool layout(const HpmnScanDesc &d, HpmnTrainLayout &L) {
     }
     L.wgrad_ws = off;
     off += up256(wmax);
+    L.pair_ws = off;
+    off += up256(gru_pair_fwd_scratch_bytes());
     L.total_bytes = off + 256;
     return true;
 }
@@ -141,28 +145,49 @@ int hpmn_scan_fwd_train(HpmnTrainCtx *ctx, const HpmnScanDesc *d, const int32_t 
     // the fused layer spends a second wave per sequence on a SIMD that would otherwise idle: a win while 2 B waves
     // still find (about) a SIMD each (measured at C3: +3.7 % at B=500, -6.6 % at B=750 / 1000)
     const bool room = 2.0 * d->B <= 1.1 * 4 * c->cus;
+    // two layers per launch (hpmn_gru_pair_fwd): one 8-wave workgroup per CU and two sequences
+    static const int pair_env = [] { const char *e = getenv("HPMN_PAIR_FWD"); return e ? atoi(e) : 1; }();
+    const bool pair_room = pair_env > 0 && (d->B + 1) / 2 <= c->cus;
     bool last_done = false;
+    auto fused_args = [&](int i) {
+        const int D = i == 0 ? D0 : d->H;
+        HpmnGruFusedFwd a = {};
+        a.B = d->B; a.T = L.T[i]; a.D = D; a.H = d->H;
+        if (i == 0) {
+            if (last && gru_fused_fwd_writes_last()) {      // uinp[:, last_index, :] straight out of the launch
+                a.last = last; a.last_t = L.T[0] + d->last_index;
+                last_done = true;
+            }
+            a.ids = ids; a.emb = emb; a.Tids = d->T; a.F = d->F; a.E = d->E; a.front_zero = d->front_zero;
+            a.mask_id0 = d->mask_id0; a.V = d->V; a.x_out = F(L.x0);
+        } else {
+            a.x = F(L.y[i - 1]);
+        }
+        a.wg = wg[i]; a.bg = bg[i]; a.wc = wc[i]; a.bc = bc[i];
+        a.h_last = memory + (size_t)i * d->H; a.h_last_stride = (int64_t)d->K * d->H;
+        a.y = i + 1 < d->K ? F(L.y[i]) : nullptr;
+        a.period = d->periods[i]; a.hs = F(L.hs[i]); a.gates = F(L.gates[i]);
+        return a;
+    };
     for (int i = 0; i < d->K; ++i) {
         const int D = i == 0 ? D0 : d->H;
         const bool fused = room && gru_fused_fwd_supported(d->H, D, i == 0) && (i > 0 || 64 % d->E == 0);
         float *y = i + 1 < d->K ? F(L.y[i]) : nullptr;
         int rc;
+        // (a pair pays while the upper layer is long enough to matter: below 8 steps it is one launch of a few us)
+        if (fused && pair_room && i + 1 < d->K && L.T[i + 1] >= 8 && gru_pair_fwd_supported(d->H, D, i == 0)) {
+            HpmnGruPairFwd p = {};
+            p.lo = fused_args(i);
+            p.up = fused_args(i + 1);
+            p.scratch = F(L.pair_ws);
+            p.flags = pair_env > 1 ? 1 : 0;
+            rc = hpmn_gru_pair_fwd(&p, stream);
+            if (rc != HPMN_OK) return rc;
+            ++i;
+            continue;
+        }
         if (fused) {
-            HpmnGruFusedFwd a = {};
-            a.B = d->B; a.T = L.T[i]; a.D = D; a.H = d->H;
-            if (i == 0) {
-                if (last && gru_fused_fwd_writes_last()) {      // uinp[:, last_index, :] straight out of the launch
-                    a.last = last; a.last_t = L.T[0] + d->last_index;
-                    last_done = true;
-                }
-                a.ids = ids; a.emb = emb; a.Tids = d->T; a.F = d->F; a.E = d->E; a.front_zero = d->front_zero;
-                a.mask_id0 = d->mask_id0; a.V = d->V; a.x_out = F(L.x0);
-            } else {
-                a.x = F(L.y[i - 1]);
-            }
-            a.wg = wg[i]; a.bg = bg[i]; a.wc = wc[i]; a.bc = bc[i];
-            a.h_last = memory + (size_t)i * d->H; a.h_last_stride = (int64_t)d->K * d->H;
-            a.y = y; a.period = d->periods[i]; a.hs = F(L.hs[i]); a.gates = F(L.gates[i]);
+            HpmnGruFusedFwd a = fused_args(i);
             rc = hpmn_gru_fused_fwd(&a, stream);
         } else {
             HpmnInputProj p = {};

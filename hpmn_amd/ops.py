@@ -173,6 +173,53 @@ def gru_fused_fwd(*, x=None, ids=None, emb=None, wg, bg, wc, bc, H, T, front_zer
     _lib.check(rc, "hpmn_gru_fused_fwd")
 
 
+def _fill_fused(a, *, x, ids, emb, wg, bg, wc, bc, H, T, front_zero, mask_id0, h_last, period, out):
+    _chk_f32(wg, bg, wc, bc)
+    if x is not None:
+        _chk_f32(x)
+        B, Tx, D = x.shape
+        assert Tx == T
+        a.x = x.data_ptr()
+    elif ids is not None:
+        _chk_ids(ids)
+        _chk_f32(emb)
+        B, Tids, F = ids.shape
+        V, E = emb.shape
+        D = F * E
+        a.ids, a.emb = ids.data_ptr(), emb.data_ptr()
+        a.Tids, a.F, a.E, a.front_zero, a.mask_id0, a.V = Tids, F, E, front_zero, int(mask_id0), V
+    else:                                   # the upper layer of a pair: its rows never leave the CU
+        B, D = h_last.shape[0], H
+    a.B, a.T, a.D, a.H = B, T, D, H
+    a.wg, a.bg, a.wc, a.bc = wg.data_ptr(), bg.data_ptr(), wc.data_ptr(), bc.data_ptr()
+    assert h_last.stride(1) == 1 and h_last.shape == (B, H)
+    a.h_last, a.h_last_stride = h_last.data_ptr(), h_last.stride(0)
+    a.period = period
+    y, hs, gates, x_out = out
+    a.y, a.hs, a.gates, a.x_out = _ptr(y), _ptr(hs), _ptr(gates), _ptr(x_out)
+
+
+_pair_scratch = {}
+
+
+def gru_pair_fwd(lo: dict, up: dict, flags: int = 0):
+    """hpmn_gru_pair_fwd: two consecutive layers in one launch.  ``lo`` / ``up``: keyword arguments of gru_fused_fwd
+    (``up`` without x / ids: its input rows are handed over inside the launch)."""
+    lib = _lib.load()
+    p = _lib.HpmnGruPairFwd()
+    _fill_fused(p.lo, x=lo.get("x"), ids=lo.get("ids"), emb=lo.get("emb"), wg=lo["wg"], bg=lo["bg"], wc=lo["wc"],
+                bc=lo["bc"], H=lo["H"], T=lo["T"], front_zero=lo.get("front_zero", 0), mask_id0=lo.get("mask_id0", False),
+                h_last=lo["h_last"], period=lo["period"], out=lo["out"])
+    _fill_fused(p.up, x=None, ids=None, emb=None, wg=up["wg"], bg=up["bg"], wc=up["wc"], bc=up["bc"], H=up["H"],
+                T=up["T"], front_zero=0, mask_id0=False, h_last=up["h_last"], period=up["period"], out=up["out"])
+    dev = lo["wg"].device
+    sc = _pair_scratch.get(str(dev))
+    if sc is None:
+        sc = _pair_scratch[str(dev)] = torch.empty(int(lib.hpmn_gru_pair_fwd_scratch_bytes()), device=dev, dtype=torch.uint8)
+    p.scratch, p.flags = sc.data_ptr(), flags
+    _lib.check(lib.hpmn_gru_pair_fwd(C.byref(p), _stream()), "hpmn_gru_pair_fwd")
+
+
 def gru_scan_fwd(xp, wg, wc, D, h_last, period, want_y, train, out=None, t_range=None, h_init=None):
     """hpmn_gru_scan_fwd.  h_last is a [B,H] strided view (e.g. memory[:, i, :]).  ``out`` = (y, hs, gates)
     preallocated; ``t_range`` = (t_begin, t_end) runs one time chunk from ``h_init`` ([B,H] strided view)."""

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define HPMN_ABI_VERSION 7
+#define HPMN_ABI_VERSION 8
 #define HPMN_MAX_LAYERS 12
 
 enum {
@@ -156,6 +156,33 @@ int hpmn_gru_fused_fwd_writes_last(void);
 int hpmn_gru_fused_fwd(const HpmnGruFusedFwd *args, void *stream);
 
 /* ------------------------------------------------------------------------------------
+ * TWO consecutive layers of build_memory in ONE launch (H = 64): layer i+1 runs while layer i runs.
+ * code/hpmn.py:124-128 hands layer i+1 every period-th output of layer i -- a pipeline that one launch
+ * per layer serialises.  A workgroup owns two sequences and both layers of them (eight waves, two per
+ * SIMD: chain + producer wave of either layer, as in hpmn_gru_fused_fwd); the rows that fire go from the
+ * lower layer's producer wave to the upper layer's through an LDS ring behind two LDS counters -- no
+ * global flag, no dependence on dispatch order.
+ *   lo : the lower layer, exactly as for hpmn_gru_fused_fwd (gather or x rows; lo.y may be NULL when nobody
+ *        else needs the subsampled outputs, e.g. in inference)
+ *   up : the upper layer: up.T == lo.T / lo.period, up.D == H, up.B == lo.B; up.x is IGNORED (the rows never
+ *        leave the CU); everything else as for hpmn_gru_fused_fwd.  (lo.hs == NULL) == (up.hs == NULL).
+ *   scratch : >= hpmn_gru_pair_fwd_scratch_bytes() bytes of device memory, 16-byte aligned (MFMA operand
+ *        images of the projection weights, rewritten by every call on `stream`)
+ *   flags : bit 0 swaps which SIMD pair hosts the upper layer's chain / producer waves (measurement switch)
+ * Results are bit-identical to two hpmn_gru_fused_fwd calls.  One workgroup per CU is resident (two waves
+ * per SIMD at 256 registers): meant for (B + 1) / 2 <= number of CUs; larger batches run but serialise.
+ * ---------------------------------------------------------------------------------- */
+typedef struct HpmnGruPairFwd {
+    HpmnGruFusedFwd lo, up;
+    void *scratch;
+    int32_t flags, pad_;
+} HpmnGruPairFwd;
+
+int hpmn_gru_pair_fwd_supported(int32_t H, int32_t D_lo, int32_t gather);
+size_t hpmn_gru_pair_fwd_scratch_bytes(void);
+int hpmn_gru_pair_fwd(const HpmnGruPairFwd *args, void *stream);
+
+/* ------------------------------------------------------------------------------------
  * One GRU layer, reverse scan (BPTT) -- the serial part of the gradient of
  * hpmn_gru_scan_fwd (TF autodiff through the while_loop of code/hpmn.py:119-120).
  *   d_h_last [B] rows at d_h_last[b*stride + 0..H) : gradient wrt the final state
@@ -279,6 +306,7 @@ typedef struct HpmnTrainLayout {
     uint64_t d_act[HPMN_MAX_LAYERS];       /* [B, T[i], 3H]                                                */
     uint64_t d_x[HPMN_MAX_LAYERS];         /* [B, T[i], D_i]                                               */
     uint64_t wgrad_ws, total_bytes;
+    uint64_t pair_ws;                      /* scratch of the two-layer launches (hpmn_gru_pair_fwd)         */
 } HpmnTrainLayout;
 
 int hpmn_train_ctx_create(HpmnTrainCtx **ctx);

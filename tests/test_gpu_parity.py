@@ -950,3 +950,79 @@ def test_fallback_kernel_paths_still_match_the_oracle(env):
                         "-k", "(tiny_and_odd and 64) or xlong_c3_shape or c_abi_alone"],
                        env=e, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+# ------------------------------------------------------------------------------- two layers per launch
+PAIR_CASES = [
+    # name, B, T_lo, D_lo (gather F = D/16 or x rows), period_lo, period_up
+    ("xlong-l0l1", 9, 1024, "g32", 2, 2),
+    ("xlong-l2l3", 5, 256, "x64", 2, 2),
+    ("top", 4, 32, "x64", 2, 2),
+    ("taobao-l0l1", 7, 300, "g64", 2, 2),
+    ("taobao-l2l3", 3, 75, "x64", 3, 5),
+    ("period5", 2, 400, "g32", 5, 1),
+    ("one-block", 3, 16, "g32", 2, 1),
+    ("odd-rows", 6, 46, "x64", 2, 1),
+    ("wide", 301, 64, "g32", 2, 2),
+]
+
+
+@pytest.mark.parametrize("train", [True, False])
+@pytest.mark.parametrize("name,B,T,src,p_lo,p_up", PAIR_CASES, ids=[c[0] for c in PAIR_CASES])
+def test_two_layers_in_one_launch_equal_two_launches(dev, name, B, T, src, p_lo, p_up, train):
+    """hpmn_gru_pair_fwd against two hpmn_gru_fused_fwd calls: the same arithmetic in the same order, so every output
+    -- final states, subsampled outputs, saved states and gates, the materialised gather -- must be BIT-identical;
+    with either SIMD assignment of the upper layer's waves, beside an unrelated kernel too."""
+    from hpmn_amd import ops
+    H, E, V = 64, 16, 700
+    g = torch.Generator(device="cpu").manual_seed(hash(name) % 1000)
+    D = int(src[1:])
+    gather = src[0] == "g"
+    Tu = T // p_lo
+    assert T % p_lo == 0 and Tu % p_up == 0
+
+    def w(*shape, scale=0.3):
+        return (torch.randn(*shape, generator=g) * scale).to(dev)
+    wl = dict(wg=w(D + H, 2 * H), bg=w(2 * H) + 1, wc=w(D + H, H), bc=w(H))
+    wu = dict(wg=w(2 * H, 2 * H), bg=w(2 * H) + 1, wc=w(2 * H, H), bc=w(H))
+    inp = {}
+    front = 0
+    if gather:
+        front = 23 if T > 64 else 0
+        ids = torch.randint(0, V, (B, T - front, D // E), generator=g, dtype=torch.int32)
+        ids[: B // 2, : (T - front) // 3] = 0
+        inp = dict(ids=ids.to(dev), emb=w(V, E, scale=1.0), front_zero=front, mask_id0=(name != "xlong-l0l1"))
+    else:
+        inp = dict(x=w(B, T, D, scale=1.0))
+
+    def outs():
+        mem = torch.full((B, 2, H), 7.0, device=dev)
+        def layer(Tl, Dl, p, want_y):
+            y = torch.full((B, Tl // p, H), 7.0, device=dev) if want_y else None
+            hs = torch.full((B, Tl + 1, H), 7.0, device=dev) if train else None
+            ga = torch.full((B, Tl, 3 * H), 7.0, device=dev) if train else None
+            return [y, hs, ga, None]
+        lo, up = layer(T, D, p_lo, True), layer(Tu, H, p_up, p_up > 0 and name != "top")
+        if gather and train:
+            lo[3] = torch.full((B, T, D), 7.0, device=dev)
+        return mem, lo, up
+
+    mem_a, lo_a, up_a = outs()
+    ops.gru_fused_fwd(**inp, **wl, H=H, T=T, h_last=mem_a[:, 0], period=p_lo, out=tuple(lo_a))
+    ops.gru_fused_fwd(x=lo_a[0], **wu, H=H, T=Tu, h_last=mem_a[:, 1], period=p_up, out=tuple(up_a))
+    junk = torch.empty(200_000_000, device=dev)
+    side = torch.cuda.Stream()
+    for flags in (0, 1, 0, 1):
+        mem_b, lo_b, up_b = outs()
+        if flags:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                junk.zero_()
+        ops.gru_pair_fwd(dict(**inp, **wl, H=H, T=T, h_last=mem_b[:, 0], period=p_lo, out=tuple(lo_b)),
+                         dict(**wu, H=H, T=Tu, h_last=mem_b[:, 1], period=p_up, out=tuple(up_b)), flags=flags)
+        torch.cuda.synchronize()
+        assert torch.equal(mem_a, mem_b), "final states (flags %d)" % flags
+        for i, (a, b) in enumerate(zip(lo_a + up_a, lo_b + up_b)):
+            assert (a is None) == (b is None)
+            if a is not None:
+                assert torch.equal(a, b), "output %d differs (flags %d)" % (i, flags)
