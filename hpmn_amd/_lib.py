@@ -111,7 +111,7 @@ class HpmnGruFusedFwd(C.Structure):
 
 class HpmnGruPairFwd(C.Structure):
     _fields_ = [("lo", HpmnGruFusedFwd), ("up", HpmnGruFusedFwd), ("scratch", C.c_void_p),
-                ("flags", C.c_int32), ("pad_", C.c_int32)]
+                ("img_lo", C.c_void_p), ("img_up", C.c_void_p), ("flags", C.c_int32), ("pad_", C.c_int32)]
 
 
 class HpmnPipe(C.Structure):
@@ -186,6 +186,9 @@ SIGNATURES = {
     "hpmn_gru_pair_fwd_supported": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),
     "hpmn_gru_pair_fwd_scratch_bytes": (C.c_size_t, []),
     "hpmn_gru_pair_fwd": (C.c_int, [C.POINTER(HpmnGruPairFwd), C.c_void_p]),
+    "hpmn_gru_proj_image_floats": (C.c_size_t, [C.c_int32]),
+    "hpmn_gru_proj_images": (C.c_int, [C.c_int32] + [C.POINTER(C.c_void_p)] * 4 + [C.POINTER(C.c_int32), C.POINTER(C.c_void_p),
+                                                                               C.c_void_p]),
     "hpmn_memory_update": (C.c_int, [C.POINTER(HpmnOnlineUpdate), C.c_void_p]),
     "hpmn_adam_step_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
                                       C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),

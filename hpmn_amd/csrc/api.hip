@@ -19,7 +19,11 @@ bool gru_fused_fwd_writes_last();
 int gru_fused_fwd_dispatch(const HpmnGruFusedFwd &a, hipStream_t st);
 bool gru_pair_fwd_supported(int H, int D_lo, int gather);
 size_t gru_pair_fwd_scratch_bytes();
-int gru_pair_fwd_launch(const HpmnGruFusedFwd &lo, const HpmnGruFusedFwd &up, int flags, float *scratch, hipStream_t st);
+int gru_pair_fwd_launch(const HpmnGruFusedFwd &lo, const HpmnGruFusedFwd &up, int flags, float *scratch,
+                        const float *img_lo, const float *img_up, hipStream_t st);
+size_t gru_proj_image_floats(int D);
+int gru_proj_images_launch(int n, const float *const *wg, const float *const *bg, const float *const *wc,
+                           const float *const *bc, const int *D, float *const *img, hipStream_t st);
 int input_proj_dispatch(const HpmnInputProj &a, hipStream_t st);
 int gru_wgrad_dispatch(const HpmnGruWgrad &a, hipStream_t st);
 int gru_dx_dispatch(const HpmnGruWgrad &a, hipStream_t st);
@@ -386,6 +390,18 @@ int hpmn_gru_pair_fwd_supported(int32_t H, int32_t D_lo, int32_t gather) {
 
 size_t hpmn_gru_pair_fwd_scratch_bytes(void) { return gru_pair_fwd_scratch_bytes(); }
 
+size_t hpmn_gru_proj_image_floats(int32_t D) { return (D == 32 || D == 64) ? gru_proj_image_floats(D) : 0; }
+
+int hpmn_gru_proj_images(int32_t n, const float *const *wg, const float *const *bg, const float *const *wc,
+                         const float *const *bc, const int32_t *D, float *const *img, void *stream) {
+    drop_stale_hip_error();
+    if (n < 0 || n > HPMN_MAX_LAYERS || (n > 0 && (!wg || !bg || !wc || !bc || !D || !img))) return HPMN_EINVAL;
+    if (n == 0) return HPMN_OK;
+    for (int i = 0; i < n; ++i)
+        if (!wg[i] || !bg[i] || !wc[i] || !bc[i] || !img[i] || (reinterpret_cast<size_t>(img[i]) & 15) != 0) return HPMN_EINVAL;
+    return gru_proj_images_launch(n, wg, bg, wc, bc, D, img, (hipStream_t)stream);
+}
+
 static int fused_args_ok(const HpmnGruFusedFwd *a, bool needs_input) {
     if (a->B < 0 || a->T < 1 || a->period < 1) return HPMN_EINVAL;
     if (!a->wg || !a->bg || !a->wc || !a->bc || !a->h_last) return HPMN_EINVAL;
@@ -401,7 +417,9 @@ static int fused_args_ok(const HpmnGruFusedFwd *a, bool needs_input) {
 
 int hpmn_gru_pair_fwd(const HpmnGruPairFwd *p, void *stream) {
     drop_stale_hip_error();
-    if (p == nullptr || p->scratch == nullptr || (reinterpret_cast<size_t>(p->scratch) & 15) != 0) return HPMN_EINVAL;
+    if (p == nullptr || (reinterpret_cast<size_t>(p->scratch) & 15) != 0) return HPMN_EINVAL;
+    if ((reinterpret_cast<size_t>(p->img_lo) & 15) != 0 || (reinterpret_cast<size_t>(p->img_up) & 15) != 0) return HPMN_EINVAL;
+    if (p->scratch == nullptr && (p->img_up == nullptr || (p->lo.D > 32 && p->img_lo == nullptr))) return HPMN_EINVAL;
     int rc = fused_args_ok(&p->lo, true);
     if (rc != HPMN_OK) return rc;
     rc = fused_args_ok(&p->up, false);
@@ -412,7 +430,8 @@ int hpmn_gru_pair_fwd(const HpmnGruPairFwd *p, void *stream) {
     if (!gru_pair_fwd_supported(p->lo.H, p->lo.D, p->lo.x == nullptr)) return HPMN_EUNSUPPORTED;
     if (p->lo.x == nullptr && p->lo.E % 4 != 0) return HPMN_EUNSUPPORTED;
     if (p->lo.B == 0) return HPMN_OK;
-    return gru_pair_fwd_launch(p->lo, p->up, p->flags, reinterpret_cast<float *>(p->scratch), (hipStream_t)stream);
+    return gru_pair_fwd_launch(p->lo, p->up, p->flags, reinterpret_cast<float *>(p->scratch), p->img_lo, p->img_up,
+                               (hipStream_t)stream);
 }
 
 int hpmn_memory_update(const HpmnOnlineUpdate *a, void *stream) {

@@ -76,7 +76,7 @@ __device__ __forceinline__ void pair_chain_wave(const HpmnGruFusedFwd &a, SeqLds
         asm volatile("" ::: "memory");
     }
     float h = 0.f;
-    int u_seen = 0;
+    int u_seen = 0, p_seen = 0;
     float xr = S.ring[0][l], xu = S.ring[0][H + l], xcand = S.ring[0][2 * H + l];
 
     auto step = [&](int t, int p) {
@@ -87,12 +87,11 @@ __device__ __forceinline__ void pair_chain_wave(const HpmnGruFusedFwd &a, SeqLds
         S.rhb[lane] = r * h;
         wave_sync();
         const float cc = tanh_scaled(xcand + split_matvec<2>(&S.rhb[0], whc, lane));
-        // crossing into the next 16-step block: its last tile is in the ring once the producer's iteration 16 q + 12 has
-        // started (gru_fused_fwd3.hip)
-        if (((t + 1) & (QB - 1)) == 0) {
-            while (u_seen < t - 2) {
-                u_seen = lds_counter_peek(&S.u_pub);
-                if (SLEEPY && u_seen < t - 2) __builtin_amdgcn_s_sleep(2);
+        // crossing into the next 16-step block: the producer has published it as projected
+        if (((t + 1) & (QB - 1)) == 0 && t + 1 < T) {
+            while (p_seen <= t + 1) {
+                p_seen = lds_counter_peek(&S.produced);
+                if (SLEEPY && p_seen <= t + 1) __builtin_amdgcn_s_sleep(2);
             }
             asm volatile("" ::: "memory");
         }
@@ -131,7 +130,7 @@ __device__ __forceinline__ void pair_chain_wave(const HpmnGruFusedFwd &a, SeqLds
 // held in registers.
 template <int D, int SRC, bool TRAIN, bool YOUT, bool WIMG, bool SLEEPY>
 __device__ __forceinline__ void pair_producer_wave(const HpmnGruFusedFwd &a, SeqLds<TRAIN> &S, YLds *yi, YLds *yo,
-                                                   const float *wimg, const long b, const int lane) {
+                                                   const float *wimg, const long b, const int lane, const bool alone = false) {
     constexpr int H = QH;
     constexpr int NJ = D / 16;
     const int T = a.T, l = lane;
@@ -249,33 +248,6 @@ __device__ __forceinline__ void pair_producer_wave(const HpmnGruFusedFwd &a, Seq
     Rows rA, rB;
     q4 wT[NJ];          // WIMG: the A operands of the tile the next iteration issues
     float bT = 0.f;
-    // block 0 before the loop
-    {
-        if constexpr (SRC == SRC_LDS) {
-            take_rows(0, rA);
-        } else {
-            fetch_ids(0, idA);
-            fetch_ids(QB, idB);
-            fetch_rows(0, idA, rA);
-            fetch_ids(2 * QB, idA);
-            fetch_rows(QB, idB, rB);
-        }
-        finish_rows(0, rA);
-#pragma unroll
-        for (int ct = 0; ct < QNT; ++ct) {
-            q4 acc;
-            if constexpr (WIMG) {
-                load_tile_w(ct, wT, bT);
-                acc = tile_mfma(wT, bT, rA);
-            } else {
-                acc = tile_stationary(ct, rA);
-            }
-            *reinterpret_cast<q4 *>(&S.ring[n16][16 * ct + 4 * g]) = acc;
-        }
-        lds_counter_set(&S.produced, QB);
-        if constexpr (SRC != SRC_LDS) rA = rB;        // rows of block 1 (in flight); idA: ids of block 2
-        if constexpr (WIMG) load_tile_w(0, wT, bT);
-    }
 
     const int period = a.period;
     const bool has_y = a.y != nullptr;
@@ -328,16 +300,62 @@ __device__ __forceinline__ void pair_producer_wave(const HpmnGruFusedFwd &a, Seq
             yrow += fire ? 1 : 0;
             lds_counter_set(&yo->pub, yrow);
         }
-        if constexpr (TILE >= 0)
+        if constexpr (TILE >= 0) {
             *reinterpret_cast<q4 *>(&S.ring[(s_next + n16) & (QRING - 1)][16 * TILE + 4 * g]) = acc;
+            if constexpr (TILE == QNT - 1) lds_counter_set(&S.produced, s_next + QB);
+        }
+    };
+    // all twelve tiles of the block at s0 in one go (rows in r): block 0, before the loop.  (Doing this for EVERY block of
+    // the upper layer -- run the block it has, then project the next the moment its rows arrive, which would keep the upper
+    // chain one block closer to the lower -- was measured: 599 vs 519 us for layers 0+1 at C3; the twelve tiles back to back
+    // hold the matrix pipe of the SIMD the lower producer lives on for 2.7 us per block, and the lower chain waits it out.)
+    auto project_block = [&](int s0, const Rows &r) {
+        if constexpr (WIMG) {
+            // (the A operands of tile ct + 3 leave L2 while tile ct is on the matrix pipe: twelve dependent round trips
+            //  in a row made this 8 us instead of 3)
+            q4 wq[3][NJ];
+            float bq[3];
+            load_tile_w(0, wq[0], bq[0]);
+            load_tile_w(1, wq[1], bq[1]);
+            load_tile_w(2, wq[2], bq[2]);
+#pragma unroll
+            for (int ct = 0; ct < QNT; ++ct) {
+                const q4 acc = tile_mfma(wq[ct % 3], bq[ct % 3], r);
+                if (ct + 3 < QNT) load_tile_w(ct + 3, wq[ct % 3], bq[ct % 3]);
+                *reinterpret_cast<q4 *>(&S.ring[(s0 + n16) & (QRING - 1)][16 * ct + 4 * g]) = acc;
+            }
+        } else {
+#pragma unroll
+            for (int ct = 0; ct < QNT; ++ct) {
+                const q4 acc = tile_stationary(ct, r);
+                *reinterpret_cast<q4 *>(&S.ring[(s0 + n16) & (QRING - 1)][16 * ct + 4 * g]) = acc;
+            }
+        }
+        lds_counter_set(&S.produced, s0 + QB);
     };
     auto full_block = [&](int s0, auto... is) {
         (iteration(s0 + decltype(is)::value, std::integral_constant<int, (decltype(is)::value < QNT ? decltype(is)::value : -1)>{},
                    s0 + QB), ...);
     };
+    // block 0 before the loop
+    {
+        if constexpr (SRC == SRC_LDS) {
+            take_rows(0, rA);
+        } else {
+            fetch_ids(0, idA);
+            fetch_ids(QB, idB);
+            fetch_rows(0, idA, rA);
+            fetch_ids(2 * QB, idA);
+            fetch_rows(QB, idB, rB);
+        }
+        finish_rows(0, rA);
+        project_block(0, rA);
+        if constexpr (SRC != SRC_LDS) rA = rB;        // rows of block 1 (in flight); idA: ids of block 2
+        if constexpr (WIMG) load_tile_w(0, wT, bT);
+    }
 
     for (int s0 = 0; s0 < T; s0 += QB) {
-        if constexpr (YOUT) {
+        if (YOUT && !alone) {
             // the ring slots this block writes (rows up to (s0 + 16) / period) must have been taken by the upper layer
             const int idx_max = (s0 + QB) / period;
             while (taken_seen <= idx_max - QYR) {
@@ -346,6 +364,7 @@ __device__ __forceinline__ void pair_producer_wave(const HpmnGruFusedFwd &a, Seq
             }
             asm volatile("" ::: "memory");
         }
+        using std::integral_constant;
         if constexpr (SRC == SRC_LDS) {
             if (s0 + QB < T) take_rows(s0 + QB, rA);
         } else {
@@ -355,7 +374,6 @@ __device__ __forceinline__ void pair_producer_wave(const HpmnGruFusedFwd &a, Seq
         if (s0 + QB < T) {                            // wave-uniform
             finish_rows(s0 + QB, rA);
             {
-                using std::integral_constant;
                 full_block(s0, integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, 2>{},
                            integral_constant<int, 3>{}, integral_constant<int, 4>{}, integral_constant<int, 5>{},
                            integral_constant<int, 6>{}, integral_constant<int, 7>{}, integral_constant<int, 8>{},
@@ -412,6 +430,8 @@ __global__ __launch_bounds__(512, 2) void gru_pair_fwd_kernel(const PairFwdArgs 
     if ((p.flags & 1) && role >= 2) role ^= 1;
     const long b = 2 * (long)blockIdx.x + seq;
     if (b >= p.lo.B) return;                         // odd batch (before the barrier: ended waves do not take part in it)
+    const bool alone = (p.flags & 2) != 0;           // (measurement: the lower layer only)
+    if (alone && role >= 2) return;
     SeqLds<TRAIN> &SL = lds_[0][seq], &SU = lds_[1][seq];
     YLds &Y = y_[seq];
     if (role == 0) {
@@ -428,7 +448,7 @@ __global__ __launch_bounds__(512, 2) void gru_pair_fwd_kernel(const PairFwdArgs 
         pair_chain_wave<TRAIN, false>(p.lo, SL, lane);
     } else if (role == 1) {
         __builtin_amdgcn_s_setprio(2);
-        pair_producer_wave<D0, SRC0, TRAIN, true, (D0 > 32), false>(p.lo, SL, nullptr, &Y, p.wimg_lo, b, lane);
+        pair_producer_wave<D0, SRC0, TRAIN, true, (D0 > 32), false>(p.lo, SL, nullptr, &Y, p.wimg_lo, b, lane, alone);
     } else if (role == 2) {
         __builtin_amdgcn_s_setprio(1);
         pair_chain_wave<TRAIN, true>(p.up, SU, lane);
@@ -440,10 +460,19 @@ __global__ __launch_bounds__(512, 2) void gru_pair_fwd_kernel(const PairFwdArgs 
 
 // A-operand image of one layer's input projection for the producers that stream it: tile (ct, kq), lane (n16, g),
 // component c  <-  W[feature 16 kq + 4 g + c][column 16 ct + n16] in the exponent domain; behind the tiles the bias of
-// every tile as the A operand of its extra k-step (lane group g == 0 only).
-__global__ void pair_wimg_kernel(const float *wg, const float *bg, const float *wc, const float *bc, int D, float *img) {
+// every tile as the A operand of its extra k-step (lane group g == 0 only).  blockIdx.y = layer of the batch.
+struct WimgBatch {
+    const float *wg[HPMN_MAX_LAYERS], *bg[HPMN_MAX_LAYERS], *wc[HPMN_MAX_LAYERS], *bc[HPMN_MAX_LAYERS];
+    float *img[HPMN_MAX_LAYERS];
+    int D[HPMN_MAX_LAYERS];
+};
+
+__global__ void pair_wimg_kernel(const WimgBatch w) {
     constexpr int H = QH;
-    const int NJ = D / 16;
+    const int L = blockIdx.y;
+    const int D = w.D[L], NJ = D / 16;
+    const float *wg = w.wg[L], *bg = w.bg[L], *wc = w.wc[L], *bc = w.bc[L];
+    float *img = w.img[L];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int ntile = QNT * NJ * 64;
     if (i < ntile) {
@@ -464,33 +493,47 @@ __global__ void pair_wimg_kernel(const float *wg, const float *bg, const float *
     }
 }
 
-size_t gru_pair_fwd_wimg_floats(int D) { return (size_t)QNT * (D / 16) * 256 + QNT * 64; }
+size_t gru_proj_image_floats(int D) { return (size_t)QNT * (D / 16) * 256 + QNT * 64; }
 
 bool gru_pair_fwd_supported(int H, int D_lo, int gather) {
     return H == QH && ((D_lo == 32 && gather) || D_lo == 64);
 }
 
-static int wimg_launch(const HpmnGruFusedFwd &a, float *img, hipStream_t st) {
-    const int n = QNT * (a.D / 16) * 64 + QNT * 64;
-    hipLaunchKernelGGL(pair_wimg_kernel, dim3((n + 255) / 256), dim3(256), 0, st, a.wg, a.bg, a.wc, a.bc, a.D, img);
+// images of n layers in ONE launch (D[i] in {32, 64}, H = 64); img[i]: gru_proj_image_floats(D[i]) floats, 16-byte aligned
+int gru_proj_images_launch(int n, const float *const *wg, const float *const *bg, const float *const *wc,
+                           const float *const *bc, const int *D, float *const *img, hipStream_t st) {
+    if (n < 1 || n > HPMN_MAX_LAYERS) return HPMN_EINVAL;
+    WimgBatch w = {};
+    for (int i = 0; i < n; ++i) {
+        if (D[i] != 32 && D[i] != 64) return HPMN_EUNSUPPORTED;
+        w.wg[i] = wg[i]; w.bg[i] = bg[i]; w.wc[i] = wc[i]; w.bc[i] = bc[i]; w.img[i] = img[i]; w.D[i] = D[i];
+    }
+    const int nmax = QNT * 4 * 64 + QNT * 64;
+    hipLaunchKernelGGL(pair_wimg_kernel, dim3((nmax + 255) / 256, n), dim3(256), 0, st, w);
     return check_launch();
 }
 
-// scratch: >= gru_pair_fwd_scratch_bytes() bytes of device memory for the A-operand images of this launch
-size_t gru_pair_fwd_scratch_bytes() { return 2 * gru_pair_fwd_wimg_floats(64) * sizeof(float); }
+// scratch of a launch that builds its own images
+size_t gru_pair_fwd_scratch_bytes() { return 2 * gru_proj_image_floats(64) * sizeof(float); }
 
-int gru_pair_fwd_launch(const HpmnGruFusedFwd &lo, const HpmnGruFusedFwd &up, int flags, float *scratch, hipStream_t st) {
+// img_lo / img_up: ready-made images (gru_proj_images_launch) or NULL: built here, into scratch
+int gru_pair_fwd_launch(const HpmnGruFusedFwd &lo, const HpmnGruFusedFwd &up, int flags, float *scratch,
+                        const float *img_lo, const float *img_up, hipStream_t st) {
     PairFwdArgs p = {};
     p.lo = lo; p.up = up; p.flags = flags;
-    float *img_up = scratch, *img_lo = scratch + gru_pair_fwd_wimg_floats(64);
-    int rc = wimg_launch(up, img_up, st);
-    if (rc != HPMN_OK) return rc;
-    p.wimg_up = img_up;
-    if (lo.D > 32) {
-        rc = wimg_launch(lo, img_lo, st);
+    const bool need_lo = lo.D > 32;
+    if (img_up == nullptr || (need_lo && img_lo == nullptr)) {
+        if (scratch == nullptr) return HPMN_EINVAL;
+        float *imgs[2] = {scratch, scratch + gru_proj_image_floats(64)};
+        const float *wg[2] = {up.wg, lo.wg}, *bg[2] = {up.bg, lo.bg}, *wc[2] = {up.wc, lo.wc}, *bc[2] = {up.bc, lo.bc};
+        const int D[2] = {up.D, lo.D};
+        const int rc = gru_proj_images_launch(need_lo ? 2 : 1, wg, bg, wc, bc, D, imgs, st);
         if (rc != HPMN_OK) return rc;
-        p.wimg_lo = img_lo;
+        img_up = imgs[0];
+        img_lo = imgs[1];
     }
+    p.wimg_up = img_up;
+    p.wimg_lo = need_lo ? img_lo : nullptr;
     const bool train = lo.hs != nullptr;
     const dim3 grid((lo.B + 1) / 2), blk(512);
     const bool gather = lo.x == nullptr;

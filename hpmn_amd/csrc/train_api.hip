@@ -14,7 +14,7 @@ int embed_gather_launch(const int32_t *ids, int64_t ids_stride, const float *emb
 bool gru_fused_fwd_supported(int H, int D, int gather);
 bool gru_fused_fwd_writes_last();
 bool gru_pair_fwd_supported(int H, int D_lo, int gather);
-size_t gru_pair_fwd_scratch_bytes();
+size_t gru_proj_image_floats(int D);
 size_t gru_wgrad_workspace_bytes(int B, int T, int D, int H);
 bool gru_scan_bwd_fuses_dx(int H, int B);
 bool gru_scan_bwd_dx_width_ok(int D);
@@ -66,7 +66,7 @@ static bool layout(const HpmnScanDesc &d, HpmnTrainLayout &L) {
     L.wgrad_ws = off;
     off += up256(wmax);
     L.pair_ws = off;
-    off += up256(gru_pair_fwd_scratch_bytes());
+    off += up256((size_t)d.K * gru_proj_image_floats(64) * sizeof(float));
     L.total_bytes = off + 256;
     return true;
 }
@@ -149,6 +149,9 @@ int hpmn_scan_fwd_train(HpmnTrainCtx *ctx, const HpmnScanDesc *d, const int32_t 
     static const int pair_env = [] { const char *e = getenv("HPMN_PAIR_FWD"); return e ? atoi(e) : 1; }();
     const bool pair_room = pair_env > 0 && (d->B + 1) / 2 <= c->cus;
     bool last_done = false;
+    const size_t img_stride = gru_proj_image_floats(64);
+    auto image = [&](int i) { return F(L.pair_ws) + (size_t)i * img_stride; };
+    bool images_built = false;
     auto fused_args = [&](int i) {
         const int D = i == 0 ? D0 : d->H;
         HpmnGruFusedFwd a = {};
@@ -176,11 +179,28 @@ int hpmn_scan_fwd_train(HpmnTrainCtx *ctx, const HpmnScanDesc *d, const int32_t 
         int rc;
         // (a pair pays while the upper layer is long enough to matter: below 8 steps it is one launch of a few us)
         if (fused && pair_room && i + 1 < d->K && L.T[i + 1] >= 8 && gru_pair_fwd_supported(d->H, D, i == 0)) {
+            if (!images_built) {
+                // every layer's projection weights as MFMA operand images, one launch in front of the first pair
+                const float *iwg[HPMN_MAX_LAYERS], *ibg[HPMN_MAX_LAYERS], *iwc[HPMN_MAX_LAYERS], *ibc[HPMN_MAX_LAYERS];
+                float *img[HPMN_MAX_LAYERS];
+                int32_t iD[HPMN_MAX_LAYERS];
+                int n = 0;
+                for (int j = i; j < d->K; ++j) {
+                    const int Dj = j == 0 ? D0 : d->H;
+                    if (Dj != 64) continue;
+                    iwg[n] = wg[j]; ibg[n] = bg[j]; iwc[n] = wc[j]; ibc[n] = bc[j]; img[n] = image(j); iD[n] = Dj;
+                    ++n;
+                }
+                rc = hpmn_gru_proj_images(n, iwg, ibg, iwc, ibc, iD, img, stream);
+                if (rc != HPMN_OK) return rc;
+                images_built = true;
+            }
             HpmnGruPairFwd p = {};
             p.lo = fused_args(i);
             p.up = fused_args(i + 1);
-            p.scratch = F(L.pair_ws);
-            p.flags = pair_env > 1 ? 1 : 0;
+            p.img_lo = D == 64 ? image(i) : nullptr;
+            p.img_up = image(i + 1);
+            p.flags = pair_env > 1 ? pair_env - 1 : 0;      // (2: upper roles swapped; 3: lower layers only -- measurement)
             rc = hpmn_gru_pair_fwd(&p, stream);
             if (rc != HPMN_OK) return rc;
             ++i;

@@ -166,8 +166,9 @@ int hpmn_gru_fused_fwd(const HpmnGruFusedFwd *args, void *stream);
  *        else needs the subsampled outputs, e.g. in inference)
  *   up : the upper layer: up.T == lo.T / lo.period, up.D == H, up.B == lo.B; up.x is IGNORED (the rows never
  *        leave the CU); everything else as for hpmn_gru_fused_fwd.  (lo.hs == NULL) == (up.hs == NULL).
- *   scratch : >= hpmn_gru_pair_fwd_scratch_bytes() bytes of device memory, 16-byte aligned (MFMA operand
- *        images of the projection weights, rewritten by every call on `stream`)
+ *   img_lo, img_up : the layers' projection weights as MFMA operand images (hpmn_gru_proj_images; img_lo is only
+ *        read when lo.D == 64), or NULL: the call builds them itself, in `scratch` (>= hpmn_gru_pair_fwd_scratch_bytes()
+ *        bytes of device memory, 16-byte aligned, rewritten by every such call on `stream`)
  *   flags : bit 0 swaps which SIMD pair hosts the upper layer's chain / producer waves (measurement switch)
  * Results are bit-identical to two hpmn_gru_fused_fwd calls.  One workgroup per CU is resident (two waves
  * per SIMD at 256 registers): meant for (B + 1) / 2 <= number of CUs; larger batches run but serialise.
@@ -175,8 +176,16 @@ int hpmn_gru_fused_fwd(const HpmnGruFusedFwd *args, void *stream);
 typedef struct HpmnGruPairFwd {
     HpmnGruFusedFwd lo, up;
     void *scratch;
+    const float *img_lo, *img_up;
     int32_t flags, pad_;
 } HpmnGruPairFwd;
+
+/* MFMA operand images of the input-projection weights of n layers (H = 64, D[i] in {32, 64}) in one launch: img[i]
+ * receives hpmn_gru_proj_image_floats(D[i]) floats (16-byte aligned).  They depend on the weights only: a caller that
+ * runs several pair launches per step builds all of them once, in front of the first. */
+size_t hpmn_gru_proj_image_floats(int32_t D);
+int hpmn_gru_proj_images(int32_t n, const float *const *wg, const float *const *bg, const float *const *wc,
+                         const float *const *bc, const int32_t *D, float *const *img, void *stream);
 
 int hpmn_gru_pair_fwd_supported(int32_t H, int32_t D_lo, int32_t gather);
 size_t hpmn_gru_pair_fwd_scratch_bytes(void);
@@ -306,7 +315,7 @@ typedef struct HpmnTrainLayout {
     uint64_t d_act[HPMN_MAX_LAYERS];       /* [B, T[i], 3H]                                                */
     uint64_t d_x[HPMN_MAX_LAYERS];         /* [B, T[i], D_i]                                               */
     uint64_t wgrad_ws, total_bytes;
-    uint64_t pair_ws;                      /* scratch of the two-layer launches (hpmn_gru_pair_fwd)         */
+    uint64_t pair_ws;                      /* K operand images of the two-layer launches (hpmn_gru_proj_images) */
 } HpmnTrainLayout;
 
 int hpmn_train_ctx_create(HpmnTrainCtx **ctx);

@@ -61,6 +61,6 @@ def bwd():
     ops.abi_backward(spec, ids, saved, weights, d_mem, d_last, grad_out)
 
 
-tb = timed(bwd)
+tb = timed(bwd) if not os.environ.get("FWD_ONLY") else 0.0
 print("B=%d T=%d K=%d F=%d  PAIR_FWD=%s PAIR_BWD=%s:  forward %.1f us   BPTT incl. weight gradients + scatter %.1f us"
       % (B, T, K, F, os.environ.get("HPMN_PAIR_FWD", "-"), os.environ.get("HPMN_PAIR_BWD", "-"), tf, tb), flush=True)
