@@ -114,6 +114,10 @@ class HpmnGruPairFwd(C.Structure):
                 ("img_lo", C.c_void_p), ("img_up", C.c_void_p), ("flags", C.c_int32), ("pad_", C.c_int32)]
 
 
+class HpmnGruPairBwd(C.Structure):
+    _fields_ = [("lo", HpmnGruBwd), ("up", HpmnGruBwd), ("flags", C.c_int32), ("pad_", C.c_int32)]
+
+
 class HpmnPipe(C.Structure):
     _fields_ = [
         ("B", C.c_int32), ("K", C.c_int32), ("H", C.c_int32), ("train", C.c_int32),
@@ -186,6 +190,8 @@ SIGNATURES = {
     "hpmn_gru_pair_fwd_supported": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),
     "hpmn_gru_pair_fwd_scratch_bytes": (C.c_size_t, []),
     "hpmn_gru_pair_fwd": (C.c_int, [C.POINTER(HpmnGruPairFwd), C.c_void_p]),
+    "hpmn_gru_pair_bwd_supported": (C.c_int, [C.c_int32, C.c_int32]),
+    "hpmn_gru_pair_bwd": (C.c_int, [C.POINTER(HpmnGruPairBwd), C.c_void_p]),
     "hpmn_gru_proj_image_floats": (C.c_size_t, [C.c_int32]),
     "hpmn_gru_proj_images": (C.c_int, [C.c_int32] + [C.POINTER(C.c_void_p)] * 4 + [C.POINTER(C.c_int32), C.POINTER(C.c_void_p),
                                                                                C.c_void_p]),

@@ -119,13 +119,16 @@ int adam_table_launch(float *p, float *g, float *m, float *v, uint8_t *flags, in
     const long n4 = V * (long)(E / 4);
     long blocks = (n4 + 255) / 256;
     // Pass 0 has the whole forward and BPTT to finish in and shares the chip with their latency-critical waves: a
-    // THIN grid (HPMN_ADAM_EARLY_WGS workgroups, default 192 -- less than one per CU) trickles through the table instead
+    // THIN grid (HPMN_ADAM_EARLY_WGS workgroups, default 256 -- one per CU) trickles through the table instead
     // of flooding every SIMD and the memory system at once (measured: with 4096 workgroups the layer-0 forward beside
     // it took 585 instead of 483 us).  Pass 1 is on the serial tail: full width.
-    // The thin grid moves ~2.2 TB/s: right for the 1.2 GB of the reference tables (0.54 ms, the forward takes 1 ms),
+    // (256, not the 192 of round 2: the pass has to be DONE when layer 0's forward launch is -- the two-layer launches
+    //  that follow it hold every register of their CUs and stretch by whatever still runs beside them; C3 step
+    //  2.823 / 2.771 / 2.786 ms at 192 / 256 / 320.)
+    // The thin grid moves ~2.5 TB/s: right for the 1.2 GB of the reference tables (0.45 ms, layer 0's forward takes as long),
     // hopeless for a table sized to HBM (256 M rows = 98 GB of optimiser traffic: 45 ms against a 10 ms chain --
     // measured 43 vs 33 ms/step) -- so it widens in proportion, up to the full width.
-    static const long early = [] { const char *e = getenv("HPMN_ADAM_EARLY_WGS"); return e ? atol(e) : 192L; }();
+    static const long early = [] { const char *e = getenv("HPMN_ADAM_EARLY_WGS"); return e ? atol(e) : 256L; }();
     long thin = early > 0 ? early : 256L * 16;
     const double gb = (double)V * E * 24.0 / 1.2e9;
     if (gb > 1.0) thin = (long)(thin * gb);

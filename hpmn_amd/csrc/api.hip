@@ -18,6 +18,8 @@ bool gru_fused_fwd_supported(int H, int D, int gather);
 bool gru_fused_fwd_writes_last();
 int gru_fused_fwd_dispatch(const HpmnGruFusedFwd &a, hipStream_t st);
 bool gru_pair_fwd_supported(int H, int D_lo, int gather);
+bool gru_pair_bwd_supported(int H, int D_lo);
+int gru_pair_bwd_launch(const HpmnGruBwd &lo, const HpmnGruBwd &up, int flags, hipStream_t st);
 size_t gru_pair_fwd_scratch_bytes();
 int gru_pair_fwd_launch(const HpmnGruFusedFwd &lo, const HpmnGruFusedFwd &up, int flags, float *scratch,
                         const float *img_lo, const float *img_up, hipStream_t st);
@@ -432,6 +434,25 @@ int hpmn_gru_pair_fwd(const HpmnGruPairFwd *p, void *stream) {
     if (p->lo.B == 0) return HPMN_OK;
     return gru_pair_fwd_launch(p->lo, p->up, p->flags, reinterpret_cast<float *>(p->scratch), p->img_lo, p->img_up,
                                (hipStream_t)stream);
+}
+
+int hpmn_gru_pair_bwd_supported(int32_t H, int32_t D_lo) { return gru_pair_bwd_supported(H, D_lo) ? 1 : 0; }
+
+int hpmn_gru_pair_bwd(const HpmnGruPairBwd *p, void *stream) {
+    drop_stale_hip_error();
+    if (p == nullptr) return HPMN_EINVAL;
+    const HpmnGruBwd *both[2] = {&p->lo, &p->up};
+    for (const HpmnGruBwd *a : both) {
+        if (a->B < 0 || a->T < 1 || a->D < 1 || a->H < 1 || a->period < 1) return HPMN_EINVAL;
+        if (!a->wg || !a->wc || !a->hs || !a->gates || !a->d_h_last || !a->d_act) return HPMN_EINVAL;
+        if (a->t_begin != 0 || a->t_end != 0) return HPMN_EINVAL;
+    }
+    if (p->up.B != p->lo.B || p->up.H != p->lo.H || p->up.D != p->lo.H) return HPMN_EINVAL;
+    if (p->lo.T % p->lo.period != 0 || p->up.T != p->lo.T / p->lo.period) return HPMN_EINVAL;
+    if (p->up.d_y != nullptr && p->up.T % p->up.period != 0) return HPMN_EINVAL;
+    if (!gru_pair_bwd_supported(p->lo.H, p->lo.D)) return HPMN_EUNSUPPORTED;
+    if (p->lo.B == 0) return HPMN_OK;
+    return gru_pair_bwd_launch(p->lo, p->up, p->flags, (hipStream_t)stream);
 }
 
 int hpmn_memory_update(const HpmnOnlineUpdate *a, void *stream) {

@@ -15,6 +15,7 @@ bool gru_fused_fwd_supported(int H, int D, int gather);
 bool gru_fused_fwd_writes_last();
 bool gru_pair_fwd_supported(int H, int D_lo, int gather);
 size_t gru_proj_image_floats(int D);
+bool gru_pair_bwd_supported(int H, int D_lo);
 size_t gru_wgrad_workspace_bytes(int B, int T, int D, int H);
 bool gru_scan_bwd_fuses_dx(int H, int B);
 bool gru_scan_bwd_dx_width_ok(int D);
@@ -145,9 +146,15 @@ int hpmn_scan_fwd_train(HpmnTrainCtx *ctx, const HpmnScanDesc *d, const int32_t 
     // the fused layer spends a second wave per sequence on a SIMD that would otherwise idle: a win while 2 B waves
     // still find (about) a SIMD each (measured at C3: +3.7 % at B=500, -6.6 % at B=750 / 1000)
     const bool room = 2.0 * d->B <= 1.1 * 4 * c->cus;
-    // two layers per launch (hpmn_gru_pair_fwd): one 8-wave workgroup per CU and two sequences
-    static const int pair_env = [] { const char *e = getenv("HPMN_PAIR_FWD"); return e ? atoi(e) : 1; }();
+    // Two layers per launch (hpmn_gru_pair_fwd): one 8-wave workgroup per CU and two sequences.  A pair launch holds
+    // every register of the CUs it runs on, so NOTHING can share the chip with it: whatever is queued on another stream
+    // either starves (the 5 us gradient clear took 486 us beside the pair of layers 0+1) or, worse, takes CUs away from
+    // it (the early table-Adam pass beside the pair of layers 2+3: 593 instead of 165 us, the whole step 3.01 instead of
+    // 2.89 ms).  HPMN_PAIR_FWD: 0 off; 1 pairs (0,1), (2,3), ...; 2 (default) layer 0 on its own -- its four-wave
+    // workgroups leave half of every CU to the caller's early optimiser pass -- and pairs (1,2), (3,4), ...
+    static const int pair_env = [] { const char *e = getenv("HPMN_PAIR_FWD"); return e ? atoi(e) : 2; }();
     const bool pair_room = pair_env > 0 && (d->B + 1) / 2 <= c->cus;
+    const int pair_first = pair_env == 1 ? 0 : 1;
     bool last_done = false;
     const size_t img_stride = gru_proj_image_floats(64);
     auto image = [&](int i) { return F(L.pair_ws) + (size_t)i * img_stride; };
@@ -178,7 +185,8 @@ int hpmn_scan_fwd_train(HpmnTrainCtx *ctx, const HpmnScanDesc *d, const int32_t 
         float *y = i + 1 < d->K ? F(L.y[i]) : nullptr;
         int rc;
         // (a pair pays while the upper layer is long enough to matter: below 8 steps it is one launch of a few us)
-        if (fused && pair_room && i + 1 < d->K && L.T[i + 1] >= 8 && gru_pair_fwd_supported(d->H, D, i == 0)) {
+        if (fused && pair_room && i >= pair_first && i + 1 < d->K && L.T[i + 1] >= 8 &&
+            gru_pair_fwd_supported(d->H, D, i == 0)) {
             if (!images_built) {
                 // every layer's projection weights as MFMA operand images, one launch in front of the first pair
                 const float *iwg[HPMN_MAX_LAYERS], *ibg[HPMN_MAX_LAYERS], *iwc[HPMN_MAX_LAYERS], *ibc[HPMN_MAX_LAYERS];
@@ -200,7 +208,6 @@ int hpmn_scan_fwd_train(HpmnTrainCtx *ctx, const HpmnScanDesc *d, const int32_t 
             p.up = fused_args(i + 1);
             p.img_lo = D == 64 ? image(i) : nullptr;
             p.img_up = image(i + 1);
-            p.flags = pair_env > 1 ? pair_env - 1 : 0;      // (2: upper roles swapped; 3: lower layers only -- measurement)
             rc = hpmn_gru_pair_fwd(&p, stream);
             if (rc != HPMN_OK) return rc;
             ++i;
@@ -270,19 +277,21 @@ int hpmn_scan_bwd(HpmnTrainCtx *ctx, const HpmnScanDesc *d, const int32_t *ids, 
         if (cut <= d->front_zero || cut >= L.T[0] + d->last_index) cut = 0;
     }
     bool scatter_pending = false;
-    HpmnGruWgrad held[4];
-    int nheld = 0;
-    for (int i = d->K - 1; i >= 0; --i) {
-        const int D = i == 0 ? D0 : d->H;
+    HpmnGruWgrad held[4], late[HPMN_MAX_LAYERS];
+    int nheld = 0, nlate = 0;
+    auto scan_args = [&](int i) {
         HpmnGruBwd a = {};
-        a.B = d->B; a.T = L.T[i]; a.D = D; a.H = d->H;
+        a.B = d->B; a.T = L.T[i]; a.D = i == 0 ? D0 : d->H; a.H = d->H;
         a.wg = wg[i]; a.wc = wc[i]; a.hs = F(L.hs[i]); a.gates = F(L.gates[i]);
         a.d_h_last = d_memory + (size_t)i * d->H; a.d_h_last_stride = (int64_t)d->K * d->H;
         a.d_y = i + 1 < d->K ? F(L.d_x[i + 1]) : nullptr;
         a.period = d->periods[i];
         a.d_act = F(L.d_act[i]);
+        return a;
+    };
+    auto wgrad_args = [&](int i) {
         HpmnGruWgrad w = {};
-        w.B = d->B; w.T = L.T[i]; w.D = D; w.H = d->H;
+        w.B = d->B; w.T = L.T[i]; w.D = i == 0 ? D0 : d->H; w.H = d->H;
         w.x = i == 0 ? F(L.x0) : F(L.y[i - 1]);
         w.hs = F(L.hs[i]); w.gates = F(L.gates[i]); w.d_act = F(L.d_act[i]);
         w.wg = wg[i]; w.wc = wc[i];
@@ -291,6 +300,50 @@ int hpmn_scan_bwd(HpmnTrainCtx *ctx, const HpmnScanDesc *d, const int32_t *ids, 
         // (layer 0's weight gradient runs beside the scatter and the table update, which are bandwidth kernels, and
         //  bounds the step's tail: it may fill the CUs -- 2.985 -> 2.905 ms/step at C3)
         w.whole_cu = i == 0 && d->H <= 64 ? 1 : 0;
+        return w;
+    };
+    // two layers per launch (hpmn_gru_pair_bwd).  HPMN_PAIR_BWD: 0 off; 1 pairs (1,0), (3,2), ...; 2 (default) layer 0
+    // alone and pairs (2,1), (4,3), ...
+    // Measured at C3 (BPTT incl. weight gradients and scatter, us): off 1624-1631; 1: 1631-1669 -- the chain of reverse
+    // scans drops from 1315 to 961, but a pair launch leaves the weight gradients no registers to run beside it, and
+    // 630 us of them end up exposed behind the last scan; 2: 1575-1586 -- the upper pairs save 166 us and layer 0's
+    // single-layer launch still hides the weight gradients (at 686 instead of 589 us).
+    static const int pair_env = [] { const char *e = getenv("HPMN_PAIR_BWD"); return e ? atoi(e) : 2; }();
+    const int pair_mode = pair_env <= 0 ? 0 : (pair_env == 1 ? 1 : 2);
+    const bool pair_ok = pair_mode > 0 && cut == 0 && (d->B + 1) / 2 <= c->cus && gru_scan_bwd_fuses_dx(d->H, d->B);
+    for (int i = d->K - 1; i >= 0; --i) {
+        const int D = i == 0 ? D0 : d->H;
+        if (pair_ok && i >= 1 && (i - 1) % 2 == (pair_mode == 1 ? 0 : 1) && L.T[i] >= 8 &&
+            gru_pair_bwd_supported(d->H, i - 1 == 0 ? D0 : d->H)) {
+            HpmnGruPairBwd p = {};
+            p.up = scan_args(i);
+            p.lo = scan_args(i - 1);
+            p.lo.d_x = F(L.d_x[i - 1]);
+            int rc = hpmn_gru_pair_bwd(&p, stream);
+            if (rc != HPMN_OK) return rc;
+            for (int h = 0; h < nheld; ++h) late[nlate++] = held[h];      // (of a single-layer launch in front of this pair)
+            nheld = 0;
+            // A pair launch holds every register of its CUs (eight waves of up to 256): a weight-gradient kernel forked
+            // beside it only gets the few CUs the launch leaves over (measured: 665 us instead of 150).  They are kept
+            // until the pairs are through (the queue of them is flushed where a single-layer launch follows: that one
+            // leaves half of every CU free) and may fill the CUs then.
+            late[nlate++] = wgrad_args(i);
+            late[nlate++] = wgrad_args(i - 1);
+            --i;
+            continue;
+        }
+        if (nlate > 0) {                       // a single-layer launch follows pairs: their weight gradients run beside it
+            HIPCHK(hipEventRecord(c->fork, st));
+            HIPCHK(hipStreamWaitEvent(c->side, c->fork, 0));
+            for (int h = 0; h < nlate; ++h) {
+                const int rc0 = hpmn_gru_param_grads(&late[h], c->side);
+                if (rc0 != HPMN_OK) return rc0;
+            }
+            nlate = 0;
+            c->pending = true;
+        }
+        HpmnGruBwd a = scan_args(i);
+        HpmnGruWgrad w = wgrad_args(i);
         if (i == 0 && cut > 0) {
             const int T0 = L.T[0];
             if (nheld) {                                   // (weight gradients of short layers still waiting for a fork)
@@ -362,6 +415,18 @@ int hpmn_scan_bwd(HpmnTrainCtx *ctx, const HpmnScanDesc *d, const int32_t *ids, 
             rc = hpmn_gru_input_grad(F(L.d_act[i]), wg[i], wc[i], F(L.d_x[i]), d->B, L.T[i], D, d->H, 0, 0, stream);
             if (rc != HPMN_OK) return rc;
         }
+    }
+    if (nlate > 0) {
+        // the pairs' weight gradients: nothing latency-critical is left on the chip, the largest (the last pair's) first
+        HIPCHK(hipEventRecord(c->fork, st));
+        HIPCHK(hipStreamWaitEvent(c->side, c->fork, 0));
+        for (int h = nlate - 1; h >= 0; --h) {
+            late[h].whole_cu = d->H <= 64 ? 1 : 0;
+            const int rc0 = hpmn_gru_param_grads(&late[h], c->side);
+            if (rc0 != HPMN_OK) return rc0;
+        }
+        nlate = 0;
+        c->pending = true;
     }
     // (d_last, the read path's gradient wrt uinp[:, last_index, :], rides into the scatter: ids step T + last_index)
     const bool last_in_scatter = d_last && !scatter_pending && d->T + d->last_index >= 0;

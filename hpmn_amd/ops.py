@@ -285,6 +285,26 @@ def gru_scan_bwd(wg, wc, D, hs, gates, d_h_last, d_y, period, out=None, t_range=
     return d_act
 
 
+def _fill_bwd(a, *, wg, wc, D, hs, gates, d_h_last, d_y, period, d_act, d_x=None):
+    B, T1, H = hs.shape
+    _chk_f32(wg, wc, hs, gates, d_y, d_act)
+    a.B, a.T, a.D, a.H = B, T1 - 1, D, H
+    a.wg, a.wc, a.hs, a.gates = wg.data_ptr(), wc.data_ptr(), hs.data_ptr(), gates.data_ptr()
+    assert d_h_last.stride(1) == 1 and d_h_last.shape == (B, H) and d_h_last.dtype == torch.float32
+    a.d_h_last, a.d_h_last_stride = d_h_last.data_ptr(), d_h_last.stride(0)
+    a.d_y, a.period, a.d_act, a.d_x = _ptr(d_y), period, d_act.data_ptr(), _ptr(d_x)
+
+
+def gru_pair_bwd(lo: dict, up: dict, flags: int = 0):
+    """hpmn_gru_pair_bwd: the reverse scans of two consecutive layers in one launch.  ``lo`` / ``up``: wg, wc, D, hs, gates,
+    d_h_last, period, d_act (+ ``up['d_y']`` from memory or None, ``lo['d_x']`` optional)."""
+    p = _lib.HpmnGruPairBwd()
+    _fill_bwd(p.lo, d_y=None, **lo)
+    _fill_bwd(p.up, **up)
+    p.flags = flags
+    _lib.check(_lib.load().hpmn_gru_pair_bwd(C.byref(p), _stream()), "hpmn_gru_pair_bwd")
+
+
 def gru_param_grads(x, hs, gates, d_act, wg, wc, d_wg, d_bg, d_wc, d_bc, want_dx=True, keep=None, t_range=None,
                     whole_cu=False):
     """hpmn_gru_param_grads: accumulates into d_wg/d_bg/d_wc/d_bc (caller-zeroed), returns dx or None.

@@ -226,6 +226,24 @@ typedef struct HpmnGruBwd {
 int hpmn_gru_scan_bwd(const HpmnGruBwd *args, void *stream);
 int hpmn_gru_scan_bwd_fuses_dx(int32_t H, int32_t B);
 
+/* The reverse scans of TWO consecutive layers in ONE launch (H = 64), the mirror of hpmn_gru_pair_fwd: the lower layer's
+ * scan runs while the upper layer's does.  A workgroup owns two sequences and both layers (eight waves); the upper
+ * layer's input gradient -- the d_y of the lower layer's firing steps -- is formed on the matrix cores underneath the upper
+ * layer's own iterations and handed over through an LDS ring; it is never written to memory.
+ *   up : the upper layer as for hpmn_gru_scan_bwd (whole sequences: t_begin == t_end == 0); up.d_y from memory or NULL;
+ *        up.d_x is IGNORED; up.D == H
+ *   lo : the lower layer; lo.d_y is IGNORED (it comes from `up`); lo.T == up.T * lo.period; lo.d_x optional
+ *        (D in {16, 32, 64}): the lower layer's input gradient, an epilogue of the launch shared by all four waves of the
+ *        sequence
+ * Results equal two hpmn_gru_scan_bwd calls (d_act bit-identical).  (B + 1) / 2 <= number of CUs, as for the forward. */
+typedef struct HpmnGruPairBwd {
+    HpmnGruBwd lo, up;
+    int32_t flags, pad_;
+} HpmnGruPairBwd;
+
+int hpmn_gru_pair_bwd_supported(int32_t H, int32_t D_lo);
+int hpmn_gru_pair_bwd(const HpmnGruPairBwd *args, void *stream);
+
 /* ------------------------------------------------------------------------------------
  * One GRU layer, parameter and input gradients -- the time-parallel half of BPTT (TF
  * autodiff of the two _Linear matmuls, code/util.py:88-107, summed over all time steps):

@@ -41,7 +41,7 @@ def test_struct_layout_matches_c_compiler(tmp_path):
     structs = {"HpmnInputProj": _lib.HpmnInputProj, "HpmnGruFwd": _lib.HpmnGruFwd,
                "HpmnGruBwd": _lib.HpmnGruBwd, "HpmnGruWgrad": _lib.HpmnGruWgrad, "HpmnReadDesc": _lib.HpmnReadDesc,
                "HpmnScanDesc": _lib.HpmnScanDesc, "HpmnOnlineUpdate": _lib.HpmnOnlineUpdate,
-               "HpmnGruFusedFwd": _lib.HpmnGruFusedFwd, "HpmnGruPairFwd": _lib.HpmnGruPairFwd, "HpmnPipe": _lib.HpmnPipe,
+               "HpmnGruFusedFwd": _lib.HpmnGruFusedFwd, "HpmnGruPairFwd": _lib.HpmnGruPairFwd, "HpmnGruPairBwd": _lib.HpmnGruPairBwd, "HpmnPipe": _lib.HpmnPipe,
                "HpmnTrainLayout": _lib.HpmnTrainLayout}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "hpmn_hip.h"', "int main(void){"]
     for name, st in structs.items():

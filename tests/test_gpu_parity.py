@@ -938,7 +938,9 @@ def test_scans_give_the_same_result_beside_an_unrelated_kernel(dev, tmp_path, B,
     {"HPMN_BWD_HELPER": "1", "HPMN_FUSED_FWD_GEN": "1"},                       # the first-generation two-wave kernels
     {"HPMN_BWD_HELPER": "0", "HPMN_FUSED_FWD": "0", "HPMN_TWO_PASS_ADAM": "0"},  # one wave per sequence, two-kernel forward
     {"HPMN_BWD_DX_WAVE": "0", "HPMN_L0_SPLIT": "1"},                           # separate input-gradient launches, layer 0 split in time
-], ids=["gen1", "one-wave", "dx-launches+split"])
+    {"HPMN_PAIR_FWD": "0", "HPMN_PAIR_BWD": "0"},                              # one launch per layer (no two-layer launches)
+    {"HPMN_PAIR_FWD": "2", "HPMN_PAIR_BWD": "1"},                              # the other pairing / SIMD assignment
+], ids=["gen1", "one-wave", "dx-launches+split", "no-pairs", "pairs-alt"])
 def test_fallback_kernel_paths_still_match_the_oracle(env):
     """The switches of DESIGN.md 3.11 select kernels at library load, so each set runs a slice of this file in a
     process of its own: H = 64 forward/gradient parity at the tiny and odd lengths and at the XLong length."""
@@ -1026,3 +1028,66 @@ def test_two_layers_in_one_launch_equal_two_launches(dev, name, B, T, src, p_lo,
             assert (a is None) == (b is None)
             if a is not None:
                 assert torch.equal(a, b), "output %d differs (flags %d)" % (i, flags)
+
+
+PAIR_BWD_CASES = [
+    # name, B, T_lo, D_lo, period_lo, period_up (0: the upper layer is the top layer, no d_y)
+    ("xlong-l1l0", 9, 1024, 32, 2, 2),
+    ("xlong-l3l2", 5, 256, 64, 2, 2),
+    ("top", 4, 32, 64, 2, 0),
+    ("taobao-l3l2", 3, 75, 64, 3, 5),
+    ("period5", 2, 400, 32, 5, 1),
+    ("one-block", 3, 32, 16, 2, 2),
+    ("odd-rows", 6, 46, 64, 2, 0),
+    ("odd-upper", 3, 27, 32, 3, 3),
+    ("wide", 301, 64, 32, 2, 2),
+]
+
+
+@pytest.mark.parametrize("name,B,T,D,p_lo,p_up", PAIR_BWD_CASES, ids=[c[0] for c in PAIR_BWD_CASES])
+def test_two_reverse_scans_in_one_launch_equal_two_launches(dev, name, B, T, D, p_lo, p_up):
+    """hpmn_gru_pair_bwd against two hpmn_gru_scan_bwd calls (the upper with its input gradient as the epilogue, the lower
+    reading it back as d_y): the same arithmetic (the compiler contracts a few multiply-adds of the coefficient
+    arithmetic differently in the two kernels, so last-bit differences are allowed: 5e-6 of each tensor's max after up to
+    1024 steps) -- with either SIMD assignment, beside an unrelated kernel too."""
+    from hpmn_amd import ops
+    H = 64
+    g = torch.Generator(device="cpu").manual_seed(len(name) * 7 + B)
+    Tu = T // p_lo
+    assert T % p_lo == 0 and (p_up == 0 or Tu % p_up == 0)
+
+    def w(*shape, scale=0.3):
+        return (torch.randn(*shape, generator=g) * scale).to(dev)
+
+    def layer(Tl, Dl):
+        gates = torch.rand(B, Tl, 3 * H, generator=g)
+        gates[..., 2 * H:] = gates[..., 2 * H:] * 2 - 1                # r, u in (0,1), c in (-1,1)
+        return dict(wg=w(Dl + H, 2 * H), wc=w(Dl + H, H), D=Dl, hs=w(B, Tl + 1, H, scale=0.7), gates=gates.to(dev))
+    lo, up = layer(T, D), layer(Tu, H)
+    d_mem = w(B, 2, H, scale=0.1)
+    d_y_up = w(B, Tu // p_up, H, scale=0.1) if p_up else None
+    per_up = p_up if p_up else 1
+
+    # reference: two launches
+    dact_up = torch.full((B, Tu, 3 * H), 7.0, device=dev)
+    dx_up = torch.full((B, Tu, H), 7.0, device=dev)
+    ops.gru_scan_bwd(up["wg"], up["wc"], H, up["hs"], up["gates"], d_mem[:, 1], d_y_up, per_up, out=dact_up, d_x=dx_up)
+    dact_lo = torch.full((B, T, 3 * H), 7.0, device=dev)
+    dx_lo = torch.full((B, T, D), 7.0, device=dev)
+    ops.gru_scan_bwd(lo["wg"], lo["wc"], D, lo["hs"], lo["gates"], d_mem[:, 0], dx_up, p_lo, out=dact_lo, d_x=dx_lo)
+    junk = torch.empty(200_000_000, device=dev)
+    side = torch.cuda.Stream()
+    for flags in (0, 1, 0, 1):
+        a_up = torch.full((B, Tu, 3 * H), 7.0, device=dev)
+        a_lo = torch.full((B, T, 3 * H), 7.0, device=dev)
+        x_lo = torch.full((B, T, D), 7.0, device=dev)
+        if flags:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                junk.zero_()
+        ops.gru_pair_bwd(dict(**lo, d_h_last=d_mem[:, 0], period=p_lo, d_act=a_lo, d_x=x_lo),
+                         dict(**up, d_h_last=d_mem[:, 1], period=per_up, d_act=a_up, d_y=d_y_up), flags=flags)
+        torch.cuda.synchronize()
+        for what, got, want in (("upper d_act", a_up, dact_up), ("lower d_act", a_lo, dact_lo), ("lower d_x", x_lo, dx_lo)):
+            err = float((got - want).abs().max()) / float(want.abs().max())
+            assert err <= 5e-6, "%s (flags %d): %g of the tensor's max" % (what, flags, err)
