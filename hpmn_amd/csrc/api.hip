@@ -198,12 +198,80 @@ static void scan_ws_sizes(const HpmnScanDesc &d, const int32_t *len, size_t &xp_
     y_bytes = d.K > 1 ? align_up((size_t)d.B * (size_t)(len[0] / d.periods[0]) * d.H * sizeof(float), 256) : 0;
 }
 
+// operand images of the two-layer launches (the paired inference path below), behind the buffers above
+static size_t scan_img_bytes(const HpmnScanDesc &d) {
+    return align_up((size_t)d.K * gru_proj_image_floats(64) * sizeof(float), 256);
+}
+
 size_t hpmn_scan_workspace_bytes(const HpmnScanDesc *d) {
     int32_t len[HPMN_MAX_LAYERS];
     if (!d || d->B < 0 || d->H < 1 || !layer_lengths(*d, len)) return 0;
     size_t xp_bytes, y_bytes;
     scan_ws_sizes(*d, len, xp_bytes, y_bytes);
-    return xp_bytes + 2 * y_bytes + 256;
+    return xp_bytes + 2 * y_bytes + scan_img_bytes(*d) + 256;
+}
+
+// Inference with two layers per launch (H = 64): pairs (0,1), (2,3), ... of hpmn_gru_pair_fwd without saved states, an odd
+// last layer through hpmn_gru_fused_fwd.  The rows between the layers of a pair never reach memory; nothing else runs on
+// the chip during an evaluation pass, so the pairs may start at layer 0, and a batch larger than two sequences per CU just
+// queues (the workgroups of a launch are independent).  HPMN_PAIR_INFER=0: the two-kernel layers below.
+static bool scan_fwd_pairs_ok(const HpmnScanDesc &d, int D0) {
+    static const int on = [] { const char *e = getenv("HPMN_PAIR_INFER"); return e ? atoi(e) : 1; }();
+    return on && d.K >= 2 && d.E % 4 == 0 && gru_pair_fwd_supported(d.H, D0, 1);
+}
+
+static int scan_fwd_pairs(const HpmnScanDesc &d, const int32_t *len, const int32_t *ids, const float *emb,
+                          const float *const *wg, const float *const *bg, const float *const *wc, const float *const *bc,
+                          float *memory, float *last, float *const *ybuf, float *img_base, hipStream_t st) {
+    const int D0 = d.F * d.E, K = d.K, H = d.H;
+    const size_t img_stride = gru_proj_image_floats(64);
+    {
+        const float *iwg[HPMN_MAX_LAYERS], *ibg[HPMN_MAX_LAYERS], *iwc[HPMN_MAX_LAYERS], *ibc[HPMN_MAX_LAYERS];
+        float *img[HPMN_MAX_LAYERS];
+        int iD[HPMN_MAX_LAYERS], n = 0;
+        for (int j = 0; j < K; ++j) {
+            if ((j == 0 ? D0 : H) != 64) continue;
+            iwg[n] = wg[j]; ibg[n] = bg[j]; iwc[n] = wc[j]; ibc[n] = bc[j]; img[n] = img_base + j * img_stride; iD[n] = 64;
+            ++n;
+        }
+        const int rc = gru_proj_images_launch(n, iwg, ibg, iwc, ibc, iD, img, st);
+        if (rc != HPMN_OK) return rc;
+    }
+    int in_buf = 0;                                  // which of the two row buffers the next launch reads its input from
+    auto layer = [&](int i) {
+        HpmnGruFusedFwd a = {};
+        a.B = d.B; a.T = len[i]; a.D = i == 0 ? D0 : H; a.H = H;
+        if (i == 0) {
+            a.ids = ids; a.emb = emb; a.Tids = d.T; a.F = d.F; a.E = d.E; a.front_zero = d.front_zero;
+            a.mask_id0 = d.mask_id0; a.V = d.V;
+            if (last) { a.last = last; a.last_t = len[0] + d.last_index; }
+        } else {
+            a.x = ybuf[in_buf];
+        }
+        a.wg = wg[i]; a.bg = bg[i]; a.wc = wc[i]; a.bc = bc[i];
+        a.h_last = memory + (size_t)i * H; a.h_last_stride = (int64_t)K * H;
+        a.period = d.periods[i];
+        return a;
+    };
+    for (int i = 0; i < K; i += 2) {
+        if (i + 1 < K) {
+            HpmnGruFusedFwd lo = layer(i), up = layer(i + 1);
+            up.x = nullptr;
+            // only a following launch reads rows from memory -- and not from the buffer this launch's lower layer is
+            // still reading ITS input rows from
+            const int out_buf = i == 0 ? 0 : in_buf ^ 1;
+            up.y = i + 2 < K ? ybuf[out_buf] : nullptr;
+            const int rc = gru_pair_fwd_launch(lo, up, 0, nullptr, i == 0 && D0 != 64 ? nullptr : img_base + i * img_stride,
+                                               img_base + (i + 1) * img_stride, st);
+            if (rc != HPMN_OK) return rc;
+            in_buf = out_buf;
+        } else {
+            const HpmnGruFusedFwd a = layer(i);
+            const int rc = gru_fused_fwd_dispatch(a, st);
+            if (rc != HPMN_OK) return rc;
+        }
+    }
+    return HPMN_OK;
 }
 
 int hpmn_scan_fwd(const HpmnScanDesc *d, const int32_t *ids, const float *emb, const float *const *wg,
@@ -226,6 +294,10 @@ int hpmn_scan_fwd(const HpmnScanDesc *d, const int32_t *ids, const float *emb, c
     char *ws = reinterpret_cast<char *>(align_up(reinterpret_cast<size_t>(workspace), 256));
     float *xp = reinterpret_cast<float *>(ws);
     float *ybuf[2] = {reinterpret_cast<float *>(ws + xp_bytes), reinterpret_cast<float *>(ws + xp_bytes + y_bytes)};
+
+    if (scan_fwd_pairs_ok(*d, D0) && gru_fused_fwd_writes_last())
+        return scan_fwd_pairs(*d, len, ids, emb, wg, bg, wc, bc, memory, last, ybuf,
+                              reinterpret_cast<float *>(ws + xp_bytes + 2 * y_bytes), st);
 
     for (int i = 0; i < d->K; ++i) {
         // (inference keeps the two-kernel layer: without the saved-state stores the fused layer's scan wave,
