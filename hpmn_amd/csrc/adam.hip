@@ -69,9 +69,15 @@ __global__ __launch_bounds__(256) void adam_rows_kernel(float4 *__restrict__ p, 
 // Dense table Adam in TWO passes with identical arithmetic (include/hpmn_hip.h, hpmn_adam_step_table): the rows a batch
 // does not touch have an exactly-zero gradient, so their update (m = b1 m, v = b2 v, p -= lr_t m / (sqrt v + eps)) needs
 // nothing of the step and runs early on another stream; the touched rows follow behind the scatter.
-__global__ __launch_bounds__(256) void table_mark_kernel(const int32_t *__restrict__ ids, long n, uint8_t *__restrict__ flags) {
+// (ids outside [0, V) are skipped: padding entries of a gathered id list are -1, and a raw-ABI caller's bad id must not
+//  write outside the flags)
+__global__ __launch_bounds__(256) void table_mark_kernel(const int32_t *__restrict__ ids, long n, uint8_t *__restrict__ flags,
+                                                         long V) {
     const long stride = (long)gridDim.x * blockDim.x;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) flags[ids[i]] = 1;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const long id = ids[i];
+        if (id >= 0 && id < V) flags[id] = 1;
+    }
 }
 
 // PASS 0: rows with flag == 0 (gradient taken as zero, not read).  PASS 1: rows with flag != 0: the gradient row is
@@ -103,11 +109,11 @@ __global__ __launch_bounds__(256) void adam_table_kernel(float4 *__restrict__ p,
     }
 }
 
-int table_mark_launch(const int32_t *ids, int64_t n, uint8_t *flags, hipStream_t st) {
+int table_mark_launch(const int32_t *ids, int64_t n, uint8_t *flags, int64_t V, hipStream_t st) {
     if (n == 0) return HPMN_OK;
     long blocks = (n + 255) / 256;
     if (blocks > 256L * 8) blocks = 256L * 8;
-    hipLaunchKernelGGL(table_mark_kernel, dim3((unsigned)blocks), dim3(256), 0, st, ids, (long)n, flags);
+    hipLaunchKernelGGL(table_mark_kernel, dim3((unsigned)blocks), dim3(256), 0, st, ids, (long)n, flags, (long)V);
     return check_launch();
 }
 

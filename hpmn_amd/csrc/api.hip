@@ -45,7 +45,7 @@ int embed_grad_scatter_launch(const int32_t *ids, const float *d_x, float *d_emb
                               hipStream_t st, const float *d_last = nullptr, int32_t t_last = 0);
 int adam_launch(float *p, const float *g, float *m, float *v, int64_t n, float lr_t, float b1, float b2,
                 float eps, float clip, float gs, hipStream_t st);
-int table_mark_launch(const int32_t *ids, int64_t n, uint8_t *flags, hipStream_t st);
+int table_mark_launch(const int32_t *ids, int64_t n, uint8_t *flags, int64_t V, hipStream_t st);
 int adam_table_launch(float *p, float *g, float *m, float *v, uint8_t *flags, int64_t V, int E, int pass, float lr_t,
                       float b1, float b2, float eps, float clip, float gs, hipStream_t st);
 int adam_rows_launch(float *p, const float *g, float *m, float *v, const int64_t *row_ids, int64_t n_rows, int E,
@@ -418,7 +418,7 @@ int hpmn_table_mark_rows(const int32_t *ids, int64_t n_ids, uint8_t *flags, int6
     if (n_ids < 0 || V < 1) return HPMN_EINVAL;
     if (n_ids == 0) return HPMN_OK;
     if (!ids || !flags) return HPMN_EINVAL;
-    return table_mark_launch(ids, n_ids, flags, (hipStream_t)stream);
+    return table_mark_launch(ids, n_ids, flags, V, (hipStream_t)stream);
 }
 
 int hpmn_adam_step_table(float *param, float *grad, float *m, float *v, uint8_t *flags, int64_t V, int32_t E,
@@ -426,7 +426,9 @@ int hpmn_adam_step_table(float *param, float *grad, float *m, float *v, uint8_t 
                          void *stream) {
     drop_stale_hip_error();
     if (V < 0 || E < 4 || (pass != 0 && pass != 1)) return HPMN_EINVAL;
-    if (E % 4 != 0 || (E / 4 & (E / 4 - 1)) != 0 || E / 4 > 256) return HPMN_EUNSUPPORTED;
+    // (a row's E/4 lanes must sit in ONE wave: the lane that clears the row's flag does so after every lane of the row has
+    //  read it only then)
+    if (E % 4 != 0 || (E / 4 & (E / 4 - 1)) != 0 || E / 4 > 64) return HPMN_EUNSUPPORTED;
     if (V == 0) return HPMN_OK;
     if (!param || !grad || !m || !v || !flags) return HPMN_EINVAL;
     if ((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(m) |

@@ -739,7 +739,17 @@ class Hpmn_Basic(object):
         """code/hpmn.py:91-92: ``saver.save(sess, save_path)`` -- written as the TensorFlow-1 tensor bundle the
         reference's Saver produces (``model.ckpt.index`` + ``model.ckpt.data-00000-of-00001`` + ``checkpoint``),
         under the variable names of the TF 1.4 graph, Adam slots and beta powers included
-        (hpmn_amd/tf_checkpoint.py), so that either implementation can restore the other's checkpoint."""
+        (hpmn_amd/tf_checkpoint.py).  This side restores either implementation's checkpoint.  The reference's
+        ``Saver().restore`` of ours needs a ``var_list`` limited to the exported names when the model is user-only: its
+        graph also creates the (never executed) item-branch variables and their Adam slots (code/hpmn.py:444-450),
+        which a user-only export does not contain.
+        Every rank must call this under data parallel with the sharded table exchange: each rank holds the Adam moments
+        of its own 1/world of the table rows only, and they are gathered here before rank 0 writes."""
+        if self.world > 1 and self.table_exchange == "sharded" and not self.lazy_table_adam:
+            n_pad = self._emb_numel_padded
+            shard = n_pad // self.world
+            for buf in (self.flat_m, self.flat_v):
+                dist.all_gather_shards_(buf[:n_pad], self.rank * shard, shard)
         if self.rank != 0:
             return
         from . import tf_checkpoint as tfc
@@ -757,7 +767,8 @@ class Hpmn_Basic(object):
         from . import tf_checkpoint as tfc
         path = self.save_path if path is None else path
         try:
-            params, m, v, t = tfc.import_model(path, {k: tuple(p.shape) for k, p in self.params.items()}, self.beta1)
+            params, m, v, t = tfc.import_model(path, {k: tuple(p.shape) for k, p in self.params.items()}, self.beta1,
+                                               self.beta2)
             self.set_params(params)
             with torch.no_grad():
                 if m is not None:

@@ -363,6 +363,7 @@ def tf_name_map(param_names: Iterable[str]) -> Dict[str, str]:
 
 
 ADAM_SCOPE = "output"        # the optimizer is created inside variable_scope('output') (code/hpmn.py:464, :209-214)
+STEP_TENSOR = "hpmn_amd/adam_step"      # int64 scalar, ours only: the exact number of Adam steps taken
 
 
 def export_model(prefix: str, params: Dict[str, np.ndarray], adam_m: Optional[Dict[str, np.ndarray]] = None,
@@ -389,10 +390,14 @@ def export_model(prefix: str, params: Dict[str, np.ndarray], adam_m: Optional[Di
             t["%s/%s/Adam_1" % (ADAM_SCOPE, names[k])] = np.asarray(adam_v[k], dtype=np.float32)
         t[ADAM_SCOPE + "/beta1_power"] = np.asarray(beta1 ** (adam_t + 1), dtype=np.float32)
         t[ADAM_SCOPE + "/beta2_power"] = np.asarray(beta2 ** (adam_t + 1), dtype=np.float32)
+        # float32 beta1^(t+1) underflows to 0 near t = 985 (TF's own variable does too, and its lr_t then is lr sqrt(1 -
+        # b2^t)): the step count is ALSO stored exactly, under a name the TF graph does not have (Saver.restore ignores
+        # tensors no variable asks for)
+        t[STEP_TENSOR] = np.asarray(adam_t, dtype=np.int64)
     write_bundle(prefix, t)
 
 
-def import_model(prefix: str, param_shapes: Dict[str, Tuple[int, ...]], beta1: float = 0.9):
+def import_model(prefix: str, param_shapes: Dict[str, Tuple[int, ...]], beta1: float = 0.9, beta2: float = 0.999):
     """-> (params, adam_m or None, adam_v or None, adam_t).  Every variable of ``param_shapes`` must be in the
     bundle with that shape (extra tensors -- the never-executed item branch of a reference checkpoint, BN's moving
     statistics -- are ignored); Adam state is optional (a checkpoint of weights only restores with t = 0)."""
@@ -409,9 +414,21 @@ def import_model(prefix: str, param_shapes: Dict[str, Tuple[int, ...]], beta1: f
         a, b = "%s/%s/Adam" % (ADAM_SCOPE, tn), "%s/%s/Adam_1" % (ADAM_SCOPE, tn)
         if a in have and b in have:
             m[k], v[k] = have[a], have[b]
-    t = 0
-    b1p = have.get(ADAM_SCOPE + "/beta1_power")
-    if b1p is not None and len(m) == len(param_shapes):
-        t = max(0, int(round(float(np.log(float(b1p)) / np.log(beta1)))) - 1)
-        return params, m, v, t
-    return params, None, None, 0
+    if len(m) != len(param_shapes):
+        return params, None, None, 0
+    return params, m, v, _adam_steps(have, beta1, beta2)
+
+
+def _adam_steps(have, beta1: float, beta2: float) -> int:
+    """Adam's step count of a checkpoint: the exact tensor our writer adds; for a checkpoint TF wrote, from beta2_power
+    (float32 0.999^(t+1) resolves t to about 87 k steps; beta1_power underflows to 0 near t = 985), then beta1_power."""
+    if STEP_TENSOR in have:
+        return max(0, int(np.asarray(have[STEP_TENSOR]).reshape(-1)[0]))
+    for name, beta in ((ADAM_SCOPE + "/beta2_power", beta2), (ADAM_SCOPE + "/beta1_power", beta1)):
+        p = have.get(name)
+        if p is None:
+            continue
+        p = float(np.asarray(p).reshape(-1)[0])
+        if np.isfinite(p) and 0.0 < p < 1.0:
+            return max(0, int(round(np.log(p) / np.log(beta))) - 1)
+    return 0

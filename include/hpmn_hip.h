@@ -482,7 +482,8 @@ int hpmn_adam_step_rows(float *param, const float *grad_rows, float *m, float *v
  *   pass 1               : every row with flag != 0, behind the scatter; consumes AND CLEARS the row's gradient and
  *                          its flag, leaving grad [V,E] and flags all-zero for the next step (the caller must not
  *                          clear the table gradient densely any more, only make sure it starts all-zero)
- * param / grad / m / v: [V, E], 16-byte aligned; E/4 a power of two. */
+ * param / grad / m / v: [V, E], 16-byte aligned; E/4 a power of two <= 64 (a row's lanes share one wave).  ids outside
+ * [0, V) are ignored by the marking (padding entries of gathered id lists are -1). */
 int hpmn_table_mark_rows(const int32_t *ids, int64_t n_ids, uint8_t *flags, int64_t V, void *stream);
 int hpmn_adam_step_table(float *param, float *grad, float *m, float *v, uint8_t *flags, int64_t V, int32_t E,
                          int32_t pass, float lr_t, float beta1, float beta2, float eps, float clip, float grad_scale,

@@ -108,3 +108,97 @@ def test_tf14_variable_names_and_model_export_import(tmp_path):
         T.import_model(prefix, dict(shapes, **{"output/fc3/bias": (2,)}))
     with pytest.raises(KeyError):
         T.import_model(prefix, dict(shapes, **{"User/map": (64, 64)}))
+
+
+@pytest.mark.parametrize("t", [0, 7, 970, 1000, 5000, 200000])
+def test_adam_step_count_survives_the_round_trip(tmp_path, t):
+    """float32 beta1^(t+1) underflows near t = 985: the step count comes back from the exact tensor our writer adds, and
+    for a bundle without it (one TF wrote) from beta2_power, which resolves it well past 5000 steps."""
+    from hpmn_amd import tf_checkpoint as tfc
+    shapes = {"Embedding/emb_mtx": (5, 4)}
+    p = {"Embedding/emb_mtx": np.arange(20, dtype=np.float32).reshape(5, 4)}
+    z = {"Embedding/emb_mtx": np.zeros((5, 4), np.float32)}
+    prefix = str(tmp_path / "m.ckpt")
+    tfc.export_model(prefix, p, z, z, t, 0.9, 0.999)
+    assert tfc.import_model(prefix, shapes)[3] == t
+    have = tfc.read_bundle(prefix)
+    del have[tfc.STEP_TENSOR]                                     # what a TF-written checkpoint looks like
+    tfc.write_bundle(prefix, have)
+    got = tfc.import_model(prefix, shapes)[3]
+    if t <= 5000:
+        assert got == t
+    else:
+        assert got >= 0                                           # (both powers have underflowed: no exception, no garbage)
+
+
+def test_reader_against_a_bundle_assembled_by_hand_from_the_published_format(tmp_path):
+    """The reader is otherwise only ever checked against our own writer.  This bundle is put together here, byte by
+    byte, from the published formats (LevelDB table format doc: blocks of prefix-compressed entries + restart array +
+    1-byte type + masked crc32c trailer, 48-byte footer; tensorflow/core/protobuf/tensor_bundle.proto and
+    tensor_shape.proto for the values), with a bitwise crc32c that shares nothing with the product's table-driven C
+    helper: two tensors, one data shard."""
+    import struct
+    from hpmn_amd import tf_checkpoint as tfc
+
+    def crc32c(data):                                   # Castagnoli, reflected, bit by bit (RFC 3720 appendix B.4)
+        crc = 0xFFFFFFFF
+        for byte in data:
+            crc ^= byte
+            for _ in range(8):
+                crc = (crc >> 1) ^ (0x82F63B78 if crc & 1 else 0)
+        return crc ^ 0xFFFFFFFF
+    assert crc32c(b"123456789") == 0xE3069283           # the check value of the CRC catalogue
+
+    def masked(crc):                                    # leveldb/util/crc32c.h Mask()
+        return ((((crc >> 15) | (crc << 17)) & 0xFFFFFFFF) + 0xA282EAD8) & 0xFFFFFFFF
+
+    a = struct.pack("<2f", 1.0, 2.0)                    # tensor "a": float32 [2]
+    bc = struct.pack("<2i", 7, -3)                      # tensor "b/c": int32 [1, 2]
+    data = a + bc
+    header = bytes([0x08, 0x01,                         # BundleHeaderProto.num_shards = 1
+                    0x1A, 0x02, 0x08, 0x01])            # .version { producer: 1 }
+    entry_a = (bytes([0x08, 0x01,                       # dtype = DT_FLOAT
+                      0x12, 0x04, 0x12, 0x02, 0x08, 0x02,   # shape { dim { size: 2 } }
+                      0x28, 0x08,                       # size = 8   (shard_id 0 and offset 0 are defaults: absent)
+                      0x35]) + struct.pack("<I", masked(crc32c(a))))
+    entry_bc = (bytes([0x08, 0x03,                      # dtype = DT_INT32
+                       0x12, 0x08, 0x12, 0x02, 0x08, 0x01, 0x12, 0x02, 0x08, 0x02,   # shape { dim {1} dim {2} }
+                       0x20, 0x08,                      # offset = 8
+                       0x28, 0x08,                      # size = 8
+                       0x35]) + struct.pack("<I", masked(crc32c(bc))))
+
+    def block(entries):                                 # one restart point, no shared prefixes
+        body = b""
+        for key, value in entries:
+            assert len(key) < 128 and len(value) < 128  # (single-byte varints)
+            body += bytes([0, len(key), len(value)]) + key + value
+        body += struct.pack("<II", 0, 1)                # restart[0] = 0, num_restarts = 1
+        return body
+
+    def with_trailer(body):
+        return body + b"\x00" + struct.pack("<I", masked(crc32c(body + b"\x00")))       # type 0 = uncompressed
+
+    data_block = block([(b"", header), (b"a", entry_a), (b"b/c", entry_bc)])
+    meta_block = block([])
+    index_block = block([(b"c", bytes([0, len(data_block)]))])      # key >= last key of the data block -> its handle
+    off_meta = len(data_block) + 5
+    off_index = off_meta + len(meta_block) + 5
+    footer = bytes([off_meta, len(meta_block), off_index, len(index_block)])
+    footer = footer + b"\x00" * (40 - len(footer)) + struct.pack("<Q", 0xDB4775248B80FB57)
+    table = with_trailer(data_block) + with_trailer(meta_block) + with_trailer(index_block) + footer
+    assert max(off_meta, off_index, len(data_block), len(index_block)) < 128 and len(footer) == 48
+
+    prefix = str(tmp_path / "hand.ckpt")
+    with open(prefix + ".index", "wb") as f:
+        f.write(table)
+    with open(prefix + ".data-00000-of-00001", "wb") as f:
+        f.write(data)
+    got = tfc.read_bundle(prefix)
+    assert sorted(got) == ["a", "b/c"]
+    assert got["a"].dtype == np.float32 and got["a"].tolist() == [1.0, 2.0]
+    assert got["b/c"].dtype == np.int32 and got["b/c"].shape == (1, 2) and got["b/c"].tolist() == [[7, -3]]
+    # and the writer produces a file this independent description agrees with, entry by entry
+    tfc.write_bundle(str(tmp_path / "ours.ckpt"), {"a": got["a"], "b/c": got["b/c"]})
+    ours = open(str(tmp_path / "ours.ckpt") + ".index", "rb").read()
+    assert entry_a in ours and entry_bc in ours and ours[-8:] == table[-8:]
+    assert open(str(tmp_path / "ours.ckpt") + ".data-00000-of-00001", "rb").read() == data
