@@ -423,6 +423,40 @@ def cpu_baseline(c, seed=0):
                       % (len(tt), bs, c["name"], sum(tt), len(tf), b1)}
 
 
+def dp_report(model, c, batches, world, ms_per_step, n_model=8, busbw_gbps=300.0):
+    """Per-step collective bytes of the data-parallel step, measured on this run's batches, and a MODEL of what they cost
+    at N = 8 (no multi-GPU box is available to the builder: the driver's SCALE run is the measurement).  The model:
+    ring collectives at ``busbw_gbps`` GB/s of bus bandwidth per rank (an assumption -- 7 xGMI links x ~153 GB/s peak,
+    RCCL typically sustains about a third to a half of that on 8 GPUs), hidden only under layer 0's weight gradient on the
+    helper stream (the ~0.3 ms between the scatter and the dense Adam), everything else exposed."""
+    from hpmn_amd import dist
+    E = c["E"]
+    n_emb = int(model.params["Embedding/emb_mtx"].numel())
+    n_dense = int(model.flat_param.numel()) - n_emb
+    uniq = [int(torch.unique(b[0].reshape(-1)).numel()) for b in batches[:4]]
+    u = sum(uniq) / len(uniq)
+    dense_b = dist.dense_allreduce_bytes(n_emb, n_model)
+    rows_b = dist.rows_exchange_bytes([int(u)] * n_model, E)
+    small_b = dist.dense_allreduce_bytes(n_dense, n_model)
+    hide_ms = 0.3
+    t_dense, t_rows = dense_b / busbw_gbps / 1e6, rows_b / busbw_gbps / 1e6
+    # this step's single-GPU time stands for the per-rank compute of the weak-scaling run
+    eff = lambda t: ms_per_step / (ms_per_step + max(0.0, t - hide_ms) + small_b / busbw_gbps / 1e6 + 0.02)
+    return {
+        "table_exchange": model.table_exchange, "world": world,
+        "measured_bytes_received_last_step": int(getattr(model, "last_exchange_bytes", 0)) if world > 1 else None,
+        "unique_rows_per_rank_per_step": u, "table_rows": n_emb // E,
+        "model_n%d" % n_model: {
+            "assumed_busbw_GBps": busbw_gbps, "hidden_under_ms": hide_ms,
+            "dense_allreduce": {"bytes_per_rank": dense_b, "ms": t_dense, "weak_scaling_efficiency": eff(t_dense)},
+            "touched_rows_allgather": {"bytes_per_rank": rows_b, "ms": t_rows, "weak_scaling_efficiency": eff(t_rows)},
+            "dense_parameters_allreduce_bytes": small_b,
+            "note": "modelled, not measured; strong scaling at a fixed global batch cannot speed up the chain of scans "
+                    "(its length does not depend on the batch)",
+        },
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -558,6 +592,7 @@ def main():
                             "train_tflops_equiv": 3 * algorithmic_flops_fwd(c) * seqs / elapsed / 1e12},
         }
         result["eval_sequences_per_s"] = eval_seq_per_s        # forward only, rank-0 clock (not barrier-bracketed)
+        result["data_parallel"] = dp_report(model, c, batches, world, elapsed / args.steps * 1e3)
         if auc is not None:
             result["auc"] = auc
         if not args.no_parity_gate:

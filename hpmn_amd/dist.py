@@ -91,3 +91,81 @@ def all_gather_shards_(flat: torch.Tensor, lo: int, shard: int) -> None:
     """Every rank contributes flat[lo:lo+shard] (its own slice); afterwards ``flat`` holds all slices in rank order."""
     mine = flat[lo:lo + shard].clone()
     td.all_gather_into_tensor(flat, mine)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Touched-rows exchange of the embedding-table gradient (SURVEY.md 8e: "large tables -> allGather of (unique row ids,
+# summed grad rows) per rank, then local scatter-add"; the gradient of code/hpmn.py:421-422 is an IndexedSlices over the
+# batch's rows before :204-205 densifies it).  A step only ever touches the rows its ids name, so for a table sized to
+# HBM the dense all-reduce (2 (N-1)/N V E 4 bytes per rank) is replaced by an all-gather of the touched rows.
+
+def gather_ids(ids: torch.Tensor, cap: int) -> torch.Tensor:
+    """All ranks' id tensors as one [world, cap] int32 tensor, -1 where a rank had fewer than ``cap`` entries (a short
+    last batch).  No host synchronisation: ``cap`` comes from the batch geometry (``shard_sizes``)."""
+    _, world = rank_world()
+    flat = ids.reshape(-1).to(torch.int32)
+    assert flat.numel() <= cap
+    mine = torch.full((cap,), -1, device=ids.device, dtype=torch.int32)
+    mine[:flat.numel()] = flat
+    if world == 1:
+        return mine.view(1, cap)
+    out = torch.empty(world * cap, device=ids.device, dtype=torch.int32)
+    td.all_gather_into_tensor(out, mine)
+    return out.view(world, cap)
+
+
+def exchange_counts(n: int, device) -> List[int]:
+    """Every rank's ``n`` (one small collective + one host read: the row lists of the next call are sized by it)."""
+    _, world = rank_world()
+    if world == 1:
+        return [int(n)]
+    mine = torch.tensor([int(n)], device=device, dtype=torch.int64)
+    out = torch.empty(world, device=device, dtype=torch.int64)
+    td.all_gather_into_tensor(out, mine)
+    return [int(x) for x in out.tolist()]
+
+
+def exchange_rows(rows: torch.Tensor, grads: torch.Tensor, counts: List[int]):
+    """All-gather of (row ids [n] int32, gradient rows [n, E]) over the ranks, padded to the largest count.
+    Returns (ids [world, cap] with -1 padding, grads [world, cap, E]); rank r's valid entries are the first counts[r]."""
+    rank, world = rank_world()
+    cap = max(1, max(counts))
+    E = grads.shape[1]
+    n = rows.numel()
+    assert n == counts[rank] and grads.shape[0] == n
+    ids_mine = torch.full((cap,), -1, device=rows.device, dtype=torch.int32)
+    ids_mine[:n] = rows.to(torch.int32)
+    g_mine = torch.zeros(cap, E, device=grads.device, dtype=grads.dtype)
+    g_mine[:n] = grads
+    if world == 1:
+        return ids_mine.view(1, cap), g_mine.view(1, cap, E)
+    ids_all = torch.empty(world * cap, device=rows.device, dtype=torch.int32)
+    g_all = torch.empty(world * cap * E, device=grads.device, dtype=grads.dtype)
+    td.all_gather_into_tensor(ids_all, ids_mine)
+    td.all_gather_into_tensor(g_all, g_mine.view(-1))
+    return ids_all.view(world, cap), g_all.view(world, cap, E)
+
+
+def sum_rows_into_(dst: torch.Tensor, ids_all: torch.Tensor, g_all: torch.Tensor, counts: List[int], row_of=None) -> None:
+    """dst[row_of(id)] += every rank's gradient rows, in RANK ORDER 0..world-1 on every rank (so that the replicas add
+    the same numbers in the same order and stay bit-identical).  ``dst`` must hold zeros in the rows named (the caller's
+    own contribution arrives through ``g_all`` like everybody else's).  ``row_of`` maps table ids to rows of ``dst``
+    (identity for the dense [V, E] gradient, a searchsorted into the union for a compact buffer)."""
+    for r, n in enumerate(counts):
+        if n == 0:
+            continue
+        idx = ids_all[r, :n].long()
+        if row_of is not None:
+            idx = row_of(idx)
+        dst.index_add_(0, idx, g_all[r, :n])
+
+
+def rows_exchange_bytes(counts: List[int], E: int) -> int:
+    """Bytes one rank RECEIVES in exchange_rows (ids + rows of every other rank, padded to the cap)."""
+    world = len(counts)
+    return (world - 1) * max(1, max(counts)) * (4 + 4 * E)
+
+
+def dense_allreduce_bytes(numel: int, world: int) -> int:
+    """Bytes one rank sends (= receives) in a ring all-reduce of ``numel`` fp32 values."""
+    return int(2 * (world - 1) / world * numel * 4) if world > 1 else 0

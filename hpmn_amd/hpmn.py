@@ -169,15 +169,18 @@ class Hpmn_Basic(object):
         # update (BASELINE configs[4]); a labelled deviation from code/hpmn.py:209-214, off unless asked for.
         self.lazy_table_adam = bool(int(os.environ.get("HPMN_LAZY_TABLE_ADAM", "0"))) if lazy_table_adam is None \
             else bool(lazy_table_adam)
-        if self.lazy_table_adam and (self.world > 1 or item or l2_reg):
-            raise NotImplementedError("lazy_table_adam: single process, user-only graph, l2_reg == 0")
+        if self.lazy_table_adam and (item or l2_reg):
+            raise NotImplementedError("lazy_table_adam: user-only graph, l2_reg == 0")
         self.table_exchange_chunks = 4
         # how the replicas keep the (replicated) table in step: "allreduce" = sum all-reduce of the table gradient in
         # a few ranges + replicated dense Adam (every rank sweeps the whole table); "sharded" = reduce-scatter of the
         # gradient, Adam on this rank's 1/world of the rows only, all-gather of the updated rows -- the same bytes
         # on the wire, 1/world of the 28 B/element optimiser traffic per GPU (identical arithmetic); "single" = one
         # blocking all-reduce over the whole flat gradient, then one update (no overlap: the fallback switch)
-        self.table_exchange = os.environ.get("HPMN_TABLE_EXCHANGE", "allreduce")
+        # auto: the two-pass step with touched rows for big tables, dense all-reduce for small ones (_train_step_dp)
+        self.table_exchange = os.environ.get("HPMN_TABLE_EXCHANGE", "auto")
+        self.TWO_PASS_MIN_NUMEL = int(os.environ.get("HPMN_TWO_PASS_MIN_NUMEL", str(type(self).TWO_PASS_MIN_NUMEL)))
+        self.last_exchange_bytes = 0            # bytes this rank received in the last step's table exchange
         self._dropout_base, self._dropout_step = (int(seed or 0) * 0x632BE59BD9B4E019 + 0x1234567) & (2 ** 63 - 1), 0
         self._save_path = None
         self._datasets: Dict[int, Tuple[object, _DeviceDataset]] = {}
@@ -499,6 +502,8 @@ class Hpmn_Basic(object):
         """sess.run(train_step) of code/hpmn.py:482: forward, BPTT, clip, dense TF Adam."""
         if self._two_pass_table_adam(ids):
             return self._train_step_two_pass(ids, label, keep_prob, masks, global_batch)
+        if self._dp_two_pass(ids):
+            return self._train_step_dp(ids, label, keep_prob, masks, global_batch)
         out, ce = self.compute_gradients(ids, label, keep_prob, masks, global_batch, defer_join=True, item_ids=item_ids)
         pending = out.pop("pending", None)
         if self.l2_reg:
@@ -517,13 +522,29 @@ class Hpmn_Basic(object):
             t = self.adam_t
             lr_t = self.learning_rate * math.sqrt(1.0 - self.beta2 ** t) / (1.0 - self.beta1 ** t)
             V, E = self.feature_size, self.embedding_size
-            if "table_rows" in out:
-                ops.adam_step_rows(self.flat_param[:n_emb].view(V, E), out.pop("table_row_grads"),
-                                   self.flat_m[:n_emb].view(V, E), self.flat_v[:n_emb].view(V, E), out.pop("table_rows"),
+            rows = out.pop("table_rows", None)
+            row_grads = out.pop("table_row_grads", None)
+            if self.world > 1:
+                # every rank's (touched rows, their gradient rows) -> the union and the summed rows, identically on
+                # every rank; an empty shard contributes nothing but takes part in the collectives
+                if rows is None:
+                    rows = torch.empty(0, device=self.device, dtype=torch.int64)
+                    row_grads = torch.empty(0, E, device=self.device, dtype=torch.float32)
+                counts = dist.exchange_counts(rows.numel(), self.device)
+                ids_all, g_all = dist.exchange_rows(rows, row_grads, counts)
+                self.last_exchange_bytes = dist.rows_exchange_bytes(counts, E)
+                valid = torch.cat([ids_all[r, :n] for r, n in enumerate(counts)]).long()
+                rows = torch.unique(valid)
+                row_grads = torch.zeros(rows.numel(), E, device=self.device, dtype=torch.float32)
+                dist.sum_rows_into_(row_grads, ids_all, g_all, counts, row_of=lambda i: torch.searchsorted(rows, i))
+            if rows is not None and rows.numel() > 0:
+                ops.adam_step_rows(self.flat_param[:n_emb].view(V, E), row_grads,
+                                   self.flat_m[:n_emb].view(V, E), self.flat_v[:n_emb].view(V, E), rows,
                                    lr_t, self.beta1, self.beta2, self.adam_eps, clip=1.0)
             if pending is not None:
                 pending.join()
             lo = self._goff
+            dist.allreduce_sum_(self.flat_grad)                 # (lazy: the flat gradient holds the dense variables only)
             ops.adam_step(self.flat_param[lo:], self.flat_grad, self.flat_m[lo:], self.flat_v[lo:], lr_t, self.beta1,
                           self.beta2, self.adam_eps, clip=1.0)
             return out, ce
@@ -606,6 +627,83 @@ class Hpmn_Basic(object):
         self._table_grad_clean = True
         if pending is not None:
             pending.join()
+        self.apply_gradients(n_emb, self.flat_param.numel(), advance=False)
+        return out, ce
+
+    # ------------------------------------------------------------------ the same step under data parallel
+    ROWS_EXCHANGE_MIN_BYTES = int(os.environ.get("HPMN_ROWS_EXCHANGE_MIN_BYTES", str(1 << 30)))
+
+    def _dp_two_pass(self, ids) -> bool:
+        """world > 1 and everything _two_pass_table_adam asks for: the N-GPU step is then the 1-GPU step (two-pass
+        dense table Adam, the four library calls) plus the collectives.  HPMN_TABLE_EXCHANGE: ``auto`` (default) =
+        ``rows`` for tables above ROWS_EXCHANGE_MIN_BYTES, else ``allreduce``; ``sharded`` / ``single`` keep their
+        one-sweep forms (train_step)."""
+        return bool(self.TWO_PASS_TABLE_ADAM and self.world > 1 and self._hip_read and not self.l2_reg
+                    and not self.lazy_table_adam and self.table_exchange in ("auto", "rows", "allreduce")
+                    and self.flat_grad.numel() >= self.TWO_PASS_MIN_NUMEL and self.embedding_size % 4 == 0)
+
+    def _train_step_dp(self, ids, label, keep_prob, masks, global_batch):
+        """_train_step_two_pass with the batch sharded over the ranks.  What a rank may treat as
+        "untouched" is what NO rank touches, so the marking runs over all ranks' ids -- gathered at the start of the
+        step (4 MB per rank at the reference batch, fixed size: no host synchronisation), underneath the forward like
+        the early pass itself.  Behind the scatter the table gradient is exchanged either densely (all-reduce of the
+        [V, E] gradient: 2 (N-1)/N x 212 MB per rank at C3) or as touched rows (all-gather of every rank's unique row
+        ids + gradient rows, summed in rank order on every rank so the replicas stay bit-identical; one host read for
+        the counts) -- then the late pass runs over the union's rows exactly as in the single-process step."""
+        n_emb = self.params["Embedding/emb_mtx"].numel()
+        V, E = self.feature_size, self.embedding_size
+        if self._row_flags is None:
+            self._row_flags = torch.zeros(V, device=self.device, dtype=torch.uint8)
+        flags = self._row_flags
+        t = self.adam_t + 1
+        lr_t = self.learning_rate * math.sqrt(1.0 - self.beta2 ** t) / (1.0 - self.beta1 ** t)
+        views = [b[:n_emb].view(V, E) for b in (self.flat_param, self.flat_grad, self.flat_m, self.flat_v)]
+        B = ids.shape[0]
+        gb = B * self.world if global_batch is None else global_batch
+        per_sample = ids[0].numel() if B > 0 else self.spec.T * self.spec.F
+        cap = max(dist.shard_sizes(gb, self.world)) * per_sample if global_batch is not None else B * per_sample
+        mode = self.table_exchange
+        if mode == "auto":
+            mode = "rows" if n_emb * 4 > self.ROWS_EXCHANGE_MIN_BYTES else "allreduce"
+
+        def early():                                          # runs on the auxiliary stream
+            if not self._table_grad_clean:
+                self.flat_grad.zero_()
+            else:
+                self.flat_grad[n_emb:].zero_()
+            all_ids = dist.gather_ids(ids, max(cap, 1))
+            ops.table_mark_rows(all_ids, flags)
+            ops.adam_step_table(*views, flags, 0, lr_t, self.beta1, self.beta2, self.adam_eps, clip=1.0)
+
+        if B > 0:
+            out, ce = self.compute_gradients(ids, label, keep_prob, masks, gb, defer_join=True, _clear_grads=early)
+        else:
+            # an empty shard (short last batch): nothing to compute, every collective still has to be entered
+            main = torch.cuda.current_stream()
+            self._aux_stream.wait_stream(main)
+            with torch.cuda.stream(self._aux_stream):
+                early()
+            main.wait_stream(self._aux_stream)
+            out, ce = dict(prediction=torch.empty(0, device=self.device)), torch.zeros((), device=self.device)
+        pending = out.pop("pending", None)
+        self.adam_t = t
+        table_grad = views[1]
+        if mode == "rows":
+            rows = torch.unique(ids.reshape(-1)).long() if B > 0 else torch.empty(0, device=self.device, dtype=torch.int64)
+            counts = dist.exchange_counts(rows.numel(), self.device)
+            mine = table_grad.index_select(0, rows)
+            ids_all, g_all = dist.exchange_rows(rows, mine, counts)
+            table_grad.index_fill_(0, rows, 0.0)              # (own rows come back through g_all, in rank order)
+            dist.sum_rows_into_(table_grad, ids_all, g_all, counts)
+            self.last_exchange_bytes = dist.rows_exchange_bytes(counts, E)
+        else:
+            dist.allreduce_sum_(self.flat_grad[:n_emb])
+            self.last_exchange_bytes = dist.dense_allreduce_bytes(n_emb, self.world)
+        ops.adam_step_table(*views, flags, 1, lr_t, self.beta1, self.beta2, self.adam_eps, clip=1.0)
+        self._table_grad_clean = True
+        if pending is not None:
+            pending.join()
+        dist.allreduce_sum_(self.flat_grad[n_emb:])
         self.apply_gradients(n_emb, self.flat_param.numel(), advance=False)
         return out, ce
 

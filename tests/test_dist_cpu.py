@@ -138,3 +138,63 @@ def test_reduce_scatter_and_shard_all_gather_helpers():
         np.testing.assert_array_equal(got[r][0], total[r * shard:(r + 1) * shard])
         want = np.concatenate([total[k * shard:(k + 1) * shard] + 1000.0 * k for k in range(world)])
         np.testing.assert_array_equal(got[r][1], want)
+
+
+def _rows_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        V, E = 40, 4
+        rng = np.random.default_rng(11 + rank)
+        ids = torch.as_tensor(rng.integers(0, V, size=(3 + rank, 5, 2)).astype(np.int32))     # ragged shards
+        dense = torch.zeros(V, E)
+        dense.index_add_(0, ids.reshape(-1).long(), torch.as_tensor(rng.normal(size=(ids.numel(), E)), dtype=torch.float32))
+        # (1) every rank's ids, fixed size, -1 padded
+        cap = 4 * 5 * 2
+        allids = dist.gather_ids(ids, cap)
+        # (2) touched rows: unique ids + their gradient rows, summed in rank order into a zeroed copy
+        rows = torch.unique(ids.reshape(-1)).long()
+        counts = dist.exchange_counts(rows.numel(), torch.device("cpu"))
+        ids_all, g_all = dist.exchange_rows(rows, dense.index_select(0, rows), counts)
+        summed = dense.clone()
+        summed.index_fill_(0, rows, 0.0)
+        dist.sum_rows_into_(summed, ids_all, g_all, counts)
+        # ... and into a compact buffer over the union (the lazy-Adam form)
+        union = torch.unique(torch.cat([ids_all[r, :n] for r, n in enumerate(counts)]).long())
+        compact = torch.zeros(union.numel(), E)
+        dist.sum_rows_into_(compact, ids_all, g_all, counts, row_of=lambda i: torch.searchsorted(union, i))
+        ref = dense.clone()
+        dist.allreduce_sum_(ref)
+        q.put((rank, allids.numpy(), summed.numpy(), ref.numpy(), union.numpy(), compact.numpy(), counts,
+               dist.rows_exchange_bytes(counts, E)))
+    finally:
+        td.destroy_process_group()
+
+
+def test_touched_rows_exchange_equals_the_dense_all_reduce():
+    """SURVEY 8e's exchange for large tables: all-gather of (unique row ids, gradient rows) + local scatter-add must give
+    the dense all-reduce's table gradient -- bit-identically on every rank (same addends, same order) -- from ragged
+    shards, and the gathered raw ids (marking the union for the two-pass Adam) must be every rank's ids, -1 padded."""
+    world = 2
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_rows_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in ps]
+    got = {r[0]: r[1:] for r in (q.get(timeout=120) for _ in range(world))}
+    [p.join(60) for p in ps]
+    assert all(p.exitcode == 0 for p in ps)
+    allids0, summed0, ref0, union0, compact0, counts0, nbytes0 = got[0]
+    allids1, summed1, ref1, union1, compact1, counts1, nbytes1 = got[1]
+    np.testing.assert_array_equal(allids0, allids1)
+    assert allids0.shape == (2, 40) and (allids0[0, 30:] == -1).all() and (allids0[0, :30] >= 0).all()
+    assert (allids0[1] >= 0).all()
+    np.testing.assert_array_equal(summed0, summed1)                     # replicas stay bit-identical
+    np.testing.assert_allclose(summed0, ref0, rtol=0, atol=1e-6)        # == the dense all-reduce
+    np.testing.assert_array_equal(union0, union1)
+    np.testing.assert_array_equal(compact0, compact1)
+    np.testing.assert_allclose(compact0, ref0[union0], rtol=0, atol=1e-6)
+    untouched = np.setdiff1d(np.arange(40), union0)
+    assert (summed0[untouched] == 0).all()
+    assert counts0 == counts1 and nbytes0 == max(counts0) * (4 + 16)

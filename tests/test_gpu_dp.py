@@ -29,6 +29,22 @@ def test_two_rank_training_matches_single_process(tmp_path, exchange):
     _run_two_ranks(tmp_path, "gloo", exchange)
 
 
+@pytest.mark.parametrize("exchange", ["allreduce", "rows"])
+def test_two_rank_two_pass_step_matches_single_process(tmp_path, monkeypatch, exchange):
+    """The N-GPU step as the 1-GPU step (_train_step_dp): union of all ranks' ids marked, early table-Adam pass, then
+    the table gradient exchanged densely or as touched rows, late pass over the union -- forced on for this small table
+    through HPMN_TWO_PASS_MIN_NUMEL=0 (single-process reference included: it runs its own two-pass step)."""
+    monkeypatch.setenv("HPMN_TWO_PASS_MIN_NUMEL", "0")
+    _run_two_ranks(tmp_path, "gloo", exchange, extra_env={"HPMN_TWO_PASS_MIN_NUMEL": "0"})
+
+
+def test_two_rank_lazy_table_adam_matches_single_process(tmp_path, monkeypatch):
+    """Row-wise (lazy) Adam under data parallel -- what a table sized to HBM needs (BASELINE configs[4]): every rank's
+    touched rows and compact gradient rows are all-gathered, the union updated identically everywhere."""
+    monkeypatch.setenv("HPMN_LAZY_TABLE_ADAM", "1")
+    _run_two_ranks(tmp_path, "gloo", "auto", extra_env={"HPMN_LAZY_TABLE_ADAM": "1"})
+
+
 def test_two_rank_training_over_rccl_matches_single_process(tmp_path):
     """The same run with one GPU per rank and backend "nccl" (= RCCL over xGMI): the asynchronous chunked table
     all-reduce, wait() as a stream dependency (not a host block as with gloo), Adam of range i under the reduce
@@ -37,13 +53,15 @@ def test_two_rank_training_over_rccl_matches_single_process(tmp_path):
         pytest.skip("needs >= 2 GPUs (RCCL refuses two ranks on one device)")
     _run_two_ranks(tmp_path, "nccl")
     _run_two_ranks(tmp_path, "nccl", "sharded")
+    _run_two_ranks(tmp_path, "nccl", "rows", extra_env={"HPMN_TWO_PASS_MIN_NUMEL": "0"})
 
 
-def _run_two_ranks(tmp_path, backend, exchange="allreduce"):
+def _run_two_ranks(tmp_path, backend, exchange="allreduce", extra_env=None):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     out = str(tmp_path / "dp.npz")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", HPMN_DP_BACKEND=backend, HPMN_TABLE_EXCHANGE=exchange)
+    env.update(extra_env or {})
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(HERE, "dp_worker.py"), out]
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
