@@ -181,6 +181,12 @@ SIGNATURES = {
     "hpmn_read_fwd": (C.c_int, [C.POINTER(HpmnReadDesc)] + [C.c_void_p] * 8),
     "hpmn_read_fwd_bwd": (C.c_int, [C.POINTER(HpmnReadDesc)] + [C.c_void_p] * 6 +
                           [C.c_float, C.c_float, C.c_float] + [C.c_void_p] * 7),
+    "hpmn_read_fwd_n": (C.c_int, [C.c_int32, C.POINTER(C.POINTER(HpmnReadDesc)), C.c_void_p, C.POINTER(C.c_void_p),
+                                  C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p]),
+    "hpmn_read_fwd_bwd_n": (C.c_int, [C.c_int32, C.POINTER(C.POINTER(HpmnReadDesc)), C.c_void_p, C.POINTER(C.c_void_p),
+                                      C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float,
+                                      C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p,
+                                      C.c_void_p, C.c_void_p]),
     "hpmn_read_param_grads": (C.c_int, [C.POINTER(HpmnReadDesc), C.c_void_p, C.c_void_p, C.c_void_p]),
     "hpmn_embed_grad_scatter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                           C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_void_p]),

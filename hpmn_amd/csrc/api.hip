@@ -38,6 +38,13 @@ int read_fwd_bwd_launch(const HpmnReadDesc &d, const float *P, const float *memo
                         float inv_global_batch, float memory_reg, float *pred, float *loss_out, float *d_memory,
                         float *d_last, float *d_params, float *workspace, hipStream_t st);
 int read_reduce_launch(const HpmnReadDesc &d, float *d_params, const float *workspace, hipStream_t st);
+int read_fwd_launch_n(const HpmnReadDesc *const *d, int nb, const float *P, const float *const *memory,
+                      const float *const *last, float *pred, float *logit, float *const *att_w0, float *mem_loss,
+                      hipStream_t st);
+int read_fwd_bwd_launch_n(const HpmnReadDesc *const *d, int nb, const float *P, const float *const *memory,
+                          const float *const *last, const int32_t *label, const float *mask1, const float *mask2,
+                          float keep_prob, float inv_global_batch, float memory_reg, float *pred, float *loss_out,
+                          float *const *d_memory, float *const *d_last, float *d_params, float *workspace, hipStream_t st);
 int embed_gather_launch(const int32_t *ids, int64_t ids_stride, const float *emb, float *out, int64_t N,
                         int32_t F, int32_t E, int32_t mask_id0, hipStream_t st);
 int embed_grad_scatter_launch(const int32_t *ids, const float *d_x, float *d_emb, int32_t B, int32_t T,
@@ -371,6 +378,35 @@ int hpmn_read_fwd_bwd(const HpmnReadDesc *d, const float *params, const float *m
     return read_fwd_bwd_launch(*d, params, memory, last, label, mask1, mask2, keep_prob, inv_global_batch,
                                memory_reg, pred, loss_out, d_memory, d_last, d_params, workspace,
                                (hipStream_t)stream);
+}
+
+int hpmn_read_fwd_n(int32_t nb, const HpmnReadDesc *const *desc, const float *params, const float *const *memory,
+                    const float *const *last, float *pred, float *logit, float *const *att_w0, float *mem_loss,
+                    void *stream) {
+    drop_stale_hip_error();
+    if (nb < 1 || nb > 2 || !desc || !desc[0] || (nb > 1 && !desc[1])) return HPMN_EINVAL;
+    if (desc[0]->B < 0) return HPMN_EINVAL;
+    if (desc[0]->B == 0) return HPMN_OK;
+    if (!params || !memory || !last || !pred || !mem_loss) return HPMN_EINVAL;
+    for (int b = 0; b < nb; ++b)
+        if (!memory[b] || !last[b]) return HPMN_EINVAL;
+    return read_fwd_launch_n(desc, nb, params, memory, last, pred, logit, att_w0, mem_loss, (hipStream_t)stream);
+}
+
+int hpmn_read_fwd_bwd_n(int32_t nb, const HpmnReadDesc *const *desc, const float *params, const float *const *memory,
+                        const float *const *last, const int32_t *label, const float *mask1, const float *mask2,
+                        float keep_prob, float inv_global_batch, float memory_reg, float *pred, float *loss_out,
+                        float *const *d_memory, float *const *d_last, float *d_params, float *workspace, void *stream) {
+    drop_stale_hip_error();
+    if (nb < 1 || nb > 2 || !desc || !desc[0] || (nb > 1 && !desc[1])) return HPMN_EINVAL;
+    if (desc[0]->B < 0) return HPMN_EINVAL;
+    if (desc[0]->B == 0) return HPMN_OK;
+    if (!params || !memory || !last || !label || !pred || !loss_out || !d_memory || !d_last || !workspace) return HPMN_EINVAL;
+    if (!(keep_prob > 0.f && keep_prob <= 1.f)) return HPMN_EINVAL;
+    for (int b = 0; b < nb; ++b)
+        if (!memory[b] || !last[b] || !d_memory[b] || !d_last[b]) return HPMN_EINVAL;
+    return read_fwd_bwd_launch_n(desc, nb, params, memory, last, label, mask1, mask2, keep_prob, inv_global_batch,
+                                 memory_reg, pred, loss_out, d_memory, d_last, d_params, workspace, (hipStream_t)stream);
 }
 
 int hpmn_read_param_grads(const HpmnReadDesc *d, float *d_params, const float *workspace, void *stream) {

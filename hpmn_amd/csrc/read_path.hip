@@ -344,98 +344,137 @@ __device__ __forceinline__ void dense_bwd_w(const float *X, int ldx, const float
     }
 }
 
-struct ReadSmem {
-    // sizes depend on (K, H, D0, hop); carved from dynamic LDS
+// ---- one or two branches ("User" alone in every reference configuration; "User" + "item" in dual mode, or "item"
+//      alone: code/hpmn.py:452-462 / :307-317).  Each branch has its own memory, query row, attention stacks and covariance
+//      regulariser; the head sees repre = concat over branches of [query_b, last_b], memory_loss = sum of the branches'.
+struct ReadArgs {
+    HpmnReadDesc d[2];          // per branch: K, H, D0, hop, off_wq/bq/map/att; head offsets, n_params, seed, B: d[0]'s
+    const float *memory[2], *last[2];
+    float *d_memory[2], *d_last[2];
+    float *att_w0[2];
+    int nb, W;                  // branches; head input width = sum_b (H_b + D0_b)
+};
+
+struct BranchSmem {
     float *mem;      // [RS*K][H]        memory slots of the tile
-    float *dmem;     // [RS*K][H]        gradient wrt memory (training)
     float *last;     // [RS][D0]
     float *q;        // [hop+1][RS][H]   query before each hop and after the last
-    float *inp;      // [RS*K][4H]       attention MLP input of the current hop
     float *x1;       // [hop][RS*K][A1]
     float *x2;       // [hop][RS*K][A2]
     float *sc;       // [hop][RS*K]      softmax scores
-    float *rep;      // [RS][H+D0]       head input (bn output after the affine map)
-    float *h1;       // [RS][F1]
-    float *h2;       // [RS][F2]
-    float *t1;       // scratch [RS*K][A1] (d of x1) / [RS][F1]
-    float *t2;       // scratch [RS*K][A2] / [RS][F2]
-    float *t3;       // scratch [RS*K] / [RS]
-    float *dq;       // [RS][H]
-    float *drep;     // [RS][H+D0]
     float *cmean;    // [RS*K]        slot means (covariance regulariser)
     float *ccov;     // [RS*K*K]      off-diagonal covariance
     float *cnorm;    // [RS]          Frobenius norms
+};
+struct ReadSmem {
+    // sizes depend on the branches' (K, H, D0, hop); carved from dynamic LDS
+    BranchSmem br[2];
+    float *inp;      // [RS*Kmax][4Hmax]  attention MLP input of the current hop (one branch at a time)
+    float *dmem;     // [RS*Kmax][Hmax]   gradient wrt memory of the branch being differentiated (training)
+    float *rep;      // [RS][W]           head input (bn output after the affine map)
+    float *h1;       // [RS][F1]
+    float *h2;       // [RS][F2]
+    float *t1;       // scratch [RS*Kmax][A1] (d of x1) / [RS][F1]
+    float *t2;       // scratch [RS*Kmax][A2] / [RS][F2]
+    float *t3;       // scratch [RS*Kmax] / [RS]
+    float *dq;       // [RS][Hmax]
+    float *tq;       // [RS][Hmax]
+    float *drep;     // [RS][W]
     float *zero;     // [max(H, D0)] zeros (bias of the bias-free products)
     float *mk1;      // [RS][F1]  dropout factor mask/keep_prob of the tile (training)
     float *mk2;      // [RS][F2]
 };
 
-__host__ __device__ inline size_t read_smem_floats(int K, int H, int D0, int hop, bool train) {
-    const size_t RK = (size_t)RS * K;
-    size_t n = RK * H + (size_t)RS * D0 + (size_t)(hop + 1) * RS * H + RK * 4 * H + (size_t)hop * RK * (A1 + A2 + 1) +
-               (size_t)RS * (H + D0) + (size_t)RS * (F1 + F2);
-    if (train) n += RK * H + RK * (A1 + A2 + 1) + (size_t)RS * H + (size_t)RS * (H + D0) + 64;
-    else n += 64;
-    n += RK + RK * K + RS + 16;
-    n += (size_t)(H > D0 ? H : D0) + 4;
-    n += (size_t)RS * (F1 + F2) + 8;
-    return n + 64;
+struct ReadDims { int Kmax, Hmax, Zmax, W; };
+__host__ __device__ inline ReadDims read_dims(const HpmnReadDesc &d0, const HpmnReadDesc &d1, int nb) {
+    ReadDims m;
+    m.Kmax = d0.K; m.Hmax = d0.H; m.Zmax = d0.H > d0.D0 ? d0.H : d0.D0; m.W = d0.H + d0.D0;
+    if (nb > 1) {
+        m.Kmax = d1.K > m.Kmax ? d1.K : m.Kmax;
+        m.Hmax = d1.H > m.Hmax ? d1.H : m.Hmax;
+        const int z = d1.H > d1.D0 ? d1.H : d1.D0;
+        m.Zmax = z > m.Zmax ? z : m.Zmax;
+        m.W += d1.H + d1.D0;
+    }
+    return m;
 }
 
-__device__ inline void carve(ReadSmem &s, float *base, int K, int H, int D0, int hop, bool train) {
-    const int RK = RS * K;
-    float *p = base;
-    auto take = [&](size_t n) { float *r = p; p += (n + 3) / 4 * 4; return r; };
-    s.mem = take((size_t)RK * H);
-    s.last = take((size_t)RS * D0);
-    s.q = take((size_t)(hop + 1) * RS * H);
-    s.inp = take((size_t)RK * 4 * H);
-    s.x1 = take((size_t)hop * RK * A1);
-    s.x2 = take((size_t)hop * RK * A2);
-    s.sc = take((size_t)hop * RK);
-    s.rep = take((size_t)RS * (H + D0));
+// carve of the dynamic LDS (straight-line on purpose: pointer tables indexed at run time put the kernel's argument
+// struct into scratch memory).  Returns the float count.
+__host__ __device__ inline size_t carve_branch(BranchSmem &x, float *base, size_t off, const HpmnReadDesc &d) {
+    auto take = [&](size_t n) { float *r = base ? base + off : nullptr; off += (n + 3) / 4 * 4; return r; };
+    const size_t RK = (size_t)RS * d.K;
+    x.mem = take(RK * d.H);
+    x.last = take((size_t)RS * d.D0);
+    x.q = take((size_t)(d.hop + 1) * RS * d.H);
+    x.x1 = take((size_t)d.hop * RK * A1);
+    x.x2 = take((size_t)d.hop * RK * A2);
+    x.sc = take((size_t)d.hop * RK);
+    x.cmean = take(RK);
+    x.ccov = take(RK * d.K);
+    x.cnorm = take(RS);
+    return off;
+}
+
+__host__ __device__ inline size_t carve_all(ReadSmem &s, float *base, const HpmnReadDesc &d0, const HpmnReadDesc &d1, int nb,
+                                            bool train) {
+    size_t off = 0;
+    auto take = [&](size_t n) { float *r = base ? base + off : nullptr; off += (n + 3) / 4 * 4; return r; };
+    const ReadDims m = read_dims(d0, d1, nb);
+    const size_t RKm = (size_t)RS * m.Kmax;
+    off = carve_branch(s.br[0], base, off, d0);
+    if (nb > 1) off = carve_branch(s.br[1], base, off, d1);
+    s.inp = take(RKm * 4 * m.Hmax);
+    s.rep = take((size_t)RS * m.W);
     s.h1 = take((size_t)RS * F1);
     s.h2 = take((size_t)RS * F2);
-    s.t3 = take(64);
-    s.cmean = take((size_t)RK);
-    s.ccov = take((size_t)RK * K);
-    s.cnorm = take(RS);
-    s.zero = take((size_t)(H > D0 ? H : D0));
-    for (int o = threadIdx.x; o < (H > D0 ? H : D0); o += RT) s.zero[o] = 0.f;   // visible after the caller's first barrier
+    s.t3 = take(RKm > 64 ? RKm + 64 : 128);        // (+ the per-sample scalars behind entries 32 / 48)
+    s.zero = take((size_t)m.Zmax);
     s.mk1 = take((size_t)RS * F1);
     s.mk2 = take((size_t)RS * F2);
+    s.dmem = s.t1 = s.t2 = s.dq = s.tq = s.drep = nullptr;
     if (train) {
-        s.dmem = take((size_t)RK * H);
-        s.t1 = take((size_t)RK * A1 > (size_t)RS * F1 ? (size_t)RK * A1 : (size_t)RS * F1);
-        s.t2 = take((size_t)RK * A2 > (size_t)RS * F2 ? (size_t)RK * A2 : (size_t)RS * F2);
-        s.dq = take((size_t)RS * H);
-        s.drep = take((size_t)RS * (H + D0));
-    } else {
-        s.dmem = s.t1 = s.t2 = s.dq = s.drep = nullptr;
+        s.dmem = take(RKm * m.Hmax);
+        s.t1 = take(RKm * A1 > (size_t)RS * F1 ? RKm * A1 : (size_t)RS * F1);
+        s.t2 = take(RKm * A2 > (size_t)RS * F2 ? RKm * A2 : (size_t)RS * F2);
+        s.dq = take((size_t)RS * m.Hmax);
+        s.tq = take((size_t)RS * m.Hmax);
+        s.drep = take((size_t)RS * m.W);
     }
+    return off + 16;
 }
 
-// ---- forward of one tile; leaves every activation in LDS --------------------------------------
-// returns (in s.t3[0..R)) the logits; covariance loss of the tile accumulated into *cov_out.
-__device__ void read_forward_tile(const HpmnReadDesc &d, const float *P, const ReadSmem &s, int R,
-                                  const float *mask1, const float *mask2, float keep_prob, long b0, float *cov_sum) {
+inline size_t read_smem_floats(const HpmnReadDesc *d, int nb, bool train) {
+    ReadSmem s;
+    return carve_all(s, nullptr, d[0], d[nb > 1 ? 1 : 0], nb, train);
+}
+
+__device__ inline void carve(ReadSmem &s, float *base, const ReadArgs &a, bool train) {
+    carve_all(s, base, a.d[0], a.d[1], a.nb, train);
+    const ReadDims m = read_dims(a.d[0], a.d[1], a.nb);
+    for (int o = threadIdx.x; o < m.Zmax; o += RT) s.zero[o] = 0.f;   // visible after the caller's first barrier
+}
+
+// ---- forward of one branch of one tile: query, hops, covariance regulariser; leaves every activation in LDS and the
+//      per-sample Frobenius norm in x.cnorm --------------------------------------------------------------------------
+__device__ __forceinline__ void read_forward_branch(const HpmnReadDesc &d, const float *P, const ReadSmem &s, const BranchSmem &x, int R) {
     const int K = d.K, H = d.H, D0 = d.D0, RK = R * K;
     const int tid = threadIdx.x;
     // q0 = last Wq + bq  (code/hpmn.py:173)
-    dense_fwd<0>(s.last, D0, R, D0, P + d.off_wq, P + d.off_bq, H, s.q, H);
+    dense_fwd<0>(x.last, D0, R, D0, P + d.off_wq, P + d.off_bq, H, x.q, H);
     __syncthreads();
     for (int hop = 0; hop < d.hop; ++hop) {
-        const float *q = s.q + (size_t)hop * RS * H;
+        const float *q = x.q + (size_t)hop * RS * H;
         // inp = [q, m, q-m, q*m]  (code/hpmn.py:135-136)
         for (int o = tid; o < RK * H; o += RT) {
             const int row = o / H, i = o - row * H;
-            const float qv = q[(row / K) * H + i], mv = s.mem[row * H + i];
-            float *x = s.inp + (size_t)row * 4 * H;
-            x[i] = qv; x[H + i] = mv; x[2 * H + i] = qv - mv; x[3 * H + i] = qv * mv;
+            const float qv = q[(row / K) * H + i], mv = x.mem[row * H + i];
+            float *xi = s.inp + (size_t)row * 4 * H;
+            xi[i] = qv; xi[H + i] = mv; xi[2 * H + i] = qv - mv; xi[3 * H + i] = qv * mv;
         }
         __syncthreads();
-        float *x1 = s.x1 + (size_t)hop * RS * K * A1, *x2 = s.x2 + (size_t)hop * RS * K * A2;
-        float *sc = s.sc + (size_t)hop * RS * K;
+        float *x1 = x.x1 + (size_t)hop * RS * K * A1, *x2 = x.x2 + (size_t)hop * RS * K * A2;
+        float *sc = x.sc + (size_t)hop * RS * K;
         const int *oa = d.off_att[hop];
         dense_fwd<1>(s.inp, 4 * H, RK, 4 * H, P + oa[0], P + oa[1], A1, x1, A1);
         __syncthreads();
@@ -454,13 +493,13 @@ __device__ void read_forward_tile(const HpmnReadDesc &d, const float *P, const R
         }
         __syncthreads();
         // q' = q Hmap + sum_k score_k m_k   (code/hpmn.py:143-144, 179)
-        float *qn = s.q + (size_t)(hop + 1) * RS * H;
+        float *qn = x.q + (size_t)(hop + 1) * RS * H;
         dense_fwd<0>(q, H, R, H, P + d.off_map, s.zero, H, qn, H);        // q Hmap (no bias: a row of zeros)
         __syncthreads();
         for (int o = tid; o < R * H; o += RT) {
             const int r = o / H, n = o - r * H;
             float acc = qn[o];
-            for (int k = 0; k < K; ++k) acc = fmaf(sc[r * K + k], s.mem[(r * K + k) * H + n], acc);
+            for (int k = 0; k < K; ++k) acc = fmaf(sc[r * K + k], x.mem[(r * K + k) * H + n], acc);
             qn[o] = acc;
         }
         __syncthreads();
@@ -469,8 +508,8 @@ __device__ void read_forward_tile(const HpmnReadDesc &d, const float *P, const R
     // Parallel over (sample, slot[, slot]); means / covariances stay in LDS for the backward.
     for (int o = tid; o < RK; o += RT) {
         float a = 0.f;
-        for (int i = 0; i < H; ++i) a += s.mem[o * H + i];
-        s.cmean[o] = a / H;
+        for (int i = 0; i < H; ++i) a += x.mem[o * H + i];
+        x.cmean[o] = a / H;
     }
     __syncthreads();
     for (int o = tid; o < RK * K; o += RT) {
@@ -478,75 +517,96 @@ __device__ void read_forward_tile(const HpmnReadDesc &d, const float *P, const R
         const int r = rk / K, k = rk - r * K;
         float cv = 0.f;
         if (j != k) {
-            const float *mk = s.mem + (size_t)rk * H, *mj = s.mem + (size_t)(r * K + j) * H;
-            const float ak = s.cmean[rk], aj = s.cmean[r * K + j];
+            const float *mk = x.mem + (size_t)rk * H, *mj = x.mem + (size_t)(r * K + j) * H;
+            const float ak = x.cmean[rk], aj = x.cmean[r * K + j];
             for (int i = 0; i < H; ++i) cv = fmaf(mk[i] - ak, mj[i] - aj, cv);
             cv /= H;
         }
-        s.ccov[o] = cv;
+        x.ccov[o] = cv;
     }
     __syncthreads();
     if (tid < R) {
         float ss = 0.f;
-        for (int o = 0; o < K * K; ++o) { const float cv = s.ccov[tid * K * K + o]; ss = fmaf(cv, cv, ss); }
-        s.cnorm[tid] = sqrtf(ss);
-        cov_sum[tid] = s.cnorm[tid];
+        for (int o = 0; o < K * K; ++o) { const float cv = x.ccov[tid * K * K + o]; ss = fmaf(cv, cv, ss); }
+        x.cnorm[tid] = sqrtf(ss);
     }
-    // head (code/hpmn.py:190-199): repre = [q, last]; bn (inference affine); fc1 elu; dropout; fc2 elu; dropout; fc3
-    const float *qf = s.q + (size_t)d.hop * RS * H;
+    __syncthreads();
+}
+
+// ---- forward of one tile: every branch, then the head.  Returns (in s.t3[0..R)) the logits and (in cov_sum[0..R)) the
+//      samples' covariance losses summed over the branches ---------------------------------------------------------
+__device__ __forceinline__ void read_forward_tile(const ReadArgs &a, const float *P, const ReadSmem &s, int R,
+                                  const float *mask1, const float *mask2, float keep_prob, long b0, float *cov_sum) {
+    const HpmnReadDesc &d0 = a.d[0];
+    const int tid = threadIdx.x, W = a.W;
+    read_forward_branch(a.d[0], P, s, s.br[0], R);
+    if (a.nb > 1) read_forward_branch(a.d[1], P, s, s.br[1], R);
+    if (tid < R) cov_sum[tid] = s.br[0].cnorm[tid] + (a.nb > 1 ? s.br[1].cnorm[tid] : 0.f);
+    // head (code/hpmn.py:190-199): repre = concat_b [q_b, last_b]; bn (inference affine); fc1 elu; dropout; fc2 elu;
+    // dropout; fc3
     const float bn_scale = rsqrtf(1.f + 1e-3f);
-    for (int o = tid; o < R * (H + D0); o += RT) {
-        const int r = o / (H + D0), i = o - r * (H + D0);
-        const float v = i < H ? qf[r * H + i] : s.last[r * D0 + (i - H)];
-        s.rep[o] = v * (P[d.off_gamma + i] * bn_scale) + P[d.off_beta + i];
+    int off = 0;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        if (b >= a.nb) break;
+        const int H = a.d[b].H, D0 = a.d[b].D0;
+        const float *qf = s.br[b].q + (size_t)a.d[b].hop * RS * H;
+        for (int o = tid; o < R * (H + D0); o += RT) {
+            const int r = o / (H + D0), i = o - r * (H + D0);
+            const float v = i < H ? qf[r * H + i] : s.br[b].last[r * D0 + (i - H)];
+            s.rep[r * W + off + i] = v * (P[d0.off_gamma + off + i] * bn_scale) + P[d0.off_beta + off + i];
+        }
+        off += H + D0;
     }
     __syncthreads();
-    dense_fwd<2>(s.rep, H + D0, R, H + D0, P + d.off_fc[0], P + d.off_fc[1], F1, s.h1, F1);
+    dense_fwd<2>(s.rep, W, R, W, P + d0.off_fc[0], P + d0.off_fc[1], F1, s.h1, F1);
     __syncthreads();
-    const bool drop = mask1 != nullptr || mask2 != nullptr || (d.dropout_seed != 0 && keep_prob < 1.f);
+    const bool drop = mask1 != nullptr || mask2 != nullptr || (d0.dropout_seed != 0 && keep_prob < 1.f);
     if (drop) {
         // the tile's dropout factors, once, into LDS (the hash is 64-bit integer math: kept out of line and out
         // of the layer loops -- inlined at its four use sites it doubled the kernel's registers and spilled)
 #pragma unroll 1
         for (int o = tid; o < R * F1; o += RT)
-            s.mk1[o] = keep_factor(mask1, d.dropout_seed, 1, b0 + o / F1, o % F1, F1, keep_prob) / keep_prob;
+            s.mk1[o] = keep_factor(mask1, d0.dropout_seed, 1, b0 + o / F1, o % F1, F1, keep_prob) / keep_prob;
 #pragma unroll 1
         for (int o = tid; o < R * F2; o += RT)
-            s.mk2[o] = keep_factor(mask2, d.dropout_seed, 2, b0 + o / F2, o % F2, F2, keep_prob) / keep_prob;
+            s.mk2[o] = keep_factor(mask2, d0.dropout_seed, 2, b0 + o / F2, o % F2, F2, keep_prob) / keep_prob;
         __syncthreads();
         for (int o = tid; o < R * F1; o += RT) s.h1[o] *= s.mk1[o];
         __syncthreads();
     }
-    dense_fwd<2>(s.h1, F1, R, F1, P + d.off_fc[2], P + d.off_fc[3], F2, s.h2, F2);
+    dense_fwd<2>(s.h1, F1, R, F1, P + d0.off_fc[2], P + d0.off_fc[3], F2, s.h2, F2);
     __syncthreads();
     if (drop) {
         for (int o = tid; o < R * F2; o += RT) s.h2[o] *= s.mk2[o];
         __syncthreads();
     }
-    dense_fwd<0>(s.h2, F2, R, F2, P + d.off_fc[4], P + d.off_fc[5], 1, s.t3, 1);
+    dense_fwd<0>(s.h2, F2, R, F2, P + d0.off_fc[4], P + d0.off_fc[5], 1, s.t3, 1);
     __syncthreads();
 }
 
-__device__ inline void load_tile_inputs(const HpmnReadDesc &d, const ReadSmem &s, const float *memory, const float *last,
-                                        long b0, int R) {
-    const int K = d.K, H = d.H, D0 = d.D0;
-    for (int o = threadIdx.x; o < R * K * H; o += RT) s.mem[o] = memory[b0 * K * H + o];
-    for (int o = threadIdx.x; o < R * D0; o += RT) s.last[o] = last[b0 * D0 + o];
+__device__ inline void load_tile_inputs(const ReadArgs &a, const ReadSmem &s, long b0, int R) {
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        if (b >= a.nb) break;
+        const int K = a.d[b].K, H = a.d[b].H, D0 = a.d[b].D0;
+        for (int o = threadIdx.x; o < R * K * H; o += RT) s.br[b].mem[o] = a.memory[b][b0 * K * H + o];
+        for (int o = threadIdx.x; o < R * D0; o += RT) s.br[b].last[o] = a.last[b][b0 * D0 + o];
+    }
     __syncthreads();
 }
 
-__global__ __launch_bounds__(RT) void read_fwd_kernel(const HpmnReadDesc d, const float *__restrict__ P,
-                                                      const float *__restrict__ memory,
-                                                      const float *__restrict__ last, float *pred, float *logit,
-                                                      float *att_w0, float *mem_loss) {
+__global__ __launch_bounds__(RT) void read_fwd_kernel(const ReadArgs a, const float *__restrict__ P, float *pred,
+                                                      float *logit, float *mem_loss) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     ReadSmem s;
-    carve(s, smem, d.K, d.H, d.D0, d.hop, false);
+    carve(s, smem, a, false);
     const long b0 = (long)blockIdx.x * RS;
-    const int R = (d.B - b0) < RS ? (int)(d.B - b0) : RS;
-    load_tile_inputs(d, s, memory, last, b0, R);
+    const int B = a.d[0].B;
+    const int R = (B - b0) < RS ? (int)(B - b0) : RS;
+    load_tile_inputs(a, s, b0, R);
     float *cov = s.t3 + 32;
-    read_forward_tile(d, P, s, R, nullptr, nullptr, 1.f, b0, cov);
+    read_forward_tile(a, P, s, R, nullptr, nullptr, 1.f, b0, cov);
     const int tid = threadIdx.x;
     if (tid < R) {
         const float lg = s.t3[tid];
@@ -554,34 +614,155 @@ __global__ __launch_bounds__(RT) void read_fwd_kernel(const HpmnReadDesc d, cons
         pred[b0 + tid] = 1.f / (1.f + __expf(-lg));
         atomicAdd(mem_loss, cov[tid]);
     }
-    if (att_w0) for (int o = tid; o < R * d.K; o += RT) att_w0[b0 * d.K + o] = s.sc[o];   // first hop (code/hpmn.py:182)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)         // first hop (code/hpmn.py:182)
+        if (b < a.nb && a.att_w0[b]) for (int o = tid; o < R * a.d[b].K; o += RT) a.att_w0[b][b0 * a.d[b].K + o] = s.br[b].sc[o];
+}
+
+// ---- backward of one branch: covariance regulariser, hops in reverse, q0; needs s.dq = gradient wrt the branch's final
+//      query and s.drep[:, doff .. doff + D0) = the head's gradient wrt the branch's `last` row; writes d_memory / d_last of
+//      the tile and the branch's parameter gradients into the slab G --------------------------------------------------
+__device__ __forceinline__ void read_backward_branch(const HpmnReadDesc &d, const float *P, const ReadSmem &s, const BranchSmem &x, int R,
+                                     float memory_reg, float *G, float *d_memory, float *d_last, long b0, int doff, int W) {
+    const int K = d.K, H = d.H, D0 = d.D0, RK = R * K;
+    const int tid = threadIdx.x;
+    // covariance regulariser backward into dmem (code/hpmn.py:161-170): loss_b = ||C_off||_F,
+    // C = cc^T / H with c = m - mean_H(m):  d m = (2/(H*norm)) * (C_off c) projected off the mean
+    for (int o = tid; o < RK * H; o += RT) s.dmem[o] = 0.f;
+    __syncthreads();
+    if (memory_reg != 0.f) {
+        // dL/dC_kj = C_kj / nrm (off-diagonal); dL/dc_k = (2/H) sum_j dC_kj c_j; the mean subtraction is a
+        // projection that leaves it unchanged because sum_i c_j[i] = 0
+        for (int o = tid; o < RK * H; o += RT) {
+            const int rk = o / H, i = o - rk * H;
+            const int r = rk / K;
+            const float nrm = x.cnorm[r];
+            float acc = 0.f;
+            if (nrm > 0.f) {
+                for (int j = 0; j < K; ++j)
+                    acc = fmaf(x.ccov[rk * K + j], x.mem[(size_t)(r * K + j) * H + i] - x.cmean[r * K + j], acc);
+                acc *= memory_reg * 2.f / (H * nrm);
+            }
+            s.dmem[o] = acc;
+        }
+    }
+    __syncthreads();
+
+    // ---- hops backward (reverse order) ---------------------------------------------------------
+    // zero the shared-across-hops gradient of Hmap in the slab, accumulate per hop
+    for (int o = tid; o < H * H; o += RT) G[d.off_map + o] = 0.f;
+    __syncthreads();
+    for (int hop = d.hop - 1; hop >= 0; --hop) {
+        const float *q = x.q + (size_t)hop * RS * H;           // query entering this hop
+        float *x1 = x.x1 + (size_t)hop * RS * K * A1, *x2 = x.x2 + (size_t)hop * RS * K * A2;
+        float *sc = x.sc + (size_t)hop * RS * K;
+        const int *oa = d.off_att[hop];
+        // q' = q Hmap + sum_k sc_k m_k : d Hmap += q^T dq';  d sc_k = <dq', m_k>;  d m_k += sc_k dq'
+        for (int o = tid; o < H * H; o += RT) {
+            const int i = o / H, n = o - i * H;
+            float acc = 0.f;
+            for (int r = 0; r < R; ++r) acc = fmaf(q[r * H + i], s.dq[r * H + n], acc);
+            G[d.off_map + o] += acc;
+        }
+        float *dsc = s.t3;          // [RK]
+        for (int o = tid; o < RK; o += RT) {
+            const int r = o / K;
+            float acc = 0.f;
+            for (int i = 0; i < H; ++i) acc = fmaf(s.dq[r * H + i], x.mem[o * H + i], acc);
+            dsc[o] = acc;
+        }
+        for (int o = tid; o < RK * H; o += RT) {
+            const int row = o / H, i = o - row * H;
+            s.dmem[o] = fmaf(sc[row], s.dq[(row / K) * H + i], s.dmem[o]);
+        }
+        __syncthreads();
+        // softmax backward: d s_k = sc_k (d sc_k - sum_j sc_j d sc_j)
+        if (tid < R) {
+            float dot = 0.f;
+            for (int k = 0; k < K; ++k) dot = fmaf(sc[tid * K + k], dsc[tid * K + k], dot);
+            for (int k = 0; k < K; ++k) dsc[tid * K + k] = sc[tid * K + k] * (dsc[tid * K + k] - dot);
+        }
+        __syncthreads();
+        // rebuild inp of this hop (the forward overwrote it hop by hop)
+        for (int o = tid; o < RK * H; o += RT) {
+            const int row = o / H, i = o - row * H;
+            const float qv = q[(row / K) * H + i], mv = x.mem[row * H + i];
+            float *xi = s.inp + (size_t)row * 4 * H;
+            xi[i] = qv; xi[H + i] = mv; xi[2 * H + i] = qv - mv; xi[3 * H + i] = qv * mv;
+        }
+        // fc3 (A2 -> 1, no activation)
+        dense_bwd_w<false>(x2, A2, dsc, 1, RK, A2, 1, G + oa[4], G + oa[5]);
+        dense_bwd_x<false>(dsc, 1, RK, 1, P + oa[4], A2, s.t2, A2);
+        __syncthreads();
+        for (int o = tid; o < RK * A2; o += RT) s.t2[o] = x2[o] > 0.f ? s.t2[o] : 0.f;      // relu
+        __syncthreads();
+        dense_bwd_w<false>(x1, A1, s.t2, A2, RK, A1, A2, G + oa[2], G + oa[3]);
+        dense_bwd_x<false>(s.t2, A2, RK, A2, P + oa[2], A1, s.t1, A1);
+        __syncthreads();
+        for (int o = tid; o < RK * A1; o += RT) s.t1[o] = x1[o] > 0.f ? s.t1[o] : 0.f;      // relu
+        __syncthreads();
+        dense_bwd_w<false>(s.inp, 4 * H, s.t1, A1, RK, 4 * H, A1, G + oa[0], G + oa[1]);
+        // d inp [RK, 4H] -> reuse s.inp AFTER the weight gradient has consumed it
+        __syncthreads();
+        dense_bwd_x<false>(s.t1, A1, RK, A1, P + oa[0], 4 * H, s.inp, 4 * H);
+        __syncthreads();
+        // inp = [q, m, q-m, q*m]:  dq_row = d0 + d2 + d3*m ; dm += d1 - d2 + d3*q
+        // new dq (gradient wrt the query entering the hop) = dq' Hmap^T + sum_k dq_row
+        float *dqn = s.tq;          // [R][H]
+        dense_bwd_x<false>(s.dq, H, R, H, P + d.off_map, H, dqn, H);     // dq' Hmap^T
+        __syncthreads();
+        for (int o = tid; o < R * H; o += RT) {
+            const int r = o / H, i = o - r * H;
+            float acc = dqn[o];
+            for (int k = 0; k < K; ++k) {
+                const float *di = s.inp + (size_t)(r * K + k) * 4 * H;
+                acc += di[i] + di[2 * H + i] + di[3 * H + i] * x.mem[(r * K + k) * H + i];
+            }
+            dqn[o] = acc;
+        }
+        for (int o = tid; o < RK * H; o += RT) {
+            const int row = o / H, i = o - row * H;
+            const float *di = s.inp + (size_t)row * 4 * H;
+            s.dmem[o] += di[H + i] - di[2 * H + i] + di[3 * H + i] * q[(row / K) * H + i];
+        }
+        __syncthreads();
+        for (int o = tid; o < R * H; o += RT) s.dq[o] = dqn[o];
+        __syncthreads();
+    }
+    // q0 = last Wq + bq
+    dense_bwd_w<false>(x.last, D0, s.dq, H, R, D0, H, G + d.off_wq, G + d.off_bq);
+    dense_bwd_x<true>(s.dq, H, R, H, P + d.off_wq, D0, s.drep + doff, W);      // += dq Wq^T onto the head part
+    __syncthreads();
+    for (int o = tid; o < R * D0; o += RT) {
+        const int r = o / D0, i = o - r * D0;
+        d_last[b0 * D0 + o] = s.drep[r * W + doff + i];
+    }
+    for (int o = tid; o < RK * H; o += RT) d_memory[b0 * K * H + o] = s.dmem[o];
+    __syncthreads();
 }
 
 // Training: forward + loss + backward of the tile in one launch.
 //   loss = sum_b ll_b * inv_global_batch + memory_reg * sum_b cov_b        (code/hpmn.py:202-207)
-// outputs: pred [B]; loss_out[0] += sum ll_b, loss_out[1] += sum cov_b (atomics); d_memory [B,K,H];
-// d_last [B,D0]; slab[blockIdx] = this tile's read-path weight gradients (layout == parameter range).
-__global__ __launch_bounds__(RT) void read_fwd_bwd_kernel(const HpmnReadDesc d, const float *__restrict__ P,
-                                                          const float *__restrict__ memory,
-                                                          const float *__restrict__ last,
+// outputs: pred [B]; loss_out[0] += sum ll_b, loss_out[1] += sum cov_b (atomics); d_memory [B,K,H] and d_last [B,D0] of
+// every branch; slab[blockIdx] = this tile's read-path weight gradients (layout == parameter range).
+__global__ __launch_bounds__(RT) void read_fwd_bwd_kernel(const ReadArgs a, const float *__restrict__ P,
                                                           const int32_t *__restrict__ label,
                                                           const float *__restrict__ mask1,
                                                           const float *__restrict__ mask2, float keep_prob,
                                                           float inv_global_batch, float memory_reg, float *pred,
-                                                          float *loss_out, float *d_memory, float *d_last,
-                                                          float *slabs) {
+                                                          float *loss_out, float *slabs) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     ReadSmem s;
-    const int K = d.K, H = d.H, D0 = d.D0;
-    carve(s, smem, K, H, D0, d.hop, true);
+    const HpmnReadDesc &d = a.d[0];
+    const int W = a.W;
+    carve(s, smem, a, true);
     const int tid = threadIdx.x;
     const long b0 = (long)blockIdx.x * RS;
     const int R = (d.B - b0) < RS ? (int)(d.B - b0) : RS;
-    const int RK = R * K;
     float *G = slabs + (long)blockIdx.x * d.n_params;      // this tile's gradient slab
-    load_tile_inputs(d, s, memory, last, b0, R);
+    load_tile_inputs(a, s, b0, R);
     float *cov = s.t3 + 32;
-    read_forward_tile(d, P, s, R, mask1, mask2, keep_prob, b0, cov);
+    read_forward_tile(a, P, s, R, mask1, mask2, keep_prob, b0, cov);
     const bool drop = mask1 != nullptr || mask2 != nullptr || (d.dropout_seed != 0 && keep_prob < 1.f);
 
     // ---- loss and d logit -------------------------------------------------------------------
@@ -623,143 +804,49 @@ __global__ __launch_bounds__(RT) void read_fwd_bwd_kernel(const HpmnReadDesc d, 
         s.t1[o] = s.t1[o] * mk * (hv > 0.f ? 1.f : hv + 1.f);
     }
     __syncthreads();
-    dense_bwd_w<false>(s.rep, H + D0, s.t1, F1, R, H + D0, F1, G + d.off_fc[0], G + d.off_fc[1]);
-    dense_bwd_x<false>(s.t1, F1, R, F1, P + d.off_fc[0], H + D0, s.drep, H + D0);   // d bn-output
+    dense_bwd_w<false>(s.rep, W, s.t1, F1, R, W, F1, G + d.off_fc[0], G + d.off_fc[1]);
+    dense_bwd_x<false>(s.t1, F1, R, F1, P + d.off_fc[0], W, s.drep, W);   // d bn-output
     __syncthreads();
-    // bn affine: rep = v*gamma*scale + beta  ->  d gamma, d beta, d v; v = [q_final, last]
+    // bn affine: rep = v*gamma*scale + beta  ->  d gamma, d beta, d v; v = concat_b [q_final_b, last_b]
     const float bn_scale = rsqrtf(1.f + 1e-3f);
-    const float *qf = s.q + (size_t)d.hop * RS * H;
-    for (int i = tid; i < H + D0; i += RT) {
-        float gg = 0.f, gb = 0.f;
-        for (int r = 0; r < R; ++r) {
-            const float v = i < H ? qf[r * H + i] : s.last[r * D0 + (i - H)];
-            const float dy = s.drep[r * (H + D0) + i];
-            gg = fmaf(dy, v * bn_scale, gg);
-            gb += dy;
+    {
+        int off = 0;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            if (b >= a.nb) break;
+            const int H = a.d[b].H, D0 = a.d[b].D0;
+            const float *qf = s.br[b].q + (size_t)a.d[b].hop * RS * H;
+            for (int i = tid; i < H + D0; i += RT) {
+                float gg = 0.f, gb = 0.f;
+                for (int r = 0; r < R; ++r) {
+                    const float v = i < H ? qf[r * H + i] : s.br[b].last[r * D0 + (i - H)];
+                    const float dy = s.drep[r * W + off + i];
+                    gg = fmaf(dy, v * bn_scale, gg);
+                    gb += dy;
+                }
+                G[d.off_gamma + off + i] = gg;
+                G[d.off_beta + off + i] = gb;
+            }
+            off += H + D0;
         }
-        G[d.off_gamma + i] = gg;
-        G[d.off_beta + i] = gb;
     }
     __syncthreads();          // the loop below rescales s.drep in place
-    // d q_final -> s.dq ; d last (head part) -> kept in s.drep[:, H:] scaled
-    for (int o = tid; o < R * (H + D0); o += RT) {
-        const int r = o / (H + D0), i = o - r * (H + D0);
-        const float dv = s.drep[o] * P[d.off_gamma + i] * bn_scale;
-        if (i < H) s.dq[r * H + i] = dv;
-        else s.drep[o] = dv;
-    }
-    // covariance regulariser backward into dmem (code/hpmn.py:161-170): loss_b = ||C_off||_F,
-    // C = cc^T / H with c = m - mean_H(m):  d m = (2/(H*norm)) * (C_off c) projected off the mean
-    for (int o = tid; o < RK * H; o += RT) s.dmem[o] = 0.f;
-    __syncthreads();
-    if (memory_reg != 0.f) {
-        // dL/dC_kj = C_kj / nrm (off-diagonal); dL/dc_k = (2/H) sum_j dC_kj c_j; the mean subtraction is a
-        // projection that leaves it unchanged because sum_i c_j[i] = 0
-        for (int o = tid; o < RK * H; o += RT) {
-            const int rk = o / H, i = o - rk * H;
-            const int r = rk / K;
-            const float nrm = s.cnorm[r];
-            float acc = 0.f;
-            if (nrm > 0.f) {
-                for (int j = 0; j < K; ++j)
-                    acc = fmaf(s.ccov[rk * K + j], s.mem[(size_t)(r * K + j) * H + i] - s.cmean[r * K + j], acc);
-                acc *= memory_reg * 2.f / (H * nrm);
-            }
-            s.dmem[o] = acc;
-        }
+    for (int o = tid; o < R * W; o += RT) {
+        const int i = o % W;
+        s.drep[o] *= P[d.off_gamma + i] * bn_scale;            // now: gradient wrt [q_final_b, last_b] of every branch
     }
     __syncthreads();
-
-    // ---- hops backward (reverse order) ---------------------------------------------------------
-    // zero the shared-across-hops gradient of Hmap in the slab, accumulate per hop
-    for (int o = tid; o < H * H; o += RT) G[d.off_map + o] = 0.f;
-    __syncthreads();
-    for (int hop = d.hop - 1; hop >= 0; --hop) {
-        const float *q = s.q + (size_t)hop * RS * H;           // query entering this hop
-        float *x1 = s.x1 + (size_t)hop * RS * K * A1, *x2 = s.x2 + (size_t)hop * RS * K * A2;
-        float *sc = s.sc + (size_t)hop * RS * K;
-        const int *oa = d.off_att[hop];
-        // q' = q Hmap + sum_k sc_k m_k : d Hmap += q^T dq';  d sc_k = <dq', m_k>;  d m_k += sc_k dq'
-        for (int o = tid; o < H * H; o += RT) {
-            const int i = o / H, n = o - i * H;
-            float acc = 0.f;
-            for (int r = 0; r < R; ++r) acc = fmaf(q[r * H + i], s.dq[r * H + n], acc);
-            G[d.off_map + o] += acc;
-        }
-        float *dsc = s.t3;          // [RK]
-        for (int o = tid; o < RK; o += RT) {
-            const int r = o / K;
-            float acc = 0.f;
-            for (int i = 0; i < H; ++i) acc = fmaf(s.dq[r * H + i], s.mem[o * H + i], acc);
-            dsc[o] = acc;
-        }
-        for (int o = tid; o < RK * H; o += RT) {
-            const int row = o / H, i = o - row * H;
-            s.dmem[o] = fmaf(sc[row], s.dq[(row / K) * H + i], s.dmem[o]);
-        }
+    // ---- the branches ---------------------------------------------------------------------------
+    int off = 0;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        if (b >= a.nb) break;
+        const int H = a.d[b].H, D0 = a.d[b].D0;
+        for (int o = tid; o < R * H; o += RT) s.dq[o] = s.drep[(o / H) * W + off + (o % H)];
         __syncthreads();
-        // softmax backward: d s_k = sc_k (d sc_k - sum_j sc_j d sc_j)
-        if (tid < R) {
-            float dot = 0.f;
-            for (int k = 0; k < K; ++k) dot = fmaf(sc[tid * K + k], dsc[tid * K + k], dot);
-            for (int k = 0; k < K; ++k) dsc[tid * K + k] = sc[tid * K + k] * (dsc[tid * K + k] - dot);
-        }
-        __syncthreads();
-        // rebuild inp of this hop (the forward overwrote it hop by hop)
-        for (int o = tid; o < RK * H; o += RT) {
-            const int row = o / H, i = o - row * H;
-            const float qv = q[(row / K) * H + i], mv = s.mem[row * H + i];
-            float *x = s.inp + (size_t)row * 4 * H;
-            x[i] = qv; x[H + i] = mv; x[2 * H + i] = qv - mv; x[3 * H + i] = qv * mv;
-        }
-        // fc3 (A2 -> 1, no activation)
-        dense_bwd_w<false>(x2, A2, dsc, 1, RK, A2, 1, G + oa[4], G + oa[5]);
-        dense_bwd_x<false>(dsc, 1, RK, 1, P + oa[4], A2, s.t2, A2);
-        __syncthreads();
-        for (int o = tid; o < RK * A2; o += RT) s.t2[o] = x2[o] > 0.f ? s.t2[o] : 0.f;      // relu
-        __syncthreads();
-        dense_bwd_w<false>(x1, A1, s.t2, A2, RK, A1, A2, G + oa[2], G + oa[3]);
-        dense_bwd_x<false>(s.t2, A2, RK, A2, P + oa[2], A1, s.t1, A1);
-        __syncthreads();
-        for (int o = tid; o < RK * A1; o += RT) s.t1[o] = x1[o] > 0.f ? s.t1[o] : 0.f;      // relu
-        __syncthreads();
-        dense_bwd_w<false>(s.inp, 4 * H, s.t1, A1, RK, 4 * H, A1, G + oa[0], G + oa[1]);
-        // d inp [RK, 4H] -> reuse s.inp AFTER the weight gradient has consumed it
-        __syncthreads();
-        dense_bwd_x<false>(s.t1, A1, RK, A1, P + oa[0], 4 * H, s.inp, 4 * H);
-        __syncthreads();
-        // inp = [q, m, q-m, q*m]:  dq_row = d0 + d2 + d3*m ; dm += d1 - d2 + d3*q
-        // new dq (gradient wrt the query entering the hop) = dq' Hmap^T + sum_k dq_row
-        float *dqn = s.drep;        // [R][H] scratch: only columns [0,H) of each row are used here ...
-        dense_bwd_x<false>(s.dq, H, R, H, P + d.off_map, H, dqn, H + D0);     // dq' Hmap^T
-        __syncthreads();
-        for (int o = tid; o < R * H; o += RT) {
-            const int r = o / H, i = o - r * H;
-            float acc = dqn[r * (H + D0) + i];
-            for (int k = 0; k < K; ++k) {
-                const float *di = s.inp + (size_t)(r * K + k) * 4 * H;
-                acc += di[i] + di[2 * H + i] + di[3 * H + i] * s.mem[(r * K + k) * H + i];
-            }
-            dqn[r * (H + D0) + i] = acc;     // ... with the head's row stride so d_last (cols >= H) is untouched
-        }
-        for (int o = tid; o < RK * H; o += RT) {
-            const int row = o / H, i = o - row * H;
-            const float *di = s.inp + (size_t)row * 4 * H;
-            s.dmem[o] += di[H + i] - di[2 * H + i] + di[3 * H + i] * q[(row / K) * H + i];
-        }
-        __syncthreads();
-        for (int o = tid; o < R * H; o += RT) s.dq[o] = dqn[(o / H) * (H + D0) + (o % H)];
-        __syncthreads();
+        read_backward_branch(a.d[b], P, s, s.br[b], R, memory_reg, G, a.d_memory[b], a.d_last[b], b0, off + H, W);
+        off += H + D0;
     }
-    // q0 = last Wq + bq
-    dense_bwd_w<false>(s.last, D0, s.dq, H, R, D0, H, G + d.off_wq, G + d.off_bq);
-    dense_bwd_x<true>(s.dq, H, R, H, P + d.off_wq, D0, s.drep + H, H + D0);      // += dq Wq^T onto the head part
-    __syncthreads();
-    for (int o = tid; o < R * D0; o += RT) {
-        const int r = o / D0, i = o - r * D0;
-        d_last[b0 * D0 + o] = s.drep[r * (H + D0) + H + i];
-    }
-    for (int o = tid; o < RK * H; o += RT) d_memory[b0 * K * H + o] = s.dmem[o];
 }
 
 // grad[e] += sum over tiles of slabs[w][e].  A block owns 32 consecutive elements; its 8 groups of 32 lanes
@@ -801,35 +888,73 @@ size_t read_workspace_bytes(const HpmnReadDesc &d) {
     return (size_t)ntile * (size_t)d.n_params * sizeof(float);
 }
 
-int read_fwd_launch(const HpmnReadDesc &d, const float *P, const float *memory, const float *last, float *pred,
-                    float *logit, float *att_w0, float *mem_loss, hipStream_t st) {
-    if (!read_desc_ok(d)) return HPMN_EUNSUPPORTED;
-    const size_t lds = read_smem_floats(d.K, d.H, d.D0, d.hop, false) * sizeof(float);
+// nb = 1: d[0] alone (the "User"-only graph); nb = 2: d[0], d[1] in the order of the head's concat (user, item).
+static int read_args(ReadArgs &a, const HpmnReadDesc *const *d, int nb, const float *const *memory,
+                     const float *const *last, float *const *d_memory, float *const *d_last, float *const *att_w0) {
+    if (nb < 1 || nb > 2) return HPMN_EINVAL;
+    a = ReadArgs{};
+    a.nb = nb;
+    for (int b = 0; b < nb; ++b) {
+        if (!d[b] || !read_desc_ok(*d[b]) || d[b]->B != d[0]->B) return d[b] ? HPMN_EUNSUPPORTED : HPMN_EINVAL;
+        a.d[b] = *d[b];
+        a.memory[b] = memory[b]; a.last[b] = last[b];
+        a.d_memory[b] = d_memory ? d_memory[b] : nullptr;
+        a.d_last[b] = d_last ? d_last[b] : nullptr;
+        a.att_w0[b] = att_w0 ? att_w0[b] : nullptr;
+        a.W += d[b]->H + d[b]->D0;
+    }
+    return HPMN_OK;
+}
+
+int read_fwd_launch_n(const HpmnReadDesc *const *d, int nb, const float *P, const float *const *memory,
+                      const float *const *last, float *pred, float *logit, float *const *att_w0, float *mem_loss,
+                      hipStream_t st) {
+    ReadArgs a;
+    int rc = read_args(a, d, nb, memory, last, nullptr, nullptr, att_w0);
+    if (rc != HPMN_OK) return rc;
+    const size_t lds = read_smem_floats(a.d, nb, false) * sizeof(float);
     if (lds > 160 * 1024) return HPMN_EUNSUPPORTED;
     hipError_t e = hipFuncSetAttribute((const void *)read_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { set_last_hip_error((int)e); return HPMN_EHIP; }
-    const unsigned grid = (unsigned)((d.B + RS - 1) / RS);
-    hipLaunchKernelGGL(read_fwd_kernel, dim3(grid), dim3(RT), lds, st, d, P, memory, last, pred, logit, att_w0, mem_loss);
+    const unsigned grid = (unsigned)((a.d[0].B + RS - 1) / RS);
+    hipLaunchKernelGGL(read_fwd_kernel, dim3(grid), dim3(RT), lds, st, a, P, pred, logit, mem_loss);
     return check_launch();
+}
+
+int read_fwd_bwd_launch_n(const HpmnReadDesc *const *d, int nb, const float *P, const float *const *memory,
+                          const float *const *last, const int32_t *label, const float *mask1, const float *mask2,
+                          float keep_prob, float inv_global_batch, float memory_reg, float *pred, float *loss_out,
+                          float *const *d_memory, float *const *d_last, float *d_params, float *workspace, hipStream_t st) {
+    ReadArgs a;
+    int rc = read_args(a, d, nb, memory, last, d_memory, d_last, nullptr);
+    if (rc != HPMN_OK) return rc;
+    const size_t lds = read_smem_floats(a.d, nb, true) * sizeof(float);
+    if (lds > 160 * 1024) return HPMN_EUNSUPPORTED;
+    hipError_t e = hipFuncSetAttribute((const void *)read_fwd_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { set_last_hip_error((int)e); return HPMN_EHIP; }
+    const unsigned grid = (unsigned)((a.d[0].B + RS - 1) / RS);
+    hipLaunchKernelGGL(read_fwd_bwd_kernel, dim3(grid), dim3(RT), lds, st, a, P, label, mask1, mask2, keep_prob,
+                       inv_global_batch, memory_reg, pred, loss_out, workspace);
+    rc = check_launch();
+    if (rc != HPMN_OK || d_params == nullptr) return rc;      // (NULL: the caller reduces the slabs itself, read_reduce_launch)
+    hipLaunchKernelGGL(read_reduce_kernel, dim3((unsigned)((a.d[0].n_params + 31) / 32)), dim3(32 * RRED_G), 0, st, workspace,
+                       (int)grid, a.d[0].n_params, d_params);
+    return check_launch();
+}
+
+int read_fwd_launch(const HpmnReadDesc &d, const float *P, const float *memory, const float *last, float *pred,
+                    float *logit, float *att_w0, float *mem_loss, hipStream_t st) {
+    const HpmnReadDesc *dp[1] = {&d};
+    return read_fwd_launch_n(dp, 1, P, &memory, &last, pred, logit, &att_w0, mem_loss, st);
 }
 
 int read_fwd_bwd_launch(const HpmnReadDesc &d, const float *P, const float *memory, const float *last,
                         const int32_t *label, const float *mask1, const float *mask2, float keep_prob,
                         float inv_global_batch, float memory_reg, float *pred, float *loss_out, float *d_memory,
                         float *d_last, float *d_params, float *workspace, hipStream_t st) {
-    if (!read_desc_ok(d)) return HPMN_EUNSUPPORTED;
-    const size_t lds = read_smem_floats(d.K, d.H, d.D0, d.hop, true) * sizeof(float);
-    if (lds > 160 * 1024) return HPMN_EUNSUPPORTED;
-    hipError_t e = hipFuncSetAttribute((const void *)read_fwd_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) { set_last_hip_error((int)e); return HPMN_EHIP; }
-    const unsigned grid = (unsigned)((d.B + RS - 1) / RS);
-    hipLaunchKernelGGL(read_fwd_bwd_kernel, dim3(grid), dim3(RT), lds, st, d, P, memory, last, label, mask1, mask2,
-                       keep_prob, inv_global_batch, memory_reg, pred, loss_out, d_memory, d_last, workspace);
-    int rc = check_launch();
-    if (rc != HPMN_OK || d_params == nullptr) return rc;      // (NULL: the caller reduces the slabs itself, read_reduce_launch)
-    hipLaunchKernelGGL(read_reduce_kernel, dim3((unsigned)((d.n_params + 31) / 32)), dim3(32 * RRED_G), 0, st, workspace,
-                       (int)grid, d.n_params, d_params);
-    return check_launch();
+    const HpmnReadDesc *dp[1] = {&d};
+    return read_fwd_bwd_launch_n(dp, 1, P, &memory, &last, label, mask1, mask2, keep_prob, inv_global_batch, memory_reg,
+                                 pred, loss_out, &d_memory, &d_last, d_params, workspace, st);
 }
 
 // the second half of read_fwd_bwd_launch on its own: d_params += the per-workgroup slabs the kernel left in `workspace`

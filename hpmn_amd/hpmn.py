@@ -190,7 +190,7 @@ class Hpmn_Basic(object):
         self.item_scope = "Item" if self.industry else "item"
         self._branches = ([("User", self.spec, self.user_num_layers)] if user else []) + \
                          ([(self.item_scope, self.item_spec, self.item_num_layers)] if item else [])
-        self._hip_read = bool(user and not item)     # the fused HIP read kernel serves the user-only graph
+        self._hip_read = bool(user and not item)     # user-only graph: the four-library-call step (no item-side scan)
         self._build_variables(emb_initializer, seed)
         self.adam_t = 0
         self.beta1, self.beta2, self.adam_eps = 0.9, 0.999, 1e-8   # tf.train.AdamOptimizer defaults
@@ -209,12 +209,16 @@ class Hpmn_Basic(object):
         H = self.hidden_size
         shp = [("Embedding/emb_mtx", (self.feature_size, self.embedding_size))]
         width = 0
+        # (every branch's GRU variables first, the read-path variables behind them: the read kernel addresses ITS
+        #  variables -- of both branches in dual mode -- as one contiguous range of the flat buffer)
         for scope, spec, K in self._branches:
             D0 = spec.D0
             for i in range(K):
                 d = D0 if i == 0 else H
                 shp += [("%s/GRU%d/gates/kernel" % (scope, i), (d + H, 2 * H)), ("%s/GRU%d/gates/bias" % (scope, i), (2 * H,)),
                         ("%s/GRU%d/candidate/kernel" % (scope, i), (d + H, H)), ("%s/GRU%d/candidate/bias" % (scope, i), (H,))]
+        for scope, spec, K in self._branches:
+            D0 = spec.D0
             shp += [(scope + "/dense/kernel", (D0, H)), (scope + "/dense/bias", (H,)), (scope + "/map", (H, H))]
             n = 1
             for _ in range(self.hop):
@@ -275,10 +279,7 @@ class Hpmn_Basic(object):
                                        ("gates/kernel", "gates/bias", "candidate/kernel", "candidate/bias")]
                                       for i in range(K)] for scope, _, K in self._branches}
         self._gru_names = self._gru_names_of[self._branches[0][0]]
-        if self._hip_read:
-            self._make_read_desc()
-        else:
-            self._read_names = [n for n, _ in shapes if "/GRU" not in n and n != "Embedding/emb_mtx"]
+        self._make_read_desc()
 
     def set_params(self, values: Dict[str, np.ndarray]):
         """Inject weights (parity tests: identical weights => identical logits)."""
@@ -295,23 +296,29 @@ class Hpmn_Basic(object):
 
     # ------------------------------------------------------------------ read path (code/hpmn.py:133-207)
     def _make_read_desc(self):
-        """Offsets of the read-path variables inside their contiguous range of the flat buffer."""
+        """Offsets of the read-path variables inside their contiguous range of the flat buffer: one descriptor per branch
+        the graph executes (user, item -- the order of the head's concat); the head's offsets ride in the first."""
         from ._lib import HpmnReadDesc
-        start = self._offs["User/dense/kernel"]
+        first = self._branches[0][0]
+        start = self._offs[first + "/dense/kernel"]
         rel = lambda name: self._offs[name] - start
-        d = HpmnReadDesc()
-        d.K, d.H, d.D0, d.hop = self.user_num_layers, self.hidden_size, self.spec.D0, self.hop
-        d.off_wq, d.off_bq, d.off_map = rel("User/dense/kernel"), rel("User/dense/bias"), rel("User/map")
-        for h in range(self.hop):
-            for j in range(3):
-                d.off_att[h][2 * j] = rel("User/dense_%d/kernel" % (3 * h + j + 1))
-                d.off_att[h][2 * j + 1] = rel("User/dense_%d/bias" % (3 * h + j + 1))
-        d.off_gamma, d.off_beta = rel("output/bn1/gamma"), rel("output/bn1/beta")
-        for j, name in enumerate(("fc1", "fc2", "fc3")):
-            d.off_fc[2 * j] = rel("output/%s/kernel" % name)
-            d.off_fc[2 * j + 1] = rel("output/%s/bias" % name)
-        d.n_params = self._n_flat - start
-        self._read_desc = d
+        descs = []
+        for scope, spec, K in self._branches:
+            d = HpmnReadDesc()
+            d.K, d.H, d.D0, d.hop = K, self.hidden_size, spec.D0, self.hop
+            d.off_wq, d.off_bq, d.off_map = rel(scope + "/dense/kernel"), rel(scope + "/dense/bias"), rel(scope + "/map")
+            for h in range(self.hop):
+                for j in range(3):
+                    d.off_att[h][2 * j] = rel("%s/dense_%d/kernel" % (scope, 3 * h + j + 1))
+                    d.off_att[h][2 * j + 1] = rel("%s/dense_%d/bias" % (scope, 3 * h + j + 1))
+            d.off_gamma, d.off_beta = rel("output/bn1/gamma"), rel("output/bn1/beta")
+            for j, name in enumerate(("fc1", "fc2", "fc3")):
+                d.off_fc[2 * j] = rel("output/%s/kernel" % name)
+                d.off_fc[2 * j + 1] = rel("output/%s/bias" % name)
+            d.n_params = self._n_flat - start
+            descs.append(d)
+        self._read_descs = descs
+        self._read_desc = descs[0]
         self._read_params = self.flat_param[start:]
         self._read_grads = self.flat_grad[start - self._goff:]
 
@@ -341,59 +348,46 @@ class Hpmn_Basic(object):
 
     @torch.no_grad()
     def _forward_inference_branches(self, ids, item_ids):
-        """item=True graphs, eval mode: both scans on the HIP inference chain, the joint read on device ops."""
-        from . import read_torch as RT
+        """item=True graphs, eval mode: both scans on the HIP inference chain, the joint read path -- two attention stacks
+        into one head -- in ONE launch of the read kernel (hpmn_read_fwd_n)."""
         emb = self.params["Embedding/emb_mtx"]
-        br, mems = [], {}
+        scopes, memories, lasts = [], [], []
         for scope, spec, x in self._branch_inputs(ids, item_ids):
             memory, last = ops.scan_forward_inference(spec, x, emb, self._gru_weights(scope))
-            br.append((scope, self.hop, memory, last))
-            mems[scope] = memory
-        B = br[0][2].shape[0]
+            scopes.append(scope); memories.append(memory); lasts.append(last)
+        mems = dict(zip(scopes, memories))
+        B = memories[0].shape[0]
         if B == 0:
             z = torch.empty(0, device=self.device)
-            return dict(prediction=z, logit=z, memory_loss=torch.zeros((), device=self.device), memory=br[0][2],
+            return dict(prediction=z, logit=z, memory_loss=torch.zeros((), device=self.device), memory=memories[0],
                         user_weights=torch.empty(0, self._branches[0][2], device=self.device))
-        out = RT.read(self.params, br, 1.0)
-        first = self._branches[0][0]
+        out = ops.read_fwd_n(self._read_descs, self._read_params, memories, lasts)
+        w = dict(zip(scopes, out["weights"]))
         return dict(prediction=out["prediction"], logit=out["logit"], memory_loss=out["memory_loss"],
-                    memory=mems[first], memories=mems, user_weights=out["weights"].get("User"),
-                    item_weights=out["weights"].get(self.item_scope))
+                    memory=memories[0], memories=mems, user_weights=w.get("User"), item_weights=w.get(self.item_scope))
 
     def _compute_gradients_branches(self, ids, item_ids, label, keep_prob, masks, global_batch, defer_join):
-        """item=True graphs: scan forward (HIP, per branch) -> joint read path + loss under autograd (device ops)
-        -> scan BPTT + embedding scatter (HIP, per branch) into the flat gradient."""
-        from . import read_torch as RT
+        """item=True graphs: scan forward (per branch) -> the joint read path, its loss and every gradient of them in one
+        launch of the read kernel (hpmn_read_fwd_bwd_n) -> scan BPTT + embedding scatter (per branch) into the flat
+        gradient.  No autograd anywhere."""
         emb = self.params["Embedding/emb_mtx"]
         fw = []
         with torch.no_grad():
             for scope, spec, x in self._branch_inputs(ids, item_ids):
                 memory, last, saved = ops.scan_forward_train(spec, x, emb, self._gru_weights(scope))
                 fw.append((scope, spec, x, memory, last, saved))
-        with torch.enable_grad():
-            leaves = [(m.detach().requires_grad_(True), l.detach().requires_grad_(True)) for _, _, _, m, l, _ in fw]
-            rp = {n: self.params[n].detach().requires_grad_(True) for n in self._read_names}
-            gen = None
+            seed = 0
             if masks is None and keep_prob < 1.0:
                 self._dropout_step += 1
-                gen = torch.Generator(device=self.device)
-                gen.manual_seed(_splitmix64(_splitmix64(self._dropout_base + self._dropout_step) ^ (self.rank + 1)) & (2 ** 62 - 1))
-            out = RT.read(rp, [(f[0], self.hop, mm, ll) for f, (mm, ll) in zip(fw, leaves)], keep_prob, masks, gen)
-            ll_sum = RT.log_loss_sum(out["prediction"], label)
-            loss = ll_sum / float(global_batch) + self.memory_reg * out["memory_loss"]
-            wrt = [t for pair in leaves for t in pair] + list(rp.values())
-            grads = torch.autograd.grad(loss, wrt, allow_unused=True)
-        with torch.no_grad():
-            for n, g in zip(rp, grads[2 * len(leaves):]):
-                if g is not None:
-                    self.grads[n].add_(g)
-            pendings = []
+                seed = _splitmix64(_splitmix64(self._dropout_base + self._dropout_step) ^ (self.rank + 1)) | 1
+            out = ops.read_fwd_bwd_n(self._read_descs, self._read_params, self._read_grads, [f[3] for f in fw],
+                                     [f[4] for f in fw], label, masks, keep_prob, 1.0 / float(global_batch),
+                                     self.memory_reg, dropout_seed=seed)
+            ll_sum = out["log_loss_sum"]
             for j, (scope, spec, x, memory, last, saved) in enumerate(fw):
-                gm, gl = grads[2 * j], grads[2 * j + 1]
-                gm = torch.zeros_like(memory) if gm is None else gm.contiguous()
-                gl = torch.zeros_like(last) if gl is None else gl.contiguous()
                 grad_out = [self.grads["Embedding/emb_mtx"]] + [self.grads[n] for ns in self._gru_names_of[scope] for n in ns]
-                pend = ops.scan_backward(spec, x, saved, self._gru_weights(scope), gm, gl, grad_out, defer_join=False)
+                pend = ops.scan_backward(spec, x, saved, self._gru_weights(scope), out["d_memory"][j], out["d_last"][j],
+                                         grad_out, defer_join=False)
                 if pend is not None:
                     pend.join()
             res = dict(prediction=out["prediction"].detach(), log_loss_sum=ll_sum.detach(),

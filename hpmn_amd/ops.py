@@ -1123,3 +1123,62 @@ def read_fwd_bwd(desc, params, d_params, memory, last, label, masks, keep_prob, 
                        "hpmn_read_param_grads")
         out["reduce_param_grads"] = reduce_param_grads
     return out
+
+
+def _desc_array(descs):
+    arr = (C.POINTER(_lib.HpmnReadDesc) * len(descs))()
+    for i, d in enumerate(descs):
+        arr[i] = C.pointer(d)
+    return arr
+
+
+def _ptr_array(ts):
+    return (C.c_void_p * len(ts))(*[None if t is None else t.data_ptr() for t in ts])
+
+
+def read_fwd_n(descs, params, memories, lasts, want_logit=True, want_att=True):
+    """hpmn_read_fwd_n: the read path of a graph with ``len(descs)`` branches (user, item) in one launch
+    -> dict(prediction, logit?, weights = [first-hop attention weights per branch], memory_loss)."""
+    _chk_f32(params, *memories, *lasts)
+    B = memories[0].shape[0]
+    dev = params.device
+    for d in descs:
+        d.B = B
+    pred = torch.empty(B, device=dev)
+    logit = torch.empty(B, device=dev) if want_logit else None
+    atts = [torch.empty(B, m.shape[1], device=dev) if want_att else None for m in memories]
+    mem_loss = torch.zeros(1, device=dev)
+    rc = _lib.load().hpmn_read_fwd_n(len(descs), _desc_array(descs), params.data_ptr(), _ptr_array(memories),
+                                      _ptr_array(lasts), pred.data_ptr(), _ptr(logit), _ptr_array(atts),
+                                      mem_loss.data_ptr(), _stream())
+    _lib.check(rc, "hpmn_read_fwd_n")
+    return dict(prediction=pred, logit=logit, weights=atts, memory_loss=mem_loss[0])
+
+
+def read_fwd_bwd_n(descs, params, d_params, memories, lasts, label, masks, keep_prob, inv_global_batch, memory_reg,
+                   dropout_seed: int = 0, loss_out: Optional[torch.Tensor] = None):
+    """hpmn_read_fwd_bwd_n: forward + loss + backward of the read path of a graph with several branches; accumulates into
+    d_params.  -> dict(prediction, log_loss_sum, memory_loss, d_memory = [...], d_last = [...])."""
+    _chk_f32(params, d_params, *memories, *lasts)
+    B = memories[0].shape[0]
+    dev = params.device
+    for d in descs:
+        d.B = B
+    descs[0].dropout_seed = int(dropout_seed) & 0xFFFFFFFFFFFFFFFF
+    assert label.dtype == torch.int32 and label.is_contiguous()
+    pred = torch.empty(B, device=dev)
+    if loss_out is None:
+        loss_out = torch.zeros(2, device=dev)
+    d_mem = [torch.empty_like(m) for m in memories]
+    d_last = [torch.empty_like(l) for l in lasts]
+    m1 = m2 = None
+    if masks is not None:
+        m1, m2 = masks
+        _chk_f32(m1, m2)
+    ws = _read_workspace(descs[0], dev)
+    rc = _lib.load().hpmn_read_fwd_bwd_n(len(descs), _desc_array(descs), params.data_ptr(), _ptr_array(memories),
+                                          _ptr_array(lasts), label.data_ptr(), _ptr(m1), _ptr(m2), float(keep_prob),
+                                          float(inv_global_batch), float(memory_reg), pred.data_ptr(), loss_out.data_ptr(),
+                                          _ptr_array(d_mem), _ptr_array(d_last), d_params.data_ptr(), ws.data_ptr(), _stream())
+    _lib.check(rc, "hpmn_read_fwd_bwd_n")
+    return dict(prediction=pred, log_loss_sum=loss_out[0], memory_loss=loss_out[1], d_memory=d_mem, d_last=d_last)

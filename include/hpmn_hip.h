@@ -435,6 +435,19 @@ int hpmn_read_fwd_bwd(const HpmnReadDesc *desc, const float *params, const float
                       const int32_t *label, const float *mask1, const float *mask2, float keep_prob,
                       float inv_global_batch, float memory_reg, float *pred, float *loss_out,
                       float *d_memory, float *d_last, float *d_params, float *workspace, void *stream);
+/* The same for graphs that execute the ITEM branch (code/hpmn.py:444-462, Industry :297-317): nb = 2 branches in the order
+ * of the head's concat (user, item) -- repre = [query_u, last_u, query_i, last_i], memory_loss = umloss + imloss -- or nb = 1
+ * (either branch alone; identical to the calls above).  desc[b] carries branch b's K, H, D0, hop and the offsets of ITS
+ * dense / map / attention variables; the head's offsets (off_gamma, off_beta: sum_b (H_b + D0_b) wide, off_fc), n_params,
+ * dropout_seed and B are read from desc[0].  memory / last / att_w0 / d_memory / d_last: nb pointers each.  One launch:
+ * both attention stacks, the head, the loss and every gradient of them. */
+int hpmn_read_fwd_n(int32_t nb, const HpmnReadDesc *const *desc, const float *params, const float *const *memory,
+                    const float *const *last, float *pred, float *logit, float *const *att_w0, float *mem_loss,
+                    void *stream);
+int hpmn_read_fwd_bwd_n(int32_t nb, const HpmnReadDesc *const *desc, const float *params, const float *const *memory,
+                        const float *const *last, const int32_t *label, const float *mask1, const float *mask2,
+                        float keep_prob, float inv_global_batch, float memory_reg, float *pred, float *loss_out,
+                        float *const *d_memory, float *const *d_last, float *d_params, float *workspace, void *stream);
 /* BPTT only waits for d_memory / d_last.  With d_params == NULL hpmn_read_fwd_bwd leaves the parameter gradients as
  * per-workgroup partial sums in `workspace`, and this call (any stream ordered behind it, before `workspace` is used
  * again) adds them to d_params -- the reduction (30 us at the reference batch) then need not sit on the serial chain. */
