@@ -210,6 +210,9 @@ GRAD_CASES = [
     # C2 -- four id columns (F=4, D0=64: gather + x_out split, 4-column scatter) with periods 2,2,3,5,5;
     # C1 -- the reference batch of 128 at K=4
     ("xlong_c3_shape", cfg_industry(H=64, K=7, T=1001, V=2000), 5),
+    # ... and wide enough that the reverse path's two-sequence workgroups, odd/even pairing and the slab reductions over
+    # dozens of partials are what the oracle sees (the 500-sequence reverse path had only been checked forward)
+    ("xlong_c3_b66", cfg_industry(H=64, K=7, T=1001, V=4000), 66),
     ("xlong_c4_h128", cfg_industry(H=128, K=7, T=1001, V=2000), 2),
     ("taobao_c2_shape", O.HpmnConfig(600, 4, 300, 64, 16, 3, (2, 2, 3, 5, 5, 1), 5, False, 1e-5), 4),
     ("amazon_c1_b128", cfg_amazon(K=4, V=3000), 128),
@@ -221,6 +224,12 @@ def test_gradients_match_float64_autograd(dev, tmp_path, name, cfg, B):
     p = f32_params(cfg, 41)
     ids, label = rand_ids(cfg, B, 42)
     ids[:, :, 0] = ids[:, -1:, 0]                  # constant uid column -> run-length pre-reduction path
+    if B > 32 and cfg.user_maxlen > 500:
+        # With random weights a wide batch holds samples whose logit is beyond +-16.6: in float32 -- TF's arithmetic as
+        # much as ours -- sigmoid() is then exactly 0 or 1 and a confidently WRONG label's loss term and gradient saturate
+        # (log(0 + 1e-7), p (1 - p) = 0), which the float64 oracle does not reproduce.  Labels that agree with the
+        # prediction keep every sample on the side where both precisions agree.
+        label = (O.forward(cfg, p, ids)["prediction"] > 0.5).astype(np.int32)
     # oracle gradients (float64 autograd over the restatement)
     tp = R.to_torch(p, torch.float64, requires_grad=True)
     ref = R.forward(cfg, tp, torch.as_tensor(ids.astype(np.int64)), torch.as_tensor(label.astype(np.int64)))
@@ -895,14 +904,16 @@ def test_two_pass_table_adam_equals_the_dense_sweep(dev, tmp_path, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B,K,T,runs", [(6, 3, 41, 24), (75, 3, 41, 24), (9, 7, 1001, 9), (3, 5, 297, 12)])
-def test_scans_give_the_same_result_beside_an_unrelated_kernel(dev, tmp_path, B, K, T, runs):
+@pytest.mark.parametrize("B,K,T,runs,H", [(6, 3, 41, 24, 64), (75, 3, 41, 24, 64), (9, 7, 1001, 9, 64), (3, 5, 297, 12, 64),
+                                           (5, 3, 41, 16, 128), (4, 4, 297, 8, 128), (7, 3, 41, 16, 32)])
+def test_scans_give_the_same_result_beside_an_unrelated_kernel(dev, tmp_path, B, K, T, runs, H):
     """The two-wave scan kernels hand data between waves through LDS behind progress counters; a missing condition
     there only shows when one wave is slowed down.  A 2.5 GB fill on another stream beside the step does that (it is
     how a stale projection tile in the fused forward was found): forward outputs, saved states and every gradient must
-    not depend on it."""
+    not depend on it.  H = 128 runs the four-wave barrier kernels, H = 32 the one-wave kernels; the first-generation and
+    helper-wave H = 64 kernels run this test in the subprocesses of test_fallback_kernel_paths_still_match_the_oracle."""
     from hpmn_amd import ops
-    cfg = cfg_industry(H=64, K=K, T=T, V=600)          # (T + 23 zero steps: 64, 1024, 320 -> odd upper layers)
+    cfg = cfg_industry(H=H, K=K, T=T, V=600)           # (T + 23 zero steps: 64, 1024, 320 -> odd upper layers)
     p = f32_params(cfg, 151)
     ids, label = rand_ids(cfg, B, 152)
     m = make_model(cfg, tmp_path, p)
@@ -949,7 +960,8 @@ def test_fallback_kernel_paths_still_match_the_oracle(env):
     e.update(env)
     here = os.path.dirname(os.path.abspath(__file__))
     r = subprocess.run([sys.executable, "-m", "pytest", here, "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider",
-                        "-k", "(tiny_and_odd and 64) or xlong_c3_shape or c_abi_alone"],
+                        "-k", "(tiny_and_odd and 64) or xlong_c3_shape or c_abi_alone or (beside_an_unrelated and 6-3-41)"
+                              " or (beside_an_unrelated and 3-5-297)"],
                        env=e, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
