@@ -440,7 +440,7 @@ def dp_report(model, c, batches, world, ms_per_step, n_model=8, busbw_gbps=300.0
     RCCL typically sustains about a third to a half of that on 8 GPUs), hidden only under layer 0's weight gradient on the
     helper stream (the ~0.3 ms between the scatter and the dense Adam), everything else exposed."""
     from hpmn_amd import dist
-    E = c["E"]
+    E = int(model.params["Embedding/emb_mtx"].shape[1])
     n_emb = int(model.params["Embedding/emb_mtx"].numel())
     n_dense = int(model.flat_param.numel()) - n_emb
     uniq = [int(torch.unique(b[0].reshape(-1)).numel()) for b in batches[:4]]

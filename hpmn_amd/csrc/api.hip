@@ -1,6 +1,7 @@
 // extern "C" surface of libhpmn_hip.so (declared in include/hpmn_hip.h): argument
 // validation, shape dispatch, and the multi-layer build_memory forward chain.
 #include "common.h"
+#include "gru32_all.h"
 
 namespace hpmn {
 
@@ -302,6 +303,11 @@ int hpmn_scan_fwd(const HpmnScanDesc *d, const int32_t *ids, const float *emb, c
     float *xp = reinterpret_cast<float *>(ws);
     float *ybuf[2] = {reinterpret_cast<float *>(ws + xp_bytes), reinterpret_cast<float *>(ws + xp_bytes + y_bytes)};
 
+    if (gru32_all_enabled() && gru32_all_supported(d->H, D0, d->K, d->E)) {
+        All32Args a = {};
+        gru32_all_fill(a, *d, len, ids, emb, wg, bg, wc, bc, memory, last);
+        return gru32_fwd_all_launch(a, D0, false, st);
+    }
     if (scan_fwd_pairs_ok(*d, D0) && gru_fused_fwd_writes_last())
         return scan_fwd_pairs(*d, len, ids, emb, wg, bg, wc, bc, memory, last, ybuf,
                               reinterpret_cast<float *>(ws + xp_bytes + 2 * y_bytes), st);

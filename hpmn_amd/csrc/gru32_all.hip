@@ -1,0 +1,261 @@
+// build_memory for H = 32 -- the reference's own hidden size (code/hpmn.py:586, :614, :653) -- with ALL K layers and the
+// embedding gather in ONE launch per direction: the kernel north_star describes ("a fused embedding-gather + K-layer
+// periodic-GRU scan kernel that stages hidden states ... in LDS, uses wavefront shuffles for the per-layer reductions").
+//
+// At the reference shapes (Amazon: B = 128, T = 100, K = 3-4) a layer's scan is 5-50 us of pure latency and the step was
+// ~35 launches of ~10 us each; the layers form a pipeline (layer i+1 consumes every period-th output of layer i,
+// code/hpmn.py:124-128) that one launch per layer serialises.  Here a workgroup owns ONE sequence and gives every layer a
+// wave of its own (K <= 7 -> at most eight waves with the loader, on up to four SIMDs):
+//
+//   wave K (loader)  gathers the layer-0 input rows (ids -> embedding rows, id-0 mask, zero prefix) a few steps ahead into
+//                    an LDS ring; in training it also writes the materialised gather (the weight gradient's input) and the
+//                    read path's `last` row
+//   wave i (layer i) the whole layer: input product AND recurrence.  H = 32 makes both small enough for one wave if the
+//                    64 lanes split k: lane (unit j = lane / 2, half h = lane % 2) holds the weights of unit j's three
+//                    gates over half of the input features and half of the state -- 3 (D/2 + 16) <= 144 registers --,
+//                    reads its half of x_t and of h_{t-1} as broadcast 16-byte LDS loads, and the two halves meet in ONE
+//                    quad_perm DPP add per gate.  Rows that fire go to the next layer's wave through an 8-row LDS ring
+//                    behind a pair of counters (rows published / rows taken); nothing but the saved states of a training
+//                    pass ever leaves the CU.
+//
+// All layers advance concurrently, so the launch takes about as long as layer 0 alone.
+//
+// The reverse launch mirrors it: wave i runs layer i's reverse scan, forms the gradient wrt its own input rows
+// (d_x = d_act [Wg[:D] | Wc[:D]]^T, 96 x D per step on the lane pairs) right behind every step and hands it down a ring as
+// the d_y of the layer below; layer 0's d_x goes to memory for the embedding scatter.
+#include <cstdlib>
+
+#include "gru32_all.h"
+
+namespace hpmn {
+
+constexpr int AH = 32;
+constexpr int AXR = 16;          // rows of the layer-0 input ring
+constexpr int AYR = 8;           // rows of an inter-layer ring
+struct RingCtr { int pub, taken; };
+
+// the two lanes of a unit add their halves
+__device__ __forceinline__ float pair_sum(float v) { return v + dpp_quad<0xB1>(v); }
+
+// ---------------------------------------------------------------------------------------------------- forward, one layer
+template <int D, bool TRAIN>
+__device__ __forceinline__ void all32_layer_fwd(const All32Args &a, const int i, const long b, const int lane,
+                                                const float *in_ring, const int in_depth, RingCtr *in_ctr,
+                                                float *out_ring, RingCtr *out_ctr, float (*hb)[AH], float *rhb) {
+    constexpr int H = AH, DX = D / 2;
+    static_assert(D % 8 == 0, "half rows are read 16 bytes at a time");
+    const int j = lane >> 1, h = lane & 1;
+    const int T = a.len[i], period = a.period[i];
+    const float *wg = a.wg[i], *wc = a.wc[i];
+    f2 wxr[DX / 2], wxu[DX / 2], wxc[DX / 2], whr[8], whu[8], whc[8];
+#pragma unroll
+    for (int q = 0; q < DX / 2; ++q) {
+        const long k = h * DX + 2 * q;
+        wxr[q] = f2{wg[k * 2 * H + j], wg[(k + 1) * 2 * H + j]} * NEG_LOG2E;
+        wxu[q] = f2{wg[k * 2 * H + H + j], wg[(k + 1) * 2 * H + H + j]} * NEG_LOG2E;
+        wxc[q] = f2{wc[k * H + j], wc[(k + 1) * H + j]} * (2.0f * NEG_LOG2E);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const long k = D + 16 * h + 2 * q;
+        whr[q] = f2{wg[k * 2 * H + j], wg[(k + 1) * 2 * H + j]} * NEG_LOG2E;
+        whu[q] = f2{wg[k * 2 * H + H + j], wg[(k + 1) * 2 * H + H + j]} * NEG_LOG2E;
+        whc[q] = f2{wc[k * H + j], wc[(k + 1) * H + j]} * (2.0f * NEG_LOG2E);
+    }
+#pragma unroll
+    for (int q = 0; q < DX / 2; ++q) { settle(wxr[q]); settle(wxu[q]); settle(wxc[q]); }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { settle(whr[q]); settle(whu[q]); settle(whc[q]); }
+    // (the bias once per unit: on the h == 0 half)
+    float br = h == 0 ? a.bg[i][j] * NEG_LOG2E : 0.f, bu = h == 0 ? a.bg[i][H + j] * NEG_LOG2E : 0.f;
+    float bcc = h == 0 ? a.bc[i][j] * (2.0f * NEG_LOG2E) : 0.f;
+    settle(br); settle(bu); settle(bcc);
+
+    float hj = 0.f;
+    hb[0][j] = 0.f;
+    wave_sync();
+    int in_seen = 0, out_taken = 0, nout = 0, next_fire = period - 1;
+    const bool has_out = out_ring != nullptr;
+    // saved states: lane h == 0 stores r and h_t, lane h == 1 stores u and c (one 128-byte line each)
+    float *gpa = nullptr, *gpb = nullptr, *yp = nullptr;
+    long gb_stride = 0;
+    if constexpr (TRAIN) {
+        float *g = a.gates[i] + b * (long)T * 3 * H, *hs = a.hs[i] + b * (long)(T + 1) * H;
+        gpa = h == 0 ? g + j : g + H + j;
+        gpb = h == 0 ? hs + H + j : g + 2 * H + j;                       // hs row t+1 / c
+        gb_stride = h == 0 ? H : 3 * H;
+        if (h == 0) hs[j] = 0.f;
+        if (a.y[i] != nullptr) yp = a.y[i] + b * (long)(T / period) * H + j;
+    }
+    const long y_adv = yp != nullptr ? H : 0;
+    if (yp == nullptr) yp = a.memory + (b * a.K + i) * H + j;      // (no subsampled outputs wanted: the final-state slot)
+
+    for (int t = 0; t < T; ++t) {
+        while (in_seen <= t) {
+            in_seen = lds_counter_peek(&in_ctr->pub);
+            if (in_seen <= t) __builtin_amdgcn_s_sleep(1);
+        }
+        asm volatile("" ::: "memory");
+        const v4f *x4 = reinterpret_cast<const v4f *>(in_ring + (long)(t & (in_depth - 1)) * D + h * DX);
+        f2 ar = {0.f, 0.f}, au = {0.f, 0.f}, ac = {0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < DX / 4; ++q) {
+            const v4f v = x4[q];
+            const f2 lo = {v.x, v.y}, hi = {v.z, v.w};
+            ar = __builtin_elementwise_fma(lo, wxr[2 * q], ar);     ar = __builtin_elementwise_fma(hi, wxr[2 * q + 1], ar);
+            au = __builtin_elementwise_fma(lo, wxu[2 * q], au);     au = __builtin_elementwise_fma(hi, wxu[2 * q + 1], au);
+            ac = __builtin_elementwise_fma(lo, wxc[2 * q], ac);     ac = __builtin_elementwise_fma(hi, wxc[2 * q + 1], ac);
+        }
+        lds_counter_set(&in_ctr->taken, t + 1);          // (LDS runs a wave's operations in order: the row has been read)
+        const v4f *h4 = reinterpret_cast<const v4f *>(&hb[t & 1][16 * h]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const v4f v = h4[q];
+            const f2 lo = {v.x, v.y}, hi = {v.z, v.w};
+            ar = __builtin_elementwise_fma(lo, whr[2 * q], ar);     ar = __builtin_elementwise_fma(hi, whr[2 * q + 1], ar);
+            au = __builtin_elementwise_fma(lo, whu[2 * q], au);     au = __builtin_elementwise_fma(hi, whu[2 * q + 1], au);
+        }
+        const float r = sigmoid_scaled(pair_sum(ar.x + ar.y + br));
+        const float u = sigmoid_scaled(pair_sum(au.x + au.y + bu));
+        rhb[j] = r * hj;                                 // (both lanes of the pair write the same value)
+        wave_sync();
+        const v4f *r4 = reinterpret_cast<const v4f *>(&rhb[16 * h]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const v4f v = r4[q];
+            ac = __builtin_elementwise_fma(f2{v.x, v.y}, whc[2 * q], ac);
+            ac = __builtin_elementwise_fma(f2{v.z, v.w}, whc[2 * q + 1], ac);
+        }
+        const float c = tanh_scaled(pair_sum(ac.x + ac.y + bcc));
+        hj = fmaf(u, hj - c, c);
+        hb[(t + 1) & 1][j] = hj;
+        if constexpr (TRAIN) {
+            *gpa = h == 0 ? r : u;
+            *gpb = h == 0 ? hj : c;
+            gpa += 3 * H;
+            gpb += gb_stride;
+        }
+        *yp = hj;                                        // (the slot of the next row to fire: final when it does)
+        const bool fire = t == next_fire;
+        if (has_out) {
+            // room in the ring -- every step, not only when the row is final: the slot is written on the way there
+            const int need = nout - (AYR - 1);
+            while (out_taken < need) {
+                out_taken = lds_counter_peek(&out_ctr->taken);
+                if (out_taken < need) __builtin_amdgcn_s_sleep(1);
+            }
+            asm volatile("" ::: "memory");
+            out_ring[(nout & (AYR - 1)) * H + j] = hj;
+        }
+        nout += fire ? 1 : 0;
+        yp += fire ? y_adv : 0;
+        next_fire += fire ? period : 0;
+        if (has_out) lds_counter_set(&out_ctr->pub, nout);
+        wave_sync();
+    }
+    if (h == 0) a.memory[(b * a.K + i) * H + j] = hj;
+}
+
+// ---------------------------------------------------------------------------------------------------- forward, loader wave
+template <int D0, bool TRAIN>
+__device__ __forceinline__ void all32_loader(const All32Args &a, const long b, const int lane, float *xring, RingCtr *ctr) {
+    const int T = a.len[0];
+    const bool live = lane < D0;
+    const int f = live ? lane / a.E : 0, e = live ? lane % a.E : 0;
+    const int32_t *idb = a.ids + b * (long)a.Tids * a.F + f;
+    constexpr int LB = 4;                               // steps per batch of loads in flight
+    int taken = 0;
+    auto fetch_ids = [&](int t0, int (&id)[LB]) {
+#pragma unroll
+        for (int s = 0; s < LB; ++s) {
+            int ti = t0 + s - a.front_zero;
+            ti = ti < 0 ? 0 : (ti < a.Tids ? ti : a.Tids - 1);
+            id[s] = idb[(long)ti * a.F];
+        }
+    };
+    auto fetch_rows = [&](const int (&id)[LB], float (&v)[LB]) {
+#pragma unroll
+        for (int s = 0; s < LB; ++s) v[s] = a.emb[(long)id[s] * a.E + e];
+    };
+    int idA[LB], idB[LB];
+    float vA[LB];
+    fetch_ids(0, idA);
+    fetch_ids(LB, idB);
+    fetch_rows(idA, vA);
+    for (int t0 = 0; t0 < T; t0 += LB) {
+        // idA / vA: this batch; idB: the next batch's ids (its rows are requested now, used next iteration)
+        float vB[LB];
+        fetch_rows(idB, vB);
+        int idC[LB];
+        fetch_ids(t0 + 2 * LB, idC);
+#pragma unroll
+        for (int s = 0; s < LB; ++s) {
+            const int t = t0 + s;
+            if (t < T) {                                // (wave-uniform)
+                while (t - taken >= AXR) {
+                    taken = lds_counter_peek(&ctr->taken);
+                    if (t - taken >= AXR) __builtin_amdgcn_s_sleep(2);
+                }
+                asm volatile("" ::: "memory");
+                const bool keep = t >= a.front_zero && !(a.mask_id0 && idA[s] == 0);
+                const float v = keep ? vA[s] : 0.f;
+                if (live) {
+                    xring[(t & (AXR - 1)) * D0 + lane] = v;
+                    if constexpr (TRAIN) a.x0[(b * (long)T + t) * D0 + lane] = v;
+                    if (a.last != nullptr && t == a.last_t) a.last[b * D0 + lane] = v;
+                }
+                lds_counter_set(&ctr->pub, t + 1);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < LB; ++s) { idA[s] = idB[s]; idB[s] = idC[s]; vA[s] = vB[s]; }
+    }
+}
+
+template <int D0, bool TRAIN>
+__global__ __launch_bounds__(512) void gru32_fwd_all_kernel(const All32Args a) {
+    __shared__ __attribute__((aligned(16))) float xring[AXR * D0];
+    __shared__ __attribute__((aligned(16))) float yring[AMAXK][AYR * AH];
+    __shared__ __attribute__((aligned(16))) float hb[AMAXK][2][AH];
+    __shared__ __attribute__((aligned(16))) float rhb[AMAXK][AH];
+    __shared__ RingCtr ctr[AMAXK + 1];                  // ctr[0]: the input ring; ctr[i + 1]: the ring behind layer i
+
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long b = blockIdx.x;
+    const int K = a.K;
+    if (threadIdx.x <= AMAXK) { ctr[threadIdx.x].pub = 0; ctr[threadIdx.x].taken = 0; }
+    __syncthreads();
+    if (w == K) {
+        all32_loader<D0, TRAIN>(a, b, lane, xring, &ctr[0]);
+    } else if (w == 0) {
+        __builtin_amdgcn_s_setprio(3);
+        all32_layer_fwd<D0, TRAIN>(a, 0, b, lane, xring, AXR, &ctr[0], K > 1 ? yring[0] : nullptr, &ctr[1], hb[0], rhb[0]);
+    } else {
+        __builtin_amdgcn_s_setprio(2);
+        all32_layer_fwd<AH, TRAIN>(a, w, b, lane, yring[w - 1], AYR, &ctr[w], w + 1 < K ? yring[w] : nullptr, &ctr[w + 1],
+                                   hb[w], rhb[w]);
+    }
+}
+
+bool gru32_all_supported(int H, int D0, int K, int E) {
+    return H == AH && K >= 1 && K <= AMAXK && (D0 == 16 || D0 == 32 || D0 == 48 || D0 == 64) && E >= 1 && D0 % E == 0;
+}
+
+int gru32_fwd_all_launch(const All32Args &a, int D0, bool train, hipStream_t st) {
+    const dim3 grid(a.B), blk(64 * (a.K + 1));
+#define ALL32_FWD(DD)                                                                          \
+    do {                                                                                       \
+        if (train) hipLaunchKernelGGL((gru32_fwd_all_kernel<DD, true>), grid, blk, 0, st, a);    \
+        else       hipLaunchKernelGGL((gru32_fwd_all_kernel<DD, false>), grid, blk, 0, st, a);   \
+    } while (0)
+    if (D0 == 16) ALL32_FWD(16);
+    else if (D0 == 32) ALL32_FWD(32);
+    else if (D0 == 48) ALL32_FWD(48);
+    else if (D0 == 64) ALL32_FWD(64);
+    else return HPMN_EUNSUPPORTED;
+#undef ALL32_FWD
+    return check_launch();
+}
+
+}  // namespace hpmn

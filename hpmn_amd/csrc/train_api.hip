@@ -16,6 +16,9 @@ bool gru_fused_fwd_writes_last();
 bool gru_pair_fwd_supported(int H, int D_lo, int gather);
 size_t gru_proj_image_floats(int D);
 bool gru_pair_bwd_supported(int H, int D_lo);
+}  // namespace hpmn
+#include "gru32_all.h"
+namespace hpmn {
 size_t gru_wgrad_workspace_bytes(int B, int T, int D, int H);
 bool gru_scan_bwd_fuses_dx(int H, int B);
 bool gru_scan_bwd_dx_width_ok(int D);
@@ -143,6 +146,17 @@ int hpmn_scan_fwd_train(HpmnTrainCtx *ctx, const HpmnScanDesc *d, const int32_t 
     if (!hpmn_gru_shape_supported(d->H, D0) || (d->K > 1 && !hpmn_gru_shape_supported(d->H, d->H))) return HPMN_EUNSUPPORTED;
     char *ws = reinterpret_cast<char *>((reinterpret_cast<size_t>(workspace) + 255) / 256 * 256);
     auto F = [&](size_t off) { return reinterpret_cast<float *>(ws + off); };
+    if (gru32_all_enabled() && gru32_all_supported(d->H, D0, d->K, d->E)) {
+        // H = 32: every layer and the gather in one launch (gru32_all.hip)
+        All32Args a = {};
+        gru32_all_fill(a, *d, L.T, ids, emb, wg, bg, wc, bc, memory, last);
+        a.x0 = F(L.x0);
+        for (int i = 0; i < d->K; ++i) {
+            a.hs[i] = F(L.hs[i]); a.gates[i] = F(L.gates[i]);
+            a.y[i] = i + 1 < d->K ? F(L.y[i]) : nullptr;
+        }
+        return gru32_fwd_all_launch(a, D0, true, (hipStream_t)stream);
+    }
     // the fused layer spends a second wave per sequence on a SIMD that would otherwise idle: a win while 2 B waves
     // still find (about) a SIMD each (measured at C3: +3.7 % at B=500, -6.6 % at B=750 / 1000)
     const bool room = 2.0 * d->B <= 1.1 * 4 * c->cus;
