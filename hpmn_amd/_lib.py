@@ -142,7 +142,7 @@ class HpmnTrainLayout(C.Structure):
         ("gates", C.c_uint64 * HPMN_MAX_LAYERS), ("y", C.c_uint64 * HPMN_MAX_LAYERS),
         ("d_act", C.c_uint64 * HPMN_MAX_LAYERS), ("d_x", C.c_uint64 * HPMN_MAX_LAYERS),
         ("wgrad_ws", C.c_uint64), ("total_bytes", C.c_uint64),
-        ("pair_ws", C.c_uint64),
+        ("pair_ws", C.c_uint64), ("wgrad_ws_layer", C.c_uint64 * HPMN_MAX_LAYERS),
     ]
 
 

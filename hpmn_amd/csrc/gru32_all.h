@@ -27,6 +27,10 @@ struct All32Args {
 bool gru32_all_supported(int H, int D0, int K, int E);
 int gru32_fwd_all_launch(const All32Args &a, int D0, bool train, hipStream_t st);
 int gru32_bwd_all_launch(const All32Args &a, int D0, hipStream_t st);
+size_t gru32_wgrad_all_workspace_bytes(int B, int K, const int *D);
+int gru32_wgrad_all_launch(int B, int K, const int *D, const int *T, const float *const *x, const float *const *hs,
+                           const float *const *gates, const float *const *d_act, float *const *d_wg, float *const *d_bg,
+                           float *const *d_wc, float *const *d_bc, float *workspace, hipStream_t st);
 
 // HPMN_ALL32=0 selects the per-layer kernels
 inline bool gru32_all_enabled() {

@@ -238,6 +238,211 @@ __global__ __launch_bounds__(512) void gru32_fwd_all_kernel(const All32Args a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------- reverse, one layer
+// Iteration k = step t = T-1-k.  Per step (lane pair of unit j, halves over the summed index n):
+//   dh_in = dh + dy (firing steps);  dc_pre = dh_in (1-u)(1-c^2);  da_u = dh_in (h_prev - c) u (1-u)
+//   d(rh)_j = sum_n dc_pre_n Wc[D+j][n];  da_r = d(rh) h_prev r (1-r)
+//   dh_j = dh_in u + d(rh) r + sum_n (da_r_n Wg[D+j][n] + da_u_n Wg[D+j][32+n])
+//   d_x_f = sum_n (da_r_n Wg[f][n] + da_u_n Wg[f][32+n] + dc_pre_n Wc[f][n]),  f = j, 32 + j, ... < D
+template <int D>
+__device__ __forceinline__ void all32_layer_bwd(const All32Args &a, const int i, const long b, const int lane,
+                                                const float *in_ring, RingCtr *in_ctr, float *out_ring, RingCtr *out_ctr,
+                                                float (*row)[3 * AH]) {
+    constexpr int H = AH;
+    constexpr int NF = (D + 31) / 32;                   // passes of the input gradient (32 features per pass)
+    const int j = lane >> 1, h = lane & 1;
+    const int T = a.len[i], period = a.period[i];
+    const float *wg = a.wg[i], *wc = a.wc[i];
+    // transposed operands: unit j's ROW of the state block, my half of its columns
+    f2 wcT[8], wrT[8], wuT[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int n = 16 * h + 2 * q;
+        wcT[q] = *reinterpret_cast<const f2 *>(wc + (long)(D + j) * H + n);
+        wrT[q] = *reinterpret_cast<const f2 *>(wg + (long)(D + j) * 2 * H + n);
+        wuT[q] = *reinterpret_cast<const f2 *>(wg + (long)(D + j) * 2 * H + H + n);
+    }
+    f2 xr[NF][8], xu[NF][8], xc[NF][8];
+    bool fok[NF];
+#pragma unroll
+    for (int p = 0; p < NF; ++p) {
+        const int f = 32 * p + j;
+        fok[p] = f < D;
+        const int fc = fok[p] ? f : 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int n = 16 * h + 2 * q;
+            xr[p][q] = *reinterpret_cast<const f2 *>(wg + (long)fc * 2 * H + n);
+            xu[p][q] = *reinterpret_cast<const f2 *>(wg + (long)fc * 2 * H + H + n);
+            xc[p][q] = *reinterpret_cast<const f2 *>(wc + (long)fc * H + n);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { settle(wcT[q]); settle(wrT[q]); settle(wuT[q]); }
+#pragma unroll
+    for (int p = 0; p < NF; ++p)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { settle(xr[p][q]); settle(xu[p][q]); settle(xc[p][q]); }
+
+    const float *gb = a.gates[i] + b * (long)T * 3 * H + j;
+    const float *hsb = a.hs[i] + b * (long)(T + 1) * H + j;
+    float *dab = a.d_act[i] + b * (long)T * 3 * H;
+    float dh = a.d_memory[(b * a.K + i) * H + j];
+    const bool has_dy = in_ring != nullptr, has_out = out_ring != nullptr;
+    int in_seen = 0, out_taken = 0, nin = 0, next_fire = 0;
+    // saved activations of the steps ahead (the same four values on both lanes of a pair), four steps deep
+    constexpr int PF = 4;
+    float pr[PF], pu[PF], pc[PF], ph[PF];
+    auto prefetch = [&](int k, int slot) {
+        int t = T - 1 - k;
+        t = t > 0 ? t : 0;
+        const float *g = gb + (long)t * 3 * H;
+        pr[slot] = g[0]; pu[slot] = g[H]; pc[slot] = g[2 * H];
+        ph[slot] = hsb[(long)t * H];
+    };
+#pragma unroll
+    for (int s = 0; s < PF; ++s) prefetch(s, s);
+
+    auto step = [&](int k, int slot) {
+        const int t = T - 1 - k;
+        const float r = pr[slot], u = pu[slot], c = pc[slot], hp = ph[slot];
+        prefetch(k + PF, slot);
+        const bool fire = has_dy && k == next_fire;
+        // (no branch around the wait: need = -1 never waits)
+        const int need = fire ? nin : -1;
+        while (in_seen <= need) {
+            in_seen = lds_counter_peek(&in_ctr->pub);
+            if (in_seen <= need) __builtin_amdgcn_s_sleep(1);
+        }
+        asm volatile("" ::: "memory");
+        float dy = 0.f;
+        if (has_dy) {
+            dy = in_ring[(nin & (AYR - 1)) * H + j];
+            nin += fire ? 1 : 0;
+            next_fire += fire ? period : 0;
+            lds_counter_set(&in_ctr->taken, nin);
+        }
+        const float dhin = dh + (fire ? dy : 0.f);
+        const float omu = 1.f - u;
+        const float dcp = dhin * omu * (1.f - c * c);
+        const float dau = dhin * (hp - c) * u * omu;
+        float *rw = row[k & 1];
+        rw[H + j] = dau;
+        rw[2 * H + j] = dcp;
+        wave_sync();
+        const v4f *c4 = reinterpret_cast<const v4f *>(rw + 2 * H + 16 * h);
+        v4f vc[4];
+        f2 acc = {0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            vc[q] = c4[q];
+            acc = __builtin_elementwise_fma(f2{vc[q].x, vc[q].y}, wcT[2 * q], acc);
+            acc = __builtin_elementwise_fma(f2{vc[q].z, vc[q].w}, wcT[2 * q + 1], acc);
+        }
+        const float drh = pair_sum(acc.x + acc.y);
+        const float dar = drh * hp * r * (1.f - r);
+        rw[j] = dar;
+        wave_sync();
+        const v4f *r4 = reinterpret_cast<const v4f *>(rw + 16 * h), *u4 = reinterpret_cast<const v4f *>(rw + H + 16 * h);
+        v4f vr[4], vu[4];
+        f2 e = {0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            vr[q] = r4[q];
+            vu[q] = u4[q];
+            e = __builtin_elementwise_fma(f2{vr[q].x, vr[q].y}, wrT[2 * q], e);
+            e = __builtin_elementwise_fma(f2{vr[q].z, vr[q].w}, wrT[2 * q + 1], e);
+            e = __builtin_elementwise_fma(f2{vu[q].x, vu[q].y}, wuT[2 * q], e);
+            e = __builtin_elementwise_fma(f2{vu[q].z, vu[q].w}, wuT[2 * q + 1], e);
+        }
+        dh = fmaf(dhin, u, fmaf(drh, r, pair_sum(e.x + e.y)));
+        // the step's d_act row (the weight gradient's operand): lane h == 0 stores da_r and dc_pre, lane h == 1 da_u
+        {
+            float *dst = dab + (long)t * 3 * H;
+            dst[h == 0 ? j : H + j] = h == 0 ? dar : dau;
+            if (h == 0) dst[2 * H + j] = dcp;
+        }
+        // the input gradient of this step, from the operand halves already in registers
+        float dx[NF];
+#pragma unroll
+        for (int p = 0; p < NF; ++p) {
+            f2 s = {0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                s = __builtin_elementwise_fma(f2{vr[q].x, vr[q].y}, xr[p][2 * q], s);
+                s = __builtin_elementwise_fma(f2{vr[q].z, vr[q].w}, xr[p][2 * q + 1], s);
+                s = __builtin_elementwise_fma(f2{vu[q].x, vu[q].y}, xu[p][2 * q], s);
+                s = __builtin_elementwise_fma(f2{vu[q].z, vu[q].w}, xu[p][2 * q + 1], s);
+                s = __builtin_elementwise_fma(f2{vc[q].x, vc[q].y}, xc[p][2 * q], s);
+                s = __builtin_elementwise_fma(f2{vc[q].z, vc[q].w}, xc[p][2 * q + 1], s);
+            }
+            dx[p] = pair_sum(s.x + s.y);
+        }
+        if (has_out) {
+            // D == 32 here (layers >= 1): one row of the ring the layer below reads its d_y from, index = this iteration
+            const int needo = k - (AYR - 1);
+            while (out_taken < needo) {
+                out_taken = lds_counter_peek(&out_ctr->taken);
+                if (out_taken < needo) __builtin_amdgcn_s_sleep(1);
+            }
+            asm volatile("" ::: "memory");
+            out_ring[(k & (AYR - 1)) * H + j] = dx[0];
+            lds_counter_set(&out_ctr->pub, k + 1);
+        } else {
+            float *dst = a.d_x0 + (b * (long)T + t) * D;
+#pragma unroll
+            for (int p = 0; p < NF; ++p)
+                if (fok[p] && h == 0) dst[32 * p + j] = dx[p];
+        }
+        wave_sync();
+    };
+    const int nfull = T / PF;
+    for (int q = 0; q < nfull; ++q) {
+        step(PF * q, 0);
+        step(PF * q + 1, 1);
+        step(PF * q + 2, 2);
+        step(PF * q + 3, 3);
+    }
+    for (int k = PF * nfull; k < T; ++k) {
+        const int slot = k & (PF - 1);
+        if (slot == 0) step(k, 0);
+        else if (slot == 1) step(k, 1);
+        else step(k, 2);
+    }
+}
+
+template <int D0>
+__global__ __launch_bounds__(512) void gru32_bwd_all_kernel(const All32Args a) {
+    __shared__ __attribute__((aligned(16))) float dyring[AMAXK][AYR * AH];      // ring i: d_y rows of layer i (from layer i + 1)
+    __shared__ __attribute__((aligned(16))) float rows[AMAXK][2][3 * AH];
+    __shared__ RingCtr ctr[AMAXK];
+
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long b = blockIdx.x;
+    const int K = a.K;
+    if (threadIdx.x < AMAXK) { ctr[threadIdx.x].pub = 0; ctr[threadIdx.x].taken = 0; }
+    __syncthreads();
+    const bool top = w == K - 1;
+    if (w == 0) {
+        __builtin_amdgcn_s_setprio(3);
+        all32_layer_bwd<D0>(a, 0, b, lane, top ? nullptr : dyring[0], &ctr[0], nullptr, nullptr, rows[0]);
+    } else {
+        __builtin_amdgcn_s_setprio(2);
+        all32_layer_bwd<AH>(a, w, b, lane, top ? nullptr : dyring[w], &ctr[w], dyring[w - 1], &ctr[w - 1], rows[w]);
+    }
+}
+
+int gru32_bwd_all_launch(const All32Args &a, int D0, hipStream_t st) {
+    const dim3 grid(a.B), blk(64 * a.K);
+    if (D0 == 16) hipLaunchKernelGGL(gru32_bwd_all_kernel<16>, grid, blk, 0, st, a);
+    else if (D0 == 32) hipLaunchKernelGGL(gru32_bwd_all_kernel<32>, grid, blk, 0, st, a);
+    else if (D0 == 48) hipLaunchKernelGGL(gru32_bwd_all_kernel<48>, grid, blk, 0, st, a);
+    else if (D0 == 64) hipLaunchKernelGGL(gru32_bwd_all_kernel<64>, grid, blk, 0, st, a);
+    else return HPMN_EUNSUPPORTED;
+    return check_launch();
+}
+
 bool gru32_all_supported(int H, int D0, int K, int E) {
     return H == AH && K >= 1 && K <= AMAXK && (D0 == 16 || D0 == 32 || D0 == 48 || D0 == 64) && E >= 1 && D0 % E == 0;
 }

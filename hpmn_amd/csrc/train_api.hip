@@ -69,6 +69,12 @@ static bool layout(const HpmnScanDesc &d, HpmnTrainLayout &L) {
     }
     L.wgrad_ws = off;
     off += up256(wmax);
+    if (d.H == 32 && d.K <= AMAXK) {               // H = 32 (gru32_wgrad.hip): the slabs of all layers, one launch
+        int Ds[HPMN_MAX_LAYERS];
+        for (int i = 0; i < d.K; ++i) Ds[i] = (int)(i == 0 ? D0 : H);
+        L.wgrad_ws_layer[0] = off;
+        off += up256(gru32_wgrad_all_workspace_bytes(d.B, d.K, Ds));
+    }
     L.pair_ws = off;
     off += up256((size_t)d.K * gru_proj_image_floats(64) * sizeof(float));
     L.total_bytes = off + 256;
@@ -105,6 +111,7 @@ int hpmn_train_ctx_create(HpmnTrainCtx **out) {
         delete c;
         return HPMN_EHIP;
     }
+
     *out = reinterpret_cast<HpmnTrainCtx *>(c);
     return HPMN_OK;
 }
@@ -289,6 +296,46 @@ int hpmn_scan_bwd(HpmnTrainCtx *ctx, const HpmnScanDesc *d, const int32_t *ids, 
         const int p0 = d->periods[0], q = (p0 % 2 == 0) ? p0 : 2 * p0;
         cut = (L.T[0] / 2) / q * q;
         if (cut <= d->front_zero || cut >= L.T[0] + d->last_index) cut = 0;
+    }
+    if (cut == 0 && gru32_all_enabled() && gru32_all_supported(d->H, D0, d->K, d->E)) {
+        // H = 32: every layer's reverse scan and input gradient in one launch (gru32_all.hip); the weight gradients follow
+        // on the helper stream, the scatter on this one
+        All32Args a = {};
+        gru32_all_fill(a, *d, L.T, ids, nullptr, wg, nullptr, wc, nullptr, nullptr, nullptr);
+        a.d_memory = d_memory;
+        a.d_x0 = F(L.d_x[0]);
+        for (int i = 0; i < d->K; ++i) { a.hs[i] = F(L.hs[i]); a.gates[i] = F(L.gates[i]); a.d_act[i] = F(L.d_act[i]); }
+        int rc = gru32_bwd_all_launch(a, D0, st);
+        if (rc != HPMN_OK) return rc;
+        // every layer's weight and bias gradient: one launch + one reduction on the helper stream (gru32_wgrad.hip)
+        HIPCHK(hipEventRecord(c->fork, st));
+        HIPCHK(hipStreamWaitEvent(c->side, c->fork, 0));
+        {
+            int Ds[HPMN_MAX_LAYERS], Ts[HPMN_MAX_LAYERS];
+            const float *xs[HPMN_MAX_LAYERS], *hss[HPMN_MAX_LAYERS], *gs[HPMN_MAX_LAYERS], *das[HPMN_MAX_LAYERS];
+            for (int i = 0; i < d->K; ++i) {
+                Ds[i] = i == 0 ? D0 : d->H; Ts[i] = L.T[i];
+                xs[i] = i == 0 ? F(L.x0) : F(L.y[i - 1]);
+                hss[i] = F(L.hs[i]); gs[i] = F(L.gates[i]); das[i] = F(L.d_act[i]);
+            }
+            rc = gru32_wgrad_all_launch(d->B, d->K, Ds, Ts, xs, hss, gs, das, d_wg, d_bg, d_wc, d_bc,
+                                        F(L.wgrad_ws_layer[0]), c->side);
+            if (rc != HPMN_OK) return rc;
+        }
+        c->pending = true;
+        const bool in_scatter = d_last && d->T + d->last_index >= 0;
+        if (d_last && !in_scatter) {
+            const long n = (long)d->B * D0;
+            hipLaunchKernelGGL(add_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                               F(L.d_x[0]) + (size_t)(L.T[0] + d->last_index) * D0, (long)L.T[0] * D0, d_last, d->B, D0);
+            rc = check_launch();
+            if (rc != HPMN_OK) return rc;
+        }
+        rc = embed_grad_scatter_launch(ids, F(L.d_x[0]), d_emb, d->B, d->T, d->F, d->E, d->front_zero, d->mask_id0, 0, d->T,
+                                       st, in_scatter ? d_last : nullptr, d->T + d->last_index);
+        if (rc != HPMN_OK) return rc;
+        if (!defer_join) return hpmn_train_join(ctx, stream);
+        return HPMN_OK;
     }
     bool scatter_pending = false;
     HpmnGruWgrad held[4], late[HPMN_MAX_LAYERS];

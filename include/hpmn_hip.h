@@ -334,6 +334,7 @@ typedef struct HpmnTrainLayout {
     uint64_t d_x[HPMN_MAX_LAYERS];         /* [B, T[i], D_i]                                               */
     uint64_t wgrad_ws, total_bytes;
     uint64_t pair_ws;                      /* K operand images of the two-layer launches (hpmn_gru_proj_images) */
+    uint64_t wgrad_ws_layer[HPMN_MAX_LAYERS]; /* [0]: the slabs of the all-layer weight-gradient launch (H = 32) */
 } HpmnTrainLayout;
 
 int hpmn_train_ctx_create(HpmnTrainCtx **ctx);
