@@ -583,6 +583,8 @@ def main():
     if not args.no_eval and args.config in ("c3", "c4") and world == 1:
         ev_ids = torch.cat([b[0] for b in batches[:4]], 0)[:4 * c["batch"]]
         n_eval_batches = 8
+        for i in range(3):                                   # (the eval leg above reshuffled the caching allocator's pools)
+            step(args.warmup + args.steps + 10 + i)
         torch.cuda.synchronize()
         tc0 = time.perf_counter()
         for i in range(10):

@@ -55,6 +55,9 @@ class HpmnGruBwd(C.Structure):
         ("t_begin", C.c_int32), ("t_end", C.c_int32),
         ("dh_carry", C.c_void_p),
         ("d_x", C.c_void_p),
+        ("scatter_ids", C.c_void_p), ("d_emb", C.c_void_p), ("d_last", C.c_void_p),
+        ("Tids", C.c_int32), ("F", C.c_int32), ("E", C.c_int32), ("front_zero", C.c_int32), ("mask_id0", C.c_int32),
+        ("last_t", C.c_int32),
     ]
 
 
@@ -168,6 +171,7 @@ SIGNATURES = {
     "hpmn_gru_scan_fwd": (C.c_int, [C.POINTER(HpmnGruFwd), C.c_void_p]),
     "hpmn_gru_scan_bwd": (C.c_int, [C.POINTER(HpmnGruBwd), C.c_void_p]),
     "hpmn_gru_scan_bwd_fuses_dx": (C.c_int, [C.c_int32, C.c_int32]),
+    "hpmn_gru_scan_bwd_fuses_scatter": (C.c_int, [C.c_int32] * 5),
     "hpmn_gru_param_grads_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "hpmn_gru_param_grads": (C.c_int, [C.POINTER(HpmnGruWgrad), C.c_void_p]),
     "hpmn_gru_input_grad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,

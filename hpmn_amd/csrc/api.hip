@@ -13,6 +13,7 @@ int gru_scan_fwd_dispatch(const HpmnGruFwd &a, hipStream_t st);
 int gru_scan_bwd_dispatch(const HpmnGruBwd &a, hipStream_t st);
 bool gru_scan_bwd_fuses_dx(int H, int B);
 bool gru_scan_bwd_dx_width_ok(int D);
+bool gru_scan_bwd_fuses_scatter(int H, int B, int D, int F, int E);
 bool input_proj_supported(int H, int D);
 int memory_update_launch(const HpmnOnlineUpdate &a, hipStream_t st);
 bool gru_fused_fwd_supported(int H, int D, int gather);
@@ -161,6 +162,11 @@ int hpmn_gru_scan_bwd(const HpmnGruBwd *a, void *stream) {
     }
     if (!gru_shape_supported(a->H, a->D)) return HPMN_EUNSUPPORTED;
     if (a->d_x && (!gru_scan_bwd_fuses_dx(a->H, a->B) || !gru_scan_bwd_dx_width_ok(a->D))) return HPMN_EUNSUPPORTED;
+    if (a->d_emb) {
+        if (!a->scatter_ids || a->Tids < 1 || a->F < 1 || a->front_zero < 0 || a->front_zero + a->Tids != a->T) return HPMN_EINVAL;
+        if (a->t_begin != 0 || (a->t_end != 0 && a->t_end != a->T)) return HPMN_EINVAL;
+        if (!gru_scan_bwd_fuses_scatter(a->H, a->B, a->D, a->F, a->E)) return HPMN_EUNSUPPORTED;
+    }
     if (a->B == 0) return HPMN_OK;
     HpmnGruBwd k = *a;
     if (k.period < 1) k.period = 1;
@@ -168,6 +174,9 @@ int hpmn_gru_scan_bwd(const HpmnGruBwd *a, void *stream) {
 }
 
 int hpmn_gru_scan_bwd_fuses_dx(int32_t H, int32_t B) { return gru_scan_bwd_fuses_dx(H, B) ? 1 : 0; }
+int hpmn_gru_scan_bwd_fuses_scatter(int32_t H, int32_t B, int32_t D, int32_t F, int32_t E) {
+    return gru_scan_bwd_fuses_scatter(H, B, D, F, E) ? 1 : 0;
+}
 
 size_t hpmn_gru_param_grads_workspace_bytes(int32_t B, int32_t T, int32_t D, int32_t H) {
     if (B < 1 || T < 1 || D < 1 || H < 1) return 0;

@@ -432,6 +432,18 @@ bool gru_scan_bwd_fuses_dx(int H, int B) {
 }
 bool gru_scan_bwd_dx_width_ok(int D) { return bwd_helper_enabled() >= 2 ? gru_scan_bwd_feed_dx_width(D) : D <= 64; }
 
+bool gru_scan_bwd_feed_scatter_ok(int D, int F, int E);      // gru_scan_bwd_feed.hip
+// does hpmn_gru_scan_bwd add the input gradient into the table gradient itself (HpmnGruBwd.d_emb)?
+// HPMN_FUSED_SCATTER=1 turns it on in hpmn_scan_bwd.  Built, parity-green, measured SLOWER at C3 (2.884 vs 2.799 ms/step):
+// the atomics lengthen layer 0's launch by 67 us (732 vs 665), and the 140 us scatter launch it removes was hidden anyway --
+// the step's tail is bounded by layer 0's weight gradient (300 us), which now shares the memory system with the late
+// table-Adam pass alone and both get slower (396 + 290 us instead of 303 + 186).
+bool gru_scan_bwd_fuses_scatter(int H, int B, int D, int F, int E) {
+    static const int on = [] { const char *e = getenv("HPMN_FUSED_SCATTER"); return e ? atoi(e) : 0; }();
+    return on && H == 64 && bwd_helper_enabled() >= 2 && B <= 640 && gru_scan_bwd_fuses_dx(H, B) &&
+           gru_scan_bwd_feed_scatter_ok(D, F, E);
+}
+
 int gru_scan_bwd128_dispatch(const HpmnGruBwd &a, hipStream_t st);   // gru_scan128.hip
 
 int gru_scan_bwd_dispatch(const HpmnGruBwd &a, hipStream_t st) {

@@ -52,7 +52,7 @@ typedef float f4m __attribute__((ext_vector_type(4)));
 // workgroups every CU had the chain wave of one sequence and the feeder of the other on ONE SIMD and a SIMD idle;
 // 4-wave workgroups land on four distinct SIMDs, the 5th and 6th wave of a 6-wave workgroup on the SIMDs of the 1st
 // and 2nd).  Waves 0,1: chain waves of sequences 2 blockIdx.x + 0,1; waves 2,3: their feeders.
-template <int DXD>
+template <int DXD, bool SCAT = false>
 __global__ __launch_bounds__(256, 1) void gru_scan_bwd_feed_kernel(const HpmnGruBwd a) {
     constexpr int H = 64;
     constexpr bool DX = DXD > 0;
@@ -285,12 +285,31 @@ __global__ __launch_bounds__(256, 1) void gru_scan_bwd_feed_kernel(const HpmnGru
         // blocks of 16 steps [t_lo0 + 16 q, ...), q = role, role + 2, ...: B operand of lane (j, g) = d_act[t][16 kq + 4 g ..+3]
         const int nblk = (nsteps + DXB - 1) / DXB;
         const float *src = a.d_act + (b * (long)T + t_lo0) * 3 * H + 4 * g;
-        float *dst = a.d_x + (b * (long)T + t_lo0) * DXD + 4 * g;
+        float *dst = a.d_x != nullptr ? a.d_x + (b * (long)T + t_lo0) * DXD + 4 * g : nullptr;
         auto fetch = [&](int q, v4f (&v)[12]) {
             int tr = DXB * q + j;
             tr = tr < nsteps ? tr : nsteps - 1;                       // (clamped: loaded, computed, not stored)
 #pragma unroll
             for (int kq = 0; kq < 12; ++kq) v[kq] = *reinterpret_cast<const v4f *>(src + (long)tr * 3 * H + 16 * kq);
+        };
+        // Fused scatter (a.d_emb != NULL; E == 16, so column tile ct IS id column ct): a tile's 16 rows go into the table
+        // gradient from here.  Lane (j, g) holds four elements of step 16 q + j's row; when the block's 16 steps share one id
+        // -- the constant uid column, padding -- the rows are summed over j inside the 16-lane groups first, and runs that
+        // continue over this wave's next block keep accumulating in registers: one atomic row add per run, not per step.
+        constexpr bool scat = SCAT;       // (a template switch: the scatter's registers would cost the layers that do not
+                                          //  use it their place beside a weight-gradient workgroup)
+        int run_id[NCT];
+        f4m run_acc[NCT];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) { run_id[ct] = -1; run_acc[ct] = f4m{0.f, 0.f, 0.f, 0.f}; }
+        auto flush = [&](int ct) {
+            if (run_id[ct] >= 0 && j == 0 && !(a.mask_id0 && run_id[ct] == 0)) {
+                float *row = a.d_emb + (long)run_id[ct] * 16 + 4 * g;
+                atomicAdd(row, run_acc[ct][0]); atomicAdd(row + 1, run_acc[ct][1]);
+                atomicAdd(row + 2, run_acc[ct][2]); atomicAdd(row + 3, run_acc[ct][3]);
+            }
+            run_id[ct] = -1;
+            run_acc[ct] = f4m{0.f, 0.f, 0.f, 0.f};
         };
         v4f cur[12], nxt[12];
         if (role < nblk) fetch(role, cur);
@@ -305,18 +324,61 @@ __global__ __launch_bounds__(256, 1) void gru_scan_bwd_feed_kernel(const HpmnGru
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
                         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wx[ct][kq][c], cur[kq][c], acc, 0, 0, 0);
-                if (tr < nsteps) *reinterpret_cast<f4m *>(dst + (long)tr * DXD + 16 * ct) = acc;
+                if (a.d_x != nullptr && tr < nsteps) *reinterpret_cast<f4m *>(dst + (long)tr * DXD + 16 * ct) = acc;
+                if (scat) {
+                    const int t = t_lo0 + tr;                          // scan step of this lane's row
+                    if (a.d_last != nullptr && t == a.last_t && tr < nsteps) {
+                        const f4m dl = *reinterpret_cast<const f4m *>(a.d_last + b * (long)DXD + 16 * ct + 4 * g);
+                        acc += dl;
+                    }
+                    const int ti = t - a.front_zero;
+                    const bool valid = tr < nsteps && ti >= 0;
+                    const int id = valid ? a.scatter_ids[(b * (long)a.Tids + ti) * a.F + ct] : -2;
+                    const int id0 = __builtin_amdgcn_readfirstlane(id);
+                    const bool uniform = __builtin_amdgcn_ballot_w64(id != id0) == 0;     // (wave-uniform)
+                    if (uniform && id0 >= 0) {
+                        // sum over the block's 16 steps: xor-shuffles stay inside the 16-lane group of equal g
+                        f4m sum = acc;
+#pragma unroll
+                        for (int m = 1; m < 16; m <<= 1) {
+                            sum[0] += __shfl_xor(sum[0], m); sum[1] += __shfl_xor(sum[1], m);
+                            sum[2] += __shfl_xor(sum[2], m); sum[3] += __shfl_xor(sum[3], m);
+                        }
+                        if (id0 != run_id[ct]) flush(ct);
+                        run_id[ct] = id0;
+                        run_acc[ct] += sum;
+                    } else {
+                        flush(ct);
+                        if (valid && !(a.mask_id0 && id == 0)) {
+                            float *row = a.d_emb + (long)id * 16 + 4 * g;
+                            atomicAdd(row, acc[0]); atomicAdd(row + 1, acc[1]); atomicAdd(row + 2, acc[2]); atomicAdd(row + 3, acc[3]);
+                        }
+                    }
+                }
             }
 #pragma unroll
             for (int kq = 0; kq < 12; ++kq) cur[kq] = nxt[kq];
+        }
+        if (scat) {
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) flush(ct);
         }
     }
 }
 
 bool gru_scan_bwd_feed_dx_width(int D) { return D == 16 || D == 32 || D == 64; }
+// the epilogue's fused scatter: id column f is column tile f of the input gradient
+bool gru_scan_bwd_feed_scatter_ok(int D, int F, int E) { return E == 16 && D == F * 16 && gru_scan_bwd_feed_dx_width(D); }
 
 int gru_scan_bwd_feed_launch(const HpmnGruBwd &a, hipStream_t st) {
     const dim3 grid((a.B + 1) / 2);
+    if (a.d_emb != nullptr) {
+        if (a.D == 16) hipLaunchKernelGGL((gru_scan_bwd_feed_kernel<16, true>), grid, dim3(256), 0, st, a);
+        else if (a.D == 32) hipLaunchKernelGGL((gru_scan_bwd_feed_kernel<32, true>), grid, dim3(256), 0, st, a);
+        else if (a.D == 64) hipLaunchKernelGGL((gru_scan_bwd_feed_kernel<64, true>), grid, dim3(256), 0, st, a);
+        else return HPMN_EUNSUPPORTED;
+        return check_launch();
+    }
     if (a.d_x == nullptr) hipLaunchKernelGGL(gru_scan_bwd_feed_kernel<0>, grid, dim3(256), 0, st, a);
     else if (a.D == 16) hipLaunchKernelGGL(gru_scan_bwd_feed_kernel<16>, grid, dim3(256), 0, st, a);
     else if (a.D == 32) hipLaunchKernelGGL(gru_scan_bwd_feed_kernel<32>, grid, dim3(256), 0, st, a);

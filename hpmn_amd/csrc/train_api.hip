@@ -22,6 +22,7 @@ namespace hpmn {
 size_t gru_wgrad_workspace_bytes(int B, int T, int D, int H);
 bool gru_scan_bwd_fuses_dx(int H, int B);
 bool gru_scan_bwd_dx_width_ok(int D);
+bool gru_scan_bwd_fuses_scatter(int H, int B, int D, int F, int E);
 int embed_grad_scatter_launch(const int32_t *ids, const float *d_x, float *d_emb, int32_t B, int32_t T,
                               int32_t F, int32_t E, int32_t front_zero, int32_t mask_id0, int32_t t_lo, int32_t t_hi,
                               hipStream_t st, const float *d_last = nullptr, int32_t t_last = 0);
@@ -205,8 +206,9 @@ int hpmn_scan_fwd_train(HpmnTrainCtx *ctx, const HpmnScanDesc *d, const int32_t 
         const bool fused = room && gru_fused_fwd_supported(d->H, D, i == 0) && (i > 0 || 64 % d->E == 0);
         float *y = i + 1 < d->K ? F(L.y[i]) : nullptr;
         int rc;
-        // (a pair pays while the upper layer is long enough to matter: below 8 steps it is one launch of a few us)
-        if (fused && pair_room && i >= pair_first && i + 1 < d->K && L.T[i + 1] >= 8 &&
+        // (a pair pays while the layers are long: the upper one ends 16-32 of ITS steps behind the lower, which for layers
+        //  of 32 + 16 steps is more than the second launch costs -- measured 54 us paired vs 26 + 16 apart at C3)
+        if (fused && pair_room && i >= pair_first && i + 1 < d->K && L.T[i + 1] >= 64 &&
             gru_pair_fwd_supported(d->H, D, i == 0)) {
             if (!images_built) {
                 // every layer's projection weights as MFMA operand images, one launch in front of the first pair
@@ -337,7 +339,7 @@ int hpmn_scan_bwd(HpmnTrainCtx *ctx, const HpmnScanDesc *d, const int32_t *ids, 
         if (!defer_join) return hpmn_train_join(ctx, stream);
         return HPMN_OK;
     }
-    bool scatter_pending = false;
+    bool scatter_pending = false, scatter_fused = false;
     HpmnGruWgrad held[4], late[HPMN_MAX_LAYERS];
     int nheld = 0, nlate = 0;
     auto scan_args = [&](int i) {
@@ -454,6 +456,14 @@ int hpmn_scan_bwd(HpmnTrainCtx *ctx, const HpmnScanDesc *d, const int32_t *ids, 
         }
         const bool fused_dx = gru_scan_bwd_fuses_dx(d->H, d->B) && gru_scan_bwd_dx_width_ok(D);
         if (fused_dx) a.d_x = F(L.d_x[i]);       // the input gradient comes out of the scan launch itself
+        if (i == 0 && fused_dx && gru_scan_bwd_fuses_scatter(d->H, d->B, D, d->F, d->E)) {
+            // ... and goes straight into the table gradient: no d_x buffer, no scatter launch behind layer 0
+            a.d_x = nullptr;
+            a.scatter_ids = ids; a.d_emb = d_emb; a.Tids = d->T; a.F = d->F; a.E = d->E;
+            a.front_zero = d->front_zero; a.mask_id0 = d->mask_id0; a.last_t = L.T[0] + d->last_index;
+            a.d_last = d->T + d->last_index >= 0 ? d_last : nullptr;
+            scatter_fused = true;
+        }
         int rc = hpmn_gru_scan_bwd(&a, stream);
         if (rc != HPMN_OK) return rc;
         // the weight gradient of this layer: an MFMA reduction over d_act, off the serial chain, on the helper stream.
@@ -488,6 +498,10 @@ int hpmn_scan_bwd(HpmnTrainCtx *ctx, const HpmnScanDesc *d, const int32_t *ids, 
         }
         nlate = 0;
         c->pending = true;
+    }
+    if (scatter_fused) {
+        if (!defer_join) return hpmn_train_join(ctx, stream);
+        return HPMN_OK;
     }
     // (d_last, the read path's gradient wrt uinp[:, last_index, :], rides into the scatter: ids step T + last_index)
     const bool last_in_scatter = d_last && !scatter_pending && d->T + d->last_index >= 0;

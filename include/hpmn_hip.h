@@ -221,10 +221,22 @@ typedef struct HpmnGruBwd {
      * Only where hpmn_gru_scan_bwd_fuses_dx(H, B) != 0 and D is 16, 32 or 64; elsewhere it must be NULL
      * (HPMN_EUNSUPPORTED otherwise). */
     float *d_x;
+    /* optional, with the fused input gradient of LAYER 0 only (D == F * E, E == 16): instead of (d_x == NULL) or besides
+     * writing d_x, the launch adds the input gradient straight into the embedding-table gradient --
+     *   d_emb[ids[b, t - front_zero, f]] += d_x[b, t, f*E:(f+1)*E]  for t >= front_zero (skipping id 0 when mask_id0),
+     *   with d_last[b] (the read path's gradient wrt uinp[:, last_index, :], may be NULL) added at step last_t --
+     * what hpmn_embed_grad_scatter does as a launch of its own behind this one.  Runs of equal ids (the constant uid column,
+     * padding) are summed in registers before one atomic row add.  NULL d_emb: off. */
+    const int32_t *scatter_ids;   /* [B, Tids, F] */
+    float *d_emb;                 /* [V, E] */
+    const float *d_last;          /* [B, D] */
+    int32_t Tids, F, E, front_zero, mask_id0, last_t;
 } HpmnGruBwd;
 
 int hpmn_gru_scan_bwd(const HpmnGruBwd *args, void *stream);
 int hpmn_gru_scan_bwd_fuses_dx(int32_t H, int32_t B);
+/* 1 where HpmnGruBwd.d_emb (the scatter fused into the launch) is supported */
+int hpmn_gru_scan_bwd_fuses_scatter(int32_t H, int32_t B, int32_t D, int32_t F, int32_t E);
 
 /* The reverse scans of TWO consecutive layers in ONE launch (H = 64), the mirror of hpmn_gru_pair_fwd: the lower layer's
  * scan runs while the upper layer's does.  A workgroup owns two sequences and both layers (eight waves); the upper

@@ -950,7 +950,7 @@ def test_scans_give_the_same_result_beside_an_unrelated_kernel(dev, tmp_path, B,
     {"HPMN_BWD_HELPER": "0", "HPMN_FUSED_FWD": "0", "HPMN_TWO_PASS_ADAM": "0"},  # one wave per sequence, two-kernel forward
     {"HPMN_BWD_DX_WAVE": "0", "HPMN_L0_SPLIT": "1"},                           # separate input-gradient launches, layer 0 split in time
     {"HPMN_PAIR_FWD": "0", "HPMN_PAIR_BWD": "0", "HPMN_PAIR_INFER": "0"},      # one launch per layer (no two-layer launches)
-    {"HPMN_PAIR_FWD": "2", "HPMN_PAIR_BWD": "1"},                              # the other pairing / SIMD assignment
+    {"HPMN_PAIR_FWD": "1", "HPMN_PAIR_BWD": "1", "HPMN_FUSED_SCATTER": "1"},   # the other pairing; scatter fused into layer 0's launch
 ], ids=["gen1", "one-wave", "dx-launches+split", "no-pairs", "pairs-alt"])
 def test_fallback_kernel_paths_still_match_the_oracle(env):
     """The switches of DESIGN.md 3.11 select kernels at library load, so each set runs a slice of this file in a
