@@ -176,7 +176,9 @@ int hpmn_scan_fwd_train(HpmnTrainCtx *ctx, const HpmnScanDesc *d, const int32_t 
     // workgroups leave half of every CU to the caller's early optimiser pass -- and pairs (1,2), (3,4), ...
     static const int pair_env = [] { const char *e = getenv("HPMN_PAIR_FWD"); return e ? atoi(e) : 2; }();
     const bool pair_room = pair_env > 0 && (d->B + 1) / 2 <= c->cus;
-    const int pair_first = pair_env == 1 ? 0 : 1;
+    // (a batch that leaves half of the CUs empty has room for the optimiser pass whatever the pairs hold: from layer 0)
+    const bool half_chip = (d->B + 1) / 2 <= c->cus / 2;
+    const int pair_first = (pair_env == 1 || half_chip) ? 0 : 1;
     bool last_done = false;
     const size_t img_stride = gru_proj_image_floats(64);
     auto image = [&](int i) { return F(L.pair_ws) + (size_t)i * img_stride; };
@@ -372,7 +374,8 @@ int hpmn_scan_bwd(HpmnTrainCtx *ctx, const HpmnScanDesc *d, const int32_t *ids, 
     // 630 us of them end up exposed behind the last scan; 2: 1575-1586 -- the upper pairs save 166 us and layer 0's
     // single-layer launch still hides the weight gradients (at 686 instead of 589 us).
     static const int pair_env = [] { const char *e = getenv("HPMN_PAIR_BWD"); return e ? atoi(e) : 2; }();
-    const int pair_mode = pair_env <= 0 ? 0 : (pair_env == 1 ? 1 : 2);
+    // (as in the forward: a batch on half of the CUs leaves the weight gradients the other half -- pairs from layer 0)
+    const int pair_mode = pair_env <= 0 ? 0 : ((pair_env == 1 || (d->B + 1) / 2 <= c->cus / 2) ? 1 : 2);
     const bool pair_ok = pair_mode > 0 && cut == 0 && (d->B + 1) / 2 <= c->cus && gru_scan_bwd_fuses_dx(d->H, d->B);
     for (int i = d->K - 1; i >= 0; --i) {
         const int D = i == 0 ? D0 : d->H;
@@ -390,8 +393,26 @@ int hpmn_scan_bwd(HpmnTrainCtx *ctx, const HpmnScanDesc *d, const int32_t *ids, 
             // beside it only gets the few CUs the launch leaves over (measured: 665 us instead of 150).  They are kept
             // until the pairs are through (the queue of them is flushed where a single-layer launch follows: that one
             // leaves half of every CU free) and may fill the CUs then.
-            late[nlate++] = wgrad_args(i);
-            late[nlate++] = wgrad_args(i - 1);
+            if ((d->B + 1) / 2 <= c->cus / 2) {
+                // (... unless the batch leaves half of the CUs empty: then they start now, on those)
+                HIPCHK(hipEventRecord(c->fork, st));
+                HIPCHK(hipStreamWaitEvent(c->side, c->fork, 0));
+                for (int h = 0; h < nlate; ++h) {
+                    const int rc0 = hpmn_gru_param_grads(&late[h], c->side);
+                    if (rc0 != HPMN_OK) return rc0;
+                }
+                nlate = 0;
+                for (int l = i; l >= i - 1; --l) {
+                    HpmnGruWgrad w = wgrad_args(l);
+                    w.whole_cu = 0;
+                    const int rc0 = hpmn_gru_param_grads(&w, c->side);
+                    if (rc0 != HPMN_OK) return rc0;
+                }
+                c->pending = true;
+            } else {
+                late[nlate++] = wgrad_args(i);
+                late[nlate++] = wgrad_args(i - 1);
+            }
             --i;
             continue;
         }
