@@ -22,6 +22,9 @@
 //
 // The interleaving (not one burst of 192 matrix instructions per block) is what the forward pair measured: back-to-back
 // matrix instructions of a co-resident wave cost the latency-critical layer their full duration (gru_pair_fwd.hip).
+// (Also measured: holding each chunk back until the LOWER feeder on the same SIMD has just published its e_u, i.e. aiming the
+//  matrix instructions at that wave's idle window -- 378.8 / 388.8 us for layers 2+1 at C3 with a wait of up to 4 / 12 polls
+//  against 378.2 without: no gain, removed.)
 //
 // Epilogue: the LOWER layer's input gradient, as in gru_scan_bwd_feed.hip -- but the upper layer's two waves have long
 // finished by then and take half of the blocks.
@@ -249,6 +252,7 @@ __device__ __forceinline__ void pair_bwd_feeder(const HpmnGruBwd &a, BwdLds<NS> 
 
     float *dap = a.d_act + (b * (long)T + (T - 1)) * 3 * H + l;      // row of iteration 0
     int seen = 0;
+
     auto iter = [&](int k, int p, bool store_prev) {
         while (seen <= k) {
             seen = lds_counter_peek(&S.dau_pub);
