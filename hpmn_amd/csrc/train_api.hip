@@ -31,7 +31,8 @@ struct TrainCtx {
     int device = -1, cus = 256;
     hipStream_t side = nullptr;
     hipEvent_t fork = nullptr, join = nullptr, scat = nullptr;
-    bool pending = false;
+    hipEvent_t probe0 = nullptr, probe1 = nullptr;      // (timing events around layer 0's reverse-scan launch, on request)
+    bool pending = false, probe = false, probed = false;
 };
 
 static size_t up256(size_t x) { return (x + 255) / 256 * 256; }
@@ -121,6 +122,8 @@ void hpmn_train_ctx_destroy(HpmnTrainCtx *ctx) {
     TrainCtx *c = reinterpret_cast<TrainCtx *>(ctx);
     if (!c) return;
     if (c->side) (void)hipStreamSynchronize(c->side);
+    if (c->probe0) (void)hipEventDestroy(c->probe0);
+    if (c->probe1) (void)hipEventDestroy(c->probe1);
     if (c->fork) (void)hipEventDestroy(c->fork);
     if (c->join) (void)hipEventDestroy(c->join);
     if (c->scat) (void)hipEventDestroy(c->scat);
@@ -475,6 +478,8 @@ int hpmn_scan_bwd(HpmnTrainCtx *ctx, const HpmnScanDesc *d, const int32_t *ids, 
             if (rc != HPMN_OK) return rc;
             continue;
         }
+        const bool probing = i == 0 && c->probe && c->probe0 != nullptr;
+        if (probing) HIPCHK(hipEventRecord(c->probe0, st));
         const bool fused_dx = gru_scan_bwd_fuses_dx(d->H, d->B) && gru_scan_bwd_dx_width_ok(D);
         if (fused_dx) a.d_x = F(L.d_x[i]);       // the input gradient comes out of the scan launch itself
         if (i == 0 && fused_dx && gru_scan_bwd_fuses_scatter(d->H, d->B, D, d->F, d->E)) {
@@ -487,6 +492,7 @@ int hpmn_scan_bwd(HpmnTrainCtx *ctx, const HpmnScanDesc *d, const int32_t *ids, 
         }
         int rc = hpmn_gru_scan_bwd(&a, stream);
         if (rc != HPMN_OK) return rc;
+        if (probing) { HIPCHK(hipEventRecord(c->probe1, st)); c->probed = true; }
         // the weight gradient of this layer: an MFMA reduction over d_act, off the serial chain, on the helper stream.
         // Every fork (event record on the launch stream) costs the chain ~6 us of queue processing, so the short top
         // layers (<= 128 steps: 30-80 us of weight-gradient work each) share the fork of the layer below them.
@@ -539,6 +545,26 @@ int hpmn_scan_bwd(HpmnTrainCtx *ctx, const HpmnScanDesc *d, const int32_t *ids, 
     if (rc != HPMN_OK) return rc;
     if (scatter_pending) HIPCHK(hipStreamWaitEvent(st, c->scat, 0));   // the caller's table update needs both halves
     if (!defer_join) return hpmn_train_join(ctx, stream);
+    return HPMN_OK;
+}
+
+int hpmn_train_probe(HpmnTrainCtx *ctx, int32_t enable) {
+    TrainCtx *c = reinterpret_cast<TrainCtx *>(ctx);
+    if (!c) return HPMN_EINVAL;
+    if (enable && c->probe0 == nullptr) {
+        HIPCHK(hipEventCreate(&c->probe0));
+        HIPCHK(hipEventCreate(&c->probe1));
+    }
+    c->probe = enable != 0;
+    c->probed = false;
+    return HPMN_OK;
+}
+
+int hpmn_train_probe_ms(HpmnTrainCtx *ctx, float *ms) {
+    TrainCtx *c = reinterpret_cast<TrainCtx *>(ctx);
+    if (!c || !ms || !c->probed) return HPMN_EINVAL;
+    HIPCHK(hipEventSynchronize(c->probe1));
+    HIPCHK(hipEventElapsedTime(ms, c->probe0, c->probe1));
     return HPMN_OK;
 }
 

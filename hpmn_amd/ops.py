@@ -720,6 +720,17 @@ def _ctx(device) -> int:
     return h
 
 
+def train_probe(device, enable: bool) -> None:
+    """hpmn_train_probe: bracket layer 0's reverse-scan launch of the following steps with timing events."""
+    _lib.check(_lib.load().hpmn_train_probe(_ctx(device), int(enable)), "hpmn_train_probe")
+
+
+def train_probe_ms(device) -> float:
+    ms = C.c_float()
+    _lib.check(_lib.load().hpmn_train_probe_ms(_ctx(device), C.byref(ms)), "hpmn_train_probe_ms")
+    return float(ms.value)
+
+
 class AbiSaved:
     """Saved states of hpmn_scan_fwd_train: one workspace + its layout.  Iterating yields the per-layer
     (x_in, hs, gates) views the per-layer Python path returns, for inspection."""

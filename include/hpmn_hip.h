@@ -361,6 +361,11 @@ int hpmn_scan_bwd(HpmnTrainCtx *ctx, const HpmnScanDesc *desc, const int32_t *id
                   float *const *d_bg, float *const *d_wc, float *const *d_bc, float *d_emb, void *workspace,
                   int32_t defer_join, void *stream);
 int hpmn_train_join(HpmnTrainCtx *ctx, void *stream);
+/* Measurement: with the probe enabled, hpmn_scan_bwd brackets the reverse-scan launch of LAYER 0 (the step's dominant
+ * kernel) with timing events on `stream`; hpmn_train_probe_ms waits for the last bracket and returns its duration.  This
+ * is the launch INSIDE a real step, weight-gradient kernels live beside it -- what bench.py's roofline entry quotes. */
+int hpmn_train_probe(HpmnTrainCtx *ctx, int32_t enable);
+int hpmn_train_probe_ms(HpmnTrainCtx *ctx, float *ms);
 
 /* ------------------------------------------------------------------------------------
  * build_memory with ALL K layers in ONE launch (H = 64): forward hpmn_pipe_fwd, BPTT hpmn_pipe_bwd.
