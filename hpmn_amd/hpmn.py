@@ -428,18 +428,29 @@ class Hpmn_Basic(object):
         aux = self._aux_stream if self.flat_grad.numel() >= (1 << 24) else main
         if aux is not main:
             aux.wait_stream(main)                            # (after the previous step's optimiser, which read it)
+        cleared = None
         with torch.cuda.stream(aux):
+            rest = None
             if _clear_grads is not None:
-                _clear_grads()                               # train_step's two-pass table update (see there)
+                rest = _clear_grads()                        # train_step's two-pass table update (see there)
             else:
                 self.flat_grad.zero_()
             self._loss_acc.zero_()
+            if callable(rest):
+                # what the read kernel waits for is the CLEARING; the early table-Adam pass behind it is only needed in
+                # front of the late pass (the wait at the end of this function) -- at C2 it outlasts the forward by 150 us
+                cleared = torch.cuda.Event()
+                cleared.record(aux)
+                rest()
         self._table_grad_clean = False                       # (until something consumes or clears the table gradient)
         emb = self.params["Embedding/emb_mtx"]
         weights = self._gru_weights()
         memory, last, saved = ops.scan_forward_train(self.spec, ids, emb, weights)
         if aux is not main:
-            main.wait_stream(aux)
+            if cleared is not None:
+                main.wait_event(cleared)
+            else:
+                main.wait_stream(aux)
         seed = 0
         if masks is None and keep_prob < 1.0:
             # masks are drawn inside the read kernel (counter-based): a fresh 64-bit seed per step and rank
@@ -610,8 +621,11 @@ class Hpmn_Basic(object):
                 self.flat_grad.zero_()                        # (a stand-alone compute_gradients left a gradient behind)
             else:
                 self.flat_grad[n_emb:].zero_()
-            ops.table_mark_rows(ids, flags)
-            ops.adam_step_table(*views, flags, 0, lr_t, self.beta1, self.beta2, self.adam_eps, clip=1.0)
+
+            def rest():                                       # (nothing of the forward or the read path waits for this)
+                ops.table_mark_rows(ids, flags)
+                ops.adam_step_table(*views, flags, 0, lr_t, self.beta1, self.beta2, self.adam_eps, clip=1.0)
+            return rest
 
         out, ce = self.compute_gradients(ids, label, keep_prob, masks, global_batch, defer_join=True, _clear_grads=early)
         pending = out.pop("pending", None)
@@ -665,9 +679,12 @@ class Hpmn_Basic(object):
                 self.flat_grad.zero_()
             else:
                 self.flat_grad[n_emb:].zero_()
-            all_ids = dist.gather_ids(ids, max(cap, 1))
-            ops.table_mark_rows(all_ids, flags)
-            ops.adam_step_table(*views, flags, 0, lr_t, self.beta1, self.beta2, self.adam_eps, clip=1.0)
+
+            def rest():
+                all_ids = dist.gather_ids(ids, max(cap, 1))
+                ops.table_mark_rows(all_ids, flags)
+                ops.adam_step_table(*views, flags, 0, lr_t, self.beta1, self.beta2, self.adam_eps, clip=1.0)
+            return rest
 
         if B > 0:
             out, ce = self.compute_gradients(ids, label, keep_prob, masks, gb, defer_join=True, _clear_grads=early)
@@ -676,7 +693,7 @@ class Hpmn_Basic(object):
             main = torch.cuda.current_stream()
             self._aux_stream.wait_stream(main)
             with torch.cuda.stream(self._aux_stream):
-                early()
+                early()()
             main.wait_stream(self._aux_stream)
             out, ce = dict(prediction=torch.empty(0, device=self.device)), torch.zeros((), device=self.device)
         pending = out.pop("pending", None)
