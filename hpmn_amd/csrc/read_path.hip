@@ -192,6 +192,9 @@ __device__ __forceinline__ void dense_fwd_col(const float *X, int ldx, int R, in
 template <int ACT>
 __device__ __forceinline__ void dense_fwd(const float *X, int ldx, int R, int I, const float *W, const float *b,
                                           int N, float *Y, int ldy) {
+#ifdef READ_ABLATE_FWD          // (timing-only builds, tools/read_ablate.sh: where the kernel's time goes; results are wrong)
+    return;
+#endif
     if (N == 1) { dense_fwd_col<ACT>(X, ldx, R, I, W, b, Y, ldy); return; }
     if (N < 16 || (I & 7) != 0) { dense_fwd_valu<ACT>(X, ldx, R, I, W, b, N, Y, ldy); return; }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -250,6 +253,9 @@ __device__ __forceinline__ void dense_fwd(const float *X, int ldx, int R, int I,
 template <bool ACCUM>
 __device__ __forceinline__ void dense_bwd_x(const float *dY, int ldy, int R, int N, const float *W, int I, float *dX,
                                             int ldx) {
+#ifdef READ_ABLATE_BWD_X
+    return;
+#endif
     if ((N & 7) != 0 || (I & 3) != 0 || I < 16) { dense_bwd_x_valu<ACCUM>(dY, ldy, R, N, W, I, dX, ldx); return; }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int c = lane & 31, p = lane >> 5;
@@ -306,6 +312,9 @@ __device__ __forceinline__ void dense_bwd_x(const float *dY, int ldy, int R, int
 template <bool ACCUM>
 __device__ __forceinline__ void dense_bwd_w(const float *X, int ldx, const float *dY, int ldy, int R, int I, int N,
                                             float *gW, float *gb) {
+#ifdef READ_ABLATE_BWD_W
+    return;
+#endif
     if (N < 16 || I < 16) { dense_bwd_w_valu<ACCUM>(X, ldx, dY, ldy, R, I, N, gW, gb); return; }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int c = lane & 31, p = lane >> 5;
