@@ -213,9 +213,17 @@ def roofline_probes(model, c, batches, step_fn):
         ops.embed_gather_seq(gids[k[0] % 8], gtab, spec.front_zero, spec.mask_id0, out=gout)
         k[0] += 1
     t_gather = time_kernel(gather_once, 16, st)
+    # ... and consumed in place (hpmn_embed_gather_sum: rows summed over time, never stored) -- the way the fused scan kernels
+    # use them; 4 B + 64 B per lookup is then ALL the traffic
+    gsum = torch.zeros(B, D0, device=ids.device)
+
+    def gather_sum_once():
+        ops.embed_gather_sum(gids[k[0] % 8], gtab, spec.mask_id0, out=gsum)
+        k[0] += 1
+    t_gather_sum = time_kernel(gather_sum_once, 16, st) if c["F"] <= 4 else None
     gather_alg = n_ids * (4 + 64)
     gather_moved = n_ids * (4 + 128)                              # incl. the materialised row write
-    del gids, gout
+    del gids, gout, gsum
     if gtab is not emb:
         del gtab
 
@@ -274,6 +282,12 @@ def roofline_probes(model, c, batches, step_fn):
                    "moved_GBs_incl_row_write": gather_moved / (t_gather * 1e-3) / 1e9,
                    "table_rows": int(gV), "table_bytes": int(gV) * 64,
                    "protocol": "8 distinct random id batches rotated inside the timed loop, table >> 256 MiB L3"},
+        "gather_in_place": None if t_gather_sum is None else {
+            "kernel": "embed_gather_sum_kernel", "ms": t_gather_sum, "bound": "hbm",
+            "achieved": gather_alg / (t_gather_sum * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "frac": gather_alg / (t_gather_sum * 1e-3) / 1e9 / PEAK_HBM_GBS,
+            "bytes": "4 B id + 64 B row per lookup: all the traffic of a gather whose rows are consumed, not stored",
+            "protocol": "same cold-cache protocol as `gather`"},
         "hbm_bytes_per_step": step_bytes,
         "algorithmic_bytes_train_per_step": alg_train,
         "hbm_over_algorithmic": None if step_bytes is None else step_bytes / alg_train,

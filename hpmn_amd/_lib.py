@@ -232,6 +232,8 @@ SIGNATURES = {
     "hpmn_pipe_bwd": (C.c_int, [C.POINTER(HpmnPipe), C.c_void_p]),
     "hpmn_embed_gather_seq": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                         C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_void_p]),
+    "hpmn_embed_gather_sum": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64,
+                                        C.c_int32, C.c_void_p]),
     "hpmn_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                  C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                  C.c_void_p]),

@@ -6,6 +6,8 @@
 // the id stream [N,F] is read coalesced.  The scatter pre-reduces runs of equal ids along
 // the time axis in registers (the uid column is constant over a sequence and the padding
 // is a run of id 0) and issues one fp32 atomic row add per run.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace hpmn {
@@ -84,6 +86,83 @@ __global__ __launch_bounds__(64) void embed_grad_scatter_kernel(
         }
     }
     if (run_id >= 0 && !(mask_id0 && run_id == 0)) atomicAdd(d_emb + (long)run_id * E + e, acc);
+}
+
+// The gather CONSUMED IN PLACE: out[b, f*E + e] = sum_t emb[ids[b,t,f], e] (mask as above) -- the pooled form of
+// Hpmn.embedding (what the reference's mean-pooling baselines do with it, and what the fused scan kernels do with the rows:
+// use them, never store them).  The roofline probe for north_star's "gather at >= 40 % of HBM": 4 B of id + 64 B of row per
+// lookup is ALL the traffic there is, where the materialising gather above also writes every row back out.
+// One workgroup per (sequence, slice of t); lane = (row slot, float4 of the row); rows of 8 steps in flight per lane.
+constexpr int GRU_ = 8;
+__global__ __launch_bounds__(256) void embed_gather_sum_kernel(const int32_t *__restrict__ ids, const float *__restrict__ emb,
+                                                               float *__restrict__ out, int T, int F, int E4, int mask_id0,
+                                                               int slices) {
+    const long b = blockIdx.x / slices;
+    const int sl = blockIdx.x % slices;
+    const int rows = T * F;                              // lookups of this sequence, index r = t * F + f
+    const int per = (rows + slices - 1) / slices;
+    const int r0 = sl * per, r1 = (r0 + per) < rows ? (r0 + per) : rows;
+    const int e4 = threadIdx.x % E4, slot = threadIdx.x / E4, nslot = 256 / E4;
+    const int32_t *idb = ids + b * (long)rows;
+    // a lane only ever sees lookups r with r % F == f0 when nslot % F == 0: one accumulator per lane then belongs to one id
+    // column; otherwise accumulate per column in F partial sums
+    float4 acc[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) acc[f] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int r = r0 + slot; r < r1; r += nslot * GRU_) {
+        int id[GRU_];
+#pragma unroll
+        for (int u = 0; u < GRU_; ++u) {
+            const int rr = r + u * nslot;
+            id[u] = rr < r1 ? idb[rr] : -1;
+        }
+        float4 v[GRU_];
+#pragma unroll
+        for (int u = 0; u < GRU_; ++u) {
+            const bool keep = id[u] >= 0 && !(mask_id0 && id[u] == 0);
+            v[u] = keep ? reinterpret_cast<const float4 *>(emb)[(long)id[u] * E4 + e4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < GRU_; ++u) {
+            const int f = (r + u * nslot) % F;
+#pragma unroll
+            for (int ff = 0; ff < 4; ++ff)
+                if (ff == f) { acc[ff].x += v[u].x; acc[ff].y += v[u].y; acc[ff].z += v[u].z; acc[ff].w += v[u].w; }
+        }
+    }
+    // sum over the row slots: lanes of a wave that hold the same float4 of a row are E4 apart (xor-shuffles), the four waves
+    // meet in LDS, and ONE atomic per element and workgroup goes to memory (per-lane atomics: 512 adds per address, serialised)
+    __shared__ float4 part[4][4][64];                    // [wave][column][e4]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        float4 a = acc[f];
+        for (int m = E4; m < 64; m <<= 1) {
+            a.x += __shfl_xor(a.x, m); a.y += __shfl_xor(a.y, m); a.z += __shfl_xor(a.z, m); a.w += __shfl_xor(a.w, m);
+        }
+        if (lane < E4) part[wave][f][lane] = a;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < F * E4; i += 256) {
+        const int f = i / E4, e = i - f * E4;
+        float4 a = part[0][f][e];
+        for (int w = 1; w < 4; ++w) { const float4 p = part[w][f][e]; a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w; }
+        float *o = out + b * (long)F * E4 * 4 + (long)f * E4 * 4 + 4 * e;
+        atomicAdd(o, a.x); atomicAdd(o + 1, a.y); atomicAdd(o + 2, a.z); atomicAdd(o + 3, a.w);
+    }
+}
+
+// out [B, F*E] must be zeroed by the caller
+int embed_gather_sum_launch(const int32_t *ids, const float *emb, float *out, int32_t B, int32_t T, int32_t F, int32_t E,
+                            int32_t mask_id0, hipStream_t st) {
+    if (F > 4 || E % 4 != 0 || 256 % (E / 4) != 0) return HPMN_EUNSUPPORTED;
+    if (B == 0) return HPMN_OK;
+    int slices = 1;
+    while ((long)B * slices < 2048 && slices < 16) slices *= 2;          // enough workgroups to fill the chip
+    if (const char *e = getenv("HPMN_GSUM_SLICES")) slices = atoi(e) > 0 ? atoi(e) : slices;
+    hipLaunchKernelGGL(embed_gather_sum_kernel, dim3((unsigned)(B * slices)), dim3(256), 0, st, ids, emb, out, T, F, E / 4,
+                       mask_id0, slices);
+    return check_launch();
 }
 
 int embed_gather_launch(const int32_t *ids, int64_t ids_stride, const float *emb, float *out, int64_t N,

@@ -2,6 +2,8 @@
 #include "pipe_common.h"
 
 namespace hpmn {
+int embed_gather_sum_launch(const int32_t *ids, const float *emb, float *out, int32_t B, int32_t T, int32_t F, int32_t E,
+                            int32_t mask_id0, hipStream_t st);
 size_t pipe_sync_bytes(int K, int ntiles);
 bool pipe_shape_supported(int H, int D);
 int pipe_fwd_launch(const PipeArgs &a, int num_cus, hipStream_t st);
@@ -104,6 +106,16 @@ int hpmn_embed_gather_seq(const int32_t *ids, const float *emb, float *out, int3
     if (B == 0) return HPMN_OK;
     if (!ids || !emb || !out) return HPMN_EINVAL;
     return embed_gather_seq_launch(ids, emb, out, B, Tids, F, E, front_zero, mask_id0, (hipStream_t)stream);
+}
+
+/* out[b, f*E:(f+1)*E] += sum_t emb[ids[b,t,f]] (id-0 mask as in hpmn_embed_gather): the gather consumed in place. */
+int hpmn_embed_gather_sum(const int32_t *ids, const float *emb, float *out, int32_t B, int32_t T, int32_t F, int32_t E,
+                          int64_t V, int32_t mask_id0, void *stream) {
+    (void)hipGetLastError();
+    if (B < 0 || T < 1 || F < 1 || E < 4 || V < 1) return HPMN_EINVAL;
+    if (B == 0) return HPMN_OK;
+    if (!ids || !emb || !out) return HPMN_EINVAL;
+    return embed_gather_sum_launch(ids, emb, out, B, T, F, E, mask_id0, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -512,6 +512,20 @@ def _pipe_sync_buffer(K: int, B: int, device) -> torch.Tensor:
     return buf
 
 
+def embed_gather_sum(ids: torch.Tensor, emb: torch.Tensor, mask_id0: bool, out=None) -> torch.Tensor:
+    """hpmn_embed_gather_sum: out[b, f*E:(f+1)*E] = sum_t emb[ids[b,t,f]] -- the gather consumed in place."""
+    _chk_ids(ids)
+    _chk_f32(emb)
+    B, T, F = ids.shape
+    V, E = emb.shape
+    if out is None:
+        out = torch.zeros(B, F * E, device=emb.device, dtype=torch.float32)
+    rc = _lib.load().hpmn_embed_gather_sum(ids.data_ptr(), emb.data_ptr(), out.data_ptr(), B, T, F, E, V, int(mask_id0),
+                                            _stream())
+    _lib.check(rc, "hpmn_embed_gather_sum")
+    return out
+
+
 def embed_gather_seq(ids, emb, front_zero: int, mask_id0: bool, out=None):
     """hpmn_embed_gather_seq: ids [B,T,F] -> x0 [B, front_zero+T, F*E] (zero prefix, id-0 mask)."""
     _chk_ids(ids)

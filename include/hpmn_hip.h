@@ -410,6 +410,13 @@ int hpmn_pipe_bwd(const HpmnPipe *args, void *stream);
 int hpmn_embed_gather_seq(const int32_t *ids, const float *emb, float *out, int32_t B, int32_t Tids, int32_t F,
                           int32_t E, int32_t front_zero, int64_t V, int32_t mask_id0, void *stream);
 
+/* The gather CONSUMED IN PLACE: out[b, f*E:(f+1)*E] += sum_t emb[ids[b,t,f]] * (mask_id0 ? id != 0 : 1) -- Hpmn.embedding
+ * (code/hpmn.py:414-423) followed by a sum over time, without ever storing the gathered rows.  This is how the fused scan
+ * kernels use the rows, and the roofline probe for north_star's gather target (4 B of id + 64 B of row per lookup is all the
+ * traffic there is).  ids [B,T,F] (F <= 4), emb [V,E], out [B, F*E] pre-zeroed by the caller. */
+int hpmn_embed_gather_sum(const int32_t *ids, const float *emb, float *out, int32_t B, int32_t T, int32_t F, int32_t E,
+                          int64_t V, int32_t mask_id0, void *stream);
+
 /* ------------------------------------------------------------------------------------
  * Memory read path: covariance regulariser (code/hpmn.py:161-170), multi-hop attention over
  * the K memory slots (query_memory :172-182, attention :133-146), prediction head in

@@ -1103,3 +1103,19 @@ def test_two_reverse_scans_in_one_launch_equal_two_launches(dev, name, B, T, D, 
         for what, got, want in (("upper d_act", a_up, dact_up), ("lower d_act", a_lo, dact_lo), ("lower d_x", x_lo, dx_lo)):
             err = float((got - want).abs().max()) / float(want.abs().max())
             assert err <= 5e-6, "%s (flags %d): %g of the tensor's max" % (what, flags, err)
+
+
+@pytest.mark.parametrize("mask", [True, False])
+@pytest.mark.parametrize("F", [1, 2, 3, 4])
+def test_gather_consumed_in_place_equals_the_gathered_rows_summed(dev, mask, F):
+    """hpmn_embed_gather_sum (the roofline probe of the in-place gather) against hpmn_embed_gather + a sum over time."""
+    from hpmn_amd import ops
+    g = torch.Generator().manual_seed(5 + F)
+    V, E, B, T = 1000, 16, 37, 211
+    emb = torch.randn(V, E, generator=g).to(dev)
+    ids = torch.randint(0, V, (B, T, F), generator=g, dtype=torch.int32)
+    ids[:, :50] = 0
+    ids = ids.to(dev)
+    got = ops.embed_gather_sum(ids, emb, mask)
+    want = ops.embed_gather(ids.view(B * T, F), emb, mask).view(B, T, F * E).double().sum(1)
+    np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=0, atol=2e-4)
