@@ -107,11 +107,11 @@ def build_library(force: bool = False, verbose: bool = False, out: str = OUT, fl
     os.replace(out + ".tmp", out)
     with open(out + ".sha1", "w") as f:
         f.write(source_sha(extra) + "\n")
-    # drop objects of older source versions
+    # drop the objects of older source versions (and of developer variants: they recompile when asked for again)
     live = {obj for _, obj in jobs}
     if out == OUT:
         for old in glob.glob(os.path.join(objdir, "*.o")):
-            if old not in live and os.path.getmtime(old) < os.path.getmtime(out) - 86400:
+            if old not in live:
                 os.remove(old)
     return out
 
