@@ -16,6 +16,7 @@ hidden 64, max_len 1000(+1 target) -> 1024 steps, batch 500 per GPU (code/hpmn.p
 per-GPU batch is fixed as N grows.  Prints ONE JSON line on rank 0.
 """
 import argparse
+import gc
 import json
 import math
 import os
@@ -561,6 +562,11 @@ def main():
             torch.cuda.synchronize()
             log("first step done")
     torch.cuda.synchronize()
+    # the host loop runs ahead of the device; a full (generation 2) pass of Python's cycle collector over torch's ~1 M
+    # objects takes ~35 ms -- 0.15 ms/step of a 200-step C1 run when it lands in the timed region.  Collect now, and keep
+    # the survivors out of later passes.
+    gc.collect()
+    gc.freeze()
     log("timing %d steps" % args.steps)
     if world > 1:
         torch.distributed.barrier()

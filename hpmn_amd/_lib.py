@@ -182,6 +182,7 @@ SIGNATURES = {
                                 C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hpmn_read_workspace_bytes": (C.c_size_t, [C.POINTER(HpmnReadDesc)]),
+    "hpmn_read_workspace_bytes_n": (C.c_size_t, [C.c_int32, C.POINTER(C.POINTER(HpmnReadDesc))]),
     "hpmn_read_fwd": (C.c_int, [C.POINTER(HpmnReadDesc)] + [C.c_void_p] * 8),
     "hpmn_read_fwd_bwd": (C.c_int, [C.POINTER(HpmnReadDesc)] + [C.c_void_p] * 6 +
                           [C.c_float, C.c_float, C.c_float] + [C.c_void_p] * 7),
@@ -192,6 +193,7 @@ SIGNATURES = {
                                       C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p,
                                       C.c_void_p, C.c_void_p]),
     "hpmn_read_param_grads": (C.c_int, [C.POINTER(HpmnReadDesc), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hpmn_read_param_grads_n": (C.c_int, [C.c_int32, C.POINTER(C.POINTER(HpmnReadDesc)), C.c_void_p, C.c_void_p, C.c_void_p]),
     "hpmn_embed_grad_scatter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                           C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_void_p]),
     "hpmn_gru_fused_fwd_supported": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),

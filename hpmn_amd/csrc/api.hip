@@ -33,13 +33,15 @@ int gru_wgrad_dispatch(const HpmnGruWgrad &a, hipStream_t st);
 int gru_dx_dispatch(const HpmnGruWgrad &a, hipStream_t st);
 size_t gru_wgrad_workspace_bytes(int B, int T, int D, int H);
 size_t read_workspace_bytes(const HpmnReadDesc &d);
+size_t read_workspace_bytes_n(const HpmnReadDesc *const *d, int nb);
+int read_param_grads_launch_n(const HpmnReadDesc *const *d, int nb, float *d_params, float *workspace, hipStream_t st);
 int read_fwd_launch(const HpmnReadDesc &d, const float *P, const float *memory, const float *last, float *pred,
                     float *logit, float *att_w0, float *mem_loss, hipStream_t st);
 int read_fwd_bwd_launch(const HpmnReadDesc &d, const float *P, const float *memory, const float *last,
                         const int32_t *label, const float *mask1, const float *mask2, float keep_prob,
                         float inv_global_batch, float memory_reg, float *pred, float *loss_out, float *d_memory,
                         float *d_last, float *d_params, float *workspace, hipStream_t st);
-int read_reduce_launch(const HpmnReadDesc &d, float *d_params, const float *workspace, hipStream_t st);
+int read_reduce_launch(const HpmnReadDesc &d, float *d_params, float *workspace, hipStream_t st);
 int read_fwd_launch_n(const HpmnReadDesc *const *d, int nb, const float *P, const float *const *memory,
                       const float *const *last, float *pred, float *logit, float *const *att_w0, float *mem_loss,
                       hipStream_t st);
@@ -369,6 +371,12 @@ size_t hpmn_read_workspace_bytes(const HpmnReadDesc *d) {
     return read_workspace_bytes(*d);
 }
 
+size_t hpmn_read_workspace_bytes_n(int32_t nb, const HpmnReadDesc *const *desc) {
+    if (nb < 1 || nb > 2 || !desc || !desc[0] || (nb > 1 && !desc[1])) return 0;
+    if (desc[0]->B < 1 || desc[0]->n_params < 1) return 0;
+    return read_workspace_bytes_n(desc, nb);
+}
+
 int hpmn_read_fwd(const HpmnReadDesc *d, const float *params, const float *memory, const float *last, float *pred,
                   float *logit, float *att_w0, float *mem_loss, void *stream) {
     drop_stale_hip_error();
@@ -424,12 +432,21 @@ int hpmn_read_fwd_bwd_n(int32_t nb, const HpmnReadDesc *const *desc, const float
                                  memory_reg, pred, loss_out, d_memory, d_last, d_params, workspace, (hipStream_t)stream);
 }
 
-int hpmn_read_param_grads(const HpmnReadDesc *d, float *d_params, const float *workspace, void *stream) {
+int hpmn_read_param_grads(const HpmnReadDesc *d, float *d_params, float *workspace, void *stream) {
     drop_stale_hip_error();
     if (!d || d->B < 0) return HPMN_EINVAL;
     if (d->B == 0) return HPMN_OK;
     if (!d_params || !workspace) return HPMN_EINVAL;
     return read_reduce_launch(*d, d_params, workspace, (hipStream_t)stream);
+}
+
+int hpmn_read_param_grads_n(int32_t nb, const HpmnReadDesc *const *desc, float *d_params, float *workspace, void *stream) {
+    drop_stale_hip_error();
+    if (nb < 1 || nb > 2 || !desc || !desc[0] || (nb > 1 && !desc[1])) return HPMN_EINVAL;
+    if (desc[0]->B < 0) return HPMN_EINVAL;
+    if (desc[0]->B == 0) return HPMN_OK;
+    if (!d_params || !workspace) return HPMN_EINVAL;
+    return read_param_grads_launch_n(desc, nb, d_params, workspace, (hipStream_t)stream);
 }
 
 int hpmn_embed_grad_scatter(const int32_t *ids, const float *d_x, float *d_emb, int32_t B, int32_t T,

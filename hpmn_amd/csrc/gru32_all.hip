@@ -38,7 +38,9 @@ struct RingCtr { int pub, taken; };
 __device__ __forceinline__ float pair_sum(float v) { return v + dpp_quad<0xB1>(v); }
 
 // ---------------------------------------------------------------------------------------------------- forward, one layer
-template <int D, bool TRAIN>
+// XP: the input ring holds PROJECTED rows (x_t [Wg[:D] | Wc[:D]] + b, exponent domain, [r | u | c] x 32) -- layer 0, whose
+// input half the loader wave forms (it has nothing else to do and layer 0 sets the pace of the launch)
+template <int D, bool TRAIN, bool XP = false>
 __device__ __forceinline__ void all32_layer_fwd(const All32Args &a, const int i, const long b, const int lane,
                                                 const float *in_ring, const int in_depth, RingCtr *in_ctr,
                                                 float *out_ring, RingCtr *out_ctr, float (*hb)[AH], float *rhb) {
@@ -47,13 +49,16 @@ __device__ __forceinline__ void all32_layer_fwd(const All32Args &a, const int i,
     const int j = lane >> 1, h = lane & 1;
     const int T = a.len[i], period = a.period[i];
     const float *wg = a.wg[i], *wc = a.wc[i];
-    f2 wxr[DX / 2], wxu[DX / 2], wxc[DX / 2], whr[8], whu[8], whc[8];
+    constexpr int NX = XP ? 1 : DX / 2;
+    f2 wxr[NX], wxu[NX], wxc[NX], whr[8], whu[8], whc[8];
+    if constexpr (!XP) {
 #pragma unroll
-    for (int q = 0; q < DX / 2; ++q) {
-        const long k = h * DX + 2 * q;
-        wxr[q] = f2{wg[k * 2 * H + j], wg[(k + 1) * 2 * H + j]} * NEG_LOG2E;
-        wxu[q] = f2{wg[k * 2 * H + H + j], wg[(k + 1) * 2 * H + H + j]} * NEG_LOG2E;
-        wxc[q] = f2{wc[k * H + j], wc[(k + 1) * H + j]} * (2.0f * NEG_LOG2E);
+        for (int q = 0; q < DX / 2; ++q) {
+            const long k = h * DX + 2 * q;
+            wxr[q] = f2{wg[k * 2 * H + j], wg[(k + 1) * 2 * H + j]} * NEG_LOG2E;
+            wxu[q] = f2{wg[k * 2 * H + H + j], wg[(k + 1) * 2 * H + H + j]} * NEG_LOG2E;
+            wxc[q] = f2{wc[k * H + j], wc[(k + 1) * H + j]} * (2.0f * NEG_LOG2E);
+        }
     }
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
@@ -62,13 +67,15 @@ __device__ __forceinline__ void all32_layer_fwd(const All32Args &a, const int i,
         whu[q] = f2{wg[k * 2 * H + H + j], wg[(k + 1) * 2 * H + H + j]} * NEG_LOG2E;
         whc[q] = f2{wc[k * H + j], wc[(k + 1) * H + j]} * (2.0f * NEG_LOG2E);
     }
+    if constexpr (!XP) {
 #pragma unroll
-    for (int q = 0; q < DX / 2; ++q) { settle(wxr[q]); settle(wxu[q]); settle(wxc[q]); }
+        for (int q = 0; q < DX / 2; ++q) { settle(wxr[q]); settle(wxu[q]); settle(wxc[q]); }
+    }
 #pragma unroll
     for (int q = 0; q < 8; ++q) { settle(whr[q]); settle(whu[q]); settle(whc[q]); }
-    // (the bias once per unit: on the h == 0 half)
-    float br = h == 0 ? a.bg[i][j] * NEG_LOG2E : 0.f, bu = h == 0 ? a.bg[i][H + j] * NEG_LOG2E : 0.f;
-    float bcc = h == 0 ? a.bc[i][j] * (2.0f * NEG_LOG2E) : 0.f;
+    // (the bias once per unit: on the h == 0 half; XP: already in the projected row)
+    float br = (h == 0 && !XP) ? a.bg[i][j] * NEG_LOG2E : 0.f, bu = (h == 0 && !XP) ? a.bg[i][H + j] * NEG_LOG2E : 0.f;
+    float bcc = (h == 0 && !XP) ? a.bc[i][j] * (2.0f * NEG_LOG2E) : 0.f;
     settle(br); settle(bu); settle(bcc);
 
     float hj = 0.f;
@@ -96,15 +103,24 @@ __device__ __forceinline__ void all32_layer_fwd(const All32Args &a, const int i,
             if (in_seen <= t) __builtin_amdgcn_s_sleep(1);
         }
         asm volatile("" ::: "memory");
-        const v4f *x4 = reinterpret_cast<const v4f *>(in_ring + (long)(t & (in_depth - 1)) * D + h * DX);
         f2 ar = {0.f, 0.f}, au = {0.f, 0.f}, ac = {0.f, 0.f};
+        if constexpr (XP) {
+            // (one lane of the pair carries the projected value, the pair sum below adds the other's zero)
+            const float *xp = in_ring + (long)(t & (in_depth - 1)) * 3 * H + j;
+            const float pr = xp[0], pu = xp[H], pc = xp[2 * H];
+            ar.x = h == 0 ? pr : 0.f;
+            au.x = h == 0 ? pu : 0.f;
+            ac.x = h == 0 ? pc : 0.f;
+        } else {
+            const v4f *x4 = reinterpret_cast<const v4f *>(in_ring + (long)(t & (in_depth - 1)) * D + h * DX);
 #pragma unroll
-        for (int q = 0; q < DX / 4; ++q) {
-            const v4f v = x4[q];
-            const f2 lo = {v.x, v.y}, hi = {v.z, v.w};
-            ar = __builtin_elementwise_fma(lo, wxr[2 * q], ar);     ar = __builtin_elementwise_fma(hi, wxr[2 * q + 1], ar);
-            au = __builtin_elementwise_fma(lo, wxu[2 * q], au);     au = __builtin_elementwise_fma(hi, wxu[2 * q + 1], au);
-            ac = __builtin_elementwise_fma(lo, wxc[2 * q], ac);     ac = __builtin_elementwise_fma(hi, wxc[2 * q + 1], ac);
+            for (int q = 0; q < DX / 4; ++q) {
+                const v4f v = x4[q];
+                const f2 lo = {v.x, v.y}, hi = {v.z, v.w};
+                ar = __builtin_elementwise_fma(lo, wxr[2 * q], ar);     ar = __builtin_elementwise_fma(hi, wxr[2 * q + 1], ar);
+                au = __builtin_elementwise_fma(lo, wxu[2 * q], au);     au = __builtin_elementwise_fma(hi, wxu[2 * q + 1], au);
+                ac = __builtin_elementwise_fma(lo, wxc[2 * q], ac);     ac = __builtin_elementwise_fma(hi, wxc[2 * q + 1], ac);
+            }
         }
         lds_counter_set(&in_ctr->taken, t + 1);          // (LDS runs a wave's operations in order: the row has been read)
         const v4f *h4 = reinterpret_cast<const v4f *>(&hb[t & 1][16 * h]);
@@ -158,9 +174,29 @@ __device__ __forceinline__ void all32_layer_fwd(const All32Args &a, const int i,
 
 // ---------------------------------------------------------------------------------------------------- forward, loader wave
 template <int D0, bool TRAIN>
-__device__ __forceinline__ void all32_loader(const All32Args &a, const long b, const int lane, float *xring, RingCtr *ctr) {
+__device__ __forceinline__ void all32_loader(const All32Args &a, const long b, const int lane, float *xrow, float *xpring,
+                                             RingCtr *ctr) {
+    constexpr int H = AH, DX = D0 / 2;
     const int T = a.len[0];
     const bool live = lane < D0;
+    // layer 0's input projection, on the lane pairs like the layers' own products
+    const int j = lane >> 1, h = lane & 1;
+    f2 wxr[DX / 2], wxu[DX / 2], wxc[DX / 2];
+    {
+        const float *wg = a.wg[0], *wc = a.wc[0];
+#pragma unroll
+        for (int q = 0; q < DX / 2; ++q) {
+            const long k = h * DX + 2 * q;
+            wxr[q] = f2{wg[k * 2 * H + j], wg[(k + 1) * 2 * H + j]} * NEG_LOG2E;
+            wxu[q] = f2{wg[k * 2 * H + H + j], wg[(k + 1) * 2 * H + H + j]} * NEG_LOG2E;
+            wxc[q] = f2{wc[k * H + j], wc[(k + 1) * H + j]} * (2.0f * NEG_LOG2E);
+        }
+#pragma unroll
+        for (int q = 0; q < DX / 2; ++q) { settle(wxr[q]); settle(wxu[q]); settle(wxc[q]); }
+    }
+    float br = h == 0 ? a.bg[0][j] * NEG_LOG2E : 0.f, bu = h == 0 ? a.bg[0][H + j] * NEG_LOG2E : 0.f;
+    float bcc = h == 0 ? a.bc[0][j] * (2.0f * NEG_LOG2E) : 0.f;
+    settle(br); settle(bu); settle(bcc);
     const int f = live ? lane / a.E : 0, e = live ? lane % a.E : 0;
     const int32_t *idb = a.ids + b * (long)a.Tids * a.F + f;
     constexpr int LB = 4;                               // steps per batch of loads in flight
@@ -200,10 +236,28 @@ __device__ __forceinline__ void all32_loader(const All32Args &a, const long b, c
                 const bool keep = t >= a.front_zero && !(a.mask_id0 && idA[s] == 0);
                 const float v = keep ? vA[s] : 0.f;
                 if (live) {
-                    xring[(t & (AXR - 1)) * D0 + lane] = v;
+                    xrow[lane] = v;
                     if constexpr (TRAIN) a.x0[(b * (long)T + t) * D0 + lane] = v;
                     if (a.last != nullptr && t == a.last_t) a.last[b * D0 + lane] = v;
                 }
+                wave_sync();
+                {
+                    const v4f *x4 = reinterpret_cast<const v4f *>(xrow + h * DX);
+                    f2 ar = {0.f, 0.f}, au = {0.f, 0.f}, ac = {0.f, 0.f};
+#pragma unroll
+                    for (int q = 0; q < DX / 4; ++q) {
+                        const v4f xv = x4[q];
+                        const f2 lo = {xv.x, xv.y}, hi = {xv.z, xv.w};
+                        ar = __builtin_elementwise_fma(lo, wxr[2 * q], ar);     ar = __builtin_elementwise_fma(hi, wxr[2 * q + 1], ar);
+                        au = __builtin_elementwise_fma(lo, wxu[2 * q], au);     au = __builtin_elementwise_fma(hi, wxu[2 * q + 1], au);
+                        ac = __builtin_elementwise_fma(lo, wxc[2 * q], ac);     ac = __builtin_elementwise_fma(hi, wxc[2 * q + 1], ac);
+                    }
+                    const float pr = pair_sum(ar.x + ar.y + br), pu = pair_sum(au.x + au.y + bu), pc = pair_sum(ac.x + ac.y + bcc);
+                    float *xp = xpring + (t & (AXR - 1)) * 3 * H;
+                    xp[(h == 0 ? 0 : H) + j] = h == 0 ? pr : pu;          // lane h == 0: r and c parts, lane h == 1: the u part
+                    if (h == 0) xp[2 * H + j] = pc;
+                }
+                wave_sync();
                 lds_counter_set(&ctr->pub, t + 1);
             }
         }
@@ -214,7 +268,8 @@ __device__ __forceinline__ void all32_loader(const All32Args &a, const long b, c
 
 template <int D0, bool TRAIN>
 __global__ __launch_bounds__(512) void gru32_fwd_all_kernel(const All32Args a) {
-    __shared__ __attribute__((aligned(16))) float xring[AXR * D0];
+    __shared__ __attribute__((aligned(16))) float xrow[64];              // the loader's current input row
+    __shared__ __attribute__((aligned(16))) float xpring[AXR * 3 * AH];   // layer 0's projected input rows
     __shared__ __attribute__((aligned(16))) float yring[AMAXK][AYR * AH];
     __shared__ __attribute__((aligned(16))) float hb[AMAXK][2][AH];
     __shared__ __attribute__((aligned(16))) float rhb[AMAXK][AH];
@@ -227,10 +282,10 @@ __global__ __launch_bounds__(512) void gru32_fwd_all_kernel(const All32Args a) {
     if (threadIdx.x <= AMAXK) { ctr[threadIdx.x].pub = 0; ctr[threadIdx.x].taken = 0; }
     __syncthreads();
     if (w == K) {
-        all32_loader<D0, TRAIN>(a, b, lane, xring, &ctr[0]);
+        all32_loader<D0, TRAIN>(a, b, lane, xrow, xpring, &ctr[0]);
     } else if (w == 0) {
         __builtin_amdgcn_s_setprio(3);
-        all32_layer_fwd<D0, TRAIN>(a, 0, b, lane, xring, AXR, &ctr[0], K > 1 ? yring[0] : nullptr, &ctr[1], hb[0], rhb[0]);
+        all32_layer_fwd<D0, TRAIN, true>(a, 0, b, lane, xpring, AXR, &ctr[0], K > 1 ? yring[0] : nullptr, &ctr[1], hb[0], rhb[0]);
     } else {
         __builtin_amdgcn_s_setprio(2);
         all32_layer_fwd<AH, TRAIN>(a, w, b, lane, yring[w - 1], AYR, &ctr[w], w + 1 < K ? yring[w] : nullptr, &ctr[w + 1],

@@ -22,11 +22,37 @@ namespace hpmn {
 #define HPMN_READ_RS 2
 #endif
 constexpr int RS = HPMN_READ_RS;          // samples per workgroup
-constexpr int RT = 256;        // threads
+#ifndef HPMN_READ_RT
+#define HPMN_READ_RT 256
+#endif
+constexpr int RT = HPMN_READ_RT;        // threads
 constexpr int A1 = 80, A2 = 40;      // attention MLP widths (code/hpmn.py:137-138)
 constexpr int F1 = 200, F2 = 80;     // head widths (code/hpmn.py:191,193)
+// Row strides in LDS: every activation row is padded by 4 floats.  The products read an operand row per lane (16 bytes
+// at lane_row * stride): with the natural strides (256, 80, 200 ... floats) the rows of a tile start in the same few
+// banks; stride = 4 * odd spreads 16 rows over all 64 banks (worth ~3 % of the launch: the operand reads are a small
+// part of a layer's time).
+constexpr int PADF = 4;
+constexpr int A1P = A1 + PADF, A2P = A2 + PADF, F1P = F1 + PADF, F2P = F2 + PADF;
 constexpr int MAXK = HPMN_MAX_LAYERS;
 constexpr int MAXHOP = 4;
+
+#ifdef READ_CLOCK      // (timing-only build, tools/read_clock.sh: cycles of workgroup 0 per phase, printed at the end of the launch;
+                       //  phases inside the hop loop are SUMS over the hops -- three in every bench configuration)
+__shared__ unsigned long long rck_acc[48], rck_last;
+#define RCLK(i)                                                                                          \
+    do {                                                                                                 \
+        __syncthreads();                                                                                 \
+        if (threadIdx.x == 0 && blockIdx.x == 0) {                                                       \
+            const unsigned long long t_ = clock64();                                                     \
+            rck_acc[i] += t_ - rck_last;                                                                 \
+            rck_last = t_;                                                                               \
+        }                                                                                                \
+    } while (0)
+#else
+#define RCLK(i)
+#endif
+
 
 __device__ __forceinline__ float elu(float x) { return x > 0.f ? x : __expf(x) - 1.f; }
 
@@ -63,7 +89,7 @@ __device__ __forceinline__ void dense_fwd_valu(const float *X, int ldx, int R, i
         const int r0 = rb * RB;
         float acc[RB];
 #pragma unroll
-        for (int j = 0; j < RB; ++j) acc[j] = b[n];
+        for (int j = 0; j < RB; ++j) acc[j] = b != nullptr ? b[n] : 0.f;
         const float *xr[RB];
 #pragma unroll
         for (int j = 0; j < RB; ++j) xr[j] = X + ((r0 + j) < R ? (r0 + j) : (R - 1)) * ldx;
@@ -140,25 +166,6 @@ __device__ __forceinline__ void dense_bwd_x_valu(const float *dY, int ldy, int R
     }
 }
 
-// gW[i][n] (+)= sum_r X[r][i] dY[r][n];  gb[n] (+)= sum_r dY[r][n]   (slab in global, owned by this workgroup)
-template <bool ACCUM>
-__device__ __forceinline__ void dense_bwd_w_valu(const float *X, int ldx, const float *dY, int ldy, int R, int I, int N,
-                                                 float *gW, float *gb) {
-    for (int o = threadIdx.x; o < I * N; o += RT) {
-        const int i = o / N, n = o - i * N;
-        float acc = 0.f;
-        for (int r = 0; r < R; ++r) acc = fmaf(X[r * ldx + i], dY[r * ldy + n], acc);
-        if (ACCUM) gW[o] += acc;
-        else gW[o] = acc;
-    }
-    for (int n = threadIdx.x; n < N; n += RT) {
-        float acc = 0.f;
-        for (int r = 0; r < R; ++r) acc += dY[r * ldy + n];
-        if (ACCUM) gb[n] += acc;
-        else gb[n] = acc;
-    }
-}
-
 // ---- MFMA versions (v_mfma_f32_32x32x2_f32) ---------------------------------------------------------
 // The tile has R <= RS*MAXK = 24 rows, so ONE 32-row MFMA tile holds all of them (lanes past R
 // repeat row R-1; their outputs are dropped) and the four waves of the workgroup split the output
@@ -181,7 +188,7 @@ __device__ __forceinline__ void dense_fwd_col(const float *X, int ldx, int R, in
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
         if (lane == 0) {
-            float v = acc + b[0];
+            float v = acc + (b != nullptr ? b[0] : 0.f);
             if (ACT == 1) v = fmaxf(v, 0.f);
             if (ACT == 2) v = elu(v);
             Y[r * ldy] = v;
@@ -190,13 +197,8 @@ __device__ __forceinline__ void dense_fwd_col(const float *X, int ldx, int R, in
 }
 
 template <int ACT>
-__device__ __forceinline__ void dense_fwd(const float *X, int ldx, int R, int I, const float *W, const float *b,
+__device__ __forceinline__ void dense_fwd_g(const float *X, int ldx, int R, int I, const float *W, const float *b,
                                           int N, float *Y, int ldy) {
-#ifdef READ_ABLATE_FWD          // (timing-only builds, tools/read_ablate.sh: where the kernel's time goes; results are wrong)
-    return;
-#endif
-    if (N == 1) { dense_fwd_col<ACT>(X, ldx, R, I, W, b, Y, ldy); return; }
-    if (N < 16 || (I & 7) != 0) { dense_fwd_valu<ACT>(X, ldx, R, I, W, b, N, Y, ldy); return; }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int c = lane & 31, p = lane >> 5;
     const int KH = I >> 1;
@@ -204,7 +206,7 @@ __device__ __forceinline__ void dense_fwd(const float *X, int ldx, int R, int I,
     for (int nt = wave; nt * 32 < N; nt += RT / 64) {
         const int n = nt * 32 + c, nc = n < N ? n : N - 1;
         const float *wp = W + (long)(p * KH) * N + nc;
-        const float bn = b[nc];
+        const float bn = b != nullptr ? b[nc] : 0.f;
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = bn;
@@ -251,12 +253,8 @@ __device__ __forceinline__ void dense_fwd(const float *X, int ldx, int R, int I,
 // dX[r][i] (+)= sum_n dY[r][n] W[i][n]:  transposed product dX^T = W dY^T, A = W rows (global, 16-byte
 // pieces of the lane's own row), B = dY (LDS rows); a lane ends up with 4 consecutive i of row r = c.
 template <bool ACCUM>
-__device__ __forceinline__ void dense_bwd_x(const float *dY, int ldy, int R, int N, const float *W, int I, float *dX,
+__device__ __forceinline__ void dense_bwd_x_g(const float *dY, int ldy, int R, int N, const float *W, int I, float *dX,
                                             int ldx) {
-#ifdef READ_ABLATE_BWD_X
-    return;
-#endif
-    if ((N & 7) != 0 || (I & 3) != 0 || I < 16) { dense_bwd_x_valu<ACCUM>(dY, ldy, R, N, W, I, dX, ldx); return; }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int c = lane & 31, p = lane >> 5;
     const int KH = N >> 1;
@@ -307,49 +305,141 @@ __device__ __forceinline__ void dense_bwd_x(const float *dY, int ldy, int R, int
     }
 }
 
-// gW[i][n] (+)= sum_r X[r][i] dY[r][n]; gb[n] (+)= sum_r dY[r][n]:  the reduction index (the tile's rows)
-// is the MFMA k, both operands are LDS row segments read by consecutive lanes
-template <bool ACCUM>
-__device__ __forceinline__ void dense_bwd_w(const float *X, int ldx, const float *dY, int ldy, int R, int I, int N,
-                                            float *gW, float *gb) {
-#ifdef READ_ABLATE_BWD_W
+template <int ACT>
+__device__ __forceinline__ void dense_fwd(const float *X, int ldx, int R, int I, const float *W, const float *b, int N, float *Y,
+                                          int ldy) {
+#ifdef READ_ABLATE_FWD          // (timing-only builds, tools/read_ablate.sh: where the kernel's time goes; results are wrong)
     return;
 #endif
-    if (N < 16 || I < 16) { dense_bwd_w_valu<ACCUM>(X, ldx, dY, ldy, R, I, N, gW, gb); return; }
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int c = lane & 31, p = lane >> 5;
-    const int nti = (I + 31) / 32, ntn = (N + 31) / 32;
-    for (int tl = wave; tl < nti * ntn; tl += RT / 64) {
-        const int ti = tl / ntn, tn = tl - ti * ntn;
-        const int i = ti * 32 + c, n = tn * 32 + c;
-        const float *xa = X + (i < I ? i : I - 1);
-        const float *yb = dY + (n < N ? n : N - 1);
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        for (int r0 = 0; r0 < R; r0 += 2) {
-            const int row = r0 + p;
-            const bool in = row < R;
-            const float av = in ? xa[row * ldx] : 0.f;
-            const float bv = in ? yb[row * ldy] : 0.f;
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
-        }
-        if (n < N) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ii = ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * p;
-                if (ii < I) {
-                    if (ACCUM) gW[(long)ii * N + n] += acc[r];
-                    else gW[(long)ii * N + n] = acc[r];
-                }
-            }
-        }
+    if (N == 1) { dense_fwd_col<ACT>(X, ldx, R, I, W, b, Y, ldy); return; }
+    if (N < 16 || (I & 7) != 0) { dense_fwd_valu<ACT>(X, ldx, R, I, W, b, N, Y, ldy); return; }
+    dense_fwd_g<ACT>(X, ldx, R, I, W, b, N, Y, ldy);
+}
+
+template <bool ACCUM>
+__device__ __forceinline__ void dense_bwd_x(const float *dY, int ldy, int R, int N, const float *W, int I, float *dX, int ldx) {
+#ifdef READ_ABLATE_BWD_X
+    return;
+#endif
+    if ((N & 7) != 0 || (I & 3) != 0 || I < 16) { dense_bwd_x_valu<ACCUM>(dY, ldy, R, N, W, I, dX, ldx); return; }
+    dense_bwd_x_g<ACCUM>(dY, ldy, R, N, W, I, dX, ldx);
+}
+
+// ---- the tape: what the read-path WEIGHT gradients are made of.  Only the optimiser needs them, BPTT waits for d_memory /
+// d_last alone -- so the training kernel does not form them (each workgroup used to write a 260 KB slab of per-tile
+// products: a third of its time, 65 MB per launch at the reference batch).  It leaves the operand rows of every product
+// in `workspace` instead, row-major per layer over the WHOLE batch, and read_wgrad_kernel (any stream behind it) forms
+// gW = X^T dY with the batch rows as the reduction index.  Offsets in floats; hop h of the attention layers: + h * hop_stride.
+struct TapeBranch {
+    long inp, dt1;          // [B*K][4H], [B*K][A1]     first attention layer: input rows, gradient behind the relu
+    long x1, dt2;           // [B*K][A1], [B*K][A2]     second
+    long x2, dsc;           // [B*K][A2], [B*K]         third (single column)
+    long hop_stride;
+    long q, dqn;            // [hop][B][H] each         Hmap (shared by the hops): query entering hop h, gradient wrt the one leaving it
+    long last, dq0;         // [B][D0], [B][H]          q0 = last Wq + bq: its input rows (a copy), the gradient wrt q0
+};
+struct Tape {
+    TapeBranch br[2];
+    long rep, dt1;          // [B][W], [B][F1]          fc1
+    long h1, dt2;           // [B][F1], [B][F2]         fc2 (h1 behind the dropout)
+    long h2, dlg;           // [B][F2], [B]             fc3
+    long v, drep;           // [B][W], [B][W]           batch-norm affine: its input, the gradient wrt its output
+    long total;
+};
+
+__host__ __device__ inline Tape tape_layout(const HpmnReadDesc &d0, const HpmnReadDesc &d1, int nb) {
+    Tape t{};
+    long off = 0;
+    auto take = [&](long n) { const long r = off; off += (n + 3) / 4 * 4; return r; };
+    const long B = d0.B;
+    int W = 0;
+    for (int b = 0; b < nb; ++b) {
+        const HpmnReadDesc &d = b == 0 ? d0 : d1;
+        TapeBranch &x = t.br[b];
+        const long BK = B * d.K;
+        const long h0 = off;
+        x.inp = take(BK * 4 * d.H); x.dt1 = take(BK * A1);
+        x.x1 = take(BK * A1); x.dt2 = take(BK * A2);
+        x.x2 = take(BK * A2); x.dsc = take(BK);
+        x.hop_stride = off - h0;
+        off = h0 + x.hop_stride * d.hop;
+        x.q = take(B * d.H * d.hop); x.dqn = take(B * d.H * d.hop);
+        x.last = take(B * d.D0); x.dq0 = take(B * d.H);
+        W += d.H + d.D0;
     }
-    for (int n = threadIdx.x; n < N; n += RT) {
-        float acc = 0.f;
-        for (int r = 0; r < R; ++r) acc += dY[r * ldy + n];
-        if (ACCUM) gb[n] += acc;
-        else gb[n] = acc;
+    t.rep = take(B * W); t.dt1 = take(B * F1);
+    t.h1 = take(B * F1); t.dt2 = take(B * F2);
+    t.h2 = take(B * F2); t.dlg = take(B);
+    t.v = take(B * W); t.drep = take(B * W);
+    t.total = off;
+    return t;
+}
+
+constexpr int WG_NCH = 16;          // row chunks per layer = slabs
+constexpr int WG_MAXL = 48;         // layers: 2 branches x (4 hops x 4 + 1) + 3 head + 1 affine
+struct WgLayer {
+    long x_off, d_off;              // tape offsets
+    int rows, I, N;
+    int w_off, b_off;               // parameter offsets of the kernel / the bias (b_off < 0: none)
+    int first;                      // first work item of the layer (items = tiles * WG_NCH)
+    int kind;                       // 0 product; 1 batch-norm affine: g_gamma[i] = scale sum d v, g_beta[i] = sum d
+    int ntn;                        // column tiles
+};
+struct WgArgs {
+    const WgLayer *L;               // the layer table: written by the training launch into the workspace (it knows the
+    int nl, items, n_params;        // descriptors; 2.4 KB of kernel arguments per launch stalled the host's queue instead)
+    const float *tape;
+    float *slabs;                   // [WG_NCH][n_params]
+};
+constexpr size_t WG_TABLE_FLOATS = (WG_MAXL * sizeof(WgLayer) + 15) / 16 * 4;
+
+// the products of a launch, in slab order; returns the number of work items.  L == nullptr: count only.
+__host__ __device__ inline int wg_layers(const HpmnReadDesc &d0, const HpmnReadDesc &d1, int nb, const Tape &t, WgLayer *L,
+                                         int *nl_out) {
+    int items = 0, nl = 0;
+    auto add = [&](long x_off, long d_off, long rows, int I, int N, int w_off, int b_off, int kind) {
+        const int ntn = (N + 31) / 32;
+        if (L != nullptr) {
+            WgLayer &l = L[nl];
+            l.x_off = x_off; l.d_off = d_off; l.rows = (int)rows; l.I = I; l.N = N; l.w_off = w_off; l.b_off = b_off;
+            l.kind = kind; l.first = items; l.ntn = ntn;
+        }
+        ++nl;
+        const int tiles = kind == 1 ? (I + 63) / 64 : ((I + 31) / 32) * ntn;
+        items += tiles * WG_NCH;
+    };
+    const long B = d0.B;
+    int W = 0;
+    for (int b = 0; b < nb; ++b) {
+        const HpmnReadDesc &x = b == 0 ? d0 : d1;
+        const TapeBranch &tb = t.br[b];
+        const long BK = B * x.K;
+        for (int h = 0; h < x.hop; ++h) {
+            const long hs = (long)h * tb.hop_stride;
+            const int *oa = x.off_att[h];
+            add(tb.inp + hs, tb.dt1 + hs, BK, 4 * x.H, A1, oa[0], oa[1], 0);
+            add(tb.x1 + hs, tb.dt2 + hs, BK, A1, A2, oa[2], oa[3], 0);
+            add(tb.x2 + hs, tb.dsc + hs, BK, A2, 1, oa[4], oa[5], 0);
+        }
+        // Hmap is shared by the hops of a branch: one product over the rows of every hop (contiguous on the tape)
+        add(tb.q, tb.dqn, B * x.hop, x.H, x.H, x.off_map, -1, 0);
+        add(tb.last, tb.dq0, B, x.D0, x.H, x.off_wq, x.off_bq, 0);
+        W += x.H + x.D0;
+    }
+    add(t.rep, t.dt1, B, W, F1, d0.off_fc[0], d0.off_fc[1], 0);
+    add(t.h1, t.dt2, B, F1, F2, d0.off_fc[2], d0.off_fc[3], 0);
+    add(t.h2, t.dlg, B, F2, 1, d0.off_fc[4], d0.off_fc[5], 0);
+    add(t.v, t.drep, B, W, W, d0.off_gamma, d0.off_beta, 1);
+    *nl_out = nl;
+    return items;
+}
+
+// rows of an LDS array (stride ld) -> rows [row0, row0 + rows) of a tape array of width `width`
+__device__ __forceinline__ void tape_store(float *g, long row0, const float *lds, int ld, int rows, int width) {
+    float *dst = g + row0 * width;
+    for (int o = threadIdx.x; o < rows * width; o += RT) {
+        const int r = o / width, i = o - r * width;
+        dst[o] = lds[r * ld + i];
     }
 }
 
@@ -362,14 +452,18 @@ struct ReadArgs {
     float *d_memory[2], *d_last[2];
     float *att_w0[2];
     int nb, W;                  // branches; head input width = sum_b (H_b + D0_b)
+    float *tape;                // training: the operand rows of the weight-gradient products
+    WgLayer *table;             //           the layer table of read_wgrad_kernel (workgroup 0 writes it)
+    Tape tp;                    //           and their layout (tape_layout, filled in by the host)
 };
 
 struct BranchSmem {
-    float *mem;      // [RS*K][H]        memory slots of the tile
-    float *last;     // [RS][D0]
-    float *q;        // [hop+1][RS][H]   query before each hop and after the last
-    float *x1;       // [hop][RS*K][A1]
-    float *x2;       // [hop][RS*K][A2]
+    // (row strides: the width + PADF)
+    float *mem;      // [RS*K][H+]       memory slots of the tile
+    float *last;     // [RS][D0+]
+    float *q;        // [hop+1][RS][H+]  query before each hop and after the last
+    float *x1;       // [hop][RS*K][A1P]
+    float *x2;       // [hop][RS*K][A2P]
     float *sc;       // [hop][RS*K]      softmax scores
     float *cmean;    // [RS*K]        slot means (covariance regulariser)
     float *ccov;     // [RS*K*K]      off-diagonal covariance
@@ -413,11 +507,11 @@ __host__ __device__ inline ReadDims read_dims(const HpmnReadDesc &d0, const Hpmn
 __host__ __device__ inline size_t carve_branch(BranchSmem &x, float *base, size_t off, const HpmnReadDesc &d) {
     auto take = [&](size_t n) { float *r = base ? base + off : nullptr; off += (n + 3) / 4 * 4; return r; };
     const size_t RK = (size_t)RS * d.K;
-    x.mem = take(RK * d.H);
-    x.last = take((size_t)RS * d.D0);
-    x.q = take((size_t)(d.hop + 1) * RS * d.H);
-    x.x1 = take((size_t)d.hop * RK * A1);
-    x.x2 = take((size_t)d.hop * RK * A2);
+    x.mem = take(RK * (d.H + PADF));
+    x.last = take((size_t)RS * (d.D0 + PADF));
+    x.q = take((size_t)(d.hop + 1) * RS * (d.H + PADF));
+    x.x1 = take((size_t)d.hop * RK * A1P);
+    x.x2 = take((size_t)d.hop * RK * A2P);
     x.sc = take((size_t)d.hop * RK);
     x.cmean = take(RK);
     x.ccov = take(RK * d.K);
@@ -433,22 +527,22 @@ __host__ __device__ inline size_t carve_all(ReadSmem &s, float *base, const Hpmn
     const size_t RKm = (size_t)RS * m.Kmax;
     off = carve_branch(s.br[0], base, off, d0);
     if (nb > 1) off = carve_branch(s.br[1], base, off, d1);
-    s.inp = take(RKm * 4 * m.Hmax);
-    s.rep = take((size_t)RS * m.W);
-    s.h1 = take((size_t)RS * F1);
-    s.h2 = take((size_t)RS * F2);
+    s.inp = take(RKm * (4 * m.Hmax + PADF));
+    s.rep = take((size_t)RS * (m.W + PADF));
+    s.h1 = take((size_t)RS * F1P);
+    s.h2 = take((size_t)RS * F2P);
     s.t3 = take(RKm > 64 ? RKm + 64 : 128);        // (+ the per-sample scalars behind entries 32 / 48)
     s.zero = take((size_t)m.Zmax);
-    s.mk1 = take((size_t)RS * F1);
-    s.mk2 = take((size_t)RS * F2);
+    s.mk1 = take((size_t)RS * F1P);
+    s.mk2 = take((size_t)RS * F2P);
     s.dmem = s.t1 = s.t2 = s.dq = s.tq = s.drep = nullptr;
     if (train) {
-        s.dmem = take(RKm * m.Hmax);
-        s.t1 = take(RKm * A1 > (size_t)RS * F1 ? RKm * A1 : (size_t)RS * F1);
-        s.t2 = take(RKm * A2 > (size_t)RS * F2 ? RKm * A2 : (size_t)RS * F2);
-        s.dq = take((size_t)RS * m.Hmax);
-        s.tq = take((size_t)RS * m.Hmax);
-        s.drep = take((size_t)RS * m.W);
+        s.dmem = take(RKm * (m.Hmax + PADF));
+        s.t1 = take(RKm * A1P > (size_t)RS * F1P ? RKm * A1P : (size_t)RS * F1P);
+        s.t2 = take(RKm * A2P > (size_t)RS * F2P ? RKm * A2P : (size_t)RS * F2P);
+        s.dq = take((size_t)RS * (m.Hmax + PADF));
+        s.tq = take((size_t)RS * (m.Hmax + PADF));
+        s.drep = take((size_t)RS * (m.W + PADF));
     }
     return off + 16;
 }
@@ -464,33 +558,52 @@ __device__ inline void carve(ReadSmem &s, float *base, const ReadArgs &a, bool t
     for (int o = threadIdx.x; o < m.Zmax; o += RT) s.zero[o] = 0.f;   // visible after the caller's first barrier
 }
 
+// dot products of rows with a per-sample vector: out[row] = <v[row / K], m[row]> over H, wave per row (a thread per row
+// walked its H terms serially)
+__device__ __forceinline__ void rows_dot(const float *v, int ldv, const float *m, int ldm, int RK, int K, int H, float *out) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int row = wave; row < RK; row += RT / 64) {
+        float acc = 0.f;
+        for (int i = lane; i < H; i += 64) acc = fmaf(v[(row / K) * ldv + i], m[row * ldm + i], acc);
+#pragma unroll
+        for (int x = 32; x >= 1; x >>= 1) acc += __shfl_xor(acc, x);
+        if (lane == 0) out[row] = acc;
+    }
+}
+
 // ---- forward of one branch of one tile: query, hops, covariance regulariser; leaves every activation in LDS and the
 //      per-sample Frobenius norm in x.cnorm --------------------------------------------------------------------------
 __device__ __forceinline__ void read_forward_branch(const HpmnReadDesc &d, const float *P, const ReadSmem &s, const BranchSmem &x, int R) {
     const int K = d.K, H = d.H, D0 = d.D0, RK = R * K;
+    const int HP = H + PADF, D0P = D0 + PADF, IP = 4 * H + PADF;
     const int tid = threadIdx.x;
     // q0 = last Wq + bq  (code/hpmn.py:173)
-    dense_fwd<0>(x.last, D0, R, D0, P + d.off_wq, P + d.off_bq, H, x.q, H);
+    dense_fwd<0>(x.last, D0P, R, D0, P + d.off_wq, P + d.off_bq, H, x.q, HP);
     __syncthreads();
+    RCLK(2);
     for (int hop = 0; hop < d.hop; ++hop) {
-        const float *q = x.q + (size_t)hop * RS * H;
+        const float *q = x.q + (size_t)hop * RS * HP;
         // inp = [q, m, q-m, q*m]  (code/hpmn.py:135-136)
         for (int o = tid; o < RK * H; o += RT) {
             const int row = o / H, i = o - row * H;
-            const float qv = q[(row / K) * H + i], mv = x.mem[row * H + i];
-            float *xi = s.inp + (size_t)row * 4 * H;
+            const float qv = q[(row / K) * HP + i], mv = x.mem[row * HP + i];
+            float *xi = s.inp + (size_t)row * IP;
             xi[i] = qv; xi[H + i] = mv; xi[2 * H + i] = qv - mv; xi[3 * H + i] = qv * mv;
         }
         __syncthreads();
-        float *x1 = x.x1 + (size_t)hop * RS * K * A1, *x2 = x.x2 + (size_t)hop * RS * K * A2;
+        RCLK(3);
+        float *x1 = x.x1 + (size_t)hop * RS * K * A1P, *x2 = x.x2 + (size_t)hop * RS * K * A2P;
         float *sc = x.sc + (size_t)hop * RS * K;
         const int *oa = d.off_att[hop];
-        dense_fwd<1>(s.inp, 4 * H, RK, 4 * H, P + oa[0], P + oa[1], A1, x1, A1);
+        dense_fwd<1>(s.inp, IP, RK, 4 * H, P + oa[0], P + oa[1], A1, x1, A1P);
         __syncthreads();
-        dense_fwd<1>(x1, A1, RK, A1, P + oa[2], P + oa[3], A2, x2, A2);
+        RCLK(4);
+        dense_fwd<1>(x1, A1P, RK, A1, P + oa[2], P + oa[3], A2, x2, A2P);
         __syncthreads();
-        dense_fwd<0>(x2, A2, RK, A2, P + oa[4], P + oa[5], 1, sc, 1);
+        RCLK(5);
+        dense_fwd<0>(x2, A2P, RK, A2, P + oa[4], P + oa[5], 1, sc, 1);
         __syncthreads();
+        RCLK(6);
         // softmax over the K slots of each sample (code/hpmn.py:141)
         if (tid < R) {
             float mx = -3.4e38f;
@@ -501,23 +614,26 @@ __device__ __forceinline__ void read_forward_branch(const HpmnReadDesc &d, const
             for (int k = 0; k < K; ++k) sc[tid * K + k] *= inv;
         }
         __syncthreads();
+        RCLK(7);
         // q' = q Hmap + sum_k score_k m_k   (code/hpmn.py:143-144, 179)
-        float *qn = x.q + (size_t)(hop + 1) * RS * H;
-        dense_fwd<0>(q, H, R, H, P + d.off_map, s.zero, H, qn, H);        // q Hmap (no bias: a row of zeros)
+        float *qn = x.q + (size_t)(hop + 1) * RS * HP;
+        dense_fwd<0>(q, HP, R, H, P + d.off_map, nullptr, H, qn, HP);        // q Hmap (no bias)
         __syncthreads();
+        RCLK(8);
         for (int o = tid; o < R * H; o += RT) {
             const int r = o / H, n = o - r * H;
-            float acc = qn[o];
-            for (int k = 0; k < K; ++k) acc = fmaf(sc[r * K + k], x.mem[(r * K + k) * H + n], acc);
-            qn[o] = acc;
+            float acc = qn[r * HP + n];
+            for (int k = 0; k < K; ++k) acc = fmaf(sc[r * K + k], x.mem[(r * K + k) * HP + n], acc);
+            qn[r * HP + n] = acc;
         }
         __syncthreads();
+        RCLK(9);
     }
     // covariance regulariser (code/hpmn.py:161-170): per-sample Frobenius norm of the off-diagonal cov.
     // Parallel over (sample, slot[, slot]); means / covariances stay in LDS for the backward.
     for (int o = tid; o < RK; o += RT) {
         float a = 0.f;
-        for (int i = 0; i < H; ++i) a += x.mem[o * H + i];
+        for (int i = 0; i < H; ++i) a += x.mem[o * HP + i];
         x.cmean[o] = a / H;
     }
     __syncthreads();
@@ -526,7 +642,7 @@ __device__ __forceinline__ void read_forward_branch(const HpmnReadDesc &d, const
         const int r = rk / K, k = rk - r * K;
         float cv = 0.f;
         if (j != k) {
-            const float *mk = x.mem + (size_t)rk * H, *mj = x.mem + (size_t)(r * K + j) * H;
+            const float *mk = x.mem + (size_t)rk * HP, *mj = x.mem + (size_t)(r * K + j) * HP;
             const float ak = x.cmean[rk], aj = x.cmean[r * K + j];
             for (int i = 0; i < H; ++i) cv = fmaf(mk[i] - ak, mj[i] - aj, cv);
             cv /= H;
@@ -540,6 +656,7 @@ __device__ __forceinline__ void read_forward_branch(const HpmnReadDesc &d, const
         x.cnorm[tid] = sqrtf(ss);
     }
     __syncthreads();
+    RCLK(10);
 }
 
 // ---- forward of one tile: every branch, then the head.  Returns (in s.t3[0..R)) the logits and (in cov_sum[0..R)) the
@@ -547,7 +664,7 @@ __device__ __forceinline__ void read_forward_branch(const HpmnReadDesc &d, const
 __device__ __forceinline__ void read_forward_tile(const ReadArgs &a, const float *P, const ReadSmem &s, int R,
                                   const float *mask1, const float *mask2, float keep_prob, long b0, float *cov_sum) {
     const HpmnReadDesc &d0 = a.d[0];
-    const int tid = threadIdx.x, W = a.W;
+    const int tid = threadIdx.x, W = a.W, WP = W + PADF;
     read_forward_branch(a.d[0], P, s, s.br[0], R);
     if (a.nb > 1) read_forward_branch(a.d[1], P, s, s.br[1], R);
     if (tid < R) cov_sum[tid] = s.br[0].cnorm[tid] + (a.nb > 1 ? s.br[1].cnorm[tid] : 0.f);
@@ -559,39 +676,43 @@ __device__ __forceinline__ void read_forward_tile(const ReadArgs &a, const float
     for (int b = 0; b < 2; ++b) {
         if (b >= a.nb) break;
         const int H = a.d[b].H, D0 = a.d[b].D0;
-        const float *qf = s.br[b].q + (size_t)a.d[b].hop * RS * H;
+        const float *qf = s.br[b].q + (size_t)a.d[b].hop * RS * (H + PADF);
         for (int o = tid; o < R * (H + D0); o += RT) {
             const int r = o / (H + D0), i = o - r * (H + D0);
-            const float v = i < H ? qf[r * H + i] : s.br[b].last[r * D0 + (i - H)];
-            s.rep[r * W + off + i] = v * (P[d0.off_gamma + off + i] * bn_scale) + P[d0.off_beta + off + i];
+            const float v = i < H ? qf[r * (H + PADF) + i] : s.br[b].last[r * (D0 + PADF) + (i - H)];
+            s.rep[r * WP + off + i] = v * (P[d0.off_gamma + off + i] * bn_scale) + P[d0.off_beta + off + i];
         }
         off += H + D0;
     }
     __syncthreads();
-    dense_fwd<2>(s.rep, W, R, W, P + d0.off_fc[0], P + d0.off_fc[1], F1, s.h1, F1);
+    dense_fwd<2>(s.rep, WP, R, W, P + d0.off_fc[0], P + d0.off_fc[1], F1, s.h1, F1P);
     __syncthreads();
+    RCLK(12);
     const bool drop = mask1 != nullptr || mask2 != nullptr || (d0.dropout_seed != 0 && keep_prob < 1.f);
     if (drop) {
         // the tile's dropout factors, once, into LDS (the hash is 64-bit integer math: kept out of line and out
         // of the layer loops -- inlined at its four use sites it doubled the kernel's registers and spilled)
 #pragma unroll 1
         for (int o = tid; o < R * F1; o += RT)
-            s.mk1[o] = keep_factor(mask1, d0.dropout_seed, 1, b0 + o / F1, o % F1, F1, keep_prob) / keep_prob;
+            s.mk1[(o / F1) * F1P + o % F1] = keep_factor(mask1, d0.dropout_seed, 1, b0 + o / F1, o % F1, F1, keep_prob) / keep_prob;
 #pragma unroll 1
         for (int o = tid; o < R * F2; o += RT)
-            s.mk2[o] = keep_factor(mask2, d0.dropout_seed, 2, b0 + o / F2, o % F2, F2, keep_prob) / keep_prob;
+            s.mk2[(o / F2) * F2P + o % F2] = keep_factor(mask2, d0.dropout_seed, 2, b0 + o / F2, o % F2, F2, keep_prob) / keep_prob;
         __syncthreads();
-        for (int o = tid; o < R * F1; o += RT) s.h1[o] *= s.mk1[o];
+        for (int o = tid; o < R * F1P; o += RT) s.h1[o] *= s.mk1[o];       // (the pad columns: finite garbage, never read)
         __syncthreads();
     }
-    dense_fwd<2>(s.h1, F1, R, F1, P + d0.off_fc[2], P + d0.off_fc[3], F2, s.h2, F2);
+    RCLK(13);
+    dense_fwd<2>(s.h1, F1P, R, F1, P + d0.off_fc[2], P + d0.off_fc[3], F2, s.h2, F2P);
     __syncthreads();
+    RCLK(14);
     if (drop) {
-        for (int o = tid; o < R * F2; o += RT) s.h2[o] *= s.mk2[o];
+        for (int o = tid; o < R * F2P; o += RT) s.h2[o] *= s.mk2[o];
         __syncthreads();
     }
-    dense_fwd<0>(s.h2, F2, R, F2, P + d0.off_fc[4], P + d0.off_fc[5], 1, s.t3, 1);
+    dense_fwd<0>(s.h2, F2P, R, F2, P + d0.off_fc[4], P + d0.off_fc[5], 1, s.t3, 1);
     __syncthreads();
+    RCLK(15);
 }
 
 __device__ inline void load_tile_inputs(const ReadArgs &a, const ReadSmem &s, long b0, int R) {
@@ -599,9 +720,12 @@ __device__ inline void load_tile_inputs(const ReadArgs &a, const ReadSmem &s, lo
     for (int b = 0; b < 2; ++b) {
         if (b >= a.nb) break;
         const int K = a.d[b].K, H = a.d[b].H, D0 = a.d[b].D0;
-        for (int o = threadIdx.x; o < R * K * H; o += RT) s.br[b].mem[o] = a.memory[b][b0 * K * H + o];
-        for (int o = threadIdx.x; o < R * D0; o += RT) s.br[b].last[o] = a.last[b][b0 * D0 + o];
+        for (int o = threadIdx.x; o < R * K * H; o += RT) s.br[b].mem[(o / H) * (H + PADF) + o % H] = a.memory[b][b0 * K * H + o];
+        for (int o = threadIdx.x; o < R * D0; o += RT) s.br[b].last[(o / D0) * (D0 + PADF) + o % D0] = a.last[b][b0 * D0 + o];
     }
+    // pad columns that elementwise loops sweep: defined values (mask products over whole padded rows)
+    for (int o = threadIdx.x; o < RS * F1P; o += RT) { s.h1[o] = 0.f; s.mk1[o] = 0.f; }
+    for (int o = threadIdx.x; o < RS * F2P; o += RT) { s.h2[o] = 0.f; s.mk2[o] = 0.f; }
     __syncthreads();
 }
 
@@ -630,61 +754,54 @@ __global__ __launch_bounds__(RT) void read_fwd_kernel(const ReadArgs a, const fl
 
 // ---- backward of one branch: covariance regulariser, hops in reverse, q0; needs s.dq = gradient wrt the branch's final
 //      query and s.drep[:, doff .. doff + D0) = the head's gradient wrt the branch's `last` row; writes d_memory / d_last of
-//      the tile and the branch's parameter gradients into the slab G --------------------------------------------------
+//      the tile and the operand rows of the branch's weight-gradient products onto the tape ---------------------------
 __device__ __forceinline__ void read_backward_branch(const HpmnReadDesc &d, const float *P, const ReadSmem &s, const BranchSmem &x, int R,
-                                     float memory_reg, float *G, float *d_memory, float *d_last, long b0, int doff, int W) {
+                                     float memory_reg, float *tape, const TapeBranch &tb, float *d_memory, float *d_last, long b0,
+                                     int doff, int W) {
     const int K = d.K, H = d.H, D0 = d.D0, RK = R * K;
+    const int HP = H + PADF, D0P = D0 + PADF, IP = 4 * H + PADF, WP = W + PADF;
     const int tid = threadIdx.x;
     // covariance regulariser backward into dmem (code/hpmn.py:161-170): loss_b = ||C_off||_F,
     // C = cc^T / H with c = m - mean_H(m):  d m = (2/(H*norm)) * (C_off c) projected off the mean
-    for (int o = tid; o < RK * H; o += RT) s.dmem[o] = 0.f;
-    __syncthreads();
-    if (memory_reg != 0.f) {
-        // dL/dC_kj = C_kj / nrm (off-diagonal); dL/dc_k = (2/H) sum_j dC_kj c_j; the mean subtraction is a
-        // projection that leaves it unchanged because sum_i c_j[i] = 0
-        for (int o = tid; o < RK * H; o += RT) {
-            const int rk = o / H, i = o - rk * H;
-            const int r = rk / K;
+    // dL/dC_kj = C_kj / nrm (off-diagonal); dL/dc_k = (2/H) sum_j dC_kj c_j; the mean subtraction is a
+    // projection that leaves it unchanged because sum_i c_j[i] = 0
+    for (int o = tid; o < RK * H; o += RT) {
+        const int rk = o / H, i = o - rk * H;
+        const int r = rk / K;
+        float acc = 0.f;
+        if (memory_reg != 0.f) {
             const float nrm = x.cnorm[r];
-            float acc = 0.f;
             if (nrm > 0.f) {
                 for (int j = 0; j < K; ++j)
-                    acc = fmaf(x.ccov[rk * K + j], x.mem[(size_t)(r * K + j) * H + i] - x.cmean[r * K + j], acc);
+                    acc = fmaf(x.ccov[rk * K + j], x.mem[(size_t)(r * K + j) * HP + i] - x.cmean[r * K + j], acc);
                 acc *= memory_reg * 2.f / (H * nrm);
             }
-            s.dmem[o] = acc;
         }
+        s.dmem[rk * HP + i] = acc;
     }
     __syncthreads();
+    RCLK(25);
 
     // ---- hops backward (reverse order) ---------------------------------------------------------
-    // zero the shared-across-hops gradient of Hmap in the slab, accumulate per hop
-    for (int o = tid; o < H * H; o += RT) G[d.off_map + o] = 0.f;
-    __syncthreads();
     for (int hop = d.hop - 1; hop >= 0; --hop) {
-        const float *q = x.q + (size_t)hop * RS * H;           // query entering this hop
-        float *x1 = x.x1 + (size_t)hop * RS * K * A1, *x2 = x.x2 + (size_t)hop * RS * K * A2;
+        const float *q = x.q + (size_t)hop * RS * HP;           // query entering this hop
+        float *x1 = x.x1 + (size_t)hop * RS * K * A1P, *x2 = x.x2 + (size_t)hop * RS * K * A2P;
         float *sc = x.sc + (size_t)hop * RS * K;
         const int *oa = d.off_att[hop];
-        // q' = q Hmap + sum_k sc_k m_k : d Hmap += q^T dq';  d sc_k = <dq', m_k>;  d m_k += sc_k dq'
-        for (int o = tid; o < H * H; o += RT) {
-            const int i = o / H, n = o - i * H;
-            float acc = 0.f;
-            for (int r = 0; r < R; ++r) acc = fmaf(q[r * H + i], s.dq[r * H + n], acc);
-            G[d.off_map + o] += acc;
-        }
+        // q' = q Hmap + sum_k sc_k m_k : d Hmap += q^T dq' (tape);  d sc_k = <dq', m_k>;  d m_k += sc_k dq'
+        float *th = tape + (long)hop * tb.hop_stride;
+        tape_store(tape + tb.q + (long)hop * d.B * H, b0, q, HP, R, H);
+        tape_store(tape + tb.dqn + (long)hop * d.B * H, b0, s.dq, HP, R, H);
+        RCLK(39);
         float *dsc = s.t3;          // [RK]
-        for (int o = tid; o < RK; o += RT) {
-            const int r = o / K;
-            float acc = 0.f;
-            for (int i = 0; i < H; ++i) acc = fmaf(s.dq[r * H + i], x.mem[o * H + i], acc);
-            dsc[o] = acc;
-        }
+        rows_dot(s.dq, HP, x.mem, HP, RK, K, H, dsc);
+        RCLK(40);
         for (int o = tid; o < RK * H; o += RT) {
             const int row = o / H, i = o - row * H;
-            s.dmem[o] = fmaf(sc[row], s.dq[(row / K) * H + i], s.dmem[o]);
+            s.dmem[row * HP + i] = fmaf(sc[row], s.dq[(row / K) * HP + i], s.dmem[row * HP + i]);
         }
         __syncthreads();
+        RCLK(26);
         // softmax backward: d s_k = sc_k (d sc_k - sum_j sc_j d sc_j)
         if (tid < R) {
             float dot = 0.f;
@@ -692,84 +809,110 @@ __device__ __forceinline__ void read_backward_branch(const HpmnReadDesc &d, cons
             for (int k = 0; k < K; ++k) dsc[tid * K + k] = sc[tid * K + k] * (dsc[tid * K + k] - dot);
         }
         __syncthreads();
+        RCLK(27);
         // rebuild inp of this hop (the forward overwrote it hop by hop)
         for (int o = tid; o < RK * H; o += RT) {
             const int row = o / H, i = o - row * H;
-            const float qv = q[(row / K) * H + i], mv = x.mem[row * H + i];
-            float *xi = s.inp + (size_t)row * 4 * H;
+            const float qv = q[(row / K) * HP + i], mv = x.mem[row * HP + i];
+            float *xi = s.inp + (size_t)row * IP;
             xi[i] = qv; xi[H + i] = mv; xi[2 * H + i] = qv - mv; xi[3 * H + i] = qv * mv;
         }
         // fc3 (A2 -> 1, no activation)
-        dense_bwd_w<false>(x2, A2, dsc, 1, RK, A2, 1, G + oa[4], G + oa[5]);
-        dense_bwd_x<false>(dsc, 1, RK, 1, P + oa[4], A2, s.t2, A2);
+        tape_store(th + tb.x2, b0 * K, x2, A2P, RK, A2);
+        tape_store(th + tb.dsc, b0 * K, dsc, 1, RK, 1);
+        dense_bwd_x<false>(dsc, 1, RK, 1, P + oa[4], A2, s.t2, A2P);
         __syncthreads();
-        for (int o = tid; o < RK * A2; o += RT) s.t2[o] = x2[o] > 0.f ? s.t2[o] : 0.f;      // relu
+        RCLK(28);
+        for (int o = tid; o < RK * A2P; o += RT) s.t2[o] = x2[o] > 0.f ? s.t2[o] : 0.f;      // relu
         __syncthreads();
-        dense_bwd_w<false>(x1, A1, s.t2, A2, RK, A1, A2, G + oa[2], G + oa[3]);
-        dense_bwd_x<false>(s.t2, A2, RK, A2, P + oa[2], A1, s.t1, A1);
+        RCLK(29);
+        tape_store(th + tb.x1, b0 * K, x1, A1P, RK, A1);
+        tape_store(th + tb.dt2, b0 * K, s.t2, A2P, RK, A2);
+        RCLK(30);
+        dense_bwd_x<false>(s.t2, A2P, RK, A2, P + oa[2], A1, s.t1, A1P);
         __syncthreads();
-        for (int o = tid; o < RK * A1; o += RT) s.t1[o] = x1[o] > 0.f ? s.t1[o] : 0.f;      // relu
+        RCLK(31);
+        for (int o = tid; o < RK * A1P; o += RT) s.t1[o] = x1[o] > 0.f ? s.t1[o] : 0.f;      // relu
         __syncthreads();
-        dense_bwd_w<false>(s.inp, 4 * H, s.t1, A1, RK, 4 * H, A1, G + oa[0], G + oa[1]);
-        // d inp [RK, 4H] -> reuse s.inp AFTER the weight gradient has consumed it
+        RCLK(32);
+        tape_store(th + tb.inp, b0 * K, s.inp, IP, RK, 4 * H);
+        tape_store(th + tb.dt1, b0 * K, s.t1, A1P, RK, A1);
+        // d inp [RK, 4H] -> reuse s.inp AFTER the tape has its copy
         __syncthreads();
-        dense_bwd_x<false>(s.t1, A1, RK, A1, P + oa[0], 4 * H, s.inp, 4 * H);
+        RCLK(33);
+        dense_bwd_x<false>(s.t1, A1P, RK, A1, P + oa[0], 4 * H, s.inp, IP);
         __syncthreads();
+        RCLK(34);
         // inp = [q, m, q-m, q*m]:  dq_row = d0 + d2 + d3*m ; dm += d1 - d2 + d3*q
         // new dq (gradient wrt the query entering the hop) = dq' Hmap^T + sum_k dq_row
-        float *dqn = s.tq;          // [R][H]
-        dense_bwd_x<false>(s.dq, H, R, H, P + d.off_map, H, dqn, H);     // dq' Hmap^T
+        float *dqn = s.tq;          // [R][H+]
+        dense_bwd_x<false>(s.dq, HP, R, H, P + d.off_map, H, dqn, HP);     // dq' Hmap^T
         __syncthreads();
+        RCLK(35);
         for (int o = tid; o < R * H; o += RT) {
             const int r = o / H, i = o - r * H;
-            float acc = dqn[o];
+            float acc = dqn[r * HP + i];
             for (int k = 0; k < K; ++k) {
-                const float *di = s.inp + (size_t)(r * K + k) * 4 * H;
-                acc += di[i] + di[2 * H + i] + di[3 * H + i] * x.mem[(r * K + k) * H + i];
+                const float *di = s.inp + (size_t)(r * K + k) * IP;
+                acc += di[i] + di[2 * H + i] + di[3 * H + i] * x.mem[(r * K + k) * HP + i];
             }
-            dqn[o] = acc;
+            dqn[r * HP + i] = acc;
         }
         for (int o = tid; o < RK * H; o += RT) {
             const int row = o / H, i = o - row * H;
-            const float *di = s.inp + (size_t)row * 4 * H;
-            s.dmem[o] += di[H + i] - di[2 * H + i] + di[3 * H + i] * q[(row / K) * H + i];
+            const float *di = s.inp + (size_t)row * IP;
+            s.dmem[row * HP + i] += di[H + i] - di[2 * H + i] + di[3 * H + i] * q[(row / K) * HP + i];
         }
         __syncthreads();
-        for (int o = tid; o < R * H; o += RT) s.dq[o] = dqn[o];
+        for (int o = tid; o < R * H; o += RT) { const int r = o / H, i = o - r * H; s.dq[r * HP + i] = dqn[r * HP + i]; }
         __syncthreads();
+        RCLK(36);
     }
     // q0 = last Wq + bq
-    dense_bwd_w<false>(x.last, D0, s.dq, H, R, D0, H, G + d.off_wq, G + d.off_bq);
-    dense_bwd_x<true>(s.dq, H, R, H, P + d.off_wq, D0, s.drep + doff, W);      // += dq Wq^T onto the head part
+    tape_store(tape + tb.last, b0, x.last, D0P, R, D0);
+    tape_store(tape + tb.dq0, b0, s.dq, HP, R, H);
+    dense_bwd_x<true>(s.dq, HP, R, H, P + d.off_wq, D0, s.drep + doff, WP);      // += dq Wq^T onto the head part
     __syncthreads();
+    RCLK(37);
     for (int o = tid; o < R * D0; o += RT) {
         const int r = o / D0, i = o - r * D0;
-        d_last[b0 * D0 + o] = s.drep[r * W + doff + i];
+        d_last[b0 * D0 + o] = s.drep[r * WP + doff + i];
     }
-    for (int o = tid; o < RK * H; o += RT) d_memory[b0 * K * H + o] = s.dmem[o];
+    for (int o = tid; o < RK * H; o += RT) d_memory[b0 * K * H + o] = s.dmem[(o / H) * HP + o % H];
     __syncthreads();
+    RCLK(38);
 }
 
 // Training: forward + loss + backward of the tile in one launch.
 //   loss = sum_b ll_b * inv_global_batch + memory_reg * sum_b cov_b        (code/hpmn.py:202-207)
 // outputs: pred [B]; loss_out[0] += sum ll_b, loss_out[1] += sum cov_b (atomics); d_memory [B,K,H] and d_last [B,D0] of
-// every branch; slab[blockIdx] = this tile's read-path weight gradients (layout == parameter range).
+// every branch; a.tape: the operand rows of the read-path weight-gradient products (read_wgrad_kernel forms them).
 __global__ __launch_bounds__(RT) void read_fwd_bwd_kernel(const ReadArgs a, const float *__restrict__ P,
                                                           const int32_t *__restrict__ label,
                                                           const float *__restrict__ mask1,
                                                           const float *__restrict__ mask2, float keep_prob,
                                                           float inv_global_batch, float memory_reg, float *pred,
-                                                          float *loss_out, float *slabs) {
+                                                          float *loss_out) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     ReadSmem s;
     const HpmnReadDesc &d = a.d[0];
-    const int W = a.W;
+    const int W = a.W, WP = W + PADF;
     carve(s, smem, a, true);
     const int tid = threadIdx.x;
     const long b0 = (long)blockIdx.x * RS;
     const int R = (d.B - b0) < RS ? (int)(d.B - b0) : RS;
-    float *G = slabs + (long)blockIdx.x * d.n_params;      // this tile's gradient slab
+    const Tape &tp = a.tp;
+    float *tape = a.tape;
+    if (blockIdx.x == 0 && tid == 0) {
+        int nl;
+        wg_layers(a.d[0], a.d[1], a.nb, tp, a.table, &nl);
+    }
+#ifdef READ_CLOCK
+    if (tid < 48) rck_acc[tid] = 0;
+    if (tid == 0) rck_last = clock64();
+#endif
     load_tile_inputs(a, s, b0, R);
+    RCLK(1);
     float *cov = s.t3 + 32;
     read_forward_tile(a, P, s, R, mask1, mask2, keep_prob, b0, cov);
     const bool drop = mask1 != nullptr || mask2 != nullptr || (d.dropout_seed != 0 && keep_prob < 1.f);
@@ -789,34 +932,48 @@ __global__ __launch_bounds__(RT) void read_fwd_bwd_kernel(const ReadArgs a, cons
         dlg[tid] = dp * p * (1.f - p);
     }
     __syncthreads();
+    RCLK(16);
 
     // ---- head backward ------------------------------------------------------------------------
     // fc3: logit = h2 W3 + b3
-    dense_bwd_w<false>(s.h2, F2, dlg, 1, R, F2, 1, G + d.off_fc[4], G + d.off_fc[5]);
-    dense_bwd_x<false>(dlg, 1, R, 1, P + d.off_fc[4], F2, s.t2, F2);        // d h2 (post-dropout)
+    tape_store(tape + tp.h2, b0, s.h2, F2P, R, F2);
+    tape_store(tape + tp.dlg, b0, dlg, 1, R, 1);
+    dense_bwd_x<false>(dlg, 1, R, 1, P + d.off_fc[4], F2, s.t2, F2P);        // d h2 (post-dropout)
     __syncthreads();
+    RCLK(17);
     // through dropout2 and elu2: h2 = elu(a2) * mask/keep.  elu'(a) = a>0 ? 1 : elu(a)+1; recover from h2.
     for (int o = tid; o < R * F2; o += RT) {
+        const int oo = (o / F2) * F2P + o % F2;
         float mk = 1.f;
-        if (drop) mk = s.mk2[o];
-        const float hv = mk != 0.f ? s.h2[o] / mk : 0.f;                    // elu(a2); irrelevant where mask==0
-        s.t2[o] = s.t2[o] * mk * (hv > 0.f ? 1.f : hv + 1.f);
+        if (drop) mk = s.mk2[oo];
+        const float hv = mk != 0.f ? s.h2[oo] / mk : 0.f;                    // elu(a2); irrelevant where mask==0
+        s.t2[oo] = s.t2[oo] * mk * (hv > 0.f ? 1.f : hv + 1.f);
     }
     __syncthreads();
-    dense_bwd_w<false>(s.h1, F1, s.t2, F2, R, F1, F2, G + d.off_fc[2], G + d.off_fc[3]);
-    dense_bwd_x<false>(s.t2, F2, R, F2, P + d.off_fc[2], F1, s.t1, F1);     // d h1 (post-dropout)
+    RCLK(18);
+    tape_store(tape + tp.h1, b0, s.h1, F1P, R, F1);
+    tape_store(tape + tp.dt2, b0, s.t2, F2P, R, F2);
+    RCLK(19);
+    dense_bwd_x<false>(s.t2, F2P, R, F2, P + d.off_fc[2], F1, s.t1, F1P);     // d h1 (post-dropout)
     __syncthreads();
+    RCLK(20);
     for (int o = tid; o < R * F1; o += RT) {
+        const int oo = (o / F1) * F1P + o % F1;
         float mk = 1.f;
-        if (drop) mk = s.mk1[o];
-        const float hv = mk != 0.f ? s.h1[o] / mk : 0.f;
-        s.t1[o] = s.t1[o] * mk * (hv > 0.f ? 1.f : hv + 1.f);
+        if (drop) mk = s.mk1[oo];
+        const float hv = mk != 0.f ? s.h1[oo] / mk : 0.f;
+        s.t1[oo] = s.t1[oo] * mk * (hv > 0.f ? 1.f : hv + 1.f);
     }
     __syncthreads();
-    dense_bwd_w<false>(s.rep, W, s.t1, F1, R, W, F1, G + d.off_fc[0], G + d.off_fc[1]);
-    dense_bwd_x<false>(s.t1, F1, R, F1, P + d.off_fc[0], W, s.drep, W);   // d bn-output
+    RCLK(21);
+    tape_store(tape + tp.rep, b0, s.rep, WP, R, W);
+    tape_store(tape + tp.dt1, b0, s.t1, F1P, R, F1);
+    RCLK(22);
+    dense_bwd_x<false>(s.t1, F1P, R, F1, P + d.off_fc[0], W, s.drep, WP);   // d bn-output
     __syncthreads();
-    // bn affine: rep = v*gamma*scale + beta  ->  d gamma, d beta, d v; v = concat_b [q_final_b, last_b]
+    RCLK(23);
+    // bn affine: rep = v*gamma*scale + beta  ->  d gamma, d beta (tape: v and the gradient wrt rep), d v;
+    // v = concat_b [q_final_b, last_b]
     const float bn_scale = rsqrtf(1.f + 1e-3f);
     {
         int off = 0;
@@ -824,39 +981,121 @@ __global__ __launch_bounds__(RT) void read_fwd_bwd_kernel(const ReadArgs a, cons
         for (int b = 0; b < 2; ++b) {
             if (b >= a.nb) break;
             const int H = a.d[b].H, D0 = a.d[b].D0;
-            const float *qf = s.br[b].q + (size_t)a.d[b].hop * RS * H;
-            for (int i = tid; i < H + D0; i += RT) {
-                float gg = 0.f, gb = 0.f;
-                for (int r = 0; r < R; ++r) {
-                    const float v = i < H ? qf[r * H + i] : s.br[b].last[r * D0 + (i - H)];
-                    const float dy = s.drep[r * W + off + i];
-                    gg = fmaf(dy, v * bn_scale, gg);
-                    gb += dy;
-                }
-                G[d.off_gamma + off + i] = gg;
-                G[d.off_beta + off + i] = gb;
+            const float *qf = s.br[b].q + (size_t)a.d[b].hop * RS * (H + PADF);
+            for (int o = tid; o < R * (H + D0); o += RT) {
+                const int r = o / (H + D0), i = o - r * (H + D0);
+                const float v = i < H ? qf[r * (H + PADF) + i] : s.br[b].last[r * (D0 + PADF) + (i - H)];
+                tape[tp.v + (b0 + r) * W + off + i] = v;
+                tape[tp.drep + (b0 + r) * W + off + i] = s.drep[r * WP + off + i];
             }
             off += H + D0;
         }
     }
     __syncthreads();          // the loop below rescales s.drep in place
     for (int o = tid; o < R * W; o += RT) {
-        const int i = o % W;
-        s.drep[o] *= P[d.off_gamma + i] * bn_scale;            // now: gradient wrt [q_final_b, last_b] of every branch
+        const int r = o / W, i = o - r * W;
+        s.drep[r * WP + i] *= P[d.off_gamma + i] * bn_scale;            // now: gradient wrt [q_final_b, last_b] of every branch
     }
     __syncthreads();
+    RCLK(24);
     // ---- the branches ---------------------------------------------------------------------------
     int off = 0;
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         if (b >= a.nb) break;
         const int H = a.d[b].H, D0 = a.d[b].D0;
-        for (int o = tid; o < R * H; o += RT) s.dq[o] = s.drep[(o / H) * W + off + (o % H)];
+        for (int o = tid; o < R * H; o += RT) s.dq[(o / H) * (H + PADF) + o % H] = s.drep[(o / H) * WP + off + (o % H)];
         __syncthreads();
-        read_backward_branch(a.d[b], P, s, s.br[b], R, memory_reg, G, a.d_memory[b], a.d_last[b], b0, off + H, W);
+        read_backward_branch(a.d[b], P, s, s.br[b], R, memory_reg, tape, tp.br[b], a.d_memory[b], a.d_last[b], b0, off + H, W);
         off += H + D0;
     }
+#ifdef READ_CLOCK
+    if (tid == 0 && blockIdx.x == 0) {
+        unsigned long long tot = 0;
+        for (int i = 0; i < 48; ++i) tot += rck_acc[i];
+        printf("RCLK total %llu :", tot);
+        for (int i = 0; i < 48; ++i) printf(" %d=%llu", i, rck_acc[i]);
+        printf("\n");
+    }
+#endif
 }
+
+
+// ---- the weight gradients, from the tape ---------------------------------------------------------------------------------
+// One product gW[I,N] = X^T dY (+ gb[N] = column sums of dY) per dense layer, X [rows, I] and dY [rows, N] row-major on the
+// tape (or, for Wq, the `last` rows of the call).  A work item = (layer, 32x32 output tile, one of WG_NCH row chunks) on ONE
+// wave: v_mfma_f32_32x32x2_f32 with the batch rows as the reduction index -- lane (c, p) feeds A = X[row + p][i0 + c],
+// B = dY[row + p][n0 + c], both 128-byte coalesced reads.  The item writes its tile into slab `chunk` of the workspace
+// (layout == parameter range, like the slabs the training kernel used to write per workgroup -- 16 now, not B/2), and
+// read_reduce_kernel adds the slabs to the gradient buffer in a fixed order.
+__global__ __launch_bounds__(256) void read_wgrad_kernel(const WgArgs a) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int item = blockIdx.x * 4 + wave;
+    if (item >= a.items) return;
+    int l = 0;
+    while (l + 1 < a.nl && a.L[l + 1].first <= item) ++l;
+    const WgLayer &L = a.L[l];
+    const int local = item - L.first;
+    const int chunk = local % WG_NCH, tile = local / WG_NCH;
+    const int per = (L.rows + WG_NCH - 1) / WG_NCH;
+    const int r0 = chunk * per, r1 = (r0 + per) < L.rows ? (r0 + per) : L.rows;
+    float *slab = a.slabs + (long)chunk * a.n_params;
+    const float *X = a.tape + L.x_off;
+    const float *D = a.tape + L.d_off;
+    if (L.kind == 1) {
+        // affine: X = v, D = gradient wrt the output; 64 features per item
+        const int i = tile * 64 + lane;
+        if (i >= L.I) return;
+        const float bn_scale = rsqrtf(1.f + 1e-3f);
+        float gg = 0.f, gb = 0.f;
+        for (int r = r0; r < r1; ++r) {
+            const float dy = D[(long)r * L.I + i];
+            gg = fmaf(dy, X[(long)r * L.I + i] * bn_scale, gg);
+            gb += dy;
+        }
+        slab[L.w_off + i] = gg;
+        slab[L.b_off + i] = gb;
+        return;
+    }
+    const int c = lane & 31, p = lane >> 5;
+    const int ti = tile / L.ntn, tn = tile - ti * L.ntn;
+    const int i = ti * 32 + c, n = tn * 32 + c;
+    const bool iv = i < L.I, nv = n < L.N;
+    const float *xp = X + (iv ? i : 0), *dp = D + (nv ? n : 0);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float bsum = 0.f;
+    constexpr int UN = 8;           // products per group: 16 loads in flight
+    for (int r = r0; r < r1; r += 2 * UN) {
+        float av[UN], bv[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int row = r + 2 * u + p;
+            const bool in = row < r1;
+            av[u] = (in && iv) ? xp[(long)row * L.I] : 0.f;
+            bv[u] = (in && nv) ? dp[(long)row * L.N] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
+            bsum += bv[u];
+        }
+    }
+    // C/D layout: lane (c, p), reg r -> row (r&3) + 8*(r>>2) + 4*p (the i index), column c (the n index)
+    if (nv) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ii = ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * p;
+            if (ii < L.I) slab[L.w_off + (long)ii * L.N + n] = acc[r];
+        }
+    }
+    if (ti == 0 && L.b_off >= 0) {
+        bsum += __shfl_xor(bsum, 32);
+        if (p == 0 && nv) slab[L.b_off + n] = bsum;
+    }
+}
+
 
 // grad[e] += sum over tiles of slabs[w][e].  A block owns 32 consecutive elements; its 8 groups of 32 lanes
 // each sum every 8th slab (4 independent partial sums, 128-byte coalesced reads) and are combined through LDS
@@ -887,14 +1126,22 @@ __global__ __launch_bounds__(32 * RRED_G) void read_reduce_kernel(const float *_
     grad[e] += tot;
 }
 
+static size_t read_slab_floats(const HpmnReadDesc &d) { return ((size_t)WG_NCH * (size_t)d.n_params + 3) / 4 * 4; }
+
 static bool read_desc_ok(const HpmnReadDesc &d) {
     return d.B >= 0 && d.K >= 1 && d.K <= MAXK && d.H >= 1 && d.D0 >= 1 && d.hop >= 1 && d.hop <= MAXHOP &&
            d.n_params > 0 && RS * d.K <= 48;
 }
 
+// workspace = [WG_NCH slabs of n_params | layer table | tape]  (the slabs first: their place must not move with the batch size -- positions
+// of the parameter range that belong to no read-path variable are never written and rely on the caller's one-time zero fill)
+size_t read_workspace_bytes_n(const HpmnReadDesc *const *d, int nb) {
+    const Tape t = tape_layout(*d[0], *d[nb > 1 ? 1 : 0], nb);
+    return ((size_t)t.total + read_slab_floats(*d[0]) + WG_TABLE_FLOATS) * sizeof(float);
+}
 size_t read_workspace_bytes(const HpmnReadDesc &d) {
-    const long ntile = (d.B + RS - 1) / RS;
-    return (size_t)ntile * (size_t)d.n_params * sizeof(float);
+    const HpmnReadDesc *dp[1] = {&d};
+    return read_workspace_bytes_n(dp, 1);
 }
 
 // nb = 1: d[0] alone (the "User"-only graph); nb = 2: d[0], d[1] in the order of the head's concat (user, item).
@@ -913,6 +1160,29 @@ static int read_args(ReadArgs &a, const HpmnReadDesc *const *d, int nb, const fl
         a.W += d[b]->H + d[b]->D0;
     }
     return HPMN_OK;
+}
+
+// the second half of the training call on its own: d_params += the read-path weight gradients, formed from the tape the
+// training kernel left in `workspace` (two launches: the products per row chunk, the fixed-order sum of the chunks)
+int read_param_grads_launch_n(const HpmnReadDesc *const *d, int nb, float *d_params, float *workspace, hipStream_t st) {
+    if (nb < 1 || nb > 2) return HPMN_EINVAL;
+    for (int b = 0; b < nb; ++b)
+        if (!d[b] || !read_desc_ok(*d[b]) || d[b]->B != d[0]->B) return d[b] ? HPMN_EUNSUPPORTED : HPMN_EINVAL;
+    const HpmnReadDesc &d0 = *d[0];
+    const Tape t = tape_layout(d0, *d[nb > 1 ? 1 : 0], nb);
+    WgArgs a{};
+    const int items = wg_layers(d0, *d[nb > 1 ? 1 : 0], nb, t, nullptr, &a.nl);
+    a.items = items;
+    a.n_params = d0.n_params;
+    a.slabs = workspace;
+    a.L = reinterpret_cast<const WgLayer *>(workspace + read_slab_floats(d0));
+    a.tape = workspace + read_slab_floats(d0) + WG_TABLE_FLOATS;
+    hipLaunchKernelGGL(read_wgrad_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, a);
+    int rc = check_launch();
+    if (rc != HPMN_OK) return rc;
+    hipLaunchKernelGGL(read_reduce_kernel, dim3((unsigned)((d0.n_params + 31) / 32)), dim3(32 * RRED_G), 0, st,
+                       workspace, WG_NCH, d0.n_params, d_params);
+    return check_launch();
 }
 
 int read_fwd_launch_n(const HpmnReadDesc *const *d, int nb, const float *P, const float *const *memory,
@@ -942,13 +1212,14 @@ int read_fwd_bwd_launch_n(const HpmnReadDesc *const *d, int nb, const float *P, 
     hipError_t e = hipFuncSetAttribute((const void *)read_fwd_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { set_last_hip_error((int)e); return HPMN_EHIP; }
     const unsigned grid = (unsigned)((a.d[0].B + RS - 1) / RS);
+    a.table = reinterpret_cast<WgLayer *>(workspace + read_slab_floats(a.d[0]));
+    a.tape = workspace + read_slab_floats(a.d[0]) + WG_TABLE_FLOATS;
+    a.tp = tape_layout(a.d[0], a.d[nb > 1 ? 1 : 0], nb);
     hipLaunchKernelGGL(read_fwd_bwd_kernel, dim3(grid), dim3(RT), lds, st, a, P, label, mask1, mask2, keep_prob,
-                       inv_global_batch, memory_reg, pred, loss_out, workspace);
+                       inv_global_batch, memory_reg, pred, loss_out);
     rc = check_launch();
-    if (rc != HPMN_OK || d_params == nullptr) return rc;      // (NULL: the caller reduces the slabs itself, read_reduce_launch)
-    hipLaunchKernelGGL(read_reduce_kernel, dim3((unsigned)((a.d[0].n_params + 31) / 32)), dim3(32 * RRED_G), 0, st, workspace,
-                       (int)grid, a.d[0].n_params, d_params);
-    return check_launch();
+    if (rc != HPMN_OK || d_params == nullptr) return rc;      // (NULL: the caller forms them later, read_param_grads_launch_n)
+    return read_param_grads_launch_n(d, nb, d_params, workspace, st);
 }
 
 int read_fwd_launch(const HpmnReadDesc &d, const float *P, const float *memory, const float *last, float *pred,
@@ -966,13 +1237,9 @@ int read_fwd_bwd_launch(const HpmnReadDesc &d, const float *P, const float *memo
                                  pred, loss_out, &d_memory, &d_last, d_params, workspace, st);
 }
 
-// the second half of read_fwd_bwd_launch on its own: d_params += the per-workgroup slabs the kernel left in `workspace`
-int read_reduce_launch(const HpmnReadDesc &d, float *d_params, const float *workspace, hipStream_t st) {
-    if (!read_desc_ok(d)) return HPMN_EUNSUPPORTED;
-    const unsigned grid = (unsigned)((d.B + RS - 1) / RS);
-    hipLaunchKernelGGL(read_reduce_kernel, dim3((unsigned)((d.n_params + 31) / 32)), dim3(32 * RRED_G), 0, st, workspace,
-                       (int)grid, d.n_params, d_params);
-    return check_launch();
+int read_reduce_launch(const HpmnReadDesc &d, float *d_params, float *workspace, hipStream_t st) {
+    const HpmnReadDesc *dp[1] = {&d};
+    return read_param_grads_launch_n(dp, 1, d_params, workspace, st);
 }
 
 }  // namespace hpmn

@@ -1083,11 +1083,18 @@ def scan_backward_layers(spec: ScanSpec, ids, saved, weights: Sequence[torch.Ten
 # read path (covariance regulariser + attention hops + head + loss)
 # ---------------------------------------------------------------------------------------
 _read_ws = {}
+_read_ws_need = {}
 
 
-def _read_workspace(desc, device):
-    """Zero-initialised once, then reused: the kernel only rewrites parameter positions."""
-    need = _lib.load().hpmn_read_workspace_bytes(C.byref(desc)) // 4
+def _read_workspace(descs, device):
+    """Zero-initialised once, then reused: [16 slabs of the parameter range (only parameter positions are ever rewritten) |
+    the tape of the weight-gradient products (rewritten whole by every training launch)]."""
+    descs = list(descs) if isinstance(descs, (list, tuple)) else [descs]
+    desc = descs[0]
+    nkey = (int(desc.B), int(desc.n_params)) + tuple((int(d.K), int(d.H), int(d.D0), int(d.hop)) for d in descs)
+    need = _read_ws_need.get(nkey)
+    if need is None:                # (asked once per shape: the call builds ctypes pointer objects, garbage for the cycle collector)
+        need = _read_ws_need[nkey] = _lib.load().hpmn_read_workspace_bytes_n(len(descs), _desc_array(descs)) // 4
     key = (str(device), int(desc.n_params), torch.cuda.current_stream().cuda_stream)
     ws = _read_ws.get(key)
     if ws is None or ws.numel() < need:
@@ -1200,7 +1207,7 @@ def read_fwd_bwd_n(descs, params, d_params, memories, lasts, label, masks, keep_
     if masks is not None:
         m1, m2 = masks
         _chk_f32(m1, m2)
-    ws = _read_workspace(descs[0], dev)
+    ws = _read_workspace(descs, dev)
     rc = _lib.load().hpmn_read_fwd_bwd_n(len(descs), _desc_array(descs), params.data_ptr(), _ptr_array(memories),
                                           _ptr_array(lasts), label.data_ptr(), _ptr(m1), _ptr(m2), float(keep_prob),
                                           float(inv_global_batch), float(memory_reg), pred.data_ptr(), loss_out.data_ptr(),

@@ -436,9 +436,12 @@ int hpmn_embed_gather_sum(const int32_t *ids, const float *emb, float *out, int3
  *                      mask1 [B,200] / mask2 [B,80]: dropout keep masks (0/1) or NULL; outputs scaled
  *                      by 1/keep_prob.  Writes pred [B], d_memory [B,K,H], d_last [B,D0];
  *                      loss_out[0] += sum_b logloss_b, loss_out[1] += sum_b covreg_b;
- *                      d_params[0..n_params) += gradients (deterministic two-stage reduction through
- *                      `workspace`, >= hpmn_read_workspace_bytes(); zero it ONCE after allocation --
- *                      only parameter positions are ever rewritten).
+ *                      d_params[0..n_params) += gradients.  The training launch does not form them (BPTT
+ *                      waits for d_memory / d_last only): it leaves the operand rows of every weight-gradient
+ *                      product in `workspace` (>= hpmn_read_workspace_bytes[_n](); zero it ONCE after
+ *                      allocation -- only parameter positions of its slab part are ever rewritten), and two
+ *                      more launches form gW = X^T dY over the batch rows in 16 row chunks and add the chunks
+ *                      in a fixed order (deterministic).
  * ---------------------------------------------------------------------------------- */
 typedef struct HpmnReadDesc {
     int32_t B, K, H, D0, hop;
@@ -454,6 +457,7 @@ typedef struct HpmnReadDesc {
 } HpmnReadDesc;
 
 size_t hpmn_read_workspace_bytes(const HpmnReadDesc *desc);
+size_t hpmn_read_workspace_bytes_n(int32_t nb, const HpmnReadDesc *const *desc);      /* (two branches: more rows on the tape) */
 int hpmn_read_fwd(const HpmnReadDesc *desc, const float *params, const float *memory, const float *last,
                   float *pred, float *logit, float *att_w0, float *mem_loss, void *stream);
 int hpmn_read_fwd_bwd(const HpmnReadDesc *desc, const float *params, const float *memory, const float *last,
@@ -473,10 +477,11 @@ int hpmn_read_fwd_bwd_n(int32_t nb, const HpmnReadDesc *const *desc, const float
                         const float *const *last, const int32_t *label, const float *mask1, const float *mask2,
                         float keep_prob, float inv_global_batch, float memory_reg, float *pred, float *loss_out,
                         float *const *d_memory, float *const *d_last, float *d_params, float *workspace, void *stream);
-/* BPTT only waits for d_memory / d_last.  With d_params == NULL hpmn_read_fwd_bwd leaves the parameter gradients as
- * per-workgroup partial sums in `workspace`, and this call (any stream ordered behind it, before `workspace` is used
- * again) adds them to d_params -- the reduction (30 us at the reference batch) then need not sit on the serial chain. */
-int hpmn_read_param_grads(const HpmnReadDesc *desc, float *d_params, const float *workspace, void *stream);
+/* BPTT only waits for d_memory / d_last.  With d_params == NULL hpmn_read_fwd_bwd[_n] stops after the training launch,
+ * and this call (any stream ordered behind it, before `workspace` is used again) forms the weight gradients from the
+ * rows it left in `workspace` and adds them to d_params -- off the serial chain. */
+int hpmn_read_param_grads(const HpmnReadDesc *desc, float *d_params, float *workspace, void *stream);
+int hpmn_read_param_grads_n(int32_t nb, const HpmnReadDesc *const *desc, float *d_params, float *workspace, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Embedding-gradient scatter-add: gradient of hpmn_embed_gather / the gather inside the
