@@ -7,7 +7,7 @@ namespace hpmn { void set_last_hip_error(int) {} }
 using namespace hpmn;
 
 __global__ __launch_bounds__(RT) void k(const float *W, const float *bias, const float *Xg, float *out, unsigned long long *clk,
-                                        int R, int I, int N, int wbf) {
+                                        int R, int I, int N) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int ldx = I + PADF, ldy = N + PADF;
     float *X = sm, *Y = X + 32 * ldx;
