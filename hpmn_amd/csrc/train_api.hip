@@ -490,7 +490,35 @@ int hpmn_scan_bwd(HpmnTrainCtx *ctx, const HpmnScanDesc *d, const int32_t *ids, 
             a.d_last = d->T + d->last_index >= 0 ? d_last : nullptr;
             scatter_fused = true;
         }
-        int rc = hpmn_gru_scan_bwd(&a, stream);
+        // Layer 0's launch in two time halves (HPMN_L0_CUT, with the fused input gradient): the late half's weight gradient
+        // then runs beside the early half's scan instead of waiting for the whole scan -- the weight gradient of layer 0 is
+        // the step's tail (326 us at C3), half of it moves under the chain.
+        static const int l0_cut_env = [] { const char *e = getenv("HPMN_L0_CUT"); return e ? atoi(e) : 0; }();
+        int cut0 = 0;
+        if (i == 0 && l0_cut_env && fused_dx && !scatter_fused && L.T[0] >= 512) {
+            const int p0 = d->periods[0], q = (p0 % 2 == 0) ? p0 : 2 * p0;
+            cut0 = (L.T[0] / 2) / q * q;
+        }
+        int rc;
+        if (cut0 > 0) {
+            a.t_begin = cut0; a.t_end = L.T[0]; a.dh_carry = F(L.xp[0]);      // (xp is free once the forward is done)
+            rc = hpmn_gru_scan_bwd(&a, stream);
+            if (rc != HPMN_OK) return rc;
+            HpmnGruWgrad wa = w;
+            wa.t_begin = cut0; wa.t_len = L.T[0] - cut0; wa.whole_cu = 0;
+            held[nheld++] = wa;
+            HIPCHK(hipEventRecord(c->fork, st));
+            HIPCHK(hipStreamWaitEvent(c->side, c->fork, 0));
+            for (int h = 0; h < nheld; ++h) {
+                rc = hpmn_gru_param_grads(&held[h], c->side);
+                if (rc != HPMN_OK) return rc;
+            }
+            nheld = 0;
+            c->pending = true;
+            a.t_begin = 0; a.t_end = cut0;
+            w.t_begin = 0; w.t_len = cut0;
+        }
+        rc = hpmn_gru_scan_bwd(&a, stream);
         if (rc != HPMN_OK) return rc;
         if (probing) { HIPCHK(hipEventRecord(c->probe1, st)); c->probed = true; }
         // the weight gradient of this layer: an MFMA reduction over d_act, off the serial chain, on the helper stream.

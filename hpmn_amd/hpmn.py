@@ -425,7 +425,7 @@ class Hpmn_Basic(object):
         # (Each hand-over between streams costs a few microseconds of queue processing: only worth it where the
         # gradient buffer is big -- C3: 213 MB -- not for the 0.5 ms steps of the small-table configurations.)
         main = torch.cuda.current_stream()
-        aux = self._aux_stream if self.flat_grad.numel() >= (1 << 24) else main
+        aux = self._aux_stream if self.flat_grad.numel() >= self.AUX_MIN_NUMEL else main
         if aux is not main:
             aux.wait_stream(main)                            # (after the previous step's optimiser, which read it)
         cleared = None
@@ -591,6 +591,7 @@ class Hpmn_Basic(object):
     # ------------------------------------------------------------------ dense table Adam in two passes
     TWO_PASS_TABLE_ADAM = int(os.environ.get("HPMN_TWO_PASS_ADAM", "1")) != 0
     TWO_PASS_MIN_NUMEL = 1 << 24          # below this the dense sweep is a few microseconds: not worth two launches
+    AUX_MIN_NUMEL = int(os.environ.get("HPMN_AUX_MIN_NUMEL", str(1 << 24)))   # smaller gradient buffers: housekeeping stays on the caller's stream
 
     def _two_pass_table_adam(self, ids) -> bool:
         """Single process, user-only graph, no densifying l2 term, a table big enough for the dense sweep to matter."""

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define HPMN_ABI_VERSION 8
+#define HPMN_ABI_VERSION 9
 #define HPMN_MAX_LAYERS 12
 
 enum {
