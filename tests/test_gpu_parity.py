@@ -1119,3 +1119,44 @@ def test_gather_consumed_in_place_equals_the_gathered_rows_summed(dev, mask, F):
     got = ops.embed_gather_sum(ids, emb, mask)
     want = ops.embed_gather(ids.view(B * T, F), emb, mask).view(B, T, F * E).double().sum(1)
     np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=0, atol=2e-4)
+
+
+# ------------------------------------------------------------------------------- read path: weight gradients from the tape
+@pytest.mark.parametrize("industry,H,K", [(False, 32, 3), (True, 64, 4), (True, 64, 12)])
+def test_read_path_weight_gradients_deferred_equal_immediate_and_survive_batch_changes(dev, tmp_path, industry, H, K):
+    """hpmn_read_fwd_bwd with d_params == NULL + hpmn_read_param_grads (the tape -> product launch -> 16-slab sum, what the
+    training step runs on its auxiliary stream) gives bit-identical gradients to the one-call form, and the workspace can be
+    reused across batch sizes (its tape part moves with B, its slab part must not pick up stale bytes)."""
+    from hpmn_amd import ops
+    cfg = cfg_industry(H=H, K=K, T=64 if K == 12 else 41) if industry else cfg_amazon(H=H, K=K, T=50)
+    if K == 12:
+        cfg = O.HpmnConfig(feature_size=500, user_dim=2, user_maxlen=4096 - 23, hidden_size=H, embedding_size=16, hop=3,
+                           user_layers=(2,) * 11 + (1,), user_num_layers=K, industry=True, memory_reg=5e-5)
+    m = make_model(cfg, tmp_path, f32_params(cfg, 5))
+    D0 = cfg.user_dim * cfg.embedding_size
+    g = torch.Generator(device=dev).manual_seed(3)
+    results = {}
+    for B in (7, 3, 7, 16):
+        memory = torch.randn(B, K, H, device=dev, generator=g) * 0.4
+        last = torch.randn(B, D0, device=dev, generator=g) * 0.4
+        label = torch.randint(0, 2, (B,), device=dev, dtype=torch.int32, generator=g)
+        grads = []
+        for defer in (False, True):
+            m._read_grads.zero_()
+            out = ops.read_fwd_bwd(m._read_desc, m._read_params, m._read_grads, memory, last, label, None, 1.0, 1.0 / B,
+                                   cfg.memory_reg, defer_param_grads=defer)
+            if defer:
+                assert float(m._read_grads.abs().max()) == 0.0        # nothing yet: the training launch alone ran
+                out.pop("reduce_param_grads")()
+            torch.cuda.synchronize()
+            grads.append(m._read_grads.clone())
+        assert torch.equal(grads[0], grads[1])
+        assert float(grads[0].abs().max()) > 0.0
+        results.setdefault(B, []).append((memory, last, label, grads[0]))
+    # the same inputs through a FRESH workspace give the same bits (B = 7 ran before and after B = 3)
+    ops._read_ws.clear()
+    memory, last, label, want = results[7][1]
+    m._read_grads.zero_()
+    ops.read_fwd_bwd(m._read_desc, m._read_params, m._read_grads, memory, last, label, None, 1.0, 1.0 / 7, cfg.memory_reg)
+    torch.cuda.synchronize()
+    assert torch.equal(m._read_grads, want)
