@@ -228,6 +228,8 @@ SIGNATURES = {
     "hpmn_train_join": (C.c_int, [C.c_void_p, C.c_void_p]),
     "hpmn_train_probe": (C.c_int, [C.c_void_p, C.c_int32]),
     "hpmn_train_probe_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "hpmn_train_mark_layer0_reverse": (C.c_int, [C.c_void_p, C.c_int32]),
+    "hpmn_train_wait_layer0_reverse": (C.c_int, [C.c_void_p, C.c_void_p]),
     "hpmn_pipe_supported": (C.c_int, [C.c_int32, C.c_int32]),
     "hpmn_pipe_sync_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "hpmn_pipe_fwd": (C.c_int, [C.POINTER(HpmnPipe), C.c_void_p]),

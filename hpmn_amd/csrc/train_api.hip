@@ -33,6 +33,8 @@ struct TrainCtx {
     hipEvent_t fork = nullptr, join = nullptr, scat = nullptr;
     hipEvent_t probe0 = nullptr, probe1 = nullptr;      // (timing events around layer 0's reverse-scan launch, on request)
     bool pending = false, probe = false, probed = false;
+    hipEvent_t l0_start = nullptr;                       // (recorded in front of layer 0's reverse launch, on request)
+    bool mark_l0 = false, l0_marked = false;
 };
 
 static size_t up256(size_t x) { return (x + 255) / 256 * 256; }
@@ -122,6 +124,7 @@ void hpmn_train_ctx_destroy(HpmnTrainCtx *ctx) {
     TrainCtx *c = reinterpret_cast<TrainCtx *>(ctx);
     if (!c) return;
     if (c->side) (void)hipStreamSynchronize(c->side);
+    if (c->l0_start) (void)hipEventDestroy(c->l0_start);
     if (c->probe0) (void)hipEventDestroy(c->probe0);
     if (c->probe1) (void)hipEventDestroy(c->probe1);
     if (c->fork) (void)hipEventDestroy(c->fork);
@@ -478,6 +481,10 @@ int hpmn_scan_bwd(HpmnTrainCtx *ctx, const HpmnScanDesc *d, const int32_t *ids, 
             if (rc != HPMN_OK) return rc;
             continue;
         }
+        if (i == 0 && c->mark_l0 && c->l0_start != nullptr) {
+            HIPCHK(hipEventRecord(c->l0_start, st));
+            c->l0_marked = true;
+        }
         const bool probing = i == 0 && c->probe && c->probe0 != nullptr;
         if (probing) HIPCHK(hipEventRecord(c->probe0, st));
         const bool fused_dx = gru_scan_bwd_fuses_dx(d->H, d->B) && gru_scan_bwd_dx_width_ok(D);
@@ -585,6 +592,24 @@ int hpmn_train_probe(HpmnTrainCtx *ctx, int32_t enable) {
     }
     c->probe = enable != 0;
     c->probed = false;
+    return HPMN_OK;
+}
+
+int hpmn_train_mark_layer0_reverse(HpmnTrainCtx *ctx, int32_t enable) {
+    TrainCtx *c = reinterpret_cast<TrainCtx *>(ctx);
+    if (!c) return HPMN_EINVAL;
+    if (enable && c->l0_start == nullptr) HIPCHK(hipEventCreateWithFlags(&c->l0_start, hipEventDisableTiming));
+    c->mark_l0 = enable != 0;
+    c->l0_marked = false;
+    return HPMN_OK;
+}
+
+int hpmn_train_wait_layer0_reverse(HpmnTrainCtx *ctx, void *stream) {
+    TrainCtx *c = reinterpret_cast<TrainCtx *>(ctx);
+    if (!c) return HPMN_EINVAL;
+    if (!c->l0_marked) return HPMN_OK;                   // (a path without a separate layer-0 launch: nothing to wait for)
+    HIPCHK(hipStreamWaitEvent((hipStream_t)stream, c->l0_start, 0));
+    c->l0_marked = false;
     return HPMN_OK;
 }
 

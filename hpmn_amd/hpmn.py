@@ -441,7 +441,9 @@ class Hpmn_Basic(object):
                 # front of the late pass (the wait at the end of this function) -- at C2 it outlasts the forward by 150 us
                 cleared = torch.cuda.Event()
                 cleared.record(aux)
-                rest()
+                if not (self.EARLY_PASS_BESIDE_L0_REVERSE and aux is not main):
+                    rest()
+                    rest = None
         self._table_grad_clean = False                       # (until something consumes or clears the table gradient)
         emb = self.params["Embedding/emb_mtx"]
         weights = self._gru_weights()
@@ -485,9 +487,17 @@ class Hpmn_Basic(object):
         else:
             d_emb, scatter_ids = self.grads["Embedding/emb_mtx"], ids
         grad_out = [d_emb] + [self.grads[n] for names in self._gru_names for n in names]
+        if callable(rest):
+            ops.train_mark_layer0_reverse(self.device, True)
         pending = ops.scan_backward(self.spec, scatter_ids, saved, weights, out["d_memory"], out["d_last"], grad_out,
                                     defer_join=defer_join and not self.l2_reg)
         out["pending"] = pending
+        if callable(rest):
+            # HPMN_EARLY_PASS=bwd: the early table-Adam pass beside layer 0's REVERSE launch instead of beside its forward
+            # (which can then be one of the two-layer launches, HPMN_PAIR_FWD=1)
+            ops.train_wait_layer0_reverse(self.device, aux)
+            with torch.cuda.stream(aux):
+                rest()
         if aux is not main:
             main.wait_stream(aux)                            # the loss scalars belong to the caller's stream again
         if self.l2_reg:
@@ -591,6 +601,7 @@ class Hpmn_Basic(object):
     # ------------------------------------------------------------------ dense table Adam in two passes
     TWO_PASS_TABLE_ADAM = int(os.environ.get("HPMN_TWO_PASS_ADAM", "1")) != 0
     TWO_PASS_MIN_NUMEL = 1 << 24          # below this the dense sweep is a few microseconds: not worth two launches
+    EARLY_PASS_BESIDE_L0_REVERSE = os.environ.get("HPMN_EARLY_PASS", "fwd") == "bwd"
     AUX_MIN_NUMEL = int(os.environ.get("HPMN_AUX_MIN_NUMEL", str(1 << 24)))   # smaller gradient buffers: housekeeping stays on the caller's stream
 
     def _two_pass_table_adam(self, ids) -> bool:

@@ -739,6 +739,17 @@ def train_probe(device, enable: bool) -> None:
     _lib.check(_lib.load().hpmn_train_probe(_ctx(device), int(enable)), "hpmn_train_probe")
 
 
+def train_mark_layer0_reverse(device, enable: bool) -> None:
+    """hpmn_train_mark_layer0_reverse: record an event in front of layer 0's reverse-scan launch of the following steps."""
+    _lib.check(_lib.load().hpmn_train_mark_layer0_reverse(_ctx(device), int(enable)), "hpmn_train_mark_layer0_reverse")
+
+
+def train_wait_layer0_reverse(device, stream) -> None:
+    """hpmn_train_wait_layer0_reverse: ``stream`` waits for the start of layer 0's reverse-scan launch of the last
+    hpmn_scan_bwd (no-op where that step had none)."""
+    _lib.check(_lib.load().hpmn_train_wait_layer0_reverse(_ctx(device), stream.cuda_stream), "hpmn_train_wait_layer0_reverse")
+
+
 def train_probe_ms(device) -> float:
     ms = C.c_float()
     _lib.check(_lib.load().hpmn_train_probe_ms(_ctx(device), C.byref(ms)), "hpmn_train_probe_ms")

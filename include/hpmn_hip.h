@@ -366,6 +366,13 @@ int hpmn_train_join(HpmnTrainCtx *ctx, void *stream);
  * is the launch INSIDE a real step, weight-gradient kernels live beside it -- what bench.py's roofline entry quotes. */
 int hpmn_train_probe(HpmnTrainCtx *ctx, int32_t enable);
 int hpmn_train_probe_ms(HpmnTrainCtx *ctx, float *ms);
+/* Scheduling hook: layer 0's reverse-scan launch is the longest of the step and, unlike the two-layer launches in front of
+ * it, leaves room on its CUs -- work that only has to be done by the end of the step (the caller's early table-Adam pass)
+ * belongs beside it.  With the mark enabled hpmn_scan_bwd records an event on `stream` in front of that launch;
+ * hpmn_train_wait_layer0_reverse (after hpmn_scan_bwd returned) makes another stream wait for it.  No-op where the step has
+ * no separate layer-0 launch (H = 32). */
+int hpmn_train_mark_layer0_reverse(HpmnTrainCtx *ctx, int32_t enable);
+int hpmn_train_wait_layer0_reverse(HpmnTrainCtx *ctx, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * build_memory with ALL K layers in ONE launch (H = 64): forward hpmn_pipe_fwd, BPTT hpmn_pipe_bwd.
