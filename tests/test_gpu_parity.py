@@ -216,6 +216,10 @@ GRAD_CASES = [
     ("xlong_c4_h128", cfg_industry(H=128, K=7, T=1001, V=2000), 2),
     ("taobao_c2_shape", O.HpmnConfig(600, 4, 300, 64, 16, 3, (2, 2, 3, 5, 5, 1), 5, False, 1e-5), 4),
     ("amazon_c1_b128", cfg_amazon(K=4, V=3000), 128),
+    # the hop count (reference CLI: 3 everywhere) shapes the read path's tape and the row count of the shared Hmap product
+    ("industry_hop1", O.HpmnConfig(150, 2, 41, 64, 16, 1, (2,) * 10 + (1,), 4, True, 5e-5), 5),
+    ("amazon_hop2", O.HpmnConfig(120, 3, 40, 32, 16, 2, (2, 2, 5, 5, 1), 3, False, 1e-5), 7),
+    ("industry_hop4", O.HpmnConfig(150, 2, 41, 64, 16, 4, (2,) * 10 + (1,), 3, True, 5e-5), 3),
 ]
 
 
