@@ -348,6 +348,7 @@ int hpmn_scan_bwd(HpmnTrainCtx *ctx, const HpmnScanDesc *d, const int32_t *ids, 
         return HPMN_OK;
     }
     bool scatter_pending = false, scatter_fused = false;
+    int scat_cut = cut;                                  // first scan step whose scatter is already under way
     HpmnGruWgrad held[4], late[HPMN_MAX_LAYERS];
     int nheld = 0, nlate = 0;
     auto scan_args = [&](int i) {
@@ -516,6 +517,15 @@ int hpmn_scan_bwd(HpmnTrainCtx *ctx, const HpmnScanDesc *d, const int32_t *ids, 
             held[nheld++] = wa;
             HIPCHK(hipEventRecord(c->fork, st));
             HIPCHK(hipStreamWaitEvent(c->side, c->fork, 0));
+            if (l0_cut_env >= 2 && cut0 > d->front_zero && d->T + d->last_index >= cut0 - d->front_zero) {
+                // ... and the late half's scatter (with the read path's d_last row, which lies in it): the step's other tail
+                rc = embed_grad_scatter_launch(ids, F(L.d_x[0]), d_emb, d->B, d->T, d->F, d->E, d->front_zero, d->mask_id0,
+                                               cut0 - d->front_zero, d->T, c->side, d_last, d->T + d->last_index);
+                if (rc != HPMN_OK) return rc;
+                HIPCHK(hipEventRecord(c->scat, c->side));
+                scatter_pending = true;
+                scat_cut = cut0;
+            }
             for (int h = 0; h < nheld; ++h) {
                 rc = hpmn_gru_param_grads(&held[h], c->side);
                 if (rc != HPMN_OK) return rc;
@@ -575,7 +585,7 @@ int hpmn_scan_bwd(HpmnTrainCtx *ctx, const HpmnScanDesc *d, const int32_t *ids, 
         if (rc != HPMN_OK) return rc;
     }
     int rc = embed_grad_scatter_launch(ids, F(L.d_x[0]), d_emb, d->B, d->T, d->F, d->E, d->front_zero, d->mask_id0, 0,
-                                       scatter_pending ? cut - d->front_zero : d->T, st,
+                                       scatter_pending ? scat_cut - d->front_zero : d->T, st,
                                        last_in_scatter ? d_last : nullptr, d->T + d->last_index);
     if (rc != HPMN_OK) return rc;
     if (scatter_pending) HIPCHK(hipStreamWaitEvent(st, c->scat, 0));   // the caller's table update needs both halves
