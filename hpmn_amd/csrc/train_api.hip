@@ -29,8 +29,9 @@ int embed_grad_scatter_launch(const int32_t *ids, const float *d_x, float *d_emb
 
 struct TrainCtx {
     int device = -1, cus = 256;
-    hipStream_t side = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr, scat = nullptr;
+    hipStream_t side = nullptr, side2 = nullptr;         // (side2: the second of two small weight-gradient launches at the end)
+    hipEvent_t fork = nullptr, join = nullptr, join2 = nullptr, scat = nullptr;
+    bool pending2 = false;
     hipEvent_t probe0 = nullptr, probe1 = nullptr;      // (timing events around layer 0's reverse-scan launch, on request)
     bool pending = false, probe = false, probed = false;
     hipEvent_t l0_start = nullptr;                       // (recorded in front of layer 0's reverse launch, on request)
@@ -73,6 +74,10 @@ static bool layout(const HpmnScanDesc &d, HpmnTrainLayout &L) {
     }
     L.wgrad_ws = off;
     off += up256(wmax);
+    if (d.H != 32) {                               // a second slab buffer: two small weight-gradient launches side by side
+        L.wgrad_ws_layer[1] = off;
+        off += up256(wmax);
+    }
     if (d.H == 32 && d.K <= AMAXK) {               // H = 32 (gru32_wgrad.hip): the slabs of all layers, one launch
         int Ds[HPMN_MAX_LAYERS];
         for (int i = 0; i < d.K; ++i) Ds[i] = (int)(i == 0 ? D0 : H);
@@ -108,6 +113,8 @@ int hpmn_train_ctx_create(HpmnTrainCtx **out) {
     int n = 0;
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && n > 0) c->cus = n;
     if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->join2, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->join, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->scat, hipEventDisableTiming) != hipSuccess) {
@@ -124,6 +131,9 @@ void hpmn_train_ctx_destroy(HpmnTrainCtx *ctx) {
     TrainCtx *c = reinterpret_cast<TrainCtx *>(ctx);
     if (!c) return;
     if (c->side) (void)hipStreamSynchronize(c->side);
+    if (c->side2) (void)hipStreamSynchronize(c->side2);
+    if (c->join2) (void)hipEventDestroy(c->join2);
+    if (c->side2) (void)hipStreamDestroy(c->side2);
     if (c->l0_start) (void)hipEventDestroy(c->l0_start);
     if (c->probe0) (void)hipEventDestroy(c->probe0);
     if (c->probe1) (void)hipEventDestroy(c->probe1);
@@ -409,11 +419,19 @@ int hpmn_scan_bwd(HpmnTrainCtx *ctx, const HpmnScanDesc *d, const int32_t *ids, 
                     if (rc0 != HPMN_OK) return rc0;
                 }
                 nlate = 0;
+                // (the pair's two weight gradients side by side: each is a few dozen workgroups; the lower layer's on a
+                //  second stream with its own slab buffer)
+                static const int two_env = [] { const char *e = getenv("HPMN_WGRAD_TWO_STREAMS"); return e ? atoi(e) : 1; }();
+                const bool two = two_env && L.wgrad_ws_layer[1] != 0;
+                if (two) HIPCHK(hipStreamWaitEvent(c->side2, c->fork, 0));
                 for (int l = i; l >= i - 1; --l) {
                     HpmnGruWgrad w = wgrad_args(l);
                     w.whole_cu = 0;
-                    const int rc0 = hpmn_gru_param_grads(&w, c->side);
+                    const bool second = two && l == i - 1;
+                    if (second) w.workspace = F(L.wgrad_ws_layer[1]);
+                    const int rc0 = hpmn_gru_param_grads(&w, second ? c->side2 : c->side);
                     if (rc0 != HPMN_OK) return rc0;
+                    if (second) c->pending2 = true;
                 }
                 c->pending = true;
             } else {
@@ -563,10 +581,18 @@ int hpmn_scan_bwd(HpmnTrainCtx *ctx, const HpmnScanDesc *d, const int32_t *ids, 
         // the pairs' weight gradients: nothing latency-critical is left on the chip, the largest (the last pair's) first
         HIPCHK(hipEventRecord(c->fork, st));
         HIPCHK(hipStreamWaitEvent(c->side, c->fork, 0));
+        // (batches that fill half of the CUs or less: the launches are small, every other one goes to a second stream with
+        //  its own slab buffer -- C2: 30 + 63 us one after the other at the end of the step)
+        static const int two_env = [] { const char *e = getenv("HPMN_WGRAD_TWO_STREAMS"); return e ? atoi(e) : 1; }();
+        const bool two = two_env && nlate >= 2 && d->H != 32 && L.wgrad_ws_layer[1] != 0 && 2 * d->B <= c->cus;
+        if (two) HIPCHK(hipStreamWaitEvent(c->side2, c->fork, 0));
         for (int h = nlate - 1; h >= 0; --h) {
             late[h].whole_cu = d->H <= 64 ? 1 : 0;
-            const int rc0 = hpmn_gru_param_grads(&late[h], c->side);
+            const bool second = two && ((nlate - 1 - h) & 1);
+            if (second) late[h].workspace = F(L.wgrad_ws_layer[1]);
+            const int rc0 = hpmn_gru_param_grads(&late[h], second ? c->side2 : c->side);
             if (rc0 != HPMN_OK) return rc0;
+            if (second) c->pending2 = true;
         }
         nlate = 0;
         c->pending = true;
@@ -634,6 +660,11 @@ int hpmn_train_probe_ms(HpmnTrainCtx *ctx, float *ms) {
 int hpmn_train_join(HpmnTrainCtx *ctx, void *stream) {
     TrainCtx *c = reinterpret_cast<TrainCtx *>(ctx);
     if (!c) return HPMN_EINVAL;
+    if (c->pending2) {
+        HIPCHK(hipEventRecord(c->join2, c->side2));
+        HIPCHK(hipStreamWaitEvent((hipStream_t)stream, c->join2, 0));
+        c->pending2 = false;
+    }
     if (!c->pending) return HPMN_OK;
     HIPCHK(hipEventRecord(c->join, c->side));
     HIPCHK(hipStreamWaitEvent((hipStream_t)stream, c->join, 0));

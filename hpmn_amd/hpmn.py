@@ -429,6 +429,7 @@ class Hpmn_Basic(object):
         if aux is not main:
             aux.wait_stream(main)                            # (after the previous step's optimiser, which read it)
         cleared = None
+        rest2 = None
         with torch.cuda.stream(aux):
             rest = None
             if _clear_grads is not None:
@@ -441,13 +442,19 @@ class Hpmn_Basic(object):
                 # front of the late pass (the wait at the end of this function) -- at C2 it outlasts the forward by 150 us
                 cleared = torch.cuda.Event()
                 cleared.record(aux)
+                rest2 = None
                 if not (self.EARLY_PASS_BESIDE_L0_REVERSE and aux is not main):
-                    rest()
+                    rest2 = rest()
                     rest = None
         self._table_grad_clean = False                       # (until something consumes or clears the table gradient)
         emb = self.params["Embedding/emb_mtx"]
         weights = self._gru_weights()
+        probe = self._split_probe if isinstance(self._split_probe, dict) and self._split_probe.get("armed") else None
+        if probe is not None:
+            probe["f0"].record()
         memory, last, saved = ops.scan_forward_train(self.spec, ids, emb, weights)
+        if probe is not None:
+            probe["f1"].record()
         if aux is not main:
             if cleared is not None:
                 main.wait_event(cleared)
@@ -472,6 +479,8 @@ class Hpmn_Basic(object):
             if aux is not main:
                 sums.record_stream(main)
                 ce.record_stream(main)
+            if callable(rest2):
+                rest2()                                      # (second part of the early table-Adam pass: beside BPTT)
         if self.lazy_table_adam:
             # touched rows only: the scatter goes to a COMPACT [U, E] buffer through ids remapped to 0..U-1 (row 0 of
             # it stays original id 0, so the id-0 mask of the Hpmn graph keeps working on the remapped ids)
@@ -602,7 +611,34 @@ class Hpmn_Basic(object):
     TWO_PASS_TABLE_ADAM = int(os.environ.get("HPMN_TWO_PASS_ADAM", "1")) != 0
     TWO_PASS_MIN_NUMEL = 1 << 24          # below this the dense sweep is a few microseconds: not worth two launches
     EARLY_PASS_BESIDE_L0_REVERSE = os.environ.get("HPMN_EARLY_PASS", "fwd") == "bwd"
+    # fraction of the table rows whose early pass runs beside the forward (the rest: beside BPTT); "auto": measured once, on the
+    # fourth step, from the durations of the forward and of the pass (HIP events) -- 1.0 unless the pass outlasts the forward
+    EARLY_PASS_SPLIT = 1.0 if os.environ.get("HPMN_EARLY_SPLIT", "auto") == "auto" else float(os.environ["HPMN_EARLY_SPLIT"])
+    EARLY_PASS_SPLIT_AUTO = os.environ.get("HPMN_EARLY_SPLIT", "auto") == "auto"
     AUX_MIN_NUMEL = int(os.environ.get("HPMN_AUX_MIN_NUMEL", str(1 << 24)))   # smaller gradient buffers: housekeeping stays on the caller's stream
+
+    _split_probe = None
+    _split_steps = 0
+
+    def _tune_early_split(self):
+        """EARLY_PASS_SPLIT = "auto": time the forward and the early pass of the fourth two-pass step with events, read them
+        two steps later (one host wait, once) and keep what fits beside the forward."""
+        if not self.EARLY_PASS_SPLIT_AUTO or self._split_probe == "done":
+            return
+        self._split_steps += 1
+        if self._split_steps == 4:
+            ev = lambda: torch.cuda.Event(enable_timing=True)
+            self._split_probe = dict(armed=True, f0=ev(), f1=ev(), a0=ev(), a1=ev())
+        elif self._split_steps == 5 and isinstance(self._split_probe, dict):
+            self._split_probe["armed"] = False
+        elif self._split_steps == 6 and isinstance(self._split_probe, dict):
+            p = self._split_probe
+            p["f1"].synchronize()
+            p["a1"].synchronize()
+            t_fwd, t_pass = p["f0"].elapsed_time(p["f1"]), p["a0"].elapsed_time(p["a1"])
+            if t_pass > 1.05 * t_fwd > 0:
+                self.EARLY_PASS_SPLIT = max(0.25, min(1.0, 0.85 * t_fwd / t_pass))
+            self._split_probe = "done"
 
     def _two_pass_table_adam(self, ids) -> bool:
         """Single process, user-only graph, no densifying l2 term, a table big enough for the dense sweep to matter."""
@@ -636,9 +672,25 @@ class Hpmn_Basic(object):
 
             def rest():                                       # (nothing of the forward or the read path waits for this)
                 ops.table_mark_rows(ids, flags)
-                ops.adam_step_table(*views, flags, 0, lr_t, self.beta1, self.beta2, self.adam_eps, clip=1.0)
+                v1 = V if self.EARLY_PASS_SPLIT >= 1.0 else max(1, min(V, int(V * self.EARLY_PASS_SPLIT)))
+                probe = self._split_probe if isinstance(self._split_probe, dict) and self._split_probe.get("armed") else None
+                if probe is not None:
+                    probe["a0"].record()
+                ops.adam_step_table(*[x[:v1] for x in views], flags[:v1], 0, lr_t, self.beta1, self.beta2, self.adam_eps,
+                                    clip=1.0)
+                if probe is not None:
+                    probe["a1"].record()
+                if v1 >= V:
+                    return None
+
+                def rest2():    # the other rows: behind the read launch (a pass longer than the forward runs into it: the
+                    #             stream of 28 B per table element pushes the read path's weights out of the L2 it lives on)
+                    ops.adam_step_table(*[x[v1:] for x in views], flags[v1:], 0, lr_t, self.beta1, self.beta2,
+                                        self.adam_eps, clip=1.0)
+                return rest2
             return rest
 
+        self._tune_early_split()
         out, ce = self.compute_gradients(ids, label, keep_prob, masks, global_batch, defer_join=True, _clear_grads=early)
         pending = out.pop("pending", None)
         self.adam_t = t
