@@ -194,6 +194,8 @@ SIGNATURES = {
                                       C.c_void_p, C.c_void_p]),
     "hpmn_read_param_grads": (C.c_int, [C.POINTER(HpmnReadDesc), C.c_void_p, C.c_void_p, C.c_void_p]),
     "hpmn_read_param_grads_n": (C.c_int, [C.c_int32, C.POINTER(C.POINTER(HpmnReadDesc)), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hpmn_read_param_grads_loss_n": (C.c_int, [C.c_int32, C.POINTER(C.POINTER(HpmnReadDesc)), C.c_void_p, C.c_void_p,
+                                              C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     "hpmn_embed_grad_scatter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                           C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_void_p]),
     "hpmn_gru_fused_fwd_supported": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),

@@ -34,7 +34,8 @@ int gru_dx_dispatch(const HpmnGruWgrad &a, hipStream_t st);
 size_t gru_wgrad_workspace_bytes(int B, int T, int D, int H);
 size_t read_workspace_bytes(const HpmnReadDesc &d);
 size_t read_workspace_bytes_n(const HpmnReadDesc *const *d, int nb);
-int read_param_grads_launch_n(const HpmnReadDesc *const *d, int nb, float *d_params, float *workspace, hipStream_t st);
+int read_param_grads_launch_n(const HpmnReadDesc *const *d, int nb, float *d_params, float *workspace, hipStream_t st,
+                              float *loss_acc, float inv_global_batch, float memory_reg, float *loss3);
 int read_fwd_launch(const HpmnReadDesc &d, const float *P, const float *memory, const float *last, float *pred,
                     float *logit, float *att_w0, float *mem_loss, hipStream_t st);
 int read_fwd_bwd_launch(const HpmnReadDesc &d, const float *P, const float *memory, const float *last,
@@ -446,7 +447,19 @@ int hpmn_read_param_grads_n(int32_t nb, const HpmnReadDesc *const *desc, float *
     if (desc[0]->B < 0) return HPMN_EINVAL;
     if (desc[0]->B == 0) return HPMN_OK;
     if (!d_params || !workspace) return HPMN_EINVAL;
-    return read_param_grads_launch_n(desc, nb, d_params, workspace, (hipStream_t)stream);
+    return read_param_grads_launch_n(desc, nb, d_params, workspace, (hipStream_t)stream, nullptr, 0.f, 0.f, nullptr);
+}
+
+int hpmn_read_param_grads_loss_n(int32_t nb, const HpmnReadDesc *const *desc, float *d_params, float *workspace,
+                                 float *loss_acc, float inv_global_batch, float memory_reg, float *loss3, void *stream) {
+    drop_stale_hip_error();
+    if (nb < 1 || nb > 2 || !desc || !desc[0] || (nb > 1 && !desc[1])) return HPMN_EINVAL;
+    if (desc[0]->B < 0) return HPMN_EINVAL;
+    if (!loss_acc || !loss3) return HPMN_EINVAL;
+    if (desc[0]->B == 0) return HPMN_OK;
+    if (!d_params || !workspace) return HPMN_EINVAL;
+    return read_param_grads_launch_n(desc, nb, d_params, workspace, (hipStream_t)stream, loss_acc, inv_global_batch,
+                                     memory_reg, loss3);
 }
 
 int hpmn_embed_grad_scatter(const int32_t *ids, const float *d_x, float *d_emb, int32_t B, int32_t T,

@@ -1102,10 +1102,20 @@ __global__ __launch_bounds__(256) void read_wgrad_kernel(const WgArgs a) {
 // in a fixed order (deterministic) -- same scheme as wgrad_reduce_kernel: one thread walking 250 slabs per
 // element was latency-bound.
 constexpr int RRED_G = 8;
+// Optionally (loss_acc != nullptr) the step's loss scalars ride along: loss3 = {sum of log-losses, sum of covariance losses,
+// cross_entropy = inv_global_batch * the first + memory_reg * the second}, and the two accumulators the training launch added
+// into are cleared for the next step -- four framework launches of a few bytes each otherwise (23 us of a 0.34 ms C1 step).
 __global__ __launch_bounds__(32 * RRED_G) void read_reduce_kernel(const float *__restrict__ slabs, int ntile, int n,
-                                                                  float *grad) {
+                                                                  float *grad, float *loss_acc, float inv_global_batch,
+                                                                  float memory_reg, float *loss3) {
     __shared__ float part[RRED_G][32];
     const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
+    if (loss_acc != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
+        const float ll = loss_acc[0], ml = loss_acc[1];
+        loss3[0] = ll; loss3[1] = ml;
+        loss3[2] = ll * inv_global_batch + memory_reg * ml;
+        loss_acc[0] = 0.f; loss_acc[1] = 0.f;
+    }
     const int e = blockIdx.x * 32 + c;
     const int ec = e < n ? e : n - 1;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -1164,7 +1174,8 @@ static int read_args(ReadArgs &a, const HpmnReadDesc *const *d, int nb, const fl
 
 // the second half of the training call on its own: d_params += the read-path weight gradients, formed from the tape the
 // training kernel left in `workspace` (two launches: the products per row chunk, the fixed-order sum of the chunks)
-int read_param_grads_launch_n(const HpmnReadDesc *const *d, int nb, float *d_params, float *workspace, hipStream_t st) {
+int read_param_grads_launch_n(const HpmnReadDesc *const *d, int nb, float *d_params, float *workspace, hipStream_t st,
+                              float *loss_acc, float inv_global_batch, float memory_reg, float *loss3) {
     if (nb < 1 || nb > 2) return HPMN_EINVAL;
     for (int b = 0; b < nb; ++b)
         if (!d[b] || !read_desc_ok(*d[b]) || d[b]->B != d[0]->B) return d[b] ? HPMN_EUNSUPPORTED : HPMN_EINVAL;
@@ -1181,7 +1192,7 @@ int read_param_grads_launch_n(const HpmnReadDesc *const *d, int nb, float *d_par
     int rc = check_launch();
     if (rc != HPMN_OK) return rc;
     hipLaunchKernelGGL(read_reduce_kernel, dim3((unsigned)((d0.n_params + 31) / 32)), dim3(32 * RRED_G), 0, st,
-                       workspace, WG_NCH, d0.n_params, d_params);
+                       workspace, WG_NCH, d0.n_params, d_params, loss_acc, inv_global_batch, memory_reg, loss3);
     return check_launch();
 }
 
@@ -1219,7 +1230,7 @@ int read_fwd_bwd_launch_n(const HpmnReadDesc *const *d, int nb, const float *P, 
                        inv_global_batch, memory_reg, pred, loss_out);
     rc = check_launch();
     if (rc != HPMN_OK || d_params == nullptr) return rc;      // (NULL: the caller forms them later, read_param_grads_launch_n)
-    return read_param_grads_launch_n(d, nb, d_params, workspace, st);
+    return read_param_grads_launch_n(d, nb, d_params, workspace, st, nullptr, 0.f, 0.f, nullptr);
 }
 
 int read_fwd_launch(const HpmnReadDesc &d, const float *P, const float *memory, const float *last, float *pred,
@@ -1239,7 +1250,7 @@ int read_fwd_bwd_launch(const HpmnReadDesc &d, const float *P, const float *memo
 
 int read_reduce_launch(const HpmnReadDesc &d, float *d_params, float *workspace, hipStream_t st) {
     const HpmnReadDesc *dp[1] = {&d};
-    return read_param_grads_launch_n(dp, 1, d_params, workspace, st);
+    return read_param_grads_launch_n(dp, 1, d_params, workspace, st, nullptr, 0.f, 0.f, nullptr);
 }
 
 }  // namespace hpmn

@@ -251,6 +251,7 @@ class Hpmn_Basic(object):
         self._goff = offs[shapes[1][0]] if self.lazy_table_adam else 0
         self.flat_grad = torch.zeros(n - self._goff, device=dev, dtype=torch.float32)
         self._loss_acc = torch.zeros(2, device=dev, dtype=torch.float32)      # log-loss sum, memory-loss sum of a step
+        self._loss_acc_clean = True
         # two-pass dense table Adam (train_step): rows the batch points at / whether the table gradient is all-zero
         self._row_flags: Optional[torch.Tensor] = None
         self._table_grad_clean = True
@@ -436,7 +437,8 @@ class Hpmn_Basic(object):
                 rest = _clear_grads()                        # train_step's two-pass table update (see there)
             else:
                 self.flat_grad.zero_()
-            self._loss_acc.zero_()
+            if not self._loss_acc_clean:
+                self._loss_acc.zero_()                       # (normally the previous step's reduce launch has cleared it)
             if callable(rest):
                 # what the read kernel waits for is the CLEARING; the early table-Adam pass behind it is only needed in
                 # front of the late pass (the wait at the end of this function) -- at C2 it outlasts the forward by 150 us
@@ -467,18 +469,19 @@ class Hpmn_Basic(object):
             seed = _splitmix64(_splitmix64(self._dropout_base + self._dropout_step) ^ (self.rank + 1)) | 1
         out = ops.read_fwd_bwd(self._read_desc, self._read_params, self._read_grads, memory, last, label, masks,
                                keep_prob, 1.0 / float(global_batch), self.memory_reg, dropout_seed=seed,
-                               loss_out=self._loss_acc, defer_param_grads=aux is not main)
+                               loss_out=self._loss_acc, defer_param_grads=True)
+        self._loss_acc_clean = False
         if aux is not main:
             aux.wait_stream(main)
         with torch.cuda.stream(aux):
-            if aux is not main:
-                out.pop("reduce_param_grads")()              # (only the optimiser needs them: off the serial chain too)
-            sums = self._loss_acc.clone()                    # (the accumulator is cleared again next step)
-            out["log_loss_sum"], out["memory_loss"] = sums[0], sums[1]
-            ce = sums[0] / float(global_batch) + self.memory_reg * sums[1]
+            # the read path's weight gradients (only the optimiser needs them: off the serial chain where there is an
+            # auxiliary stream) and, from the same two launches, the loss scalars + the cleared accumulator
+            sums = (torch.empty if ids.shape[0] > 0 else torch.zeros)(3, device=self.device, dtype=torch.float32)
+            out.pop("reduce_param_grads")(sums)
+            self._loss_acc_clean = True
+            out["log_loss_sum"], out["memory_loss"], ce = sums[0], sums[1], sums[2]
             if aux is not main:
                 sums.record_stream(main)
-                ce.record_stream(main)
             if callable(rest2):
                 rest2()                                      # (second part of the early table-Adam pass: beside BPTT)
         if self.lazy_table_adam:

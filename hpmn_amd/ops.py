@@ -1161,9 +1161,17 @@ def read_fwd_bwd(desc, params, d_params, memory, last, label, masks, keep_prob, 
     _lib.check(rc, "hpmn_read_fwd_bwd")
     out = dict(prediction=pred, log_loss_sum=loss_out[0], memory_loss=loss_out[1], d_memory=d_memory, d_last=d_last)
     if defer_param_grads:
-        def reduce_param_grads():
-            _lib.check(_lib.load().hpmn_read_param_grads(C.byref(desc), d_params.data_ptr(), ws.data_ptr(), _stream()),
-                       "hpmn_read_param_grads")
+        def reduce_param_grads(loss3: Optional[torch.Tensor] = None):
+            """adds the read path's weight gradients to d_params (current stream); with ``loss3`` (a [3] buffer) the same
+            launches also leave {log-loss sum, memory-loss sum, cross_entropy} there and clear ``loss_out``."""
+            if loss3 is None:
+                _lib.check(_lib.load().hpmn_read_param_grads(C.byref(desc), d_params.data_ptr(), ws.data_ptr(), _stream()),
+                           "hpmn_read_param_grads")
+            else:
+                _lib.check(_lib.load().hpmn_read_param_grads_loss_n(1, _desc_array([desc]), d_params.data_ptr(), ws.data_ptr(),
+                                                                     loss_out.data_ptr(), float(inv_global_batch),
+                                                                     float(memory_reg), loss3.data_ptr(), _stream()),
+                           "hpmn_read_param_grads_loss_n")
         out["reduce_param_grads"] = reduce_param_grads
     return out
 

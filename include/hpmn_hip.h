@@ -489,6 +489,12 @@ int hpmn_read_fwd_bwd_n(int32_t nb, const HpmnReadDesc *const *desc, const float
  * rows it left in `workspace` and adds them to d_params -- off the serial chain. */
 int hpmn_read_param_grads(const HpmnReadDesc *desc, float *d_params, float *workspace, void *stream);
 int hpmn_read_param_grads_n(int32_t nb, const HpmnReadDesc *const *desc, float *d_params, float *workspace, void *stream);
+/* The same, and the step's loss scalars with it (they need every workgroup of the training launch, like the gradients do):
+ * loss3 = {loss_acc[0], loss_acc[1], inv_global_batch * loss_acc[0] + memory_reg * loss_acc[1]} -- the last is
+ * cross_entropy of code/hpmn.py:202-207 without the l2 term -- and loss_acc[0..1] (the loss_out the training launch added
+ * into) cleared for the next step.  Replaces four framework launches on a few bytes. */
+int hpmn_read_param_grads_loss_n(int32_t nb, const HpmnReadDesc *const *desc, float *d_params, float *workspace,
+                                 float *loss_acc, float inv_global_batch, float memory_reg, float *loss3, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Embedding-gradient scatter-add: gradient of hpmn_embed_gather / the gather inside the
