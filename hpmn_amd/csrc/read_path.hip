@@ -452,6 +452,8 @@ struct ReadArgs {
     float *d_memory[2], *d_last[2];
     float *att_w0[2];
     int nb, W;                  // branches; head input width = sum_b (H_b + D0_b)
+    int rs;                     // samples per workgroup: RS (training; latency per workgroup is what counts), 4 for large
+                                // inference batches (4 K <= 32 rows fill the matrix tile: half the workgroups, the same work each)
     float *tape;                // training: the operand rows of the weight-gradient products
     WgLayer *table;             //           the layer table of read_wgrad_kernel (workgroup 0 writes it)
     Tape tp;                    //           and their layout (tape_layout, filled in by the host)
@@ -486,6 +488,7 @@ struct ReadSmem {
     float *zero;     // [max(H, D0)] zeros (bias of the bias-free products)
     float *mk1;      // [RS][F1]  dropout factor mask/keep_prob of the tile (training)
     float *mk2;      // [RS][F2]
+    int rs;          // samples per workgroup (the "RS" of the comments above)
 };
 
 struct ReadDims { int Kmax, Hmax, Zmax, W; };
@@ -504,7 +507,7 @@ __host__ __device__ inline ReadDims read_dims(const HpmnReadDesc &d0, const Hpmn
 
 // carve of the dynamic LDS (straight-line on purpose: pointer tables indexed at run time put the kernel's argument
 // struct into scratch memory).  Returns the float count.
-__host__ __device__ inline size_t carve_branch(BranchSmem &x, float *base, size_t off, const HpmnReadDesc &d) {
+__host__ __device__ inline size_t carve_branch(BranchSmem &x, float *base, size_t off, const HpmnReadDesc &d, int RS) {
     auto take = [&](size_t n) { float *r = base ? base + off : nullptr; off += (n + 3) / 4 * 4; return r; };
     const size_t RK = (size_t)RS * d.K;
     x.mem = take(RK * (d.H + PADF));
@@ -520,13 +523,14 @@ __host__ __device__ inline size_t carve_branch(BranchSmem &x, float *base, size_
 }
 
 __host__ __device__ inline size_t carve_all(ReadSmem &s, float *base, const HpmnReadDesc &d0, const HpmnReadDesc &d1, int nb,
-                                            bool train) {
+                                            bool train, int RS) {
+    s.rs = RS;
     size_t off = 0;
     auto take = [&](size_t n) { float *r = base ? base + off : nullptr; off += (n + 3) / 4 * 4; return r; };
     const ReadDims m = read_dims(d0, d1, nb);
     const size_t RKm = (size_t)RS * m.Kmax;
-    off = carve_branch(s.br[0], base, off, d0);
-    if (nb > 1) off = carve_branch(s.br[1], base, off, d1);
+    off = carve_branch(s.br[0], base, off, d0, RS);
+    if (nb > 1) off = carve_branch(s.br[1], base, off, d1, RS);
     s.inp = take(RKm * (4 * m.Hmax + PADF));
     s.rep = take((size_t)RS * (m.W + PADF));
     s.h1 = take((size_t)RS * F1P);
@@ -547,13 +551,13 @@ __host__ __device__ inline size_t carve_all(ReadSmem &s, float *base, const Hpmn
     return off + 16;
 }
 
-inline size_t read_smem_floats(const HpmnReadDesc *d, int nb, bool train) {
+inline size_t read_smem_floats(const HpmnReadDesc *d, int nb, bool train, int rs) {
     ReadSmem s;
-    return carve_all(s, nullptr, d[0], d[nb > 1 ? 1 : 0], nb, train);
+    return carve_all(s, nullptr, d[0], d[nb > 1 ? 1 : 0], nb, train, rs);
 }
 
 __device__ inline void carve(ReadSmem &s, float *base, const ReadArgs &a, bool train) {
-    carve_all(s, base, a.d[0], a.d[1], a.nb, train);
+    carve_all(s, base, a.d[0], a.d[1], a.nb, train, a.rs);
     const ReadDims m = read_dims(a.d[0], a.d[1], a.nb);
     for (int o = threadIdx.x; o < m.Zmax; o += RT) s.zero[o] = 0.f;   // visible after the caller's first barrier
 }
@@ -582,7 +586,7 @@ __device__ __forceinline__ void read_forward_branch(const HpmnReadDesc &d, const
     __syncthreads();
     RCLK(2);
     for (int hop = 0; hop < d.hop; ++hop) {
-        const float *q = x.q + (size_t)hop * RS * HP;
+        const float *q = x.q + (size_t)hop * s.rs * HP;
         // inp = [q, m, q-m, q*m]  (code/hpmn.py:135-136)
         for (int o = tid; o < RK * H; o += RT) {
             const int row = o / H, i = o - row * H;
@@ -592,8 +596,8 @@ __device__ __forceinline__ void read_forward_branch(const HpmnReadDesc &d, const
         }
         __syncthreads();
         RCLK(3);
-        float *x1 = x.x1 + (size_t)hop * RS * K * A1P, *x2 = x.x2 + (size_t)hop * RS * K * A2P;
-        float *sc = x.sc + (size_t)hop * RS * K;
+        float *x1 = x.x1 + (size_t)hop * s.rs * K * A1P, *x2 = x.x2 + (size_t)hop * s.rs * K * A2P;
+        float *sc = x.sc + (size_t)hop * s.rs * K;
         const int *oa = d.off_att[hop];
         dense_fwd<1>(s.inp, IP, RK, 4 * H, P + oa[0], P + oa[1], A1, x1, A1P);
         __syncthreads();
@@ -616,7 +620,7 @@ __device__ __forceinline__ void read_forward_branch(const HpmnReadDesc &d, const
         __syncthreads();
         RCLK(7);
         // q' = q Hmap + sum_k score_k m_k   (code/hpmn.py:143-144, 179)
-        float *qn = x.q + (size_t)(hop + 1) * RS * HP;
+        float *qn = x.q + (size_t)(hop + 1) * s.rs * HP;
         dense_fwd<0>(q, HP, R, H, P + d.off_map, nullptr, H, qn, HP);        // q Hmap (no bias)
         __syncthreads();
         RCLK(8);
@@ -676,7 +680,7 @@ __device__ __forceinline__ void read_forward_tile(const ReadArgs &a, const float
     for (int b = 0; b < 2; ++b) {
         if (b >= a.nb) break;
         const int H = a.d[b].H, D0 = a.d[b].D0;
-        const float *qf = s.br[b].q + (size_t)a.d[b].hop * RS * (H + PADF);
+        const float *qf = s.br[b].q + (size_t)a.d[b].hop * s.rs * (H + PADF);
         for (int o = tid; o < R * (H + D0); o += RT) {
             const int r = o / (H + D0), i = o - r * (H + D0);
             const float v = i < H ? qf[r * (H + PADF) + i] : s.br[b].last[r * (D0 + PADF) + (i - H)];
@@ -724,8 +728,8 @@ __device__ inline void load_tile_inputs(const ReadArgs &a, const ReadSmem &s, lo
         for (int o = threadIdx.x; o < R * D0; o += RT) s.br[b].last[(o / D0) * (D0 + PADF) + o % D0] = a.last[b][b0 * D0 + o];
     }
     // pad columns that elementwise loops sweep: defined values (mask products over whole padded rows)
-    for (int o = threadIdx.x; o < RS * F1P; o += RT) { s.h1[o] = 0.f; s.mk1[o] = 0.f; }
-    for (int o = threadIdx.x; o < RS * F2P; o += RT) { s.h2[o] = 0.f; s.mk2[o] = 0.f; }
+    for (int o = threadIdx.x; o < s.rs * F1P; o += RT) { s.h1[o] = 0.f; s.mk1[o] = 0.f; }
+    for (int o = threadIdx.x; o < s.rs * F2P; o += RT) { s.h2[o] = 0.f; s.mk2[o] = 0.f; }
     __syncthreads();
 }
 
@@ -734,9 +738,9 @@ __global__ __launch_bounds__(RT) void read_fwd_kernel(const ReadArgs a, const fl
     extern __shared__ __attribute__((aligned(16))) float smem[];
     ReadSmem s;
     carve(s, smem, a, false);
-    const long b0 = (long)blockIdx.x * RS;
+    const long b0 = (long)blockIdx.x * a.rs;
     const int B = a.d[0].B;
-    const int R = (B - b0) < RS ? (int)(B - b0) : RS;
+    const int R = (B - b0) < a.rs ? (int)(B - b0) : a.rs;
     load_tile_inputs(a, s, b0, R);
     float *cov = s.t3 + 32;
     read_forward_tile(a, P, s, R, nullptr, nullptr, 1.f, b0, cov);
@@ -784,9 +788,9 @@ __device__ __forceinline__ void read_backward_branch(const HpmnReadDesc &d, cons
 
     // ---- hops backward (reverse order) ---------------------------------------------------------
     for (int hop = d.hop - 1; hop >= 0; --hop) {
-        const float *q = x.q + (size_t)hop * RS * HP;           // query entering this hop
-        float *x1 = x.x1 + (size_t)hop * RS * K * A1P, *x2 = x.x2 + (size_t)hop * RS * K * A2P;
-        float *sc = x.sc + (size_t)hop * RS * K;
+        const float *q = x.q + (size_t)hop * s.rs * HP;           // query entering this hop
+        float *x1 = x.x1 + (size_t)hop * s.rs * K * A1P, *x2 = x.x2 + (size_t)hop * s.rs * K * A2P;
+        float *sc = x.sc + (size_t)hop * s.rs * K;
         const int *oa = d.off_att[hop];
         // q' = q Hmap + sum_k sc_k m_k : d Hmap += q^T dq' (tape);  d sc_k = <dq', m_k>;  d m_k += sc_k dq'
         float *th = tape + (long)hop * tb.hop_stride;
@@ -899,8 +903,8 @@ __global__ __launch_bounds__(RT) void read_fwd_bwd_kernel(const ReadArgs a, cons
     const int W = a.W, WP = W + PADF;
     carve(s, smem, a, true);
     const int tid = threadIdx.x;
-    const long b0 = (long)blockIdx.x * RS;
-    const int R = (d.B - b0) < RS ? (int)(d.B - b0) : RS;
+    const long b0 = (long)blockIdx.x * a.rs;
+    const int R = (d.B - b0) < a.rs ? (int)(d.B - b0) : a.rs;
     const Tape &tp = a.tp;
     float *tape = a.tape;
     if (blockIdx.x == 0 && tid == 0) {
@@ -981,7 +985,7 @@ __global__ __launch_bounds__(RT) void read_fwd_bwd_kernel(const ReadArgs a, cons
         for (int b = 0; b < 2; ++b) {
             if (b >= a.nb) break;
             const int H = a.d[b].H, D0 = a.d[b].D0;
-            const float *qf = s.br[b].q + (size_t)a.d[b].hop * RS * (H + PADF);
+            const float *qf = s.br[b].q + (size_t)a.d[b].hop * s.rs * (H + PADF);
             for (int o = tid; o < R * (H + D0); o += RT) {
                 const int r = o / (H + D0), i = o - r * (H + D0);
                 const float v = i < H ? qf[r * (H + PADF) + i] : s.br[b].last[r * (D0 + PADF) + (i - H)];
@@ -1202,11 +1206,20 @@ int read_fwd_launch_n(const HpmnReadDesc *const *d, int nb, const float *P, cons
     ReadArgs a;
     int rc = read_args(a, d, nb, memory, last, nullptr, nullptr, att_w0);
     if (rc != HPMN_OK) return rc;
-    const size_t lds = read_smem_floats(a.d, nb, false) * sizeof(float);
+    // Inference is a throughput problem once the batch covers the chip several times: four samples per workgroup fill the
+    // 32-row matrix tile (4 K rows, K <= 8) -- half the workgroups, the same matrix instructions each.  HPMN_READ_INFER_RS.
+    static const int rs_env = [] { const char *e = getenv("HPMN_READ_INFER_RS"); return e ? atoi(e) : 0; }();
+    int kmax = a.d[0].K;
+    if (nb > 1 && a.d[1].K > kmax) kmax = a.d[1].K;
+    a.rs = RS;
+    if (rs_env == 4 || (rs_env == 0 && a.d[0].B >= 1024)) a.rs = 4;
+    if (a.rs * kmax > 32) a.rs = RS;
+    size_t lds = read_smem_floats(a.d, nb, false, a.rs) * sizeof(float);
+    if (lds > 160 * 1024 && a.rs != RS) { a.rs = RS; lds = read_smem_floats(a.d, nb, false, a.rs) * sizeof(float); }
     if (lds > 160 * 1024) return HPMN_EUNSUPPORTED;
     hipError_t e = hipFuncSetAttribute((const void *)read_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { set_last_hip_error((int)e); return HPMN_EHIP; }
-    const unsigned grid = (unsigned)((a.d[0].B + RS - 1) / RS);
+    const unsigned grid = (unsigned)((a.d[0].B + a.rs - 1) / a.rs);
     hipLaunchKernelGGL(read_fwd_kernel, dim3(grid), dim3(RT), lds, st, a, P, pred, logit, mem_loss);
     return check_launch();
 }
@@ -1218,7 +1231,8 @@ int read_fwd_bwd_launch_n(const HpmnReadDesc *const *d, int nb, const float *P, 
     ReadArgs a;
     int rc = read_args(a, d, nb, memory, last, d_memory, d_last, nullptr);
     if (rc != HPMN_OK) return rc;
-    const size_t lds = read_smem_floats(a.d, nb, true) * sizeof(float);
+    a.rs = RS;
+    const size_t lds = read_smem_floats(a.d, nb, true, a.rs) * sizeof(float);
     if (lds > 160 * 1024) return HPMN_EUNSUPPORTED;
     hipError_t e = hipFuncSetAttribute((const void *)read_fwd_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { set_last_hip_error((int)e); return HPMN_EHIP; }

@@ -1164,3 +1164,28 @@ def test_read_path_weight_gradients_deferred_equal_immediate_and_survive_batch_c
     ops.read_fwd_bwd(m._read_desc, m._read_params, m._read_grads, memory, last, label, None, 1.0, 1.0 / 7, cfg.memory_reg)
     torch.cuda.synchronize()
     assert torch.equal(m._read_grads, want)
+
+
+def test_inference_read_launch_with_four_samples_per_workgroup_equals_two(dev, tmp_path):
+    """hpmn_read_fwd takes four samples per workgroup once the batch reaches 1024 rows: the same batch in
+    slices of 500 (two per workgroup) must give the same predictions, first-hop weights and memory loss -- per-sample
+    arithmetic does not depend on the tile a sample sits in -- incl. a batch size that leaves a partial last tile."""
+    from hpmn_amd import ops
+    for cfg in (cfg_industry(H=64, K=7, T=41, V=400), cfg_amazon(H=32, K=4, T=50, V=300)):
+        m = make_model(cfg, tmp_path, f32_params(cfg, 9))
+        K, H, D0 = cfg.user_num_layers, cfg.hidden_size, cfg.user_dim * cfg.embedding_size
+        B = 1027
+        g = torch.Generator(device=dev).manual_seed(11)
+        memory = torch.randn(B, K, H, device=dev, generator=g) * 0.5
+        last = torch.randn(B, D0, device=dev, generator=g) * 0.5
+        big = ops.read_fwd(m._read_desc, m._read_params, memory, last, want_logit=True, want_att=True)
+        preds, logits, atts, ml = [], [], [], 0.0
+        for lo in range(0, B, 500):
+            o = ops.read_fwd(m._read_desc, m._read_params, memory[lo:lo + 500].contiguous(), last[lo:lo + 500].contiguous(),
+                             want_logit=True, want_att=True)
+            preds.append(o["prediction"]); logits.append(o["logit"]); atts.append(o["user_weights"])
+            ml += float(o["memory_loss"])
+        assert torch.equal(big["logit"], torch.cat(logits))
+        assert torch.equal(big["prediction"], torch.cat(preds))
+        assert torch.equal(big["user_weights"], torch.cat(atts))
+        np.testing.assert_allclose(float(big["memory_loss"]), ml, rtol=1e-5)
