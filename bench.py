@@ -383,14 +383,21 @@ def log(msg):
 T_START = time.perf_counter()
 
 
-def cpu_baseline(c, seed=0):
+def cpu_baseline(c, seed=0, budget_s=25.0):
     """The oracle's PyTorch-CPU eager restatement (per-timestep small ops like the TF graph, dense TF-form Adam
     over the whole table), float32, timed on this host's cores at the FULL shape of the workload (sequence length,
-    layers, vocabulary, the reference batch): a thread sweep {1,4,8,16,32} on a batch of 16 picks the thread count,
-    then median of 3 training steps and of 3 forward-only passes at the bounded batch below."""
+    layers, vocabulary, the reference batch).
+
+    Protocol (BASELINE.md section 3 bounded to ~25 s of timed CPU work):
+    * ``torch.set_flush_denormal(True)``: fresh-init BPTT over 1024 steps produces denormal gradients, TensorFlow's
+      CPU kernels run with flush-to-zero, PyTorch's do not by default -- without it a step costs 4-10x more and the
+      first steps of a run are outliers;
+    * a thread sweep {1,4,8,16,32} on a batch of 16 (after a warm-up at that batch) picks the thread count;
+    * ONE warm-up step AT THE MEASURED BATCH, then >= 5 timed steps (as many as fit the budget, at most 20), the
+      MEDIAN is the value and every sample is reported; a second run must agree within 10 %."""
     from oracle import hpmn_oracle as O
     from oracle import torch_restatement as R
-    threads = min(os.cpu_count() or 1, 32)      # tiny per-step ops: more threads only add sync cost
+    flush_ok = bool(torch.set_flush_denormal(True))     # (stays on: this is the last leg of the run)
     cfg = O.HpmnConfig(feature_size=c["V"], user_dim=c["F"], user_maxlen=c["T"], hidden_size=c["H"],
                        embedding_size=16, hop=3, user_layers=tuple(c["periods"]), user_num_layers=c["K"],
                        industry=c["industry"], memory_reg=c["memory_reg"])
@@ -415,44 +422,48 @@ def cpu_baseline(c, seed=0):
             R.forward(cfg, p, ids, label)
         return time.perf_counter() - t0
 
-    torch.set_num_threads(threads)
-    train(8)                                   # warm-up (allocator, thread pool, first-touch of the table)
+    ncpu = os.cpu_count() or 1
+    torch.set_num_threads(min(ncpu, 8))
+    train(16)                                  # warm-up (allocator, thread pool, first touch of the table and moments)
     # Thread sweep on a batch of 16: the restatement dispatches ~25 tiny ops per time step, and a thread pool that is too
-    # wide loses more to fork/join than it gains (r2: 32 threads at batch 500 were SLOWER per sequence than 1 thread at
-    # batch 16).  The baseline reported is the best thread count's.
+    # wide loses more to fork/join than it gains.  The baseline reported is the best thread count's.
     sweep = {}
     for th in (1, 4, 8, 16, 32):
-        if th > (os.cpu_count() or 1):
+        if th > ncpu:
             break
         torch.set_num_threads(th)
         sweep[th] = train(16)
         log("cpu baseline thread sweep: %2d threads, batch 16 train step %.2fs" % (th, sweep[th]))
     threads = min(sweep, key=sweep.get)
     torch.set_num_threads(threads)
-    t_cal = sweep[threads]
-    log("cpu baseline calibration: batch 16 step %.2fs on %d threads (best of the sweep)" % (t_cal, threads))
-    # per-timestep dispatch overhead dominates small batches: linear extrapolation from batch 16 is an upper bound
-    bs = c["batch"] if t_cal / 16.0 * c["batch"] <= 120.0 else int(max(16, 30.0 / (t_cal / 16.0)))
+    bs = c["batch"]
+    warm = train(bs)                           # warm-up AT the measured batch
+    log("cpu baseline: warm-up step batch %d %.2fs on %d threads" % (bs, warm, threads))
+    if warm * 5 > budget_s * 1.6:              # a host too slow for 5 steps of the full batch: bound the batch, say so
+        bs = max(16, int(bs * budget_s / (5.0 * warm)))
+        warm = train(bs)
+        log("cpu baseline: batch bounded to %d, warm-up %.2fs" % (bs, warm))
     tt = []
-    for _ in range(3):
+    while len(tt) < 5 or (len(tt) < 20 and sum(tt) + 1.5 * tt[-1] < budget_s):
         tt.append(train(bs))
-        log("cpu baseline: train step batch %d %.2fs" % (bs, tt[-1]))
-        if sum(tt) > 90.0:
-            break
-    tf = [fwd(bs) for _ in range(3 if sum(tt) < 60.0 else 1)]
+    log("cpu baseline: %d train steps batch %d: %s" % (len(tt), bs, " ".join("%.2f" % x for x in tt)))
+    tf = [fwd(bs) for _ in range(4)][1:]      # (first pass: warm-up of the no-grad path)
     log("cpu baseline: forward batch %d %s" % (bs, " ".join("%.2fs" % x for x in tf)))
-    b1 = 16
-    t1 = sweep.get(1, t_cal)
+    t1 = sweep.get(1, sweep[threads])
     med = sorted(tt)[len(tt) // 2]
     medf = sorted(tf)[len(tf) // 2]
     return {"value": bs / med, "unit": "sequences/s", "cores": threads, "kind": "port",
-            "train_step_seconds": tt, "forward_only": {"value": bs / medf, "unit": "sequences/s", "seconds": tf},
-            "one_thread": {"value": b1 / t1, "unit": "sequences/s", "cores": 1, "batch": b1, "seconds": t1},
+            "host_cpus": ncpu, "flush_denormal": flush_ok, "batch": bs, "warmup_steps_at_batch": 1,
+            "train_step_seconds": tt, "train_step_seconds_median": med,
+            "train_step_seconds_spread": (max(tt) - min(tt)) / med,
+            "forward_only": {"value": bs / medf, "unit": "sequences/s", "seconds": tf},
+            "one_thread": {"value": 16 / t1, "unit": "sequences/s", "cores": 1, "batch": 16, "seconds": t1},
             "thread_sweep_batch16_seconds": {str(k): v for k, v in sweep.items()},
-            "sample": "median of %d train step(s) (fwd+BPTT+clip+dense Adam) of batch %d at the full %s shape, fp32 "
-                      "PyTorch-CPU eager restatement (oracle/torch_restatement.py), %.1fs in total; forward-only: median "
-                      "of %d passes of the same batch; 1 thread: one train step of batch %d"
-                      % (len(tt), bs, c["name"], sum(tt), len(tf), b1)}
+            "sample": "median of %d train steps (fwd+BPTT+clip+dense Adam) of batch %d at the full %s shape after one "
+                      "warm-up step at that batch, fp32 PyTorch-CPU eager restatement (oracle/torch_restatement.py), "
+                      "flush-to-zero denormals (as TensorFlow's CPU kernels), %d threads (best of a batch-16 sweep), "
+                      "%.1fs timed in total; forward-only: median of %d passes of the same batch; 1 thread: one train "
+                      "step of batch 16" % (len(tt), bs, c["name"], threads, sum(tt), len(tf))}
 
 
 def dp_report(model, c, batches, world, ms_per_step, n_model=8, busbw_gbps=300.0):
@@ -489,6 +500,26 @@ def dp_report(model, c, batches, world, ms_per_step, n_model=8, busbw_gbps=300.0
     }
 
 
+def self_spawn(n, backend):
+    """Re-execute this command line under ``python -m torch.distributed.run --nnodes=1 --nproc-per-node n`` and
+    return the job's exit code.  RCCL needs one device per rank; the gloo dry run lets ranks share devices."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if backend == "nccl" and have < n:
+        print("bench.py --gpus %d: only %d GPU(s) visible (RCCL needs one per rank; --backend gloo shares devices "
+              "for a dry run)" % (n, have), file=sys.stderr)
+        return 2
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))   # (the CPU legs run on rank 0 only)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -517,9 +548,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` as the driver's single-GPU command line spells it: start the N ranks ourselves
+        # (one process per GPU under torch.distributed.run, 127.0.0.1 rendezvous) and hand their exit code back;
+        # rank 0 of the child job prints the ONE JSON line on the stdout it inherits from us.
+        raise SystemExit(self_spawn(args.gpus, args.backend))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node %d" % (args.gpus, world, args.gpus))
     if args.backend == "gloo":
         local_rank = local_rank % max(1, torch.cuda.device_count())      # dry run: ranks may share a device
     torch.cuda.set_device(local_rank)

@@ -155,7 +155,8 @@ __global__ __launch_bounds__(256) void embed_gather_sum_kernel(const int32_t *__
 // out [B, F*E] must be zeroed by the caller
 int embed_gather_sum_launch(const int32_t *ids, const float *emb, float *out, int32_t B, int32_t T, int32_t F, int32_t E,
                             int32_t mask_id0, hipStream_t st) {
-    if (F > 4 || E % 4 != 0 || 256 % (E / 4) != 0) return HPMN_EUNSUPPORTED;
+    // a row's E/4 float4 lanes must sit inside one wave (part[][][64], the xor-shuffles): E <= 256
+    if (F > 4 || E % 4 != 0 || E / 4 > 64 || 64 % (E / 4) != 0) return HPMN_EUNSUPPORTED;
     if (B == 0) return HPMN_OK;
     int slices = 1;
     while ((long)B * slices < 2048 && slices < 16) slices *= 2;          // enough workgroups to fill the chip

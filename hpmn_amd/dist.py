@@ -125,6 +125,40 @@ def exchange_counts(n: int, device) -> List[int]:
     return [int(x) for x in out.tolist()]
 
 
+class _Counts:
+    """Every rank's count, on its way to pinned host memory: ``result()`` waits for the copy (an event, not a device
+    synchronisation) and returns the list."""
+
+    def __init__(self, host, event, fallback=None):
+        self._host, self._event, self._list = host, event, fallback
+
+    def result(self) -> List[int]:
+        if self._list is None:
+            self._event.synchronize()
+            self._list = [int(x) for x in self._host.tolist()]
+        return self._list
+
+
+def exchange_counts_async(n: int, device) -> "_Counts":
+    """exchange_counts whose host read is deferred: the all-gather and a non-blocking copy into pinned memory are
+    enqueued on the CURRENT stream now, the caller asks for ``result()`` when it needs the numbers (data-parallel step:
+    enqueued at the start of the step underneath the forward, read when the row exchange is sized -- long after the
+    copy completed, so the host never waits on the device's critical path)."""
+    _, world = rank_world()
+    if world == 1:
+        return _Counts(None, None, [int(n)])
+    mine = torch.tensor([int(n)], device=device, dtype=torch.int64)
+    out = torch.empty(world, device=device, dtype=torch.int64)
+    td.all_gather_into_tensor(out, mine)
+    if out.is_cuda:
+        host = torch.empty(world, dtype=torch.int64, pin_memory=True)
+        host.copy_(out, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return _Counts(host, ev)
+    return _Counts(None, None, [int(x) for x in out.tolist()])
+
+
 def exchange_rows(rows: torch.Tensor, grads: torch.Tensor, counts: List[int]):
     """All-gather of (row ids [n] int32, gradient rows [n, E]) over the ranks, padded to the largest count.
     Returns (ids [world, cap] with -1 padding, grads [world, cap, E]); rank r's valid entries are the first counts[r]."""

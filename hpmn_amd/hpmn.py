@@ -21,7 +21,7 @@ import numpy as np
 import torch
 
 from . import dist, ops
-from .data_loader import DataLoader, DataLoader_Mul
+from .data_loader import DataLoader, DataLoader_Mul, load_xlong_tsv
 from .ops import ScanSpec
 
 BN_EPS = 1e-3        # tf.layers.batch_normalization default (code/hpmn.py:190)
@@ -92,15 +92,10 @@ class _DeviceDataset:
             length = dataset.get("length")
             item_ids = dataset.get("item_ids")
         elif isinstance(dataset, str):
-            chunks, ichunks, labels = [], [], []
-            for _, data in DataLoader_Mul(dataset, 512):
-                labels += data[0]
-                chunks.append(np.asarray(data[1], dtype=np.int32))
-                if want_item:
-                    ichunks.append(np.asarray(data[3], dtype=np.int32))     # item_inp <- data[3] (code/hpmn.py:330)
-            ids = np.concatenate(chunks, axis=0)
-            item_ids = np.concatenate(ichunks, axis=0) if want_item else None
-            label = np.asarray(labels, dtype=np.int32)
+            # XLong TSV (code/data_loader.py:56-85): parsed once by a process pool into an array cache next to the file
+            z = load_xlong_tsv(dataset)
+            ids, label = z["ids"], z["label"]
+            item_ids = z["item_ids"] if want_item else None     # item_inp <- data[3] (code/hpmn.py:330)
             length = None
         else:
             label = np.asarray([s[0] for s in dataset], dtype=np.int32)
@@ -116,12 +111,24 @@ class _DeviceDataset:
         if feature_size is not None and self.n:
             lo, hi = int(np.min(ids)), int(np.max(ids))
             if lo < 0 or hi >= feature_size:
-                raise ValueError("dataset ids span [%d, %d] but the embedding table has %d rows" % (lo, hi, feature_size))
+                # HPMN_OOB_IDS=zero: what TF's GPU gather does with such an id -- a row of zeros, no gradient.  Only where the
+                # graph has such a row already (the Hpmn class masks id 0, code/hpmn.py:417-423): the ids are mapped onto it.
+                # The reference's own Taobao files need this: their target rows carry btag == feature_size
+                # (preprocess_taobao.py:48,131), one past the table.
+                if os.environ.get("HPMN_OOB_IDS", "raise") == "zero" and not industry and lo >= 0:
+                    ids = np.where(np.asarray(ids) >= feature_size, 0, ids)
+                else:
+                    raise ValueError("dataset ids span [%d, %d] but the embedding table has %d rows (tf.nn.embedding_lookup "
+                                     "raises on the CPU; HPMN_OOB_IDS=zero gives its GPU behaviour for the Hpmn class: a "
+                                     "zero row, no gradient)" % (lo, hi, feature_size))
         self.ids = torch.as_tensor(np.ascontiguousarray(ids, dtype=np.int32)).to(device)
         self.item_ids = None
         if want_item:
             if feature_size is not None and self.n and (int(np.min(item_ids)) < 0 or int(np.max(item_ids)) >= feature_size):
-                raise ValueError("item-side ids out of the embedding table's range")
+                if os.environ.get("HPMN_OOB_IDS", "raise") == "zero" and not industry and int(np.min(item_ids)) >= 0:
+                    item_ids = np.where(np.asarray(item_ids) >= feature_size, 0, item_ids)
+                else:
+                    raise ValueError("item-side ids out of the embedding table's range")
             self.item_ids = torch.as_tensor(np.ascontiguousarray(item_ids, dtype=np.int32)).to(device)
         self.label_np = np.asarray(label, dtype=np.int32)
         self.label = torch.as_tensor(self.label_np).to(device)
@@ -179,6 +186,7 @@ class Hpmn_Basic(object):
         # blocking all-reduce over the whole flat gradient, then one update (no overlap: the fallback switch)
         # auto: the two-pass step with touched rows for big tables, dense all-reduce for small ones (_train_step_dp)
         self.table_exchange = os.environ.get("HPMN_TABLE_EXCHANGE", "auto")
+        self._sharded_moments = False     # set once the sharded table update has run (save_model gathers the moments then)
         self.TWO_PASS_MIN_NUMEL = int(os.environ.get("HPMN_TWO_PASS_MIN_NUMEL", str(type(self).TWO_PASS_MIN_NUMEL)))
         self.last_exchange_bytes = 0            # bytes this rank received in the last step's table exchange
         self._dropout_base, self._dropout_step = (int(seed or 0) * 0x632BE59BD9B4E019 + 0x1234567) & (2 ** 63 - 1), 0
@@ -586,6 +594,7 @@ class Hpmn_Basic(object):
             n_pad = self._emb_numel_padded
             shard = n_pad // self.world
             lo = self.rank * shard
+            self._sharded_moments = True
             g = dist.reduce_scatter_sum(self.flat_grad[:n_pad], self.rank, self.world)      # [shard]
             self.adam_t += 1
             t = self.adam_t
@@ -643,11 +652,17 @@ class Hpmn_Basic(object):
                 self.EARLY_PASS_SPLIT = max(0.25, min(1.0, 0.85 * t_fwd / t_pass))
             self._split_probe = "done"
 
+    def _table_adam_width_ok(self) -> bool:
+        """hpmn_adam_step_table handles rows of E floats with E/4 a power of two <= 64 (api.hip); other widths take the
+        dense one-sweep Adam."""
+        e4, rem = divmod(self.embedding_size, 4)
+        return rem == 0 and 1 <= e4 <= 64 and (e4 & (e4 - 1)) == 0
+
     def _two_pass_table_adam(self, ids) -> bool:
         """Single process, user-only graph, no densifying l2 term, a table big enough for the dense sweep to matter."""
         return bool(self.TWO_PASS_TABLE_ADAM and self.world == 1 and self._hip_read and not self.l2_reg
                     and not self.lazy_table_adam and ids.shape[0] > 0 and self.flat_grad.numel() >= self.TWO_PASS_MIN_NUMEL
-                    and self.embedding_size % 4 == 0)
+                    and self._table_adam_width_ok())
 
     def _train_step_two_pass(self, ids, label, keep_prob, masks, global_batch):
         """The same step with the dense table update (99.5 % of the parameters, 1.5 GB of HBM traffic, the longest kernel
@@ -715,7 +730,7 @@ class Hpmn_Basic(object):
         one-sweep forms (train_step)."""
         return bool(self.TWO_PASS_TABLE_ADAM and self.world > 1 and self._hip_read and not self.l2_reg
                     and not self.lazy_table_adam and self.table_exchange in ("auto", "rows", "allreduce")
-                    and self.flat_grad.numel() >= self.TWO_PASS_MIN_NUMEL and self.embedding_size % 4 == 0)
+                    and self.flat_grad.numel() >= self.TWO_PASS_MIN_NUMEL and self._table_adam_width_ok())
 
     def _train_step_dp(self, ids, label, keep_prob, masks, global_batch):
         """_train_step_two_pass with the batch sharded over the ranks.  What a rank may treat as
@@ -723,10 +738,22 @@ class Hpmn_Basic(object):
         step (4 MB per rank at the reference batch, fixed size: no host synchronisation), underneath the forward like
         the early pass itself.  Behind the scatter the table gradient is exchanged either densely (all-reduce of the
         [V, E] gradient: 2 (N-1)/N x 212 MB per rank at C3) or as touched rows (all-gather of every rank's unique row
-        ids + gradient rows, summed in rank order on every rank so the replicas stay bit-identical; one host read for
-        the counts) -- then the late pass runs over the union's rows exactly as in the single-process step."""
+        ids + gradient rows, summed in rank order on every rank so the replicas stay bit-identical) -- then the late
+        pass runs over the union's rows exactly as in the single-process step.
+
+        r4: the ids are known before the step computes anything, so the unique row list and the ranks' counts are
+        produced AT THE START of the step on the auxiliary stream (underneath the forward) and land in pinned host
+        memory through an asynchronous copy; the host looks at them only when it sizes the row exchange, after it has
+        enqueued forward + BPTT -- by then the copy finished milliseconds ago, so there is no host read on the critical
+        path.  ``auto`` picks the exchange PER STEP from those counts by modelled bytes received per rank
+        ((N-1) x max count x (4 + 4 E) for the rows against 2 (N-1)/N x table bytes for the ring all-reduce): the same
+        numbers on every rank, hence the same decision."""
         n_emb = self.params["Embedding/emb_mtx"].numel()
         V, E = self.feature_size, self.embedding_size
+        if global_batch is None:
+            # (ADVICE r3) without the global batch the fixed-size id gather is sized from the LOCAL shard: every rank
+            # must then hold the same number of rows -- ragged shards have to pass global_batch
+            global_batch = ids.shape[0] * self.world
         if self._row_flags is None:
             self._row_flags = torch.zeros(V, device=self.device, dtype=torch.uint8)
         flags = self._row_flags
@@ -734,12 +761,14 @@ class Hpmn_Basic(object):
         lr_t = self.learning_rate * math.sqrt(1.0 - self.beta2 ** t) / (1.0 - self.beta1 ** t)
         views = [b[:n_emb].view(V, E) for b in (self.flat_param, self.flat_grad, self.flat_m, self.flat_v)]
         B = ids.shape[0]
-        gb = B * self.world if global_batch is None else global_batch
+        gb = global_batch
         per_sample = ids[0].numel() if B > 0 else self.spec.T * self.spec.F
-        cap = max(dist.shard_sizes(gb, self.world)) * per_sample if global_batch is not None else B * per_sample
-        mode = self.table_exchange
-        if mode == "auto":
-            mode = "rows" if n_emb * 4 > self.ROWS_EXCHANGE_MIN_BYTES else "allreduce"
+        cap = max(dist.shard_sizes(gb, self.world)) * per_sample
+        if B * per_sample > cap:
+            raise ValueError("this rank's shard (%d rows) is larger than the largest shard of global_batch=%d over %d ranks"
+                             % (B, gb, self.world))
+        want_counts = self.table_exchange in ("auto", "rows")
+        box = {}
 
         def early():                                          # runs on the auxiliary stream
             if not self._table_grad_clean:
@@ -749,6 +778,11 @@ class Hpmn_Basic(object):
 
             def rest():
                 all_ids = dist.gather_ids(ids, max(cap, 1))
+                if want_counts:
+                    rows = (torch.unique(ids.reshape(-1)).long() if B > 0
+                            else torch.empty(0, device=self.device, dtype=torch.int64))
+                    box["rows"] = rows
+                    box["counts"] = dist.exchange_counts_async(rows.numel(), self.device)
                 ops.table_mark_rows(all_ids, flags)
                 ops.adam_step_table(*views, flags, 0, lr_t, self.beta1, self.beta2, self.adam_eps, clip=1.0)
             return rest
@@ -766,9 +800,15 @@ class Hpmn_Basic(object):
         pending = out.pop("pending", None)
         self.adam_t = t
         table_grad = views[1]
+        mode = self.table_exchange
+        counts = box["counts"].result() if want_counts else None
+        if mode == "auto":
+            mode = ("rows" if dist.rows_exchange_bytes(counts, E) < dist.dense_allreduce_bytes(n_emb, self.world)
+                    else "allreduce")
+        self.last_exchange_mode = mode
         if mode == "rows":
-            rows = torch.unique(ids.reshape(-1)).long() if B > 0 else torch.empty(0, device=self.device, dtype=torch.int64)
-            counts = dist.exchange_counts(rows.numel(), self.device)
+            rows = box["rows"]
+            rows.record_stream(torch.cuda.current_stream())   # (made on the auxiliary stream, consumed here)
             mine = table_grad.index_select(0, rows)
             ids_all, g_all = dist.exchange_rows(rows, mine, counts)
             table_grad.index_fill_(0, rows, 0.0)              # (own rows come back through g_all, in rank order)
@@ -921,7 +961,9 @@ class Hpmn_Basic(object):
         which a user-only export does not contain.
         Every rank must call this under data parallel with the sharded table exchange: each rank holds the Adam moments
         of its own 1/world of the table rows only, and they are gathered here before rank 0 writes."""
-        if self.world > 1 and self.table_exchange == "sharded" and not self.lazy_table_adam:
+        if self.world > 1 and self._sharded_moments:
+            # (the sharded update ran: every rank holds 1/world of the table's moments -- a collective, so EVERY rank has
+            # to call save_model then; README / INTEGRATION state it.  Keyed on what ran, not on the switch: ADVICE r3)
             n_pad = self._emb_numel_padded
             shard = n_pad // self.world
             for buf in (self.flat_m, self.flat_v):

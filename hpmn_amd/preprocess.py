@@ -3,7 +3,7 @@
 What the reference's ``code/preprocess_amazon.py`` / ``code/preprocess_taobao.py`` produce, rebuilt as
 one array-based pipeline (the reference scripts are Python-2 pandas loops that do not run as written --
 ``pickle`` is never imported under that name, py2-only file modes -- so they are the SPEC here, cited
-line by line, not code that was executed):
+line by line; their functions DO run when extracted, which is what pins this module, see below):
 
     events (uid, iid, extra columns, time)
       -> remap every id column into ONE shared id space, column after column, each column's values in
@@ -22,8 +22,13 @@ line by line, not code that was executed):
          (:189-197 + util.front_padding, code/util.py:152-159)
       -> sample = (label, user_rows [T][F], user_len, item_rows [T'][F'], item_len)
 
-Python 3's ``random`` draws a different stream than Python 2's for the same seed, so a dataset built
-here is distributed like, not identical to, one built by the reference in 2019.
+Pinned by executing the reference (r4): ``tests/golden/make_golden.py`` AST-extracts the reference's own ``remap`` /
+``gen_user_item_group`` / ``gen_dataset`` of both scripts, runs them under Python 3 on small synthetic logs and commits
+inputs + outputs; ``tests/test_preprocess.py`` requires this module to reproduce them exactly -- ids, rows, lengths,
+labels, split and (Amazon) the shuffled order -- from the same ``random`` seed, which works because the draws are made
+in the same order (one ``randint(0, 1)`` per user, ``randint(0, n_item - 1)`` until the item differs, two shuffles).
+Python 2's ``random`` draws a different stream for the same seed, so a dataset built here is distributed like, not
+identical to, one the reference built in 2019.
 
 Besides the pickle (protocol 2, readable by the reference) ``write_dataset`` drops an ``.npz`` next to
 it with the same samples as int32 arrays; ``load_dataset`` prefers it (the list-of-lists pickle of the
@@ -52,7 +57,12 @@ class Schema:
     user_max: int
     item_max: int                         # rows kept when cropping the item side
     item_pad: int                         # rows after front padding (Taobao pads 35 kept rows to 36)
-    unknown_btag: bool = False            # Taobao: the target row's btag is the extra id feature_size
+    unknown_btag: bool = False            # Taobao: one extra id is reserved for the target row's btag (feature_size += 1)
+    # The reference writes that btag as ``feature_size`` itself (preprocess_taobao.py:131 after :48) -- ONE PAST the last row
+    # of a [feature_size, E] table: TF's CPU gather raises on it, its GPU gather returns a zero row.  True reproduces the
+    # reference's files byte for byte (pinned by tests/golden/preprocess_reference.npz, produced by executing the reference's
+    # functions); False writes the reserved in-range id feature_size - 1 instead.
+    unknown_btag_out_of_range: bool = True
     shuffle: bool = True                  # preprocess_amazon.py:205-206 shuffles, preprocess_taobao.py does not
 
 
@@ -146,7 +156,9 @@ def build_samples(ev: Dict[str, np.ndarray], n_item: int, feature_size: int, sch
     uorder, ukeys, ustart, uend = _groups(ev["uid"], ev["time"])
     iorder, ikeys, istart, iend = _groups(ev["iid"], ev["time"])
     item_slot = {int(k): n for n, k in enumerate(ikeys)}
-    unknown = feature_size - 1 if schema.unknown_btag else None
+    unknown = None
+    if schema.unknown_btag:
+        unknown = feature_size if schema.unknown_btag_out_of_range else feature_size - 1
 
     last_touch = ev["time"][uorder[uend - 1]]
     split_time = np.sort(last_touch)[int(len(last_touch) * 0.7)]
@@ -237,9 +249,13 @@ def preprocess_amazon(review_file: str, meta_file: str, out_pkl: str, seed: int 
     return len(train), len(test), fs
 
 
-def preprocess_taobao(csv_file: str, out_pkl: str, seed: int = 1111):
-    ev, n_item, fs = remap(read_taobao(csv_file), TAOBAO)
-    train, test = build_samples(ev, n_item, fs, TAOBAO, seed)
+def preprocess_taobao(csv_file: str, out_pkl: str, seed: int = 1111, in_range_unknown_btag: bool = False):
+    """``in_range_unknown_btag``: write the target rows' btag as feature_size - 1 (inside the table) instead of the
+    reference's feature_size (see Schema.unknown_btag_out_of_range)."""
+    import dataclasses
+    schema = dataclasses.replace(TAOBAO, unknown_btag_out_of_range=not in_range_unknown_btag)
+    ev, n_item, fs = remap(read_taobao(csv_file), schema)
+    train, test = build_samples(ev, n_item, fs, schema, seed)
     write_dataset(out_pkl, train, test, fs)
     return len(train), len(test), fs
 
@@ -255,11 +271,13 @@ def main(argv: Optional[List[str]] = None) -> int:
     t = sub.add_parser("taobao")
     t.add_argument("--csv", default="../data/raw_data/taobao/taobao_sample.csv")         # preprocess_taobao.py:12
     t.add_argument("--out", default="../data/taobao/dataset_hpmn.pkl")
+    t.add_argument("--in-range-unknown-btag", action="store_true",
+                   help="target btag = feature_size - 1 instead of the reference's out-of-range feature_size")
     args = ap.parse_args(argv)
     if args.which == "amazon":
         print("train %d test %d feature_size %d" % preprocess_amazon(args.reviews, args.meta, args.out))
     else:
-        print("train %d test %d feature_size %d" % preprocess_taobao(args.csv, args.out))
+        print("train %d test %d feature_size %d" % preprocess_taobao(args.csv, args.out, in_range_unknown_btag=args.in_range_unknown_btag))
     return 0
 
 

@@ -421,14 +421,23 @@ def import_model(prefix: str, param_shapes: Dict[str, Tuple[int, ...]], beta1: f
 
 def _adam_steps(have, beta1: float, beta2: float) -> int:
     """Adam's step count of a checkpoint: the exact tensor our writer adds; for a checkpoint TF wrote, from beta2_power
-    (float32 0.999^(t+1) resolves t to about 87 k steps; beta1_power underflows to 0 near t = 985), then beta1_power."""
+    (float32 0.999^(t+1) resolves t to about 87 k steps; beta1_power underflows to 0 near t = 985), then beta1_power.
+    A power that is 0 or below float32's smallest normal has underflowed: TF's lr_t = lr sqrt(1 - b2^t) / (1 - b1^t) is
+    then lr itself, so the count returned SATURATES (log(tiny)/log(beta2), about 87 k for 0.999) instead of falling
+    back to 0, which would restart the bias correction (lr_t = 0.32 lr) on late-step moments."""
     if STEP_TENSOR in have:
         return max(0, int(np.asarray(have[STEP_TENSOR]).reshape(-1)[0]))
+    tiny = float(np.finfo(np.float32).tiny)
+    underflowed = False
     for name, beta in ((ADAM_SCOPE + "/beta2_power", beta2), (ADAM_SCOPE + "/beta1_power", beta1)):
         p = have.get(name)
         if p is None:
             continue
         p = float(np.asarray(p).reshape(-1)[0])
-        if np.isfinite(p) and 0.0 < p < 1.0:
+        if np.isfinite(p) and tiny <= p < 1.0:
             return max(0, int(round(np.log(p) / np.log(beta))) - 1)
+        if np.isfinite(p) and 0.0 <= p < tiny:
+            underflowed = True
+    if underflowed:
+        return int(np.log(tiny) / np.log(beta2))
     return 0

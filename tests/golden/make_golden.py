@@ -106,9 +106,261 @@ def make_oracle_vectors():
                         cross_entropy=out2["cross_entropy"])
 
 
+# -----------------------------------------------------------------------------------------------------------------
+# 3. preprocess fixtures: the reference's OWN remap / gen_user_item_group / gen_dataset executed on small synthetic
+#    logs.  The scripts cannot be imported (module-level ``from util import ...`` pulls in
+#    tensorflow; ``pickle`` is used under a name that is never bound), so the functions are AST-extracted -- exactly
+#    like front_padding above -- and run in a namespace that supplies what the module level would have: pandas,
+#    ``random`` (seeded as preprocess_amazon.py:12 does), the MAX_LEN constants, and a ``pickle``/``open`` pair that
+#    keeps the dumped objects in memory instead of on disk.  Only inputs and returned outputs are stored.
+# -----------------------------------------------------------------------------------------------------------------
+class _MemPickle:
+    """Stands in for the module name ``pickle`` / ``pkl`` inside the extracted functions: dump() keeps the object,
+    load() hands the kept objects back in order."""
+    HIGHEST_PROTOCOL = 2
+
+    def __init__(self):
+        self.objs, self.pos = [], 0
+
+    def dump(self, obj, f, protocol=None):
+        self.objs.append(obj)
+
+    def load(self, f):
+        obj = self.objs[self.pos]
+        self.pos += 1
+        return obj
+
+
+class _NullFile:
+    def __init__(self, *a, **k):
+        pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+def _extract(script, names, extra):
+    import random as _random
+
+    import pandas as pd
+    src = open(os.path.join(REF, script)).read()
+    tree = ast.parse(src)
+    fns = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in names]
+    assert sorted(f.name for f in fns) == sorted(names)
+    ns = dict(pd=pd, random=_random, open=_NullFile, print=lambda *a, **k: None)
+    ns.update(extra)
+    exec(compile(ast.Module(body=fns, type_ignores=[]), script, "exec"), ns)
+    return ns
+
+
+def synthetic_amazon_events(seed=11, n_user=40, n_item=25, n_cate=6):
+    """Raw review events with string keys (as the Amazon dumps have), time ties inside a user, one user longer than
+    MAX_LEN, one item touched by many users (so an item side longer than MAX_LEN exists for a later target)."""
+    rng = np.random.default_rng(seed)
+    items = ["B%05d" % i for i in range(n_item)]
+    cate_of = {a: "cat%d" % int(rng.integers(0, n_cate)) for a in items}
+    ev = []
+    for u in range(n_user):
+        n = 130 if u == 3 else int(rng.integers(2, 9))
+        ts = np.sort(rng.integers(1000, 4000, size=n))          # a narrow range: equal times do occur
+        for t in ts:
+            a = items[0] if rng.random() < 0.35 else items[int(rng.integers(0, n_item))]
+            ev.append(("U%03d" % u, a, cate_of[a], int(t)))
+    # 110 extra one-off users who all touched item 0 early: its item side outgrows MAX_LEN
+    for u in range(n_user, n_user + 110):
+        ev.append(("U%03d" % u, items[0], cate_of[items[0]], int(rng.integers(10, 900))))
+        ev.append(("U%03d" % u, items[int(rng.integers(1, n_item))], cate_of[items[1]], int(rng.integers(900, 1000))))
+    order = rng.permutation(len(ev))                           # file order is not sorted
+    return [ev[i] for i in order]
+
+
+def make_preprocess_amazon():
+    import random as _random
+
+    import pandas as pd
+    ev = synthetic_amazon_events()
+    # categories must be a function of the item (aggregator joins them from the meta file): re-derive to be safe
+    cate = {}
+    for u, a, c, t in ev:
+        cate.setdefault(a, c)
+    ev = [(u, a, cate[a], t) for u, a, c, t in ev]
+    df = pd.DataFrame(dict(reviewerID=[e[0] for e in ev], asin=[e[1] for e in ev],
+                           unixReviewTime=[e[3] for e in ev], category=[e[2] for e in ev]))
+    mem = _MemPickle()
+    ns = _extract("preprocess_amazon.py", ["remap", "gen_user_item_group", "gen_dataset"],
+                  dict(pickle=mem, pkl=mem, MAX_LEN=100, SAVE_PKL_PATH="save.pkl"))
+    _random.seed(1111)                                          # preprocess_amazon.py:12
+    df2, item_cnt, feature_size = ns["remap"](df)
+    remapped = dict(uid=df2["reviewerID"].tolist(), iid=df2["asin"].tolist(), cid=df2["category"].tolist())
+    ns["gen_user_item_group"](df2, item_cnt, feature_size)      # dumps user_df, item_df, item_cnt, feature_size
+    ns["gen_dataset"]("save.pkl", "dataset.pkl")                # loads those four, dumps train, test, feature_size
+    train, test, fs = mem.objs[4], mem.objs[5], mem.objs[6]
+    fp = reference_front_padding()
+    train_fp = [fp(s, 100, 3, 100, 2) for s in train]           # preprocess_amazon.py:331,335
+    test_fp = [fp(s, 100, 3, 100, 2) for s in test]
+    return dict(events=ev, remapped=remapped, item_cnt=int(item_cnt), feature_size=int(fs),
+                train=_pack(train_fp), test=_pack(test_fp), seed=1111)
+
+
+def synthetic_taobao_events(seed=12, n_user=30, n_item=40, n_cate=7):
+    rng = np.random.default_rng(seed)
+    tags = ["buy", "cart", "fav", "pv"]
+    cate_of = rng.integers(100, 100 + n_cate, size=n_item)
+    ev = []
+    for u in range(n_user):
+        n = 320 if u == 2 else int(rng.integers(2, 12))
+        ts = np.sort(rng.integers(5000, 9000, size=n))
+        for t in ts:
+            i = 0 if rng.random() < 0.3 else int(rng.integers(0, n_item))
+            ev.append((1000 + 7 * u, 50000 + 3 * i, int(cate_of[i]), tags[int(rng.integers(0, 4))], int(t)))
+    for u in range(n_user, n_user + 45):                       # item 0's item side outgrows MAX_LEN_USER = 35
+        ev.append((1000 + 7 * u, 50000, int(cate_of[0]), "pv", int(rng.integers(10, 4000))))
+        ev.append((1000 + 7 * u, 50000 + 3 * int(rng.integers(1, n_item)), int(cate_of[1]), "pv", int(rng.integers(4000, 5000))))
+    order = rng.permutation(len(ev))
+    return [ev[i] for i in order]
+
+
+def make_preprocess_taobao():
+    import random as _random
+
+    import pandas as pd
+    ev = synthetic_taobao_events()
+    df = pd.DataFrame(dict(uid=[e[0] for e in ev], iid=[e[1] for e in ev], cid=[e[2] for e in ev],
+                           btag=[e[3] for e in ev], time=[e[4] for e in ev]))
+    mem = _MemPickle()
+    ns = _extract("preprocess_taobao.py", ["remap", "gen_user_item_group", "gen_dataset"],
+                  dict(pkl=mem, pickle=mem, MAX_LEN_ITEM=300, MAX_LEN_USER=35))
+    _random.seed(1111)                    # (preprocess_taobao.py never seeds: the fixture fixes the stream it ran with)
+    df2, item_cnt, feature_size = ns["remap"](df)
+    remapped = dict(uid=df2["uid"].tolist(), iid=df2["iid"].tolist(), cid=df2["cid"].tolist(), btag=df2["btag"].tolist())
+    user_df, item_df = ns["gen_user_item_group"](df2, item_cnt, feature_size)
+    ns["gen_dataset"](user_df, item_df, item_cnt, feature_size, "dataset.pkl")
+    train, test, fs = mem.objs[0], mem.objs[1], mem.objs[2]
+    fp = reference_front_padding()
+    train_fp = [fp(s, 300, 4, 36, 3) for s in train]            # preprocess_taobao.py:211,215
+    test_fp = [fp(s, 300, 4, 36, 3) for s in test]
+    return dict(events=ev, remapped=remapped, item_cnt=int(item_cnt), feature_size=int(fs),
+                train=_pack(train_fp), test=_pack(test_fp), seed=1111)
+
+
+def _pack(samples):
+    return dict(label=[int(s[0]) for s in samples],
+                user=np.asarray([s[1] for s in samples], dtype=np.int64),
+                user_len=[int(s[2]) for s in samples],
+                item=np.asarray([s[3] for s in samples], dtype=np.int64),
+                item_len=[int(s[4]) for s in samples])
+
+
+def make_preprocess_fixtures():
+    out = {}
+    for name, fx in (("amazon", make_preprocess_amazon()), ("taobao", make_preprocess_taobao())):
+        ev = fx["events"]
+        for c in range(len(ev[0])):
+            col = [e[c] for e in ev]
+            out["%s_ev%d" % (name, c)] = np.asarray(col)
+        for k, v in fx["remapped"].items():
+            out["%s_remap_%s" % (name, k)] = np.asarray(v, dtype=np.int64)
+        out[name + "_item_cnt"] = np.int64(fx["item_cnt"])
+        out[name + "_feature_size"] = np.int64(fx["feature_size"])
+        for split in ("train", "test"):
+            for k, v in fx[split].items():
+                out["%s_%s_%s" % (name, split, k)] = np.asarray(v, dtype=np.int64 if k != "user" and k != "item" else np.int32)
+    np.savez_compressed(os.path.join(HERE, "preprocess_reference.npz"), **out)
+    print("preprocess fixture: amazon %d+%d samples, taobao %d+%d samples" % (
+        len(out["amazon_train_label"]), len(out["amazon_test_label"]),
+        len(out["taobao_train_label"]), len(out["taobao_test_label"])))
+
+
+# -----------------------------------------------------------------------------------------------------------------
+# 4. XLong TSV lines through the reference's OWN DataLoader_Mul.worker (code/data_loader.py:47-89), in process: the
+#    method is called unbound on a stand-in ``self`` whose queues are plain lists (the 1+8 process plumbing around it
+#    moves lines, it does not change them).  Python-2 semantics are restored without touching the source: the module
+#    global ``map`` is bound to a list-returning map (py2's), and the chunks are ``batchsize // 2`` lines (py2's
+#    integer ``/``, data_loader.py:13).
+# -----------------------------------------------------------------------------------------------------------------
+class _Val:
+    def __init__(self, v):
+        self.value = v
+
+    def get_lock(self):
+        return _NullFile()
+
+
+class _ListQueue:
+    def __init__(self, items=()):
+        self.items = list(items)
+
+    def get(self, timeout=None):
+        if not self.items:
+            raise RuntimeError("empty")
+        return self.items.pop(0)
+
+    def put(self, x):
+        self.items.append(x)
+
+    def qsize(self):
+        return 0
+
+
+def synthetic_xlong_lines(n_lines=5, seed=21):
+    rng = np.random.default_rng(seed)
+    lines = []
+    for k in range(n_lines):
+        hist = rng.integers(1, 3269017, size=1000)
+        up, un = rng.integers(0, 20000, size=184), rng.integers(0, 20000, size=184)
+        lines.append("\t".join([str(100 + k), str(int(rng.integers(0, 20000))), ",".join(map(str, hist)),
+                                str(int(rng.integers(1, 3269017))), str(int(rng.integers(1, 3269017))),
+                                ",".join(map(str, up)), ",".join(map(str, un))]) + "\n")
+    return lines
+
+
+def make_xlong_fixture():
+    import builtins
+    sys.path.insert(0, REF)
+    import data_loader as ref_dl
+    ref_dl.map = lambda f, *it: list(builtins.map(f, *it))      # Python 2's map (data_loader.py:65,72-73 rely on it)
+    lines = synthetic_xlong_lines()
+    batchsize = 4
+    per = batchsize // 2                                        # data_loader.py:13 under Python 2
+    chunks = [lines[i:i + per] for i in range(0, len(lines), per)]
+
+    class FakeSelf:
+        pass
+    me = FakeSelf()
+    me.wait_time, me.max_q_size = 0.0, 10
+    me.read_stop, me.work_qsize = _Val(1.0), _Val(len(chunks))
+    me.qsize, me.work_stop = _Val(0.0), _Val(0.0)
+    me.work, me.results = _ListQueue(chunks), _ListQueue()
+    ref_dl.DataLoader_Mul.worker(me, 0)
+    assert len(me.results.items) == len(chunks) and me.work_stop.value == 1.0
+    out = dict(lines=np.asarray(lines), batchsize=np.int64(batchsize))
+    for b, (i, data) in enumerate(me.results.items):
+        label, item_part, item_part_len, user_part, user_part_len = data
+        assert i is None
+        out["b%d_label" % b] = np.asarray(label, dtype=np.int64)
+        out["b%d_item_part" % b] = np.asarray(item_part, dtype=np.int64)
+        out["b%d_item_part_len" % b] = np.asarray(item_part_len, dtype=np.int64)
+        out["b%d_user_part" % b] = np.asarray(user_part, dtype=np.int64)
+        out["b%d_user_part_len" % b] = np.asarray(user_part_len, dtype=np.int64)
+    out["n_batches"] = np.int64(len(chunks))
+    np.savez_compressed(os.path.join(HERE, "xlong_worker_reference.npz"), **out)
+    print("xlong fixture: %d lines -> %d batches, item_part %s user_part %s" % (
+        len(lines), len(chunks), out["b0_item_part"].shape, out["b0_user_part"].shape))
+
+
 O_SEED = 20190521
 
 if __name__ == "__main__":
-    make_input_surface()
-    make_oracle_vectors()
+    which = sys.argv[1:] or ["surface", "oracle", "preprocess", "xlong"]
+    if "surface" in which:
+        make_input_surface()
+    if "oracle" in which:
+        make_oracle_vectors()
+    if "preprocess" in which:
+        make_preprocess_fixtures()
+    if "xlong" in which:
+        make_xlong_fixture()
     print("wrote", sorted(os.listdir(HERE)))

@@ -100,3 +100,37 @@ def test_xlong_tsv_line_format_and_loader(tmp_path):
     ids, lab = datasets.make_synthetic_xlong_arrays(5, seed=3)
     np.testing.assert_array_equal(np.concatenate([b[1][1] for b in batches]), ids)
     assert lab.tolist() == [1, 0] * 5
+
+
+def test_xlong_loader_reproduces_the_executed_reference_worker(tmp_path):
+    """tests/golden/xlong_worker_reference.npz: synthetic TSV lines and what the reference's OWN
+    ``DataLoader_Mul.worker`` (code/data_loader.py:47-89) returned for them, executed in the build container with Python-2
+    ``map`` semantics restored (tests/golden/make_golden.py:make_xlong_fixture).  Our reader -- the streaming class and the
+    whole-file staging with its array cache -- has to yield the same batches."""
+    import os
+    from hpmn_amd.data_loader import load_xlong_tsv
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "xlong_worker_reference.npz"))
+    path = str(tmp_path / "ref_lines.txt")
+    with open(path, "w") as f:
+        f.write("".join(z["lines"].tolist()))
+    got = list(DataLoader_Mul(path, int(z["batchsize"])))
+    assert len(got) == int(z["n_batches"]) == 3
+    for b, (i, (label, ipart, ilen, upart, ulen)) in enumerate(got):
+        assert i is None
+        assert list(label) == z["b%d_label" % b].tolist()
+        np.testing.assert_array_equal(ipart, z["b%d_item_part" % b])
+        np.testing.assert_array_equal(upart, z["b%d_user_part" % b])
+        assert list(ilen) == z["b%d_item_part_len" % b].tolist() and list(ulen) == z["b%d_user_part_len" % b].tolist()
+    want_ids = np.concatenate([z["b%d_item_part" % b] for b in range(3)])
+    want_user = np.concatenate([z["b%d_user_part" % b] for b in range(3)])
+    want_label = np.concatenate([z["b%d_label" % b] for b in range(3)])
+    for attempt, workers in ((0, 2), (1, 0)):                    # second call: served by the cache
+        a = load_xlong_tsv(path, workers=workers, chunk_lines=2)
+        assert a["ids"].dtype == np.int32
+        np.testing.assert_array_equal(a["ids"], want_ids)
+        np.testing.assert_array_equal(a["item_ids"], want_user)
+        np.testing.assert_array_equal(a["label"], want_label)
+        assert os.path.exists(path + ".hpmn_cache.npz")
+    with open(path, "a") as f:                                    # the file changed: the cache is not trusted
+        f.write(z["lines"].tolist()[0])
+    assert load_xlong_tsv(path)["ids"].shape[0] == want_ids.shape[0] + 2

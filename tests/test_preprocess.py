@@ -1,12 +1,69 @@
-"""Raw logs -> dataset_hpmn.pkl (hpmn_amd/preprocess.py): schema invariants of the reference pipeline
-(code/preprocess_amazon.py:51-67,123-215; code/preprocess_taobao.py:26-48,104-186; code/util.py:152-159)
-on small synthetic raw files."""
+"""Raw logs -> dataset_hpmn.pkl (hpmn_amd/preprocess.py).
+
+PINNED BY REFERENCE EXECUTION (r4): tests/golden/preprocess_reference.npz holds synthetic raw events and what the
+reference's own ``remap`` / ``gen_user_item_group`` / ``gen_dataset`` (code/preprocess_amazon.py:51-67,104-212;
+code/preprocess_taobao.py:26-57,109-189) + ``front_padding`` (code/util.py:152-159) returned for them when executed in
+the build container (tests/golden/make_golden.py); this module has to reproduce every id, row, length, label, the
+train/test split and the shuffled order exactly.  Plus schema invariants on small synthetic raw files."""
 import json
 import os
 
 import numpy as np
 
 from hpmn_amd import datasets, preprocess as P
+
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "preprocess_reference.npz")
+
+
+def _check_split(z, pre, samples):
+    assert [s[0] for s in samples] == z[pre + "label"].tolist()
+    np.testing.assert_array_equal(np.asarray([s[1] for s in samples]), z[pre + "user"])
+    np.testing.assert_array_equal(np.asarray([s[3] for s in samples]), z[pre + "item"])
+    assert [s[2] for s in samples] == z[pre + "user_len"].tolist()
+    assert [s[4] for s in samples] == z[pre + "item_len"].tolist()
+
+
+def test_amazon_port_reproduces_the_executed_reference():
+    """remap: same ids for every event; build_samples from random.seed(1111) (preprocess_amazon.py:12): the same samples in
+    the same (shuffled) order as the reference's gen_dataset -- incl. equal times inside a user, a user and an item side
+    longer than MAX_LEN, negative targets and their categories."""
+    z = np.load(GOLD)
+    ev = dict(uid=z["amazon_ev0"], iid=z["amazon_ev1"], cid=z["amazon_ev2"], time=z["amazon_ev3"])
+    out, n_item, fs = P.remap(ev, P.AMAZON)
+    assert n_item == int(z["amazon_item_cnt"]) and fs == int(z["amazon_feature_size"])
+    for k in ("uid", "iid", "cid"):
+        np.testing.assert_array_equal(out[k], z["amazon_remap_" + k])
+    train, test = P.build_samples(out, n_item, fs, P.AMAZON, seed=1111)
+    assert len(train) == len(z["amazon_train_label"]) > 50 and len(test) == len(z["amazon_test_label"]) > 20
+    _check_split(z, "amazon_train_", train)
+    _check_split(z, "amazon_test_", test)
+    assert max(z["amazon_train_user_len"].max(), z["amazon_test_user_len"].max()) == 100      # the fixture does crop
+    assert max(z["amazon_train_item_len"].max(), z["amazon_test_item_len"].max()) == 100
+    assert 0 in z["amazon_train_label"] and 1 in z["amazon_train_label"]
+
+
+def test_taobao_port_reproduces_the_executed_reference():
+    """The Taobao pair: id order items, users, categories, btags, +1; no shuffle; 35 item-side rows padded to 36; and the
+    reference's target btag = feature_size (one past the table -- reproduced as written; the in-range variant is a switch)."""
+    import dataclasses
+    z = np.load(GOLD)
+    ev = dict(uid=z["taobao_ev0"], iid=z["taobao_ev1"], cid=z["taobao_ev2"], btag=z["taobao_ev3"], time=z["taobao_ev4"])
+    out, n_item, fs = P.remap(ev, P.TAOBAO)
+    assert n_item == int(z["taobao_item_cnt"]) and fs == int(z["taobao_feature_size"])
+    for k in ("uid", "iid", "cid", "btag"):
+        np.testing.assert_array_equal(out[k], z["taobao_remap_" + k])
+    train, test = P.build_samples(out, n_item, fs, P.TAOBAO, seed=1111)
+    _check_split(z, "taobao_train_", train)
+    _check_split(z, "taobao_test_", test)
+    assert int(z["taobao_train_user"].max()) == fs                            # the reference's out-of-range unknown btag
+    assert max(z["taobao_train_user_len"].max(), z["taobao_test_user_len"].max()) == 300
+    assert max(z["taobao_train_item_len"].max(), z["taobao_test_item_len"].max()) == 35
+    # the switch: identical except that id
+    fixed = dataclasses.replace(P.TAOBAO, unknown_btag_out_of_range=False)
+    train2, _ = P.build_samples(out, n_item, fs, fixed, seed=1111)
+    a, b = np.asarray([s[1] for s in train]), np.asarray([s[1] for s in train2])
+    assert (a != b).sum() == len(train) and set(b[a != b].tolist()) == {fs - 1} and int(b.max()) < fs
 
 
 def _write_amazon(tmp, n_user=40, n_item=25, n_cate=6, seed=3):
@@ -106,7 +163,7 @@ def test_taobao_pipeline_invariants(tmp_path):
                 rows.append(r)
                 f.write("%d,%d,%d,%s,%d\n" % r)
     out = str(tmp_path / "taobao" / "dataset_hpmn.pkl")
-    ntr, nte, fs = P.preprocess_taobao(path, out)
+    ntr, nte, fs = P.preprocess_taobao(path, out, in_range_unknown_btag=True)
     n_item, n_user = len({r[1] for r in rows}), len({r[0] for r in rows})
     n_cate, n_btag = len({r[2] for r in rows}), len({r[3] for r in rows})
     assert fs == n_item + n_user + n_cate + n_btag + 1 and ntr + nte == n_user   # items, users, categories, btags, +1
