@@ -133,15 +133,33 @@ def source_sha():
 
 
 def pmc_digest(c, B):
-    """profiles/r03_pmc_summary.json (tools/pmc_digest.py: two separate rocprofv3 --pmc passes of this command,
+    """profiles/r04_pmc_summary.json (tools/pmc_digest.py: two separate rocprofv3 --pmc passes of this command,
     FETCH x2 gfx950 correction) -- used only if it was taken on the current kernel sources, config and batch."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_summary.json")))
+        d = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_summary.json")))
         if d.get("source_sha") == source_sha() and d.get("config_id") == c.get("config_id") and d.get("batch") == B:
             return d
     except Exception:
         pass
     return None
+
+
+def gather_pmc_digest():
+    """profiles/r04_gather_pmc.json (tools/gather_pmc.py: a separate rocprofv3 --pmc FETCH_SIZE pass over the two gather
+    probes at the cold / C3 / C1 tables and a sequential-id calibration) -> FETCH bytes per row, per case.  Quoted only while
+    embed.hip is the file the digest was taken on."""
+    import hashlib
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r04_gather_pmc.json")))
+        sha = hashlib.sha1(open(os.path.join(ROOT, "hpmn_amd", "csrc", "embed.hip"), "rb").read()).hexdigest()[:16]
+        if d.get("embed_hip_sha") != sha:
+            return None
+        out = {k: {"raw": v["fetch_bytes_per_row_raw"], "x2": v["fetch_bytes_per_row_x2"]} for k, v in d["cases"].items()}
+        out["_calibration"] = {"sequential_ids_fetch_bytes_per_row_raw": d["cases"]["seq/embed_gather_sum_kernel"]["fetch_bytes_per_row_raw"],
+                               "truth_bytes_per_row": 64, "source": "profiles/r04_gather_pmc.json"}
+        return out
+    except Exception:
+        return None
 
 
 def roofline_probes(model, c, batches, step_fn):
@@ -224,9 +242,34 @@ def roofline_probes(model, c, batches, step_fn):
     t_gather_sum = time_kernel(gather_sum_once, 16, st) if c["F"] <= 4 else None
     gather_alg = n_ids * (4 + 64)
     gather_moved = n_ids * (4 + 128)                              # incl. the materialised row write
-    del gids, gout, gsum
+    # ... and IN-CONFIG: the same two probes on the model's own table with ids drawn over ITS rows --
+    # C3's 212 MB and C1's 16 MB sit inside the 256 MiB Infinity Cache, so this is what the product's gather sees
+    in_config = None
     if gtab is not emb:
         del gtab
+        mV = emb.shape[0]
+        mids = [torch.randint(0, mV, (B, c["T"], c["F"]), device=ids.device, dtype=torch.int32, generator=gen)
+                for _ in range(8)]
+
+        def gather_cfg():
+            ops.embed_gather_seq(mids[k[0] % 8], emb, spec.front_zero, spec.mask_id0, out=gout)
+            k[0] += 1
+
+        def gather_sum_cfg():
+            ops.embed_gather_sum(mids[k[0] % 8], emb, spec.mask_id0, out=gsum)
+            k[0] += 1
+        t_gc = time_kernel(gather_cfg, 16, st)
+        t_gsc = time_kernel(gather_sum_cfg, 16, st) if c["F"] <= 4 else None
+        in_config = {"table_rows": int(mV), "table_bytes": int(mV) * 64,
+                     "materialised": {"ms": t_gc, "achieved": gather_alg / (t_gc * 1e-3) / 1e9,
+                                      "frac": gather_alg / (t_gc * 1e-3) / 1e9 / PEAK_HBM_GBS},
+                     "in_place": None if t_gsc is None else {"ms": t_gsc, "achieved": gather_alg / (t_gsc * 1e-3) / 1e9,
+                                                             "frac": gather_alg / (t_gsc * 1e-3) / 1e9 / PEAK_HBM_GBS},
+                     "unit": "GB/s", "note": "table inside the 256 MiB Infinity Cache: a cache-bandwidth figure, not an HBM one; "
+                                             "at C1's 2.6 MB per step it is launch latency"}
+        del mids
+    del gids, gout, gsum
+    gpmc = gather_pmc_digest()
 
     scan_flops = B * T0 * 2 * H * 3 * H           # recurrent half; the input half is accounted to input_proj
     # (H = 64 at the reference batch runs the chain + feeder variant of the reverse scan, gru_scan_bwd_feed.hip)
@@ -255,7 +298,7 @@ def roofline_probes(model, c, batches, step_fn):
             "achieved": scan_flops / (dom_t * 1e-3) / 1e12, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
             "frac": scan_flops / (dom_t * 1e-3) / 1e12 / PEAK_F32_TFLOPS,
             "traffic": traffic, "traffic_unit": "bytes/launch",
-            "traffic_source": None if pmc is None else "profiles/r03_pmc_summary.json taken at source sha %s "
+            "traffic_source": None if pmc is None else "profiles/r04_pmc_summary.json taken at source sha %s "
                               "(separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x2 gfx950 correction)"
                               % pmc["source_sha"],
             "ms_per_launch": dom_t,
@@ -282,13 +325,17 @@ def roofline_probes(model, c, batches, step_fn):
                    "bytes": "SURVEY 8d algorithmic: 4 B id + 64 B row per id (the row WRITE is not counted)",
                    "moved_GBs_incl_row_write": gather_moved / (t_gather * 1e-3) / 1e9,
                    "table_rows": int(gV), "table_bytes": int(gV) * 64,
-                   "protocol": "8 distinct random id batches rotated inside the timed loop, table >> 256 MiB L3"},
+                   "protocol": "8 distinct random id batches rotated inside the timed loop, table >> 256 MiB L3",
+                   "fetch_bytes_per_row": None if gpmc is None else gpmc.get("cold/embed_gather_seq_kernel")},
         "gather_in_place": None if t_gather_sum is None else {
             "kernel": "embed_gather_sum_kernel", "ms": t_gather_sum, "bound": "hbm",
             "achieved": gather_alg / (t_gather_sum * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
             "frac": gather_alg / (t_gather_sum * 1e-3) / 1e9 / PEAK_HBM_GBS,
             "bytes": "4 B id + 64 B row per lookup: all the traffic of a gather whose rows are consumed, not stored",
-            "protocol": "same cold-cache protocol as `gather`"},
+            "protocol": "same cold-cache protocol as `gather`",
+            "fetch_bytes_per_row": None if gpmc is None else gpmc.get("cold/embed_gather_sum_kernel")},
+        "gather_in_config": in_config,
+        "gather_fetch_calibration": None if gpmc is None else gpmc.get("_calibration"),
         "hbm_bytes_per_step": step_bytes,
         "algorithmic_bytes_train_per_step": alg_train,
         "hbm_over_algorithmic": None if step_bytes is None else step_bytes / alg_train,
@@ -392,9 +439,9 @@ def cpu_baseline(c, seed=0, budget_s=25.0):
     * ``torch.set_flush_denormal(True)``: fresh-init BPTT over 1024 steps produces denormal gradients, TensorFlow's
       CPU kernels run with flush-to-zero, PyTorch's do not by default -- without it a step costs 4-10x more and the
       first steps of a run are outliers;
-    * a thread sweep {1,4,8,16,32} on a batch of 16 (after a warm-up at that batch) picks the thread count;
-    * ONE warm-up step AT THE MEASURED BATCH, then >= 5 timed steps (as many as fit the budget, at most 20), the
-      MEDIAN is the value and every sample is reported; a second run must agree within 10 %."""
+    * ONE warm-up step AT THE MEASURED BATCH (the reference batch), a thread sweep {8,16,32} of one step each at that
+      batch picks the thread count, then >= 5 timed steps (as many as fit the budget, at most 20): the MEDIAN is the
+      value and every sample is reported; a second run must agree within 10 %."""
     from oracle import hpmn_oracle as O
     from oracle import torch_restatement as R
     flush_ok = bool(torch.set_flush_denormal(True))     # (stays on: this is the last leg of the run)
@@ -423,47 +470,55 @@ def cpu_baseline(c, seed=0, budget_s=25.0):
         return time.perf_counter() - t0
 
     ncpu = os.cpu_count() or 1
-    torch.set_num_threads(min(ncpu, 8))
-    train(16)                                  # warm-up (allocator, thread pool, first touch of the table and moments)
-    # Thread sweep on a batch of 16: the restatement dispatches ~25 tiny ops per time step, and a thread pool that is too
-    # wide loses more to fork/join than it gains.  The baseline reported is the best thread count's.
-    sweep = {}
-    for th in (1, 4, 8, 16, 32):
-        if th > ncpu:
-            break
-        torch.set_num_threads(th)
-        sweep[th] = train(16)
-        log("cpu baseline thread sweep: %2d threads, batch 16 train step %.2fs" % (th, sweep[th]))
-    threads = min(sweep, key=sweep.get)
-    torch.set_num_threads(threads)
     bs = c["batch"]
-    warm = train(bs)                           # warm-up AT the measured batch
-    log("cpu baseline: warm-up step batch %d %.2fs on %d threads" % (bs, warm, threads))
-    if warm * 5 > budget_s * 1.6:              # a host too slow for 5 steps of the full batch: bound the batch, say so
-        bs = max(16, int(bs * budget_s / (5.0 * warm)))
+    cands = [th for th in (8, 16, 32) if th <= ncpu] or [ncpu]
+    torch.set_num_threads(cands[len(cands) // 2])
+    # Warm-up AT the measured batch.  The first step of a batch size is not representative even with flush-to-zero on: the
+    # autograd tape of 2032 time steps x ~25 ops x [batch, .] tensors is ~10 GB of fresh heap, page-faulted in once
+    # (r4, driver-class host: 21-23 s for the first step of batch 500 against ~2.4 s for every later one).
+    warm = train(bs)
+    log("cpu baseline: warm-up step batch %d %.2fs" % (bs, warm))
+    if warm > 75.0:                            # a host that cannot do this batch in bounded time: bound the batch, say so
+        bs = max(16, int(bs * 30.0 / warm))
         warm = train(bs)
         log("cpu baseline: batch bounded to %d, warm-up %.2fs" % (bs, warm))
+    # Thread count: the per-time-step ops are tiny at batch 16 and a pool that is too wide loses to fork/join there, but at
+    # the measured batch more threads pay (r4: 4 threads chosen on batch 16 gave 96 sequences/s where 16 gave 127) -- so the
+    # sweep runs AT the measured batch, one step per candidate; near-equal candidates give near-equal values, which keeps
+    # two runs within 10 % whichever of them wins.
+    sweep = {}
+    for th in cands:
+        torch.set_num_threads(th)
+        sweep[th] = train(bs)
+        log("cpu baseline thread sweep: %2d threads, batch %d train step %.2fs" % (th, bs, sweep[th]))
+    threads = min(sweep, key=sweep.get)
+    torch.set_num_threads(threads)
     tt = []
     while len(tt) < 5 or (len(tt) < 20 and sum(tt) + 1.5 * tt[-1] < budget_s):
         tt.append(train(bs))
-    log("cpu baseline: %d train steps batch %d: %s" % (len(tt), bs, " ".join("%.2f" % x for x in tt)))
+    log("cpu baseline: %d train steps batch %d on %d threads: %s" % (len(tt), bs, threads, " ".join("%.2f" % x for x in tt)))
     tf = [fwd(bs) for _ in range(4)][1:]      # (first pass: warm-up of the no-grad path)
     log("cpu baseline: forward batch %d %s" % (bs, " ".join("%.2fs" % x for x in tf)))
-    t1 = sweep.get(1, sweep[threads])
+    torch.set_num_threads(1)
+    train(16)
+    t1 = train(16)
+    torch.set_num_threads(threads)
     med = sorted(tt)[len(tt) // 2]
     medf = sorted(tf)[len(tf) // 2]
     return {"value": bs / med, "unit": "sequences/s", "cores": threads, "kind": "port",
-            "host_cpus": ncpu, "flush_denormal": flush_ok, "batch": bs, "warmup_steps_at_batch": 1,
+            "host_cpus": ncpu, "flush_denormal": flush_ok, "batch": bs, "warmup_steps_at_batch": 1 + len(cands),
+            "warmup_step_seconds": warm,
             "train_step_seconds": tt, "train_step_seconds_median": med,
             "train_step_seconds_spread": (max(tt) - min(tt)) / med,
             "forward_only": {"value": bs / medf, "unit": "sequences/s", "seconds": tf},
             "one_thread": {"value": 16 / t1, "unit": "sequences/s", "cores": 1, "batch": 16, "seconds": t1},
-            "thread_sweep_batch16_seconds": {str(k): v for k, v in sweep.items()},
-            "sample": "median of %d train steps (fwd+BPTT+clip+dense Adam) of batch %d at the full %s shape after one "
-                      "warm-up step at that batch, fp32 PyTorch-CPU eager restatement (oracle/torch_restatement.py), "
-                      "flush-to-zero denormals (as TensorFlow's CPU kernels), %d threads (best of a batch-16 sweep), "
-                      "%.1fs timed in total; forward-only: median of %d passes of the same batch; 1 thread: one train "
-                      "step of batch 16" % (len(tt), bs, c["name"], threads, sum(tt), len(tf))}
+            "thread_sweep_seconds_at_batch": {str(k): v for k, v in sweep.items()},
+            "sample": "median of %d train steps (fwd+BPTT+clip+dense Adam) of batch %d at the full %s shape after a warm-up "
+                      "step at that batch (%.1fs: first-touch of the ~10 GB autograd tape) and a one-step-per-candidate "
+                      "thread sweep at that batch, fp32 PyTorch-CPU eager restatement (oracle/torch_restatement.py), "
+                      "flush-to-zero denormals (as TensorFlow's CPU kernels), %d threads, %.1fs timed in total; forward-only: "
+                      "median of %d passes of the same batch; 1 thread: second of two train steps of batch 16"
+                      % (len(tt), bs, c["name"], warm, threads, sum(tt), len(tf))}
 
 
 def dp_report(model, c, batches, world, ms_per_step, n_model=8, busbw_gbps=300.0):

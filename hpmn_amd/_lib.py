@@ -10,7 +10,7 @@ import os
 from typing import Optional
 
 HPMN_MAX_LAYERS = 12
-HPMN_ABI_VERSION = 9
+HPMN_ABI_VERSION = 10
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libhpmn_hip.so")
@@ -160,6 +160,11 @@ class HpmnOnlineUpdate(C.Structure):
 
 
 # every symbol include/hpmn_hip.h declares: (restype, argtypes)
+class HpmnScatterPlan(C.Structure):
+    _fields_ = [("n", C.c_int64), ("perm", C.c_void_p), ("seg", C.c_void_p), ("start", C.c_void_p), ("rows", C.c_void_p),
+                ("count", C.c_void_p), ("out_rows", C.c_void_p), ("partials", C.c_void_p)]
+
+
 SIGNATURES = {
     "hpmn_abi_version": (C.c_int, []),
     "hpmn_strerror": (C.c_char_p, [C.c_int]),
@@ -212,7 +217,7 @@ SIGNATURES = {
     "hpmn_memory_update": (C.c_int, [C.POINTER(HpmnOnlineUpdate), C.c_void_p]),
     "hpmn_adam_step_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
                                       C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
-    "hpmn_table_mark_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
+    "hpmn_table_mark_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
     "hpmn_adam_step_table": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
                                        C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                        C.c_void_p]),
@@ -244,6 +249,15 @@ SIGNATURES = {
                                  C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                  C.c_void_p]),
 }
+
+
+SIGNATURES.update({
+    "hpmn_scatter_plan": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hpmn_embed_grad_segsum_partials_floats": (C.c_size_t, [C.c_int64, C.c_int32]),
+    "hpmn_embed_grad_segsum": (C.c_int, [C.POINTER(HpmnScatterPlan), C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                         C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
+    "hpmn_train_set_scatter_plan": (C.c_int, [C.c_void_p, C.POINTER(HpmnScatterPlan)]),
+})
 
 
 class HpmnLibraryError(RuntimeError):

@@ -71,11 +71,11 @@ __global__ __launch_bounds__(256) void adam_rows_kernel(float4 *__restrict__ p, 
 // nothing of the step and runs early on another stream; the touched rows follow behind the scatter.
 // (ids outside [0, V) are skipped: padding entries of a gathered id list are -1, and a raw-ABI caller's bad id must not
 //  write outside the flags)
-__global__ __launch_bounds__(256) void table_mark_kernel(const int32_t *__restrict__ ids, long n, uint8_t *__restrict__ flags,
-                                                         long V) {
+__global__ __launch_bounds__(256) void table_mark_kernel(const void *__restrict__ ids, long n, uint8_t *__restrict__ flags,
+                                                         long V, int id_flags) {
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const long id = ids[i];
+        const long id = load_id(ids, i, id_flags);
         if (id >= 0 && id < V) flags[id] = 1;
     }
 }
@@ -109,11 +109,11 @@ __global__ __launch_bounds__(256) void adam_table_kernel(float4 *__restrict__ p,
     }
 }
 
-int table_mark_launch(const int32_t *ids, int64_t n, uint8_t *flags, int64_t V, hipStream_t st) {
+int table_mark_launch(const void *ids, int64_t n, uint8_t *flags, int64_t V, int32_t id_flags, hipStream_t st) {
     if (n == 0) return HPMN_OK;
     long blocks = (n + 255) / 256;
     if (blocks > 256L * 8) blocks = 256L * 8;
-    hipLaunchKernelGGL(table_mark_kernel, dim3((unsigned)blocks), dim3(256), 0, st, ids, (long)n, flags, (long)V);
+    hipLaunchKernelGGL(table_mark_kernel, dim3((unsigned)blocks), dim3(256), 0, st, ids, (long)n, flags, (long)V, (int)id_flags);
     return check_launch();
 }
 

@@ -50,14 +50,20 @@ int read_fwd_bwd_launch_n(const HpmnReadDesc *const *d, int nb, const float *P, 
                           const float *const *last, const int32_t *label, const float *mask1, const float *mask2,
                           float keep_prob, float inv_global_batch, float memory_reg, float *pred, float *loss_out,
                           float *const *d_memory, float *const *d_last, float *d_params, float *workspace, hipStream_t st);
-int embed_gather_launch(const int32_t *ids, int64_t ids_stride, const float *emb, float *out, int64_t N,
+int embed_gather_launch(const void *ids, int64_t ids_stride, const float *emb, float *out, int64_t N,
                         int32_t F, int32_t E, int32_t mask_id0, hipStream_t st);
-int embed_grad_scatter_launch(const int32_t *ids, const float *d_x, float *d_emb, int32_t B, int32_t T,
+int embed_grad_scatter_launch(const void *ids, const float *d_x, float *d_emb, int32_t B, int32_t T,
                               int32_t F, int32_t E, int32_t front_zero, int32_t mask_id0, int32_t t_lo, int32_t t_hi,
                               hipStream_t st, const float *d_last = nullptr, int32_t t_last = 0);
 int adam_launch(float *p, const float *g, float *m, float *v, int64_t n, float lr_t, float b1, float b2,
                 float eps, float clip, float gs, hipStream_t st);
-int table_mark_launch(const int32_t *ids, int64_t n, uint8_t *flags, int64_t V, hipStream_t st);
+int table_mark_launch(const void *ids, int64_t n, uint8_t *flags, int64_t V, int32_t id_flags, hipStream_t st);
+int scatter_plan_launch(const void *sorted_ids, int32_t id_flags, int64_t n, const int32_t *seg, int32_t *start, void *rows,
+                        int32_t *count, hipStream_t st);
+size_t segsum_partials_floats(int64_t n, int32_t E);
+int embed_grad_segsum_launch(const HpmnScatterPlan &p, const float *d_x, float *d_emb, int32_t B, int32_t T, int32_t F,
+                             int32_t E, int32_t front_zero, int32_t id_flags, const float *d_last, int32_t t_last,
+                             hipStream_t st);
 int adam_table_launch(float *p, float *g, float *m, float *v, uint8_t *flags, int64_t V, int E, int pass, float lr_t,
                       float b1, float b2, float eps, float clip, float gs, hipStream_t st);
 int adam_rows_launch(float *p, const float *g, float *m, float *v, const int64_t *row_ids, int64_t n_rows, int E,
@@ -107,7 +113,7 @@ int hpmn_gru_shape_supported(int32_t H, int32_t D) {
     return (gru_shape_supported(H, D) && input_proj_supported(H, D)) ? 1 : 0;
 }
 
-int hpmn_embed_gather(const int32_t *ids, const float *emb, float *out, int64_t N, int32_t F, int32_t E,
+int hpmn_embed_gather(const void *ids, const float *emb, float *out, int64_t N, int32_t F, int32_t E,
                       int64_t V, int32_t mask_id0, void *stream) {
     drop_stale_hip_error();
     if (N < 0 || F < 1 || E < 4 || V < 1) return HPMN_EINVAL;
@@ -169,6 +175,7 @@ int hpmn_gru_scan_bwd(const HpmnGruBwd *a, void *stream) {
         if (!a->scatter_ids || a->Tids < 1 || a->F < 1 || a->front_zero < 0 || a->front_zero + a->Tids != a->T) return HPMN_EINVAL;
         if (a->t_begin != 0 || (a->t_end != 0 && a->t_end != a->T)) return HPMN_EINVAL;
         if (!gru_scan_bwd_fuses_scatter(a->H, a->B, a->D, a->F, a->E)) return HPMN_EUNSUPPORTED;
+        if (a->mask_id0 & HPMN_ID_I64) return HPMN_EUNSUPPORTED;   // the fused scatter reads int32 ids (hpmn_embed_grad_scatter takes both)
     }
     if (a->B == 0) return HPMN_OK;
     HpmnGruBwd k = *a;
@@ -240,7 +247,7 @@ static bool scan_fwd_pairs_ok(const HpmnScanDesc &d, int D0) {
     return on && d.K >= 2 && d.E % 4 == 0 && gru_pair_fwd_supported(d.H, D0, 1);
 }
 
-static int scan_fwd_pairs(const HpmnScanDesc &d, const int32_t *len, const int32_t *ids, const float *emb,
+static int scan_fwd_pairs(const HpmnScanDesc &d, const int32_t *len, const void *ids, const float *emb,
                           const float *const *wg, const float *const *bg, const float *const *wc, const float *const *bc,
                           float *memory, float *last, float *const *ybuf, float *img_base, hipStream_t st) {
     const int D0 = d.F * d.E, K = d.K, H = d.H;
@@ -294,7 +301,7 @@ static int scan_fwd_pairs(const HpmnScanDesc &d, const int32_t *len, const int32
     return HPMN_OK;
 }
 
-int hpmn_scan_fwd(const HpmnScanDesc *d, const int32_t *ids, const float *emb, const float *const *wg,
+int hpmn_scan_fwd(const HpmnScanDesc *d, const void *ids, const float *emb, const float *const *wg,
                   const float *const *bg, const float *const *wc, const float *const *bc, float *memory,
                   float *last, void *workspace, void *stream) {
     drop_stale_hip_error();
@@ -359,7 +366,8 @@ int hpmn_scan_fwd(const HpmnScanDesc *d, const int32_t *ids, const float *emb, c
             hipError_t e = hipMemsetAsync(last, 0, (size_t)d->B * D0 * sizeof(float), st);
             if (e != hipSuccess) { set_last_hip_error((int)e); return HPMN_EHIP; }
         } else {
-            int rc = embed_gather_launch(ids + tid * d->F, (int64_t)d->T * d->F, emb, last, d->B, d->F, d->E,
+            const size_t idw = (d->mask_id0 & HPMN_ID_I64) ? 8 : 4;
+            int rc = embed_gather_launch(static_cast<const char *>(ids) + (size_t)(tid * d->F) * idw, (int64_t)d->T * d->F, emb, last, d->B, d->F, d->E,
                                          d->mask_id0, st);
             if (rc != HPMN_OK) return rc;
         }
@@ -462,7 +470,7 @@ int hpmn_read_param_grads_loss_n(int32_t nb, const HpmnReadDesc *const *desc, fl
                                      memory_reg, loss3);
 }
 
-int hpmn_embed_grad_scatter(const int32_t *ids, const float *d_x, float *d_emb, int32_t B, int32_t T,
+int hpmn_embed_grad_scatter(const void *ids, const float *d_x, float *d_emb, int32_t B, int32_t T,
                             int32_t F, int32_t E, int32_t front_zero, int64_t V, int32_t mask_id0,
                             void *stream) {
     drop_stale_hip_error();
@@ -471,6 +479,30 @@ int hpmn_embed_grad_scatter(const int32_t *ids, const float *d_x, float *d_emb, 
     if (B == 0) return HPMN_OK;
     if (!ids || !d_x || !d_emb) return HPMN_EINVAL;
     return embed_grad_scatter_launch(ids, d_x, d_emb, B, T, F, E, front_zero, mask_id0, 0, T, (hipStream_t)stream);
+}
+
+int hpmn_scatter_plan(const void *sorted_ids, int32_t id_flags, int64_t n, const int32_t *seg, int32_t *start, void *rows,
+                      int32_t *count, void *stream) {
+    drop_stale_hip_error();
+    if (n < 0 || n > 0x7fffffffLL) return HPMN_EINVAL;
+    if (n == 0) return HPMN_OK;
+    if (!sorted_ids || !seg || !start || !rows || !count) return HPMN_EINVAL;
+    return scatter_plan_launch(sorted_ids, id_flags, n, seg, start, rows, count, (hipStream_t)stream);
+}
+
+size_t hpmn_embed_grad_segsum_partials_floats(int64_t n, int32_t E) { return n > 0 && E > 0 ? segsum_partials_floats(n, E) : 0; }
+
+int hpmn_embed_grad_segsum(const HpmnScatterPlan *plan, const float *d_x, float *d_emb, int32_t B, int32_t T, int32_t F,
+                           int32_t E, int32_t front_zero, int32_t id_flags, const float *d_last, int32_t t_last,
+                           void *stream) {
+    drop_stale_hip_error();
+    if (!plan || B < 0 || T < 1 || F < 1 || E < 4 || front_zero < 0) return HPMN_EINVAL;
+    if (E % 4 != 0 || 256 % (E / 4) != 0) return HPMN_EUNSUPPORTED;
+    if (plan->n != (int64_t)B * T * F) return HPMN_EINVAL;
+    if (B == 0) return HPMN_OK;
+    if (!plan->perm || !plan->seg || !plan->start || !plan->rows || !plan->count || !plan->partials || !d_x) return HPMN_EINVAL;
+    if (!plan->out_rows && !d_emb) return HPMN_EINVAL;
+    return embed_grad_segsum_launch(*plan, d_x, d_emb, B, T, F, E, front_zero, id_flags, d_last, t_last, (hipStream_t)stream);
 }
 
 int hpmn_adam_step(float *param, const float *grad, float *m, float *v, int64_t n, float lr_t, float beta1,
@@ -494,12 +526,12 @@ int hpmn_adam_step_rows(float *param, const float *grad_rows, float *m, float *v
                             (hipStream_t)stream);
 }
 
-int hpmn_table_mark_rows(const int32_t *ids, int64_t n_ids, uint8_t *flags, int64_t V, void *stream) {
+int hpmn_table_mark_rows(const void *ids, int64_t n_ids, uint8_t *flags, int64_t V, int32_t id_flags, void *stream) {
     drop_stale_hip_error();
     if (n_ids < 0 || V < 1) return HPMN_EINVAL;
     if (n_ids == 0) return HPMN_OK;
     if (!ids || !flags) return HPMN_EINVAL;
-    return table_mark_launch(ids, n_ids, flags, V, (hipStream_t)stream);
+    return table_mark_launch(ids, n_ids, flags, V, id_flags, (hipStream_t)stream);
 }
 
 int hpmn_adam_step_table(float *param, float *grad, float *m, float *v, uint8_t *flags, int64_t V, int32_t E,

@@ -49,6 +49,15 @@ __device__ __forceinline__ float tanh_scaled(float z2) {
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
+// Table ids arrive as int32 or -- for tables beyond 2^31 - 1 rows (BASELINE configs[4] sized to HBM) -- int64: bit
+// HPMN_ID_I64 of the id-flags word every entry point with ids carries (bit HPMN_ID_MASK0 is the id-0 mask of
+// code/hpmn.py:417-422).  The flag is a kernel argument, so the branch is wave-uniform (s_cbranch around two loads); row
+// arithmetic is 64-bit everywhere.
+__device__ __forceinline__ long load_id(const void *__restrict__ ids, long i, int id_flags) {
+    return (id_flags & HPMN_ID_I64) ? reinterpret_cast<const long *>(ids)[i] : (long)reinterpret_cast<const int *>(ids)[i];
+}
+__device__ __forceinline__ bool id_masked(long id, int id_flags) { return (id_flags & HPMN_ID_MASK0) && id == 0; }
+
 // Progress counters between the waves of a workgroup live in LDS and MUST be accessed as LDS: a `volatile int *`
 // parameter is a GENERIC pointer, for which hipcc emits flat_load/flat_store ... sc0 sc1 followed by
 // s_waitcnt vmcnt(0) lgkmcnt(0) -- every poll then drains every outstanding global store of the wave (seen in the

@@ -13,7 +13,7 @@
 namespace hpmn {
 
 // out[n, f*E + e] = emb[ids[n,f], e] * (mask ? ids != 0 : 1);   one float4 per thread.
-__global__ __launch_bounds__(256) void embed_gather_kernel(const int32_t *__restrict__ ids,
+__global__ __launch_bounds__(256) void embed_gather_kernel(const void *__restrict__ ids,
                                                            const float *__restrict__ emb,
                                                            float *__restrict__ out, long total4,
                                                            int E4, int F, long ids_stride, int mask_id0) {
@@ -23,10 +23,10 @@ __global__ __launch_bounds__(256) void embed_gather_kernel(const int32_t *__rest
         const long row = i / E4;
         const int e4 = (int)(i - row * E4);
         const long n = row / F;
-        const int id = ids[n * ids_stride + (row - n * F)];
+        const long id = load_id(ids, n * ids_stride + (row - n * F), mask_id0);
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (!(mask_id0 && id == 0))
-            v = reinterpret_cast<const float4 *>(emb)[(long)id * E4 + e4];
+        if (!id_masked(id, mask_id0))
+            v = reinterpret_cast<const float4 *>(emb)[id * E4 + e4];
         reinterpret_cast<float4 *>(out)[i] = v;
     }
 }
@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void embed_gather_kernel(const int32_t *__rest
 constexpr int SCU = 8;      // steps per load chunk
 constexpr int SSEG = 128;   // steps per wave
 __global__ __launch_bounds__(64) void embed_grad_scatter_kernel(
-    const int32_t *__restrict__ ids, const float *__restrict__ d_x, float *__restrict__ d_emb, int B,
+    const void *__restrict__ ids, const float *__restrict__ d_x, float *__restrict__ d_emb, int B,
     int T, int F, int E, int front_zero, int mask_id0, int groups, int nseg, int t_lo, int t_hi,
     const float *__restrict__ d_last, int t_last) {
     const int cpw = 64 / E;                          // id columns per wave
@@ -53,12 +53,12 @@ __global__ __launch_bounds__(64) void embed_grad_scatter_kernel(
     const int Dx = F * E;
     const int t_begin = t_lo + seg * SSEG;
     const int t_end = (t_begin + SSEG) < t_hi ? (t_begin + SSEG) : t_hi;
-    const int32_t *idp = ids + (b * T) * F + f;
+    const long idp = (b * T) * F + f;               // index of ids[b, 0, f]
     const float *gp = d_x + (b * (long)(front_zero + T) + front_zero) * Dx + f * E + e;
-    int run_id = -1;
+    long run_id = -1;
     float acc = 0.f;
     for (int t0 = t_begin; t0 < t_end; t0 += SCU) {
-        int idv[SCU];
+        long idv[SCU];
         float gv[SCU];
 #pragma unroll
         for (int i = 0; i < SCU; ++i) {
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(64) void embed_grad_scatter_kernel(
             idv[i] = -1;
             gv[i] = 0.f;
             if (t < t_end) {
-                idv[i] = idp[(long)t * F];
+                idv[i] = load_id(ids, idp + (long)t * F, mask_id0);
                 gv[i] = gp[(long)t * Dx];
                 // the read path's gradient wrt uinp[:, last_index, :] joins the scan's at that step (instead of a
                 // row-add launch of its own in front of this one)
@@ -77,15 +77,15 @@ __global__ __launch_bounds__(64) void embed_grad_scatter_kernel(
         for (int i = 0; i < SCU; ++i) {
             if (idv[i] < 0) continue;
             if (idv[i] != run_id) {
-                if (run_id >= 0 && !(mask_id0 && run_id == 0))
-                    atomicAdd(d_emb + (long)run_id * E + e, acc);
+                if (run_id >= 0 && !id_masked(run_id, mask_id0))
+                    atomicAdd(d_emb + run_id * E + e, acc);
                 run_id = idv[i];
                 acc = 0.f;
             }
             acc += gv[i];
         }
     }
-    if (run_id >= 0 && !(mask_id0 && run_id == 0)) atomicAdd(d_emb + (long)run_id * E + e, acc);
+    if (run_id >= 0 && !id_masked(run_id, mask_id0)) atomicAdd(d_emb + run_id * E + e, acc);
 }
 
 // The gather CONSUMED IN PLACE: out[b, f*E + e] = sum_t emb[ids[b,t,f], e] (mask as above) -- the pooled form of
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(64) void embed_grad_scatter_kernel(
 // lookup is ALL the traffic there is, where the materialising gather above also writes every row back out.
 // One workgroup per (sequence, slice of t); lane = (row slot, float4 of the row); rows of 8 steps in flight per lane.
 constexpr int GRU_ = 8;
-__global__ __launch_bounds__(256) void embed_gather_sum_kernel(const int32_t *__restrict__ ids, const float *__restrict__ emb,
+__global__ __launch_bounds__(256) void embed_gather_sum_kernel(const void *__restrict__ ids, const float *__restrict__ emb,
                                                                float *__restrict__ out, int T, int F, int E4, int mask_id0,
                                                                int slices) {
     const long b = blockIdx.x / slices;
@@ -103,24 +103,24 @@ __global__ __launch_bounds__(256) void embed_gather_sum_kernel(const int32_t *__
     const int per = (rows + slices - 1) / slices;
     const int r0 = sl * per, r1 = (r0 + per) < rows ? (r0 + per) : rows;
     const int e4 = threadIdx.x % E4, slot = threadIdx.x / E4, nslot = 256 / E4;
-    const int32_t *idb = ids + b * (long)rows;
+    const long idb = b * (long)rows;                     // index of this sequence's first lookup
     // a lane only ever sees lookups r with r % F == f0 when nslot % F == 0: one accumulator per lane then belongs to one id
     // column; otherwise accumulate per column in F partial sums
     float4 acc[4];
 #pragma unroll
     for (int f = 0; f < 4; ++f) acc[f] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int r = r0 + slot; r < r1; r += nslot * GRU_) {
-        int id[GRU_];
+        long id[GRU_];
 #pragma unroll
         for (int u = 0; u < GRU_; ++u) {
             const int rr = r + u * nslot;
-            id[u] = rr < r1 ? idb[rr] : -1;
+            id[u] = rr < r1 ? load_id(ids, idb + rr, mask_id0) : -1;
         }
         float4 v[GRU_];
 #pragma unroll
         for (int u = 0; u < GRU_; ++u) {
-            const bool keep = id[u] >= 0 && !(mask_id0 && id[u] == 0);
-            v[u] = keep ? reinterpret_cast<const float4 *>(emb)[(long)id[u] * E4 + e4] : make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool keep = id[u] >= 0 && !id_masked(id[u], mask_id0);
+            v[u] = keep ? reinterpret_cast<const float4 *>(emb)[id[u] * E4 + e4] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int u = 0; u < GRU_; ++u) {
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void embed_gather_sum_kernel(const int32_t *__
 }
 
 // out [B, F*E] must be zeroed by the caller
-int embed_gather_sum_launch(const int32_t *ids, const float *emb, float *out, int32_t B, int32_t T, int32_t F, int32_t E,
+int embed_gather_sum_launch(const void *ids, const float *emb, float *out, int32_t B, int32_t T, int32_t F, int32_t E,
                             int32_t mask_id0, hipStream_t st) {
     // a row's E/4 float4 lanes must sit inside one wave (part[][][64], the xor-shuffles): E <= 256
     if (F > 4 || E % 4 != 0 || E / 4 > 64 || 64 % (E / 4) != 0) return HPMN_EUNSUPPORTED;
@@ -166,7 +166,7 @@ int embed_gather_sum_launch(const int32_t *ids, const float *emb, float *out, in
     return check_launch();
 }
 
-int embed_gather_launch(const int32_t *ids, int64_t ids_stride, const float *emb, float *out, int64_t N,
+int embed_gather_launch(const void *ids, int64_t ids_stride, const float *emb, float *out, int64_t N,
                         int32_t F, int32_t E, int32_t mask_id0, hipStream_t st) {
     const long total4 = (long)N * F * (E / 4);
     if (total4 == 0) return HPMN_OK;
@@ -179,7 +179,7 @@ int embed_gather_launch(const int32_t *ids, int64_t ids_stride, const float *emb
 
 // steps [t_lo, t_hi) of every sequence (ids time; t_hi == 0: T)
 // d_last [B, F*E] (optional): added to the gradient rows of ids step t_last
-int embed_grad_scatter_launch(const int32_t *ids, const float *d_x, float *d_emb, int32_t B, int32_t T,
+int embed_grad_scatter_launch(const void *ids, const float *d_x, float *d_emb, int32_t B, int32_t T,
                               int32_t F, int32_t E, int32_t front_zero, int32_t mask_id0, int32_t t_lo, int32_t t_hi,
                               hipStream_t st, const float *d_last, int32_t t_last) {
     if (t_hi <= 0 || t_hi > T) t_hi = T;

@@ -10,7 +10,7 @@ struct All32Args {
     int32_t B, Tids, F, E, K, front_zero, mask_id0, last_t;
     int64_t V;
     int32_t period[AMAXK], len[AMAXK];
-    const int32_t *ids;
+    const void *ids;
     const float *emb;
     const float *wg[AMAXK], *bg[AMAXK], *wc[AMAXK], *bc[AMAXK];
     float *memory;               // [B, K, 32]
@@ -38,7 +38,7 @@ inline bool gru32_all_enabled() {
     return on != 0;
 }
 
-inline void gru32_all_fill(All32Args &a, const HpmnScanDesc &d, const int32_t *len, const int32_t *ids, const float *emb,
+inline void gru32_all_fill(All32Args &a, const HpmnScanDesc &d, const int32_t *len, const void *ids, const float *emb,
                            const float *const *wg, const float *const *bg, const float *const *wc, const float *const *bc,
                            float *memory, float *last) {
     a.B = d.B; a.Tids = d.T; a.F = d.F; a.E = d.E; a.K = d.K; a.front_zero = d.front_zero; a.mask_id0 = d.mask_id0;

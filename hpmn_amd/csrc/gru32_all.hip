@@ -198,22 +198,22 @@ __device__ __forceinline__ void all32_loader(const All32Args &a, const long b, c
     float bcc = h == 0 ? a.bc[0][j] * (2.0f * NEG_LOG2E) : 0.f;
     settle(br); settle(bu); settle(bcc);
     const int f = live ? lane / a.E : 0, e = live ? lane % a.E : 0;
-    const int32_t *idb = a.ids + b * (long)a.Tids * a.F + f;
+    const long idb = b * (long)a.Tids * a.F + f;      // index of ids[b, 0, f]
     constexpr int LB = 4;                               // steps per batch of loads in flight
     int taken = 0;
-    auto fetch_ids = [&](int t0, int (&id)[LB]) {
+    auto fetch_ids = [&](int t0, long (&id)[LB]) {
 #pragma unroll
         for (int s = 0; s < LB; ++s) {
             int ti = t0 + s - a.front_zero;
             ti = ti < 0 ? 0 : (ti < a.Tids ? ti : a.Tids - 1);
-            id[s] = idb[(long)ti * a.F];
+            id[s] = load_id(a.ids, idb + (long)ti * a.F, a.mask_id0);
         }
     };
-    auto fetch_rows = [&](const int (&id)[LB], float (&v)[LB]) {
+    auto fetch_rows = [&](const long (&id)[LB], float (&v)[LB]) {
 #pragma unroll
-        for (int s = 0; s < LB; ++s) v[s] = a.emb[(long)id[s] * a.E + e];
+        for (int s = 0; s < LB; ++s) v[s] = a.emb[id[s] * a.E + e];
     };
-    int idA[LB], idB[LB];
+    long idA[LB], idB[LB];
     float vA[LB];
     fetch_ids(0, idA);
     fetch_ids(LB, idB);
@@ -222,7 +222,7 @@ __device__ __forceinline__ void all32_loader(const All32Args &a, const long b, c
         // idA / vA: this batch; idB: the next batch's ids (its rows are requested now, used next iteration)
         float vB[LB];
         fetch_rows(idB, vB);
-        int idC[LB];
+        long idC[LB];
         fetch_ids(t0 + 2 * LB, idC);
 #pragma unroll
         for (int s = 0; s < LB; ++s) {
@@ -233,7 +233,7 @@ __device__ __forceinline__ void all32_loader(const All32Args &a, const long b, c
                     if (t - taken >= AXR) __builtin_amdgcn_s_sleep(2);
                 }
                 asm volatile("" ::: "memory");
-                const bool keep = t >= a.front_zero && !(a.mask_id0 && idA[s] == 0);
+                const bool keep = t >= a.front_zero && !id_masked(idA[s], a.mask_id0);
                 const float v = keep ? vA[s] : 0.f;
                 if (live) {
                     xrow[lane] = v;

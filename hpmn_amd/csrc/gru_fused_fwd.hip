@@ -148,9 +148,9 @@ __global__ __launch_bounds__(HELP ? 192 : 128, 1) void gru_fused_fwd_kernel(cons
         const int l = lane < D ? lane : D - 1;          // lanes past D repeat the last column (never used)
         // input stream: block of FBLK steps, rows one block ahead, ids two blocks ahead
         float xq[FBLK], xn[FBLK];
-        int idn[FBLK];
+        long idn[FBLK];
         bool keep_q[FBLK], keep_n[FBLK];
-        auto fetch_ids = [&](int t0, int (&id)[FBLK]) {
+        auto fetch_ids = [&](int t0, long (&id)[FBLK]) {
             if constexpr (GATHER) {
                 const int f = l / a.E;
 #pragma unroll
@@ -158,26 +158,26 @@ __global__ __launch_bounds__(HELP ? 192 : 128, 1) void gru_fused_fwd_kernel(cons
                     int t = t0 + i;
                     t = t < T ? t : T - 1;
                     const int ti = t - a.front_zero;
-                    id[i] = a.ids[(b * a.Tids + (ti > 0 ? ti : 0)) * a.F + f];      // clamped address, never examined here
+                    id[i] = load_id(a.ids, (b * (long)a.Tids + (ti > 0 ? ti : 0)) * a.F + f, a.mask_id0);      // clamped address, never examined here
                 }
             }
         };
-        auto fetch_rows = [&](int t0, const int (&id)[FBLK], float (&x)[FBLK], bool (&keep)[FBLK]) {
+        auto fetch_rows = [&](int t0, const long (&id)[FBLK], float (&x)[FBLK], bool (&keep)[FBLK]) {
 #pragma unroll
             for (int i = 0; i < FBLK; ++i) {
                 int t = t0 + i;
                 t = t < T ? t : T - 1;
                 if constexpr (GATHER) {
                     const int e = l % a.E;
-                    x[i] = a.emb[(long)id[i] * a.E + e];
-                    keep[i] = (t >= a.front_zero) && !(a.mask_id0 && id[i] == 0);
+                    x[i] = a.emb[id[i] * a.E + e];
+                    keep[i] = (t >= a.front_zero) && !id_masked(id[i], a.mask_id0);
                 } else {
                     x[i] = a.x[(b * (long)T + t) * D + l];
                     keep[i] = true;
                 }
             }
         };
-        int id0[FBLK];
+        long id0[FBLK];
         fetch_ids(0, id0);
         fetch_ids(FBLK, idn);
         fetch_rows(0, id0, xq, keep_q);

@@ -111,25 +111,25 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_mfma_kernel(const HpmnGruFused
 
         struct Rows { v4f v[NJ]; bool keep[NJ]; };
         // lane (n16, g) of block s0: step s0 + n16, features 16 kq + 4 g .. + 3
-        auto fetch_ids = [&](int s0, int (&id)[NJ]) {
+        auto fetch_ids = [&](int s0, long (&id)[NJ]) {
             if constexpr (GATHER) {
                 int t = s0 + n16;
                 t = t < T ? t : T - 1;
                 const int ti = t - a.front_zero;
 #pragma unroll
                 for (int kq = 0; kq < NJ; ++kq)
-                    id[kq] = a.ids[(b * a.Tids + (ti > 0 ? ti : 0)) * a.F + (16 * kq + 4 * g) / a.E];   // clamped, never examined here
+                    id[kq] = load_id(a.ids, (b * (long)a.Tids + (ti > 0 ? ti : 0)) * a.F + (16 * kq + 4 * g) / a.E, a.mask_id0);   // clamped, never examined here
             }
         };
-        auto fetch_rows = [&](int s0, const int (&id)[NJ], Rows &r) {
+        auto fetch_rows = [&](int s0, const long (&id)[NJ], Rows &r) {
             int t = s0 + n16;
             t = t < T ? t : T - 1;
 #pragma unroll
             for (int kq = 0; kq < NJ; ++kq) {
                 const int e0 = 16 * kq + 4 * g;
                 if constexpr (GATHER) {
-                    r.v[kq] = *reinterpret_cast<const v4f *>(a.emb + (long)id[kq] * a.E + e0 % a.E);
-                    r.keep[kq] = (t >= a.front_zero) && !(a.mask_id0 && id[kq] == 0);
+                    r.v[kq] = *reinterpret_cast<const v4f *>(a.emb + id[kq] * a.E + e0 % a.E);
+                    r.keep[kq] = (t >= a.front_zero) && !id_masked(id[kq], a.mask_id0);
                 } else {
                     r.v[kq] = *reinterpret_cast<const v4f *>(a.x + (b * (long)T + t) * D + e0);
                     r.keep[kq] = true;
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_mfma_kernel(const HpmnGruFused
             *reinterpret_cast<f4v *>(&ring[(s0 + n16) & (MRING - 1)][16 * ct + 4 * g]) = acc;
         };
 
-        int idA[NJ], idB[NJ];
+        long idA[NJ], idB[NJ];
         Rows rA, rB;
         // block 0 before the loop
         {

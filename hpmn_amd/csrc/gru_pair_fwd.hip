@@ -166,25 +166,25 @@ __device__ __forceinline__ void pair_producer_wave(const HpmnGruFusedFwd &a, Seq
     const float *bimg = wimg + (long)QNT * NJ * 256 + lane;                    // bias of tile ct at [ct * 64]
 
     struct Rows { v4f v[NJ]; bool keep[NJ]; };
-    auto fetch_ids = [&](int s0, int (&id)[NJ]) {
+    auto fetch_ids = [&](int s0, long (&id)[NJ]) {
         if constexpr (SRC == SRC_GATHER) {
             int t = s0 + n16;
             t = t < T ? t : T - 1;
             const int ti = t - a.front_zero;
 #pragma unroll
             for (int kq = 0; kq < NJ; ++kq)
-                id[kq] = a.ids[(b * a.Tids + (ti > 0 ? ti : 0)) * a.F + (16 * kq + 4 * g) / a.E];
+                id[kq] = load_id(a.ids, (b * (long)a.Tids + (ti > 0 ? ti : 0)) * a.F + (16 * kq + 4 * g) / a.E, a.mask_id0);
         }
     };
-    auto fetch_rows = [&](int s0, const int (&id)[NJ], Rows &r) {
+    auto fetch_rows = [&](int s0, const long (&id)[NJ], Rows &r) {
         int t = s0 + n16;
         t = t < T ? t : T - 1;
 #pragma unroll
         for (int kq = 0; kq < NJ; ++kq) {
             const int e0 = 16 * kq + 4 * g;
             if constexpr (SRC == SRC_GATHER) {
-                r.v[kq] = *reinterpret_cast<const v4f *>(a.emb + (long)id[kq] * a.E + e0 % a.E);
-                r.keep[kq] = (t >= a.front_zero) && !(a.mask_id0 && id[kq] == 0);
+                r.v[kq] = *reinterpret_cast<const v4f *>(a.emb + id[kq] * a.E + e0 % a.E);
+                r.keep[kq] = (t >= a.front_zero) && !id_masked(id[kq], a.mask_id0);
             } else if constexpr (SRC == SRC_GLOBAL) {
                 r.v[kq] = *reinterpret_cast<const v4f *>(a.x + (b * (long)T + t) * D + e0);
                 r.keep[kq] = true;
@@ -203,7 +203,7 @@ __device__ __forceinline__ void pair_producer_wave(const HpmnGruFusedFwd &a, Seq
             if (y_seen < need) __builtin_amdgcn_s_sleep(8);
         }
         asm volatile("" ::: "memory");
-        int none[NJ];
+        long none[NJ];
         fetch_rows(s0, none, r);
         lds_counter_set(&yi->taken, need);            // (LDS executes a wave's operations in order: the reads are done)
     };
@@ -244,7 +244,7 @@ __device__ __forceinline__ void pair_producer_wave(const HpmnGruFusedFwd &a, Seq
         return acc;
     };
 
-    int idA[NJ], idB[NJ];
+    long idA[NJ], idB[NJ];
     Rows rA, rB;
     q4 wT[NJ];          // WIMG: the A operands of the tile the next iteration issues
     float bT = 0.f;

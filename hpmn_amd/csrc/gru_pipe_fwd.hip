@@ -405,7 +405,7 @@ __global__ __launch_bounds__(FWD_THREADS, 1) void gru_pipe_fwd_kernel(const Pipe
 // x0[b, t, :] = (t < front_zero) ? 0 : emb[ids[b, t - front_zero, f]] * (mask ? id != 0 : 1) -- the layer-0 input
 // rows (Hpmn.embedding, code/hpmn.py:414-423 / :266-276, with the zero prefix of :288-289), one float4 per thread:
 // E/4 adjacent lanes move one 64-byte table row, the id stream is read coalesced.
-__global__ __launch_bounds__(256) void embed_gather_seq_kernel(const int32_t *__restrict__ ids,
+__global__ __launch_bounds__(256) void embed_gather_seq_kernel(const void *__restrict__ ids,
                                                                const float *__restrict__ emb, float *__restrict__ out,
                                                                long total4, int E4, int F, int Tids, int front_zero,
                                                                int mask_id0) {
@@ -415,7 +415,8 @@ __global__ __launch_bounds__(256) void embed_gather_seq_kernel(const int32_t *__
     const long stride = (long)gridDim.x * blockDim.x;
     const int T0 = Tids + front_zero;
     for (long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x; i0 < total4; i0 += U * stride) {
-        int id[U], e4[U];
+        long id[U];
+        int e4[U];
         bool real[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -428,21 +429,21 @@ __global__ __launch_bounds__(256) void embed_gather_seq_kernel(const int32_t *__
             const long bb = bt / T0;
             const int t = (int)(bt - bb * T0) - front_zero;
             real[u] = t >= 0;
-            id[u] = ids[(bb * Tids + (t >= 0 ? t : 0)) * F + f];
+            id[u] = load_id(ids, (bb * Tids + (t >= 0 ? t : 0)) * F + f, mask_id0);
         }
         float4 v[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) v[u] = reinterpret_cast<const float4 *>(emb)[(long)id[u] * E4 + e4[u]];
+        for (int u = 0; u < U; ++u) v[u] = reinterpret_cast<const float4 *>(emb)[id[u] * E4 + e4[u]];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const long i = i0 + u * stride;
-            if (!real[u] || (mask_id0 && id[u] == 0)) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!real[u] || id_masked(id[u], mask_id0)) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (i < total4) reinterpret_cast<float4 *>(out)[i] = v[u];
         }
     }
 }
 
-int embed_gather_seq_launch(const int32_t *ids, const float *emb, float *out, int B, int Tids, int F, int E,
+int embed_gather_seq_launch(const void *ids, const float *emb, float *out, int B, int Tids, int F, int E,
                             int front_zero, int mask_id0, hipStream_t st) {
     const long total4 = (long)B * (Tids + front_zero) * F * E / 4;
     if (total4 == 0) return HPMN_OK;

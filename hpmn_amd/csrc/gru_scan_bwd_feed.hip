@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256, 1) void gru_scan_bwd_feed_kernel(const HpmnGru
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) { run_id[ct] = -1; run_acc[ct] = f4m{0.f, 0.f, 0.f, 0.f}; }
         auto flush = [&](int ct) {
-            if (run_id[ct] >= 0 && j == 0 && !(a.mask_id0 && run_id[ct] == 0)) {
+            if (run_id[ct] >= 0 && j == 0 && !((a.mask_id0 & HPMN_ID_MASK0) && run_id[ct] == 0)) {
                 float *row = a.d_emb + (long)run_id[ct] * 16 + 4 * g;
                 atomicAdd(row, run_acc[ct][0]); atomicAdd(row + 1, run_acc[ct][1]);
                 atomicAdd(row + 2, run_acc[ct][2]); atomicAdd(row + 3, run_acc[ct][3]);
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256, 1) void gru_scan_bwd_feed_kernel(const HpmnGru
                     }
                     const int ti = t - a.front_zero;
                     const bool valid = tr < nsteps && ti >= 0;
-                    const int id = valid ? a.scatter_ids[(b * (long)a.Tids + ti) * a.F + ct] : -2;
+                    const int id = valid ? reinterpret_cast<const int *>(a.scatter_ids)[(b * (long)a.Tids + ti) * a.F + ct] : -2;   // (int32 ids only: api.hip)
                     const int id0 = __builtin_amdgcn_readfirstlane(id);
                     const bool uniform = __builtin_amdgcn_ballot_w64(id != id0) == 0;     // (wave-uniform)
                     if (uniform && id0 >= 0) {
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256, 1) void gru_scan_bwd_feed_kernel(const HpmnGru
                         run_acc[ct] += sum;
                     } else {
                         flush(ct);
-                        if (valid && !(a.mask_id0 && id == 0)) {
+                        if (valid && !((a.mask_id0 & HPMN_ID_MASK0) && id == 0)) {
                             float *row = a.d_emb + (long)id * 16 + 4 * g;
                             atomicAdd(row, acc[0]); atomicAdd(row + 1, acc[1]); atomicAdd(row + 2, acc[2]); atomicAdd(row + 3, acc[3]);
                         }

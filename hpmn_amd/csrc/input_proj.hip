@@ -80,25 +80,25 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void input_proj_kernel(const Hpmn
     // kernel was latency-bound at 1.2 TB/s without its stores).
     // (load_ids must not LOOK at the ids it loads -- a compare would wait for them on the spot: the address
     // is clamped instead and "this row is all zero" travels in `live`; the id-0 mask is applied in load_rows)
-    auto load_ids = [&](unsigned tile, int (&id)[Q], bool &live) {
+    auto load_ids = [&](unsigned tile, long (&id)[Q], bool &live) {
         const unsigned m = flat_row(tile_row(tile));
         const unsigned b = m / (unsigned)a.T;
         const int t = (int)(m - b * a.T) - a.front_zero;
         live = t >= 0;
         const long base = ((long)b * a.Tids + (live ? t : 0)) * a.F;
 #pragma unroll
-        for (int q = 0; q < Q; ++q) id[q] = a.ids[base + (p * KH + 4 * q) / a.E];
+        for (int q = 0; q < Q; ++q) id[q] = load_id(a.ids, base + (p * KH + 4 * q) / a.E, a.mask_id0);
     };
     // rows are loaded UNCONDITIONALLY (every id read from the clamped address is a valid row) and zeroed by
     // `keep` bits when they are consumed: conditional loads put branches and full vmcnt waits into the loop
-    auto load_rows = [&](const int (&id)[Q], bool live, float4 (&v)[Q], unsigned &keep) {
+    auto load_rows = [&](const long (&id)[Q], bool live, float4 (&v)[Q], unsigned &keep) {
         keep = 0;
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
             const int j = p * KH + 4 * q;
             const int f = j / a.E;
-            v[q] = *reinterpret_cast<const float4 *>(a.emb + (long)id[q] * a.E + (j - f * a.E));
-            keep |= (live && !(a.mask_id0 && id[q] == 0)) ? (1u << q) : 0u;
+            v[q] = *reinterpret_cast<const float4 *>(a.emb + id[q] * a.E + (j - f * a.E));
+            keep |= (live && !id_masked(id[q], a.mask_id0)) ? (1u << q) : 0u;
         }
     };
     auto load_x = [&](unsigned tile, float4 (&v)[Q]) {
@@ -108,11 +108,11 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void input_proj_kernel(const Hpmn
     };
 
     float4 cur[Q], nxt[Q], nx2[Q];
-    int idn[Q];                         // ids of the tile whose rows are fetched next
+    long idn[Q];                        // ids of the tile whose rows are fetched next
     bool liven = false;
     unsigned kcur = ~0u, knxt = ~0u, knx2 = ~0u;   // per-stage keep bits (GATHER only)
     if constexpr (GATHER) {
-        int id0[Q];
+        long id0[Q];
         bool live0;
         load_ids(wave_id, id0, live0);
         load_ids(wave_id + nwave, idn, liven);

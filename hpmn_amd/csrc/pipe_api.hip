@@ -2,13 +2,13 @@
 #include "pipe_common.h"
 
 namespace hpmn {
-int embed_gather_sum_launch(const int32_t *ids, const float *emb, float *out, int32_t B, int32_t T, int32_t F, int32_t E,
+int embed_gather_sum_launch(const void *ids, const float *emb, float *out, int32_t B, int32_t T, int32_t F, int32_t E,
                             int32_t mask_id0, hipStream_t st);
 size_t pipe_sync_bytes(int K, int ntiles);
 bool pipe_shape_supported(int H, int D);
 int pipe_fwd_launch(const PipeArgs &a, int num_cus, hipStream_t st);
 int pipe_bwd_launch(const PipeArgs &a, int num_cus, hipStream_t st);
-int embed_gather_seq_launch(const int32_t *ids, const float *emb, float *out, int B, int Tids, int F, int E,
+int embed_gather_seq_launch(const void *ids, const float *emb, float *out, int B, int Tids, int F, int E,
                             int front_zero, int mask_id0, hipStream_t st);
 
 static constexpr size_t DUMP_BYTES = 16384;   // 256 lanes x 16 B, plus the +2H float offsets of the gate stores
@@ -98,7 +98,7 @@ int hpmn_pipe_bwd(const HpmnPipe *p, void *stream) {
     return pipe_bwd_launch(a, device_cus(), (hipStream_t)stream);
 }
 
-int hpmn_embed_gather_seq(const int32_t *ids, const float *emb, float *out, int32_t B, int32_t Tids, int32_t F,
+int hpmn_embed_gather_seq(const void *ids, const float *emb, float *out, int32_t B, int32_t Tids, int32_t F,
                           int32_t E, int32_t front_zero, int64_t V, int32_t mask_id0, void *stream) {
     (void)hipGetLastError();
     if (B < 0 || Tids < 1 || F < 1 || E < 4 || front_zero < 0 || V < 1) return HPMN_EINVAL;
@@ -109,7 +109,7 @@ int hpmn_embed_gather_seq(const int32_t *ids, const float *emb, float *out, int3
 }
 
 /* out[b, f*E:(f+1)*E] += sum_t emb[ids[b,t,f]] (id-0 mask as in hpmn_embed_gather): the gather consumed in place. */
-int hpmn_embed_gather_sum(const int32_t *ids, const float *emb, float *out, int32_t B, int32_t T, int32_t F, int32_t E,
+int hpmn_embed_gather_sum(const void *ids, const float *emb, float *out, int32_t B, int32_t T, int32_t F, int32_t E,
                           int64_t V, int32_t mask_id0, void *stream) {
     (void)hipGetLastError();
     if (B < 0 || T < 1 || F < 1 || E < 4 || V < 1) return HPMN_EINVAL;

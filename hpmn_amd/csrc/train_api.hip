@@ -9,7 +9,7 @@
 #include "common.h"
 
 namespace hpmn {
-int embed_gather_launch(const int32_t *ids, int64_t ids_stride, const float *emb, float *out, int64_t N, int32_t F,
+int embed_gather_launch(const void *ids, int64_t ids_stride, const float *emb, float *out, int64_t N, int32_t F,
                         int32_t E, int32_t mask_id0, hipStream_t st);
 bool gru_fused_fwd_supported(int H, int D, int gather);
 bool gru_fused_fwd_writes_last();
@@ -23,7 +23,7 @@ size_t gru_wgrad_workspace_bytes(int B, int T, int D, int H);
 bool gru_scan_bwd_fuses_dx(int H, int B);
 bool gru_scan_bwd_dx_width_ok(int D);
 bool gru_scan_bwd_fuses_scatter(int H, int B, int D, int F, int E);
-int embed_grad_scatter_launch(const int32_t *ids, const float *d_x, float *d_emb, int32_t B, int32_t T,
+int embed_grad_scatter_launch(const void *ids, const float *d_x, float *d_emb, int32_t B, int32_t T,
                               int32_t F, int32_t E, int32_t front_zero, int32_t mask_id0, int32_t t_lo, int32_t t_hi,
                               hipStream_t st, const float *d_last = nullptr, int32_t t_last = 0);
 
@@ -36,7 +36,26 @@ struct TrainCtx {
     bool pending = false, probe = false, probed = false;
     hipEvent_t l0_start = nullptr;                       // (recorded in front of layer 0's reverse launch, on request)
     bool mark_l0 = false, l0_marked = false;
+    HpmnScatterPlan plan = {};                           // (one-shot: the next hpmn_scan_bwd scatters through it, n > 0)
 };
+
+int embed_grad_segsum_launch(const HpmnScatterPlan &p, const float *d_x, float *d_emb, int32_t B, int32_t T, int32_t F,
+                             int32_t E, int32_t front_zero, int32_t id_flags, const float *d_last, int32_t t_last,
+                             hipStream_t st);
+
+// The whole-range scatter of a step: through the context's plan (deterministic segmented reduction) when one is set.
+static int scatter_all(TrainCtx *c, const HpmnScanDesc *d, const void *ids, const float *d_x0, float *d_emb,
+                       const float *d_last, hipStream_t st) {
+    const int t_last = d->T + d->last_index;
+    if (c->plan.n > 0) {
+        const HpmnScatterPlan p = c->plan;
+        c->plan = HpmnScatterPlan{};
+        if (p.n != (int64_t)d->B * d->T * d->F) return HPMN_EINVAL;
+        return embed_grad_segsum_launch(p, d_x0, d_emb, d->B, d->T, d->F, d->E, d->front_zero, d->mask_id0, d_last, t_last, st);
+    }
+    return embed_grad_scatter_launch(ids, d_x0, d_emb, d->B, d->T, d->F, d->E, d->front_zero, d->mask_id0, 0, d->T, st, d_last,
+                                     t_last);
+}
 
 static size_t up256(size_t x) { return (x + 255) / 256 * 256; }
 
@@ -155,7 +174,7 @@ size_t hpmn_scan_train_workspace_bytes(const HpmnScanDesc *d) {
     return L.total_bytes;
 }
 
-int hpmn_scan_fwd_train(HpmnTrainCtx *ctx, const HpmnScanDesc *d, const int32_t *ids, const float *emb,
+int hpmn_scan_fwd_train(HpmnTrainCtx *ctx, const HpmnScanDesc *d, const void *ids, const float *emb,
                         const float *const *wg, const float *const *bg, const float *const *wc,
                         const float *const *bc, float *memory, float *last, void *workspace, void *stream) {
     (void)hipGetLastError();
@@ -287,7 +306,7 @@ int hpmn_scan_fwd_train(HpmnTrainCtx *ctx, const HpmnScanDesc *d, const int32_t 
     return HPMN_OK;
 }
 
-int hpmn_scan_bwd(HpmnTrainCtx *ctx, const HpmnScanDesc *d, const int32_t *ids, const float *const *wg,
+int hpmn_scan_bwd(HpmnTrainCtx *ctx, const HpmnScanDesc *d, const void *ids, const float *const *wg,
                   const float *const *wc, const float *d_memory, const float *d_last, float *const *d_wg,
                   float *const *d_bg, float *const *d_wc, float *const *d_bc, float *d_emb, void *workspace,
                   int32_t defer_join, void *stream) {
@@ -351,8 +370,7 @@ int hpmn_scan_bwd(HpmnTrainCtx *ctx, const HpmnScanDesc *d, const int32_t *ids, 
             rc = check_launch();
             if (rc != HPMN_OK) return rc;
         }
-        rc = embed_grad_scatter_launch(ids, F(L.d_x[0]), d_emb, d->B, d->T, d->F, d->E, d->front_zero, d->mask_id0, 0, d->T,
-                                       st, in_scatter ? d_last : nullptr, d->T + d->last_index);
+        rc = scatter_all(c, d, ids, F(L.d_x[0]), d_emb, in_scatter ? d_last : nullptr, st);
         if (rc != HPMN_OK) return rc;
         if (!defer_join) return hpmn_train_join(ctx, stream);
         return HPMN_OK;
@@ -508,7 +526,7 @@ int hpmn_scan_bwd(HpmnTrainCtx *ctx, const HpmnScanDesc *d, const int32_t *ids, 
         if (probing) HIPCHK(hipEventRecord(c->probe0, st));
         const bool fused_dx = gru_scan_bwd_fuses_dx(d->H, d->B) && gru_scan_bwd_dx_width_ok(D);
         if (fused_dx) a.d_x = F(L.d_x[i]);       // the input gradient comes out of the scan launch itself
-        if (i == 0 && fused_dx && gru_scan_bwd_fuses_scatter(d->H, d->B, D, d->F, d->E)) {
+        if (i == 0 && fused_dx && !(d->mask_id0 & HPMN_ID_I64) && gru_scan_bwd_fuses_scatter(d->H, d->B, D, d->F, d->E)) {
             // ... and goes straight into the table gradient: no d_x buffer, no scatter launch behind layer 0
             a.d_x = nullptr;
             a.scatter_ids = ids; a.d_emb = d_emb; a.Tids = d->T; a.F = d->F; a.E = d->E;
@@ -610,12 +628,23 @@ int hpmn_scan_bwd(HpmnTrainCtx *ctx, const HpmnScanDesc *d, const int32_t *ids, 
         int rc = check_launch();
         if (rc != HPMN_OK) return rc;
     }
-    int rc = embed_grad_scatter_launch(ids, F(L.d_x[0]), d_emb, d->B, d->T, d->F, d->E, d->front_zero, d->mask_id0, 0,
-                                       scatter_pending ? scat_cut - d->front_zero : d->T, st,
-                                       last_in_scatter ? d_last : nullptr, d->T + d->last_index);
+    int rc = scatter_pending
+                 ? embed_grad_scatter_launch(ids, F(L.d_x[0]), d_emb, d->B, d->T, d->F, d->E, d->front_zero, d->mask_id0, 0,
+                                             scat_cut - d->front_zero, st, last_in_scatter ? d_last : nullptr,
+                                             d->T + d->last_index)
+                 : scatter_all(c, d, ids, F(L.d_x[0]), d_emb, last_in_scatter ? d_last : nullptr, st);
     if (rc != HPMN_OK) return rc;
     if (scatter_pending) HIPCHK(hipStreamWaitEvent(st, c->scat, 0));   // the caller's table update needs both halves
     if (!defer_join) return hpmn_train_join(ctx, stream);
+    return HPMN_OK;
+}
+
+int hpmn_train_set_scatter_plan(HpmnTrainCtx *ctx, const HpmnScatterPlan *plan) {
+    TrainCtx *c = reinterpret_cast<TrainCtx *>(ctx);
+    if (!c) return HPMN_EINVAL;
+    if (!plan || plan->n <= 0) { c->plan = HpmnScatterPlan{}; return HPMN_OK; }
+    if (!plan->perm || !plan->seg || !plan->start || !plan->rows || !plan->count || !plan->partials) return HPMN_EINVAL;
+    c->plan = *plan;
     return HPMN_OK;
 }
 

@@ -21,6 +21,13 @@ def rank_world() -> Tuple[int, int]:
     return 0, 1
 
 
+def forced() -> bool:
+    """HPMN_DP_FORCE_COLLECTIVES=1 inside an initialised process group: no world-size-1 short cuts, every collective is
+    issued (a 1-GPU box runs the RCCL calls of the data-parallel step this way)."""
+    import os
+    return bool(os.environ.get("HPMN_DP_FORCE_COLLECTIVES") == "1" and td.is_available() and td.is_initialized())
+
+
 def shard_bounds(lo: int, hi: int, rank: int, world: int) -> Tuple[int, int]:
     """Contiguous slice of the global batch [lo, hi) owned by ``rank``."""
     n = hi - lo
@@ -39,7 +46,7 @@ def sharded_loss(ll_sum: torch.Tensor, mem_loss: torch.Tensor, global_batch: int
 
 def allreduce_sum_(flat: torch.Tensor) -> torch.Tensor:
     """One collective over the whole flat gradient buffer (dense variables + embedding table)."""
-    if td.is_available() and td.is_initialized() and td.get_world_size() > 1:
+    if td.is_available() and td.is_initialized() and (td.get_world_size() > 1 or forced()):
         td.all_reduce(flat, op=td.ReduceOp.SUM)
     return flat
 
@@ -64,7 +71,7 @@ def gather_predictions(pred: torch.Tensor, n_global: int) -> torch.Tensor:
     """All-gather per-rank prediction slices (sizes from ``shard_sizes``) into the global order.
     Uses one equal-size all_gather_into_tensor (slices padded to the largest)."""
     rank, world = rank_world()
-    if world == 1:
+    if world == 1 and not forced():
         return pred
     sizes = shard_sizes(n_global, world)
     cap = max(sizes)
@@ -100,16 +107,18 @@ def all_gather_shards_(flat: torch.Tensor, lo: int, shard: int) -> None:
 # HBM the dense all-reduce (2 (N-1)/N V E 4 bytes per rank) is replaced by an all-gather of the touched rows.
 
 def gather_ids(ids: torch.Tensor, cap: int) -> torch.Tensor:
-    """All ranks' id tensors as one [world, cap] int32 tensor, -1 where a rank had fewer than ``cap`` entries (a short
-    last batch).  No host synchronisation: ``cap`` comes from the batch geometry (``shard_sizes``)."""
+    """All ranks' id tensors as one [world, cap] tensor of the ids' own width (int32, or int64 for tables beyond 2^31 - 1
+    rows), -1 where a rank had fewer than ``cap`` entries (a short last batch).  No host synchronisation: ``cap`` comes from
+    the batch geometry (``shard_sizes``)."""
     _, world = rank_world()
-    flat = ids.reshape(-1).to(torch.int32)
+    idt = torch.int64 if ids.dtype == torch.int64 else torch.int32
+    flat = ids.reshape(-1).to(idt)
     assert flat.numel() <= cap
-    mine = torch.full((cap,), -1, device=ids.device, dtype=torch.int32)
+    mine = torch.full((cap,), -1, device=ids.device, dtype=idt)
     mine[:flat.numel()] = flat
-    if world == 1:
+    if world == 1 and not forced():
         return mine.view(1, cap)
-    out = torch.empty(world * cap, device=ids.device, dtype=torch.int32)
+    out = torch.empty(world * cap, device=ids.device, dtype=idt)
     td.all_gather_into_tensor(out, mine)
     return out.view(world, cap)
 
@@ -117,7 +126,7 @@ def gather_ids(ids: torch.Tensor, cap: int) -> torch.Tensor:
 def exchange_counts(n: int, device) -> List[int]:
     """Every rank's ``n`` (one small collective + one host read: the row lists of the next call are sized by it)."""
     _, world = rank_world()
-    if world == 1:
+    if world == 1 and not forced():
         return [int(n)]
     mine = torch.tensor([int(n)], device=device, dtype=torch.int64)
     out = torch.empty(world, device=device, dtype=torch.int64)
@@ -139,15 +148,25 @@ class _Counts:
         return self._list
 
 
-def exchange_counts_async(n: int, device) -> "_Counts":
-    """exchange_counts whose host read is deferred: the all-gather and a non-blocking copy into pinned memory are
+def exchange_counts_async(n, device) -> "_Counts":
+    """``n``: an int or a one-element device tensor.  exchange_counts whose host read is deferred: the all-gather and a non-blocking copy into pinned memory are
     enqueued on the CURRENT stream now, the caller asks for ``result()`` when it needs the numbers (data-parallel step:
     enqueued at the start of the step underneath the forward, read when the row exchange is sized -- long after the
     copy completed, so the host never waits on the device's critical path)."""
     _, world = rank_world()
-    if world == 1:
+    on_device = isinstance(n, torch.Tensor)              # (a device-side count: it is never read on the host here)
+    if world == 1 and not forced() and not on_device:
         return _Counts(None, None, [int(n)])
-    mine = torch.tensor([int(n)], device=device, dtype=torch.int64)
+    mine = n.reshape(1).to(torch.int64) if on_device else torch.tensor([int(n)], device=device, dtype=torch.int64)
+    if world == 1 and not forced():
+        out = mine
+        if out.is_cuda:
+            host = torch.empty(1, dtype=torch.int64, pin_memory=True)
+            host.copy_(out, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            return _Counts(host, ev)
+        return _Counts(None, None, [int(out.item())])
     out = torch.empty(world, device=device, dtype=torch.int64)
     td.all_gather_into_tensor(out, mine)
     if out.is_cuda:
@@ -159,21 +178,23 @@ def exchange_counts_async(n: int, device) -> "_Counts":
     return _Counts(None, None, [int(x) for x in out.tolist()])
 
 
-def exchange_rows(rows: torch.Tensor, grads: torch.Tensor, counts: List[int]):
-    """All-gather of (row ids [n] int32, gradient rows [n, E]) over the ranks, padded to the largest count.
+def exchange_rows(rows: torch.Tensor, grads: torch.Tensor, counts: List[int], wide_ids: bool = False):
+    """All-gather of (row ids [n] -- int32 on the wire, int64 with ``wide_ids`` (tables beyond 2^31 - 1 rows; the same on every
+    rank: it follows from the table size) --, gradient rows [n, E]) over the ranks, padded to the largest count.
     Returns (ids [world, cap] with -1 padding, grads [world, cap, E]); rank r's valid entries are the first counts[r]."""
     rank, world = rank_world()
     cap = max(1, max(counts))
     E = grads.shape[1]
     n = rows.numel()
     assert n == counts[rank] and grads.shape[0] == n
-    ids_mine = torch.full((cap,), -1, device=rows.device, dtype=torch.int32)
-    ids_mine[:n] = rows.to(torch.int32)
+    idt = torch.int64 if wide_ids else torch.int32
+    ids_mine = torch.full((cap,), -1, device=rows.device, dtype=idt)
+    ids_mine[:n] = rows.to(idt)
     g_mine = torch.zeros(cap, E, device=grads.device, dtype=grads.dtype)
     g_mine[:n] = grads
-    if world == 1:
+    if world == 1 and not forced():
         return ids_mine.view(1, cap), g_mine.view(1, cap, E)
-    ids_all = torch.empty(world * cap, device=rows.device, dtype=torch.int32)
+    ids_all = torch.empty(world * cap, device=rows.device, dtype=idt)
     g_all = torch.empty(world * cap * E, device=grads.device, dtype=grads.dtype)
     td.all_gather_into_tensor(ids_all, ids_mine)
     td.all_gather_into_tensor(g_all, g_mine.view(-1))
@@ -194,10 +215,10 @@ def sum_rows_into_(dst: torch.Tensor, ids_all: torch.Tensor, g_all: torch.Tensor
         dst.index_add_(0, idx, g_all[r, :n])
 
 
-def rows_exchange_bytes(counts: List[int], E: int) -> int:
+def rows_exchange_bytes(counts: List[int], E: int, wide_ids: bool = False) -> int:
     """Bytes one rank RECEIVES in exchange_rows (ids + rows of every other rank, padded to the cap)."""
     world = len(counts)
-    return (world - 1) * max(1, max(counts)) * (4 + 4 * E)
+    return (world - 1) * max(1, max(counts)) * ((8 if wide_ids else 4) + 4 * E)
 
 
 def dense_allreduce_bytes(numel: int, world: int) -> int:

@@ -121,7 +121,10 @@ class _DeviceDataset:
                     raise ValueError("dataset ids span [%d, %d] but the embedding table has %d rows (tf.nn.embedding_lookup "
                                      "raises on the CPU; HPMN_OOB_IDS=zero gives its GPU behaviour for the Hpmn class: a "
                                      "zero row, no gradient)" % (lo, hi, feature_size))
-        self.ids = torch.as_tensor(np.ascontiguousarray(ids, dtype=np.int32)).to(device)
+        # int32 ids like the reference's placeholders (code/hpmn.py:248-251) -- int64 only for a table whose row count does not
+        # fit them (BASELINE configs[4] sized to HBM; the documented deviation of SURVEY.md section 7, hard part 4)
+        id_dtype = np.int64 if (feature_size is not None and feature_size > 2 ** 31 - 1) else np.int32
+        self.ids = torch.as_tensor(np.ascontiguousarray(ids, dtype=id_dtype)).to(device)
         self.item_ids = None
         if want_item:
             if feature_size is not None and self.n and (int(np.min(item_ids)) < 0 or int(np.max(item_ids)) >= feature_size):
@@ -129,7 +132,7 @@ class _DeviceDataset:
                     item_ids = np.where(np.asarray(item_ids) >= feature_size, 0, item_ids)
                 else:
                     raise ValueError("item-side ids out of the embedding table's range")
-            self.item_ids = torch.as_tensor(np.ascontiguousarray(item_ids, dtype=np.int32)).to(device)
+            self.item_ids = torch.as_tensor(np.ascontiguousarray(item_ids, dtype=id_dtype)).to(device)
         self.label_np = np.asarray(label, dtype=np.int32)
         self.label = torch.as_tensor(self.label_np).to(device)
         self.length_np = None if length is None else np.asarray(length)
@@ -145,6 +148,7 @@ class Hpmn_Basic(object):
 
     eval_every = 100
     industry = False
+    _dp = False                  # data-parallel code paths on (set in __init__: world > 1, or forced collectives)
 
     def __init__(self, path, trainset, testset, feature_size, user_dim, item_dim, learning_rate,
                  hidden_size, embedding_size, hop, user_layers, item_layers, user_num_layers,
@@ -172,6 +176,9 @@ class Hpmn_Basic(object):
         assert self.user_num_layers <= len(self.user_layers)     # code/hpmn.py:115
         assert not item or self.item_num_layers <= len(self.item_layers)
         self.rank, self.world = dist.rank_world()
+        # data-parallel code paths on: more than one rank, or HPMN_DP_FORCE_COLLECTIVES=1 inside an initialised process
+        # group of ONE rank (every collective really issued: how a 1-GPU box exercises the RCCL calls, tests/test_gpu_dp.py)
+        self._dp = self.world > 1 or dist.forced()
         # Row-wise ("lazy") Adam on the embedding table: ONLY for tables that cannot afford the reference's dense
         # update (BASELINE configs[4]); a labelled deviation from code/hpmn.py:209-214, off unless asked for.
         self.lazy_table_adam = bool(int(os.environ.get("HPMN_LAZY_TABLE_ADAM", "0"))) if lazy_table_adam is None \
@@ -186,6 +193,11 @@ class Hpmn_Basic(object):
         # blocking all-reduce over the whole flat gradient, then one update (no overlap: the fallback switch)
         # auto: the two-pass step with touched rows for big tables, dense all-reduce for small ones (_train_step_dp)
         self.table_exchange = os.environ.get("HPMN_TABLE_EXCHANGE", "auto")
+        # Deterministic table gradients (r4): the scatter as a segmented reduction in row order, no atomics (ops.ScatterPlan,
+        # csrc/scatter_sorted.hip).  HPMN_DET_SCATTER=0: the atomic kernel (run-length pre-reduced fp32 atomics).
+        self.det_scatter = os.environ.get("HPMN_DET_SCATTER", "1") != "0"
+        self._plan_wants_rows = False     # (the data-parallel rows exchange sends the plan's compact rows)
+        self.last_scatter_plan = None
         self._sharded_moments = False     # set once the sharded table update has run (save_model gathers the moments then)
         self.TWO_PASS_MIN_NUMEL = int(os.environ.get("HPMN_TWO_PASS_MIN_NUMEL", str(type(self).TWO_PASS_MIN_NUMEL)))
         self.last_exchange_bytes = 0            # bytes this rank received in the last step's table exchange
@@ -439,6 +451,21 @@ class Hpmn_Basic(object):
             aux.wait_stream(main)                            # (after the previous step's optimiser, which read it)
         cleared = None
         rest2 = None
+        # The deterministic scatter's row order (ops.ScatterPlan: a stable sort of the batch's ids) depends on the ids alone:
+        # built on the auxiliary stream underneath the forward, consumed behind BPTT.
+        plan, plan_ready = None, None
+        if self.det_scatter and not self.lazy_table_adam and self.embedding_size % 4 == 0 and 256 % (self.embedding_size // 4) == 0:
+            pst = self._aux_stream
+            if aux is main:
+                pst.wait_stream(main)                        # (the ids may have been produced on the caller's stream just now)
+            with torch.cuda.stream(pst):
+                plan = ops.ScatterPlan(ids, self.embedding_size, want_rows=self._plan_wants_rows,
+                                       host_count=self._plan_wants_rows)
+                plan_ready = torch.cuda.Event()
+                plan_ready.record(pst)
+            plan.ready = plan_ready
+            plan.record_stream(main)
+            self.last_scatter_plan = plan
         with torch.cuda.stream(aux):
             rest = None
             if _clear_grads is not None:
@@ -509,8 +536,10 @@ class Hpmn_Basic(object):
         grad_out = [d_emb] + [self.grads[n] for names in self._gru_names for n in names]
         if callable(rest):
             ops.train_mark_layer0_reverse(self.device, True)
+        if plan_ready is not None:
+            main.wait_event(plan_ready)
         pending = ops.scan_backward(self.spec, scatter_ids, saved, weights, out["d_memory"], out["d_last"], grad_out,
-                                    defer_join=defer_join and not self.l2_reg)
+                                    defer_join=defer_join and not self.l2_reg, scatter_plan=plan)
         out["pending"] = pending
         if callable(rest):
             # HPMN_EARLY_PASS=bwd: the early table-Adam pass beside layer 0's REVERSE launch instead of beside its forward
@@ -559,15 +588,16 @@ class Hpmn_Basic(object):
             V, E = self.feature_size, self.embedding_size
             rows = out.pop("table_rows", None)
             row_grads = out.pop("table_row_grads", None)
-            if self.world > 1:
+            if self._dp:
                 # every rank's (touched rows, their gradient rows) -> the union and the summed rows, identically on
                 # every rank; an empty shard contributes nothing but takes part in the collectives
                 if rows is None:
                     rows = torch.empty(0, device=self.device, dtype=torch.int64)
                     row_grads = torch.empty(0, E, device=self.device, dtype=torch.float32)
                 counts = dist.exchange_counts(rows.numel(), self.device)
-                ids_all, g_all = dist.exchange_rows(rows, row_grads, counts)
-                self.last_exchange_bytes = dist.rows_exchange_bytes(counts, E)
+                wide = self.feature_size > 2 ** 31 - 1
+                ids_all, g_all = dist.exchange_rows(rows, row_grads, counts, wide_ids=wide)
+                self.last_exchange_bytes = dist.rows_exchange_bytes(counts, E, wide)
                 valid = torch.cat([ids_all[r, :n] for r, n in enumerate(counts)]).long()
                 rows = torch.unique(valid)
                 row_grads = torch.zeros(rows.numel(), E, device=self.device, dtype=torch.float32)
@@ -583,14 +613,14 @@ class Hpmn_Basic(object):
             ops.adam_step(self.flat_param[lo:], self.flat_grad, self.flat_m[lo:], self.flat_v[lo:], lr_t, self.beta1,
                           self.beta2, self.adam_eps, clip=1.0)
             return out, ce
-        if self.world > 1 and self.table_exchange == "single":
+        if self._dp and self.table_exchange == "single":
             # the plainest scheme (fallback switch): join, ONE all-reduce over the whole flat gradient, one update
             if pending is not None:
                 pending.join()
             dist.allreduce_sum_(self.flat_grad)
             self.apply_gradients()
             return out, ce
-        if self.world > 1 and self.table_exchange == "sharded":
+        if self._dp and self.table_exchange == "sharded":
             n_pad = self._emb_numel_padded
             shard = n_pad // self.world
             lo = self.rank * shard
@@ -603,7 +633,7 @@ class Hpmn_Basic(object):
                           lr_t, self.beta1, self.beta2, self.adam_eps, clip=1.0)
             dist.all_gather_shards_(self.flat_param[:n_pad], lo, shard)
             n_emb = n_pad
-        elif self.world > 1:
+        elif self._dp:
             # the table exchange is the one big collective of the step (212 MB at C3): cut it into a few
             # ranges so that clip + Adam of range i run while RCCL is still reducing range i+1
             bounds = dist.chunk_bounds(n_emb, self.table_exchange_chunks, align=1024)
@@ -660,7 +690,7 @@ class Hpmn_Basic(object):
 
     def _two_pass_table_adam(self, ids) -> bool:
         """Single process, user-only graph, no densifying l2 term, a table big enough for the dense sweep to matter."""
-        return bool(self.TWO_PASS_TABLE_ADAM and self.world == 1 and self._hip_read and not self.l2_reg
+        return bool(self.TWO_PASS_TABLE_ADAM and not self._dp and self._hip_read and not self.l2_reg
                     and not self.lazy_table_adam and ids.shape[0] > 0 and self.flat_grad.numel() >= self.TWO_PASS_MIN_NUMEL
                     and self._table_adam_width_ok())
 
@@ -728,7 +758,7 @@ class Hpmn_Basic(object):
         dense table Adam, the four library calls) plus the collectives.  HPMN_TABLE_EXCHANGE: ``auto`` (default) =
         ``rows`` for tables above ROWS_EXCHANGE_MIN_BYTES, else ``allreduce``; ``sharded`` / ``single`` keep their
         one-sweep forms (train_step)."""
-        return bool(self.TWO_PASS_TABLE_ADAM and self.world > 1 and self._hip_read and not self.l2_reg
+        return bool(self.TWO_PASS_TABLE_ADAM and self._dp and self._hip_read and not self.l2_reg
                     and not self.lazy_table_adam and self.table_exchange in ("auto", "rows", "allreduce")
                     and self.flat_grad.numel() >= self.TWO_PASS_MIN_NUMEL and self._table_adam_width_ok())
 
@@ -768,6 +798,9 @@ class Hpmn_Basic(object):
             raise ValueError("this rank's shard (%d rows) is larger than the largest shard of global_batch=%d over %d ranks"
                              % (B, gb, self.world))
         want_counts = self.table_exchange in ("auto", "rows")
+        use_plan = bool(want_counts and self.det_scatter)
+        self._plan_wants_rows = use_plan
+        self.last_scatter_plan = None
         box = {}
 
         def early():                                          # runs on the auxiliary stream
@@ -779,10 +812,18 @@ class Hpmn_Basic(object):
             def rest():
                 all_ids = dist.gather_ids(ids, max(cap, 1))
                 if want_counts:
-                    rows = (torch.unique(ids.reshape(-1)).long() if B > 0
-                            else torch.empty(0, device=self.device, dtype=torch.int64))
-                    box["rows"] = rows
-                    box["counts"] = dist.exchange_counts_async(rows.numel(), self.device)
+                    plan = self.last_scatter_plan if (use_plan and B > 0) else None
+                    if plan is not None:
+                        # the scatter plan already holds this rank's distinct rows and their count ON THE DEVICE: no
+                        # torch.unique (whose data-dependent output shape is a host synchronisation), no index_select later
+                        box["plan"] = plan
+                        torch.cuda.current_stream().wait_event(plan.ready)
+                        box["counts"] = dist.exchange_counts_async(plan.count, self.device)
+                    else:
+                        rows = (torch.unique(ids.reshape(-1)).long() if B > 0
+                                else torch.empty(0, device=self.device, dtype=torch.int64))
+                        box["rows"] = rows
+                        box["counts"] = dist.exchange_counts_async(rows.numel(), self.device)
                 ops.table_mark_rows(all_ids, flags)
                 ops.adam_step_table(*views, flags, 0, lr_t, self.beta1, self.beta2, self.adam_eps, clip=1.0)
             return rest
@@ -807,13 +848,17 @@ class Hpmn_Basic(object):
                     else "allreduce")
         self.last_exchange_mode = mode
         if mode == "rows":
-            rows = box["rows"]
-            rows.record_stream(torch.cuda.current_stream())   # (made on the auxiliary stream, consumed here)
-            mine = table_grad.index_select(0, rows)
-            ids_all, g_all = dist.exchange_rows(rows, mine, counts)
+            if "plan" in box:
+                n_mine = counts[self.rank]
+                rows, mine = box["plan"].rows[:n_mine].long(), box["plan"].out_rows[:n_mine]
+            else:
+                rows = box["rows"]
+                rows.record_stream(torch.cuda.current_stream())   # (made on the auxiliary stream, consumed here)
+                mine = table_grad.index_select(0, rows)
+            ids_all, g_all = dist.exchange_rows(rows, mine, counts, wide_ids=V > 2 ** 31 - 1)
             table_grad.index_fill_(0, rows, 0.0)              # (own rows come back through g_all, in rank order)
             dist.sum_rows_into_(table_grad, ids_all, g_all, counts)
-            self.last_exchange_bytes = dist.rows_exchange_bytes(counts, E)
+            self.last_exchange_bytes = dist.rows_exchange_bytes(counts, E, V > 2 ** 31 - 1)
         else:
             dist.allreduce_sum_(self.flat_grad[:n_emb])
             self.last_exchange_bytes = dist.dense_allreduce_bytes(n_emb, self.world)
@@ -901,7 +946,7 @@ class Hpmn_Basic(object):
             a, b = dist.shard_bounds(lo, hi, self.rank, self.world)
             out = self.forward_inference(ds.ids[a:b], item_ids=None if ds.item_ids is None else ds.item_ids[a:b])
             pred, ml = out["prediction"], out["memory_loss"].reshape(1)
-            if self.world > 1:
+            if self._dp:
                 pred = dist.gather_predictions(pred.contiguous(), hi - lo)
                 dist.allreduce_sum_(ml)
             preds.append(pred)
@@ -961,7 +1006,7 @@ class Hpmn_Basic(object):
         which a user-only export does not contain.
         Every rank must call this under data parallel with the sharded table exchange: each rank holds the Adam moments
         of its own 1/world of the table rows only, and they are gathered here before rank 0 writes."""
-        if self.world > 1 and self._sharded_moments:
+        if self._dp and self._sharded_moments:
             # (the sharded update ran: every rank holds 1/world of the table's moments -- a collective, so EVERY rank has
             # to call save_model then; README / INTEGRATION state it.  Keyed on what ran, not on the switch: ADVICE r3)
             n_pad = self._emb_numel_padded

@@ -41,8 +41,17 @@ def _chk_f32(*ts):
 
 
 def _chk_ids(ids):
-    if not (ids.is_cuda and ids.dtype == torch.int32 and ids.is_contiguous()):
-        raise ValueError("ids must be a contiguous int32 CUDA tensor")
+    if not (ids.is_cuda and ids.dtype in (torch.int32, torch.int64) and ids.is_contiguous()):
+        raise ValueError("ids must be a contiguous int32 or int64 CUDA tensor")
+
+
+ID_MASK0, ID_I64 = 1, 2          # include/hpmn_hip.h: HPMN_ID_MASK0, HPMN_ID_I64
+
+
+def _idf(ids, mask_id0) -> int:
+    """The id-flags word of the C ABI (the slot named mask_id0): bit 0 = id-0 mask, bit 1 = the ids tensor is int64 (tables
+    beyond 2^31 - 1 rows; the reference's placeholders are int32, code/hpmn.py:248-251)."""
+    return (ID_MASK0 if mask_id0 else 0) | (ID_I64 if ids is not None and ids.dtype == torch.int64 else 0)
 
 
 @dataclass(frozen=True)
@@ -72,10 +81,10 @@ class ScanSpec:
             t //= self.periods[i]
         return out
 
-    def desc(self, B: int, V: int) -> HpmnScanDesc:
+    def desc(self, B: int, V: int, ids=None) -> HpmnScanDesc:
         d = HpmnScanDesc()
         d.B, d.T, d.F, d.E, d.H, d.K = B, self.T, self.F, self.E, self.H, self.K
-        d.front_zero, d.mask_id0, d.last_index, d.V = self.front_zero, int(self.mask_id0), self.last_index, V
+        d.front_zero, d.mask_id0, d.last_index, d.V = self.front_zero, _idf(ids, self.mask_id0), self.last_index, V
         for i in range(self.K):
             d.periods[i] = self.periods[i]
         return d
@@ -93,7 +102,7 @@ def embed_gather(ids: torch.Tensor, emb: torch.Tensor, mask_id0: bool) -> torch.
     N = ids.numel() // F
     out = torch.empty(*ids.shape[:-1], F * E, device=emb.device, dtype=torch.float32)
     rc = _lib.load().hpmn_embed_gather(ids.data_ptr(), emb.data_ptr(), out.data_ptr(), N, F, E, V,
-                                        int(mask_id0), _stream())
+                                        _idf(ids, mask_id0), _stream())
     _lib.check(rc, "hpmn_embed_gather")
     return out
 
@@ -117,7 +126,7 @@ def gru_input_proj(spec_or_none, *, x=None, ids=None, emb=None, wg, bg, wc, bc, 
         V, E = emb.shape
         D = F * E
         a.ids, a.emb = ids.data_ptr(), emb.data_ptr()
-        a.Tids, a.F, a.E, a.front_zero, a.mask_id0, a.V = Tids, F, E, front_zero, int(mask_id0), V
+        a.Tids, a.F, a.E, a.front_zero, a.mask_id0, a.V = Tids, F, E, front_zero, _idf(ids, mask_id0), V
         dev = emb.device
     a.B, a.T, a.D, a.H = B, T, D, H
     a.wg, a.bg, a.wc, a.bc = wg.data_ptr(), bg.data_ptr(), wc.data_ptr(), bc.data_ptr()
@@ -161,7 +170,7 @@ def gru_fused_fwd(*, x=None, ids=None, emb=None, wg, bg, wc, bc, H, T, front_zer
         V, E = emb.shape
         D = F * E
         a.ids, a.emb = ids.data_ptr(), emb.data_ptr()
-        a.Tids, a.F, a.E, a.front_zero, a.mask_id0, a.V = Tids, F, E, front_zero, int(mask_id0), V
+        a.Tids, a.F, a.E, a.front_zero, a.mask_id0, a.V = Tids, F, E, front_zero, _idf(ids, mask_id0), V
     a.B, a.T, a.D, a.H = B, T, D, H
     a.wg, a.bg, a.wc, a.bc = wg.data_ptr(), bg.data_ptr(), wc.data_ptr(), bc.data_ptr()
     assert h_last.stride(1) == 1 and h_last.shape == (B, H)
@@ -187,7 +196,7 @@ def _fill_fused(a, *, x, ids, emb, wg, bg, wc, bc, H, T, front_zero, mask_id0, h
         V, E = emb.shape
         D = F * E
         a.ids, a.emb = ids.data_ptr(), emb.data_ptr()
-        a.Tids, a.F, a.E, a.front_zero, a.mask_id0, a.V = Tids, F, E, front_zero, int(mask_id0), V
+        a.Tids, a.F, a.E, a.front_zero, a.mask_id0, a.V = Tids, F, E, front_zero, _idf(ids, mask_id0), V
     else:                                   # the upper layer of a pair: its rows never leave the CU
         B, D = h_last.shape[0], H
     a.B, a.T, a.D, a.H = B, T, D, H
@@ -356,7 +365,7 @@ def embed_grad_scatter(ids, d_x, d_emb, front_zero, mask_id0):
     V, E = d_emb.shape
     assert d_x.shape == (B, front_zero + T, F * E)
     rc = _lib.load().hpmn_embed_grad_scatter(ids.data_ptr(), d_x.data_ptr(), d_emb.data_ptr(), B, T, F, E,
-                                              front_zero, V, int(mask_id0), _stream())
+                                              front_zero, V, _idf(ids, mask_id0), _stream())
     _lib.check(rc, "hpmn_embed_grad_scatter")
 
 
@@ -386,7 +395,8 @@ def table_mark_rows(ids: torch.Tensor, flags: torch.Tensor):
     """hpmn_table_mark_rows: flags[id] = 1 for every id of the batch (flags: uint8 [V], all zero before)."""
     _chk_ids(ids)
     assert flags.dtype == torch.uint8 and flags.is_cuda and flags.is_contiguous()
-    rc = _lib.load().hpmn_table_mark_rows(ids.data_ptr(), ids.numel(), flags.data_ptr(), flags.numel(), _stream())
+    rc = _lib.load().hpmn_table_mark_rows(ids.data_ptr(), ids.numel(), flags.data_ptr(), flags.numel(), _idf(ids, False),
+                                           _stream())
     _lib.check(rc, "hpmn_table_mark_rows")
 
 
@@ -412,7 +422,7 @@ def scan_forward_inference(spec: ScanSpec, ids, emb, weights: Sequence[torch.Ten
     lib = _lib.load()
     if B == 0:       # nothing to launch (and a 0-element tensor has a null data pointer)
         return (torch.empty(0, spec.K, spec.H, device=emb.device), torch.empty(0, spec.D0, device=emb.device))
-    d = spec.desc(B, V)
+    d = spec.desc(B, V, ids)
     need = lib.hpmn_scan_workspace_bytes(C.byref(d))
     if need == 0:
         raise ValueError("inconsistent scan description (layer lengths must divide by the periods)")
@@ -520,7 +530,7 @@ def embed_gather_sum(ids: torch.Tensor, emb: torch.Tensor, mask_id0: bool, out=N
     V, E = emb.shape
     if out is None:
         out = torch.zeros(B, F * E, device=emb.device, dtype=torch.float32)
-    rc = _lib.load().hpmn_embed_gather_sum(ids.data_ptr(), emb.data_ptr(), out.data_ptr(), B, T, F, E, V, int(mask_id0),
+    rc = _lib.load().hpmn_embed_gather_sum(ids.data_ptr(), emb.data_ptr(), out.data_ptr(), B, T, F, E, V, _idf(ids, mask_id0),
                                             _stream())
     _lib.check(rc, "hpmn_embed_gather_sum")
     return out
@@ -535,7 +545,7 @@ def embed_gather_seq(ids, emb, front_zero: int, mask_id0: bool, out=None):
     if out is None:
         out = torch.empty(B, front_zero + T, F * E, device=emb.device, dtype=torch.float32)
     rc = _lib.load().hpmn_embed_gather_seq(ids.data_ptr(), emb.data_ptr(), out.data_ptr(), B, T, F, E, front_zero, V,
-                                            int(mask_id0), _stream())
+                                            _idf(ids, mask_id0), _stream())
     _lib.check(rc, "hpmn_embed_gather_seq")
     return out
 
@@ -577,6 +587,48 @@ def pipe_forward(spec: ScanSpec, ids, emb, weights: Sequence[torch.Tensor], trai
     last = x0[:, spec.last_index, :].contiguous()
     x_in = [x0] + y[:-1]
     return memory, last, [(x_in[i], hs[i], gates[i]) for i in range(K)]
+
+
+def tiled_forward_inference(spec: ScanSpec, ids, emb, weights: Sequence[torch.Tensor], group: int = 1):
+    """build_memory forward for LARGE batches (evaluation): the 16-sequence-tile kernel of hpmn_pipe_fwd -- a step's
+    recurrent product as a real [3H x H] x [H x 16] contraction on the matrix cores, split-f16 operands, three products per
+    tile, fp32 accumulate -- run LAYER GROUP BY LAYER GROUP instead of all K layers in one launch.
+
+    Per tile-step the tiled kernel costs ~1830 cycles for 16 sequences where the one-sequence-per-wave kernels cost ~1240
+    for (at best) 4-8 per CU, so it wins as soon as the batch fills the chip with tiles; what lost at B = 500 was (a) 32
+    tiles on 256 CUs and (b) the in-launch layer pipeline: with all K layers resident, layers 1..K-1 hold a CU each for the
+    whole 1024-step duration of layer 0 while doing 1/2, 1/4, ... of its work.  ``group`` layers per launch (1: none of
+    that waiting; 2: for batches that only half-fill the chip with tiles) chained through the y rows in memory.
+    Returns (memory [B,K,H], last [B,D0]) like scan_forward_inference."""
+    _chk_ids(ids)
+    _chk_f32(emb, *weights)
+    B, H, K = ids.shape[0], spec.H, spec.K
+    dev = emb.device
+    f32 = dict(device=dev, dtype=torch.float32)
+    lens = spec.layer_lengths()
+    memory = torch.empty(B, K, H, **f32)
+    x = embed_gather_seq(ids, emb, spec.front_zero, spec.mask_id0)
+    last = x[:, spec.last_index, :].contiguous()
+    lib = _lib.load()
+    first = 0
+    while first < K:
+        n = min(group, K - first)
+        p = _lib.HpmnPipe()
+        p.B, p.K, p.H, p.train = B, n, H, 0
+        p.mem_stride = K * H
+        y = []
+        for j in range(n):
+            i = first + j
+            p.T[j], p.D[j], p.period[j] = lens[i], (spec.D0 if i == 0 else H), spec.periods[i]
+            p.wg[j], p.bg[j], p.wc[j], p.bc[j] = (t.data_ptr() for t in weights[4 * i:4 * i + 4])
+            y.append(torch.empty(B, lens[i] // spec.periods[i], H, **f32) if i + 1 < K else None)
+            p.y[j] = _ptr(y[j])
+        p.x0, p.memory = x.data_ptr(), memory[:, first, :].data_ptr()
+        p.sync = _pipe_sync_buffer(n, B, dev).data_ptr()
+        _lib.check(lib.hpmn_pipe_fwd(C.byref(p), _stream()), "hpmn_pipe_fwd")
+        x = y[-1]
+        first += n
+    return memory, last
 
 
 def pipe_error_word(K: int, B: int, device) -> int:
@@ -734,6 +786,77 @@ def _ctx(device) -> int:
     return h
 
 
+class ScatterPlan:
+    """Row order of a batch's lookups (hpmn_scatter_plan): what the deterministic scatter walks.  Built from the ids alone,
+    on whatever stream is current (the data-parallel / two-pass step: the auxiliary stream, underneath the forward).
+    ``rows[:U]`` = the batch's distinct table rows (ascending), ``out_rows[:U]`` = their gradient rows once the scatter has
+    run, ``count`` = U on the device; ``count_host()`` is an event-guarded read of its pinned copy (no device sync)."""
+
+    def __init__(self, ids: torch.Tensor, E: int, want_rows: bool = False, host_count: bool = False):
+        _chk_ids(ids)
+        dev = ids.device
+        flat = ids.reshape(-1)
+        n = flat.numel()
+        self.n, self.E, self.id_flags = n, E, _idf(ids, False)
+        i32 = dict(device=dev, dtype=torch.int32)
+        self.sorted, perm = torch.sort(flat, stable=True)
+        self.perm = perm.to(torch.int32)
+        head = torch.ones(n, **i32)
+        if n > 1:
+            head[1:] = (self.sorted[1:] != self.sorted[:-1]).to(torch.int32)
+        self.seg = torch.cumsum(head, 0, dtype=torch.int32) - 1
+        self.start = torch.empty(n + 1, **i32)
+        self.rows = torch.empty(n, device=dev, dtype=ids.dtype)
+        self.count = torch.zeros(1, **i32)
+        lib = _lib.load()
+        _lib.check(lib.hpmn_scatter_plan(self.sorted.data_ptr(), self.id_flags, n, self.seg.data_ptr(), self.start.data_ptr(),
+                                         self.rows.data_ptr(), self.count.data_ptr(), _stream()), "hpmn_scatter_plan")
+        self.partials = torch.empty(max(1, lib.hpmn_embed_grad_segsum_partials_floats(n, E)), device=dev, dtype=torch.float32)
+        self.out_rows = torch.empty(max(n, 1), E, device=dev, dtype=torch.float32) if want_rows else None
+        self._host = self._event = None
+        if host_count:
+            self._host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+            self._host.copy_(self.count, non_blocking=True)
+            self._event = torch.cuda.Event()
+            self._event.record()
+
+    def count_host(self) -> int:
+        if self._host is None:
+            return int(self.count.item())
+        self._event.synchronize()
+        return int(self._host[0])
+
+    def struct(self) -> "_lib.HpmnScatterPlan":
+        p = _lib.HpmnScatterPlan()
+        p.n, p.perm, p.seg, p.start = self.n, self.perm.data_ptr(), self.seg.data_ptr(), self.start.data_ptr()
+        p.rows, p.count, p.partials = self.rows.data_ptr(), self.count.data_ptr(), self.partials.data_ptr()
+        p.out_rows = _ptr(self.out_rows)
+        return p
+
+    def record_stream(self, stream) -> None:
+        """The plan was built on another stream than the one that consumes it."""
+        for t in (self.sorted, self.perm, self.seg, self.start, self.rows, self.count, self.partials, self.out_rows):
+            if t is not None:
+                t.record_stream(stream)
+
+
+def set_scatter_plan(device, plan: Optional[ScatterPlan]) -> None:
+    """hpmn_train_set_scatter_plan: the next hpmn_scan_bwd on the current stream's context scatters through ``plan``."""
+    st = plan.struct() if plan is not None and plan.n > 0 else None
+    _lib.check(_lib.load().hpmn_train_set_scatter_plan(_ctx(device), C.byref(st) if st is not None else None),
+               "hpmn_train_set_scatter_plan")
+
+
+def embed_grad_segsum(plan: ScatterPlan, ids_shape, d_x, d_emb, front_zero: int, mask_id0: bool, d_last=None, t_last: int = 0):
+    """hpmn_embed_grad_segsum: the deterministic scatter as a call of its own (d_emb may be None when plan.out_rows is set)."""
+    B, T, F = ids_shape
+    _chk_f32(d_x, d_emb, d_last)
+    st = plan.struct()
+    rc = _lib.load().hpmn_embed_grad_segsum(C.byref(st), d_x.data_ptr(), _ptr(d_emb), B, T, F, plan.E, front_zero,
+                                            plan.id_flags | (ID_MASK0 if mask_id0 else 0), _ptr(d_last), t_last, _stream())
+    _lib.check(rc, "hpmn_embed_grad_segsum")
+
+
 def train_probe(device, enable: bool) -> None:
     """hpmn_train_probe: bracket layer 0's reverse-scan launch of the following steps with timing events."""
     _lib.check(_lib.load().hpmn_train_probe(_ctx(device), int(enable)), "hpmn_train_probe")
@@ -800,7 +923,7 @@ def abi_forward_train(spec: ScanSpec, ids, emb, weights: Sequence[torch.Tensor])
     B, K, H = ids.shape[0], spec.K, spec.H
     V = emb.shape[0]
     lib = _lib.load()
-    d = spec.desc(B, V)
+    d = spec.desc(B, V, ids)
     lay = _lib.HpmnTrainLayout()
     _lib.check(lib.hpmn_scan_train_layout(C.byref(d), C.byref(lay)), "hpmn_scan_train_layout")
     ws = torch.empty(int(lay.total_bytes), device=emb.device, dtype=torch.uint8)
@@ -832,6 +955,7 @@ def abi_backward(spec: ScanSpec, ids, saved: "AbiSaved", weights, d_memory, d_la
     gw = list(grad_out[1:])
     arr = lambda j: (C.c_void_p * K)(*[gw[4 * i + j].data_ptr() for i in range(K)])
     ctx = _ctx(d_memory.device)
+    saved.desc.mask_id0 = _idf(ids, spec.mask_id0)     # (the scatter's ids may be narrower than the forward's: lazy table Adam)
     rc = _lib.load().hpmn_scan_bwd(ctx, C.byref(saved.desc), ids.data_ptr(), _wptrs(weights, K, 0),
                                    _wptrs(weights, K, 2), d_memory.data_ptr(), d_last.data_ptr(), arr(0), arr(1),
                                    arr(2), arr(3), grad_out[0].data_ptr(), saved.workspace.data_ptr(),
@@ -964,10 +1088,12 @@ class PendingGrads:
 
 
 def scan_backward(spec: ScanSpec, ids, saved, weights: Sequence[torch.Tensor], d_memory, d_last, grad_out,
-                  defer_join: bool = False):
-    """BPTT of scan_forward_train (every forward path leaves the same saved states)."""
+                  defer_join: bool = False, scatter_plan: Optional["ScatterPlan"] = None):
+    """BPTT of scan_forward_train (every forward path leaves the same saved states).  ``scatter_plan``: the library step
+    scatters through it (deterministic segmented reduction); the per-layer measurement paths keep the atomic kernel."""
     if isinstance(saved, AbiSaved):
         if PROBE is None:
+            set_scatter_plan(d_memory.device, scatter_plan)
             return abi_backward(spec, ids, saved, weights, d_memory, d_last, grad_out, defer_join)
         saved = list(saved)            # bench.py's in-step probe brackets a launch: per-layer path over the same states
         return scan_backward_layers(spec, ids, saved, weights, d_memory, d_last, grad_out, defer_join)

@@ -13,7 +13,12 @@
  *    this repo); the library never allocates device memory, frees or synchronises (the only objects it
  *    creates are the helper stream + two events of an HpmnTrainCtx);
  *  - all work is enqueued on `stream` (a hipStream_t passed as void*); no host sync;
- *  - all tensors are dense row-major, fp32 unless stated, ids are int32;
+ *  - all tensors are dense row-major, fp32 unless stated;
+ *  - TABLE IDS are int32 or int64: every entry point that takes ids (`const void *ids`) also carries an id-flags word
+ *    -- the argument / struct field historically named `mask_id0` -- whose bit HPMN_ID_MASK0 asks for the id-0 mask of
+ *    code/hpmn.py:417-422 and whose bit HPMN_ID_I64 says the ids are int64.  The reference feeds int32 placeholders
+ *    (code/hpmn.py:248-251); a table of more than 2^31 - 1 rows (BASELINE configs[4], "tables sized to 288 GB") needs the
+ *    wide form -- a documented deviation (hard part 4).  Row arithmetic is 64-bit throughout;
  *  - return value: 0 (HPMN_OK) or a negative HPMN_E* code; a failing HIP runtime call
  *    is reported as HPMN_EHIP and its hipError_t kept in hpmn_last_hip_error();
  *  - nothing throws across the ABI; thread-safe for distinct streams (the only global
@@ -29,7 +34,9 @@
 extern "C" {
 #endif
 
-#define HPMN_ABI_VERSION 9
+#define HPMN_ABI_VERSION 10
+#define HPMN_ID_MASK0 1   /* id-flags bit 0: id 0 gathers a zero row and receives no gradient (the Hpmn class)  */
+#define HPMN_ID_I64 2     /* id-flags bit 1: the ids tensor is int64 (default: int32)                          */
 #define HPMN_MAX_LAYERS 12
 
 enum {
@@ -50,9 +57,9 @@ int hpmn_gru_shape_supported(int32_t H, int32_t D);
  * Embedding gather.  Replaces Hpmn.embedding / Hpmn_Industry.embedding
  * (code/hpmn.py:414-423, :266-276):  out[n, f*E:(f+1)*E] = emb[ids[n,f]] * (mask_id0 ?
  * ids[n,f] != 0 : 1).  Also the gather-only roofline micro-benchmark.
- *   ids [N,F] int32, emb [V,E], out [N, F*E].   E % 4 == 0.
+ *   ids [N,F] int32 / int64 (mask_id0 = id flags, see Conventions), emb [V,E], out [N, F*E].   E % 4 == 0.
  * ---------------------------------------------------------------------------------- */
-int hpmn_embed_gather(const int32_t *ids, const float *emb, float *out,
+int hpmn_embed_gather(const void *ids, const float *emb, float *out,
                       int64_t N, int32_t F, int32_t E, int64_t V, int32_t mask_id0,
                       void *stream);
 
@@ -88,7 +95,7 @@ int hpmn_embed_gather(const int32_t *ids, const float *emb, float *out,
 typedef struct HpmnInputProj {
     int32_t B, T, D, H;
     const float *x;
-    const int32_t *ids;
+    const void *ids;
     const float *emb;
     int32_t Tids, F, E, front_zero, mask_id0;
     int64_t V;
@@ -133,7 +140,7 @@ int hpmn_gru_scan_fwd(const HpmnGruFwd *args, void *stream);
 typedef struct HpmnGruFusedFwd {
     int32_t B, T, D, H;
     const float *x;            /* [B,T,D], or NULL: gather from (ids, emb) as in HpmnInputProj */
-    const int32_t *ids;
+    const void *ids;
     const float *emb;
     int32_t Tids, F, E, front_zero, mask_id0;
     int64_t V;
@@ -227,7 +234,7 @@ typedef struct HpmnGruBwd {
      *   with d_last[b] (the read path's gradient wrt uinp[:, last_index, :], may be NULL) added at step last_t --
      * what hpmn_embed_grad_scatter does as a launch of its own behind this one.  Runs of equal ids (the constant uid column,
      * padding) are summed in registers before one atomic row add.  NULL d_emb: off. */
-    const int32_t *scatter_ids;   /* [B, Tids, F] */
+    const void *scatter_ids;   /* [B, Tids, F] */
     float *d_emb;                 /* [V, E] */
     const float *d_last;          /* [B, D] */
     int32_t Tids, F, E, front_zero, mask_id0, last_t;
@@ -307,7 +314,7 @@ typedef struct HpmnScanDesc {
 } HpmnScanDesc;
 
 size_t hpmn_scan_workspace_bytes(const HpmnScanDesc *desc);
-int hpmn_scan_fwd(const HpmnScanDesc *desc, const int32_t *ids, const float *emb,
+int hpmn_scan_fwd(const HpmnScanDesc *desc, const void *ids, const float *emb,
                   const float *const *wg, const float *const *bg,
                   const float *const *wc, const float *const *bc,
                   float *memory, float *last, void *workspace, void *stream);
@@ -353,10 +360,10 @@ int hpmn_train_ctx_create(HpmnTrainCtx **ctx);
 void hpmn_train_ctx_destroy(HpmnTrainCtx *ctx);
 size_t hpmn_scan_train_workspace_bytes(const HpmnScanDesc *desc);
 int hpmn_scan_train_layout(const HpmnScanDesc *desc, HpmnTrainLayout *out);
-int hpmn_scan_fwd_train(HpmnTrainCtx *ctx, const HpmnScanDesc *desc, const int32_t *ids, const float *emb,
+int hpmn_scan_fwd_train(HpmnTrainCtx *ctx, const HpmnScanDesc *desc, const void *ids, const float *emb,
                         const float *const *wg, const float *const *bg, const float *const *wc,
                         const float *const *bc, float *memory, float *last, void *workspace, void *stream);
-int hpmn_scan_bwd(HpmnTrainCtx *ctx, const HpmnScanDesc *desc, const int32_t *ids, const float *const *wg,
+int hpmn_scan_bwd(HpmnTrainCtx *ctx, const HpmnScanDesc *desc, const void *ids, const float *const *wg,
                   const float *const *wc, const float *d_memory, const float *d_last, float *const *d_wg,
                   float *const *d_bg, float *const *d_wc, float *const *d_bc, float *d_emb, void *workspace,
                   int32_t defer_join, void *stream);
@@ -373,6 +380,48 @@ int hpmn_train_probe_ms(HpmnTrainCtx *ctx, float *ms);
  * no separate layer-0 launch (H = 32). */
 int hpmn_train_mark_layer0_reverse(HpmnTrainCtx *ctx, int32_t enable);
 int hpmn_train_wait_layer0_reverse(HpmnTrainCtx *ctx, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * DETERMINISTIC embedding-gradient scatter (r4): the gradient of Hpmn.embedding (code/hpmn.py:421-422; TF sums the
+ * IndexedSlices of equal ids when it densifies them, :204-205) as a segmented reduction over the batch's lookups in ROW
+ * ORDER.  Every table row's gradient rows are added in ONE fixed order (ascending lookup index b*T*F + t*F + f) by one
+ * group of lanes and stored plainly -- no atomics: bit-reproducible run to run, identical on every data-parallel replica.
+ *
+ * The order depends on the ids only, so it is prepared off the serial chain:
+ *   the caller sorts the n = B*T*F flattened ids STABLY: sorted_ids [n], perm [n] int32 (perm[j] = lookup index of the
+ *   j-th entry in row order), and seg [n] int32 (seg[j] = number of distinct ids in front of entry j: an inclusive
+ *   prefix count of "differs from its predecessor" minus 1) -- torch.sort / cumsum in this repo;
+ *   hpmn_scatter_plan  ->  start [n+1] int32 (start[u] = first entry of row u; start[U] = n), rows [n] (ids' width:
+ *                          rows[u] = table row of segment u, ascending), count [1] int32 = U  (only [0, U] / [0, U) written)
+ *   hpmn_embed_grad_segsum : out_rows[u, :] = sum_j d_x(lookup perm[j]) over start[u] <= j < start[u+1]   (optional, [n, E])
+ *                            d_emb[rows[u], :] += the same sum                                            (optional, [V, E])
+ *     with d_last[b] (the read path's gradient wrt uinp[:, last_index, :], may be NULL) joined at step t_last, and id 0
+ *     skipped (zero row in out_rows) under HPMN_ID_MASK0 -- exactly what hpmn_embed_grad_scatter adds atomically.
+ *     partials: scratch of hpmn_embed_grad_segsum_partials_floats(n, E) floats.   E % 4 == 0, 256 % (E/4) == 0.
+ * (rows, out_rows, count) are at the same time the touched-rows list a data-parallel rank exchanges and the compact
+ * gradient hpmn_adam_step_rows consumes.
+ * hpmn_train_set_scatter_plan(ctx, plan): the NEXT hpmn_scan_bwd on ctx scatters through the plan instead of the
+ * atomic kernel (plan == NULL or plan->n == 0: atomic); the plan is copied, its arrays must stay alive until that call's
+ * work has run.  One-shot: cleared by the hpmn_scan_bwd that used it.
+ * ---------------------------------------------------------------------------------- */
+typedef struct HpmnScatterPlan {
+    int64_t n;               /* B*T*F lookups of the batch                                        */
+    const int32_t *perm;     /* [n]                                                                */
+    const int32_t *seg;      /* [n]                                                                */
+    const int32_t *start;    /* [n+1]                                                              */
+    const void *rows;        /* [n] int32 / int64 (HPMN_ID_I64 of the id flags)                    */
+    const int32_t *count;    /* [1]                                                                */
+    float *out_rows;         /* optional [n, E]                                                    */
+    float *partials;         /* hpmn_embed_grad_segsum_partials_floats(n, E) floats                */
+} HpmnScatterPlan;
+
+int hpmn_scatter_plan(const void *sorted_ids, int32_t id_flags, int64_t n, const int32_t *seg, int32_t *start, void *rows,
+                      int32_t *count, void *stream);
+size_t hpmn_embed_grad_segsum_partials_floats(int64_t n, int32_t E);
+int hpmn_embed_grad_segsum(const HpmnScatterPlan *plan, const float *d_x, float *d_emb, int32_t B, int32_t T, int32_t F,
+                           int32_t E, int32_t front_zero, int32_t id_flags, const float *d_last, int32_t t_last,
+                           void *stream);
+int hpmn_train_set_scatter_plan(HpmnTrainCtx *ctx, const HpmnScatterPlan *plan);
 
 /* ------------------------------------------------------------------------------------
  * build_memory with ALL K layers in ONE launch (H = 64): forward hpmn_pipe_fwd, BPTT hpmn_pipe_bwd.
@@ -413,15 +462,15 @@ int hpmn_pipe_fwd(const HpmnPipe *args, void *stream);
 int hpmn_pipe_bwd(const HpmnPipe *args, void *stream);
 /* out[b, t, f*E:(f+1)*E] = t < front_zero ? 0 : emb[ids[b, t-front_zero, f]] * (mask_id0 ? id != 0 : 1):
  * Hpmn.embedding (code/hpmn.py:414-423 / :266-276) with the zero prefix of code/hpmn.py:288-289.
- *   ids [B, Tids, F] int32, emb [V, E], out [B, front_zero+Tids, F*E] */
-int hpmn_embed_gather_seq(const int32_t *ids, const float *emb, float *out, int32_t B, int32_t Tids, int32_t F,
+ *   ids [B, Tids, F] int32 / int64 (id flags in mask_id0), emb [V, E], out [B, front_zero+Tids, F*E] */
+int hpmn_embed_gather_seq(const void *ids, const float *emb, float *out, int32_t B, int32_t Tids, int32_t F,
                           int32_t E, int32_t front_zero, int64_t V, int32_t mask_id0, void *stream);
 
 /* The gather CONSUMED IN PLACE: out[b, f*E:(f+1)*E] += sum_t emb[ids[b,t,f]] * (mask_id0 ? id != 0 : 1) -- Hpmn.embedding
  * (code/hpmn.py:414-423) followed by a sum over time, without ever storing the gathered rows.  This is how the fused scan
  * kernels use the rows, and the roofline probe for north_star's gather target (4 B of id + 64 B of row per lookup is all the
  * traffic there is).  ids [B,T,F] (F <= 4), emb [V,E], out [B, F*E] pre-zeroed by the caller. */
-int hpmn_embed_gather_sum(const int32_t *ids, const float *emb, float *out, int32_t B, int32_t T, int32_t F, int32_t E,
+int hpmn_embed_gather_sum(const void *ids, const float *emb, float *out, int32_t B, int32_t T, int32_t F, int32_t E,
                           int64_t V, int32_t mask_id0, void *stream);
 
 /* ------------------------------------------------------------------------------------
@@ -504,7 +553,7 @@ int hpmn_read_param_grads_loss_n(int32_t nb, const HpmnReadDesc *const *desc, fl
  * in registers before one atomic row add.  d_emb must be zeroed by the caller.
  *   ids [B,T,F], d_x [B, front_zero+T, F*E], d_emb [V,E]
  * ---------------------------------------------------------------------------------- */
-int hpmn_embed_grad_scatter(const int32_t *ids, const float *d_x, float *d_emb,
+int hpmn_embed_grad_scatter(const void *ids, const float *d_x, float *d_emb,
                             int32_t B, int32_t T, int32_t F, int32_t E, int32_t front_zero,
                             int64_t V, int32_t mask_id0, void *stream);
 
@@ -539,8 +588,8 @@ int hpmn_adam_step_rows(float *param, const float *grad_rows, float *m, float *v
  *                          its flag, leaving grad [V,E] and flags all-zero for the next step (the caller must not
  *                          clear the table gradient densely any more, only make sure it starts all-zero)
  * param / grad / m / v: [V, E], 16-byte aligned; E/4 a power of two <= 64 (a row's lanes share one wave).  ids outside
- * [0, V) are ignored by the marking (padding entries of gathered id lists are -1). */
-int hpmn_table_mark_rows(const int32_t *ids, int64_t n_ids, uint8_t *flags, int64_t V, void *stream);
+ * [0, V) are ignored by the marking (padding entries of gathered id lists are -1).  id_flags: HPMN_ID_I64 for int64 ids. */
+int hpmn_table_mark_rows(const void *ids, int64_t n_ids, uint8_t *flags, int64_t V, int32_t id_flags, void *stream);
 int hpmn_adam_step_table(float *param, float *grad, float *m, float *v, uint8_t *flags, int64_t V, int32_t E,
                          int32_t pass, float lr_t, float beta1, float beta2, float eps, float clip, float grad_scale,
                          void *stream);

@@ -43,6 +43,41 @@ def run(m, tr, te, steps=5, batch=50):
     return out
 
 
+BIG_V = 2_200_000_000        # more rows than an int32 id can name (HPMN_DP_BIG=1)
+
+
+def build_big(tmp):
+    """configs[4]'s size class under data parallel: a 2.2 G-row table (rows of 4 floats: 35 GB per buffer), lazy (row-wise)
+    table Adam -- param + m + v, no dense gradient -- and int64 ids.  Only the top 400 rows are ever named."""
+    from hpmn_amd.hpmn import Hpmn_Industry
+    rng = np.random.default_rng(5)
+    n = 48
+    ids = rng.integers(BIG_V - 400, BIG_V, size=(n, 41, 4), dtype=np.int64)
+    ids[:, :, 0] = ids[:, -1:, 0]
+    tr = dict(ids=ids, label=rng.integers(0, 2, size=n).astype(np.int32))
+    m = Hpmn_Industry(tmp, tr, tr, BIG_V, 4, 1, 41, 1, 0.003, 64, 4, 3, [2] * 10 + [1], [1], 3, 1, True, False,
+                      memory_reg=5e-5, verbose=False, seed=3, lazy_table_adam=True)
+    return m, tr, tr
+
+
+def run_big(m, tr, te, steps=3, batch=16):
+    from hpmn_amd import dist
+    ds = m._dev(tr)
+    assert ds.ids.dtype == torch.int64
+    for step, (lo, hi) in enumerate(ds.batches(batch)):
+        a, b = dist.shard_bounds(lo, hi, m.rank, m.world)
+        m.train_step(ds.ids[a:b], ds.label[a:b], keep_prob=1.0, global_batch=hi - lo)
+        if step + 1 == steps:
+            break
+    out = {k: v.detach().cpu().numpy() for k, v in m.params.items() if k != "Embedding/emb_mtx"}
+    emb = m.params["Embedding/emb_mtx"]
+    out["top_rows"] = emb[BIG_V - 400:].detach().cpu().numpy()
+    out["below"] = emb[BIG_V - 100400:BIG_V - 400].abs().max().reshape(1).cpu().numpy()
+    out["m_top"] = m.flat_m[(BIG_V - 400) * 4:BIG_V * 4].detach().cpu().numpy()
+    out["__eval__"] = np.array(m.eval(te, 16))
+    return out
+
+
 def main():
     # HPMN_DP_BACKEND=nccl: one GPU per rank over RCCL (needs >= 2 devices); default: gloo, both ranks on cuda:0
     backend = os.environ.get("HPMN_DP_BACKEND", "gloo")
@@ -53,9 +88,10 @@ def main():
     else:
         td.init_process_group("gloo")
         torch.cuda.set_device(0)
-    m, tr, te = build(sys.argv[1] + ".model%d" % td.get_rank())
-    assert m.world == 2
-    out = run(m, tr, te)
+    big = os.environ.get("HPMN_DP_BIG") == "1"
+    m, tr, te = (build_big if big else build)(sys.argv[1] + ".model%d" % td.get_rank())
+    assert m.world == int(os.environ.get("WORLD_SIZE", "1"))
+    out = (run_big if big else run)(m, tr, te)
     if td.get_rank() == 0:
         np.savez(sys.argv[1], **out)
     td.barrier()

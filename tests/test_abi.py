@@ -42,7 +42,7 @@ def test_struct_layout_matches_c_compiler(tmp_path):
                "HpmnGruBwd": _lib.HpmnGruBwd, "HpmnGruWgrad": _lib.HpmnGruWgrad, "HpmnReadDesc": _lib.HpmnReadDesc,
                "HpmnScanDesc": _lib.HpmnScanDesc, "HpmnOnlineUpdate": _lib.HpmnOnlineUpdate,
                "HpmnGruFusedFwd": _lib.HpmnGruFusedFwd, "HpmnGruPairFwd": _lib.HpmnGruPairFwd, "HpmnGruPairBwd": _lib.HpmnGruPairBwd, "HpmnPipe": _lib.HpmnPipe,
-               "HpmnTrainLayout": _lib.HpmnTrainLayout}
+               "HpmnTrainLayout": _lib.HpmnTrainLayout, "HpmnScatterPlan": _lib.HpmnScatterPlan}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "hpmn_hip.h"', "int main(void){"]
     for name, st in structs.items():
         lines.append('printf("%s %%zu\\n", sizeof(%s));' % (name, name))
@@ -78,6 +78,13 @@ def test_error_codes_without_touching_a_device(lib):
     assert lib.hpmn_embed_gather(None, None, None, 0, 3, 16, 10, 1, None) == 0                          # N == 0
     assert lib.hpmn_embed_gather(None, None, None, 5, 3, 6, 10, 1, None) == -2                          # E % 4
     assert lib.hpmn_embed_grad_scatter(None, None, None, 2, 5, 3, 24, 0, 10, 1, None) == -2             # 64 % E
+    assert lib.hpmn_table_mark_rows(None, 0, None, 10, 2, None) == 0 and lib.hpmn_table_mark_rows(None, 4, None, 10, 2, None) == -1
+    plan = _lib.HpmnScatterPlan()
+    plan.n = 30
+    assert lib.hpmn_embed_grad_segsum(C.byref(plan), None, None, 2, 5, 3, 24, 0, 0, None, 0, None) == -2  # 256 % (E/4)
+    assert lib.hpmn_embed_grad_segsum(C.byref(plan), None, None, 2, 5, 4, 16, 0, 0, None, 0, None) == -1  # n != B*T*F
+    assert lib.hpmn_embed_grad_segsum(C.byref(plan), None, None, 2, 5, 3, 16, 0, 0, None, 0, None) == -1  # null arrays
+    assert lib.hpmn_embed_grad_segsum_partials_floats(64, 16) == 2 * 2 * 16 and lib.hpmn_scatter_plan(None, 0, 0, None, None, None, None, None) == 0
     # workspace size / divisibility of the layer lengths (the tf.reshape at code/hpmn.py:124)
     d = _lib.HpmnScanDesc()
     d.B, d.T, d.F, d.E, d.H, d.K, d.V = 128, 100, 3, 16, 32, 3, 1000

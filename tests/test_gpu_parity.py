@@ -618,6 +618,108 @@ def test_scatter_matches_dense_index_add(dev):
         np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-5, atol=1e-4)
 
 
+@pytest.mark.parametrize("wide", [False, True])
+@pytest.mark.parametrize("E", [16, 4])
+def test_deterministic_scatter_is_exact_ordered_and_reproducible(dev, wide, E):
+    """hpmn_scatter_plan + hpmn_embed_grad_segsum (csrc/scatter_sorted.hip): a row's gradient is the sum of its lookups' rows
+    in ascending lookup order, added by ONE lane group and stored plainly.  Against (a) float64 np.add.at, (b) a float32
+    emulation of exactly that order (per-chunk sums, chunks in order) -- BIT-identical, which is what "fixed order" means --,
+    and twice in a row
+    (torch.equal).  The id pattern covers every path of the two passes: rows inside one 32-entry chunk, the constant uid
+    column (1000-entry rows: dozens of chunks, the partial chain of pass 2), a hot id crossing exactly one chunk border,
+    the masked padding id 0 (thousands of entries, skipped), the read path's d_last row, int32 and int64 ids."""
+    from hpmn_amd import ops
+    rng = np.random.default_rng(83)
+    B, T, F, V, Z = 5, 1001, 2, 3000, 23
+    ids = rng.integers(1, V, size=(B, T, F)).astype(np.int64)
+    ids[:, :, 0] = rng.integers(1, V, size=(B, 1))               # constant column
+    ids[1, :400] = 0                                             # padding
+    ids[3, 100:140, 1] = 7                                       # a 40-entry row
+    ids[0, 5, 1] = 2999
+    dx = (rng.normal(size=(B, Z + T, F * E)) * 10.0 ** rng.integers(-6, 1, size=(B, Z + T, 1))).astype(np.float32)
+    dlast = rng.normal(size=(B, F * E)).astype(np.float32)
+    t_last = T - 2
+    t_ids = torch.as_tensor(ids if wide else ids.astype(np.int32)).to(dev)
+    t_dx, t_dl = torch.as_tensor(dx).to(dev), torch.as_tensor(dlast).to(dev)
+    term = dx[:, Z:].reshape(B, T, F, E).copy()
+    term[:, t_last] += dlast.reshape(B, F, E)                    # (joined to the lookup's row BEFORE the sum, as in the kernel)
+    for mask in (True, False):
+        want64 = np.zeros((V, E), dtype=np.float64)
+        np.add.at(want64, ids.reshape(-1), term.reshape(-1, E).astype(np.float64))
+        # the kernel's order in float32: entries in stable row order, cut into 32-entry chunks; a row's entries inside one
+        # chunk are added left to right, a row that spans chunks is the sum of its per-chunk sums in chunk order
+        flat_ids, flat_t = ids.reshape(-1), term.reshape(-1, E)
+        order = np.argsort(flat_ids, kind="stable")
+        want32 = np.zeros((V, E), dtype=np.float32)
+        started = np.zeros(V, bool)
+        for j0 in range(0, len(order), 32):
+            part = {}
+            for j in order[j0:j0 + 32]:
+                r = flat_ids[j]
+                part[r] = flat_t[j].copy() if r not in part else part[r] + flat_t[j]
+            for r, v in part.items():
+                want32[r] = v if not started[r] else want32[r] + v
+                started[r] = True
+        if mask:
+            want64[0] = 0
+            want32[0] = 0
+        plan = ops.ScatterPlan(t_ids, E, want_rows=True)
+        U = plan.count_host()
+        uniq = np.unique(ids.reshape(-1))
+        assert U == len(uniq) and np.array_equal(plan.rows[:U].cpu().numpy(), uniq)
+        outs = []
+        for rep in range(2):
+            got = torch.zeros(V, E, device=dev)
+            ops.embed_grad_segsum(plan, (B, T, F), t_dx, got, Z, mask, d_last=t_dl, t_last=t_last)
+            outs.append((got.clone(), plan.out_rows[:U].clone()))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        got = outs[0][0].cpu().numpy()
+        np.testing.assert_allclose(got, want64, rtol=1e-5, atol=1e-5)
+        assert np.array_equal(got, want32), "not the fixed-order float32 sum"
+        assert np.array_equal(outs[0][1].cpu().numpy(), want32[uniq])          # the compact rows == the dense rows
+        # += semantics (dual mode scatters two branches into one table gradient)
+        acc = torch.ones(V, E, device=dev)
+        ops.embed_grad_segsum(plan, (B, T, F), t_dx, acc, Z, mask, d_last=t_dl, t_last=t_last)
+        touched = np.zeros(V, bool)
+        touched[uniq] = True
+        if mask:
+            touched[0] = False
+        np.testing.assert_array_equal(acc.cpu().numpy()[~touched], 1.0)
+        np.testing.assert_allclose(acc.cpu().numpy()[touched], want32[touched] + 1.0, rtol=1e-6, atol=1e-6)
+        # and the atomic kernel it replaces agrees to rounding
+        old = torch.zeros(V, E, device=dev)
+        t_dx2 = t_dx.clone()
+        t_dx2[:, Z + t_last] += t_dl
+        ops.embed_grad_scatter(t_ids, t_dx2, old, Z, mask)
+        np.testing.assert_allclose(old.cpu().numpy(), want64, rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("name,cfg,B", [("industry_c3_shape", cfg_industry(H=64, K=7, T=1001, V=2000), 9),
+                                        ("amazon_h32", cfg_amazon(K=4, V=3000), 33)])
+def test_training_steps_are_bit_reproducible(dev, tmp_path, monkeypatch, name, cfg, B):
+    """with the scatter's atomics gone nothing in a train step depends on execution order -- two models
+    from the same weights fed the same batches end on torch.equal parameters and moments (dense two-pass table Adam
+    included), and the table gradient of a stand-alone compute_gradients is bit-identical run to run."""
+    monkeypatch.setenv("HPMN_TWO_PASS_MIN_NUMEL", "0")
+    p = f32_params(cfg, 191)
+    ids, label = rand_ids(cfg, B, 192)
+    ids[:, :, 0] = ids[:, -1:, 0]
+    t_ids, t_lab = torch.as_tensor(ids).to(dev), torch.as_tensor(label).to(dev)
+    runs = []
+    for r in range(2):
+        m = make_model(cfg, tmp_path / ("r%d" % r), p)
+        assert m.det_scatter
+        m.compute_gradients(t_ids, t_lab, keep_prob=1.0)
+        g0 = m.grads["Embedding/emb_mtx"].clone()
+        for step in range(3):
+            m.train_step(t_ids.roll(step, 0), t_lab.roll(step, 0), keep_prob=1.0)
+        torch.cuda.synchronize()
+        runs.append((g0, m.flat_param.clone(), m.flat_m.clone(), m.flat_v.clone()))
+    for a, b in zip(*runs):
+        assert torch.equal(a, b)
+    assert float(runs[0][0].abs().max()) > 0
+
+
 # ------------------------------------------------------------------------------- end to end
 def test_training_learns_planted_signal_and_save_load(dev, tmp_path):
     from hpmn_amd import datasets
@@ -919,6 +1021,99 @@ def test_table_rows_beyond_2_gib_give_identical_results(dev, tmp_path):
     np.testing.assert_allclose(big.params["Embedding/emb_mtx"][base:].cpu().numpy(),
                                small.params["Embedding/emb_mtx"].cpu().numpy(), rtol=0, atol=2e-6)
     assert float(big.params["Embedding/emb_mtx"][:base].abs().max()) == 0.0
+
+
+INT64_CASES = [
+    ("amazon_h32", cfg_amazon(K=3, T=100, V=300), 7),                       # all layers + gather in one launch (gru32_all)
+    ("industry_h64", cfg_industry(H=64, K=4, T=41, V=500), 5),              # fused layer-0 forward + pair launches
+    ("industry_h128", cfg_industry(H=128, K=3, T=41, V=500), 3),            # input_proj gather + four-wave scans
+    ("taobao_f4", O.HpmnConfig(600, 4, 300, 64, 16, 3, (2, 2, 3, 5, 5, 1), 5, False, 1e-5), 4),   # D0 = 64, pairs from layer 0
+    ("e4_f4", O.HpmnConfig(400, 4, 41, 64, 4, 3, (2,) * 10 + (1,), 3, True, 5e-5), 4),            # 16-byte rows (the big-table test's shape)
+]
+
+
+@pytest.mark.parametrize("name,cfg,B", INT64_CASES, ids=[c[0] for c in INT64_CASES])
+def test_int64_ids_give_the_results_of_int32_ids(dev, tmp_path, name, cfg, B):
+    """ABI v10: every entry point that takes ids takes them as int32 or int64 (HPMN_ID_I64 in the id-flags word).  Same ids in
+    both widths through inference, the training forward, BPTT + scatter, the two-pass table Adam and the gather probes: the
+    outputs must be IDENTICAL bit for bit (same kernels, same order; only the scatter's atomics may differ in the last bit)."""
+    from hpmn_amd import ops
+    p = f32_params(cfg, 171)
+    ids, label = rand_ids(cfg, B, 172)
+    m32 = make_model(cfg, tmp_path / "a", p)
+    m64 = make_model(cfg, tmp_path / "b", p)
+    for m in (m32, m64):
+        m.TWO_PASS_MIN_NUMEL = 0
+    t32, t64 = torch.as_tensor(ids).to(dev), torch.as_tensor(ids.astype(np.int64)).to(dev)
+    tl = torch.as_tensor(label).to(dev)
+    a, b = m32.forward_inference(t32), m64.forward_inference(t64)
+    for k in ("logit", "memory", "user_weights"):
+        assert torch.equal(a[k], b[k]), k
+    oa, ca = m32.compute_gradients(t32, tl, keep_prob=1.0)
+    ob, cb = m64.compute_gradients(t64, tl, keep_prob=1.0)
+    assert torch.equal(oa["memory"], ob["memory"]) and float(ca) == float(cb)
+    for k in p:
+        ga, gb = m32.grads[k], m64.grads[k]
+        if k == "Embedding/emb_mtx":
+            np.testing.assert_allclose(gb.cpu().numpy(), ga.cpu().numpy(), rtol=0, atol=1e-6 * float(ga.abs().max()))
+        else:
+            assert torch.equal(ga, gb), k
+    m32.train_step(t32, tl, keep_prob=1.0)
+    m64.train_step(t64, tl, keep_prob=1.0)
+    np.testing.assert_allclose(m64.flat_param.cpu().numpy(), m32.flat_param.cpu().numpy(), rtol=0, atol=2e-6)
+    emb = m32.params["Embedding/emb_mtx"]
+    if cfg.embedding_size == 16:
+        assert torch.equal(ops.embed_gather_seq(t32, emb, 3, not cfg.industry), ops.embed_gather_seq(t64, emb, 3, not cfg.industry))
+        assert torch.equal(ops.embed_gather_sum(t32, emb, not cfg.industry), ops.embed_gather_sum(t64, emb, not cfg.industry))
+    assert torch.equal(ops.embed_gather(t32, emb, not cfg.industry), ops.embed_gather(t64, emb, not cfg.industry))
+
+
+def test_a_table_of_more_rows_than_int32_holds(dev, tmp_path):
+    """Row g of the scope table (BASELINE configs[4]: "embedding tables sized to 288 GB"): a table of 2.2 G rows -- more than
+    an int32 id can name -- on the PRODUCT path: int64 ids end to end through the gather inside the forward kernels, the
+    scatter, the row marking and the dense two-pass Adam.  Rows of 4 floats keep the four flat buffers at 35 GB each (with
+    E = 16 param + grad + m + v of such a table would need 563 GB).  The top 400 rows hold a small model's table, ids shifted
+    to match: logits, gradient rows and updated rows must equal the small model's; everything below stays untouched."""
+    from hpmn_amd.hpmn import Hpmn_Industry
+    free, _ = torch.cuda.mem_get_info()
+    V = 2_200_000_000
+    if free < 4.4 * V * 16:
+        pytest.skip("needs ~155 GB of free HBM")
+    cfg = O.HpmnConfig(400, 4, 41, 64, 4, 3, (2,) * 10 + (1,), 3, True, 5e-5)
+    p = f32_params(cfg, 181)
+    ids, label = rand_ids(cfg, 6, 182)
+    base = V - 400
+    small = make_model(cfg, tmp_path / "small", p)
+    big = Hpmn_Industry(str(tmp_path / "big"), [], [], V, 4, 1, 41, 1, 0.003, 64, 4, 3, [2] * 10 + [1], [1], 3, 1,
+                        True, False, memory_reg=cfg.memory_reg, verbose=False)
+    assert big.params["Embedding/emb_mtx"].shape == (V, 4)
+    big.set_params({k: v for k, v in p.items() if k != "Embedding/emb_mtx"})
+    with torch.no_grad():
+        big.params["Embedding/emb_mtx"].zero_()
+        big.params["Embedding/emb_mtx"][base:].copy_(small.params["Embedding/emb_mtx"])
+    ts = torch.as_tensor(ids).to(dev)
+    tb = torch.as_tensor(ids.astype(np.int64) + base).to(dev)
+    assert int(tb.max()) > 2 ** 31
+    tl = torch.as_tensor(label).to(dev)
+    a, b = small.forward_inference(ts), big.forward_inference(tb)
+    assert torch.equal(a["logit"], b["logit"]) and torch.equal(a["memory"], b["memory"])
+    small.compute_gradients(ts, tl, keep_prob=1.0)
+    big.compute_gradients(tb, tl, keep_prob=1.0)
+    gs, gb = small.grads["Embedding/emb_mtx"], big.grads["Embedding/emb_mtx"]
+    np.testing.assert_allclose(gb[base:].cpu().numpy(), gs.cpu().numpy(), rtol=0, atol=1e-7)
+    assert float(gb[base - 1_000_000:base].abs().max()) == 0.0 and float(gb[:1_000_000].abs().max()) == 0.0
+    assert float(gb[:base].abs().max()) == 0.0                   # (one reduction over 35 GB: nothing anywhere below the top rows)
+    small.train_step(ts, tl, keep_prob=1.0)
+    big.train_step(tb, tl, keep_prob=1.0)                         # two-pass dense Adam over 2.2 G rows, int64 row marking
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(big.params["Embedding/emb_mtx"][base:].cpu().numpy(),
+                               small.params["Embedding/emb_mtx"].cpu().numpy(), rtol=0, atol=2e-6)
+    assert float(big.params["Embedding/emb_mtx"][base - 1_000_000:base].abs().max()) == 0.0
+    assert float(big.flat_grad[:V * 4].view(-1)[::4099].abs().max()) == 0.0          # pass 1 cleared the rows it consumed
+    a, b = small.forward_inference(ts), big.forward_inference(tb)
+    np.testing.assert_allclose(b["logit"].cpu().numpy(), a["logit"].cpu().numpy(), rtol=0, atol=1e-5)
+    del big
+    torch.cuda.empty_cache()
 
 
 @pytest.mark.gpu

@@ -21,7 +21,7 @@ batch=$(python -c "import bench; print(bench.CONFIGS['$cfg']['batch'])")
 python tools/pmc_digest.py $out/pmc_FETCH_SIZE.csv $out/pmc_WRITE_SIZE.csv 4 $cfg $batch $out/pmc_summary.json
 rm -f $out/pmc_FETCH_SIZE.csv $out/pmc_WRITE_SIZE.csv
 # bench.py reads the digest from profiles/ (and checks its source sha against the kernels it is about to run)
-[ "$cfg" = "c3" ] && cp $out/pmc_summary.json profiles/r03_pmc_summary.json
+[ "$cfg" = "c3" ] && cp $out/pmc_summary.json profiles/r04_pmc_summary.json
 rm -rf $out/step/prof
 timeout 900 python bench.py --config $cfg > $out/bench.json 2> $out/bench.err < /dev/null
 echo "bench rc=$?"
