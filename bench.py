@@ -439,12 +439,28 @@ def cpu_baseline(c, seed=0, budget_s=25.0):
     * ``torch.set_flush_denormal(True)``: fresh-init BPTT over 1024 steps produces denormal gradients, TensorFlow's
       CPU kernels run with flush-to-zero, PyTorch's do not by default -- without it a step costs 4-10x more and the
       first steps of a run are outliers;
+    * ``mallopt``: tensors up to 32 MB from the heap, heap never trimmed (see below: without it a step of batch 500 costs
+      2.3 s or 20 s at random);
     * ONE warm-up step AT THE MEASURED BATCH (the reference batch), a thread sweep {8,16,32} of one step each at that
       batch picks the thread count, then >= 5 timed steps (as many as fit the budget, at most 20): the MEDIAN is the
       value and every sample is reported; a second run must agree within 10 %."""
     from oracle import hpmn_oracle as O
     from oracle import torch_restatement as R
     flush_ok = bool(torch.set_flush_denormal(True))     # (stays on: this is the last leg of the run)
+    # glibc's allocator defaults are pathological for this workload: the per-time-step tensors of a batch of 500 are 128 KB --
+    # exactly the mmap threshold -- so, depending on the threshold's dynamic adjustment and on which arena a thread lands in,
+    # every tensor of a step is its own mmap + page faults + munmap: steps of the SAME batch took 2.3 s or 20 s at random
+    # (r4: 21.17 2.35 2.38 2.62 15.63 in one run).  Serve them from the heap and never trim it, as a tuned deployment (or
+    # TensorFlow's own CPU allocator) would: first step page-faults the heap in once, every later step reuses it.
+    malloc_tuned = False
+    try:
+        import ctypes
+        libc = ctypes.CDLL("libc.so.6")
+        M_TRIM_THRESHOLD, M_TOP_PAD, M_MMAP_THRESHOLD = -1, -2, -3
+        malloc_tuned = bool(libc.mallopt(M_MMAP_THRESHOLD, 32 << 20) and libc.mallopt(M_TRIM_THRESHOLD, 2 ** 31 - 1)
+                            and libc.mallopt(M_TOP_PAD, 256 << 20))
+    except OSError:
+        pass
     cfg = O.HpmnConfig(feature_size=c["V"], user_dim=c["F"], user_maxlen=c["T"], hidden_size=c["H"],
                        embedding_size=16, hop=3, user_layers=tuple(c["periods"]), user_num_layers=c["K"],
                        industry=c["industry"], memory_reg=c["memory_reg"])
@@ -506,7 +522,7 @@ def cpu_baseline(c, seed=0, budget_s=25.0):
     med = sorted(tt)[len(tt) // 2]
     medf = sorted(tf)[len(tf) // 2]
     return {"value": bs / med, "unit": "sequences/s", "cores": threads, "kind": "port",
-            "host_cpus": ncpu, "flush_denormal": flush_ok, "batch": bs, "warmup_steps_at_batch": 1 + len(cands),
+            "host_cpus": ncpu, "flush_denormal": flush_ok, "malloc_tuned": malloc_tuned, "batch": bs, "warmup_steps_at_batch": 1 + len(cands),
             "warmup_step_seconds": warm,
             "train_step_seconds": tt, "train_step_seconds_median": med,
             "train_step_seconds_spread": (max(tt) - min(tt)) / med,
@@ -516,7 +532,8 @@ def cpu_baseline(c, seed=0, budget_s=25.0):
             "sample": "median of %d train steps (fwd+BPTT+clip+dense Adam) of batch %d at the full %s shape after a warm-up "
                       "step at that batch (%.1fs: first-touch of the ~10 GB autograd tape) and a one-step-per-candidate "
                       "thread sweep at that batch, fp32 PyTorch-CPU eager restatement (oracle/torch_restatement.py), "
-                      "flush-to-zero denormals (as TensorFlow's CPU kernels), %d threads, %.1fs timed in total; forward-only: "
+                      "flush-to-zero denormals (as TensorFlow's CPU kernels), heap-served allocations (mallopt), %d threads, %.1fs "
+                      "timed in total; forward-only: "
                       "median of %d passes of the same batch; 1 thread: second of two train steps of batch 16"
                       % (len(tt), bs, c["name"], warm, threads, sum(tt), len(tf))}
 

@@ -20,12 +20,14 @@
 // the time loop has no control flow for the s_waitcnt pass to lose count in (see gru_scan_fwd.hip).
 // LDS reads go two (not four) 16-byte groups deep: with four the kernel needs ~275 registers and the
 // compiler parks ~50 stationary weights per lane in AGPRs (one v_accvgpr_read per use, every step).
+#include <cstdlib>
+
 #include "common.h"
 
 namespace hpmn {
 
 constexpr int H128 = 128;
-constexpr int PF = 4;          // prefetch distance (steps) == unroll factor of the time loop
+constexpr int PF4 = 4;         // prefetch distance (steps) == unroll factor of the time loop (four-wave form; eight-wave: 2)
 
 __device__ __forceinline__ void wg_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -37,31 +39,56 @@ __device__ __forceinline__ float join_halves(float x) {
     auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
+// x[lane] + x[lane ^ 16] + x[lane ^ 32] + x[lane ^ 48] in every lane (v_permlane16_swap: odd rows of 16 <-> even rows)
+__device__ __forceinline__ float join_quarters(float x) {
+    const unsigned v = __float_as_uint(x);
+    auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    return join_halves(__uint_as_float(r[0]) + __uint_as_float(r[1]));
+}
+template <int KQ> __device__ __forceinline__ float join_parts(float x) {
+    if constexpr (KQ == 2) return join_halves(x);
+    else return join_quarters(x);
+}
 
-template <bool TRAIN>
-__global__ __launch_bounds__(256, 1) void gru_scan_fwd128_kernel(const HpmnGruFwd a) {
+// r4: the same design with EIGHT waves per sequence (NW = 8).  unit u = 16 w + (lane & 15), k-quarter
+// p = lane >> 4: 3 * 32 = 96 stationary weights per lane instead of 192 -- half the packed FMAs and half the LDS reads on
+// every wave's step, under 128 registers, so two eight-wave workgroups share a CU (four waves per SIMD where the four-wave
+// form has two): the step is latency (two barriers, two LDS round trips, the activations), and twice the waves in flight
+// is what hides it.  The four partial dot products are joined with v_permlane16_swap + v_permlane32_swap.
+// Registers decide who gets it: 96 weights + the prefetch slots + two LDS read groups come to ~150 (forcing 128 spills
+// 46-117 of them into the time loop), so ONE eight-wave workgroup fits a CU, not two -- the eight-wave form is for batches
+// of at most one sequence per CU (B <= CUs: the per-GPU shard of configs[4] under data parallel, B = 63..250), where every
+// sequence is resident at once and each step has twice the lanes; beyond that the four-wave form (two workgroups of 260
+// registers per CU) keeps 2 x CUs sequences in flight.  HPMN_SCAN128_WAVES=4 / 8 forces either (measurement switch).
+
+template <bool TRAIN, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void gru_scan_fwd128_kernel(const HpmnGruFwd a) {
     constexpr int H = H128;
+    constexpr int KQ = NW / 2;            // k-parts per dot product (lanes of a wave that share a unit)
+    constexpr int UW = 64 / KQ;           // units per wave
+    constexpr int KP = H / KQ;            // k per part
+    constexpr int PF = NW == 8 ? 2 : PF4;
     __shared__ __attribute__((aligned(16))) float hb[H];
     __shared__ __attribute__((aligned(16))) float rhb[H];
     __builtin_amdgcn_s_setprio(3);
 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int c = lane & 31, p = lane >> 5;
-    const int u = 32 * w + c;
+    const int c = lane % UW, p = lane / UW;
+    const int u = UW * w + c;
     const int T = a.T, D = a.D;
     const long b = blockIdx.x;
 
-    // stationary recurrent weights of unit u, k in [64p, 64p + 64), exponent scale folded in
-    f2 whr[32], whu[32], whc[32];
+    // stationary recurrent weights of unit u, k in [KP p, KP p + KP), exponent scale folded in
+    f2 whr[KP / 2], whu[KP / 2], whc[KP / 2];
 #pragma unroll
-    for (int i = 0; i < 32; ++i) {
-        const long k = D + 64 * p + 2 * i;
+    for (int i = 0; i < KP / 2; ++i) {
+        const long k = D + KP * p + 2 * i;
         whr[i] = f2{a.wg[k * 2 * H + u], a.wg[(k + 1) * 2 * H + u]} * NEG_LOG2E;
         whu[i] = f2{a.wg[k * 2 * H + H + u], a.wg[(k + 1) * 2 * H + H + u]} * NEG_LOG2E;
         whc[i] = f2{a.wc[k * H + u], a.wc[(k + 1) * H + u]} * (2.0f * NEG_LOG2E);
     }
 #pragma unroll
-    for (int i = 0; i < 32; ++i) { settle(whr[i]); settle(whu[i]); settle(whc[i]); }
+    for (int i = 0; i < KP / 2; ++i) { settle(whr[i]); settle(whu[i]); settle(whc[i]); }
 
     const int t0 = a.t_begin;
     const int t1 = a.t_end > 0 ? a.t_end : T;
@@ -92,39 +119,50 @@ __global__ __launch_bounds__(256, 1) void gru_scan_fwd128_kernel(const HpmnGruFw
     int next_fire = t0 + period - 1;
     float *yp = has_y ? a.y + (b * (long)(T / period) + t0 / period) * H + u : a.h_last + b * a.h_last_stride + u;
     const int y_adv = has_y ? H : 0;
-    // TRAIN stores, split over the half-waves by select: p == 0 writes (hs, r), p == 1 writes (u, c)
+    // TRAIN stores, split over the lane parts by select: (KQ = 2) p == 0 writes (hs, r), p == 1 writes (u, c);
+    // (KQ = 4) one value per part: hs, r, u, c
     float *s0 = nullptr, *s1 = nullptr;
     long adv0 = 0, adv1 = 0;
     if constexpr (TRAIN) {
         float *hsp = a.hs + (b * (long)(T + 1) + t0 + 1) * H + u;
         float *gp = a.gates + (b * (long)T + t0) * 3 * H + u;
-        s0 = p == 0 ? hsp : gp + H;
-        s1 = p == 0 ? gp : gp + 2 * H;
-        adv0 = p == 0 ? H : 3 * H;
-        adv1 = 3 * H;
+        if constexpr (KQ == 2) {
+            s0 = p == 0 ? hsp : gp + H;
+            s1 = p == 0 ? gp : gp + 2 * H;
+            adv0 = p == 0 ? H : 3 * H;
+            adv1 = 3 * H;
+        } else {
+            s0 = p == 0 ? hsp : gp + (p - 1) * H;
+            adv0 = p == 0 ? H : 3 * H;
+        }
     }
-    const float4 *hrow = reinterpret_cast<const float4 *>(&hb[64 * p]);
-    const float4 *rrow = reinterpret_cast<const float4 *>(&rhb[64 * p]);
+    const float4 *hrow = reinterpret_cast<const float4 *>(&hb[KP * p]);
+    const float4 *rrow = reinterpret_cast<const float4 *>(&rhb[KP * p]);
 
     auto step = [&](int t, int slot) {
         f2 ar = {0.f, 0.f}, au = {0.f, 0.f};
-        bcast_matvec2<16, 2>(hrow, whr, whu, ar, au);
-        const float r = sigmoid_scaled(xr[slot] + join_halves(ar.x + ar.y));
-        const float ug = sigmoid_scaled(xu[slot] + join_halves(au.x + au.y));
+        bcast_matvec2<KP / 4, 2>(hrow, whr, whu, ar, au);
+        const float r = sigmoid_scaled(xr[slot] + join_parts<KQ>(ar.x + ar.y));
+        const float ug = sigmoid_scaled(xu[slot] + join_parts<KQ>(au.x + au.y));
         rhb[u] = r * h;                     // both halves write the same value: no branch
         wg_barrier();                       // every wave's r*h is in place; every wave is done reading hb
         f2 ac = {0.f, 0.f}, ac2 = {0.f, 0.f};
-        bcast_matvec<16, 2>(rrow, whc, ac, ac2);
+        bcast_matvec<KP / 4, 2>(rrow, whc, ac, ac2);
         ac += ac2;
-        const float cc = tanh_scaled(xc[slot] + join_halves(ac.x + ac.y));
+        const float cc = tanh_scaled(xc[slot] + join_parts<KQ>(ac.x + ac.y));
         h = fmaf(ug, h - cc, cc);
         hb[u] = h;
         fetch(t + PF, slot);
         if constexpr (TRAIN) {
-            *s0 = p == 0 ? h : ug;
-            *s1 = p == 0 ? r : cc;
-            s0 += adv0;
-            s1 += adv1;
+            if constexpr (KQ == 2) {
+                *s0 = p == 0 ? h : ug;
+                *s1 = p == 0 ? r : cc;
+                s0 += adv0;
+                s1 += adv1;
+            } else {
+                *s0 = p == 0 ? h : (p == 1 ? r : (p == 2 ? ug : cc));
+                s0 += adv0;
+            }
         }
         *yp = h;
         const bool fire = t == next_fire;
@@ -145,28 +183,32 @@ __global__ __launch_bounds__(256, 1) void gru_scan_fwd128_kernel(const HpmnGruFw
     if (p == 0) a.h_last[b * a.h_last_stride + u] = h;
 }
 
-__global__ __launch_bounds__(256, 1) void gru_scan_bwd128_kernel(const HpmnGruBwd a) {
+template <int NW>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void gru_scan_bwd128_kernel(const HpmnGruBwd a) {
     constexpr int H = H128;
+    constexpr int KQ = NW / 2, UW = 64 / KQ;
+    constexpr int KC = H / KQ, KG = 2 * H / KQ;      // columns of wc / wg per lane part
+    constexpr int PF = NW == 8 ? 2 : PF4;
     __shared__ __attribute__((aligned(16))) float bufA[H];
     __shared__ __attribute__((aligned(16))) float bufB[2 * H];
     __builtin_amdgcn_s_setprio(3);
 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int c = lane & 31, p = lane >> 5;
-    const int j = 32 * w + c;
+    const int c = lane % UW, p = lane / UW;
+    const int j = UW * w + c;
     const int T = a.T, D = a.D;
     const long b = blockIdx.x;
 
-    // row D + j of the recurrent kernels (transposed products): wc columns [64p, 64p+64), wg columns [128p, 128p+128)
-    f2 wcT[32], wgT[64];
+    // row D + j of the recurrent kernels (transposed products): wc columns [KC p, KC p + KC), wg columns [KG p, KG p + KG)
+    f2 wcT[KC / 2], wgT[KG / 2];
 #pragma unroll
-    for (int n = 0; n < 32; ++n) wcT[n] = *reinterpret_cast<const f2 *>(a.wc + (long)(D + j) * H + 64 * p + 2 * n);
+    for (int n = 0; n < KC / 2; ++n) wcT[n] = *reinterpret_cast<const f2 *>(a.wc + (long)(D + j) * H + KC * p + 2 * n);
 #pragma unroll
-    for (int n = 0; n < 64; ++n) wgT[n] = *reinterpret_cast<const f2 *>(a.wg + (long)(D + j) * 2 * H + 128 * p + 2 * n);
+    for (int n = 0; n < KG / 2; ++n) wgT[n] = *reinterpret_cast<const f2 *>(a.wg + (long)(D + j) * 2 * H + KG * p + 2 * n);
 #pragma unroll
-    for (int n = 0; n < 32; ++n) settle(wcT[n]);
+    for (int n = 0; n < KC / 2; ++n) settle(wcT[n]);
 #pragma unroll
-    for (int n = 0; n < 64; ++n) settle(wgT[n]);
+    for (int n = 0; n < KG / 2; ++n) settle(wgT[n]);
 
     const int period = a.period;
     const bool has_dy = a.d_y != nullptr;
@@ -201,10 +243,11 @@ __global__ __launch_bounds__(256, 1) void gru_scan_bwd128_kernel(const HpmnGruBw
 #pragma unroll
     for (int i = 0; i < PF; ++i) { settle(gr[i]); settle(gu[i]); settle(gc[i]); settle(ghp[i]); settle(gdy[i]); }
 
-    const float4 *arow = reinterpret_cast<const float4 *>(&bufA[64 * p]);
-    const float4 *brow = reinterpret_cast<const float4 *>(&bufB[128 * p]);
-    // d_act stores split over the half-waves by select: p == 0 writes (da_r, da_u), p == 1 writes (dc_pre, dc_pre)
-    float *da0 = a.d_act + (b * (long)T + (t_hi - 1)) * 3 * H + j + (p == 0 ? 0 : 2 * H);
+    const float4 *arow = reinterpret_cast<const float4 *>(&bufA[KC * p]);
+    const float4 *brow = reinterpret_cast<const float4 *>(&bufB[KG * p]);
+    // d_act stores split over the lane parts by select: (KQ = 2) p == 0 writes (da_r, da_u), p == 1 writes (dc_pre, dc_pre);
+    // (KQ = 4) one value per part: da_r, da_u, dc_pre, dc_pre
+    float *da0 = a.d_act + (b * (long)T + (t_hi - 1)) * 3 * H + j + (KQ == 2 ? (p == 0 ? 0 : 2 * H) : (p < 2 ? p : 2) * H);
     float *da1 = a.d_act + (b * (long)T + (t_hi - 1)) * 3 * H + j + (p == 0 ? H : 2 * H);
 
     auto step = [&](int t, int slot) {
@@ -217,21 +260,26 @@ __global__ __launch_bounds__(256, 1) void gru_scan_bwd128_kernel(const HpmnGruBw
         fetch(t - PF, slot);
         wg_barrier();                       // dc_pre of all units in place; everyone is done reading bufB
         f2 d0 = {0.f, 0.f}, d1 = {0.f, 0.f};
-        bcast_matvec<16, 2>(arow, wcT, d0, d1);
+        bcast_matvec<KC / 4, 2>(arow, wcT, d0, d1);
         d0 += d1;
-        const float drh = join_halves(d0.x + d0.y);
+        const float drh = join_parts<KQ>(d0.x + d0.y);
         const float dar = drh * hp * r * (1.f - r);
         bufB[j] = dar;
         bufB[H + j] = dau;
         wg_barrier();                       // [da_r | da_u] in place; everyone is done reading bufA
         f2 e0 = {0.f, 0.f}, e1 = {0.f, 0.f};
-        bcast_matvec<32, 2>(brow, wgT, e0, e1);
+        bcast_matvec<KG / 4, 2>(brow, wgT, e0, e1);
         e0 += e1;
-        const float e = join_halves(e0.x + e0.y);
-        *da0 = p == 0 ? dar : dcp;
-        *da1 = p == 0 ? dau : dcp;
-        da0 -= 3 * H;
-        da1 -= 3 * H;
+        const float e = join_parts<KQ>(e0.x + e0.y);
+        if constexpr (KQ == 2) {
+            *da0 = p == 0 ? dar : dcp;
+            *da1 = p == 0 ? dau : dcp;
+            da0 -= 3 * H;
+            da1 -= 3 * H;
+        } else {
+            *da0 = p == 0 ? dar : (p == 1 ? dau : dcp);
+            da0 -= 3 * H;
+        }
         dh = fmaf(dh, ug, fmaf(drh, r, e));
     };
 
@@ -246,14 +294,33 @@ __global__ __launch_bounds__(256, 1) void gru_scan_bwd128_kernel(const HpmnGruBw
     if (t_lo0 > 0 && p == 0) a.dh_carry[b * H + j] = dh;
 }
 
+// eight waves per sequence while one such workgroup per CU holds the whole batch; beyond that (or HPMN_SCAN128_WAVES=4) four
+static int scan128_waves(int B) {
+    static const int env = [] { const char *e = getenv("HPMN_SCAN128_WAVES"); return e ? atoi(e) : 0; }();
+    if (env == 4 || env == 8) return env;
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return 256;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return 256;
+        return n;
+    }();
+    return B <= cus ? 8 : 4;
+}
+
 int gru_scan_fwd128_dispatch(const HpmnGruFwd &a, hipStream_t st) {
-    if (a.hs != nullptr) hipLaunchKernelGGL((gru_scan_fwd128_kernel<true>), dim3(a.B), dim3(256), 0, st, a);
-    else                 hipLaunchKernelGGL((gru_scan_fwd128_kernel<false>), dim3(a.B), dim3(256), 0, st, a);
+    if (scan128_waves(a.B) == 8) {
+        if (a.hs != nullptr) hipLaunchKernelGGL((gru_scan_fwd128_kernel<true, 8>), dim3(a.B), dim3(512), 0, st, a);
+        else                 hipLaunchKernelGGL((gru_scan_fwd128_kernel<false, 8>), dim3(a.B), dim3(512), 0, st, a);
+    } else {
+        if (a.hs != nullptr) hipLaunchKernelGGL((gru_scan_fwd128_kernel<true, 4>), dim3(a.B), dim3(256), 0, st, a);
+        else                 hipLaunchKernelGGL((gru_scan_fwd128_kernel<false, 4>), dim3(a.B), dim3(256), 0, st, a);
+    }
     return check_launch();
 }
 
 int gru_scan_bwd128_dispatch(const HpmnGruBwd &a, hipStream_t st) {
-    hipLaunchKernelGGL(gru_scan_bwd128_kernel, dim3(a.B), dim3(256), 0, st, a);
+    if (scan128_waves(a.B) == 8) hipLaunchKernelGGL((gru_scan_bwd128_kernel<8>), dim3(a.B), dim3(512), 0, st, a);
+    else                         hipLaunchKernelGGL((gru_scan_bwd128_kernel<4>), dim3(a.B), dim3(256), 0, st, a);
     return check_launch();
 }
 

@@ -43,9 +43,13 @@ static int fill_args(const HpmnPipe &p, bool bwd, PipeArgs &a) {
         if (!p.wg[i] || !p.wc[i]) return HPMN_EINVAL;
         L.wg = p.wg[i]; L.bg = p.bg[i]; L.wc = p.wc[i]; L.bc = p.bc[i];
         L.T = p.T[i]; L.D = p.D[i];
-        L.period = i + 1 < p.K ? p.period[i] : 1;       // the top layer has no subsampled output
+        // the top layer of the call has no subsampled output -- unless the caller hands it a y buffer (forward only, r4): the
+        // call then is a GROUP of layers of a taller stack and the next call's x0 is this y (ops.tiled_forward_inference)
+        const bool top_y = !bwd && i + 1 == p.K && p.y[i] != nullptr;
+        if (top_y && p.T[i] % p.period[i] != 0) return HPMN_EINVAL;
+        L.period = (i + 1 < p.K || top_y) ? p.period[i] : 1;
         L.x = i == 0 ? p.x0 : p.y[i - 1];
-        L.y = i + 1 < p.K ? p.y[i] : nullptr;
+        L.y = (i + 1 < p.K || top_y) ? p.y[i] : nullptr;
         if (i + 1 < p.K && !p.y[i]) return HPMN_EINVAL;
         L.hs = p.hs[i]; L.gates = p.gates[i];
         L.h_last_stride = p.mem_stride > 0 ? (long)p.mem_stride : (long)p.K * p.H;

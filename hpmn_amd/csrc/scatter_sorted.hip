@@ -19,7 +19,7 @@
 
 namespace hpmn {
 
-constexpr int SCH = 32;          // entries per chunk
+constexpr int SCH = 16;          // entries per chunk
 
 // start[u] = first sorted entry of segment u, rows[u] = its table row, start[U] = n, count[0] = U.
 __global__ __launch_bounds__(256) void scatter_plan_kernel(const void *__restrict__ sorted_ids, int id_flags, long n,
@@ -81,13 +81,17 @@ __device__ __forceinline__ void write_row(const SegArgs &a, int u, int e4, float
     }
 }
 
-// PASS 1.  thread = (chunk, e4): E4 adjacent lanes own a chunk.
+// PASS 1.  thread = (chunk, e4): E4 adjacent lanes own a chunk.  Everything a chunk needs is requested up front in three
+// batches of independent loads (order + segment of its entries; their gradient rows and table rows; the table-gradient rows
+// it will add to): the first version looked segment extents up inside the serial run loop -- two dependent loads per row,
+// 32 rows deep -- and cost the C3 step 0.16 ms.
 __global__ __launch_bounds__(256) void segsum_chunks_kernel(SegArgs a, long nchunk) {
     const long g = ((long)blockIdx.x * blockDim.x + threadIdx.x) / a.E4;
     const int e4 = threadIdx.x % a.E4;
     if (g >= nchunk) return;
     const long j0 = g * SCH;
     const int m = (int)((a.n - j0) < SCH ? (a.n - j0) : SCH);
+    const long jend = j0 + m;
     int q[SCH], sg[SCH];
 #pragma unroll
     for (int i = 0; i < SCH; ++i) {
@@ -95,33 +99,72 @@ __global__ __launch_bounds__(256) void segsum_chunks_kernel(SegArgs a, long nchu
         q[i] = a.perm[j];
         sg[i] = a.seg[j];
     }
+    const int sg_prev = j0 > 0 ? a.seg[j0 - 1] : -1;               // does the first run continue one from the chunk before?
+    const int sg_next = jend < a.n ? a.seg[jend] : -1;             // does the last run continue into the next chunk?
     float4 v[SCH];
-#pragma unroll
-    for (int i = 0; i < SCH; ++i) v[i] = lookup_grad(a, q[i], e4);     // all of the chunk's rows in flight at once
-    const long jend = j0 + m;
-    int run = sg[0];
-    long run_begin = j0;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    bool first_run = true;
-    auto flush = [&](long run_end) {               // [run_begin, run_end) summed into acc, segment `run`
-        const bool whole = a.start[run] >= run_begin && a.start[run + 1] <= run_end;
-        if (whole) write_row(a, run, e4, acc);
-        else reinterpret_cast<float4 *>(a.partials)[(2 * g + (first_run ? 0 : 1)) * a.E4 + e4] = acc;
-        first_run = false;
-    };
+    long row[SCH];
 #pragma unroll
     for (int i = 0; i < SCH; ++i) {
-        if (i < m) {
-            if (sg[i] != run) {
-                flush(j0 + i);
-                run = sg[i];
-                run_begin = j0 + i;
-                acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        v[i] = lookup_grad(a, q[i], e4);
+        row[i] = load_id(a.rows, sg[i], a.id_flags);
+    }
+    // run sums, left to right: the LAST entry of a run ends up holding the run's sum
+    unsigned ends = 0, first_run = 0;                               // bit i: entry i closes a run / that run began at entry 0
+    {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        bool from0 = true;
+#pragma unroll
+        for (int i = 0; i < SCH; ++i) {
+            if (i < m) {
+                acc.x += v[i].x; acc.y += v[i].y; acc.z += v[i].z; acc.w += v[i].w;
+                const bool end = (i == m - 1) || (sg[i + 1 < SCH ? i + 1 : i] != sg[i]);
+                if (end) {
+                    v[i] = acc;
+                    acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                    ends |= 1u << i;
+                    first_run |= from0 ? (1u << i) : 0u;
+                    from0 = false;
+                }
             }
-            acc.x += v[i].x; acc.y += v[i].y; acc.z += v[i].z; acc.w += v[i].w;
         }
     }
-    flush(jend);
+    // a run is WHOLE unless it touches a chunk border across which its segment continues
+    unsigned whole = 0;
+#pragma unroll
+    for (int i = 0; i < SCH; ++i) {
+        if ((ends >> i) & 1u) {
+            const bool left = ((first_run >> i) & 1u) && sg_prev == sg[i];
+            const bool right = (i == m - 1) && sg_next == sg[i];
+            whole |= (!left && !right) ? (1u << i) : 0u;
+        }
+    }
+    float4 *P = reinterpret_cast<float4 *>(a.partials);
+    float4 *D = reinterpret_cast<float4 *>(a.d_emb);
+    float4 *O = reinterpret_cast<float4 *>(a.out_rows);
+#pragma unroll
+    for (int h = 0; h < SCH; h += 8) {                              // the read-modify-write of the table gradient, 8 rows in flight
+        float4 old[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int k = h + i;
+            old[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (((whole >> k) & 1u) && D != nullptr && !id_masked(row[k], a.id_flags)) old[i] = D[row[k] * a.E4 + e4];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int k = h + i;
+            if (!((ends >> k) & 1u)) continue;
+            if ((whole >> k) & 1u) {
+                const bool masked = id_masked(row[k], a.id_flags);
+                const float4 s = masked ? make_float4(0.f, 0.f, 0.f, 0.f) : v[k];
+                if (O != nullptr) O[(long)sg[k] * a.E4 + e4] = s;
+                if (D != nullptr && !masked)
+                    D[row[k] * a.E4 + e4] = make_float4(old[i].x + s.x, old[i].y + s.y, old[i].z + s.z, old[i].w + s.w);
+            } else {
+                P[(2 * g + (((first_run >> k) & 1u) ? 0 : 1)) * a.E4 + e4] = v[k];
+            }
+        }
+    }
 }
 
 // PASS 2.  The chunk in which a row that crosses a chunk border BEGINS: its partial (this chunk's last run), then the first

@@ -195,7 +195,11 @@ class Hpmn_Basic(object):
         self.table_exchange = os.environ.get("HPMN_TABLE_EXCHANGE", "auto")
         # Deterministic table gradients (r4): the scatter as a segmented reduction in row order, no atomics (ops.ScatterPlan,
         # csrc/scatter_sorted.hip).  HPMN_DET_SCATTER=0: the atomic kernel (run-length pre-reduced fp32 atomics).
-        self.det_scatter = os.environ.get("HPMN_DET_SCATTER", "1") != "0"
+        # "auto" (default): on where the plan's sort hides underneath the forward on the auxiliary stream (tables big enough for
+        # the step to use that stream: XLong) and under the data-parallel rows exchange (which needs the distinct rows anyway);
+        # the 0.3 ms steps of the small-table configurations would pay ~20 extra launches of host time for it (C1: +17 %).
+        self._det_env = os.environ.get("HPMN_DET_SCATTER", "auto")
+        self.det_scatter = self._det_env == "1"
         self._plan_wants_rows = False     # (the data-parallel rows exchange sends the plan's compact rows)
         self.last_scatter_plan = None
         self._sharded_moments = False     # set once the sharded table update has run (save_model gathers the moments then)
@@ -349,13 +353,28 @@ class Hpmn_Basic(object):
         """Eval-mode forward (keep_prob 1): hpmn_scan_fwd chain + hpmn_read_fwd."""
         if not self._hip_read:
             return self._forward_inference_branches(ids, item_ids)
-        memory, last = ops.scan_forward_inference(self.spec, ids, self.params["Embedding/emb_mtx"],
-                                                  self._gru_weights())
+        if self._tiled_inference(ids.shape[0]):
+            # evaluation-sized batches: the 16-sequence-tile MFMA kernel, layer by layer (ops.tiled_forward_inference)
+            memory, last = ops.tiled_forward_inference(self.spec, ids, self.params["Embedding/emb_mtx"], self._gru_weights(),
+                                                       group=1)
+        else:
+            memory, last = ops.scan_forward_inference(self.spec, ids, self.params["Embedding/emb_mtx"],
+                                                      self._gru_weights())
         if ids.shape[0] == 0:
             z = torch.empty(0, device=self.device)
             return dict(memory=memory, prediction=z, logit=z, user_weights=torch.empty(0, self.spec.K, device=self.device),
                         memory_loss=torch.zeros((), device=self.device))
         return ops.read_fwd(self._read_desc, self._read_params, memory, last, want_logit, want_att)
+
+    # Rows from which the forward-only path switches from one sequence per wave to 16-sequence tiles on the matrix cores
+    # (r4, C3 shape, build_memory alone: 673 k / 565 k sequences/s at 1000 rows, 690 k / 1.06 M at 2000, 725 k / 1.76 M at
+    # 4000 -- a tile kernel needs ~256 tiles to fill the chip, the per-sequence kernels saturate at one wave per SIMD)
+    TILED_EVAL_MIN_ROWS = int(os.environ.get("HPMN_TILED_EVAL_MIN_ROWS", "1536"))
+    TILED_EVAL_ROWS = int(os.environ.get("HPMN_TILED_EVAL_ROWS", "4096"))        # rows eval() puts in flight per pass
+
+    def _tiled_inference(self, rows: int) -> bool:
+        return bool(self.TILED_EVAL_MIN_ROWS > 0 and rows >= self.TILED_EVAL_MIN_ROWS and self.spec.H == 64
+                    and self.spec.E % 4 == 0 and ops.tile_kernel_supported(64, self.spec.D0))
 
     # ------------------------------------------------------------------ graphs that execute the item branch
     def _branch_inputs(self, ids, item_ids):
@@ -454,7 +473,8 @@ class Hpmn_Basic(object):
         # The deterministic scatter's row order (ops.ScatterPlan: a stable sort of the batch's ids) depends on the ids alone:
         # built on the auxiliary stream underneath the forward, consumed behind BPTT.
         plan, plan_ready = None, None
-        if self.det_scatter and not self.lazy_table_adam and self.embedding_size % 4 == 0 and 256 % (self.embedding_size // 4) == 0:
+        det = self.det_scatter or (self._det_env == "auto" and (aux is not main or self._plan_wants_rows))
+        if det and not self.lazy_table_adam and self.embedding_size % 4 == 0 and 256 % (self.embedding_size // 4) == 0:
             pst = self._aux_stream
             if aux is main:
                 pst.wait_stream(main)                        # (the ids may have been produced on the caller's stream just now)
@@ -798,7 +818,8 @@ class Hpmn_Basic(object):
             raise ValueError("this rank's shard (%d rows) is larger than the largest shard of global_batch=%d over %d ranks"
                              % (B, gb, self.world))
         want_counts = self.table_exchange in ("auto", "rows")
-        use_plan = bool(want_counts and self.det_scatter)
+        use_plan = bool(want_counts and self._det_env != "0" and self.embedding_size % 4 == 0
+                        and 256 % (self.embedding_size // 4) == 0)
         self._plan_wants_rows = use_plan
         self.last_scatter_plan = None
         box = {}
@@ -942,7 +963,24 @@ class Hpmn_Basic(object):
         parallel every rank scores a slice of each batch and predictions are all-gathered."""
         ds = self._dev(dataset)
         preds, mem_losses = [], []
-        for lo, hi in ds.batches(batchsize):
+        if (not self._dp and ds.item_ids is None and getattr(self, "_hip_read", False) and ds.n > batchsize
+                and self._tiled_inference(self.TILED_EVAL_ROWS)):
+            # Single process, user-only graph: SEVERAL reference batches per pass (the tile kernel wants ~4096 rows in
+            # flight; the harness's 4 x 500 = 2000 half-fill the chip).  The reference's third return value is the mean over
+            # batches of the per-batch memory_loss SUMS (code/hpmn.py:360-369, :512-519) = the sum over all rows divided by the
+            # number of reference batches, whatever the grouping -- so only the float32 summation order differs.
+            n_ref = -(-ds.n // batchsize)
+            per_pass = batchsize * max(1, -(-self.TILED_EVAL_ROWS // batchsize))
+            total = torch.zeros(1, device=self.device)
+            for lo in range(0, ds.n, per_pass):
+                out = self.forward_inference(ds.ids[lo:lo + per_pass], want_logit=False, want_att=False)
+                preds.append(out["prediction"])
+                total += out["memory_loss"].reshape(1)
+            mem_losses = [total / float(n_ref)]
+            batches = ()
+        else:
+            batches = ds.batches(batchsize)
+        for lo, hi in batches:
             a, b = dist.shard_bounds(lo, hi, self.rank, self.world)
             out = self.forward_inference(ds.ids[a:b], item_ids=None if ds.item_ids is None else ds.item_ids[a:b])
             pred, ml = out["prediction"], out["memory_loss"].reshape(1)

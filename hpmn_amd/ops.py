@@ -512,6 +512,13 @@ def pipe_supported(spec: ScanSpec) -> bool:
     return pipe_mode(spec) == "all"
 
 
+def tile_kernel_supported(H: int, D0: int) -> bool:
+    """hpmn_pipe_supported: the 16-sequence-tile MFMA scan has instantiations for (H, D0) -- whatever the HPMN_PIPE switch says
+    about using it for TRAINING (ops.tiled_forward_inference is the forward-only use)."""
+    lib = _lib.load()
+    return bool(lib.hpmn_pipe_supported(H, D0) and lib.hpmn_pipe_supported(H, H))
+
+
 def _pipe_sync_buffer(K: int, B: int, device) -> torch.Tensor:
     """Progress words of the in-launch hand-offs, private to the current stream (re-zeroed by every call)."""
     need = _lib.load().hpmn_pipe_sync_bytes(K, B)

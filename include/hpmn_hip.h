@@ -434,7 +434,8 @@ int hpmn_train_set_scatter_plan(HpmnTrainCtx *ctx, const HpmnScatterPlan *plan);
  *
  *   x0      [B, T[0], D[0]]   layer-0 input rows (hpmn_embed_gather_seq: gather + zero prefix)
  *   y[i]    [B, T[i]/period[i], H]  every period-th output of layer i, i < K-1 (= the input rows of layer
- *                             i+1: T[i+1] == T[i]/period[i], D[i+1] == H)
+ *                             i+1: T[i+1] == T[i]/period[i], D[i+1] == H); hpmn_pipe_fwd also accepts y[K-1] (ABI v10):
+ *                             the call is then a GROUP of layers of a taller stack and y[K-1] the next group's x0
  *   hs[i]   [B, T[i]+1, H], gates[i] [B, T[i], 3H]   saved states as in hpmn_gru_scan_fwd (train != 0, and bwd)
  *   memory  [B, K, H] out (fwd);  d_memory [B, K, H] in (bwd): gradient wrt memory (row stride mem_stride)
  *   d_act[i] [B, T[i], 3H] out (bwd);  d_x[i] [B, T[i], H] out for i >= 1 (the gradient wrt y[i-1]; layer 0's

@@ -204,7 +204,8 @@ GRAD_CASES = [
     ("amazon_h64", cfg_amazon(H=64, K=2, T=20, V=120), 3),
     ("industry", cfg_industry(H=64, K=4, T=41, V=150), 4),
     ("industry_h32", cfg_industry(H=32, K=3, T=41, V=150), 3),
-    ("industry_h128", cfg_industry(H=128, K=3, T=41, V=150), 3),
+    ("industry_h128", cfg_industry(H=128, K=3, T=41, V=150), 3),            # (B <= CUs: eight waves per sequence, r4)
+    ("industry_h128_b300", cfg_industry(H=128, K=2, T=41, V=150), 300),     # (B > CUs: the four-wave form)
     # the shapes the throughput numbers are quoted on (BASELINE configs[1..4]), not miniatures of them:
     # C3 -- 1024-step fp32 reverse scan, 7 layers, T=1001 scatter; C4's hidden size at the same length;
     # C2 -- four id columns (F=4, D0=64: gather + x_out split, 4-column scatter) with periods 2,2,3,5,5;
@@ -618,6 +619,51 @@ def test_scatter_matches_dense_index_add(dev):
         np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-5, atol=1e-4)
 
 
+@pytest.mark.parametrize("group", [1, 2, 3])
+def test_tiled_inference_by_layer_groups_matches_the_oracle(dev, tmp_path, group):
+    """ops.tiled_forward_inference: the 16-sequence-tile MFMA scan (split-f16 operands, three products, fp32 accumulate) run
+    layer group by layer group, the next group reading the y rows the group before left in memory (hpmn_pipe_fwd with a y
+    buffer on its top layer, ABI v10).  Against the float64 oracle at the usual 1e-4, incl. a partial last tile and the
+    Industry zero prefix; and against the per-sequence inference chain."""
+    from hpmn_amd import ops
+    cfg = cfg_industry(H=64, K=5, T=105, V=700)            # 128 steps: 128, 64, 32, 16, 8
+    p = f32_params(cfg, 201)
+    B = 37                                                  # two full tiles + a partial one
+    ids, label = rand_ids(cfg, B, 202)
+    want = O.forward(cfg, p, ids, label)
+    m = make_model(cfg, tmp_path, p)
+    t = torch.as_tensor(ids).to(dev)
+    mem, last = ops.tiled_forward_inference(m.spec, t, m.params["Embedding/emb_mtx"], m._gru_weights(), group=group)
+    np.testing.assert_allclose(mem.cpu().numpy(), want["memory"], rtol=0, atol=TOL)
+    ref_mem, ref_last = ops.scan_forward_inference(m.spec, t, m.params["Embedding/emb_mtx"], m._gru_weights())
+    assert torch.equal(last, ref_last)
+    np.testing.assert_allclose(mem.cpu().numpy(), ref_mem.cpu().numpy(), rtol=0, atol=2e-5)
+
+
+def test_eval_on_the_tiled_path_equals_eval_batch_by_batch(dev, tmp_path, monkeypatch):
+    """Hpmn.eval with several reference batches per pass on the tile kernels (single process, evaluation-sized passes) returns
+    what the batch-by-batch evaluation on the per-sequence kernels returns: AUC, log-loss and the mean over REFERENCE batches
+    of the per-batch memory_loss sums (code/hpmn.py:512-519) -- incl. a short last batch."""
+    from hpmn_amd.hpmn import Hpmn_Industry
+    rng = np.random.default_rng(203)
+    n, T = 2300, 41
+    ids = rng.integers(0, 900, size=(n, T, 2)).astype(np.int32)
+    label = rng.integers(0, 2, size=n).astype(np.int32)
+    ds = dict(ids=ids, label=label)
+
+    def build(tag):
+        return Hpmn_Industry(str(tmp_path / tag), ds, ds, 900, 2, 1, T, 1, 0.003, 64, 16, 3, [2] * 10 + [1], [1], 4, 1,
+                             True, False, memory_reg=5e-5, verbose=False, seed=7)
+    a = build("tiled")
+    a.TILED_EVAL_MIN_ROWS, a.TILED_EVAL_ROWS = 600, 1024      # 3 reference batches of 400 per pass; last pass: 300 rows... 
+    got = a.eval(ds, 400)
+    b = build("plain")
+    b.TILED_EVAL_MIN_ROWS = 0
+    want = b.eval(ds, 400)
+    assert abs(got[0] - want[0]) < 1e-6 and abs(got[1] - want[1]) < 1e-6
+    assert abs(got[2] - want[2]) <= 1e-5 * abs(want[2])
+
+
 @pytest.mark.parametrize("wide", [False, True])
 @pytest.mark.parametrize("E", [16, 4])
 def test_deterministic_scatter_is_exact_ordered_and_reproducible(dev, wide, E):
@@ -625,7 +671,7 @@ def test_deterministic_scatter_is_exact_ordered_and_reproducible(dev, wide, E):
     in ascending lookup order, added by ONE lane group and stored plainly.  Against (a) float64 np.add.at, (b) a float32
     emulation of exactly that order (per-chunk sums, chunks in order) -- BIT-identical, which is what "fixed order" means --,
     and twice in a row
-    (torch.equal).  The id pattern covers every path of the two passes: rows inside one 32-entry chunk, the constant uid
+    (torch.equal).  The id pattern covers every path of the two passes: rows inside one 16-entry chunk, the constant uid
     column (1000-entry rows: dozens of chunks, the partial chain of pass 2), a hot id crossing exactly one chunk border,
     the masked padding id 0 (thousands of entries, skipped), the read path's d_last row, int32 and int64 ids."""
     from hpmn_amd import ops
@@ -646,15 +692,15 @@ def test_deterministic_scatter_is_exact_ordered_and_reproducible(dev, wide, E):
     for mask in (True, False):
         want64 = np.zeros((V, E), dtype=np.float64)
         np.add.at(want64, ids.reshape(-1), term.reshape(-1, E).astype(np.float64))
-        # the kernel's order in float32: entries in stable row order, cut into 32-entry chunks; a row's entries inside one
+        # the kernel's order in float32: entries in stable row order, cut into 16-entry chunks; a row's entries inside one
         # chunk are added left to right, a row that spans chunks is the sum of its per-chunk sums in chunk order
         flat_ids, flat_t = ids.reshape(-1), term.reshape(-1, E)
         order = np.argsort(flat_ids, kind="stable")
         want32 = np.zeros((V, E), dtype=np.float32)
         started = np.zeros(V, bool)
-        for j0 in range(0, len(order), 32):
+        for j0 in range(0, len(order), 16):                      # (SCH of csrc/scatter_sorted.hip)
             part = {}
-            for j in order[j0:j0 + 32]:
+            for j in order[j0:j0 + 16]:
                 r = flat_ids[j]
                 part[r] = flat_t[j].copy() if r not in part else part[r] + flat_t[j]
             for r, v in part.items():
@@ -707,6 +753,7 @@ def test_training_steps_are_bit_reproducible(dev, tmp_path, monkeypatch, name, c
     t_ids, t_lab = torch.as_tensor(ids).to(dev), torch.as_tensor(label).to(dev)
     runs = []
     for r in range(2):
+        monkeypatch.setenv("HPMN_DET_SCATTER", "1")
         m = make_model(cfg, tmp_path / ("r%d" % r), p)
         assert m.det_scatter
         m.compute_gradients(t_ids, t_lab, keep_prob=1.0)
@@ -1051,7 +1098,7 @@ def test_int64_ids_give_the_results_of_int32_ids(dev, tmp_path, name, cfg, B):
         assert torch.equal(a[k], b[k]), k
     oa, ca = m32.compute_gradients(t32, tl, keep_prob=1.0)
     ob, cb = m64.compute_gradients(t64, tl, keep_prob=1.0)
-    assert torch.equal(oa["memory"], ob["memory"]) and float(ca) == float(cb)
+    assert torch.equal(oa["memory"], ob["memory"]) and abs(float(ca) - float(cb)) <= 1e-6 * abs(float(ca))   # (loss sums: atomics)
     for k in p:
         ga, gb = m32.grads[k], m64.grads[k]
         if k == "Embedding/emb_mtx":
@@ -1064,7 +1111,9 @@ def test_int64_ids_give_the_results_of_int32_ids(dev, tmp_path, name, cfg, B):
     emb = m32.params["Embedding/emb_mtx"]
     if cfg.embedding_size == 16:
         assert torch.equal(ops.embed_gather_seq(t32, emb, 3, not cfg.industry), ops.embed_gather_seq(t64, emb, 3, not cfg.industry))
-        assert torch.equal(ops.embed_gather_sum(t32, emb, not cfg.industry), ops.embed_gather_sum(t64, emb, not cfg.industry))
+        # (the in-place probe combines its time slices with atomics: equal to rounding, not to the bit)
+        np.testing.assert_allclose(ops.embed_gather_sum(t64, emb, not cfg.industry).cpu().numpy(),
+                                   ops.embed_gather_sum(t32, emb, not cfg.industry).cpu().numpy(), rtol=1e-5, atol=1e-5)
     assert torch.equal(ops.embed_gather(t32, emb, not cfg.industry), ops.embed_gather(t64, emb, not cfg.industry))
 
 
