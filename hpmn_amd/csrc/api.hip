@@ -61,6 +61,7 @@ int table_mark_launch(const void *ids, int64_t n, uint8_t *flags, int64_t V, int
 int scatter_plan_launch(const void *sorted_ids, int32_t id_flags, int64_t n, const int32_t *seg, int32_t *start, void *rows,
                         int32_t *count, hipStream_t st);
 size_t segsum_partials_floats(int64_t n, int32_t E);
+int segsum_chunk_entries();
 int embed_grad_segsum_launch(const HpmnScatterPlan &p, const float *d_x, float *d_emb, int32_t B, int32_t T, int32_t F,
                              int32_t E, int32_t front_zero, int32_t id_flags, const float *d_last, int32_t t_last,
                              hipStream_t st);
@@ -491,6 +492,7 @@ int hpmn_scatter_plan(const void *sorted_ids, int32_t id_flags, int64_t n, const
 }
 
 size_t hpmn_embed_grad_segsum_partials_floats(int64_t n, int32_t E) { return n > 0 && E > 0 ? segsum_partials_floats(n, E) : 0; }
+int hpmn_embed_grad_segsum_chunk(void) { return segsum_chunk_entries(); }
 
 int hpmn_embed_grad_segsum(const HpmnScatterPlan *plan, const float *d_x, float *d_emb, int32_t B, int32_t T, int32_t F,
                            int32_t E, int32_t front_zero, int32_t id_flags, const float *d_last, int32_t t_last,

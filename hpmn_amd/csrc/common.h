@@ -53,8 +53,15 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 // HPMN_ID_I64 of the id-flags word every entry point with ids carries (bit HPMN_ID_MASK0 is the id-0 mask of
 // code/hpmn.py:417-422).  The flag is a kernel argument, so the branch is wave-uniform (s_cbranch around two loads); row
 // arithmetic is 64-bit everywhere.
+// BRANCH-FREE on purpose: a load inside a (wave-uniform) branch is waited for at the join, s_waitcnt vmcnt(0) -- seen in the
+// ISA of the sorted scatter, where sixteen row loads meant to be in flight together were serialised by the id load between
+// them.  Two 4-byte loads that are valid for either width (int32: element i twice; int64: its low and high word) and a select.
 __device__ __forceinline__ long load_id(const void *__restrict__ ids, long i, int id_flags) {
-    return (id_flags & HPMN_ID_I64) ? reinterpret_cast<const long *>(ids)[i] : (long)reinterpret_cast<const int *>(ids)[i];
+    const int w = (id_flags & HPMN_ID_I64) ? 1 : 0;
+    const int *p = reinterpret_cast<const int *>(ids) + (i << w);
+    const int lo = p[0], hi = p[w];
+    const long wide = (long)(((unsigned long)(unsigned)hi << 32) | (unsigned long)(unsigned)lo);
+    return w ? wide : (long)lo;
 }
 __device__ __forceinline__ bool id_masked(long id, int id_flags) { return (id_flags & HPMN_ID_MASK0) && id == 0; }
 

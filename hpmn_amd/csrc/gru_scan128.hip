@@ -50,17 +50,16 @@ template <int KQ> __device__ __forceinline__ float join_parts(float x) {
     else return join_quarters(x);
 }
 
-// r4: the same design with EIGHT waves per sequence (NW = 8).  unit u = 16 w + (lane & 15), k-quarter
-// p = lane >> 4: 3 * 32 = 96 stationary weights per lane instead of 192 -- half the packed FMAs and half the LDS reads on
-// every wave's step, under 128 registers, so two eight-wave workgroups share a CU (four waves per SIMD where the four-wave
-// form has two): the step is latency (two barriers, two LDS round trips, the activations), and twice the waves in flight
-// is what hides it.  The four partial dot products are joined with v_permlane16_swap + v_permlane32_swap.
-// Registers decide who gets it: 96 weights + the prefetch slots + two LDS read groups come to ~150 (forcing 128 spills
-// 46-117 of them into the time loop), so ONE eight-wave workgroup fits a CU, not two -- the eight-wave form is for batches
-// of at most one sequence per CU (B <= CUs: the per-GPU shard of configs[4] under data parallel, B = 63..250), where every
-// sequence is resident at once and each step has twice the lanes; beyond that the four-wave form (two workgroups of 260
-// registers per CU) keeps 2 x CUs sequences in flight.  HPMN_SCAN128_WAVES=4 / 8 forces either (measurement switch).
-
+// r4: the same design with EIGHT waves per sequence (NW = 8) -- built, parity-green, MEASURED SLOWER, kept
+// behind HPMN_SCAN128_WAVES=8.  unit u = 16 w + (lane & 15), k-quarter p = lane >> 4: 3 * 32 = 96 stationary weights per lane
+// instead of 192, half the packed FMAs and half the LDS reads on every wave's step; the four partial dot products are joined
+// with v_permlane16_swap + v_permlane32_swap.  Two things decide against it:
+//  * registers: 96 weights + prefetch slots + two LDS read groups come to 146-160 (forcing 128 spills 46-117 of them into the
+//    time loop), so ONE eight-wave workgroup fits a CU, not two: it can only serve batches of at most one sequence per CU;
+//  * and there -- C4 training steps at the data-parallel shard sizes, 1x MI355X -- it loses to the four-wave form all the same:
+//    B = 250: 5.85 vs 5.48 ms/step, B = 63: 4.16 vs 3.85 (profiles/r04_experiments.txt).  The step is two barriers, two LDS
+//    round trips and the activations; twice the waves make each barrier and each join longer (eight waves to collect, two
+//    swaps instead of one) by more than the halved FMA/LDS issue saves.
 template <bool TRAIN, int NW>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void gru_scan_fwd128_kernel(const HpmnGruFwd a) {
     constexpr int H = H128;
@@ -294,17 +293,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void gru_scan_bwd128_kern
     if (t_lo0 > 0 && p == 0) a.dh_carry[b * H + j] = dh;
 }
 
-// eight waves per sequence while one such workgroup per CU holds the whole batch; beyond that (or HPMN_SCAN128_WAVES=4) four
-static int scan128_waves(int B) {
+// four waves per sequence; HPMN_SCAN128_WAVES=8: the eight-wave form (measured slower, see the top of the file)
+static int scan128_waves(int) {
     static const int env = [] { const char *e = getenv("HPMN_SCAN128_WAVES"); return e ? atoi(e) : 0; }();
-    if (env == 4 || env == 8) return env;
-    static const int cus = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess) return 256;
-        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return 256;
-        return n;
-    }();
-    return B <= cus ? 8 : 4;
+    return env == 8 ? 8 : 4;
 }
 
 int gru_scan_fwd128_dispatch(const HpmnGruFwd &a, hipStream_t st) {

@@ -195,9 +195,11 @@ class Hpmn_Basic(object):
         self.table_exchange = os.environ.get("HPMN_TABLE_EXCHANGE", "auto")
         # Deterministic table gradients (r4): the scatter as a segmented reduction in row order, no atomics (ops.ScatterPlan,
         # csrc/scatter_sorted.hip).  HPMN_DET_SCATTER=0: the atomic kernel (run-length pre-reduced fp32 atomics).
-        # "auto" (default): on where the plan's sort hides underneath the forward on the auxiliary stream (tables big enough for
-        # the step to use that stream: XLong) and under the data-parallel rows exchange (which needs the distinct rows anyway);
-        # the 0.3 ms steps of the small-table configurations would pay ~20 extra launches of host time for it (C1: +17 %).
+        # "auto" (default): on under the data-parallel rows exchange, which needs the batch's distinct rows and their compact
+        # gradient rows anyway (the plan replaces torch.unique + index_select there); off in a single process, where it costs
+        # 3 % of the C3 step (2.81 -> 2.90 ms: the 240 us sort shares HBM with the forward, the two passes are 160 us beside
+        # the weight gradient where the atomic kernel is 136) and 17 % of the 0.33 ms C1 step (~20 launches of host time).
+        # "1": always (bit-reproducible training, tests/test_gpu_parity.py::test_training_steps_are_bit_reproducible).
         self._det_env = os.environ.get("HPMN_DET_SCATTER", "auto")
         self.det_scatter = self._det_env == "1"
         self._plan_wants_rows = False     # (the data-parallel rows exchange sends the plan's compact rows)
@@ -471,21 +473,27 @@ class Hpmn_Basic(object):
         cleared = None
         rest2 = None
         # The deterministic scatter's row order (ops.ScatterPlan: a stable sort of the batch's ids) depends on the ids alone:
-        # built on the auxiliary stream underneath the forward, consumed behind BPTT.
+        # built on the auxiliary stream, consumed behind BPTT.  WHERE on that stream matters (r4: in front of the early
+        # table-Adam pass its 240 us delayed that pass past the forward and cost the C3 step 0.26 ms): behind the pass, unless
+        # the data-parallel rows exchange wants the distinct-row count at the start of the step.
         plan, plan_ready = None, None
-        det = self.det_scatter or (self._det_env == "auto" and (aux is not main or self._plan_wants_rows))
-        if det and not self.lazy_table_adam and self.embedding_size % 4 == 0 and 256 % (self.embedding_size // 4) == 0:
+        det = self.det_scatter or (self._det_env == "auto" and self._plan_wants_rows)
+        det = bool(det and not self.lazy_table_adam and self.embedding_size % 4 == 0 and 256 % (self.embedding_size // 4) == 0)
+
+        def make_plan():
             pst = self._aux_stream
-            if aux is main:
+            if pst != torch.cuda.current_stream():
                 pst.wait_stream(main)                        # (the ids may have been produced on the caller's stream just now)
             with torch.cuda.stream(pst):
-                plan = ops.ScatterPlan(ids, self.embedding_size, want_rows=self._plan_wants_rows,
-                                       host_count=self._plan_wants_rows)
-                plan_ready = torch.cuda.Event()
-                plan_ready.record(pst)
-            plan.ready = plan_ready
-            plan.record_stream(main)
-            self.last_scatter_plan = plan
+                pl = ops.ScatterPlan(ids, self.embedding_size, want_rows=self._plan_wants_rows,
+                                     host_count=self._plan_wants_rows)
+                pl.ready = torch.cuda.Event()
+                pl.ready.record(pst)
+            pl.record_stream(main)
+            self.last_scatter_plan = pl
+            return pl
+        if det and self._plan_wants_rows:
+            plan = make_plan()
         with torch.cuda.stream(aux):
             rest = None
             if _clear_grads is not None:
@@ -503,6 +511,10 @@ class Hpmn_Basic(object):
                 if not (self.EARLY_PASS_BESIDE_L0_REVERSE and aux is not main):
                     rest2 = rest()
                     rest = None
+            if det and plan is None:
+                plan = make_plan()
+        if plan is not None:
+            plan_ready = plan.ready
         self._table_grad_clean = False                       # (until something consumes or clears the table gradient)
         emb = self.params["Embedding/emb_mtx"]
         weights = self._gru_weights()
@@ -970,7 +982,7 @@ class Hpmn_Basic(object):
             # batches of the per-batch memory_loss SUMS (code/hpmn.py:360-369, :512-519) = the sum over all rows divided by the
             # number of reference batches, whatever the grouping -- so only the float32 summation order differs.
             n_ref = -(-ds.n // batchsize)
-            per_pass = batchsize * max(1, -(-self.TILED_EVAL_ROWS // batchsize))
+            per_pass = batchsize * max(1, self.TILED_EVAL_ROWS // batchsize)   # (<= 4096 rows = 256 tiles: one round of CUs)
             total = torch.zeros(1, device=self.device)
             for lo in range(0, ds.n, per_pass):
                 out = self.forward_inference(ds.ids[lo:lo + per_pass], want_logit=False, want_att=False)

@@ -418,6 +418,9 @@ typedef struct HpmnScatterPlan {
 int hpmn_scatter_plan(const void *sorted_ids, int32_t id_flags, int64_t n, const int32_t *seg, int32_t *start, void *rows,
                       int32_t *count, void *stream);
 size_t hpmn_embed_grad_segsum_partials_floats(int64_t n, int32_t E);
+/* entries per chunk of the reduction (its summation order: a row's entries inside one chunk left to right; a row that spans
+ * chunks = its per-chunk sums cut into min(16, 256/E) consecutive blocks, each block left to right, blocks in order) */
+int hpmn_embed_grad_segsum_chunk(void);
 int hpmn_embed_grad_segsum(const HpmnScatterPlan *plan, const float *d_x, float *d_emb, int32_t B, int32_t T, int32_t F,
                            int32_t E, int32_t front_zero, int32_t id_flags, const float *d_last, int32_t t_last,
                            void *stream);

@@ -204,8 +204,8 @@ GRAD_CASES = [
     ("amazon_h64", cfg_amazon(H=64, K=2, T=20, V=120), 3),
     ("industry", cfg_industry(H=64, K=4, T=41, V=150), 4),
     ("industry_h32", cfg_industry(H=32, K=3, T=41, V=150), 3),
-    ("industry_h128", cfg_industry(H=128, K=3, T=41, V=150), 3),            # (B <= CUs: eight waves per sequence, r4)
-    ("industry_h128_b300", cfg_industry(H=128, K=2, T=41, V=150), 300),     # (B > CUs: the four-wave form)
+    ("industry_h128", cfg_industry(H=128, K=3, T=41, V=150), 3),
+    ("industry_h128_b300", cfg_industry(H=128, K=2, T=41, V=150), 300),     # (more sequences than CUs)
     # the shapes the throughput numbers are quoted on (BASELINE configs[1..4]), not miniatures of them:
     # C3 -- 1024-step fp32 reverse scan, 7 layers, T=1001 scatter; C4's hidden size at the same length;
     # C2 -- four id columns (F=4, D0=64: gather + x_out split, 4-column scatter) with periods 2,2,3,5,5;
@@ -229,7 +229,7 @@ def test_gradients_match_float64_autograd(dev, tmp_path, name, cfg, B):
     p = f32_params(cfg, 41)
     ids, label = rand_ids(cfg, B, 42)
     ids[:, :, 0] = ids[:, -1:, 0]                  # constant uid column -> run-length pre-reduction path
-    if B > 32 and cfg.user_maxlen > 500:
+    if B > 32 and (cfg.user_maxlen > 500 or cfg.hidden_size >= 128):
         # With random weights a wide batch holds samples whose logit is beyond +-16.6: in float32 -- TF's arithmetic as
         # much as ours -- sigmoid() is then exactly 0 or 1 and a confidently WRONG label's loss term and gradient saturate
         # (log(0 + 1e-7), p (1 - p) = 0), which the float64 oracle does not reproduce.  Labels that agree with the
@@ -671,7 +671,7 @@ def test_deterministic_scatter_is_exact_ordered_and_reproducible(dev, wide, E):
     in ascending lookup order, added by ONE lane group and stored plainly.  Against (a) float64 np.add.at, (b) a float32
     emulation of exactly that order (per-chunk sums, chunks in order) -- BIT-identical, which is what "fixed order" means --,
     and twice in a row
-    (torch.equal).  The id pattern covers every path of the two passes: rows inside one 16-entry chunk, the constant uid
+    (torch.equal).  The id pattern covers every path of the two passes: rows inside one chunk, the constant uid
     column (1000-entry rows: dozens of chunks, the partial chain of pass 2), a hot id crossing exactly one chunk border,
     the masked padding id 0 (thousands of entries, skipped), the read path's d_last row, int32 and int64 ids."""
     from hpmn_amd import ops
@@ -692,20 +692,35 @@ def test_deterministic_scatter_is_exact_ordered_and_reproducible(dev, wide, E):
     for mask in (True, False):
         want64 = np.zeros((V, E), dtype=np.float64)
         np.add.at(want64, ids.reshape(-1), term.reshape(-1, E).astype(np.float64))
-        # the kernel's order in float32: entries in stable row order, cut into 16-entry chunks; a row's entries inside one
-        # chunk are added left to right, a row that spans chunks is the sum of its per-chunk sums in chunk order
+        # the kernel's order in float32 (include/hpmn_hip.h, hpmn_embed_grad_segsum_chunk): entries in stable row order, cut
+        # into SCH-entry chunks; a row's entries inside one chunk are added left to right; a row that spans chunks is its
+        # per-chunk sums cut into min(16, 256/E) consecutive blocks, each block added left to right, the blocks in order
+        from hpmn_amd import _lib
+        sch = int(_lib.load().hpmn_embed_grad_segsum_chunk())
+        nb = min(16, 256 // E)
         flat_ids, flat_t = ids.reshape(-1), term.reshape(-1, E)
         order = np.argsort(flat_ids, kind="stable")
-        want32 = np.zeros((V, E), dtype=np.float32)
-        started = np.zeros(V, bool)
-        for j0 in range(0, len(order), 16):                      # (SCH of csrc/scatter_sorted.hip)
+        parts = {}                                               # row -> its per-chunk sums, in chunk order
+        for j0 in range(0, len(order), sch):
             part = {}
-            for j in order[j0:j0 + 16]:
+            for j in order[j0:j0 + sch]:
                 r = flat_ids[j]
                 part[r] = flat_t[j].copy() if r not in part else part[r] + flat_t[j]
             for r, v in part.items():
-                want32[r] = v if not started[r] else want32[r] + v
-                started[r] = True
+                parts.setdefault(r, []).append(v)
+        want32 = np.zeros((V, E), dtype=np.float32)
+        for r, ps in parts.items():
+            if len(ps) == 1:
+                want32[r] = ps[0]
+                continue
+            per = -(-len(ps) // nb)
+            tot = None
+            for b0 in range(0, len(ps), per):
+                blk = ps[b0].copy()
+                for v in ps[b0 + 1:b0 + per]:
+                    blk = blk + v
+                tot = blk if tot is None else tot + blk
+            want32[r] = tot
         if mask:
             want64[0] = 0
             want32[0] = 0
@@ -1258,6 +1273,19 @@ def test_fallback_kernel_paths_still_match_the_oracle(env):
     r = subprocess.run([sys.executable, "-m", "pytest", here, "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider",
                         "-k", "(tiny_and_odd and 64) or xlong_c3_shape or c_abi_alone or (beside_an_unrelated and 6-3-41)"
                               " or (beside_an_unrelated and 3-5-297)"],
+                       env=e, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_eight_wave_h128_scans_match_the_oracle():
+    """HPMN_SCAN128_WAVES=8 (gru_scan128.hip: eight waves per sequence, measured slower and therefore off by default): H = 128
+    forward / gradient parity at the tiny and odd lengths, the K = 3 case and the wide batch, in a process of its own."""
+    import subprocess
+    e = dict(os.environ, HPMN_SCAN128_WAVES="8")
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", here, "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider",
+                        "-k", "(tiny_and_odd and 128) or industry_h128"],
                        env=e, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
