@@ -698,8 +698,10 @@ def main():
         out = model.forward_inference(batches[0][0])
         finite = bool(torch.isfinite(out["prediction"]).all())
 
-    # forward-only (eval) throughput at the harness's eval batch = 4x the train batch (code/hpmn.py:485-486)
+    # forward-only (eval) throughput at the harness's eval batch = 4x the train batch (code/hpmn.py:485-486): one
+    # forward_inference call per reference batch ...
     eval_seq_per_s = None
+    eval_pass = None
     if not args.no_eval:
         ev_ids = torch.cat([b[0] for b in batches[:4]], 0)[:4 * c["batch"]]
         model.forward_inference(ev_ids)
@@ -709,6 +711,27 @@ def main():
             model.forward_inference(ev_ids)
         torch.cuda.synchronize()
         eval_seq_per_s = 5 * ev_ids.shape[0] * world / (time.perf_counter() - te0)
+        # ... and what model.eval() does with a whole set (r4): 8 reference batches of rows through Hpmn.eval -- several
+        # reference batches per pass on the tile kernels where the graph has them (single process, H = 64), AUC / log-loss /
+        # memory-loss on the device, ONE host synchronisation at the end
+        if world == 1:
+            ev_all = torch.cat([ev_ids] * 8, 0).cpu().numpy()
+            rng_l = np.random.default_rng(5)
+            ev_ds = dict(ids=ev_all, label=rng_l.integers(0, 2, size=ev_all.shape[0]).astype(np.int32))
+            model.eval(ev_ds, 4 * c["batch"])
+            torch.cuda.synchronize()
+            te1 = time.perf_counter()
+            model.eval(ev_ds, 4 * c["batch"])
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - te1
+            eval_pass = {"rows": int(ev_all.shape[0]), "reference_batch": 4 * c["batch"], "seconds": dt,
+                         "sequences_per_s": ev_all.shape[0] / dt,
+                         "rows_per_pass": (int(model.TILED_EVAL_ROWS // (4 * c["batch"]) * 4 * c["batch"])
+                                           if model._tiled_inference(model.TILED_EVAL_ROWS) and 4 * c["batch"] <= model.TILED_EVAL_ROWS
+                                           else 4 * c["batch"]),
+                         "what": "Hpmn.eval(dataset, 4 x batch) incl. the device-side AUC / log-loss / memory-loss and its one sync"}
+            model.invalidate_dataset(ev_ds)
+            del ev_ds, ev_all
         del ev_ids
 
     # what a user of code/hpmn.py:336-349 feels: 10 training steps, then a full evaluation pass (train + test rows) at the
@@ -725,14 +748,23 @@ def main():
             step(args.warmup + args.steps + i)
         torch.cuda.synchronize()
         tc1 = time.perf_counter()
-        for _ in range(n_eval_batches):
-            model.forward_inference(ev_ids)
+        # (as Hpmn.eval does it: several reference batches per pass where the tile kernels serve the graph)
+        per = 1
+        if model._tiled_inference(model.TILED_EVAL_ROWS) and ev_ids.shape[0] <= model.TILED_EVAL_ROWS:
+            per = max(1, model.TILED_EVAL_ROWS // int(ev_ids.shape[0]))
+        ev_pass = torch.cat([ev_ids] * per, 0) if per > 1 else ev_ids
+        for _ in range(n_eval_batches // per):
+            model.forward_inference(ev_pass, want_logit=False, want_att=False)
         torch.cuda.synchronize()
         tc2 = time.perf_counter()
-        cadence = {"train_10_steps_ms": (tc1 - tc0) * 1e3, "eval_rows": n_eval_batches * int(ev_ids.shape[0]),
+        n_rows = (n_eval_batches // per) * int(ev_pass.shape[0])
+        cadence = {"train_10_steps_ms": (tc1 - tc0) * 1e3, "eval_rows": n_rows,
                    "eval_ms": (tc2 - tc1) * 1e3, "eval_share": (tc2 - tc1) / (tc2 - tc0),
+                   "rows_per_pass": int(ev_pass.shape[0]),
+                   "full_set_ratio": {"eval_rows_per_10_steps_at_reference": "train + test sets, ~100x these rows",
+                                      "eval_share_at_100x": 100.0 * (tc2 - tc1) / (100.0 * (tc2 - tc1) + (tc1 - tc0))},
                    "note": "code/hpmn.py:338 evaluates train AND test every 10 steps on XLong; the full sets are ~100x these rows"}
-        del ev_ids
+        del ev_ids, ev_pass
 
     auc = None
     if args.config == "c3" and not args.no_auc:
@@ -759,6 +791,8 @@ def main():
                             "train_tflops_equiv": 3 * algorithmic_flops_fwd(c) * seqs / elapsed / 1e12},
         }
         result["eval_sequences_per_s"] = eval_seq_per_s        # forward only, rank-0 clock (not barrier-bracketed)
+        if eval_pass is not None:
+            result["eval_pass"] = eval_pass
         if cadence is not None:
             result["xlong_cadence"] = cadence
         if not args.no_eval:                                   # (its torch.unique would show up in the PMC passes)
