@@ -718,13 +718,17 @@ def main():
             ev_all = torch.cat([ev_ids] * 8, 0).cpu().numpy()
             rng_l = np.random.default_rng(5)
             ev_ds = dict(ids=ev_all, label=rng_l.integers(0, 2, size=ev_all.shape[0]).astype(np.int32))
+            model.eval(ev_ds, 4 * c["batch"])                  # (stages the rows on the device, grows the allocator's pools)
             model.eval(ev_ds, 4 * c["batch"])
-            torch.cuda.synchronize()
-            te1 = time.perf_counter()
-            model.eval(ev_ds, 4 * c["batch"])
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - te1
-            eval_pass = {"rows": int(ev_all.shape[0]), "reference_batch": 4 * c["batch"], "seconds": dt,
+            dts = []
+            for _ in range(5):
+                torch.cuda.synchronize()
+                te1 = time.perf_counter()
+                model.eval(ev_ds, 4 * c["batch"])
+                torch.cuda.synchronize()
+                dts.append(time.perf_counter() - te1)
+            dt = sorted(dts)[len(dts) // 2]
+            eval_pass = {"rows": int(ev_all.shape[0]), "reference_batch": 4 * c["batch"], "seconds": dt, "seconds_all": dts,
                          "sequences_per_s": ev_all.shape[0] / dt,
                          "rows_per_pass": (int(model.TILED_EVAL_ROWS // (4 * c["batch"]) * 4 * c["batch"])
                                            if model._tiled_inference(model.TILED_EVAL_ROWS) and 4 * c["batch"] <= model.TILED_EVAL_ROWS
