@@ -255,6 +255,7 @@ SIGNATURES.update({
     "hpmn_scatter_plan": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hpmn_embed_grad_segsum_partials_floats": (C.c_size_t, [C.c_int64, C.c_int32]),
     "hpmn_embed_grad_segsum_chunk": (C.c_int, []),
+    "hpmn_has_legacy_kernels": (C.c_int, []),
     "hpmn_embed_grad_segsum": (C.c_int, [C.POINTER(HpmnScatterPlan), C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                          C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
     "hpmn_train_set_scatter_plan": (C.c_int, [C.c_void_p, C.POINTER(HpmnScatterPlan)]),

@@ -97,6 +97,14 @@ extern "C" {
 
 int hpmn_abi_version(void) { return HPMN_ABI_VERSION; }
 
+int hpmn_has_legacy_kernels(void) {
+#ifdef HPMN_LEGACY_KERNELS
+    return 1;
+#else
+    return 0;
+#endif
+}
+
 const char *hpmn_strerror(int code) {
     switch (code) {
         case HPMN_OK: return "ok";

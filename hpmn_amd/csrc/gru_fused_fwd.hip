@@ -27,6 +27,9 @@
 
 namespace hpmn {
 
+// r4: the first generation below is a measured-slower fallback (0.571 vs 0.508 ms at C3 layer 0); it is compiled only with
+// -DHPMN_LEGACY_KERNELS (HPMN_HIPCC_FLAGS) -- the default library dispatches every call to gru_fused_fwd3.hip.
+#ifdef HPMN_LEGACY_KERNELS
 constexpr int FH = 64;        // hidden size of this kernel
 constexpr int FRING = 8;      // ring slots (steps the producer may run ahead)
 constexpr int FBLK = 8;       // producer prefetch block (steps)
@@ -306,11 +309,6 @@ __global__ __launch_bounds__(HELP ? 192 : 128, 1) void gru_fused_fwd_kernel(cons
     a.h_last[b * a.h_last_stride + l] = h;
 }
 
-bool gru_fused_fwd_supported(int H, int D, int gather) {
-    (void)gather;
-    return H == FH && (D == 32 || D == 64);
-}
-
 template <int D, bool HELP>
 static int launch_fused_h(const HpmnGruFusedFwd &a, hipStream_t st) {
     const bool train = a.hs != nullptr;
@@ -334,11 +332,22 @@ static int launch_fused(const HpmnGruFusedFwd &a, hipStream_t st) {
     else                   return launch_fused_h<D, false>(a, st);
 }
 
+#endif  // HPMN_LEGACY_KERNELS
+
+bool gru_fused_fwd_supported(int H, int D, int gather) {
+    (void)gather;
+    return H == 64 && (D == 32 || D == 64);
+}
+
 int gru_fwd_mfma_dispatch(const HpmnGruFusedFwd &a, hipStream_t st);  // gru_fused_fwd3.hip
 
 static int fused_gen() {
+#ifdef HPMN_LEGACY_KERNELS
     static const int gen = [] { const char *e = getenv("HPMN_FUSED_FWD_GEN"); return e ? atoi(e) : 3; }();
     return gen;
+#else
+    return 3;
+#endif
 }
 // does the launch write HpmnGruFusedFwd.last itself?
 bool gru_fused_fwd_writes_last() { return fused_gen() >= 3; }
@@ -348,11 +357,13 @@ int gru_fused_fwd_dispatch(const HpmnGruFusedFwd &a, hipStream_t st) {
     // first generation below
     const int gen = fused_gen();
     if (gen >= 3) return gru_fwd_mfma_dispatch(a, st);
+#ifdef HPMN_LEGACY_KERNELS
     if (a.last != nullptr) return HPMN_EUNSUPPORTED;
     if (a.B == 0) return HPMN_OK;
     if (a.H != FH) return HPMN_EUNSUPPORTED;
     if (a.D == 32) return launch_fused<32>(a, st);
     if (a.D == 64) return launch_fused<64>(a, st);
+#endif
     return HPMN_EUNSUPPORTED;
 }
 

@@ -16,6 +16,14 @@
 // (double-buffered by step parity: the d_x product still reads step t's images while step t-1 writes).
 #include "pipe_common.h"
 
+// r4: the tile kernel's forward is the EVALUATION kernel now (ops.tiled_forward_inference); its training backward was
+// measured slower than the per-sequence kernels at the reference batch and is compiled only with
+// -DHPMN_LEGACY_KERNELS; the default library answers hpmn_pipe_bwd with HPMN_EUNSUPPORTED.
+#ifndef HPMN_LEGACY_KERNELS
+namespace hpmn {
+int pipe_bwd_launch(const PipeArgs &, int, hipStream_t) { return HPMN_EUNSUPPORTED; }
+}  // namespace hpmn
+#else
 namespace hpmn {
 
 constexpr int BWD_IMGS = 12;                      // (dcp, dau, dar) x (hi, lo) x 2 parities
@@ -298,3 +306,5 @@ int pipe_bwd_launch(const PipeArgs &a, int num_cus, hipStream_t st) {
 }
 
 }  // namespace hpmn
+
+#endif  // HPMN_LEGACY_KERNELS

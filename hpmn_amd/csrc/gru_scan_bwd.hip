@@ -188,6 +188,8 @@ __global__ __launch_bounds__(64, 1) void gru_scan_bwd_kernel(const HpmnGruBwd a)
 // iteration k is in LDS" (data, then a counter: LDS operations of a wave execute in order), the helper publishes
 // "e_u of iteration k is in LDS"; the main wave cannot overwrite da_u before it has consumed e_u, which the helper
 // only produces after reading all of da_u.  Everything else is gru_scan_bwd_kernel<64>.
+// r4: measured slower than the chain + feeder kernel (gru_scan_bwd_feed.hip); compiled only with -DHPMN_LEGACY_KERNELS.
+#ifdef HPMN_LEGACY_KERNELS
 __device__ __forceinline__ int bw_peek(int *p) { return lds_counter_peek(p); }
 
 // DX = true adds a THIRD wave: the gradient wrt the layer's input rows, d_x[t] = [da_r | da_u | dc_pre] [Wg[:D] | Wc[:D]]^T
@@ -411,10 +413,16 @@ __global__ __launch_bounds__(DX ? 192 : 128, DX ? 2 : 1) void gru_scan_bwd_helpe
     if (t_lo0 > 0) a.dh_carry[b * H + l] = dh;
 }
 
+#endif  // HPMN_LEGACY_KERNELS
+
 // HPMN_BWD_HELPER: 2 (default) chain + feeder wave (gru_scan_bwd_feed.hip), 1 the e_u helper wave above, 0 one wave
 static int bwd_helper_enabled() {
     static const int helper = [] { const char *e = getenv("HPMN_BWD_HELPER"); return e ? atoi(e) : 2; }();
+#ifdef HPMN_LEGACY_KERNELS
     return helper;
+#else
+    return helper == 1 ? 2 : helper;         // (the helper-wave kernel is not in this build: 1 means the feeder kernel too)
+#endif
 }
 int gru_scan_bwd_feed_launch(const HpmnGruBwd &a, hipStream_t st);   // gru_scan_bwd_feed.hip
 bool gru_scan_bwd_feed_dx_width(int D);
@@ -457,10 +465,12 @@ int gru_scan_bwd_dispatch(const HpmnGruBwd &a, hipStream_t st) {
         if (bwd_helper_enabled() && a.B <= 640) {
             if (bwd_helper_enabled() >= 2)
                 return gru_scan_bwd_feed_launch(a, st);
+#ifdef HPMN_LEGACY_KERNELS
             else if (a.d_x != nullptr && gru_scan_bwd_fuses_dx(a.H, a.B))
                 hipLaunchKernelGGL(gru_scan_bwd_helper_kernel<true>, dim3(a.B), dim3(192), 0, st, a);
             else
                 hipLaunchKernelGGL(gru_scan_bwd_helper_kernel<false>, dim3(a.B), dim3(128), 0, st, a);
+#endif
         } else {
             hipLaunchKernelGGL((gru_scan_bwd_kernel<64>), dim3(a.B), dim3(64), 0, st, a);
         }

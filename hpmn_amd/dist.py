@@ -135,53 +135,54 @@ def exchange_counts(n: int, device) -> List[int]:
 
 
 class _Counts:
-    """Every rank's count, on its way to pinned host memory: ``result()`` waits for the copy (an event, not a device
-    synchronisation) and returns the list."""
+    """Every rank's count(s), on their way to pinned host memory: ``result()`` waits for the copy (an event, not a device
+    synchronisation) and returns the list -- one int per rank, or one list per rank for a vector of counts."""
 
-    def __init__(self, host, event, fallback=None):
-        self._host, self._event, self._list = host, event, fallback
+    def __init__(self, host, event, fallback=None, width=1):
+        self._host, self._event, self._list, self._width = host, event, fallback, width
 
-    def result(self) -> List[int]:
+    def result(self):
         if self._list is None:
             self._event.synchronize()
-            self._list = [int(x) for x in self._host.tolist()]
+            flat = [int(x) for x in self._host.tolist()]
+            w = self._width
+            self._list = flat if w == 1 else [flat[i:i + w] for i in range(0, len(flat), w)]
         return self._list
 
 
 def exchange_counts_async(n, device) -> "_Counts":
-    """``n``: an int or a one-element device tensor.  exchange_counts whose host read is deferred: the all-gather and a non-blocking copy into pinned memory are
-    enqueued on the CURRENT stream now, the caller asks for ``result()`` when it needs the numbers (data-parallel step:
-    enqueued at the start of the step underneath the forward, read when the row exchange is sized -- long after the
-    copy completed, so the host never waits on the device's critical path)."""
+    """``n``: an int, or a device tensor of one or several counts.  exchange_counts whose host read is deferred: the
+    all-gather and a non-blocking copy into pinned memory are enqueued on the CURRENT stream now, the caller asks for
+    ``result()`` when it needs the numbers (data-parallel step: enqueued at the start of the step underneath the forward, read
+    when the row exchange is sized -- long after the copy completed, so the host never waits on the device's critical
+    path).  A vector of C counts per rank comes back as ``[world][C]``."""
     _, world = rank_world()
     on_device = isinstance(n, torch.Tensor)              # (a device-side count: it is never read on the host here)
     if world == 1 and not forced() and not on_device:
         return _Counts(None, None, [int(n)])
-    mine = n.reshape(1).to(torch.int64) if on_device else torch.tensor([int(n)], device=device, dtype=torch.int64)
+    mine = n.reshape(-1).to(torch.int64) if on_device else torch.tensor([int(n)], device=device, dtype=torch.int64)
+    width = int(mine.numel())
     if world == 1 and not forced():
         out = mine
-        if out.is_cuda:
-            host = torch.empty(1, dtype=torch.int64, pin_memory=True)
-            host.copy_(out, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
-            return _Counts(host, ev)
-        return _Counts(None, None, [int(out.item())])
-    out = torch.empty(world, device=device, dtype=torch.int64)
-    td.all_gather_into_tensor(out, mine)
+    else:
+        out = torch.empty(world * width, device=device, dtype=torch.int64)
+        td.all_gather_into_tensor(out, mine.contiguous())
     if out.is_cuda:
-        host = torch.empty(world, dtype=torch.int64, pin_memory=True)
+        host = torch.empty(out.numel(), dtype=torch.int64, pin_memory=True)
         host.copy_(out, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        return _Counts(host, ev)
-    return _Counts(None, None, [int(x) for x in out.tolist()])
+        return _Counts(host, ev, width=width)
+    flat = [int(x) for x in out.tolist()]
+    return _Counts(None, None, flat if width == 1 else [flat[i:i + width] for i in range(0, len(flat), width)], width)
 
 
-def exchange_rows(rows: torch.Tensor, grads: torch.Tensor, counts: List[int], wide_ids: bool = False):
+def exchange_rows(rows: torch.Tensor, grads: torch.Tensor, counts: List[int], wide_ids: bool = False, async_op: bool = False):
     """All-gather of (row ids [n] -- int32 on the wire, int64 with ``wide_ids`` (tables beyond 2^31 - 1 rows; the same on every
     rank: it follows from the table size) --, gradient rows [n, E]) over the ranks, padded to the largest count.
-    Returns (ids [world, cap] with -1 padding, grads [world, cap, E]); rank r's valid entries are the first counts[r]."""
+    Returns (ids [world, cap] with -1 padding, grads [world, cap, E]); rank r's valid entries are the first counts[r].
+    ``async_op``: the two collectives are only STARTED; a third return value holds their handles (``.wait()`` orders the
+    current stream behind them) -- several exchanges in flight while the caller consumes the first."""
     rank, world = rank_world()
     cap = max(1, max(counts))
     E = grads.shape[1]
@@ -193,9 +194,13 @@ def exchange_rows(rows: torch.Tensor, grads: torch.Tensor, counts: List[int], wi
     g_mine = torch.zeros(cap, E, device=grads.device, dtype=grads.dtype)
     g_mine[:n] = grads
     if world == 1 and not forced():
-        return ids_mine.view(1, cap), g_mine.view(1, cap, E)
+        return (ids_mine.view(1, cap), g_mine.view(1, cap, E)) + (([],) if async_op else ())
     ids_all = torch.empty(world * cap, device=rows.device, dtype=idt)
     g_all = torch.empty(world * cap * E, device=grads.device, dtype=grads.dtype)
+    if async_op:
+        works = [td.all_gather_into_tensor(ids_all, ids_mine, async_op=True),
+                 td.all_gather_into_tensor(g_all, g_mine.view(-1), async_op=True)]
+        return ids_all.view(world, cap), g_all.view(world, cap, E), works
     td.all_gather_into_tensor(ids_all, ids_mine)
     td.all_gather_into_tensor(g_all, g_mine.view(-1))
     return ids_all.view(world, cap), g_all.view(world, cap, E)

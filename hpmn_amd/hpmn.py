@@ -203,6 +203,7 @@ class Hpmn_Basic(object):
         self._det_env = os.environ.get("HPMN_DET_SCATTER", "auto")
         self.det_scatter = self._det_env == "1"
         self._plan_wants_rows = False     # (the data-parallel rows exchange sends the plan's compact rows)
+        self._plan_row_bounds = None
         self.last_scatter_plan = None
         self._sharded_moments = False     # set once the sharded table update has run (save_model gathers the moments then)
         self.TWO_PASS_MIN_NUMEL = int(os.environ.get("HPMN_TWO_PASS_MIN_NUMEL", str(type(self).TWO_PASS_MIN_NUMEL)))
@@ -486,7 +487,7 @@ class Hpmn_Basic(object):
                 pst.wait_stream(main)                        # (the ids may have been produced on the caller's stream just now)
             with torch.cuda.stream(pst):
                 pl = ops.ScatterPlan(ids, self.embedding_size, want_rows=self._plan_wants_rows,
-                                     host_count=self._plan_wants_rows)
+                                     host_count=False, row_bounds=self._plan_row_bounds if self._plan_wants_rows else None)
                 pl.ready = torch.cuda.Event()
                 pl.ready.record(pst)
             pl.record_stream(main)
@@ -834,6 +835,12 @@ class Hpmn_Basic(object):
                         and 256 % (self.embedding_size // 4) == 0)
         self._plan_wants_rows = use_plan
         self.last_scatter_plan = None
+        # The rows travel in C chunks of the table's row range (the plan's distinct rows are ascending: a chunk is a slice), so
+        # that the sum + late table-Adam pass of chunk c run while RCCL is still gathering chunk c+1 -- the collective is
+        # xGMI-bound, the pass HBM-bound.  Same addends in the same order per row: results do not depend on C.
+        C = max(1, int(self.table_exchange_chunks)) if use_plan else 1
+        bounds = [(V * k) // C for k in range(C + 1)]
+        self._plan_row_bounds = bounds if use_plan else None
         box = {}
 
         def early():                                          # runs on the auxiliary stream
@@ -851,7 +858,10 @@ class Hpmn_Basic(object):
                         # torch.unique (whose data-dependent output shape is a host synchronisation), no index_select later
                         box["plan"] = plan
                         torch.cuda.current_stream().wait_event(plan.ready)
-                        box["counts"] = dist.exchange_counts_async(plan.count, self.device)
+                        box["counts"] = dist.exchange_counts_async(plan.chunk_counts, self.device)
+                    elif use_plan:                                # (an empty shard: C zeros, like everybody's C counts)
+                        box["counts"] = dist.exchange_counts_async(torch.zeros(C, device=self.device, dtype=torch.int64),
+                                                                   self.device)
                     else:
                         rows = (torch.unique(ids.reshape(-1)).long() if B > 0
                                 else torch.empty(0, device=self.device, dtype=torch.int64))
@@ -876,26 +886,55 @@ class Hpmn_Basic(object):
         table_grad = views[1]
         mode = self.table_exchange
         counts = box["counts"].result() if want_counts else None
+        if use_plan and want_counts:
+            counts2d = [c if isinstance(c, list) else [c] for c in counts]     # [world][C] (C == 1 comes back flat)
+            counts = [sum(c) for c in counts2d]                   # distinct rows per rank
+        wide = V > 2 ** 31 - 1
         if mode == "auto":
-            mode = ("rows" if dist.rows_exchange_bytes(counts, E) < dist.dense_allreduce_bytes(n_emb, self.world)
+            mode = ("rows" if dist.rows_exchange_bytes(counts, E, wide) < dist.dense_allreduce_bytes(n_emb, self.world)
                     else "allreduce")
         self.last_exchange_mode = mode
-        if mode == "rows":
-            if "plan" in box:
-                n_mine = counts[self.rank]
-                rows, mine = box["plan"].rows[:n_mine].long(), box["plan"].out_rows[:n_mine]
-            else:
-                rows = box["rows"]
-                rows.record_stream(torch.cuda.current_stream())   # (made on the auxiliary stream, consumed here)
-                mine = table_grad.index_select(0, rows)
-            ids_all, g_all = dist.exchange_rows(rows, mine, counts, wide_ids=V > 2 ** 31 - 1)
+        late_done = False
+        if mode == "rows" and use_plan:
+            plan = box.get("plan")
+            # every chunk's all-gather is started now (they queue on RCCL's stream in order); chunk c is consumed -- own rows
+            # zeroed, every rank's rows added in rank order, late table-Adam pass over the chunk's row range -- while chunk
+            # c+1 is still travelling
+            inflight, p0 = [], 0
+            for c in range(C):
+                n_mine = counts2d[self.rank][c]
+                if plan is not None:
+                    rows_c, g_c = plan.rows[p0:p0 + n_mine].long(), plan.out_rows[p0:p0 + n_mine]
+                else:
+                    rows_c = torch.empty(0, device=self.device, dtype=torch.int64)
+                    g_c = torch.empty(0, E, device=self.device, dtype=torch.float32)
+                p0 += n_mine
+                cc = [counts2d[r][c] for r in range(len(counts2d))]
+                inflight.append((rows_c, cc) + dist.exchange_rows(rows_c, g_c, cc, wide_ids=wide, async_op=True))
+            self.last_exchange_bytes = sum(dist.rows_exchange_bytes(x[1], E, wide) for x in inflight)
+            for c, (rows_c, cc, ids_all, g_all, works) in enumerate(inflight):
+                for w in works:
+                    w.wait()                                      # (orders the current stream behind the collective)
+                table_grad.index_fill_(0, rows_c, 0.0)            # (own rows come back through g_all, in rank order)
+                dist.sum_rows_into_(table_grad, ids_all, g_all, cc)
+                v0, v1 = bounds[c], bounds[c + 1]
+                if v1 > v0:
+                    ops.adam_step_table(*[x[v0:v1] for x in views], flags[v0:v1], 1, lr_t, self.beta1, self.beta2,
+                                        self.adam_eps, clip=1.0)
+            late_done = True
+        elif mode == "rows":
+            rows = box["rows"]
+            rows.record_stream(torch.cuda.current_stream())   # (made on the auxiliary stream, consumed here)
+            mine = table_grad.index_select(0, rows)
+            ids_all, g_all = dist.exchange_rows(rows, mine, counts, wide_ids=wide)
             table_grad.index_fill_(0, rows, 0.0)              # (own rows come back through g_all, in rank order)
             dist.sum_rows_into_(table_grad, ids_all, g_all, counts)
-            self.last_exchange_bytes = dist.rows_exchange_bytes(counts, E, V > 2 ** 31 - 1)
+            self.last_exchange_bytes = dist.rows_exchange_bytes(counts, E, wide)
         else:
             dist.allreduce_sum_(self.flat_grad[:n_emb])
             self.last_exchange_bytes = dist.dense_allreduce_bytes(n_emb, self.world)
-        ops.adam_step_table(*views, flags, 1, lr_t, self.beta1, self.beta2, self.adam_eps, clip=1.0)
+        if not late_done:
+            ops.adam_step_table(*views, flags, 1, lr_t, self.beta1, self.beta2, self.adam_eps, clip=1.0)
         self._table_grad_clean = True
         if pending is not None:
             pending.join()

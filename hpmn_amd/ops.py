@@ -501,6 +501,8 @@ def pipe_mode(spec: ScanSpec) -> str:
     if PIPE in (False, None, "0", "", "off") or spec.H != 64 or spec.E % 4:
         return ""
     lib = _lib.load()
+    if not lib.hpmn_has_legacy_kernels():       # (the tile kernel's TRAINING backward is a -DHPMN_LEGACY_KERNELS build)
+        return ""
     if PIPE in (True, "all") and lib.hpmn_pipe_supported(spec.H, spec.D0):
         return "all"
     if spec.K >= 3 and lib.hpmn_pipe_supported(spec.H, spec.H):
@@ -799,7 +801,7 @@ class ScatterPlan:
     ``rows[:U]`` = the batch's distinct table rows (ascending), ``out_rows[:U]`` = their gradient rows once the scatter has
     run, ``count`` = U on the device; ``count_host()`` is an event-guarded read of its pinned copy (no device sync)."""
 
-    def __init__(self, ids: torch.Tensor, E: int, want_rows: bool = False, host_count: bool = False):
+    def __init__(self, ids: torch.Tensor, E: int, want_rows: bool = False, host_count: bool = False, row_bounds=None):
         _chk_ids(ids)
         dev = ids.device
         flat = ids.reshape(-1)
@@ -813,13 +815,22 @@ class ScatterPlan:
             head[1:] = (self.sorted[1:] != self.sorted[:-1]).to(torch.int32)
         self.seg = torch.cumsum(head, 0, dtype=torch.int32) - 1
         self.start = torch.empty(n + 1, **i32)
-        self.rows = torch.empty(n, device=dev, dtype=ids.dtype)
+        # ``row_bounds`` (ascending table-row boundaries b_0 = 0 < ... < b_C = V): chunk_counts[c] = distinct rows in
+        # [b_c, b_c+1) -- the data-parallel exchange sends the rows chunk by chunk (hpmn.py).  The unused tail of `rows` is
+        # then filled with the id type's maximum so that a searchsorted over the whole buffer stops at the count.
+        self.rows = (torch.full((n,), torch.iinfo(ids.dtype).max, device=dev, dtype=ids.dtype) if row_bounds is not None
+                     else torch.empty(n, device=dev, dtype=ids.dtype))
         self.count = torch.zeros(1, **i32)
         lib = _lib.load()
         _lib.check(lib.hpmn_scatter_plan(self.sorted.data_ptr(), self.id_flags, n, self.seg.data_ptr(), self.start.data_ptr(),
                                          self.rows.data_ptr(), self.count.data_ptr(), _stream()), "hpmn_scatter_plan")
         self.partials = torch.empty(max(1, lib.hpmn_embed_grad_segsum_partials_floats(n, E)), device=dev, dtype=torch.float32)
         self.out_rows = torch.empty(max(n, 1), E, device=dev, dtype=torch.float32) if want_rows else None
+        self.chunk_counts = None
+        if row_bounds is not None:
+            b = torch.as_tensor(list(row_bounds), device=dev, dtype=ids.dtype)
+            pos = torch.searchsorted(self.rows, b)                     # first entry >= b_c: [C + 1], pos[C] = U
+            self.chunk_counts = pos[1:] - pos[:-1]
         self._host = self._event = None
         if host_count:
             self._host = torch.empty(1, dtype=torch.int32, pin_memory=True)
@@ -842,7 +853,8 @@ class ScatterPlan:
 
     def record_stream(self, stream) -> None:
         """The plan was built on another stream than the one that consumes it."""
-        for t in (self.sorted, self.perm, self.seg, self.start, self.rows, self.count, self.partials, self.out_rows):
+        for t in (self.sorted, self.perm, self.seg, self.start, self.rows, self.count, self.partials, self.out_rows,
+                  self.chunk_counts):
             if t is not None:
                 t.record_stream(stream)
 

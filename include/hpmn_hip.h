@@ -48,6 +48,11 @@ enum {
 };
 
 int hpmn_abi_version(void);
+/* 1 when the library was built with -DHPMN_LEGACY_KERNELS: the measured-slower kernel generations (first-generation fused
+ * forward, helper-wave reverse scan, the tile kernel's training backward hpmn_pipe_bwd) are compiled in and selectable
+ * through their switches; 0 (default build): those switches fall through to the current kernels, hpmn_pipe_bwd returns
+ * HPMN_EUNSUPPORTED. */
+int hpmn_has_legacy_kernels(void);
 const char *hpmn_strerror(int code);
 int hpmn_last_hip_error(void);
 /* 1 when a (H, D) GRU layer shape has a kernel instantiation, else 0. */

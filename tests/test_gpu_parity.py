@@ -26,6 +26,14 @@ def dev():
     return torch.device("cuda:0")
 
 
+def _needs_legacy_build():
+    """Kernel generations that were measured slower and retired behind -DHPMN_LEGACY_KERNELS (r4):
+    their tests run against a library built with HPMN_HIPCC_FLAGS=-DHPMN_LEGACY_KERNELS."""
+    from hpmn_amd import _lib
+    if not _lib.load().hpmn_has_legacy_kernels():
+        pytest.skip("needs a library built with -DHPMN_LEGACY_KERNELS")
+
+
 def make_model(cfg: O.HpmnConfig, tmp, params=None, lr=0.003):
     from hpmn_amd.hpmn import Hpmn, Hpmn_Industry
     cls = Hpmn_Industry if cfg.industry else Hpmn
@@ -852,7 +860,8 @@ def test_pipelined_mfma_scan_matches_oracle_and_per_layer_kernels(dev, tmp_path,
     """hpmn_pipe_fwd / hpmn_pipe_bwd (batch-tiled split-f16 MFMA recurrence, layers pipelined across workgroups
     inside one launch, in-launch hand-offs through progress words): forward vs the float64 oracle, gradients vs
     float64 autograd, at the XLong graph's full length, an odd batch with a partial tile, four id columns, and
-    short / odd layer lengths; and no lost hand-off (error word 0)."""
+    short / odd layer lengths; and no lost hand-off (error word 0).  (Training on the tile kernel: a legacy build.)"""
+    _needs_legacy_build()
     from hpmn_amd import ops
     monkeypatch.setattr(ops, "PIPE", mode)
     cases = [(cfg_industry(H=64, K=7, T=1001, V=900), 21),               # two tiles, the second partial
@@ -1264,6 +1273,8 @@ def test_scans_give_the_same_result_beside_an_unrelated_kernel(dev, tmp_path, B,
     {"HPMN_PAIR_FWD": "1", "HPMN_PAIR_BWD": "1", "HPMN_FUSED_SCATTER": "1"},   # the other pairing; scatter fused into layer 0's launch
 ], ids=["gen1", "one-wave", "dx-launches+split", "no-pairs", "pairs-alt"])
 def test_fallback_kernel_paths_still_match_the_oracle(env):
+    if env.get("HPMN_FUSED_FWD_GEN") == "1":
+        _needs_legacy_build()
     """The switches of DESIGN.md 3.11 select kernels at library load, so each set runs a slice of this file in a
     process of its own: H = 64 forward/gradient parity at the tiny and odd lengths and at the XLong length."""
     import subprocess
@@ -1274,6 +1285,25 @@ def test_fallback_kernel_paths_still_match_the_oracle(env):
                         "-k", "(tiny_and_odd and 64) or xlong_c3_shape or c_abi_alone or (beside_an_unrelated and 6-3-41)"
                               " or (beside_an_unrelated and 3-5-297)"],
                        env=e, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_retired_kernel_generations_in_a_legacy_build(tmp_path):
+    """Opt-in (HPMN_TEST_LEGACY=1: it compiles a second library, minutes): build with -DHPMN_LEGACY_KERNELS and run the tests
+    of the retired generations -- first-generation fused forward + helper-wave reverse scan, training on the tile kernel --
+    against it in a process of its own (HPMN_LIB_PATH)."""
+    if os.environ.get("HPMN_TEST_LEGACY") != "1":
+        pytest.skip("opt-in: HPMN_TEST_LEGACY=1")
+    import subprocess
+    from hpmn_amd import build
+    lib = build.build_library(out=str(tmp_path / "libhpmn_hip_legacy.so"), flags=["-DHPMN_LEGACY_KERNELS"])
+    e = dict(os.environ, HPMN_LIB_PATH=lib)
+    e.pop("HPMN_TEST_LEGACY", None)
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", here, "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider",
+                        "-k", "pipelined_mfma_scan or (fallback_kernel_paths and gen1)"],
+                       env=e, capture_output=True, text=True, timeout=2400)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
