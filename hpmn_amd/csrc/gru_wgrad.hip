@@ -255,6 +255,7 @@ __global__ __launch_bounds__(32 * RED_G) void wgrad_reduce_kernel(const float *_
 }
 
 int gru_dx_dispatch(const HpmnGruWgrad &a, hipStream_t st);   // input_proj.hip (row-wise MFMA)
+bool gru_wgrad_bf16_launch(const HpmnGruWgrad &k, int nwg, bool solo, hipStream_t st);   // gru_wgrad_bf16.hip
 
 static int wgrad_seq_per_wg(int T) {   // T = steps per sequence in this launch
     int spw = (WG_MIN_ROWS + T - 1) / T;
@@ -295,7 +296,10 @@ static int launch_wgrad(const HpmnGruWgrad &a, hipStream_t st) {
         }();
         lds_pad = pad;
     }
-    hipLaunchKernelGGL((gru_wgrad_kernel<HT, DT, CS>), dim3((unsigned)nwg, CS), dim3(64 * (HT + DT)), lds_pad, st, k);
+    // H = 64: the same reduction on the bf16 matrix pipe with split operands (gru_wgrad_bf16.hip), HPMN_WGRAD_BF16=0: fp32
+    static const int bf16_env = [] { const char *e = getenv("HPMN_WGRAD_BF16"); return e ? atoi(e) : 1; }();
+    if (!(bf16_env && CS == 1 && gru_wgrad_bf16_launch(k, nwg, rows <= solo_rows && !a.whole_cu, st)))
+        hipLaunchKernelGGL((gru_wgrad_kernel<HT, DT, CS>), dim3((unsigned)nwg, CS), dim3(64 * (HT + DT)), lds_pad, st, k);
     int rc = check_launch();
     if (rc != HPMN_OK) return rc;
     const int H = a.H, D = a.D;

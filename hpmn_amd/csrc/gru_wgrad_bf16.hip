@@ -1,0 +1,249 @@
+// Weight / bias gradients of one GRU layer (H = 64) on the bf16 matrix pipe with SPLIT operands (round 4).
+//
+//   dWg += [x | h_prev]^T d_act[:, 0:2H]      dbg += sum_rows d_act[:, 0:2H]
+//   dWc += [x | r*h_prev]^T d_act[:, 2H:3H]   dbc += sum_rows d_act[:, 2H:3H]
+//
+// Same decomposition as gru_wgrad.hip (a workgroup owns whole sequences, its waves split the OUTPUT rows -- wave w < DT: 32
+// input columns, the others 32 state columns -- and keep their 3H/32 accumulator tiles resident; slabs + wgrad_reduce_kernel),
+// but the products run as v_mfma_f32_32x32x16_bf16: every fp32 operand is split x = hi + lo (hi = bf16(x), lo = bf16(x - hi),
+// |x - hi - lo| <= 2^-17 |x|, fp32's exponent range: no scaling) and a tile is three products, hi*hi + hi*lo + lo*hi, fp32
+// accumulate: 3 x 32 cycles per 16 rows where the fp32 instruction needs 8 x 64 -- 5.3x less time on the matrix pipe that the
+// reverse scan of layer 0 shares with six layers' weight gradients.
+//
+// The bf16 instruction wants 8 consecutive k (= rows of the [B*T, .] operands) per lane, the tensors are row-major with the
+// features contiguous: a transpose.  It is done by the global LOADS, not in LDS: the lane that will hold column c, rows
+// 8 kg .. 8 kg + 7 of a 32-column block loads exactly those eight dwords -- each of the eight load instructions covers 2 rows
+// x 128 contiguous bytes across the wave, fully coalesced --, splits them in registers (v_cvt_pk_bf16_f32: ~22 VALU per 8
+// values) and writes its two 16-byte fragments (hi, lo) to LDS IN LANE ORDER; a consumer wave reads a block's fragment with one
+// linear ds_read_b128 per lane.  No bank conflicts on either side, and every element is converted once per workgroup (each
+// wave stages ~1/NW of a tile's blocks), not once per consuming wave.
+#include <cstdlib>
+
+#include "common.h"
+
+namespace hpmn {
+
+typedef float f32x16b __attribute__((ext_vector_type(16)));
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+
+
+constexpr int BR = 16;            // rows per tile == k of the instruction
+
+struct Frag { bf8 hi, lo; };
+__device__ __forceinline__ Frag split8(const float (&v)[8]) {
+    Frag f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        f.hi[j] = (__bf16)v[j];
+        f.lo[j] = (__bf16)(v[j] - (float)f.hi[j]);
+    }
+    return f;
+}
+
+__host__ __device__ inline long wgrad_slab_floats_bf(int D, int H) { return (long)(D + H) * 3 * H + 3 * H; }   // == gru_wgrad.hip
+
+// blocks of a tile, in LDS order: [0, DT) x, [DT, DT+HT) h_prev, [DT+HT, DT+2HT) r*h_prev, then 3HT blocks of d_act.
+// The body is instantiated PER WAVE (W is a template argument, the kernel dispatches once at the top): which blocks a wave
+// stages and which source each comes from are then compile-time facts and the time loop is straight-line code -- with the
+// wave index at run time every staging load sat inside a (uniform) branch and was waited for at its join, vmcnt(0), before
+// the tile's matrix instructions could start (the lesson of gru_scan_fwd.hip and of scatter_sorted.hip again).  Loads are
+// unconditional: rows beyond the range are clamped to a valid row and zeroed by a select.
+template <int HT, int DT, int W>
+__device__ __forceinline__ void wgrad_bf16_wave(const HpmnGruWgrad &a, bf8 (*img)[DT + 2 * HT + 3 * HT][2][64]) {
+    constexpr int H = 32 * HT;
+    constexpr int NJ = 3 * HT;                 // 32-column tiles of d_act
+    constexpr int NW = HT + DT;                // waves
+    constexpr int NBLK = DT + 2 * HT + NJ;
+    constexpr int MAXT = (NBLK - W + NW - 1) / NW;   // staging tasks of this wave: blocks W, W + NW, ...
+    constexpr bool role_x = W < DT;
+    constexpr int tile = role_x ? W : W - DT;
+
+    const int lane = threadIdx.x & 63;
+    const int c = lane & 31, kg = lane >> 5;
+    const int T = a.T, D = a.D;
+
+    f32x16b acc[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    float bsum[MAXT];                           // column sums of the d_act blocks THIS wave stages (this lane's 8 rows)
+#pragma unroll
+    for (int i = 0; i < MAXT; ++i) bsum[i] = 0.f;
+
+    const int b_begin = blockIdx.x * a.seq_per_wg;
+    const int b_end = (b_begin + a.seq_per_wg) < a.B ? (b_begin + a.seq_per_wg) : a.B;
+    const int tb = a.t_begin, te = a.t_len > 0 ? a.t_begin + a.t_len : T;
+    const int ipt = (te - tb + BR - 1) / BR;
+    const int niter = (b_end - b_begin) * ipt;
+
+    // raw (unconverted) values of this wave's staging tasks for one tile.  Nothing is computed on them at load time -- not even
+    // the zeroing of rows beyond the range (clamped addresses; the mask is recomputed from the tile index when the tile is
+    // parked) -- so that two tiles' worth of them can be in flight without anything waiting on a load.
+    constexpr bool has_rh = (W >= 0) && ([] { for (int i = 0; i < MAXT; ++i) { const int q = W + i * NW; if (q >= DT + HT && q < DT + 2 * HT) return true; } return false; }());
+    struct Raw { float v[MAXT][8]; float r2[has_rh ? 8 : 1]; };
+    auto load_raw = [&](int it, Raw &g) {
+        const int b = b_begin + it / ipt;
+        const int t0 = tb + (it % ipt) * BR + 8 * kg;
+        long rowx[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rowx[j] = (long)b * T + ((t0 + j) < te ? (t0 + j) : (te - 1));
+#pragma unroll
+        for (int i = 0; i < MAXT; ++i) {
+            const int q = W + i * NW;           // (a constant after unrolling)
+            if (q < DT) {
+                const int col = 32 * q + c;
+                const int colc = col < D ? col : D - 1;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) g.v[i][j] = a.x[rowx[j] * D + colc];
+            } else if (q < DT + HT) {
+                const int col = 32 * (q - DT) + c;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) g.v[i][j] = a.hs[(rowx[j] + b) * H + col];       // hs has T + 1 rows per sequence
+            } else if (q < DT + 2 * HT) {
+                const int col = 32 * (q - DT - HT) + c;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    g.v[i][j] = a.hs[(rowx[j] + b) * H + col];
+                    g.r2[j] = a.gates[rowx[j] * 3 * H + col];
+                }
+            } else {
+                const int col = 32 * (q - DT - 2 * HT) + c;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) g.v[i][j] = a.d_act[rowx[j] * 3 * H + col];
+            }
+        }
+    };
+    auto park = [&](int buf, const Raw &g, int it) {
+        const int t0 = tb + (it % ipt) * BR + 8 * kg;
+#pragma unroll
+        for (int i = 0; i < MAXT; ++i) {
+            const int q = W + i * NW;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float x = g.v[i][j];
+                if (q >= DT + HT && q < DT + 2 * HT) x *= g.r2[j];                  // r * h_prev (not stored by the forward)
+                bool live = (t0 + j) < te;
+                if (q < DT) live = live && (32 * q + c) < D;
+                v[j] = live ? x : 0.f;
+            }
+            const Frag f = split8(v);
+            img[buf][q][0][lane] = f.hi;
+            img[buf][q][1][lane] = f.lo;
+            if (q >= DT + 2 * HT) {
+                float s = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s += v[j];
+                bsum[i] += s;
+            }
+        }
+    };
+
+    // Prefetch distance ONE tile: the loads of tile it + 1 are issued in front of tile it's matrix instructions and parked
+    // behind them.  (Distance two -- two tiles of raw values in registers -- was tried: 165-245 registers spilled beside the
+    // 96 accumulators; the second workgroup on the CU is what overlaps the round trip instead.)
+    auto compute = [&](int buf) {
+        constexpr int qa = role_x ? tile : DT + tile;      // x block / h_prev block (r*h_prev: + HT)
+        const bf8 ah = img[buf][qa][0][lane], al = img[buf][qa][1][lane];
+        const bf8 ch = img[buf][role_x ? qa : qa + HT][0][lane], cl = img[buf][role_x ? qa : qa + HT][1][lane];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const bf8 bh = img[buf][DT + 2 * HT + j][0][lane], bl = img[buf][DT + 2 * HT + j][1][lane];
+            // gate columns (tile < 2 HT) pair with x / h_prev, candidate columns with x / r * h_prev
+            const bf8 xh = (j < 2 * HT) ? ah : ch, xl = (j < 2 * HT) ? al : cl;
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bh, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bl, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, bh, acc[j], 0, 0, 0);
+        }
+    };
+    const int last = niter - 1;
+    Raw sa;
+    if (niter > 0) {
+        load_raw(0, sa);
+        park(0, sa, 0);
+    }
+    __syncthreads();
+    for (int it = 0; it < niter; ++it) {
+        const int buf = it & 1;
+        load_raw(it < last ? it + 1 : last, sa);          // (clamped: no branch around the loads)
+        compute(buf);
+        if (it < last) park(buf ^ 1, sa, it + 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: this workgroup's partial slab (summed by wgrad_reduce_kernel), C/D layout of the 32x32 instructions:
+    //      rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column lane & 31
+    float *slab = a.workspace + (long)blockIdx.x * wgrad_slab_floats_bf(D, H);
+    float *s_wg = slab, *s_bg = slab + (long)(D + H) * 2 * H, *s_wc = s_bg + 2 * H;
+    float *s_bc = s_wc + (long)(D + H) * H;
+    const int row_base = role_x ? 32 * tile : D + 32 * tile;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const bool gate_tile = j < 2 * HT;
+        float *dst = gate_tile ? s_wg : s_wc;
+        const int ld = gate_tile ? 2 * H : H;
+        const int col = gate_tile ? 32 * j + c : 32 * (j - 2 * HT) + c;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = (r & 3) + 8 * (r >> 2) + 4 * kg;
+            if (!role_x || 32 * tile + i < D) dst[(long)(row_base + i) * ld + col] = acc[j][r];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXT; ++i) {
+        const int q = W + i * NW;
+        if (q < DT + 2 * HT) continue;
+        const int j = q - DT - 2 * HT;
+        const float tot = bsum[i] + __shfl_xor(bsum[i], 32);     // the two half-waves hold rows 0-7 / 8-15 of every tile
+        if (kg == 0) {
+            if (j < 2 * HT) s_bg[32 * j + c] = tot;
+            else            s_bc[32 * (j - 2 * HT) + c] = tot;
+        }
+    }
+}
+
+template <int HT, int DT>
+__global__ __launch_bounds__(64 * (HT + DT), 2) void gru_wgrad_bf16_kernel(const HpmnGruWgrad a) {
+    static_assert(HT == 2 && (DT == 1 || DT == 2), "H = 64, D <= 64");
+    __shared__ __attribute__((aligned(16))) bf8 img[2][DT + 2 * HT + 3 * HT][2][64];
+    const int wave = threadIdx.x >> 6;          // (wave-uniform: one dispatch, then straight-line code per wave)
+    if (wave == 0) wgrad_bf16_wave<HT, DT, 0>(a, img);
+    else if (wave == 1) wgrad_bf16_wave<HT, DT, 1>(a, img);
+    else if (wave == 2) wgrad_bf16_wave<HT, DT, 2>(a, img);
+    else if constexpr (HT + DT > 3) wgrad_bf16_wave<HT, DT, 3>(a, img);
+}
+
+template <int HT, int DT>
+static void launch_bf16(const HpmnGruWgrad &k, int nwg, size_t lds_pad, hipStream_t st) {
+    hipLaunchKernelGGL((gru_wgrad_bf16_kernel<HT, DT>), dim3((unsigned)nwg), dim3(64 * (HT + DT)), lds_pad, st, k);
+}
+
+// H = 64, D <= 64 only.  Returns false when the shape is not served (the caller keeps the fp32 kernel).
+bool gru_wgrad_bf16_launch(const HpmnGruWgrad &k, int nwg, bool solo, hipStream_t st) {
+    if (k.H != 64 || k.D > 64) return false;
+    const int DT = (k.D + 31) / 32;
+    // (one workgroup per CU beside a reverse scan, as in gru_wgrad.hip: unused dynamic LDS caps the occupancy)
+    size_t pad = 0;
+    if (solo) {
+        const void *fn = DT == 1 ? reinterpret_cast<const void *>(gru_wgrad_bf16_kernel<2, 1>)
+                                 : reinterpret_cast<const void *>(gru_wgrad_bf16_kernel<2, 2>);
+        static size_t pads[2] = {(size_t)-1, (size_t)-1};
+        size_t &p = pads[DT - 1];
+        if (p == (size_t)-1) {
+            hipFuncAttributes fa = {};
+            p = 0;
+            if (hipFuncGetAttributes(&fa, fn) == hipSuccess) {
+                const size_t want = 82 * 1024;
+                p = fa.sharedSizeBytes < want ? want - fa.sharedSizeBytes : 0;
+                (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p);
+            }
+        }
+        pad = p;
+    }
+    if (DT == 1) launch_bf16<2, 1>(k, nwg, pad, st);
+    else         launch_bf16<2, 2>(k, nwg, pad, st);
+    return true;
+}
+
+}  // namespace hpmn
