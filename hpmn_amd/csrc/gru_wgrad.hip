@@ -298,7 +298,7 @@ static int launch_wgrad(const HpmnGruWgrad &a, hipStream_t st) {
     }
     // H = 64: the same reduction on the bf16 matrix pipe with split operands (gru_wgrad_bf16.hip), HPMN_WGRAD_BF16=0: fp32
     static const int bf16_env = [] { const char *e = getenv("HPMN_WGRAD_BF16"); return e ? atoi(e) : 1; }();
-    if (!(bf16_env && CS == 1 && gru_wgrad_bf16_launch(k, nwg, rows <= solo_rows && !a.whole_cu, st)))
+    if (!(bf16_env && HT >= 2 && gru_wgrad_bf16_launch(k, nwg, rows <= solo_rows && !a.whole_cu, st)))
         hipLaunchKernelGGL((gru_wgrad_kernel<HT, DT, CS>), dim3((unsigned)nwg, CS), dim3(64 * (HT + DT)), lds_pad, st, k);
     int rc = check_launch();
     if (rc != HPMN_OK) return rc;

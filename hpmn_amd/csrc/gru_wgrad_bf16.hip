@@ -48,12 +48,16 @@ __host__ __device__ inline long wgrad_slab_floats_bf(int D, int H) { return (lon
 // wave index at run time every staging load sat inside a (uniform) branch and was waited for at its join, vmcnt(0), before
 // the tile's matrix instructions could start (the lesson of gru_scan_fwd.hip and of scatter_sorted.hip again).  Loads are
 // unconditional: rows beyond the range are clamped to a valid row and zeroed by a select.
-template <int HT, int DT, int W>
-__device__ __forceinline__ void wgrad_bf16_wave(const HpmnGruWgrad &a, bf8 (*img)[DT + 2 * HT + 3 * HT][2][64]) {
+// CS = column split (H = 128): blockIdx.y picks one of CS groups of 3 HT / CS consecutive 32-column tiles of d_act -- twelve
+// accumulator tiles would be 192 registers; each group stages only ITS columns of d_act (plus x, h_prev, r: re-read per group,
+// as in the fp32 kernel).
+template <int HT, int DT, int CS, int W>
+__device__ __forceinline__ void wgrad_bf16_wave(const HpmnGruWgrad &a, bf8 (*img)[DT + 2 * HT + 3 * HT / CS][2][64]) {
     constexpr int H = 32 * HT;
-    constexpr int NJ = 3 * HT;                 // 32-column tiles of d_act
+    constexpr int NJ = 3 * HT / CS;            // 32-column tiles of d_act held by this workgroup
     constexpr int NW = HT + DT;                // waves
     constexpr int NBLK = DT + 2 * HT + NJ;
+    const int jb = blockIdx.y * NJ;            // first (global) column tile
     constexpr int MAXT = (NBLK - W + NW - 1) / NW;   // staging tasks of this wave: blocks W, W + NW, ...
     constexpr bool role_x = W < DT;
     constexpr int tile = role_x ? W : W - DT;
@@ -108,7 +112,7 @@ __device__ __forceinline__ void wgrad_bf16_wave(const HpmnGruWgrad &a, bf8 (*img
                     g.r2[j] = a.gates[rowx[j] * 3 * H + col];
                 }
             } else {
-                const int col = 32 * (q - DT - 2 * HT) + c;
+                const int col = 32 * (jb + q - DT - 2 * HT) + c;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) g.v[i][j] = a.d_act[rowx[j] * 3 * H + col];
             }
@@ -151,7 +155,8 @@ __device__ __forceinline__ void wgrad_bf16_wave(const HpmnGruWgrad &a, bf8 (*img
         for (int j = 0; j < NJ; ++j) {
             const bf8 bh = img[buf][DT + 2 * HT + j][0][lane], bl = img[buf][DT + 2 * HT + j][1][lane];
             // gate columns (tile < 2 HT) pair with x / h_prev, candidate columns with x / r * h_prev
-            const bf8 xh = (j < 2 * HT) ? ah : ch, xl = (j < 2 * HT) ? al : cl;
+            const bool gate = (jb + j) < 2 * HT;               // (uniform per workgroup)
+            const bf8 xh = gate ? ah : ch, xl = gate ? al : cl;
             acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bh, acc[j], 0, 0, 0);
             acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bl, acc[j], 0, 0, 0);
             acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, bh, acc[j], 0, 0, 0);
@@ -180,10 +185,11 @@ __device__ __forceinline__ void wgrad_bf16_wave(const HpmnGruWgrad &a, bf8 (*img
     const int row_base = role_x ? 32 * tile : D + 32 * tile;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        const bool gate_tile = j < 2 * HT;
+        const int jg = jb + j;
+        const bool gate_tile = jg < 2 * HT;
         float *dst = gate_tile ? s_wg : s_wc;
         const int ld = gate_tile ? 2 * H : H;
-        const int col = gate_tile ? 32 * j + c : 32 * (j - 2 * HT) + c;
+        const int col = gate_tile ? 32 * jg + c : 32 * (jg - 2 * HT) + c;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int i = (r & 3) + 8 * (r >> 2) + 4 * kg;
@@ -194,7 +200,7 @@ __device__ __forceinline__ void wgrad_bf16_wave(const HpmnGruWgrad &a, bf8 (*img
     for (int i = 0; i < MAXT; ++i) {
         const int q = W + i * NW;
         if (q < DT + 2 * HT) continue;
-        const int j = q - DT - 2 * HT;
+        const int j = jb + q - DT - 2 * HT;
         const float tot = bsum[i] + __shfl_xor(bsum[i], 32);     // the two half-waves hold rows 0-7 / 8-15 of every tile
         if (kg == 0) {
             if (j < 2 * HT) s_bg[32 * j + c] = tot;
@@ -203,46 +209,56 @@ __device__ __forceinline__ void wgrad_bf16_wave(const HpmnGruWgrad &a, bf8 (*img
     }
 }
 
-template <int HT, int DT>
-__global__ __launch_bounds__(64 * (HT + DT), 2) void gru_wgrad_bf16_kernel(const HpmnGruWgrad a) {
-    static_assert(HT == 2 && (DT == 1 || DT == 2), "H = 64, D <= 64");
-    __shared__ __attribute__((aligned(16))) bf8 img[2][DT + 2 * HT + 3 * HT][2][64];
+template <int HT, int DT, int CS>
+__global__ __launch_bounds__(64 * (HT + DT), (HT + DT) > 5 ? 1 : 2) void gru_wgrad_bf16_kernel(const HpmnGruWgrad a) {
+    static_assert((3 * HT) % CS == 0 && HT + DT <= 8, "column tiles split evenly; at most eight waves");
+    __shared__ __attribute__((aligned(16))) bf8 img[2][DT + 2 * HT + 3 * HT / CS][2][64];
     const int wave = threadIdx.x >> 6;          // (wave-uniform: one dispatch, then straight-line code per wave)
-    if (wave == 0) wgrad_bf16_wave<HT, DT, 0>(a, img);
-    else if (wave == 1) wgrad_bf16_wave<HT, DT, 1>(a, img);
-    else if (wave == 2) wgrad_bf16_wave<HT, DT, 2>(a, img);
-    else if constexpr (HT + DT > 3) wgrad_bf16_wave<HT, DT, 3>(a, img);
-}
-
-template <int HT, int DT>
-static void launch_bf16(const HpmnGruWgrad &k, int nwg, size_t lds_pad, hipStream_t st) {
-    hipLaunchKernelGGL((gru_wgrad_bf16_kernel<HT, DT>), dim3((unsigned)nwg), dim3(64 * (HT + DT)), lds_pad, st, k);
-}
-
-// H = 64, D <= 64 only.  Returns false when the shape is not served (the caller keeps the fp32 kernel).
-bool gru_wgrad_bf16_launch(const HpmnGruWgrad &k, int nwg, bool solo, hipStream_t st) {
-    if (k.H != 64 || k.D > 64) return false;
-    const int DT = (k.D + 31) / 32;
-    // (one workgroup per CU beside a reverse scan, as in gru_wgrad.hip: unused dynamic LDS caps the occupancy)
-    size_t pad = 0;
-    if (solo) {
-        const void *fn = DT == 1 ? reinterpret_cast<const void *>(gru_wgrad_bf16_kernel<2, 1>)
-                                 : reinterpret_cast<const void *>(gru_wgrad_bf16_kernel<2, 2>);
-        static size_t pads[2] = {(size_t)-1, (size_t)-1};
-        size_t &p = pads[DT - 1];
-        if (p == (size_t)-1) {
-            hipFuncAttributes fa = {};
-            p = 0;
-            if (hipFuncGetAttributes(&fa, fn) == hipSuccess) {
-                const size_t want = 82 * 1024;
-                p = fa.sharedSizeBytes < want ? want - fa.sharedSizeBytes : 0;
-                (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p);
+    constexpr int NW = HT + DT;
+    if (wave == 0) wgrad_bf16_wave<HT, DT, CS, 0>(a, img);
+    else if (wave == 1) wgrad_bf16_wave<HT, DT, CS, 1>(a, img);
+    else if (wave == 2) wgrad_bf16_wave<HT, DT, CS, 2>(a, img);
+    else if constexpr (NW > 3) {
+        if (wave == 3) wgrad_bf16_wave<HT, DT, CS, 3>(a, img);
+        else if constexpr (NW > 4) {
+            if (wave == 4) wgrad_bf16_wave<HT, DT, CS, 4>(a, img);
+            else if constexpr (NW > 5) {
+                if (wave == 5) wgrad_bf16_wave<HT, DT, CS, 5>(a, img);
+                else if (wave == 6) wgrad_bf16_wave<HT, DT, CS, 6>(a, img);
+                else wgrad_bf16_wave<HT, DT, CS, 7>(a, img);
             }
         }
+    }
+}
+
+template <int HT, int DT, int CS>
+static void launch_bf16(const HpmnGruWgrad &k, int nwg, bool solo, hipStream_t st) {
+    // (one workgroup per CU beside a reverse scan, as in gru_wgrad.hip: unused dynamic LDS caps the occupancy; H <= 64 only --
+    //  the H = 128 form is shaped around its column split)
+    size_t pad = 0;
+    if (solo) {
+        static const size_t p = [] {
+            hipFuncAttributes fa = {};
+            const void *fn = reinterpret_cast<const void *>(gru_wgrad_bf16_kernel<HT, DT, CS>);
+            if (hipFuncGetAttributes(&fa, fn) != hipSuccess) return (size_t)0;
+            const size_t want = 82 * 1024;
+            const size_t q = fa.sharedSizeBytes < want ? want - fa.sharedSizeBytes : 0;
+            (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q);
+            return q;
+        }();
         pad = p;
     }
-    if (DT == 1) launch_bf16<2, 1>(k, nwg, pad, st);
-    else         launch_bf16<2, 2>(k, nwg, pad, st);
+    hipLaunchKernelGGL((gru_wgrad_bf16_kernel<HT, DT, CS>), dim3((unsigned)nwg, CS), dim3(64 * (HT + DT)), pad, st, k);
+}
+
+// H = 64 with D <= 64, H = 128 with D = 32 / 128.  Returns false when the shape is not served (the caller keeps the fp32 kernel).
+bool gru_wgrad_bf16_launch(const HpmnGruWgrad &k, int nwg, bool solo, hipStream_t st) {
+    const int DT = (k.D + 31) / 32;
+    if (k.H == 64 && DT == 1) launch_bf16<2, 1, 1>(k, nwg, solo, st);
+    else if (k.H == 64 && DT == 2) launch_bf16<2, 2, 1>(k, nwg, solo, st);
+    else if (k.H == 128 && DT == 1) launch_bf16<4, 1, 2>(k, nwg, false, st);   // (two column groups: x, h_prev, r re-read twice, not 3x)
+    else if (k.H == 128 && DT == 4) launch_bf16<4, 4, 3>(k, nwg, false, st);
+    else return false;
     return true;
 }
 

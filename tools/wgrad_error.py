@@ -1,7 +1,7 @@
 """Weight gradients of one H = 64 GRU layer: error against float64 and time, for the kernel the library dispatches
 (HPMN_WGRAD_BF16=1 split-bf16 matrix pipe / =0 fp32 matrix pipe).  Worst-case inputs: mixed-sign values whose magnitudes
 span 1e-6 .. 1 (the gradient scale of a training step), 1024-step reductions.
-    python tools/wgrad_error.py [D]"""
+    python tools/wgrad_error.py [D [H]]"""
 import os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,7 +10,7 @@ from hpmn_amd import build, ops
 build.build_library()
 dev = torch.device("cuda:0")
 D = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-H = 64
+H = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 rng = np.random.default_rng(7)
 
 
@@ -51,6 +51,6 @@ def run(B, T, timing=False):
 mode = os.environ.get("HPMN_WGRAD_BF16", "1")
 for B, T in ((8, 1024), (3, 41)):
     for name, rel_max, rel_cond, pct in run(B, T):
-        print("bf16=%s B=%d T=%d D=%d %-5s max|err|/max|grad| %.2e   max|err|/sum|terms| %.2e   percentiles of |err|/max|grad| (50/90/99/100) %s"
+        print(("bf16=%s H=" + str(H) + " B=%d T=%d D=%d %-5s max|err|/max|grad| %.2e   max|err|/sum|terms| %.2e   percentiles of |err|/max|grad| (50/90/99/100) %s")
               % (mode, B, T, D, name, rel_max, rel_cond, " ".join("%.1e" % p for p in pct)))
-print("bf16=%s time B=500 T=1024 D=%d whole_cu: %.1f us" % (mode, D, run(500, 1024, timing=True)))
+print("bf16=%s time B=500 T=1024 D=%d H=%d whole_cu: %.1f us" % (mode, D, H, run(500, 1024, timing=True)))
