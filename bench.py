@@ -156,7 +156,8 @@ def gather_pmc_digest():
             return None
         out = {k: {"raw": v["fetch_bytes_per_row_raw"], "x2": v["fetch_bytes_per_row_x2"]} for k, v in d["cases"].items()}
         out["_calibration"] = {"sequential_ids_fetch_bytes_per_row_raw": d["cases"]["seq/embed_gather_sum_kernel"]["fetch_bytes_per_row_raw"],
-                               "truth_bytes_per_row": 64, "source": "profiles/r04_gather_pmc.json"}
+                               "truth_bytes_per_row": 68, "truth": "64 B row + 4 B id, every row once in order",
+                               "source": "profiles/r04_gather_pmc.json"}
         return out
     except Exception:
         return None
