@@ -53,15 +53,18 @@ def device_auc(pred: torch.Tensor, label: torch.Tensor) -> torch.Tensor:
     order = torch.argsort(pred)
     ps = pred[order]
     n = ps.numel()
-    # groups of equal predictions: every member gets the mean of the group's 1-based positions
-    new_group = torch.ones(n, dtype=torch.bool, device=pred.device)
-    new_group[1:] = ps[1:] != ps[:-1]
-    gid = torch.cumsum(new_group.long(), 0) - 1
-    pos = torch.arange(1, n + 1, device=pred.device, dtype=torch.float64)
-    ng = n                                     # at most n groups (sized without a host round trip)
-    gsum = torch.zeros(ng, dtype=torch.float64, device=pred.device).index_add_(0, gid, pos)
-    gcnt = torch.zeros(ng, dtype=torch.float64, device=pred.device).index_add_(0, gid, torch.ones_like(pos))
-    rank = (gsum / gcnt.clamp(min=1.0))[gid]
+    # groups of equal predictions: every member gets the mean of the group's 1-based positions = (first + last) / 2 + 1.
+    # First / last position of an element's group by two scans (cummax of the group heads, reversed cummin of the group tails)
+    # -- no index_add_: with heavy ties (a collapsed model predicts ONE value: r4, bench.py's random-label rows after 200
+    # steps) 16 000 double-precision atomics on one address took 7 ms each way and eval() 100 ms instead of 12.
+    idx = torch.arange(n, device=pred.device)
+    head = torch.ones(n, dtype=torch.bool, device=pred.device)
+    head[1:] = ps[1:] != ps[:-1]
+    tail = torch.ones(n, dtype=torch.bool, device=pred.device)
+    tail[:-1] = head[1:]
+    first = torch.cummax(torch.where(head, idx, torch.zeros_like(idx)), 0).values
+    last = torch.flip(torch.cummin(torch.flip(torch.where(tail, idx, torch.full_like(idx, n)), [0]), 0).values, [0])
+    rank = (first + last).double() / 2.0 + 1.0
     ys = y[order]
     n1 = ys.sum()
     n0 = n - n1

@@ -180,3 +180,16 @@ def test_single_class_eval_raises_like_sklearn(tmp_path):
     auc, ll, mem = m.eval(two, 4)
     from sklearn.metrics import roc_auc_score
     assert abs(auc - roc_auc_score(two["label"], np.linspace(0.1, 0.9, 4).tolist() + np.linspace(0.1, 0.9, 2).tolist())) < 1e-12
+
+
+def test_device_auc_with_heavy_ties_equals_sklearn():
+    """A collapsed model predicts one value (or a handful) for every row: the mid-rank form must still equal sklearn's AUC, and
+    it is computed by scans (no atomics on one address: r4)."""
+    from sklearn.metrics import roc_auc_score
+    from hpmn_amd.hpmn import device_auc
+    rng = np.random.default_rng(9)
+    y = rng.integers(0, 2, size=5000)
+    for pred in (np.full(5000, 0.5), rng.choice([0.1, 0.5, 0.9], size=5000), np.r_[np.full(4999, 0.3), 0.7],
+                 np.round(rng.random(5000), 2)):
+        got = float(device_auc(torch.as_tensor(pred), torch.as_tensor(y)))
+        assert abs(got - roc_auc_score(y, pred)) < 1e-12

@@ -23,3 +23,19 @@ print("device_auc + log_loss + tolist: %.1f ms" % t(lambda: torch.stack([H.devic
 print("_dev lookup: %.3f ms" % t(lambda: m._dev(ds)))
 m.TILED_EVAL_MIN_ROWS = 0
 print("eval(ds, 2000) per-sequence kernels, batch by batch: %.1f ms" % t(lambda: m.eval(ds, 2000)))
+# --- the same inside a process that has trained (bench.py measured 61 ms per eval() where this script measures 12.6)
+import gc
+m.TILED_EVAL_MIN_ROWS = 1536
+batches = bench.synth_batches(c, 4, c["batch"], 1, dev)
+for i in range(10):
+    m.train_step(batches[i % 4][0], batches[i % 4][1], keep_prob=0.5, global_batch=c["batch"])
+torch.cuda.synchronize()
+print("after training: eval(ds, 2000): %.1f ms" % t(lambda: m.eval(ds, 2000)))
+gc.collect(); gc.freeze()
+print("after gc.collect + gc.freeze: %.1f ms" % t(lambda: m.eval(ds, 2000)))
+gc.disable()
+print("gc disabled: %.1f ms" % t(lambda: m.eval(ds, 2000)))
+gc.enable()
+import cProfile, pstats
+pr = cProfile.Profile(); pr.enable(); m.eval(ds, 2000); torch.cuda.synchronize(); pr.disable()
+pstats.Stats(pr).sort_stats("cumulative").print_stats(12)
