@@ -508,7 +508,7 @@ int hpmn_embed_grad_segsum(const HpmnScatterPlan *plan, const float *d_x, float 
     drop_stale_hip_error();
     if (!plan || B < 0 || T < 1 || F < 1 || E < 4 || front_zero < 0) return HPMN_EINVAL;
     if (E % 4 != 0 || 256 % (E / 4) != 0) return HPMN_EUNSUPPORTED;
-    if (plan->n != (int64_t)B * T * F) return HPMN_EINVAL;
+    if (plan->n != (int64_t)B * T * F || plan->n > 0x7fffffffLL) return HPMN_EINVAL;     // (perm / start are int32)
     if (B == 0) return HPMN_OK;
     if (!plan->perm || !plan->seg || !plan->start || !plan->rows || !plan->count || !plan->partials || !d_x) return HPMN_EINVAL;
     if (!plan->out_rows && !d_emb) return HPMN_EINVAL;

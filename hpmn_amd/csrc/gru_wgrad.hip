@@ -272,7 +272,6 @@ template <int HT, int DT, int CS = 1>
 static int launch_wgrad(const HpmnGruWgrad &a, hipStream_t st) {
     HpmnGruWgrad k = a;
     k.seq_per_wg = wgrad_seq_per_wg(a.t_len > 0 ? a.t_len : a.T);
-    const int nwg = (a.B + k.seq_per_wg - 1) / k.seq_per_wg;
     // One weight-gradient workgroup per CU while the launch shares the chip with a reverse scan (every layer but the
     // longest): two of them take every register of a CU, and the single-wave workgroups of the next reverse scan --
     // the serial chain -- then cannot even be dispatched until they retire.  Padding the workgroup's LDS to 82 KiB with
@@ -283,6 +282,20 @@ static int launch_wgrad(const HpmnGruWgrad &a, hipStream_t st) {
     static const long solo_env = [] { const char *e = getenv("HPMN_WGRAD_SOLO_ROWS"); return e ? atol(e) : -1L; }();
     const long solo_rows = solo_env >= 0 ? solo_env : (a.H <= 64 ? (1L << 62) : 0L);
     const long rows = (long)a.B * (a.t_len > 0 ? a.t_len : a.T);
+    // A launch that is capped at one workgroup per CU anyway (beside a reverse scan) gains nothing from more workgroups than
+    // CUs: let each take ceil(B / CUs) sequences -- half the slabs at B = 500 (their write + the reduction's read: 0.15 GB of
+    // the step's 8.3, and the reduce launches on the helper stream's chain shrink with them).
+    if (rows <= solo_rows && !a.whole_cu) {
+        static const int cus = [] {
+            int dev = 0, n = 0;
+            if (hipGetDevice(&dev) != hipSuccess) return 256;
+            if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return 256;
+            return n;
+        }();
+        const int per_cu = (a.B + cus - 1) / cus;
+        if (per_cu > k.seq_per_wg) k.seq_per_wg = per_cu;
+    }
+    const int nwg = (a.B + k.seq_per_wg - 1) / k.seq_per_wg;
     size_t lds_pad = 0;
     if (rows <= solo_rows && !a.whole_cu) {
         static const size_t pad = [] {
