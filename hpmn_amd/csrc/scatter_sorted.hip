@@ -57,7 +57,6 @@ struct SegArgs {
     float *d_emb;         // optional [V, E]
     const float *d_last;  // optional [B, F*E]
     int T, F, E4, front_zero, id_flags, t_last;
-    int dbg;              // timing ablation (HPMN_SEGSUM_DEBUG, tools/segsum_time.py): 1 no table RMW, 2 no d_x loads, 4 no row-id loads
 };
 
 // float4 index of lookup q = (b, t, f)'s gradient row (this lane's e4-th piece) in d_x; `at_last`: its step is t_last
@@ -111,9 +110,8 @@ __global__ __launch_bounds__(256) void segsum_chunks_kernel(SegArgs a, long nchu
         bool at_last;
         long li;
         const long idx = lookup_index(a, q[i], e4, at_last, li);
-        v[i] = (a.dbg & 2) ? make_float4(1.f, 1.f, 1.f, 1.f)
-                           : reinterpret_cast<const float4 *>(a.d_x)[idx];       // (no use of v in this loop: 16 row loads in flight)
-        row[i] = (a.dbg & 4) ? (long)sg[i] : load_id(a.rows, sg[i], a.id_flags);
+        v[i] = reinterpret_cast<const float4 *>(a.d_x)[idx];       // (no use of v in this loop: all of the chunk's row loads in flight)
+        row[i] = load_id(a.rows, sg[i], a.id_flags);
         if (at_last && i < m) { last_bits |= 1u << i; last_idx = li; }
     }
     if (last_bits != 0) {                                           // joined to the lookup's row BEFORE the sums, as the atomic kernel does
@@ -168,7 +166,7 @@ __global__ __launch_bounds__(256) void segsum_chunks_kernel(SegArgs a, long nchu
         float4 old[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) old[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (D != nullptr && !(a.dbg & 1)) {                         // (uniform; the loads inside are UNCONDITIONAL: a lane that
+        if (D != nullptr) {                                         // (uniform; the loads inside are UNCONDITIONAL: a lane that
 #pragma unroll                                                      //  will not use the value reads its own valid row all the same)
             for (int i = 0; i < 8; ++i) old[i] = D[row[h + i] * a.E4 + e4];
         }
@@ -180,7 +178,7 @@ __global__ __launch_bounds__(256) void segsum_chunks_kernel(SegArgs a, long nchu
                 const bool masked = id_masked(row[k], a.id_flags);
                 const float4 s = masked ? make_float4(0.f, 0.f, 0.f, 0.f) : v[k];
                 if (O != nullptr) O[(long)sg[k] * a.E4 + e4] = s;
-                if (D != nullptr && !masked && !(a.dbg & 1))
+                if (D != nullptr && !masked)
                     D[row[k] * a.E4 + e4] = make_float4(old[i].x + s.x, old[i].y + s.y, old[i].z + s.z, old[i].w + s.w);
             } else {
                 P[(2 * g + (((first_run >> k) & 1u) ? 0 : 1)) * a.E4 + e4] = v[k];
@@ -271,7 +269,6 @@ int embed_grad_segsum_launch(const HpmnScatterPlan &p, const float *d_x, float *
     a.n = p.n; a.perm = p.perm; a.seg = p.seg; a.start = p.start; a.rows = p.rows; a.out_rows = p.out_rows;
     a.partials = p.partials; a.d_x = d_x; a.d_emb = d_emb; a.d_last = d_last;
     a.T = T; a.F = F; a.E4 = E / 4; a.front_zero = front_zero; a.id_flags = id_flags; a.t_last = t_last;
-    { const char *e = getenv("HPMN_SEGSUM_DEBUG"); a.dbg = e ? atoi(e) : 0; }
     const long nchunk = (p.n + SCH - 1) / SCH;
     a.heads = reinterpret_cast<int *>(p.partials + 2 * nchunk * E);
     a.nheads = a.heads + nchunk;

@@ -1,5 +1,5 @@
 """Deterministic scatter at the C3 shape: plan build, the two segsum passes and the atomic kernel it replaces.
-    python tools/segsum_time.py            (HPMN_SEGSUM_DEBUG=1/2/4/...: timing ablations of pass 1)"""
+    python tools/segsum_time.py"""
 import os, sys, time
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -31,5 +31,5 @@ t_seg = timed(lambda: ops.embed_grad_segsum(plan, (B, T, F), dx, demb, Z, False)
 plan2 = ops.ScatterPlan(ids, E, want_rows=False)
 t_seg2 = timed(lambda: ops.embed_grad_segsum(plan2, (B, T, F), dx, demb, Z, False))
 t_atomic = timed(lambda: ops.embed_grad_scatter(ids, dx, demb, Z, False))
-print("dbg=%s  plan %.1f us   segsum (dense + rows) %.1f us   segsum (dense only) %.1f us   atomic scatter %.1f us   U=%d"
-      % (os.environ.get("HPMN_SEGSUM_DEBUG", "0"), t_plan, t_seg, t_seg2, t_atomic, plan.count_host()))
+print("plan %.1f us   segsum (dense + rows) %.1f us   segsum (dense only) %.1f us   atomic scatter %.1f us   U=%d"
+      % (t_plan, t_seg, t_seg2, t_atomic, plan.count_host()))
