@@ -457,9 +457,13 @@ def cpu_baseline(c, seed=0, budget_s=25.0):
     try:
         import ctypes
         libc = ctypes.CDLL("libc.so.6")
-        M_TRIM_THRESHOLD, M_TOP_PAD, M_MMAP_THRESHOLD = -1, -2, -3
-        malloc_tuned = bool(libc.mallopt(M_MMAP_THRESHOLD, 32 << 20) and libc.mallopt(M_TRIM_THRESHOLD, 2 ** 31 - 1)
-                            and libc.mallopt(M_TOP_PAD, 256 << 20))
+        M_TRIM_THRESHOLD, M_TOP_PAD, M_MMAP_THRESHOLD, M_ARENA_MAX = -1, -2, -3, -8
+        # (one arena: the autograd thread's own arena is made of 64 MB sub-heaps that are unmapped when they empty, whatever
+        #  the trim threshold says -- one step in five still took 14 s with the three settings above alone)
+        # (trim threshold -1: mallopt takes an int and the library widens it to size_t, i.e. "never" -- INT_MAX = 2 GB still
+        #  let free() hand the ~10 GB heap back to the kernel now and then: 2.1 2.2 2.1 14.8 2.0)
+        malloc_tuned = bool(libc.mallopt(M_MMAP_THRESHOLD, 32 << 20) and libc.mallopt(M_TRIM_THRESHOLD, -1)
+                            and libc.mallopt(M_TOP_PAD, 256 << 20) and libc.mallopt(M_ARENA_MAX, 1))
     except OSError:
         pass
     cfg = O.HpmnConfig(feature_size=c["V"], user_dim=c["F"], user_maxlen=c["T"], hidden_size=c["H"],
