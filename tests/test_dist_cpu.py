@@ -198,3 +198,84 @@ def test_touched_rows_exchange_equals_the_dense_all_reduce():
     untouched = np.setdiff1d(np.arange(40), union0)
     assert (summed0[untouched] == 0).all()
     assert counts0 == counts1 and nbytes0 == max(counts0) * (4 + 16)
+
+
+def _chunked_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        V, E, C = 64, 4, 4
+        rng = np.random.default_rng(23 + rank)
+        ids = torch.as_tensor(rng.integers(0, V, size=(2 + 3 * rank, 6, 2)))                   # ragged shards, int64 ids
+        dense = torch.zeros(V, E)
+        dense.index_add_(0, ids.reshape(-1), torch.as_tensor(rng.normal(size=(ids.numel(), E)), dtype=torch.float32))
+        rows = torch.unique(ids.reshape(-1))                                                   # sorted: chunks are row ranges
+        bounds = dist.chunk_bounds(V, C, 8)
+        cuts = torch.searchsorted(rows, torch.tensor([lo for lo, _ in bounds] + [V]))
+        per_chunk = cuts[1:] - cuts[:-1]                                                       # this rank's rows per row range
+        pending = dist.exchange_counts_async(per_chunk, torch.device("cpu"))                   # the vector form: [world][C]
+        counts = pending.result()
+        scalar = dist.exchange_counts_async(int(rows.numel()), torch.device("cpu")).result()   # the int form: [world]
+        summed = dense.clone()
+        summed.index_fill_(0, rows, 0.0)
+        flights = []
+        for c in range(len(bounds)):                                                           # every chunk started ...
+            a, b = int(cuts[c]), int(cuts[c + 1])
+            cc = [counts[r][c] for r in range(world)]
+            flights.append((cc,) + tuple(dist.exchange_rows(rows[a:b], dense.index_select(0, rows[a:b]), cc,
+                                                            wide_ids=(c % 2 == 1), async_op=True)))
+        widths = []
+        for c, (cc, ids_all, g_all, works) in enumerate(flights):                              # ... then consumed in order
+            [w.wait() for w in works]
+            widths.append(ids_all.dtype)
+            lo, hi = bounds[c]
+            valid = torch.cat([ids_all[r, :n] for r, n in enumerate(cc)])
+            assert valid.numel() == 0 or (int(valid.min()) >= lo and int(valid.max()) < hi)
+            assert all((ids_all[r, n:] == -1).all() for r, n in enumerate(cc))
+            dist.sum_rows_into_(summed[lo:hi], ids_all, g_all, cc, row_of=lambda i, lo=lo: i.long() - lo)
+        ref = dense.clone()
+        dist.allreduce_sum_(ref)
+        q.put((rank, summed.numpy(), ref.numpy(), counts, scalar, int(rows.numel()), [str(w) for w in widths],
+               [dist.rows_exchange_bytes([counts[r][c] for r in range(world)], E, wide_ids=(c % 2 == 1))
+                for c in range(len(bounds))]))
+    finally:
+        td.destroy_process_group()
+
+
+def test_chunked_async_rows_exchange_with_vector_counts():
+    """The data-parallel step's form of the exchange (hpmn_amd/hpmn.py _train_step_dp): the table is cut into row ranges,
+    ONE all-gather carries every rank's row count per range ([world][C]), every range's (ids, rows) all-gathers are started
+    before the first is consumed, and each range is summed into its slice of the table -- the result must still be the dense
+    all-reduce, bit-identical across ranks; narrow and wide id widths alternate over the ranges."""
+    world = 2
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_chunked_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in ps]
+    got = {r[0]: r[1:] for r in (q.get(timeout=120) for _ in range(world))}
+    [p.join(60) for p in ps]
+    assert all(p.exitcode == 0 for p in ps)
+    s0, ref0, counts0, scalar0, n0, w0, bytes0 = got[0]
+    s1, ref1, counts1, scalar1, n1, w1, bytes1 = got[1]
+    np.testing.assert_array_equal(s0, s1)
+    np.testing.assert_allclose(s0, ref0, rtol=0, atol=1e-6)
+    assert counts0 == counts1 and len(counts0) == 2 and all(len(c) == 4 for c in counts0)
+    assert scalar0 == scalar1 == [n0, n1] == [sum(counts0[0]), sum(counts0[1])]
+    assert w0 == w1 == ["torch.int32", "torch.int64", "torch.int32", "torch.int64"]
+    assert bytes0 == [max(counts0[0][c], counts0[1][c]) * ((8 if c % 2 else 4) + 16) for c in range(4)]
+
+
+def test_single_process_exchange_is_the_identity():
+    """world 1, no process group: the helpers return this rank's own rows (padded form) and counts without a collective."""
+    rows = torch.tensor([3, 9, 11])
+    g = torch.arange(12, dtype=torch.float32).view(3, 4)
+    assert dist.exchange_counts_async(3, torch.device("cpu")).result() == [3]
+    assert dist.exchange_counts_async(torch.tensor([2, 1]), torch.device("cpu")).result() == [[2, 1]]
+    ids_all, g_all, works = dist.exchange_rows(rows, g, [3], async_op=True)
+    assert works == [] and ids_all.shape == (1, 3) and ids_all.dtype == torch.int32
+    dst = torch.zeros(16, 4)
+    dist.sum_rows_into_(dst, ids_all, g_all, [3])
+    np.testing.assert_array_equal(dst[rows].numpy(), g.numpy())
+    assert float(dst.sum()) == float(g.sum())
