@@ -10,7 +10,9 @@ import os
 from typing import Optional
 
 HPMN_MAX_LAYERS = 12
-HPMN_ABI_VERSION = 10
+HPMN_ABI_VERSION = 11
+HPMN_FWD_NO_CANDIDATE = 1
+HPMN_BWD_CANDIDATE_FROM_HS = 1
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libhpmn_hip.so")
@@ -58,6 +60,7 @@ class HpmnGruBwd(C.Structure):
         ("scatter_ids", C.c_void_p), ("d_emb", C.c_void_p), ("d_last", C.c_void_p),
         ("Tids", C.c_int32), ("F", C.c_int32), ("E", C.c_int32), ("front_zero", C.c_int32), ("mask_id0", C.c_int32),
         ("last_t", C.c_int32),
+        ("flags", C.c_int32), ("pad_", C.c_int32),
     ]
 
 
@@ -108,7 +111,7 @@ class HpmnGruFusedFwd(C.Structure):
         ("h_last", C.c_void_p), ("h_last_stride", C.c_int64),
         ("y", C.c_void_p), ("period", C.c_int32),
         ("hs", C.c_void_p), ("gates", C.c_void_p),
-        ("last", C.c_void_p), ("last_t", C.c_int32), ("pad_", C.c_int32),
+        ("last", C.c_void_p), ("last_t", C.c_int32), ("flags", C.c_int32),
     ]
 
 
@@ -176,6 +179,7 @@ SIGNATURES = {
     "hpmn_gru_scan_fwd": (C.c_int, [C.POINTER(HpmnGruFwd), C.c_void_p]),
     "hpmn_gru_scan_bwd": (C.c_int, [C.POINTER(HpmnGruBwd), C.c_void_p]),
     "hpmn_gru_scan_bwd_fuses_dx": (C.c_int, [C.c_int32, C.c_int32]),
+    "hpmn_gru_candidate_elision": (C.c_int, [C.c_int32, C.c_int32]),
     "hpmn_gru_scan_bwd_fuses_scatter": (C.c_int, [C.c_int32] * 5),
     "hpmn_gru_param_grads_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "hpmn_gru_param_grads": (C.c_int, [C.POINTER(HpmnGruWgrad), C.c_void_p]),

@@ -12,6 +12,7 @@ bool gru_shape_supported(int H, int D);
 int gru_scan_fwd_dispatch(const HpmnGruFwd &a, hipStream_t st);
 int gru_scan_bwd_dispatch(const HpmnGruBwd &a, hipStream_t st);
 bool gru_scan_bwd_fuses_dx(int H, int B);
+bool gru_candidate_elision(int H, int B);
 bool gru_scan_bwd_dx_width_ok(int D);
 bool gru_scan_bwd_fuses_scatter(int H, int B, int D, int F, int E);
 bool input_proj_supported(int H, int D);
@@ -180,6 +181,7 @@ int hpmn_gru_scan_bwd(const HpmnGruBwd *a, void *stream) {
     }
     if (!gru_shape_supported(a->H, a->D)) return HPMN_EUNSUPPORTED;
     if (a->d_x && (!gru_scan_bwd_fuses_dx(a->H, a->B) || !gru_scan_bwd_dx_width_ok(a->D))) return HPMN_EUNSUPPORTED;
+    if ((a->flags & HPMN_BWD_CANDIDATE_FROM_HS) && !gru_candidate_elision(a->H, a->B)) return HPMN_EUNSUPPORTED;
     if (a->d_emb) {
         if (!a->scatter_ids || a->Tids < 1 || a->F < 1 || a->front_zero < 0 || a->front_zero + a->Tids != a->T) return HPMN_EINVAL;
         if (a->t_begin != 0 || (a->t_end != 0 && a->t_end != a->T)) return HPMN_EINVAL;
@@ -193,6 +195,7 @@ int hpmn_gru_scan_bwd(const HpmnGruBwd *a, void *stream) {
 }
 
 int hpmn_gru_scan_bwd_fuses_dx(int32_t H, int32_t B) { return gru_scan_bwd_fuses_dx(H, B) ? 1 : 0; }
+int hpmn_gru_candidate_elision(int32_t H, int32_t B) { return gru_candidate_elision(H, B) ? 1 : 0; }
 int hpmn_gru_scan_bwd_fuses_scatter(int32_t H, int32_t B, int32_t D, int32_t F, int32_t E) {
     return gru_scan_bwd_fuses_scatter(H, B, D, F, E) ? 1 : 0;
 }
@@ -648,6 +651,7 @@ int hpmn_gru_pair_bwd(const HpmnGruPairBwd *p, void *stream) {
     if (p->lo.T % p->lo.period != 0 || p->up.T != p->lo.T / p->lo.period) return HPMN_EINVAL;
     if (p->up.d_y != nullptr && p->up.T % p->up.period != 0) return HPMN_EINVAL;
     if (!gru_pair_bwd_supported(p->lo.H, p->lo.D)) return HPMN_EUNSUPPORTED;
+    if (((p->lo.flags | p->up.flags) & HPMN_BWD_CANDIDATE_FROM_HS) && !gru_candidate_elision(p->lo.H, p->lo.B)) return HPMN_EUNSUPPORTED;
     if (p->lo.B == 0) return HPMN_OK;
     return gru_pair_bwd_launch(p->lo, p->up, p->flags, (hipStream_t)stream);
 }

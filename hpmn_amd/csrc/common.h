@@ -110,6 +110,17 @@ __device__ __forceinline__ void land_group(v4f (&v)[G], f2 &a, f2 &b) {
 __device__ __forceinline__ void settle(float &x) { asm volatile("" : "+v"(x)); }
 __device__ __forceinline__ void settle(f2 &x) { asm volatile("" : "+v"(x)); }
 
+// BPTT through h = u h_prev + (1 - u) c WITHOUT the stored candidate (include/hpmn_hip.h, HPMN_BWD_CANDIDATE_FROM_HS):
+// q = (1 - u) c = h - u h_prev;  k1 = (1 - u)(1 - c^2) = (1 - u) - q c;  k2 = (h_prev - c) u (1 - u) = u ((1 - u) h_prev - q).
+// Where u rounds to 1 the candidate cannot be recovered and is not needed: k1 = 0, |k2| <= one rounding of h (true value 0).
+// c = q / (1 - u) carries an absolute error of eps |h| / (1 - u); it only enters k1 multiplied by q = O(1 - u).
+__device__ __forceinline__ void gru_coeff_from_states(float h_new, float h_prev, float u, float omu, float &k1, float &k2) {
+    const float q = fmaf(-u, h_prev, h_new);
+    const float c = omu > 0.f ? q * __builtin_amdgcn_rcpf(omu) : 0.f;
+    k1 = fmaf(-q, c, omu);
+    k2 = u * fmaf(h_prev, omu, -q);
+}
+
 // acc0/acc1 += sum over NQ float4's of a wave-uniform LDS row (a broadcast) times the lane's packed
 // weights w[2*q], w[2*q+1] (pairs over consecutive k).  The LDS reads are software-pipelined in
 // groups of G float4 (G reads in flight while the previous group's packed FMAs issue) and fenced

@@ -358,7 +358,7 @@ int gru_fused_fwd_dispatch(const HpmnGruFusedFwd &a, hipStream_t st) {
     const int gen = fused_gen();
     if (gen >= 3) return gru_fwd_mfma_dispatch(a, st);
 #ifdef HPMN_LEGACY_KERNELS
-    if (a.last != nullptr) return HPMN_EUNSUPPORTED;
+    if (a.last != nullptr || (a.flags & HPMN_FWD_NO_CANDIDATE)) return HPMN_EUNSUPPORTED;
     if (a.B == 0) return HPMN_OK;
     if (a.H != FH) return HPMN_EUNSUPPORTED;
     if (a.D == 32) return launch_fused<32>(a, st);

@@ -185,6 +185,7 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_mfma_kernel(const HpmnGruFused
         float *gp = TRAIN ? a.gates + (b * (long)T) * 3 * H + l : nullptr;  // row t-1 (row 0 twice, see below)
         int h_seen = 0;
         float u_prev = 0.f;
+        const bool keep_c = !(a.flags & HPMN_FWD_NO_CANDIDATE);            // (wave-uniform)
 
         // iteration t: u_t for the chain wave; then the saved rows of step t-1.  TILE >= 0: one 16-column tile of the
         // NEXT block's projection is issued right behind the wait, so that the matrix pipe works underneath the packed
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_mfma_kernel(const HpmnGruFused
                 // (t == 0 writes an undefined row 0, which iteration 1 overwrites: same wave, same address, in order)
                 gp[0] = rc.x;
                 gp[H] = UPROD ? u_prev : rc.y;
-                gp[2 * H] = rc.z;
+                if (keep_c) gp[2 * H] = rc.z;            // (HPMN_FWD_NO_CANDIDATE: two 128-byte lines per step stay unwritten)
                 gp += t > 0 ? 3 * H : 0;
                 u_prev = u_now;
             }
@@ -279,7 +280,7 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_mfma_kernel(const HpmnGruFused
                 *hsp = hlast;
                 gp[0] = rc.x;
                 gp[H] = UPROD ? u_prev : rc.y;
-                gp[2 * H] = rc.z;
+                if (keep_c) gp[2 * H] = rc.z;
             }
             *yp = hlast;                                  // T is a multiple of period: the last output row (or h_last)
             a.h_last[b * a.h_last_stride + l] = hlast;

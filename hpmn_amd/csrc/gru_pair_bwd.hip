@@ -141,6 +141,9 @@ __device__ __forceinline__ void pair_bwd_feeder(const HpmnGruBwd &a, BwdLds<NS> 
     int pf_next = 0, pf_cnt = 0;
     int dy_seen = 0;
 
+    // (HPMN_BWD_CANDIDATE_FROM_HS: c[] holds the state after the step instead of the candidate, see gru_scan_bwd_feed.hip)
+    const bool c_from_hs = (a.flags & HPMN_BWD_CANDIDATE_FROM_HS) != 0;                // (wave-uniform)
+    float h_after = c_from_hs ? hsb[(long)T * H] : 0.f;
     struct Raw { float r[2], u[2], c[2], hp[2], dy[2]; bool m[2]; };
     auto load_chunk = [&](int q, Raw &w) {
 #pragma unroll
@@ -151,8 +154,10 @@ __device__ __forceinline__ void pair_bwd_feeder(const HpmnGruBwd &a, BwdLds<NS> 
             const float *g = gb + (long)t * 3 * H;
             w.r[j] = g[0];
             w.u[j] = g[H];
-            w.c[j] = g[2 * H];
             w.hp[j] = hsb[(long)t * H];
+            const float cv = *(c_from_hs ? hsb + (long)t * H : g + 2 * H);     // (no branch around a load)
+            w.c[j] = c_from_hs ? h_after : cv;
+            h_after = w.hp[j];
             const bool fire = has_dy && m == pf_next && m < T;
             if constexpr (DY_LDS) {
                 // (no branch around the wait: need = -1 never waits; the cached count answers 15 times out of 16)
@@ -177,10 +182,11 @@ __device__ __forceinline__ void pair_bwd_feeder(const HpmnGruBwd &a, BwdLds<NS> 
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int slot = (2 * q + j) & (RFS - 1);
-            const float r = w.r[j], u = w.u[j], c = w.c[j], hp = w.hp[j];
+            const float r = w.r[j], u = w.u[j], hp = w.hp[j];
             const float omu = 1.f - u;
-            const float k1 = omu * (1.f - c * c);
-            const float k2 = (hp - c) * u * omu;
+            float k1, k2;
+            if (c_from_hs) gru_coeff_from_states(w.c[j], hp, u, omu, k1, k2);
+            else { const float c = w.c[j]; k1 = omu * (1.f - c * c); k2 = (hp - c) * u * omu; }
             const float k3 = hp * r * (1.f - r);
             S.ringA[slot][l] = v4f{w.m[j] ? w.dy[j] : 0.f, k1, k2, k3};
             S.ringB[slot][l] = f2{r, u};

@@ -258,6 +258,7 @@ __device__ __forceinline__ void pair_producer_wave(const HpmnGruFusedFwd &a, Seq
     float *gp = TRAIN ? a.gates + (b * (long)T) * 3 * H + l : nullptr;
     int h_seen = 0;
     int yrow = 0, taken_seen = 0;
+    const bool keep_c = !(a.flags & HPMN_FWD_NO_CANDIDATE);                // (wave-uniform)
 
     // iteration t: the saved rows of step t-1 (h_{t-1} from the chain wave's state buffer, r,u,c from the hand-off), the
     // row that fires; TILE >= 0: one 16-column tile of the NEXT block's projection is issued right behind the wait
@@ -288,7 +289,7 @@ __device__ __forceinline__ void pair_producer_wave(const HpmnGruFusedFwd &a, Seq
             hsp += H;
             gp[0] = rc.x;
             gp[H] = rc.y;
-            gp[2 * H] = rc.z;
+            if (keep_c) gp[2 * H] = rc.z;               // (HPMN_FWD_NO_CANDIDATE, as in gru_fused_fwd3.hip)
             gp += t > 0 ? 3 * H : 0;
         }
         *yp = hprev;
@@ -401,7 +402,7 @@ __device__ __forceinline__ void pair_producer_wave(const HpmnGruFusedFwd &a, Seq
             *hsp = hlast;
             gp[0] = rc.x;
             gp[H] = rc.y;
-            gp[2 * H] = rc.z;
+            if (keep_c) gp[2 * H] = rc.z;
         }
         *yp = hlast;                                  // T is a multiple of period: the last output row (or h_last)
         a.h_last[b * a.h_last_stride + l] = hlast;

@@ -438,6 +438,13 @@ bool gru_scan_bwd_fuses_dx(int H, int B) {
     if (dxw >= 0) return H == 64 && B <= 640 && bwd_helper_enabled() && dxw;
     return H == 64 && B <= 640 && bwd_helper_enabled() >= 2;
 }
+// HPMN_FWD_NO_CANDIDATE / HPMN_BWD_CANDIDATE_FROM_HS (include/hpmn_hip.h): the chain + feeder reverse kernels (single layer
+// and pair) recover the candidate's coefficients from the saved states; the forward kernels that honour the flag are the
+// current fused ones (gru_fused_fwd3.hip, gru_pair_fwd.hip).  HPMN_CANDIDATE_ELISION=0: off.
+bool gru_candidate_elision(int H, int B) {
+    static const int on = [] { const char *e = getenv("HPMN_CANDIDATE_ELISION"); return e ? atoi(e) : 1; }();
+    return on && H == 64 && B <= 640 && bwd_helper_enabled() >= 2;
+}
 bool gru_scan_bwd_dx_width_ok(int D) { return bwd_helper_enabled() >= 2 ? gru_scan_bwd_feed_dx_width(D) : D <= 64; }
 
 bool gru_scan_bwd_feed_scatter_ok(int D, int F, int E);      // gru_scan_bwd_feed.hip
@@ -455,6 +462,7 @@ bool gru_scan_bwd_fuses_scatter(int H, int B, int D, int F, int E) {
 int gru_scan_bwd128_dispatch(const HpmnGruBwd &a, hipStream_t st);   // gru_scan128.hip
 
 int gru_scan_bwd_dispatch(const HpmnGruBwd &a, hipStream_t st) {
+    if ((a.flags & HPMN_BWD_CANDIDATE_FROM_HS) && !gru_candidate_elision(a.H, a.B)) return HPMN_EUNSUPPORTED;
     if (a.H == 128) return gru_scan_bwd128_dispatch(a, st);
     if (a.H == 32) {
         hipLaunchKernelGGL((gru_scan_bwd_kernel<32>), dim3((a.B + 1) / 2), dim3(64), 0, st, a);

@@ -99,6 +99,11 @@ __global__ __launch_bounds__(256, 1) void gru_scan_bwd_feed_kernel(const HpmnGru
         // d_y row j belongs to step (j+1)*period - 1 (t_hi is a multiple of period, so step t_hi-1 has one)
         int pf_fire = t_hi - 1, pf_row = t_hi / period - 1;
 
+        // c[]: the stored candidate, or (HPMN_BWD_CANDIDATE_FROM_HS: the forward did not store it) the state AFTER the step,
+        // h_t = hs[t + 1] -- the h_prev of the iteration before, kept in a register; the candidate's two 128-byte lines of
+        // every gates row are never fetched
+        const bool c_from_hs = (a.flags & HPMN_BWD_CANDIDATE_FROM_HS) != 0;            // (wave-uniform)
+        float h_after = c_from_hs ? hsb[(long)t_hi * H] : 0.f;
         struct Raw { float r[2], u[2], c[2], hp[2], dy[2]; bool m[2]; };
         // chunk q = iterations 2q, 2q+1 = steps t_hi-1-2q, t_hi-2-2q; rows before the sequence start are clamped
         // (loaded, parked, never consumed)
@@ -110,8 +115,12 @@ __global__ __launch_bounds__(256, 1) void gru_scan_bwd_feed_kernel(const HpmnGru
                 const float *g = gb + (long)t * 3 * H;
                 w.r[j] = g[0];
                 w.u[j] = g[H];
-                w.c[j] = g[2 * H];
                 w.hp[j] = hsb[(long)t * H];
+                // (no branch around a load -- it would be waited for at the join: with c_from_hs the candidate's load
+                //  re-reads h_prev's address instead, a hit in the line that load just fetched)
+                const float cv = *(c_from_hs ? hsb + (long)t * H : g + 2 * H);
+                w.c[j] = c_from_hs ? h_after : cv;
+                h_after = w.hp[j];
                 const bool fire = has_dy && t_raw == pf_fire && pf_row >= 0;
                 w.dy[j] = dyb[(long)(pf_row > 0 ? pf_row : 0) * dy_stride];
                 w.m[j] = fire;
@@ -123,10 +132,11 @@ __global__ __launch_bounds__(256, 1) void gru_scan_bwd_feed_kernel(const HpmnGru
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int slot = (2 * q + j) & (FR_STEPS - 1);
-                const float r = w.r[j], u = w.u[j], c = w.c[j], hp = w.hp[j];
+                const float r = w.r[j], u = w.u[j], hp = w.hp[j];
                 const float omu = 1.f - u;
-                const float k1 = omu * (1.f - c * c);
-                const float k2 = (hp - c) * u * omu;
+                float k1, k2;
+                if (c_from_hs) gru_coeff_from_states(w.c[j], hp, u, omu, k1, k2);
+                else { const float c = w.c[j]; k1 = omu * (1.f - c * c); k2 = (hp - c) * u * omu; }
                 const float k3 = hp * r * (1.f - r);
                 ringA[slot][l] = v4f{w.m[j] ? w.dy[j] : 0.f, k1, k2, k3};
                 ringB[slot][l] = f2{r, u};

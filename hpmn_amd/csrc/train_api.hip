@@ -21,6 +21,7 @@ bool gru_pair_bwd_supported(int H, int D_lo);
 namespace hpmn {
 size_t gru_wgrad_workspace_bytes(int B, int T, int D, int H);
 bool gru_scan_bwd_fuses_dx(int H, int B);
+bool gru_candidate_elision(int H, int B);
 bool gru_scan_bwd_dx_width_ok(int D);
 bool gru_scan_bwd_fuses_scatter(int H, int B, int D, int F, int E);
 int embed_grad_scatter_launch(const void *ids, const float *d_x, float *d_emb, int32_t B, int32_t T,
@@ -42,6 +43,16 @@ struct TrainCtx {
 int embed_grad_segsum_launch(const HpmnScatterPlan &p, const float *d_x, float *d_emb, int32_t B, int32_t T, int32_t F,
                              int32_t E, int32_t front_zero, int32_t id_flags, const float *d_last, int32_t t_last,
                              hipStream_t st);
+
+// Does layer i's saved `gates` tensor go WITHOUT the candidate (include/hpmn_hip.h, ABI v11)?  hpmn_scan_fwd_train and
+// hpmn_scan_bwd both decide with this: the layer's forward runs on a fused kernel that honours HPMN_FWD_NO_CANDIDATE (single
+// layer or pair) and its reverse scan on a chain + feeder kernel that honours HPMN_BWD_CANDIDATE_FROM_HS.
+static bool drops_candidate(const TrainCtx *c, const HpmnScanDesc *d, int i) {
+    const int D = i == 0 ? d->F * d->E : d->H;
+    const bool room = 2.0 * d->B <= 1.1 * 4 * c->cus;
+    const bool fused = room && gru_fused_fwd_supported(d->H, D, i == 0) && (i > 0 || 64 % d->E == 0);
+    return fused && gru_fused_fwd_writes_last() && gru_candidate_elision(d->H, d->B);
+}
 
 // The whole-range scatter of a step: through the context's plan (deterministic segmented reduction) when one is set.
 static int scatter_all(TrainCtx *c, const HpmnScanDesc *d, const void *ids, const float *d_x0, float *d_emb,
@@ -236,6 +247,7 @@ int hpmn_scan_fwd_train(HpmnTrainCtx *ctx, const HpmnScanDesc *d, const void *id
         a.h_last = memory + (size_t)i * d->H; a.h_last_stride = (int64_t)d->K * d->H;
         a.y = i + 1 < d->K ? F(L.y[i]) : nullptr;
         a.period = d->periods[i]; a.hs = F(L.hs[i]); a.gates = F(L.gates[i]);
+        a.flags = drops_candidate(c, d, i) ? HPMN_FWD_NO_CANDIDATE : 0;
         return a;
     };
     for (int i = 0; i < d->K; ++i) {
@@ -387,6 +399,7 @@ int hpmn_scan_bwd(HpmnTrainCtx *ctx, const HpmnScanDesc *d, const void *ids, con
         a.d_y = i + 1 < d->K ? F(L.d_x[i + 1]) : nullptr;
         a.period = d->periods[i];
         a.d_act = F(L.d_act[i]);
+        a.flags = drops_candidate(c, d, i) ? HPMN_BWD_CANDIDATE_FROM_HS : 0;
         return a;
     };
     auto wgrad_args = [&](int i) {

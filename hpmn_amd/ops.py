@@ -153,9 +153,10 @@ def fused_fwd_supported(H: int, D: int, gather: bool) -> bool:
 
 
 def gru_fused_fwd(*, x=None, ids=None, emb=None, wg, bg, wc, bc, H, T, front_zero=0, mask_id0=False, h_last, period,
-                  out):
+                  out, no_candidate=False):
     """hpmn_gru_fused_fwd: input projection + recurrence of one layer in one launch (two specialised waves per
-    sequence).  ``out`` = (y, hs, gates, x_out), any of them None."""
+    sequence).  ``out`` = (y, hs, gates, x_out), any of them None.  ``no_candidate``: HPMN_FWD_NO_CANDIDATE (the candidate
+    third of ``gates`` stays unwritten; the reverse scan then needs ``candidate_from_hs``)."""
     a = _lib.HpmnGruFusedFwd()
     _chk_f32(wg, bg, wc, bc)
     if x is not None:
@@ -178,12 +179,14 @@ def gru_fused_fwd(*, x=None, ids=None, emb=None, wg, bg, wc, bc, H, T, front_zer
     a.period = period
     y, hs, gates, x_out = out
     a.y, a.hs, a.gates, a.x_out = _ptr(y), _ptr(hs), _ptr(gates), _ptr(x_out)
+    a.flags = _lib.HPMN_FWD_NO_CANDIDATE if no_candidate else 0
     rc = _lib.load().hpmn_gru_fused_fwd(C.byref(a), _stream())
     _lib.check(rc, "hpmn_gru_fused_fwd")
 
 
-def _fill_fused(a, *, x, ids, emb, wg, bg, wc, bc, H, T, front_zero, mask_id0, h_last, period, out):
+def _fill_fused(a, *, x, ids, emb, wg, bg, wc, bc, H, T, front_zero, mask_id0, h_last, period, out, no_candidate=False):
     _chk_f32(wg, bg, wc, bc)
+    a.flags = _lib.HPMN_FWD_NO_CANDIDATE if no_candidate else 0
     if x is not None:
         _chk_f32(x)
         B, Tx, D = x.shape
@@ -218,9 +221,10 @@ def gru_pair_fwd(lo: dict, up: dict, flags: int = 0):
     p = _lib.HpmnGruPairFwd()
     _fill_fused(p.lo, x=lo.get("x"), ids=lo.get("ids"), emb=lo.get("emb"), wg=lo["wg"], bg=lo["bg"], wc=lo["wc"],
                 bc=lo["bc"], H=lo["H"], T=lo["T"], front_zero=lo.get("front_zero", 0), mask_id0=lo.get("mask_id0", False),
-                h_last=lo["h_last"], period=lo["period"], out=lo["out"])
+                h_last=lo["h_last"], period=lo["period"], out=lo["out"], no_candidate=lo.get("no_candidate", False))
     _fill_fused(p.up, x=None, ids=None, emb=None, wg=up["wg"], bg=up["bg"], wc=up["wc"], bc=up["bc"], H=up["H"],
-                T=up["T"], front_zero=0, mask_id0=False, h_last=up["h_last"], period=up["period"], out=up["out"])
+                T=up["T"], front_zero=0, mask_id0=False, h_last=up["h_last"], period=up["period"], out=up["out"],
+                no_candidate=up.get("no_candidate", False))
     dev = lo["wg"].device
     sc = _pair_scratch.get(str(dev))
     if sc is None:
@@ -268,7 +272,13 @@ def scan_bwd_fuses_dx(H: int, B: int) -> bool:
     return bool(_lib.load().hpmn_gru_scan_bwd_fuses_dx(H, B))
 
 
-def gru_scan_bwd(wg, wc, D, hs, gates, d_h_last, d_y, period, out=None, t_range=None, dh_carry=None, d_x=None):
+def candidate_elision(H: int, B: int) -> bool:
+    """hpmn_gru_candidate_elision: saved gates without the candidate are supported by both directions (ABI v11)."""
+    return bool(_lib.load().hpmn_gru_candidate_elision(H, B))
+
+
+def gru_scan_bwd(wg, wc, D, hs, gates, d_h_last, d_y, period, out=None, t_range=None, dh_carry=None, d_x=None,
+                 candidate_from_hs=False):
     """hpmn_gru_scan_bwd -> d_act [B,T,3H].  ``out`` = preallocated d_act; ``t_range`` = (t_begin, t_end)
     runs one time chunk (reverse) with the boundary gradient handed over through ``dh_carry`` [B,H]."""
     B, T1, H = hs.shape
@@ -289,13 +299,15 @@ def gru_scan_bwd(wg, wc, D, hs, gates, d_h_last, d_y, period, out=None, t_range=
         a.dh_carry = dh_carry.data_ptr()
     if d_x is not None:             # the input gradient from the scan launch itself (scan_bwd_fuses_dx)
         a.d_x = d_x.data_ptr()
+    a.flags = _lib.HPMN_BWD_CANDIDATE_FROM_HS if candidate_from_hs else 0
     rc = _lib.load().hpmn_gru_scan_bwd(C.byref(a), _stream())
     _lib.check(rc, "hpmn_gru_scan_bwd")
     return d_act
 
 
-def _fill_bwd(a, *, wg, wc, D, hs, gates, d_h_last, d_y, period, d_act, d_x=None):
+def _fill_bwd(a, *, wg, wc, D, hs, gates, d_h_last, d_y, period, d_act, d_x=None, candidate_from_hs=False):
     B, T1, H = hs.shape
+    a.flags = _lib.HPMN_BWD_CANDIDATE_FROM_HS if candidate_from_hs else 0
     _chk_f32(wg, wc, hs, gates, d_y, d_act)
     a.B, a.T, a.D, a.H = B, T1 - 1, D, H
     a.wg, a.wc, a.hs, a.gates = wg.data_ptr(), wc.data_ptr(), hs.data_ptr(), gates.data_ptr()

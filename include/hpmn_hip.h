@@ -34,10 +34,20 @@
 extern "C" {
 #endif
 
-#define HPMN_ABI_VERSION 10
+#define HPMN_ABI_VERSION 11
 #define HPMN_ID_MASK0 1   /* id-flags bit 0: id 0 gathers a zero row and receives no gradient (the Hpmn class)  */
 #define HPMN_ID_I64 2     /* id-flags bit 1: the ids tensor is int64 (default: int32)                          */
 #define HPMN_MAX_LAYERS 12
+/* Saved gates without the candidate (ABI v11): the forward leaves the candidate third of every gates row unwritten
+ * (HpmnGruFusedFwd.flags), the reverse scan recovers what it needs of it from the saved states it reads anyway
+ * (HpmnGruBwd.flags): h_t = u h_{t-1} + (1 - u) c gives q = (1 - u) c = h_t - u h_{t-1}, and the candidate only ever enters
+ * BPTT through q: (1 - u)(1 - c^2) = (1 - u) - q c, (h_{t-1} - c) u (1 - u) = u ((1 - u) h_{t-1} - q); c = q / (1 - u) for
+ * the one remaining factor (taken as 0 where u rounds to 1: both coefficients vanish there).  A third of the saved-gates
+ * traffic (two 128-byte lines per step at H = 64, written by the forward and read by the reverse scan) disappears; the
+ * coefficients differ from the stored-candidate ones by <= ~2.4e-7 ABSOLUTE (they are O(1); measured in
+ * tests/test_gpu_parity.py).  hpmn_gru_candidate_elision(H, B) != 0 where both sides support it. */
+#define HPMN_FWD_NO_CANDIDATE 1      /* HpmnGruFusedFwd.flags bit 0: gates[..., 2H:3H] is NOT written            */
+#define HPMN_BWD_CANDIDATE_FROM_HS 1 /* HpmnGruBwd.flags bit 0: gates[..., 2H:3H] is NOT read (see above)        */
 
 enum {
     HPMN_OK = 0,
@@ -160,7 +170,8 @@ typedef struct HpmnGruFusedFwd {
     float *last;               /* optional [B,D]: a copy of the (gathered, masked) input row of step last_t -- the read
                                 * path's uinp[:, last_index, :] -- written by the launch itself.  Only where
                                 * hpmn_gru_fused_fwd_writes_last() != 0 (HPMN_EUNSUPPORTED otherwise); NULL: none */
-    int32_t last_t, pad_;
+    int32_t last_t;
+    int32_t flags;             /* HPMN_FWD_NO_CANDIDATE (ABI v11; this word was padding before: 0 = the old behaviour) */
 } HpmnGruFusedFwd;
 
 int hpmn_gru_fused_fwd_supported(int32_t H, int32_t D, int32_t gather);
@@ -243,10 +254,14 @@ typedef struct HpmnGruBwd {
     float *d_emb;                 /* [V, E] */
     const float *d_last;          /* [B, D] */
     int32_t Tids, F, E, front_zero, mask_id0, last_t;
+    int32_t flags, pad_;          /* HPMN_BWD_CANDIDATE_FROM_HS (ABI v11) */
 } HpmnGruBwd;
 
 int hpmn_gru_scan_bwd(const HpmnGruBwd *args, void *stream);
 int hpmn_gru_scan_bwd_fuses_dx(int32_t H, int32_t B);
+/* 1 where hpmn_gru_fused_fwd / hpmn_gru_pair_fwd honour HPMN_FWD_NO_CANDIDATE and hpmn_gru_scan_bwd / hpmn_gru_pair_bwd
+ * honour HPMN_BWD_CANDIDATE_FROM_HS for a batch of B sequences (elsewhere the flags give HPMN_EUNSUPPORTED) */
+int hpmn_gru_candidate_elision(int32_t H, int32_t B);
 /* 1 where HpmnGruBwd.d_emb (the scatter fused into the launch) is supported */
 int hpmn_gru_scan_bwd_fuses_scatter(int32_t H, int32_t B, int32_t D, int32_t F, int32_t E);
 

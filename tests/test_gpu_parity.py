@@ -1459,6 +1459,85 @@ def test_two_reverse_scans_in_one_launch_equal_two_launches(dev, name, B, T, D, 
             assert err <= 5e-6, "%s (flags %d): %g of the tensor's max" % (what, flags, err)
 
 
+@pytest.mark.parametrize("pair", [False, True])
+@pytest.mark.parametrize("B,T,D", [(5, 200, 32), (3, 46, 64), (130, 64, 32)])
+def test_saved_gates_without_the_candidate(dev, pair, B, T, D):
+    """ABI v11 (HPMN_FWD_NO_CANDIDATE / HPMN_BWD_CANDIDATE_FROM_HS, include/hpmn_hip.h): the forward leaves the candidate third of
+    `gates` UNWRITTEN (it stays NaN here) and everything else bit-identical; the reverse scan never reads it and recovers the
+    two coefficients the candidate enters from the saved states -- d_act and d_x within 2e-6 of each tensor's max of the
+    stored-candidate launch, with update gates saturated both ways (u == 1.0f exactly on some units: the candidate cannot be
+    recovered there and both coefficients are 0; u ~ 1e-8 on others) -- single-layer launches and the two-layer launches."""
+    from hpmn_amd import ops
+    H = 64
+    if not ops.candidate_elision(H, B):
+        pytest.skip("candidate elision is off in this build / environment")
+    g = torch.Generator(device="cpu").manual_seed(B * 1000 + T)
+    p_lo, p_up = 2, 1
+    Tu = T // p_lo
+
+    def w(*shape, scale=0.3):
+        return (torch.randn(*shape, generator=g) * scale).to(dev)
+
+    def weights(Dl):
+        bg = w(2 * H) + 1
+        bg[H + 3] = 30.0; bg[H + 17] = 19.0; bg[H + 40] = -18.0; bg[H + 41] = 12.0      # saturated / nearly saturated update gates
+        return dict(wg=w(Dl + H, 2 * H), bg=bg, wc=w(Dl + H, H), bc=w(H))
+    wl, wu = weights(D), weights(H)
+    if D == 32:                                       # (the two-layer launch takes a 32-wide lower layer in gather form only)
+        inp = dict(ids=torch.randint(0, 500, (B, T, 2), generator=g, dtype=torch.int32).to(dev), emb=w(500, 16, scale=1.0))
+    else:
+        inp = dict(x=w(B, T, D, scale=1.0))
+
+    def forward(no_c):
+        mem = torch.zeros(B, 2, H, device=dev)
+        def bufs(Tl, p):
+            ga = torch.full((B, Tl, 3 * H), float("nan"), device=dev)
+            return [torch.zeros(B, Tl // p, H, device=dev), torch.zeros(B, Tl + 1, H, device=dev), ga, None]
+        lo, up = bufs(T, p_lo), bufs(Tu, p_up)
+        if pair:
+            ops.gru_pair_fwd(dict(**inp, **wl, H=H, T=T, h_last=mem[:, 0], period=p_lo, out=tuple(lo), no_candidate=no_c),
+                             dict(**wu, H=H, T=Tu, h_last=mem[:, 1], period=p_up, out=tuple(up), no_candidate=no_c))
+        else:
+            ops.gru_fused_fwd(**inp, **wl, H=H, T=T, h_last=mem[:, 0], period=p_lo, out=tuple(lo), no_candidate=no_c)
+            ops.gru_fused_fwd(x=lo[0], **wu, H=H, T=Tu, h_last=mem[:, 1], period=p_up, out=tuple(up), no_candidate=no_c)
+        return mem, lo, up
+    mem_a, lo_a, up_a = forward(False)
+    mem_b, lo_b, up_b = forward(True)
+    assert torch.equal(mem_a, mem_b)
+    for a, b in ((lo_a, lo_b), (up_a, up_b)):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])                       # y, hs
+        assert torch.equal(a[2][..., :2 * H], b[2][..., :2 * H])                        # r, u
+        assert not torch.isnan(a[2]).any() and torch.isnan(b[2][..., 2 * H:]).all()     # the candidate: written / untouched
+    u_lo = lo_a[2][..., H:2 * H]
+    assert float((u_lo == 1.0).float().mean()) > 0.01 and float((u_lo < 1e-6).float().mean()) > 0.005   # both saturations occur
+
+    d_mem = w(B, 2, H, scale=0.1)
+
+    def backward(lo, up, from_hs):
+        a_up = torch.full((B, Tu, 3 * H), 7.0, device=dev)
+        a_lo = torch.full((B, T, 3 * H), 7.0, device=dev)
+        x_lo = torch.full((B, T, D), 7.0, device=dev)
+        kl = dict(wg=wl["wg"], wc=wl["wc"], D=D, hs=lo[1], gates=lo[2])
+        ku = dict(wg=wu["wg"], wc=wu["wc"], D=H, hs=up[1], gates=up[2])
+        if pair:
+            ops.gru_pair_bwd(dict(**kl, d_h_last=d_mem[:, 0], period=p_lo, d_act=a_lo, d_x=x_lo, candidate_from_hs=from_hs),
+                             dict(**ku, d_h_last=d_mem[:, 1], period=p_up, d_act=a_up, d_y=None, candidate_from_hs=from_hs))
+        else:
+            x_up = torch.full((B, Tu, H), 7.0, device=dev)
+            ops.gru_scan_bwd(ku["wg"], ku["wc"], H, ku["hs"], ku["gates"], d_mem[:, 1], None, p_up, out=a_up, d_x=x_up,
+                             candidate_from_hs=from_hs)
+            ops.gru_scan_bwd(kl["wg"], kl["wc"], D, kl["hs"], kl["gates"], d_mem[:, 0], x_up, p_lo, out=a_lo, d_x=x_lo,
+                             candidate_from_hs=from_hs)
+        torch.cuda.synchronize()
+        return a_up, a_lo, x_lo
+    want = backward(lo_a, up_a, False)
+    got = backward(lo_b, up_b, True)                  # (gates with a NaN candidate third: reading it would poison everything)
+    for what, gt, wt in zip(("upper d_act", "lower d_act", "lower d_x"), got, want):
+        assert torch.isfinite(gt).all(), what
+        err = float((gt - wt).abs().max()) / float(wt.abs().max())
+        assert err <= 2e-6, "%s: %g of the tensor's max" % (what, err)
+
+
 @pytest.mark.parametrize("mask", [True, False])
 @pytest.mark.parametrize("F", [1, 2, 3, 4])
 def test_gather_consumed_in_place_equals_the_gathered_rows_summed(dev, mask, F):
