@@ -118,7 +118,7 @@ __device__ __forceinline__ void pair_bwd_chain(const HpmnGruBwd &a, BwdLds<NS> &
 // ------------------------------------------------------------------------------------------------ feeder wave (either layer)
 // DY_LDS: the d_y rows of the firing steps come from the upper layer's ring `yi` (the lower layer of the pair), else from
 // a.d_y / a.d_h_last in memory.  DXOUT: this is the upper layer -- it also produces its input gradient into `yo`.
-template <int NS, bool DY_LDS, bool DXOUT, bool SLEEPY>
+template <int NS, bool DY_LDS, bool DXOUT, bool SLEEPY, bool CFH>
 __device__ __forceinline__ void pair_bwd_feeder(const HpmnGruBwd &a, BwdLds<NS> &S, DyLds *yi, DyLds *yo, const long b,
                                                 const int lane) {
     constexpr int H = RH;
@@ -142,7 +142,7 @@ __device__ __forceinline__ void pair_bwd_feeder(const HpmnGruBwd &a, BwdLds<NS> 
     int dy_seen = 0;
 
     // (HPMN_BWD_CANDIDATE_FROM_HS: c[] holds the state after the step instead of the candidate, see gru_scan_bwd_feed.hip)
-    const bool c_from_hs = (a.flags & HPMN_BWD_CANDIDATE_FROM_HS) != 0;                // (wave-uniform)
+    constexpr bool c_from_hs = CFH;                    // (a template switch: see gru_scan_bwd_feed.hip)
     float h_after = c_from_hs ? hsb[(long)T * H] : 0.f;
     struct Raw { float r[2], u[2], c[2], hp[2], dy[2]; bool m[2]; };
     auto load_chunk = [&](int q, Raw &w) {
@@ -155,9 +155,7 @@ __device__ __forceinline__ void pair_bwd_feeder(const HpmnGruBwd &a, BwdLds<NS> 
             w.r[j] = g[0];
             w.u[j] = g[H];
             w.hp[j] = hsb[(long)t * H];
-            const float cv = *(c_from_hs ? hsb + (long)t * H : g + 2 * H);     // (no branch around a load)
-            w.c[j] = c_from_hs ? h_after : cv;
-            h_after = w.hp[j];
+            w.c[j] = c_from_hs ? 0.f : g[2 * H];
             const bool fire = has_dy && m == pf_next && m < T;
             if constexpr (DY_LDS) {
                 // (no branch around the wait: need = -1 never waits; the cached count answers 15 times out of 16)
@@ -185,8 +183,9 @@ __device__ __forceinline__ void pair_bwd_feeder(const HpmnGruBwd &a, BwdLds<NS> 
             const float r = w.r[j], u = w.u[j], hp = w.hp[j];
             const float omu = 1.f - u;
             float k1, k2;
-            if (c_from_hs) gru_coeff_from_states(w.c[j], hp, u, omu, k1, k2);
+            if (c_from_hs) gru_coeff_from_states(h_after, hp, u, omu, k1, k2);
             else { const float c = w.c[j]; k1 = omu * (1.f - c * c); k2 = (hp - c) * u * omu; }
+            h_after = hp;
             const float k3 = hp * r * (1.f - r);
             S.ringA[slot][l] = v4f{w.m[j] ? w.dy[j] : 0.f, k1, k2, k3};
             S.ringB[slot][l] = f2{r, u};
@@ -392,7 +391,7 @@ struct PairBwdArgs {
     int32_t flags, pad;
 };
 
-template <int DXD>
+template <int DXD, bool CFH>
 __global__ __launch_bounds__(512, 2) void gru_pair_bwd_kernel(const PairBwdArgs p) {
     __shared__ __attribute__((aligned(16))) BwdLds<2> lo_[2];
     __shared__ __attribute__((aligned(16))) BwdLds<RDR> up_[2];
@@ -419,13 +418,13 @@ __global__ __launch_bounds__(512, 2) void gru_pair_bwd_kernel(const PairBwdArgs 
         pair_bwd_chain<2, false>(p.lo, SL, b, lane);
     } else if (role == 1) {
         __builtin_amdgcn_s_setprio(2);
-        pair_bwd_feeder<2, true, false, false>(p.lo, SL, &Y, nullptr, b, lane);
+        pair_bwd_feeder<2, true, false, false, CFH>(p.lo, SL, &Y, nullptr, b, lane);
     } else if (role == 2) {
         __builtin_amdgcn_s_setprio(1);
         pair_bwd_chain<RDR, true>(p.up, SU, b, lane);
     } else {
         __builtin_amdgcn_s_setprio(0);
-        pair_bwd_feeder<RDR, false, true, true>(p.up, SU, nullptr, &Y, b, lane);
+        pair_bwd_feeder<RDR, false, true, true, CFH>(p.up, SU, nullptr, &Y, b, lane);
     }
 
     if constexpr (DXD > 0) {
@@ -444,10 +443,21 @@ int gru_pair_bwd_launch(const HpmnGruBwd &lo, const HpmnGruBwd &up, int flags, h
     PairBwdArgs p = {};
     p.lo = lo; p.up = up; p.flags = flags;
     const dim3 grid((lo.B + 1) / 2), blk(512);
-    if (lo.d_x == nullptr) hipLaunchKernelGGL(gru_pair_bwd_kernel<0>, grid, blk, 0, st, p);
-    else if (lo.D == 16) hipLaunchKernelGGL(gru_pair_bwd_kernel<16>, grid, blk, 0, st, p);
-    else if (lo.D == 32) hipLaunchKernelGGL(gru_pair_bwd_kernel<32>, grid, blk, 0, st, p);
-    else if (lo.D == 64) hipLaunchKernelGGL(gru_pair_bwd_kernel<64>, grid, blk, 0, st, p);
+    // (the candidate switch is a template argument of the whole launch: both layers the same way)
+    const bool cfh = (lo.flags & HPMN_BWD_CANDIDATE_FROM_HS) != 0;
+    if (cfh != ((up.flags & HPMN_BWD_CANDIDATE_FROM_HS) != 0)) return HPMN_EUNSUPPORTED;
+    if (cfh) {
+        if (lo.d_x == nullptr) hipLaunchKernelGGL((gru_pair_bwd_kernel<0, true>), grid, blk, 0, st, p);
+        else if (lo.D == 16) hipLaunchKernelGGL((gru_pair_bwd_kernel<16, true>), grid, blk, 0, st, p);
+        else if (lo.D == 32) hipLaunchKernelGGL((gru_pair_bwd_kernel<32, true>), grid, blk, 0, st, p);
+        else if (lo.D == 64) hipLaunchKernelGGL((gru_pair_bwd_kernel<64, true>), grid, blk, 0, st, p);
+        else return HPMN_EUNSUPPORTED;
+        return check_launch();
+    }
+    if (lo.d_x == nullptr) hipLaunchKernelGGL((gru_pair_bwd_kernel<0, false>), grid, blk, 0, st, p);
+    else if (lo.D == 16) hipLaunchKernelGGL((gru_pair_bwd_kernel<16, false>), grid, blk, 0, st, p);
+    else if (lo.D == 32) hipLaunchKernelGGL((gru_pair_bwd_kernel<32, false>), grid, blk, 0, st, p);
+    else if (lo.D == 64) hipLaunchKernelGGL((gru_pair_bwd_kernel<64, false>), grid, blk, 0, st, p);
     else return HPMN_EUNSUPPORTED;
     return check_launch();
 }

@@ -35,6 +35,7 @@
 // step k-1's operands at the start of its step k, before it publishes e_u(k), and the chain wave cannot reach step
 // k+1 (which overwrites them) without e_u(k).
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 
@@ -46,17 +47,39 @@ constexpr int DROW = 192;       // floats per operand row [da_r | da_u | dc_pre]
 constexpr int DXB = 16;         // steps per input-gradient block (= MFMA N)
 
 typedef float f4m __attribute__((ext_vector_type(4)));
+typedef float xf4 __attribute__((ext_vector_type(4)));
+typedef __bf16 xbf8 __attribute__((ext_vector_type(8)));
+
+// x = hi + lo in bf16 (|x - hi - lo| <= 2^-17 |x|), eight values at once
+__device__ __forceinline__ void split_bf16x8(const v4f a, const v4f b, xbf8 &hi, xbf8 &lo) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float x = i < 4 ? a[i] : b[i - 4];
+        hi[i] = (__bf16)x;
+        lo[i] = (__bf16)(x - (float)hi[i]);
+    }
+}
 
 // TWO sequences per workgroup: the hardware places the waves of a workgroup on consecutive SIMDs of its rotation,
 // but starts the next workgroup of the CU on the SIMD the previous one ended on (tools/micro/where.hip: with 2-wave
 // workgroups every CU had the chain wave of one sequence and the feeder of the other on ONE SIMD and a SIMD idle;
 // 4-wave workgroups land on four distinct SIMDs, the 5th and 6th wave of a 6-wave workgroup on the SIMDs of the 1st
 // and 2nd).  Waves 0,1: chain waves of sequences 2 blockIdx.x + 0,1; waves 2,3: their feeders.
-template <int DXD, bool SCAT = false>
+// LOOPDX (D <= 32): the input gradient is formed INSIDE the loop, by the feeder, on the bf16 matrix pipe with split operands
+// (x = hi + lo, three products, fp32 accumulate -- gru_wgrad_bf16.hip's arithmetic): the chain wave keeps its operand rows in
+// a 32-row LDS ring instead of two parity slots, and while it fills one half (16 iterations) the feeder multiplies the
+// other half by [Wg[:D] | Wc[:D]]^T, one (column tile, 32-wide k slice) unit per iteration BEHIND the iteration's e_u hand-off:
+// two 16-byte LDS reads, the split (24 VALU), three v_mfma_f32_16x16x32_bf16 -- 48 cycles of matrix pipe per iteration where
+// the fp32 form of round 2 held it for 384 (which is what sank the concurrent input gradient then).  The weights' operand
+// fragments are stationary in the feeder's registers (96 at D = 32: the feeder had them to spare, the kernel's register
+// count is set by the chain wave + epilogue).  No d_act row is read back from memory (0.38 GB per step at C3's layer 0) and
+// the launch ends with the scan.
+template <int DXD, bool SCAT = false, bool LOOPDX = false, bool CFH = false>
 __global__ __launch_bounds__(256, 1) void gru_scan_bwd_feed_kernel(const HpmnGruBwd a) {
     constexpr int H = 64;
     constexpr bool DX = DXD > 0;
-    constexpr int NSLOT = 2;                                               // operand rows kept in LDS (step parity)
+    static_assert(!LOOPDX || (DXD > 0 && DXD <= 32 && !SCAT), "in-loop input gradient: D = 16 / 32, no fused scatter");
+    constexpr int NSLOT = LOOPDX ? 32 : 2;                                 // operand rows kept in LDS (step parity / ring)
     __shared__ __attribute__((aligned(16))) v4f ringA_[2][FR_STEPS][H];    // dy, k1, k2, k3
     __shared__ __attribute__((aligned(16))) f2 ringB_[2][FR_STEPS][H];     // r, u
     __shared__ __attribute__((aligned(16))) float dact_[2][NSLOT][DROW];   // da_r | da_u | dc_pre of iteration k in row k % NSLOT
@@ -102,7 +125,9 @@ __global__ __launch_bounds__(256, 1) void gru_scan_bwd_feed_kernel(const HpmnGru
         // c[]: the stored candidate, or (HPMN_BWD_CANDIDATE_FROM_HS: the forward did not store it) the state AFTER the step,
         // h_t = hs[t + 1] -- the h_prev of the iteration before, kept in a register; the candidate's two 128-byte lines of
         // every gates row are never fetched
-        const bool c_from_hs = (a.flags & HPMN_BWD_CANDIDATE_FROM_HS) != 0;            // (wave-uniform)
+        // (CFH: a template switch -- as a run-time flag it cost the feeder a redundant load, a select and a branch per step,
+        //  +1.5 % on the whole C3 step with the flag off)
+        constexpr bool c_from_hs = CFH;
         float h_after = c_from_hs ? hsb[(long)t_hi * H] : 0.f;
         struct Raw { float r[2], u[2], c[2], hp[2], dy[2]; bool m[2]; };
         // chunk q = iterations 2q, 2q+1 = steps t_hi-1-2q, t_hi-2-2q; rows before the sequence start are clamped
@@ -116,11 +141,9 @@ __global__ __launch_bounds__(256, 1) void gru_scan_bwd_feed_kernel(const HpmnGru
                 w.r[j] = g[0];
                 w.u[j] = g[H];
                 w.hp[j] = hsb[(long)t * H];
-                // (no branch around a load -- it would be waited for at the join: with c_from_hs the candidate's load
-                //  re-reads h_prev's address instead, a hit in the line that load just fetched)
-                const float cv = *(c_from_hs ? hsb + (long)t * H : g + 2 * H);
-                w.c[j] = c_from_hs ? h_after : cv;
-                h_after = w.hp[j];
+                w.c[j] = c_from_hs ? 0.f : g[2 * H];
+                // (NOTHING is computed on a loaded value here -- not even the select between the candidate and the state
+                //  after the step: it would wait for the loads just issued.  park_chunk does it, chunks are parked in order)
                 const bool fire = has_dy && t_raw == pf_fire && pf_row >= 0;
                 w.dy[j] = dyb[(long)(pf_row > 0 ? pf_row : 0) * dy_stride];
                 w.m[j] = fire;
@@ -135,8 +158,9 @@ __global__ __launch_bounds__(256, 1) void gru_scan_bwd_feed_kernel(const HpmnGru
                 const float r = w.r[j], u = w.u[j], hp = w.hp[j];
                 const float omu = 1.f - u;
                 float k1, k2;
-                if (c_from_hs) gru_coeff_from_states(w.c[j], hp, u, omu, k1, k2);
+                if (c_from_hs) gru_coeff_from_states(h_after, hp, u, omu, k1, k2);
                 else { const float c = w.c[j]; k1 = omu * (1.f - c * c); k2 = (hp - c) * u * omu; }
+                h_after = hp;
                 const float k3 = hp * r * (1.f - r);
                 ringA[slot][l] = v4f{w.m[j] ? w.dy[j] : 0.f, k1, k2, k3};
                 ringB[slot][l] = f2{r, u};
@@ -155,14 +179,62 @@ __global__ __launch_bounds__(256, 1) void gru_scan_bwd_feed_kernel(const HpmnGru
         Raw w0, w1;                          // two chunks of loads in flight
         load_chunk(FR_AHEAD, w1);
 
+        // ---- LOOPDX: unit U = (column tile U / 6, k slice U % 6) of a 16-iteration block.  A operand (stationary): lane
+        //      (j, kg) = W[input column 16 ct + j][gate columns 32 ks + 8 kg .. + 7], W = [wg[0:D] | wc[0:D]]; B operand: lane
+        //      (n, kg) = d_act[iteration 16 kb + n][the same gate columns], out of the ring; C: lane (n, kg) holds input columns
+        //      16 ct + 4 kg .. + 3 of iteration n -- 16 contiguous bytes of the d_x row.
+        constexpr int NU = LOOPDX ? (DXD / 16) * 6 : 1;
+        const int j16 = lane & 15, kg = lane >> 4;
+        xbf8 wAh[NU], wAl[NU];
+        if constexpr (LOOPDX) {
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int ct = u / 6, ks = u % 6;
+                const long col = 16 * ct + j16;
+                const int gc = 32 * ks + 8 * kg;
+                const float *src = gc < 2 * H ? a.wg + col * 2 * H + gc : a.wc + col * H + (gc - 2 * H);
+                const v4f v0 = *reinterpret_cast<const v4f *>(src), v1 = *reinterpret_cast<const v4f *>(src + 4);
+                split_bf16x8(v0, v1, wAh[u], wAl[u]);
+            }
+        }
+        xf4 xacc = {0.f, 0.f, 0.f, 0.f};
+        float *dxb = LOOPDX ? a.d_x + (b * (long)T) * DXD + 4 * kg : nullptr;
+        auto dx_unit = [&](auto uc, int kb) {
+            constexpr int U = decltype(uc)::value;
+            if constexpr (LOOPDX && U >= 0 && U < NU) {
+                constexpr int ct = U / 6, ks = U % 6;
+                const int it_raw = DXB * kb + j16;
+                const int it = it_raw < nsteps ? it_raw : nsteps - 1;          // (clamped: computed, not stored)
+                const float *src = &dact[it & (NSLOT - 1)][32 * ks + 8 * kg];
+                const v4f b0 = *reinterpret_cast<const v4f *>(src), b1 = *reinterpret_cast<const v4f *>(src + 4);
+                xbf8 bh, bl;
+                split_bf16x8(b0, b1, bh, bl);
+                if constexpr (ks == 0) xacc = xf4{0.f, 0.f, 0.f, 0.f};
+                xacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wAh[U], bh, xacc, 0, 0, 0);
+                xacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wAh[U], bl, xacc, 0, 0, 0);
+                xacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wAl[U], bh, xacc, 0, 0, 0);
+                // (no branch in here -- the feeder's prefetch loads are in flight and a branch's join would wait for all of
+                //  them: a clamped lane holds the last row's result and stores it to the last row's place once more)
+                if constexpr (ks == 5) *reinterpret_cast<xf4 *>(dxb + (long)(t_hi - 1 - it) * DXD + 16 * ct) = xacc;
+            }
+        };
+        auto dx_block = [&](int kb) {            // a whole block at once (behind the unrolled loop, and the last blocks)
+            dx_unit(std::integral_constant<int, 0>{}, kb); dx_unit(std::integral_constant<int, 1>{}, kb);
+            dx_unit(std::integral_constant<int, 2>{}, kb); dx_unit(std::integral_constant<int, 3>{}, kb);
+            dx_unit(std::integral_constant<int, 4>{}, kb); dx_unit(std::integral_constant<int, 5>{}, kb);
+            dx_unit(std::integral_constant<int, 6>{}, kb); dx_unit(std::integral_constant<int, 7>{}, kb);
+            dx_unit(std::integral_constant<int, 8>{}, kb); dx_unit(std::integral_constant<int, 9>{}, kb);
+            dx_unit(std::integral_constant<int, 10>{}, kb); dx_unit(std::integral_constant<int, 11>{}, kb);
+        };
+
         float *dap = a.d_act + (b * (long)T + (t_hi - 1)) * 3 * H + l;     // row of iteration 0
         int seen = 0;
-        // one iteration: e_u(k); the d_act row of iteration k-1 goes out behind it
-        auto iter = [&](int k, int p, bool store_prev) {
+        // one iteration: e_u(k); the d_act row of iteration k-1 goes out behind it; then (LOOPDX) one unit of block kb
+        auto iter = [&](int k, int p, bool store_prev, auto uc, int kb) {
             while (seen <= k) seen = lds_counter_peek(&dau_pub);
             asm volatile("" ::: "memory");
-            const float *row = dact[p];
-            const float *old = dact[p ^ 1];
+            const float *row = dact[LOOPDX ? (k & (NSLOT - 1)) : p];
+            const float *old = dact[LOOPDX ? ((k - 1) & (NSLOT - 1)) : (p ^ 1)];
             const float euv = split_matvec<2>(row + H, wuS, lane);
             const float o_dar = old[l], o_dau = old[H + l], o_dcp = old[2 * H + l];
             eU[p][l] = euv;
@@ -173,34 +245,63 @@ __global__ __launch_bounds__(256, 1) void gru_scan_bwd_feed_kernel(const HpmnGru
                 dap[2 * H] = o_dcp;
                 dap -= 3 * H;
             }
+            dx_unit(uc, kb);                           // (the reads of block kb end 2 iterations before the chain wave can
+                                                       //  overwrite its rows, see the loop below)
         };
+        const std::integral_constant<int, -1> no_unit{};
 
         // iteration 0 has no previous row to store: peeled together with iteration 1
         int q = 0;
         if (nfull > 0) {
             load_chunk(FR_AHEAD + 1, w0);
-            iter(0, 0, false);
-            iter(1, 1, true);
+            iter(0, 0, false, no_unit, -1);
+            iter(1, 1, true, no_unit, -1);
             park_chunk(FR_AHEAD, w1);
             q = 1;
         }
-        for (; q + 1 < nfull; q += 2) {
-            load_chunk(q + FR_AHEAD + 1, w1);
-            iter(2 * q, 0, true);
-            iter(2 * q + 1, 1, true);
-            park_chunk(q + FR_AHEAD, w0);
-            load_chunk(q + FR_AHEAD + 2, w0);
-            iter(2 * q + 2, 0, true);
-            iter(2 * q + 3, 1, true);
-            park_chunk(q + FR_AHEAD + 1, w1);
+        // four iterations (two chunks); U0 >= 0: they carry units U0 .. U0 + 3 of block kb
+        auto group = [&](int qq, auto u0c, int kb) {
+            constexpr int U0 = decltype(u0c)::value;
+            constexpr int S = U0 >= 0 ? 1 : 0;
+            load_chunk(qq + FR_AHEAD + 1, w1);
+            iter(2 * qq, 0, true, std::integral_constant<int, U0>{}, kb);
+            iter(2 * qq + 1, 1, true, std::integral_constant<int, U0 + S>{}, kb);
+            park_chunk(qq + FR_AHEAD, w0);
+            load_chunk(qq + FR_AHEAD + 2, w0);
+            iter(2 * qq + 2, 0, true, std::integral_constant<int, U0 + 2 * S>{}, kb);
+            iter(2 * qq + 3, 1, true, std::integral_constant<int, U0 + 3 * S>{}, kb);
+            park_chunk(qq + FR_AHEAD + 1, w1);
+        };
+        if constexpr (LOOPDX) {
+            // 16 iterations k = 16 n + 2 .. 16 n + 17 per trip, unit p at iteration 16 n + 2 + p (p < NU <= 12): block
+            // kb = n - 1, whose rows were complete at iteration 16 n and stay in the ring until the chain wave starts iteration
+            // 16 (n + 1) -- which needs e_u(16 n + 15), published two iterations after the last unit's reads.
+            if (q + 7 < nfull) {                   // (the first trip: no block is complete yet)
+                group(q, std::integral_constant<int, -1>{}, -1);
+                group(q + 2, std::integral_constant<int, -1>{}, -1);
+                group(q + 4, std::integral_constant<int, -1>{}, -1);
+                group(q + 6, std::integral_constant<int, -1>{}, -1);
+                q += 8;
+            }
+            for (; q + 7 < nfull; q += 8) {
+                const int kb = ((2 * q - 2) >> 4) - 1;
+                group(q, std::integral_constant<int, 0>{}, kb);
+                group(q + 2, std::integral_constant<int, 4>{}, kb);
+                group(q + 4, std::integral_constant<int, 8>{}, kb);
+                group(q + 6, std::integral_constant<int, -1>{}, -1);
+            }
+            // the block that was complete when the loop ended, at once: up to 15 iterations follow, the last of which may
+            // start overwriting it (a pause of ~2 steps for the chain wave, once per launch)
+            if (q > 1) dx_block(((2 * q - 2) >> 4) - 1);
         }
+        for (; q + 1 < nfull; q += 2) group(q, std::integral_constant<int, -1>{}, -1);
         if (q < nfull) {
-            iter(2 * q, 0, true);
-            iter(2 * q + 1, 1, true);
+            iter(2 * q, 0, true, no_unit, -1);
+            iter(2 * q + 1, 1, true, no_unit, -1);
             park_chunk(q + FR_AHEAD, w0);
             q += 1;
         }
-        if (nsteps & 1) iter(nsteps - 1, 0, nsteps > 1);
+        if (nsteps & 1) iter(nsteps - 1, 0, nsteps > 1, no_unit, -1);
         // the last iteration's row: the chain wave reports "da_r of the last step is written" as dau_pub = nsteps+1
         {
             while (seen <= nsteps) {
@@ -212,6 +313,12 @@ __global__ __launch_bounds__(256, 1) void gru_scan_bwd_feed_kernel(const HpmnGru
             dap[0] = row[l];
             dap[H] = row[H + l];
             dap[2 * H] = row[2 * H + l];
+        }
+        if constexpr (LOOPDX) {
+            // the blocks the loop did not reach: all of their rows are still in the ring (at most the last 31 iterations)
+            const int nblk = (nsteps + DXB - 1) / DXB;
+            const int done = nfull >= 9 ? ((nfull - 9) / 8 + 1) - 1 : -1;      // trips of the 16-iteration loop - 1 = last block done
+            for (int kb = done + 1; kb < nblk; ++kb) dx_block(kb);
         }
     } else {
     // ====================================================================== chain wave
@@ -236,7 +343,7 @@ __global__ __launch_bounds__(256, 1) void gru_scan_bwd_feed_kernel(const HpmnGru
     f2 cb = ringB[0][l];
 
     auto step = [&](int k, int p) {
-        float *row = dact[p];
+        float *row = dact[LOOPDX ? (k & (NSLOT - 1)) : p];
         const float dhin = dh + ca.x;
         const float dcp = dhin * ca.y;
         const float dau = dhin * ca.z;
@@ -274,7 +381,7 @@ __global__ __launch_bounds__(256, 1) void gru_scan_bwd_feed_kernel(const HpmnGru
     if (t_lo0 > 0) a.dh_carry[b * H + l] = dh;
     }
 
-    if constexpr (DX) {
+    if constexpr (DX && !LOOPDX) {
         // ================================================================== epilogue: the input gradient of this launch's steps
         __builtin_amdgcn_s_setprio(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the feeders' d_act rows have reached memory
@@ -380,21 +487,30 @@ bool gru_scan_bwd_feed_dx_width(int D) { return D == 16 || D == 32 || D == 64; }
 // the epilogue's fused scatter: id column f is column tile f of the input gradient
 bool gru_scan_bwd_feed_scatter_ok(int D, int F, int E) { return E == 16 && D == F * 16 && gru_scan_bwd_feed_dx_width(D); }
 
-int gru_scan_bwd_feed_launch(const HpmnGruBwd &a, hipStream_t st) {
+template <bool CFH>
+static int feed_launch(const HpmnGruBwd &a, hipStream_t st) {
     const dim3 grid((a.B + 1) / 2);
     if (a.d_emb != nullptr) {
-        if (a.D == 16) hipLaunchKernelGGL((gru_scan_bwd_feed_kernel<16, true>), grid, dim3(256), 0, st, a);
-        else if (a.D == 32) hipLaunchKernelGGL((gru_scan_bwd_feed_kernel<32, true>), grid, dim3(256), 0, st, a);
-        else if (a.D == 64) hipLaunchKernelGGL((gru_scan_bwd_feed_kernel<64, true>), grid, dim3(256), 0, st, a);
+        if (a.D == 16) hipLaunchKernelGGL((gru_scan_bwd_feed_kernel<16, true, false, CFH>), grid, dim3(256), 0, st, a);
+        else if (a.D == 32) hipLaunchKernelGGL((gru_scan_bwd_feed_kernel<32, true, false, CFH>), grid, dim3(256), 0, st, a);
+        else if (a.D == 64) hipLaunchKernelGGL((gru_scan_bwd_feed_kernel<64, true, false, CFH>), grid, dim3(256), 0, st, a);
         else return HPMN_EUNSUPPORTED;
         return check_launch();
     }
-    if (a.d_x == nullptr) hipLaunchKernelGGL(gru_scan_bwd_feed_kernel<0>, grid, dim3(256), 0, st, a);
-    else if (a.D == 16) hipLaunchKernelGGL(gru_scan_bwd_feed_kernel<16>, grid, dim3(256), 0, st, a);
-    else if (a.D == 32) hipLaunchKernelGGL(gru_scan_bwd_feed_kernel<32>, grid, dim3(256), 0, st, a);
-    else if (a.D == 64) hipLaunchKernelGGL(gru_scan_bwd_feed_kernel<64>, grid, dim3(256), 0, st, a);
+    // HPMN_BWD_DX_INLOOP=0: the input gradient of D <= 32 as an epilogue too (the round-2/3 form)
+    static const int inloop = [] { const char *e = getenv("HPMN_BWD_DX_INLOOP"); return e ? atoi(e) : 1; }();
+    if (a.d_x == nullptr) hipLaunchKernelGGL((gru_scan_bwd_feed_kernel<0, false, false, CFH>), grid, dim3(256), 0, st, a);
+    else if (a.D == 16 && inloop) hipLaunchKernelGGL((gru_scan_bwd_feed_kernel<16, false, true, CFH>), grid, dim3(256), 0, st, a);
+    else if (a.D == 32 && inloop) hipLaunchKernelGGL((gru_scan_bwd_feed_kernel<32, false, true, CFH>), grid, dim3(256), 0, st, a);
+    else if (a.D == 16) hipLaunchKernelGGL((gru_scan_bwd_feed_kernel<16, false, false, CFH>), grid, dim3(256), 0, st, a);
+    else if (a.D == 32) hipLaunchKernelGGL((gru_scan_bwd_feed_kernel<32, false, false, CFH>), grid, dim3(256), 0, st, a);
+    else if (a.D == 64) hipLaunchKernelGGL((gru_scan_bwd_feed_kernel<64, false, false, CFH>), grid, dim3(256), 0, st, a);
     else return HPMN_EUNSUPPORTED;
     return check_launch();
+}
+
+int gru_scan_bwd_feed_launch(const HpmnGruBwd &a, hipStream_t st) {
+    return (a.flags & HPMN_BWD_CANDIDATE_FROM_HS) ? feed_launch<true>(a, st) : feed_launch<false>(a, st);
 }
 
 }  // namespace hpmn

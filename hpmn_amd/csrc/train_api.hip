@@ -47,11 +47,14 @@ int embed_grad_segsum_launch(const HpmnScatterPlan &p, const float *d_x, float *
 // Does layer i's saved `gates` tensor go WITHOUT the candidate (include/hpmn_hip.h, ABI v11)?  hpmn_scan_fwd_train and
 // hpmn_scan_bwd both decide with this: the layer's forward runs on a fused kernel that honours HPMN_FWD_NO_CANDIDATE (single
 // layer or pair) and its reverse scan on a chain + feeder kernel that honours HPMN_BWD_CANDIDATE_FROM_HS.
-static bool drops_candidate(const TrainCtx *c, const HpmnScanDesc *d, int i) {
-    const int D = i == 0 ? d->F * d->E : d->H;
-    const bool room = 2.0 * d->B <= 1.1 * 4 * c->cus;
-    const bool fused = room && gru_fused_fwd_supported(d->H, D, i == 0) && (i > 0 || 64 % d->E == 0);
-    return fused && gru_fused_fwd_writes_last() && gru_candidate_elision(d->H, d->B);
+// (All layers or none: the two-layer reverse launch takes the switch as one template argument for both of its layers.)
+static bool drops_candidate(const TrainCtx *c, const HpmnScanDesc *d, int) {
+    if (!(2.0 * d->B <= 1.1 * 4 * c->cus) || !gru_fused_fwd_writes_last() || !gru_candidate_elision(d->H, d->B)) return false;
+    for (int i = 0; i < d->K; ++i) {
+        const int D = i == 0 ? d->F * d->E : d->H;
+        if (!(gru_fused_fwd_supported(d->H, D, i == 0) && (i > 0 || 64 % d->E == 0))) return false;
+    }
+    return true;
 }
 
 // The whole-range scatter of a step: through the context's plan (deterministic segmented reduction) when one is set.

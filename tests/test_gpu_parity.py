@@ -446,7 +446,10 @@ def test_fused_forward_matches_the_two_kernel_forward(dev, tmp_path, monkeypatch
         assert torch.equal(last_f, last_u)
         for (x_f, hs_f, ga_f), (x_u, hs_u, ga_u) in zip(saved_f, saved_u):
             np.testing.assert_allclose(hs_f.cpu().numpy(), hs_u.cpu().numpy(), rtol=0, atol=2e-6)
-            np.testing.assert_allclose(ga_f.cpu().numpy(), ga_u.cpu().numpy(), rtol=0, atol=2e-6)
+            # (ABI v11: the fused training forward leaves the candidate third of `gates` unwritten where the reverse scan can
+            #  do without it -- every layer of these shapes; the gradients below are what it must not change)
+            cols = 2 * 64 if ops.candidate_elision(64, B) else 3 * 64
+            np.testing.assert_allclose(ga_f[..., :cols].cpu().numpy(), ga_u[..., :cols].cpu().numpy(), rtol=0, atol=2e-6)
         assert torch.equal(saved_f[0][0], saved_u[0][0])                     # the materialised gather
         np.testing.assert_allclose(g_f.cpu().numpy(), g_u.cpu().numpy(), rtol=0, atol=2e-5 * float(g_u.abs().max()))
 
@@ -1456,7 +1459,56 @@ def test_two_reverse_scans_in_one_launch_equal_two_launches(dev, name, B, T, D, 
         torch.cuda.synchronize()
         for what, got, want in (("upper d_act", a_up, dact_up), ("lower d_act", a_lo, dact_lo), ("lower d_x", x_lo, dx_lo)):
             err = float((got - want).abs().max()) / float(want.abs().max())
-            assert err <= 5e-6, "%s (flags %d): %g of the tensor's max" % (what, flags, err)
+            # (D <= 32: the single-layer launch forms d_x on the bf16 matrix pipe with split operands, the pair's epilogue in fp32)
+            tol = 2e-5 if what == "lower d_x" and D <= 32 else 5e-6
+            assert err <= tol, "%s (flags %d): %g of the tensor's max" % (what, flags, err)
+
+
+@pytest.mark.parametrize("D", [16, 32])
+@pytest.mark.parametrize("T", [1, 2, 15, 16, 17, 18, 31, 33, 34, 47, 50, 65, 200, 1001])
+def test_input_gradient_formed_inside_the_reverse_scan(dev, D, T):
+    """The layer's input gradient out of the reverse-scan launch (HpmnGruBwd.d_x; for D <= 32 formed in the loop on the bf16
+    matrix pipe with split operands, gru_scan_bwd_feed.hip) against the fp32 launch of its own (hpmn_gru_input_grad) and
+    float64, over the block structure's edge lengths (16-iteration blocks, the 16-iteration unrolled loop starting at
+    iteration 2, odd lengths), an odd batch, and a launch cut in two time chunks; d_act must not depend on who forms d_x."""
+    from hpmn_amd import ops
+    H, B = 64, 5
+    if not ops.scan_bwd_fuses_dx(H, B):
+        pytest.skip("the scan launch does not produce d_x in this configuration")
+    g = torch.Generator(device="cpu").manual_seed(T * 10 + D)
+
+    def w(*shape, scale=0.3):
+        return (torch.randn(*shape, generator=g) * scale).to(dev)
+    gates = torch.rand(B, T, 3 * H, generator=g)
+    gates[..., 2 * H:] = gates[..., 2 * H:] * 2 - 1
+    gates = gates.to(dev)
+    wg, wc, hs = w(D + H, 2 * H, scale=0.12), w(D + H, H, scale=0.12), w(B, T + 1, H, scale=0.7)
+    d_last = w(B, H, scale=0.1)
+    period = 1
+    d_y = w(B, T, H, scale=0.1)
+    plain = ops.gru_scan_bwd(wg, wc, D, hs, gates, d_last, d_y, period)                  # no d_x: the scan alone
+    dx = torch.full((B, T, D), 7.0, device=dev)
+    d_act = ops.gru_scan_bwd(wg, wc, D, hs, gates, d_last, d_y, period, d_x=dx)
+    torch.cuda.synchronize()
+    # (the two kernel variants contract a few multiply-adds of the coefficient arithmetic differently: last bits)
+    assert float((plain - d_act).abs().max()) <= 2e-6 * float(plain.abs().max())
+    want32 = ops.gru_input_grad(d_act, wg, wc, D)
+    w64 = torch.cat([wg[:D].double(), wc[:D].double()], dim=1)                           # [D, 3H]
+    want64 = d_act.double() @ w64.t()
+    scale = float(want64.abs().max())
+    assert float((want32.double() - want64).abs().max()) <= 2e-6 * scale
+    err = float((dx.double() - want64).abs().max()) / scale
+    assert err <= 2e-5, "in-launch d_x: %g of the tensor's max" % err
+    if T >= 34:
+        cut = (T // 2) // 2 * 2
+        carry = torch.zeros(B, H, device=dev)
+        dx2 = torch.full((B, T, D), 7.0, device=dev)
+        da2 = torch.full((B, T, 3 * H), 7.0, device=dev)
+        ops.gru_scan_bwd(wg, wc, D, hs, gates, d_last, d_y, period, out=da2, t_range=(cut, T), dh_carry=carry, d_x=dx2)
+        ops.gru_scan_bwd(wg, wc, D, hs, gates, d_last, d_y, period, out=da2, t_range=(0, cut), dh_carry=carry, d_x=dx2)
+        torch.cuda.synchronize()
+        assert float((da2 - d_act).abs().max()) <= 5e-6 * float(d_act.abs().max())
+        assert float((dx2.double() - want64).abs().max()) / scale <= 2e-5
 
 
 @pytest.mark.parametrize("pair", [False, True])
@@ -1535,7 +1587,9 @@ def test_saved_gates_without_the_candidate(dev, pair, B, T, D):
     for what, gt, wt in zip(("upper d_act", "lower d_act", "lower d_x"), got, want):
         assert torch.isfinite(gt).all(), what
         err = float((gt - wt).abs().max()) / float(wt.abs().max())
-        assert err <= 2e-6, "%s: %g of the tensor's max" % (what, err)
+        # (a 32-wide d_x of the single-layer launch comes off the bf16 matrix pipe: each side is within ~5e-6 of the exact product)
+        tol = 2e-5 if what == "lower d_x" and D <= 32 and not pair else 2e-6
+        assert err <= tol, "%s: %g of the tensor's max" % (what, err)
 
 
 @pytest.mark.parametrize("mask", [True, False])
