@@ -281,7 +281,7 @@ def roofline_probes(model, c, batches, step_fn):
         if mode != "1" and ops.scan_bwd_fuses_dx(H, B) and D0 in (16, 32, 64):
             # the launch also produces the layer's input gradient (MFMA epilogue, gru_scan_bwd_feed.hip): its
             # 2*3H*D0 flops per step belong to the launch's algorithmic work
-            dom_kernel = "gru_scan_bwd_feed_kernel<%d,false>" % D0
+            dom_kernel = "gru_scan_bwd_feed_kernel<%d,false" % D0      # (+ the in-loop / candidate template switches)
             dx_in_scan = True
             scan_flops += B * T0 * 2 * 3 * H * D0
     else:
@@ -291,11 +291,12 @@ def roofline_probes(model, c, batches, step_fn):
     traffic = None
     step_bytes = None
     if pmc is not None:
-        kk = pmc["kernels"].get(dom_kernel)
+        kk = [v for k, v in pmc["kernels"].items() if k.startswith(dom_kernel)]
         if kk:
-            traffic = kk["hbm_bytes_max_launch"]
+            traffic = max(v["hbm_bytes_max_launch"] for v in kk)
         step_bytes = pmc.get("hbm_bytes_per_step")
-    roof = {"kernel": "%s layer 0 (T=%d)" % (dom_kernel, T0), "bound": "mfma",
+    dx_inloop = dx_in_scan and D0 <= 32 and os.environ.get("HPMN_BWD_DX_INLOOP", "1") != "0"
+    roof = {"kernel": "%s%s layer 0 (T=%d)" % (dom_kernel, ",...>" if dx_in_scan else "", T0), "bound": "mfma",
             "achieved": scan_flops / (dom_t * 1e-3) / 1e12, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
             "frac": scan_flops / (dom_t * 1e-3) / 1e12 / PEAK_F32_TFLOPS,
             "traffic": traffic, "traffic_unit": "bytes/launch",
@@ -308,7 +309,9 @@ def roofline_probes(model, c, batches, step_fn):
             "ms_per_launch_standalone": t_bwd,
             "algorithmic_flops_per_launch": scan_flops,
             "note": "fp32 FMA chain, latency-bound serial recurrence; peak = dense fp32 (vector == f32 MFMA)"
-                    + ("; the launch includes the layer's input gradient (MFMA epilogue) and its flops" if dx_in_scan else "")}
+                    + (("; the launch includes the layer's input gradient (%s) and its flops"
+                        % ("formed in the loop on the bf16 matrix pipe, split operands" if dx_inloop else "MFMA epilogue"))
+                       if dx_in_scan else "")}
     wgrad_flops = B * T0 * 2 * (D0 + H) * 3 * H
     proj_bytes = n_ids * (4 + 64) + B * T0 * 3 * H * 4
     alg_train = B * bytes_train_per_seq(c)
@@ -457,13 +460,18 @@ def cpu_baseline(c, seed=0, budget_s=25.0):
     try:
         import ctypes
         libc = ctypes.CDLL("libc.so.6")
-        M_TRIM_THRESHOLD, M_TOP_PAD, M_MMAP_THRESHOLD, M_ARENA_MAX = -1, -2, -3, -8
+        M_TRIM_THRESHOLD, M_TOP_PAD, M_MMAP_THRESHOLD, M_MMAP_MAX, M_ARENA_MAX = -1, -2, -3, -4, -8
         # (one arena: the autograd thread's own arena is made of 64 MB sub-heaps that are unmapped when they empty, whatever
         #  the trim threshold says -- one step in five still took 14 s with the three settings above alone)
         # (trim threshold -1: mallopt takes an int and the library widens it to size_t, i.e. "never" -- INT_MAX = 2 GB still
         #  let free() hand the ~10 GB heap back to the kernel now and then: 2.1 2.2 2.1 14.8 2.0)
+        # (no mmap at all: the threshold cannot exceed 32 MB, and the step's large tensors -- 64 MB of gathered rows, the dense
+        #  Adam's 212 MB table-sized temporaries -- were still mapped, faulted in and unmapped every step: on a host whose
+        #  free memory is fragmented (no huge pages to hand out) two steps in five took 15 s instead of 2.1.  From the heap
+        #  they are faulted in once)
         malloc_tuned = bool(libc.mallopt(M_MMAP_THRESHOLD, 32 << 20) and libc.mallopt(M_TRIM_THRESHOLD, -1)
-                            and libc.mallopt(M_TOP_PAD, 256 << 20) and libc.mallopt(M_ARENA_MAX, 1))
+                            and libc.mallopt(M_TOP_PAD, 256 << 20) and libc.mallopt(M_ARENA_MAX, 1)
+                            and libc.mallopt(M_MMAP_MAX, 0))
     except OSError:
         pass
     cfg = O.HpmnConfig(feature_size=c["V"], user_dim=c["F"], user_maxlen=c["T"], hidden_size=c["H"],

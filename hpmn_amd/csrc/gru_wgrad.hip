@@ -258,7 +258,10 @@ int gru_dx_dispatch(const HpmnGruWgrad &a, hipStream_t st);   // input_proj.hip 
 bool gru_wgrad_bf16_launch(const HpmnGruWgrad &k, int nwg, bool solo, hipStream_t st);   // gru_wgrad_bf16.hip
 
 static int wgrad_seq_per_wg(int T) {   // T = steps per sequence in this launch
-    int spw = (WG_MIN_ROWS + T - 1) / T;
+    // (HPMN_WGRAD_MIN_ROWS: every workgroup writes a slab of (D + H + 1) 3H floats -- 98 KB at H = D = 64 -- and the reduction
+    //  reads it back; for the short top layers the slabs outweigh the rows they summarise)
+    static const int min_rows = [] { const char *e = getenv("HPMN_WGRAD_MIN_ROWS"); return e && atoi(e) > 0 ? atoi(e) : WG_MIN_ROWS; }();
+    int spw = (min_rows + T - 1) / T;
     return spw < 1 ? 1 : spw;
 }
 

@@ -17,19 +17,23 @@ sys.path.insert(0, ROOT)
 
 
 def per_kernel(path, counter):
+    """-> ({kernel: [values of the launches of the steps]}, KB of the launches IN FRONT of the first product kernel).  The
+    model's construction (torch.zeros of the flat gradient / moment buffers: three table-sized fills) is not part of any
+    step; until round 4 the digest divided it into the per-step figure (+0.2 GB at S + W = 4)."""
+    rows = [r for r in csv.DictReader(open(path)) if r.get("Counter_Name") == counter]
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    first = next((i for i, r in enumerate(rows) if "hpmn::" in r["Kernel_Name"]), 0)
     acc = defaultdict(list)
-    for r in csv.DictReader(open(path)):
-        if r.get("Counter_Name") != counter:
-            continue
+    for r in rows[first:]:
         name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace(" ", "")
         name = name.replace("hpmn::", "")
         acc[name].append(float(r["Counter_Value"]))
-    return acc
+    return acc, sum(float(r["Counter_Value"]) for r in rows[:first])
 
 
 def main(fetch_csv, write_csv, nsteps, config_id, batch, out):
     import bench
-    f, w = per_kernel(fetch_csv, "FETCH_SIZE"), per_kernel(write_csv, "WRITE_SIZE")
+    (f, f_setup), (w, w_setup) = per_kernel(fetch_csv, "FETCH_SIZE"), per_kernel(write_csv, "WRITE_SIZE")
     kernels, total = {}, 0.0
     for name in sorted(set(f) | set(w)):
         fv, wv = f.get(name, [0.0]), w.get(name, [0.0])
@@ -45,7 +49,8 @@ def main(fetch_csv, write_csv, nsteps, config_id, batch, out):
                     % (config_id, nsteps),
          "units": "rocprofv3 reports KB; hbm bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE x2 correction)",
          "source_sha": bench.source_sha(), "config_id": config_id, "batch": batch, "steps_in_run": nsteps,
-         "hbm_bytes_per_step": total / nsteps, "kernels": kernels}
+         "hbm_bytes_per_step": total / nsteps,
+         "setup_bytes_not_in_any_step": (2.0 * f_setup + w_setup) * 1024.0, "kernels": kernels}
     json.dump(d, open(out, "w"), indent=1)
     print("hbm bytes per step: %.3f GB over %d kernels (source sha %s)" % (total / nsteps / 1e9, len(kernels), d["source_sha"]))
 
