@@ -40,4 +40,4 @@ for name in names:
         vm = [int(re.search(r"vmcnt\((\d+)\)", l).group(1)) for l in seg if "vmcnt" in l]
         nv = sum(1 for l in seg if l.split()[0].startswith(("global_load", "buffer_load")))
         ns = sum(1 for l in seg if l.split()[0].startswith(("global_store", "buffer_store")))
-        print("   loop %5d-%5d  %4d instr  %3d loads %3d stores  vmcnt waits: min %s  %s" % (a, b, len(seg), nv, ns, min(vm) if vm else "-", vm[:24]))
+        print("   loop %5d-%5d  %4d instr  %3d loads %3d stores  vmcnt waits: min %s  %s" % (a, b, len(seg), nv, ns, min(vm) if vm else "-", vm[:80]))
