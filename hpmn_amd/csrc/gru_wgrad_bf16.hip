@@ -233,8 +233,8 @@ __global__ __launch_bounds__(64 * (HT + DT), (HT + DT) > 5 ? 1 : 2) void gru_wgr
 
 template <int HT, int DT, int CS>
 static void launch_bf16(const HpmnGruWgrad &k, int nwg, bool solo, hipStream_t st) {
-    // (one workgroup per CU beside a reverse scan, as in gru_wgrad.hip: unused dynamic LDS caps the occupancy; H <= 64 only --
-    //  the H = 128 form is shaped around its column split)
+    // (one workgroup per CU beside a reverse scan, as in gru_wgrad.hip: unused dynamic LDS caps the occupancy; by default for
+    //  H <= 64 only -- the H = 128 form is shaped around its column split; HPMN_WGRAD_SOLO_ROWS reaches it too)
     size_t pad = 0;
     if (solo) {
         static const size_t p = [] {
@@ -256,8 +256,8 @@ bool gru_wgrad_bf16_launch(const HpmnGruWgrad &k, int nwg, bool solo, hipStream_
     const int DT = (k.D + 31) / 32;
     if (k.H == 64 && DT == 1) launch_bf16<2, 1, 1>(k, nwg, solo, st);
     else if (k.H == 64 && DT == 2) launch_bf16<2, 2, 1>(k, nwg, solo, st);
-    else if (k.H == 128 && DT == 1) launch_bf16<4, 1, 2>(k, nwg, false, st);   // (two column groups: x, h_prev, r re-read twice, not 3x)
-    else if (k.H == 128 && DT == 4) launch_bf16<4, 4, 3>(k, nwg, false, st);
+    else if (k.H == 128 && DT == 1) launch_bf16<4, 1, 2>(k, nwg, solo, st);   // (two column groups: x, h_prev, r re-read twice, not 3x)
+    else if (k.H == 128 && DT == 4) launch_bf16<4, 4, 3>(k, nwg, solo, st);
     else return false;
     return true;
 }

@@ -16,6 +16,8 @@
 // epilogue is 16-byte stores (4x fewer store instructions than the row-major product, whose
 // lanes hold 4 consecutive ROWS of one column).  The bias rides in as one extra k-step.
 // Persistent waves walk 32-row tiles; the next tile's rows are in flight under the current MFMAs.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace hpmn {
@@ -288,6 +290,211 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void gru_dx_kernel(const HpmnGruW
     }
 }
 
+// The same product on the bf16 matrix pipe with SPLIT operands (x = hi + lo in bf16, hi*hi + hi*lo + lo*hi, fp32 accumulate:
+// gru_wgrad_bf16.hip's arithmetic, ~5e-6 of the result's max) for H = 128, where the fp32 form is bound by the matrix pipe:
+// K = 384 is 192 v_mfma_f32_32x32x2_f32 per 32-row tile and wave, 12 288 cycles -- the launch of a 250 k-row layer took 322 us,
+// all of it on the serial chain between two reverse scans (C4: 0.95 ms of 9.5).  Here a tile is 24 k-steps of 16: two 16-byte
+// loads of the lane's own row (lane (row, p) holds columns 16 ks + 8 p .. + 7 -- the instruction's 8 consecutive k, no
+// transpose), the split (24 VALU), three v_mfma_f32_32x32x16_bf16 (96 cycles): 2304 cycles of matrix pipe per tile, and the
+// launch is bound by reading d_act once.  The weights' fragments (the "A" operand: lane (d, p) = Wx[d][16 ks + 8 p .. + 7],
+// contiguous in memory) are stationary, split once: 192 registers.  Rows stream through a ring of PD k-steps of raw loads,
+// across tile borders, clamped past the end (no branch around a load or store in the loop).
+typedef __bf16 dbf8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void dx_split8(const float4 a, const float4 b, dbf8 &hi, dbf8 &lo) {
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        hi[i] = (__bf16)v[i];
+        lo[i] = (__bf16)(v[i] - (float)hi[i]);
+    }
+}
+
+template <int K, int NS>
+__global__ __launch_bounds__(64 * RW_WAVES, 1) void gru_dx_bf16_kernel(const HpmnGruWgrad a) {
+    constexpr int KS = K / 16;          // k-steps per tile
+    constexpr int PD = 12;              // k-steps of raw row data in flight (24 x 16-byte loads per lane: 24 KB per wave)
+    constexpr int H = K / 3;
+    static_assert(KS % PD == 0 && (2 * H) % 16 == 0, "ring slots are compile-time; a k-step never straddles wg | wc");
+    const int lane = threadIdx.x & 63;
+    const int c = lane & 31, p = lane >> 5;
+    const int D = a.D;
+    const int TL = a.t_len > 0 ? a.t_len : a.T;
+    const unsigned M = (unsigned)a.B * (unsigned)TL;
+    const unsigned ntile = (M + 31u) / 32u;
+    auto flat_row = [&](unsigned r) -> unsigned { const unsigned b = r / (unsigned)TL; return b * a.T + a.t_begin + (r - b * TL); };
+    const unsigned gwave = blockIdx.x * RW_WAVES + (threadIdx.x >> 6);
+    const int n_base = (int)(gwave % NS) * 32;
+    const unsigned wave_id = gwave / NS;
+    const unsigned nwave = gridDim.x * RW_WAVES / NS;
+
+    dbf8 wh[KS], wl[KS];
+    {
+        const int d = n_base + c;
+        const long dr = d < D ? d : D - 1;          // (columns past D are clamped: computed, never stored)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int j = 16 * ks + 8 * p;
+            const float *src = j < 2 * H ? a.wg + dr * 2 * H + j : a.wc + dr * H + (j - 2 * H);
+            dx_split8(*reinterpret_cast<const float4 *>(src), *reinterpret_cast<const float4 *>(src + 4), wh[ks], wl[ks]);
+        }
+    }
+    auto tile_row = [&](unsigned tile) -> unsigned { const unsigned rr = tile * 32u + c; return rr < M ? rr : M - 1u; };
+    auto row_ptr = [&](unsigned tile) { return a.d_act + (long)flat_row(tile_row(tile)) * K + 8 * p; };
+    float4 ring[PD][2];
+    const float *cur = row_ptr(wave_id);
+#pragma unroll
+    for (int i = 0; i < PD; ++i) {
+        ring[i][0] = *reinterpret_cast<const float4 *>(cur + 16 * i);
+        ring[i][1] = *reinterpret_cast<const float4 *>(cur + 16 * i + 4);
+    }
+    // (land the prologue's loads before the loop, as in input_proj_kernel: pending loads at loop entry make the compiler
+    //  merge entry and back-edge states into waits for nearly everything in flight -- vmcnt(3) where 10 are allowed)
+#pragma unroll
+    for (int i = 0; i < PD; ++i)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) { settle(ring[i][h].x); settle(ring[i][h].y); settle(ring[i][h].z); settle(ring[i][h].w); }
+    for (unsigned tile = wave_id; tile < ntile; tile += nwave) {
+        const float *nxt = row_ptr(tile + nwave);
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            dbf8 xh, xl;
+            {   // the k-step's consumption point, pinned in the order of the volatile statements (so are the reloads below):
+                // left alone the compiler hoists every split of the tile to its top and sinks the reloads to their uses --
+                // the ISA then shows the ring draining, vmcnt(22) .. vmcnt(0), then each k-step waiting for a load just issued
+                float4 &r0 = ring[ks % PD][0], &r1 = ring[ks % PD][1];
+                asm volatile("" : "+v"(r0.x), "+v"(r0.y), "+v"(r0.z), "+v"(r0.w), "+v"(r1.x), "+v"(r1.y), "+v"(r1.z), "+v"(r1.w));
+            }
+            dx_split8(ring[ks % PD][0], ring[ks % PD][1], xh, xl);
+            asm volatile("" ::: "memory");
+            // the slot is free: k-step ks + PD of this tile, or the next tile's first ones
+            const float *src = ks + PD < KS ? cur + 16 * (ks + PD) : nxt + 16 * (ks + PD - KS);
+            ring[ks % PD][0] = *reinterpret_cast<const float4 *>(src);
+            ring[ks % PD][1] = *reinterpret_cast<const float4 *>(src + 4);
+            asm volatile("" ::: "memory");
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[ks], xh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[ks], xl, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[ks], xh, acc, 0, 0, 0);
+        }
+        // transposed product (file header): lane (c, p) owns row tile*32 + c, columns 8 g + 4 p + 0..3 of this wave's 32
+        {
+            float *dst = a.d_x + (long)flat_row(tile_row(tile)) * D + n_base + 4 * p;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                if (n_base + 8 * g + 4 * p < D)
+                    *reinterpret_cast<float4 *>(dst + 8 * g) = make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+        }
+        cur = nxt;
+    }
+}
+
+// The forward's input projection at H = 128 with a 128-wide input (the upper layers of configs[4]) the same way: the fp32 form
+// is 195 matrix instructions of 64 cycles per 32-row tile and wave (12.5 k cycles; 268 us for the 250 k rows of layer 1, on the
+// serial chain in front of that layer's scan), here 8 k-steps x 3 column tiles x 3 products of 32 cycles = 2304, and the launch
+// is bound by writing xp.  Results within ~5e-6 of the row's largest pre-activation of the fp32 kernel's (the H = 128 forward
+// parity tests hold 1e-4 on the logits).  Rows from memory only (layer 0 gathers: its launch is bound by its 0.83 GB of
+// stores, not by the matrix pipe, and keeps the fp32 kernel).  The bias enters as one more k-step (hi and lo against 1.0).
+template <int K, int NT, int NS>
+__global__ __launch_bounds__(64 * RW_WAVES, 1) void input_proj_bf16_kernel(const HpmnInputProj a) {
+    constexpr int KS = K / 16;
+    const int lane = threadIdx.x & 63;
+    const int c = lane & 31, p = lane >> 5;
+    const int H = a.H, N = 3 * H;
+    const int TL = a.t_len > 0 ? a.t_len : a.T;
+    const unsigned M = (unsigned)a.B * (unsigned)TL;
+    const unsigned ntile = (M + 31u) / 32u;
+    auto flat_row = [&](unsigned r) -> unsigned { const unsigned b = r / (unsigned)TL; return b * a.T + a.t_begin + (r - b * TL); };
+    const unsigned gwave = blockIdx.x * RW_WAVES + (threadIdx.x >> 6);
+    const int ns = (int)(gwave % NS);
+    const unsigned wave_id = gwave / NS;
+    const unsigned nwave = gridDim.x * RW_WAVES / NS;
+    const int n_base = ns * NT * 32;
+
+    // A operand (stationary): lane (n = c, p) = sc * Wcat[16 ks + 8 p .. + 7][n_base + 32 nt + c], Wcat = [wg[0:D] | wc[0:D]]
+    dbf8 wh[NT][KS], wl[NT][KS], bh[NT], bl[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = n_base + 32 * nt + c;
+        const bool gate = n < 2 * H;
+        const float sc = gate ? NEG_LOG2E : 2.0f * NEG_LOG2E;          // (xp is produced in the scan's exponent domain)
+        const float *wcol = gate ? a.wg + n : a.wc + (n - 2 * H);
+        const long ldw = gate ? 2 * H : H;
+        const float *bcol = gate ? a.bg + n : a.bc + (n - 2 * H);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            float4 v0, v1;
+            const float *w0 = wcol + (long)(16 * ks + 8 * p) * ldw;
+            v0.x = sc * w0[0]; v0.y = sc * w0[ldw]; v0.z = sc * w0[2 * ldw]; v0.w = sc * w0[3 * ldw];
+            v1.x = sc * w0[4 * ldw]; v1.y = sc * w0[5 * ldw]; v1.z = sc * w0[6 * ldw]; v1.w = sc * w0[7 * ldw];
+            dx_split8(v0, v1, wh[nt][ks], wl[nt][ks]);
+        }
+        // the bias step: k slot 0 of half-wave 0 carries the bias, everything else 0, against a row operand of 1.0 there
+        const float bv = p == 0 ? sc * bcol[0] : 0.f;
+        dx_split8(make_float4(bv, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), bh[nt], bl[nt]);
+    }
+    dbf8 one;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) one[i] = (__bf16)(i == 0 ? 1.0f : 0.0f);
+
+    auto tile_row = [&](unsigned tile) -> unsigned { const unsigned rr = tile * 32u + c; return rr < M ? rr : M - 1u; };
+    auto load_x = [&](unsigned tile, float4 (&v)[KS][2]) {
+        const float *src = a.x + (long)flat_row(tile_row(tile)) * K + 8 * p;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            v[ks][0] = *reinterpret_cast<const float4 *>(src + 16 * ks);
+            v[ks][1] = *reinterpret_cast<const float4 *>(src + 16 * ks + 4);
+        }
+    };
+    // one tile: bias step, 8 k-steps x NT column tiles x 3 products, 16-byte stores (transposed product, file header)
+    auto do_tile = [&](unsigned tile, const float4 (&v)[KS][2]) {
+        f32x16 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            f32x16 z;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) z[r] = 0.f;
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[nt], one, z, 0, 0, 0);
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[nt], one, acc[nt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            dbf8 xh, xl;
+            dx_split8(v[ks][0], v[ks][1], xh, xl);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[nt][ks], xh, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[nt][ks], xl, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[nt][ks], xh, acc[nt], 0, 0, 0);
+            }
+        }
+        float *dst = a.xp + (long)flat_row(tile_row(tile)) * N + n_base + 4 * p;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4 *>(dst + 32 * nt + 8 * g) =
+                    make_float4(acc[nt][4 * g], acc[nt][4 * g + 1], acc[nt][4 * g + 2], acc[nt][4 * g + 3]);
+    };
+    // The next tile's rows are issued in front of this tile's work and copied over behind it (the copy is where they are
+    // waited for: one tile of work, ~1 us, after their issue).  (Two buffers and two tiles per trip, no copy, with the
+    // consumption points pinned by volatile statements: 512 registers and 54 spills -- not kept.)
+    float4 cur[KS][2], nxt[KS][2];
+    load_x(wave_id, cur);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) { settle(cur[ks][h].x); settle(cur[ks][h].y); settle(cur[ks][h].z); settle(cur[ks][h].w); }
+    for (unsigned tile = wave_id; tile < ntile; tile += nwave) {
+        load_x(tile + nwave, nxt);
+        asm volatile("" ::: "memory");
+        do_tile(tile, cur);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) { cur[ks][0] = nxt[ks][0]; cur[ks][1] = nxt[ks][1]; }
+    }
+}
+
 // persistent grid for a row-wise kernel whose row tile is shared by NS waves: one workgroup per CU at most,
 // (grid * RW_WAVES) a multiple of NS
 static unsigned rowwise_grid(long M, int NS) {
@@ -332,6 +539,13 @@ bool input_proj_supported(int H, int D) {
 
 int input_proj_dispatch(const HpmnInputProj &a, hipStream_t st) {
     if (a.H == 128) {
+        // HPMN_PROJ_BF16=0: the fp32 kernel for the 128-wide layers too
+        static const int pbf = [] { const char *e = getenv("HPMN_PROJ_BF16"); return e ? atoi(e) : 1; }();
+        if (a.D == 128 && a.x != nullptr && pbf && (long)a.B * a.T < (1L << 31) - 64) {
+            const unsigned grid = rowwise_grid((long)a.B * (a.t_len > 0 ? a.t_len : a.T), 4);
+            hipLaunchKernelGGL((input_proj_bf16_kernel<128, 3, 4>), dim3(grid), dim3(64 * RW_WAVES), 0, st, a);
+            return check_launch();
+        }
         if (a.D == 32) return launch_proj<32, 3, 4>(a, st);
         if (a.D == 128) return launch_proj<128, 3, 4>(a, st);
         return HPMN_EUNSUPPORTED;
@@ -343,6 +557,12 @@ int input_proj_dispatch(const HpmnInputProj &a, hipStream_t st) {
     return HPMN_EUNSUPPORTED;
 }
 
+// HPMN_DX_BF16=0: the fp32 kernel for H = 128 as well
+static bool dx_bf16() {
+    static const int on = [] { const char *e = getenv("HPMN_DX_BF16"); return e ? atoi(e) : 1; }();
+    return on != 0;
+}
+
 int gru_dx_dispatch(const HpmnGruWgrad &a, hipStream_t st) {
     const long rows = (long)a.B * (a.t_len > 0 ? a.t_len : a.T);
     const int DT = (a.D + 31) / 32;
@@ -352,6 +572,8 @@ int gru_dx_dispatch(const HpmnGruWgrad &a, hipStream_t st) {
     else if (a.H == 32 && DT == 2) hipLaunchKernelGGL((gru_dx_kernel<96, 2, 1, true>), dim3(rowwise_grid(rows, 1)), blk, 0, st, a);
     else if (a.H == 64 && DT == 1) hipLaunchKernelGGL((gru_dx_kernel<192, 1, 1, true>), dim3(rowwise_grid(rows, 1)), blk, 0, st, a);
     else if (a.H == 64 && DT == 2) hipLaunchKernelGGL((gru_dx_kernel<192, 2, 1, true>), dim3(rowwise_grid(rows, 1)), blk, 0, st, a);
+    else if (a.H == 128 && DT == 1 && dx_bf16()) hipLaunchKernelGGL((gru_dx_bf16_kernel<384, 1>), dim3(rowwise_grid(rows, 1)), blk, 0, st, a);
+    else if (a.H == 128 && DT == 4 && dx_bf16()) hipLaunchKernelGGL((gru_dx_bf16_kernel<384, 4>), dim3(rowwise_grid(rows, 4)), blk, 0, st, a);
     else if (a.H == 128 && DT == 1) hipLaunchKernelGGL((gru_dx_kernel<384, 1, 1, false>), dim3(rowwise_grid(rows, 1)), blk, 0, st, a);
     else if (a.H == 128 && DT == 4) hipLaunchKernelGGL((gru_dx_kernel<384, 1, 4, false>), dim3(rowwise_grid(rows, 4)), blk, 0, st, a);
     else return HPMN_EUNSUPPORTED;

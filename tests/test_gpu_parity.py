@@ -1464,6 +1464,30 @@ def test_two_reverse_scans_in_one_launch_equal_two_launches(dev, name, B, T, D, 
             assert err <= tol, "%s (flags %d): %g of the tensor's max" % (what, flags, err)
 
 
+@pytest.mark.parametrize("D", [32, 128])
+@pytest.mark.parametrize("B,T", [(1, 1), (3, 33), (7, 250), (64, 257)])
+def test_input_gradient_launch_h128(dev, B, T, D):
+    """hpmn_gru_input_grad at H = 128 (bf16 matrix pipe, split operands, rows streamed through a register ring across tile
+    borders: input_proj.hip) against float64: <= 2e-5 of the tensor's max; partial last tile, one row, a time chunk."""
+    from hpmn_amd import ops
+    H = 128
+    g = torch.Generator(device="cpu").manual_seed(B * 100 + T + D)
+    d_act = (torch.randn(B, T, 3 * H, generator=g) * torch.rand(B, T, 1, generator=g)).to(dev)
+    wg = (torch.randn(D + H, 2 * H, generator=g) * 0.3).to(dev)
+    wc = (torch.randn(D + H, H, generator=g) * 0.3).to(dev)
+    want = d_act.double() @ torch.cat([wg[:D].double(), wc[:D].double()], dim=1).t()
+    scale = float(want.abs().max())
+    got = ops.gru_input_grad(d_act, wg, wc, D)
+    torch.cuda.synchronize()
+    assert float((got.double() - want).abs().max()) <= 2e-5 * scale
+    if T >= 33:
+        out = torch.full((B, T, D), 7.0, device=dev)
+        ops.gru_input_grad(d_act, wg, wc, D, out=out, t_range=(5, T - 9))
+        torch.cuda.synchronize()
+        assert float((out[:, 5:T - 4].double() - want[:, 5:T - 4]).abs().max()) <= 2e-5 * scale
+        assert bool((out[:, :5] == 7.0).all()) and bool((out[:, T - 4:] == 7.0).all())
+
+
 @pytest.mark.parametrize("D", [16, 32])
 @pytest.mark.parametrize("T", [1, 2, 15, 16, 17, 18, 31, 33, 34, 47, 50, 65, 200, 1001])
 def test_input_gradient_formed_inside_the_reverse_scan(dev, D, T):
