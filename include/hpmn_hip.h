@@ -274,7 +274,9 @@ int hpmn_gru_scan_bwd_fuses_scatter(int32_t H, int32_t B, int32_t D, int32_t F, 
  *   lo : the lower layer; lo.d_y is IGNORED (it comes from `up`); lo.T == up.T * lo.period; lo.d_x optional
  *        (D in {16, 32, 64}): the lower layer's input gradient, an epilogue of the launch shared by all four waves of the
  *        sequence
- * Results equal two hpmn_gru_scan_bwd calls (d_act bit-identical).  (B + 1) / 2 <= number of CUs, as for the forward. */
+ * Results equal two hpmn_gru_scan_bwd calls (d_act bit-identical).  (B + 1) / 2 <= number of CUs, as for the forward.
+ * HPMN_BWD_CANDIDATE_FROM_HS must be set on both layers or on neither (HPMN_EUNSUPPORTED otherwise: the switch is one
+ * template argument of the launch). */
 typedef struct HpmnGruPairBwd {
     HpmnGruBwd lo, up;
     int32_t flags, pad_;
