@@ -1,5 +1,7 @@
+"""d_act of the reverse scan with / without the in-launch input gradient, and that gradient against float64, over the block
+structure's edge lengths (gru_scan_bwd_feed.hip, LOOPDX).  python tools/dx_inloop_check.py"""
 import torch, sys
-sys.path.insert(0,'/root/repo')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from hpmn_amd import ops
 dev=torch.device('cuda:0')
 H,B=64,5
