@@ -44,8 +44,8 @@ extern "C" {
  * BPTT through q: (1 - u)(1 - c^2) = (1 - u) - q c, (h_{t-1} - c) u (1 - u) = u ((1 - u) h_{t-1} - q); c = q / (1 - u) for
  * the one remaining factor (taken as 0 where u rounds to 1: both coefficients vanish there).  A third of the saved-gates
  * traffic (two 128-byte lines per step at H = 64, written by the forward and read by the reverse scan) disappears; the
- * coefficients differ from the stored-candidate ones by <= ~2.4e-7 ABSOLUTE (they are O(1); measured in
- * tests/test_gpu_parity.py).  hpmn_gru_candidate_elision(H, B) != 0 where both sides support it. */
+ * coefficients differ from the float64 ones by <= ~2.4e-7 ABSOLUTE (they are O(1)) -- 3.2e-7 in the corner u = 1 - 2^-24, where q is
+ * smaller than the forward's own rounding of h (tests/test_candidate_elision_cpu.py, tests/test_gpu_parity.py).  hpmn_gru_candidate_elision(H, B) != 0 where both sides support it. */
 #define HPMN_FWD_NO_CANDIDATE 1      /* HpmnGruFusedFwd.flags bit 0: gates[..., 2H:3H] is NOT written            */
 #define HPMN_BWD_CANDIDATE_FROM_HS 1 /* HpmnGruBwd.flags bit 0: gates[..., 2H:3H] is NOT read (see above)        */
 
