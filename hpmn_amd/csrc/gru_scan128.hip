@@ -27,7 +27,19 @@
 namespace hpmn {
 
 constexpr int H128 = 128;
+constexpr int HPMN_SCAN128_SOLO_DEFAULT = 0;   // (see scan128_solo_mask)
 constexpr int PF4 = 4;         // prefetch distance (steps) == unroll factor of the time loop (four-wave form; eight-wave: 2)
+
+// A wave-uniform global pointer pinned to an SGPR pair and made opaque, so that an access through it with a 32-bit lane
+// offset is emitted as `global_load/store v, v_off, s[base:base+1]` -- one VGPR per lane offset instead of a 64-bit lane
+// pointer per stream (the optimiser otherwise folds the lane offset into the base and keeps base + lane in two VGPRs).
+typedef __attribute__((address_space(1))) float gfloat;
+__device__ __forceinline__ gfloat *sgpr_base(const float *p) {
+    const unsigned long v = reinterpret_cast<unsigned long>(p);
+    unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    asm("" : "+s"(lo), "+s"(hi));
+    return reinterpret_cast<gfloat *>(((unsigned long)hi << 32) | lo);
+}
 
 __device__ __forceinline__ void wg_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -61,7 +73,7 @@ template <int KQ> __device__ __forceinline__ float join_parts(float x) {
 //    round trips and the activations; twice the waves make each barrier and each join longer (eight waves to collect, two
 //    swaps instead of one) by more than the halved FMA/LDS issue saves.
 template <bool TRAIN, int NW>
-__global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void gru_scan_fwd128_kernel(const HpmnGruFwd a) {
+__global__ __launch_bounds__(64 * NW, 2) void gru_scan_fwd128_kernel(const HpmnGruFwd a) {
     constexpr int H = H128;
     constexpr int KQ = NW / 2;            // k-parts per dot product (lanes of a wave that share a unit)
     constexpr int UW = 64 / KQ;           // units per wave
@@ -91,14 +103,18 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void gru_scan_fwd128_kern
 
     const int t0 = a.t_begin;
     const int t1 = a.t_end > 0 ? a.t_end : T;
-    const float *xpb = a.xp + b * (long)T * 3 * H + u;
+    // Addresses are (wave-uniform base: the sequence's row, in SGPRs) + (the lane's 32-bit offset): a 64-bit pointer per lane
+    // and stream cost the four-wave form 260 registers -- four over the 256 that let TWO workgroups share a CU (occupancy 1:
+    // a batch of 500 ran as two rounds of 256 workgroups).
+    const unsigned uo = (unsigned)u;
+    const float *xp_seq = a.xp + b * (long)T * 3 * H;            // (uniform)
     float xr[PF], xu[PF], xc[PF];
     auto fetch = [&](int t, int slot) {
         const int tc = t < T ? t : T - 1;
-        const float *row = xpb + (long)tc * 3 * H;
-        xr[slot] = row[0];
-        xu[slot] = row[H];
-        xc[slot] = row[2 * H];
+        const gfloat *row = sgpr_base(xp_seq + (long)tc * 3 * H);   // (uniform)
+        xr[slot] = row[uo];
+        xu[slot] = row[H + uo];
+        xc[slot] = row[2 * H + uo];
     };
 #pragma unroll
     for (int i = 0; i < PF; ++i) fetch(t0 + i, i);
@@ -116,20 +132,22 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void gru_scan_fwd128_kern
     const int period = a.period;
     const bool has_y = a.y != nullptr;
     int next_fire = t0 + period - 1;
-    float *yp = has_y ? a.y + (b * (long)(T / period) + t0 / period) * H + u : a.h_last + b * a.h_last_stride + u;
+    float *yp = has_y ? a.y + (b * (long)(T / period) + t0 / period) * H : a.h_last + b * a.h_last_stride;   // (uniform)
     const int y_adv = has_y ? H : 0;
     // TRAIN stores, split over the lane parts by select: (KQ = 2) p == 0 writes (hs, r), p == 1 writes (u, c);
     // (KQ = 4) one value per part: hs, r, u, c
-    float *s0 = nullptr, *s1 = nullptr;
-    long adv0 = 0, adv1 = 0;
+    // (KQ = 2: the second store goes to the gates row alone -- uniform row + the lane's column, r or c)
+    float *s0 = nullptr, *grow = nullptr;
+    int adv0 = 0;
+    unsigned s1o = 0;
     if constexpr (TRAIN) {
         float *hsp = a.hs + (b * (long)(T + 1) + t0 + 1) * H + u;
-        float *gp = a.gates + (b * (long)T + t0) * 3 * H + u;
+        grow = a.gates + (b * (long)T + t0) * 3 * H;             // (uniform)
+        float *gp = grow + u;
         if constexpr (KQ == 2) {
             s0 = p == 0 ? hsp : gp + H;
-            s1 = p == 0 ? gp : gp + 2 * H;
+            s1o = p == 0 ? uo : 2 * H + uo;
             adv0 = p == 0 ? H : 3 * H;
-            adv1 = 3 * H;
         } else {
             s0 = p == 0 ? hsp : gp + (p - 1) * H;
             adv0 = p == 0 ? H : 3 * H;
@@ -155,15 +173,15 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void gru_scan_fwd128_kern
         if constexpr (TRAIN) {
             if constexpr (KQ == 2) {
                 *s0 = p == 0 ? h : ug;
-                *s1 = p == 0 ? r : cc;
+                sgpr_base(grow)[s1o] = p == 0 ? r : cc;
                 s0 += adv0;
-                s1 += adv1;
+                grow += 3 * H;
             } else {
                 *s0 = p == 0 ? h : (p == 1 ? r : (p == 2 ? ug : cc));
                 s0 += adv0;
             }
         }
-        *yp = h;
+        yp[uo] = h;
         const bool fire = t == next_fire;
         next_fire += fire ? period : 0;
         yp += fire ? y_adv : 0;
@@ -183,7 +201,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void gru_scan_fwd128_kern
 }
 
 template <int NW>
-__global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void gru_scan_bwd128_kernel(const HpmnGruBwd a) {
+__global__ __launch_bounds__(64 * NW, 2) void gru_scan_bwd128_kernel(const HpmnGruBwd a) {
     constexpr int H = H128;
     constexpr int KQ = NW / 2, UW = 64 / KQ;
     constexpr int KC = H / KQ, KG = 2 * H / KQ;      // columns of wc / wg per lane part
@@ -211,9 +229,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void gru_scan_bwd128_kern
 
     const int period = a.period;
     const bool has_dy = a.d_y != nullptr;
-    const float *gb = a.gates + b * (long)T * 3 * H + j;
-    const float *hsb = a.hs + b * (long)(T + 1) * H + j;
-    const float *dyb = has_dy ? a.d_y + b * (long)(T / period) * H + j : a.d_h_last + b * a.d_h_last_stride + j;
+    // (uniform bases + the lane's 32-bit offset, as in the forward kernel: 263 -> <= 256 registers, two workgroups per CU)
+    const unsigned jo = (unsigned)j;
+    const float *gb = a.gates + b * (long)T * 3 * H;
+    const float *hsb = a.hs + b * (long)(T + 1) * H;
+    const float *dyb = has_dy ? a.d_y + b * (long)(T / period) * H : a.d_h_last + b * a.d_h_last_stride;
     const long dy_stride = has_dy ? H : 0;
     const int t_lo0 = a.t_begin;
     const int t_hi = a.t_end > 0 ? a.t_end : T;
@@ -224,13 +244,13 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void gru_scan_bwd128_kern
     bool gm[PF];
     auto fetch = [&](int t, int slot) {
         const int tc = t > 0 ? t : 0;
-        const float *row = gb + (long)tc * 3 * H;
-        gr[slot] = row[0];
-        gu[slot] = row[H];
-        gc[slot] = row[2 * H];
-        ghp[slot] = hsb[(long)tc * H];
+        const gfloat *row = sgpr_base(gb + (long)tc * 3 * H);
+        gr[slot] = row[jo];
+        gu[slot] = row[H + jo];
+        gc[slot] = row[2 * H + jo];
+        ghp[slot] = sgpr_base(hsb + (long)tc * H)[jo];
         const bool fire = has_dy && t == pf_fire && pf_row >= 0;
-        gdy[slot] = dyb[(long)(pf_row > 0 ? pf_row : 0) * dy_stride];
+        gdy[slot] = sgpr_base(dyb + (long)(pf_row > 0 ? pf_row : 0) * dy_stride)[jo];
         gm[slot] = fire;
         pf_row -= fire ? 1 : 0;
         pf_fire -= fire ? period : 0;
@@ -246,8 +266,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void gru_scan_bwd128_kern
     const float4 *brow = reinterpret_cast<const float4 *>(&bufB[KG * p]);
     // d_act stores split over the lane parts by select: (KQ = 2) p == 0 writes (da_r, da_u), p == 1 writes (dc_pre, dc_pre);
     // (KQ = 4) one value per part: da_r, da_u, dc_pre, dc_pre
-    float *da0 = a.d_act + (b * (long)T + (t_hi - 1)) * 3 * H + j + (KQ == 2 ? (p == 0 ? 0 : 2 * H) : (p < 2 ? p : 2) * H);
-    float *da1 = a.d_act + (b * (long)T + (t_hi - 1)) * 3 * H + j + (p == 0 ? H : 2 * H);
+    float *darow = a.d_act + (b * (long)T + (t_hi - 1)) * 3 * H;          // (uniform: the step's d_act row)
+    const unsigned da0o = jo + (KQ == 2 ? (p == 0 ? 0 : 2 * H) : (p < 2 ? p : 2) * H);
+    const unsigned da1o = jo + (p == 0 ? H : 2 * H);
 
     auto step = [&](int t, int slot) {
         const float r = gr[slot], ug = gu[slot], cc = gc[slot], hp = ghp[slot];
@@ -270,14 +291,15 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void gru_scan_bwd128_kern
         bcast_matvec<KG / 4, 2>(brow, wgT, e0, e1);
         e0 += e1;
         const float e = join_parts<KQ>(e0.x + e0.y);
-        if constexpr (KQ == 2) {
-            *da0 = p == 0 ? dar : dcp;
-            *da1 = p == 0 ? dau : dcp;
-            da0 -= 3 * H;
-            da1 -= 3 * H;
-        } else {
-            *da0 = p == 0 ? dar : (p == 1 ? dau : dcp);
-            da0 -= 3 * H;
+        {
+            gfloat *drow = sgpr_base(darow);
+            if constexpr (KQ == 2) {
+                drow[da0o] = p == 0 ? dar : dcp;
+                drow[da1o] = p == 0 ? dau : dcp;
+            } else {
+                drow[da0o] = p == 0 ? dar : (p == 1 ? dau : dcp);
+            }
+            darow -= 3 * H;
         }
         dh = fmaf(dh, ug, fmaf(drh, r, e));
     };
@@ -299,20 +321,50 @@ static int scan128_waves(int) {
     return env == 8 ? 8 : 4;
 }
 
+// The four-wave kernels fit 256 registers (r4: lane offsets against uniform bases), so TWO workgroups share a CU and a batch
+// of up to 2 x CUs sequences runs in one round.  `solo` launches pad the workgroup's LDS (unused dynamic LDS) to more than
+// half of the CU's, which caps the occupancy at one workgroup per CU again and leaves half of every CU's registers to a
+// kernel on another stream (the weight gradients beside the reverse scans).  HPMN_SCAN128_SOLO: bit 0 forward, bit 1 reverse.
+static int scan128_solo_mask() {
+    static const int env = [] { const char *e = getenv("HPMN_SCAN128_SOLO"); return e ? atoi(e) : HPMN_SCAN128_SOLO_DEFAULT; }();
+    return env;
+}
+template <typename K>
+static size_t solo_pad(K kernel, bool solo) {
+    if (!solo) return 0;
+    hipFuncAttributes fa = {};
+    const void *fn = reinterpret_cast<const void *>(kernel);
+    if (hipFuncGetAttributes(&fa, fn) != hipSuccess) return 0;
+    const size_t want = 82 * 1024;
+    const size_t q = fa.sharedSizeBytes < want ? want - fa.sharedSizeBytes : 0;
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q);
+    return q;
+}
+
 int gru_scan_fwd128_dispatch(const HpmnGruFwd &a, hipStream_t st) {
     if (scan128_waves(a.B) == 8) {
         if (a.hs != nullptr) hipLaunchKernelGGL((gru_scan_fwd128_kernel<true, 8>), dim3(a.B), dim3(512), 0, st, a);
         else                 hipLaunchKernelGGL((gru_scan_fwd128_kernel<false, 8>), dim3(a.B), dim3(512), 0, st, a);
     } else {
-        if (a.hs != nullptr) hipLaunchKernelGGL((gru_scan_fwd128_kernel<true, 4>), dim3(a.B), dim3(256), 0, st, a);
-        else                 hipLaunchKernelGGL((gru_scan_fwd128_kernel<false, 4>), dim3(a.B), dim3(256), 0, st, a);
+        const bool solo = (scan128_solo_mask() & 1) != 0;
+        if (a.hs != nullptr) {
+            static const size_t pad = solo_pad(gru_scan_fwd128_kernel<true, 4>, true);
+            hipLaunchKernelGGL((gru_scan_fwd128_kernel<true, 4>), dim3(a.B), dim3(256), solo ? pad : 0, st, a);
+        } else {
+            static const size_t pad = solo_pad(gru_scan_fwd128_kernel<false, 4>, true);
+            hipLaunchKernelGGL((gru_scan_fwd128_kernel<false, 4>), dim3(a.B), dim3(256), solo ? pad : 0, st, a);
+        }
     }
     return check_launch();
 }
 
 int gru_scan_bwd128_dispatch(const HpmnGruBwd &a, hipStream_t st) {
     if (scan128_waves(a.B) == 8) hipLaunchKernelGGL((gru_scan_bwd128_kernel<8>), dim3(a.B), dim3(512), 0, st, a);
-    else                         hipLaunchKernelGGL((gru_scan_bwd128_kernel<4>), dim3(a.B), dim3(256), 0, st, a);
+    else {
+        const bool solo = (scan128_solo_mask() & 2) != 0;
+        static const size_t pad = solo_pad(gru_scan_bwd128_kernel<4>, true);
+        hipLaunchKernelGGL((gru_scan_bwd128_kernel<4>), dim3(a.B), dim3(256), solo ? pad : 0, st, a);
+    }
     return check_launch();
 }
 

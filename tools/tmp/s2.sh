@@ -1,0 +1,17 @@
+export TMPDIR=/tmp
+o=gpurun_out/s2
+mkdir -p $o
+timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "h128 or 128" > $o/test_h128.txt 2>&1; echo "rc=$?" >> $o/test_h128.txt
+tail -3 $o/test_h128.txt
+for m in 3 2 0 1; do
+  SWEEP_CONFIG=c4 sh tools/env_sweep.sh $o/sweep "HPMN_SCAN128_SOLO=$m"
+done
+SWEEP_CONFIG=c4 sh tools/env_sweep.sh $o/sweep "HPMN_SCAN128_SOLO=0 HPMN_EARLY_PASS=bwd"
+for m in 3 0; do
+HPMN_SCAN128_SOLO=$m timeout 600 python bench.py --config c4 --steps 20 --warmup 3 --no-cpu-baseline --no-roofline --no-auc --no-parity-gate > $o/bench_c4_solo$m.json 2>$o/bench_c4_solo$m.err
+python -c "
+import json
+d=json.load(open('$o/bench_c4_solo$m.json')); print('solo$m', round(d['ms_per_step'],4), d.get('eval_sequences_per_s'), (d.get('eval_pass') or {}).get('sequences_per_s'))"
+done
+HPMN_SCAN128_SOLO=0 BENCH_ARGS="--config c4 --steps 10 --warmup 3 --no-parity-gate --no-eval" sh tools/profile_step.sh $o/c4 > /dev/null 2>&1
+rm -rf $o/c4/prof
