@@ -80,6 +80,14 @@ __device__ __forceinline__ void pair_chain_wave(const HpmnGruFusedFwd &a, SeqLds
     float xr = S.ring[0][l], xu = S.ring[0][H + l], xcand = S.ring[0][2 * H + l];
 
     auto step = [&](int t, int p) {
+        // The lane index is RECOMPUTED in every step (two v_mbcnt, opaque to the optimiser): with 192 stationary weights and the
+        // LDS read groups the loop has no register left for loop-invariant address terms, and the training instantiations that
+        // start at layer 0 kept `lane` and its k-group offset in SCRATCH -- a scratch_load + s_waitcnt vmcnt(0) in every step
+        // of the serial chain (tools/check_resources.py reports the kernel's scratch, the ISA shows where it is touched).
+        int lane, l;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+        __builtin_assume(lane >= 0 && lane < 64);
+        l = lane;
         float sr, su;
         split_matvec2x(&S.hb[p][0], whr, whu, lane, sr, su);
         const float r = sigmoid_scaled(xr + sr);

@@ -329,6 +329,17 @@ static int scan128_solo_mask() {
     static const int env = [] { const char *e = getenv("HPMN_SCAN128_SOLO"); return e ? atoi(e) : HPMN_SCAN128_SOLO_DEFAULT; }();
     return env;
 }
+// (a batch that fits one workgroup per CU is spread that way: left to the dispatcher, 250 workgroups doubled up on some CUs
+//  while others stayed empty -- C4 at B = 250: 4.83 vs 4.77 ms/step)
+static bool scan128_fits_one_per_cu(int B) {
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return 256;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return 256;
+        return n;
+    }();
+    return B <= cus;
+}
 template <typename K>
 static size_t solo_pad(K kernel, bool solo) {
     if (!solo) return 0;
@@ -346,7 +357,7 @@ int gru_scan_fwd128_dispatch(const HpmnGruFwd &a, hipStream_t st) {
         if (a.hs != nullptr) hipLaunchKernelGGL((gru_scan_fwd128_kernel<true, 8>), dim3(a.B), dim3(512), 0, st, a);
         else                 hipLaunchKernelGGL((gru_scan_fwd128_kernel<false, 8>), dim3(a.B), dim3(512), 0, st, a);
     } else {
-        const bool solo = (scan128_solo_mask() & 1) != 0;
+        const bool solo = (scan128_solo_mask() & 1) != 0 || scan128_fits_one_per_cu(a.B);
         if (a.hs != nullptr) {
             static const size_t pad = solo_pad(gru_scan_fwd128_kernel<true, 4>, true);
             hipLaunchKernelGGL((gru_scan_fwd128_kernel<true, 4>), dim3(a.B), dim3(256), solo ? pad : 0, st, a);
@@ -361,7 +372,7 @@ int gru_scan_fwd128_dispatch(const HpmnGruFwd &a, hipStream_t st) {
 int gru_scan_bwd128_dispatch(const HpmnGruBwd &a, hipStream_t st) {
     if (scan128_waves(a.B) == 8) hipLaunchKernelGGL((gru_scan_bwd128_kernel<8>), dim3(a.B), dim3(512), 0, st, a);
     else {
-        const bool solo = (scan128_solo_mask() & 2) != 0;
+        const bool solo = (scan128_solo_mask() & 2) != 0 || scan128_fits_one_per_cu(a.B);
         static const size_t pad = solo_pad(gru_scan_bwd128_kernel<4>, true);
         hipLaunchKernelGGL((gru_scan_bwd128_kernel<4>), dim3(a.B), dim3(256), solo ? pad : 0, st, a);
     }

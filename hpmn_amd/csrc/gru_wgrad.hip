@@ -257,16 +257,18 @@ __global__ __launch_bounds__(32 * RED_G) void wgrad_reduce_kernel(const float *_
 int gru_dx_dispatch(const HpmnGruWgrad &a, hipStream_t st);   // input_proj.hip (row-wise MFMA)
 bool gru_wgrad_bf16_launch(const HpmnGruWgrad &k, int nwg, bool solo, hipStream_t st);   // gru_wgrad_bf16.hip
 
-static int wgrad_seq_per_wg(int T) {   // T = steps per sequence in this launch
+static int wgrad_seq_per_wg(int T, int H) {   // T = steps per sequence in this launch
     // (HPMN_WGRAD_MIN_ROWS: every workgroup writes a slab of (D + H + 1) 3H floats -- 98 KB at H = D = 64 -- and the reduction
-    //  reads it back; for the short top layers the slabs outweigh the rows they summarise)
-    static const int min_rows = [] { const char *e = getenv("HPMN_WGRAD_MIN_ROWS"); return e && atoi(e) > 0 ? atoi(e) : WG_MIN_ROWS; }();
+    //  reads it back; for the short top layers the slabs outweigh the rows they summarise.  H = 128: a slab is 395 KB and the
+    //  launch has three column groups' worth of workgroups anyway: 1024 rows -- C4 7.44 -> 7.34 ms/step)
+    static const int env_rows = [] { const char *e = getenv("HPMN_WGRAD_MIN_ROWS"); return e && atoi(e) > 0 ? atoi(e) : 0; }();
+    const int min_rows = env_rows > 0 ? env_rows : (H >= 128 ? 1024 : WG_MIN_ROWS);
     int spw = (min_rows + T - 1) / T;
     return spw < 1 ? 1 : spw;
 }
 
 size_t gru_wgrad_workspace_bytes(int B, int T, int D, int H) {
-    const int spw = wgrad_seq_per_wg(T);
+    const int spw = wgrad_seq_per_wg(T, H);
     const long nwg = (B + spw - 1) / spw;
     return (size_t)nwg * (size_t)wgrad_slab_floats(D, H) * sizeof(float);
 }
@@ -274,7 +276,7 @@ size_t gru_wgrad_workspace_bytes(int B, int T, int D, int H) {
 template <int HT, int DT, int CS = 1>
 static int launch_wgrad(const HpmnGruWgrad &a, hipStream_t st) {
     HpmnGruWgrad k = a;
-    k.seq_per_wg = wgrad_seq_per_wg(a.t_len > 0 ? a.t_len : a.T);
+    k.seq_per_wg = wgrad_seq_per_wg(a.t_len > 0 ? a.t_len : a.T, a.H);
     // One weight-gradient workgroup per CU while the launch shares the chip with a reverse scan (every layer but the
     // longest): two of them take every register of a CU, and the single-wave workgroups of the next reverse scan --
     // the serial chain -- then cannot even be dispatched until they retire.  Padding the workgroup's LDS to 82 KiB with

@@ -52,12 +52,13 @@ __host__ __device__ inline long wgrad_slab_floats_bf(int D, int H) { return (lon
 // accumulator tiles would be 192 registers; each group stages only ITS columns of d_act (plus x, h_prev, r: re-read per group,
 // as in the fp32 kernel).
 template <int HT, int DT, int CS, int W>
-__device__ __forceinline__ void wgrad_bf16_wave(const HpmnGruWgrad &a, bf8 (*img)[DT + 2 * HT + 3 * HT / CS][2][64]) {
+__device__ __forceinline__ void wgrad_bf16_wave(const HpmnGruWgrad &a, bf8 (*img)[DT + 2 * HT + 3 * HT / CS][2][64], const int bx,
+                                                const int by) {
     constexpr int H = 32 * HT;
     constexpr int NJ = 3 * HT / CS;            // 32-column tiles of d_act held by this workgroup
     constexpr int NW = HT + DT;                // waves
     constexpr int NBLK = DT + 2 * HT + NJ;
-    const int jb = blockIdx.y * NJ;            // first (global) column tile
+    const int jb = by * NJ;                    // first (global) column tile
     constexpr int MAXT = (NBLK - W + NW - 1) / NW;   // staging tasks of this wave: blocks W, W + NW, ...
     constexpr bool role_x = W < DT;
     constexpr int tile = role_x ? W : W - DT;
@@ -75,7 +76,7 @@ __device__ __forceinline__ void wgrad_bf16_wave(const HpmnGruWgrad &a, bf8 (*img
 #pragma unroll
     for (int i = 0; i < MAXT; ++i) bsum[i] = 0.f;
 
-    const int b_begin = blockIdx.x * a.seq_per_wg;
+    const int b_begin = bx * a.seq_per_wg;
     const int b_end = (b_begin + a.seq_per_wg) < a.B ? (b_begin + a.seq_per_wg) : a.B;
     const int tb = a.t_begin, te = a.t_len > 0 ? a.t_begin + a.t_len : T;
     const int ipt = (te - tb + BR - 1) / BR;
@@ -179,7 +180,7 @@ __device__ __forceinline__ void wgrad_bf16_wave(const HpmnGruWgrad &a, bf8 (*img
 
     // ---- epilogue: this workgroup's partial slab (summed by wgrad_reduce_kernel), C/D layout of the 32x32 instructions:
     //      rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column lane & 31
-    float *slab = a.workspace + (long)blockIdx.x * wgrad_slab_floats_bf(D, H);
+    float *slab = a.workspace + (long)bx * wgrad_slab_floats_bf(D, H);
     float *s_wg = slab, *s_bg = slab + (long)(D + H) * 2 * H, *s_wc = s_bg + 2 * H;
     float *s_bc = s_wc + (long)(D + H) * H;
     const int row_base = role_x ? 32 * tile : D + 32 * tile;
@@ -209,23 +210,43 @@ __device__ __forceinline__ void wgrad_bf16_wave(const HpmnGruWgrad &a, bf8 (*img
     }
 }
 
-template <int HT, int DT, int CS>
+template <int HT, int DT, int CS, bool XCD = true>
 __global__ __launch_bounds__(64 * (HT + DT), (HT + DT) > 5 ? 1 : 2) void gru_wgrad_bf16_kernel(const HpmnGruWgrad a) {
     static_assert((3 * HT) % CS == 0 && HT + DT <= 8, "column tiles split evenly; at most eight waves");
     __shared__ __attribute__((aligned(16))) bf8 img[2][DT + 2 * HT + 3 * HT / CS][2][64];
     const int wave = threadIdx.x >> 6;          // (wave-uniform: one dispatch, then straight-line code per wave)
     constexpr int NW = HT + DT;
-    if (wave == 0) wgrad_bf16_wave<HT, DT, CS, 0>(a, img);
-    else if (wave == 1) wgrad_bf16_wave<HT, DT, CS, 1>(a, img);
-    else if (wave == 2) wgrad_bf16_wave<HT, DT, CS, 2>(a, img);
+    // The CS column groups of a sequence range read the SAME x / h_prev / r rows.  Linear workgroup id L runs on XCD L % 8
+    // (observed dispatch rule, used for speed only), and every XCD has its own L2: a 1-D grid with
+    //     L = ((bx / 8) * CS + by) * 8 + bx % 8
+    // puts a range's column groups on ONE XCD, 8 ids apart in dispatch order -- they start together, do the same work per tile
+    // and stream the shared rows at the same pace, so the second and third reader of a row find it in that XCD's L2.
+    // (The 2-D grid had them on linear ids bx, bx + nwg, bx + 2 nwg: different XCDs unless nwg % 8 == 0, and dispatched a
+    //  whole grid row apart.)
+    int bx = blockIdx.x, by = 0;
+    if constexpr (CS > 1) {
+        if constexpr (XCD) {
+            const int L = blockIdx.x, xcd = L & 7, slot = L >> 3;
+            by = slot % CS;
+            bx = (slot / CS) * 8 + xcd;
+        } else {                                 // (HPMN_WGRAD_XCD=0: column group after column group, the 2-D grid's order)
+            const int n8 = gridDim.x / CS;
+            by = blockIdx.x / n8;
+            bx = blockIdx.x - by * n8;
+        }
+        if (bx * a.seq_per_wg >= a.B) return;    // (the grid is rounded up to whole groups of 8 ranges)
+    }
+    if (wave == 0) wgrad_bf16_wave<HT, DT, CS, 0>(a, img, bx, by);
+    else if (wave == 1) wgrad_bf16_wave<HT, DT, CS, 1>(a, img, bx, by);
+    else if (wave == 2) wgrad_bf16_wave<HT, DT, CS, 2>(a, img, bx, by);
     else if constexpr (NW > 3) {
-        if (wave == 3) wgrad_bf16_wave<HT, DT, CS, 3>(a, img);
+        if (wave == 3) wgrad_bf16_wave<HT, DT, CS, 3>(a, img, bx, by);
         else if constexpr (NW > 4) {
-            if (wave == 4) wgrad_bf16_wave<HT, DT, CS, 4>(a, img);
+            if (wave == 4) wgrad_bf16_wave<HT, DT, CS, 4>(a, img, bx, by);
             else if constexpr (NW > 5) {
-                if (wave == 5) wgrad_bf16_wave<HT, DT, CS, 5>(a, img);
-                else if (wave == 6) wgrad_bf16_wave<HT, DT, CS, 6>(a, img);
-                else wgrad_bf16_wave<HT, DT, CS, 7>(a, img);
+                if (wave == 5) wgrad_bf16_wave<HT, DT, CS, 5>(a, img, bx, by);
+                else if (wave == 6) wgrad_bf16_wave<HT, DT, CS, 6>(a, img, bx, by);
+                else wgrad_bf16_wave<HT, DT, CS, 7>(a, img, bx, by);
             }
         }
     }
@@ -239,7 +260,7 @@ static void launch_bf16(const HpmnGruWgrad &k, int nwg, bool solo, hipStream_t s
     if (solo) {
         static const size_t p = [] {
             hipFuncAttributes fa = {};
-            const void *fn = reinterpret_cast<const void *>(gru_wgrad_bf16_kernel<HT, DT, CS>);
+            const void *fn = reinterpret_cast<const void *>(gru_wgrad_bf16_kernel<HT, DT, CS, true>);
             if (hipFuncGetAttributes(&fa, fn) != hipSuccess) return (size_t)0;
             const size_t want = 82 * 1024;
             const size_t q = fa.sharedSizeBytes < want ? want - fa.sharedSizeBytes : 0;
@@ -248,7 +269,12 @@ static void launch_bf16(const HpmnGruWgrad &k, int nwg, bool solo, hipStream_t s
         }();
         pad = p;
     }
-    hipLaunchKernelGGL((gru_wgrad_bf16_kernel<HT, DT, CS>), dim3((unsigned)nwg, CS), dim3(64 * (HT + DT)), pad, st, k);
+    const unsigned grid = CS > 1 ? (unsigned)((nwg + 7) / 8) * 8u * CS : (unsigned)nwg;
+    static const int xcd_env = [] { const char *e = getenv("HPMN_WGRAD_XCD"); return e ? atoi(e) : 1; }();
+    if (CS > 1 && !xcd_env)
+        hipLaunchKernelGGL((gru_wgrad_bf16_kernel<HT, DT, CS, false>), dim3(grid), dim3(64 * (HT + DT)), pad, st, k);
+    else
+        hipLaunchKernelGGL((gru_wgrad_bf16_kernel<HT, DT, CS, true>), dim3(grid), dim3(64 * (HT + DT)), pad, st, k);
 }
 
 // H = 64 with D <= 64, H = 128 with D = 32 / 128.  Returns false when the shape is not served (the caller keeps the fp32 kernel).

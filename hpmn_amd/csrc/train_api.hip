@@ -595,13 +595,25 @@ int hpmn_scan_bwd(HpmnTrainCtx *ctx, const HpmnScanDesc *d, const void *ids, con
         // layers (<= 128 steps: 30-80 us of weight-gradient work each) share the fork of the layer below them.
         // (Only where a long chain is still ahead to hide them under: with short sequences -- Amazon: 100 steps -- holding
         // them back just moves them into the tail.)
+        // H = 128 (r4): the scans fill every register of the chip now (two workgroups per CU), so a weight gradient forked beside
+        // one mostly waits for it and the big ones -- layers 1 and 0 -- end up one behind the other in the step's tail, each
+        // latency-bound on its own at ~2.3 TB/s.  HPMN_WGRAD_ALTERNATE=1: layers alternate between the two helper streams (each
+        // with its own slab buffer, the reduction behind its launch on the same stream) so that neighbours overlap -- measured
+        // NEUTRAL (C4 7.52 vs 7.39-7.68 ms/step: two weight gradients resident when a scan launches take its CUs, layer 0's scan
+        // 1430 instead of 1100 us), default off.
+        static const int alt_env = [] { const char *e = getenv("HPMN_WGRAD_ALTERNATE"); return e ? atoi(e) : 0; }();
+        const bool alternate = alt_env && d->H == 128 && L.wgrad_ws_layer[1] != 0 && cut0 == 0;
+        if (alternate && (i & 1) == 0) w.workspace = F(L.wgrad_ws_layer[1]);
         held[nheld++] = w;
         if (L.T[i] > 128 || L.T[0] < 512 || i == 0 || nheld == 4) {
             HIPCHK(hipEventRecord(c->fork, st));
             HIPCHK(hipStreamWaitEvent(c->side, c->fork, 0));
+            if (alternate) HIPCHK(hipStreamWaitEvent(c->side2, c->fork, 0));
             for (int h = 0; h < nheld; ++h) {
-                rc = hpmn_gru_param_grads(&held[h], c->side);
+                const bool second = alternate && held[h].workspace == F(L.wgrad_ws_layer[1]);
+                rc = hpmn_gru_param_grads(&held[h], second ? c->side2 : c->side);
                 if (rc != HPMN_OK) return rc;
+                if (second) c->pending2 = true;
             }
             nheld = 0;
             c->pending = true;

@@ -1,6 +1,13 @@
-"""Register / scratch report of every product kernel (cross-compiles each .hip to gfx950 assembly and reads the
-kernel metadata).  Anything with scratch or spills deserves a look: the scan and read kernels went 15-40 %
-slower more than once from an innocent-looking change that pushed them over a register cliff.
+"""Register / scratch / occupancy report of every product kernel (cross-compiles each .hip to gfx950 assembly and reads the
+kernel metadata and the compiler's "Kernel info" comments).  Anything with scratch or spills deserves a look: the scan and
+read kernels went 15-40 % slower more than once from an innocent-looking change that pushed them over a register cliff.
+
+Two things the plain register count hides (round 4, both found in the ISA, both cost double-digit percentages):
+  * OCCUPANCY CLIFFS: arch VGPRs + AGPRs share 512 registers per SIMD lane, so 257-264 of them mean ONE wave per SIMD where 256
+    mean two.  The four-wave H = 128 scans sat at 259-263 ("256 VGPRs + a few AGPRs"): a batch of 500 sequences ran as two
+    rounds of 256 workgroups.  Kernels within 8 registers ABOVE a boundary (128 / 168 / 256) are marked "<-- cliff".
+  * SCRATCH INSIDE LOOPS: a few spilled dwords are harmless in a prologue and poison in a serial chain's loop (a scratch_load
+    and its s_waitcnt vmcnt(0) per step).  Loops (backward branches) that touch scratch are listed per kernel.
 Usage: python tools/check_resources.py [--fail-on-scratch]"""
 import glob
 import os
@@ -23,6 +30,27 @@ def demangle(names):
         return names
 
 
+def kernel_info(text):
+    """mangled name -> (arch VGPRs + AGPRs, waves per SIMD, [(first, last) line of every loop that touches scratch])."""
+    out = {}
+    for m in re.finditer(r"^(_Z\w+):\s*; @.*?^; TotalNumVgprs: (\d+).*?^; Occupancy: (\d+)", text, re.S | re.M):
+        body = text[m.start():m.end()].split("\n")
+        labels, loops = {}, []
+        for i, line in enumerate(body):
+            lm = re.match(r"^(\.LBB\d+_\d+):", line)
+            if lm:
+                labels[lm.group(1)] = i
+        for i, line in enumerate(body):
+            bm = re.search(r"s_c?branch\w* (\.LBB\d+_\d+)", line)
+            if bm and labels.get(bm.group(1), i) < i:
+                a = labels[bm.group(1)]
+                # (role-dispatch kernels are one big pseudo-loop over thousands of lines: only real, inner loops count)
+                if i - a < 3000 and any("scratch_" in x for x in body[a:i + 1]):
+                    loops.append((a, i))
+        out[m.group(1)] = (int(m.group(2)), int(m.group(3)), loops)
+    return out
+
+
 def main():
     bad = 0
     with tempfile.TemporaryDirectory() as tmp:
@@ -39,12 +67,18 @@ def main():
                 print("%-58s %d flat_load/store/atomic instruction(s)  <-- generic-pointer access" % (os.path.basename(src), nflat))
             rows = PAT.findall(text)
             names = demangle([r[0] for r in rows])
+            info = kernel_info(text)
             for name, r in zip(names, rows):
                 scratch, sgpr, sspill, vgpr, vspill = map(int, r[1:])
+                tot, occ, loops = info.get(r[0], (vgpr, 0, []))
                 flag = "  <-- scratch/spill" if (scratch or vspill) else ""
+                if any(b < tot <= b + 8 for b in (128, 168, 256)):
+                    flag += "  <-- cliff (%d registers over an occupancy boundary)" % min(tot - b for b in (128, 168, 256) if tot > b)
+                if loops:
+                    flag += "  <-- scratch inside %d loop(s), lines %s" % (len(loops), ",".join("%d-%d" % ab for ab in loops[:3]))
                 bad += 1 if (scratch or vspill) else 0
-                print("%-58s vgpr %3d  sgpr %3d  scratch %4d  vspill %3d  sspill %3d%s"
-                      % (name[:58], vgpr, sgpr, scratch, vspill, sspill, flag))
+                print("%-58s vgpr+agpr %3d  occ %d  sgpr %3d  scratch %4d  vspill %3d  sspill %3d%s"
+                      % (name[:58], tot, occ, sgpr, scratch, vspill, sspill, flag))
     print("%d kernel(s) with scratch or VGPR spills" % bad)
     return 1 if (bad and "--fail-on-scratch" in sys.argv) else 0
 

@@ -1,0 +1,9 @@
+export TMPDIR=/tmp
+o=gpurun_out/s7
+mkdir -p $o
+timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -x > $o/test_parity.txt 2>&1; echo "rc=$?" >> $o/test_parity.txt
+tail -3 $o/test_parity.txt
+SWEEP_CONFIG=c2 sh tools/env_sweep.sh $o/sweep_c2 "-"
+SWEEP_CONFIG=c3 sh tools/env_sweep.sh $o/sweep_c3 "-" "HPMN_PAIR_FWD=1" "HPMN_PAIR_FWD=1 HPMN_EARLY_PASS=bwd"
+BENCH_ARGS="--config c2 --steps 20 --warmup 3 --no-parity-gate --no-eval" sh tools/profile_step.sh $o/c2 > /dev/null 2>&1
+rm -rf $o/c2/prof
