@@ -59,7 +59,11 @@ __device__ __forceinline__ void wgrad_bf16_wave(const HpmnGruWgrad &a, bf8 (*img
     constexpr int NW = HT + DT;                // waves
     constexpr int NBLK = DT + 2 * HT + NJ;
     const int jb = by * NJ;                    // first (global) column tile
-    constexpr int MAXT = (NBLK - W + NW - 1) / NW;   // staging tasks of this wave: blocks W, W + NW, ...
+    // staging TASKS: [0, DT) the x blocks, [DT, DT + HT) one per 32 state columns -- h_prev is loaded ONCE and parked twice, as
+    // h_prev and as r * h_prev (two blocks of the image; r4: they were two tasks with two loads of the same rows) --, then the
+    // NJ d_act blocks
+    constexpr int NTASK = DT + HT + NJ;
+    constexpr int MAXT = (NTASK - W + NW - 1) / NW;  // staging tasks of this wave: tasks W, W + NW, ...
     constexpr bool role_x = W < DT;
     constexpr int tile = role_x ? W : W - DT;
 
@@ -85,7 +89,7 @@ __device__ __forceinline__ void wgrad_bf16_wave(const HpmnGruWgrad &a, bf8 (*img
     // raw (unconverted) values of this wave's staging tasks for one tile.  Nothing is computed on them at load time -- not even
     // the zeroing of rows beyond the range (clamped addresses; the mask is recomputed from the tile index when the tile is
     // parked) -- so that two tiles' worth of them can be in flight without anything waiting on a load.
-    constexpr bool has_rh = (W >= 0) && ([] { for (int i = 0; i < MAXT; ++i) { const int q = W + i * NW; if (q >= DT + HT && q < DT + 2 * HT) return true; } return false; }());
+    constexpr bool has_rh = (W >= 0) && ([] { for (int i = 0; i < MAXT; ++i) { const int q = W + i * NW; if (q >= DT && q < DT + HT) return true; } return false; }());
     struct Raw { float v[MAXT][8]; float r2[has_rh ? 8 : 1]; };
     auto load_raw = [&](int it, Raw &g) {
         const int b = b_begin + it / ipt;
@@ -104,16 +108,12 @@ __device__ __forceinline__ void wgrad_bf16_wave(const HpmnGruWgrad &a, bf8 (*img
             } else if (q < DT + HT) {
                 const int col = 32 * (q - DT) + c;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) g.v[i][j] = a.hs[(rowx[j] + b) * H + col];       // hs has T + 1 rows per sequence
-            } else if (q < DT + 2 * HT) {
-                const int col = 32 * (q - DT - HT) + c;
-#pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    g.v[i][j] = a.hs[(rowx[j] + b) * H + col];
+                    g.v[i][j] = a.hs[(rowx[j] + b) * H + col];       // hs has T + 1 rows per sequence
                     g.r2[j] = a.gates[rowx[j] * 3 * H + col];
                 }
             } else {
-                const int col = 32 * (jb + q - DT - 2 * HT) + c;
+                const int col = 32 * (jb + q - DT - HT) + c;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) g.v[i][j] = a.d_act[rowx[j] * 3 * H + col];
             }
@@ -127,16 +127,23 @@ __device__ __forceinline__ void wgrad_bf16_wave(const HpmnGruWgrad &a, bf8 (*img
             float v[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                float x = g.v[i][j];
-                if (q >= DT + HT && q < DT + 2 * HT) x *= g.r2[j];                  // r * h_prev (not stored by the forward)
                 bool live = (t0 + j) < te;
                 if (q < DT) live = live && (32 * q + c) < D;
-                v[j] = live ? x : 0.f;
+                v[j] = live ? g.v[i][j] : 0.f;
             }
+            const int blk = q < DT + HT ? q : q + HT;                               // image block: x | h_prev | (r h_prev) | d_act
             const Frag f = split8(v);
-            img[buf][q][0][lane] = f.hi;
-            img[buf][q][1][lane] = f.lo;
-            if (q >= DT + 2 * HT) {
+            img[buf][blk][0][lane] = f.hi;
+            img[buf][blk][1][lane] = f.lo;
+            if (q >= DT && q < DT + HT) {                                           // r * h_prev (not stored by the forward)
+                float w[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) w[j] = v[j] * g.r2[j];
+                const Frag f2 = split8(w);
+                img[buf][q + HT][0][lane] = f2.hi;
+                img[buf][q + HT][1][lane] = f2.lo;
+            }
+            if (q >= DT + HT) {
                 float s = 0.f;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) s += v[j];
@@ -200,8 +207,8 @@ __device__ __forceinline__ void wgrad_bf16_wave(const HpmnGruWgrad &a, bf8 (*img
 #pragma unroll
     for (int i = 0; i < MAXT; ++i) {
         const int q = W + i * NW;
-        if (q < DT + 2 * HT) continue;
-        const int j = jb + q - DT - 2 * HT;
+        if (q < DT + HT) continue;
+        const int j = jb + q - DT - HT;
         const float tot = bsum[i] + __shfl_xor(bsum[i], 32);     // the two half-waves hold rows 0-7 / 8-15 of every tile
         if (kg == 0) {
             if (j < 2 * HT) s_bg[32 * j + c] = tot;

@@ -390,6 +390,105 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void gru_dx_bf16_kernel(const Hpm
     }
 }
 
+// D = 128 (NS = 4 column slices = the four waves of a workgroup, all on the SAME row tile): the row-per-lane loads above are
+// issued four times per tile -- every load instruction touches 32 rows (32 different 128-byte lines, 32 bytes of each), the four
+// waves' rings together are three times the CU's vector L1, and every wave splits the same values again: the launch ran at
+// ~9 us per 32-row tile, 1.85 TB/s on 0.5 GB (layer 1 of C4: 284 us on the serial chain between two reverse scans) where its
+// matrix instructions need 1 us.  Here the WORKGROUP stages a tile once: 256 threads load its 48 KB fully coalesced (four
+// adjacent lanes = one row's 128-byte line), split each 8-float fragment once, and park (hi, lo) in LDS in the B operand's
+// lane order; the four waves read their k-steps from there (two ds_read_b128 per k-step) against their stationary weights.
+// Two LDS buffers, the next tile's loads in flight underneath the current tile's 72 matrix instructions, one barrier per tile.
+// LDS slot of fragment (row, ks, p): plane ks, slot ((row + 4 (2 (ks & 1) + p)) & 31) + 32 p -- the rotation by 4 rows per
+// fragment-of-a-line puts the 16 lanes of a write group (4 rows x the 4 fragments of a line) on 16 different bank quads; a
+// reader's 16 consecutive rows of one (ks, p) are consecutive slots either way.
+template <int K>
+__global__ __launch_bounds__(64 * RW_WAVES, 1) void gru_dx_bf16_lds_kernel(const HpmnGruWgrad a) {
+    constexpr int KS = K / 16;                      // k-steps per tile (24)
+    constexpr int FPT = 32 * KS * 2 / (64 * RW_WAVES);   // fragments a thread stages per tile (6)
+    static_assert(RW_WAVES == 4 && (32 * KS * 2) % (64 * RW_WAVES) == 0 && KS % 2 == 0, "four column slices, whole passes");
+    extern __shared__ __attribute__((aligned(16))) char dx_smem[];
+    dbf8 (*img)[KS][2][64] = reinterpret_cast<dbf8 (*)[KS][2][64]>(dx_smem);      // [buffer][k-step][hi | lo][slot]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int c = lane & 31, p = lane >> 5;
+    const int D = a.D;
+    const int TL = a.t_len > 0 ? a.t_len : a.T;
+    const unsigned M = (unsigned)a.B * (unsigned)TL;
+    const unsigned ntile = (M + 31u) / 32u;
+    auto flat_row = [&](unsigned r) -> unsigned { const unsigned b = r / (unsigned)TL; return b * a.T + a.t_begin + (r - b * TL); };
+    const int n_base = wv * 32;
+
+    dbf8 wh[KS], wl[KS];
+    {
+        const int d = n_base + c;
+        const long dr = d < D ? d : D - 1;          // (columns past D are clamped: computed, never stored)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int j = 16 * ks + 8 * p;
+            const float *src = j < 2 * (K / 3) ? a.wg + dr * 2 * (K / 3) + j : a.wc + dr * (K / 3) + (j - 2 * (K / 3));
+            dx_split8(*reinterpret_cast<const float4 *>(src), *reinterpret_cast<const float4 *>(src + 4), wh[ks], wl[ks]);
+        }
+    }
+    // staging role of this thread: row (tid >> 2) & 31 of the tile, fragments q = 8 j + 4 (tid >> 7) + (tid & 3), j < FPT
+    const int s_row = (tid >> 2) & 31, s_sub = tid & 3, s_grp = tid >> 7;
+    const int s_slot = ((s_row + 4 * s_sub) & 31) + 32 * (s_sub & 1);
+    float4 raw[FPT][2];
+    auto load_tile = [&](unsigned tile) {
+        unsigned rr = tile * 32u + (unsigned)s_row;
+        rr = rr < M ? rr : M - 1u;                  // (clamped: loaded, multiplied, never stored)
+        const float *src = a.d_act + (long)flat_row(rr) * K + 8 * (4 * s_grp + s_sub);
+#pragma unroll
+        for (int j = 0; j < FPT; ++j) {
+            raw[j][0] = *reinterpret_cast<const float4 *>(src + 64 * j);
+            raw[j][1] = *reinterpret_cast<const float4 *>(src + 64 * j + 4);
+        }
+    };
+    auto park_tile = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < FPT; ++j) {
+            const int ks = 4 * j + 2 * s_grp + (s_sub >> 1);       // q / 2, q = 8 j + 4 s_grp + s_sub
+            dbf8 hi, lo;
+            dx_split8(raw[j][0], raw[j][1], hi, lo);
+            img[buf][ks][0][s_slot] = hi;
+            img[buf][ks][1][s_slot] = lo;
+        }
+    };
+    auto barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+    unsigned tile = blockIdx.x;
+    if (tile >= ntile) return;
+    load_tile(tile);
+    park_tile(0);
+    barrier();
+    int buf = 0;
+    for (; tile < ntile; tile += gridDim.x, buf ^= 1) {
+        const unsigned nxt = tile + gridDim.x < ntile ? tile + gridDim.x : tile;    // (the last tile once more: no branch around loads)
+        load_tile(nxt);
+        asm volatile("" ::: "memory");              // (the loads stay HERE: left alone they sink below the matrix instructions, to their uses)
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int slot = ((c + 4 * (2 * (ks & 1) + p)) & 31) + 32 * p;
+            const dbf8 xh = img[buf][ks][0][slot], xl = img[buf][ks][1][slot];
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[ks], xh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[ks], xl, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[ks], xh, acc, 0, 0, 0);
+        }
+        {   // transposed product (file header): lane (c, p) owns row tile*32 + c, columns 8 g + 4 p + 0..3 of this wave's 32
+            unsigned rr = tile * 32u + (unsigned)c;
+            rr = rr < M ? rr : M - 1u;
+            float *dst = a.d_x + (long)flat_row(rr) * D + n_base + 4 * p;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                if (n_base + 8 * g + 4 * p < D)
+                    *reinterpret_cast<float4 *>(dst + 8 * g) = make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+        }
+        park_tile(buf ^ 1);
+        barrier();
+    }
+}
+
 // The forward's input projection at H = 128 with a 128-wide input (the upper layers of configs[4]) the same way: the fp32 form
 // is 195 matrix instructions of 64 cycles per 32-row tile and wave (12.5 k cycles; 268 us for the 250 k rows of layer 1, on the
 // serial chain in front of that layer's scan), here 8 k-steps x 3 column tiles x 3 products of 32 cycles = 2304, and the launch
@@ -563,6 +662,23 @@ static bool dx_bf16() {
     return on != 0;
 }
 
+// HPMN_DX_LDS=0: D = 128 through the row-per-lane kernel as well; HPMN_DX_LDS_GRID: workgroups of the staged form (default: CUs)
+static bool dx_lds() {
+    static const int on = [] { const char *e = getenv("HPMN_DX_LDS"); return e ? atoi(e) : 1; }();
+    return on != 0;
+}
+static long dx_lds_grid() {
+    static const long n = [] {
+        const char *e = getenv("HPMN_DX_LDS_GRID");
+        if (e && atol(e) > 0) return atol(e);
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return 256L;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return 256L;
+        return (long)cus;
+    }();
+    return n;
+}
+
 int gru_dx_dispatch(const HpmnGruWgrad &a, hipStream_t st) {
     const long rows = (long)a.B * (a.t_len > 0 ? a.t_len : a.T);
     const int DT = (a.D + 31) / 32;
@@ -573,6 +689,18 @@ int gru_dx_dispatch(const HpmnGruWgrad &a, hipStream_t st) {
     else if (a.H == 64 && DT == 1) hipLaunchKernelGGL((gru_dx_kernel<192, 1, 1, true>), dim3(rowwise_grid(rows, 1)), blk, 0, st, a);
     else if (a.H == 64 && DT == 2) hipLaunchKernelGGL((gru_dx_kernel<192, 2, 1, true>), dim3(rowwise_grid(rows, 1)), blk, 0, st, a);
     else if (a.H == 128 && DT == 1 && dx_bf16()) hipLaunchKernelGGL((gru_dx_bf16_kernel<384, 1>), dim3(rowwise_grid(rows, 1)), blk, 0, st, a);
+    else if (a.H == 128 && DT == 4 && dx_bf16() && dx_lds()) {
+        // (the workgroup-staged form: one tile per workgroup at a time, persistent over the CUs)
+        constexpr int lds = 2 * 24 * 2 * 64 * 16;
+        static const bool attr = [] {
+            return hipFuncSetAttribute(reinterpret_cast<const void *>(gru_dx_bf16_lds_kernel<384>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
+        }();
+        (void)attr;
+        const long ntile = (rows + 31) / 32;
+        const unsigned grid = (unsigned)(ntile < dx_lds_grid() ? ntile : dx_lds_grid());
+        hipLaunchKernelGGL((gru_dx_bf16_lds_kernel<384>), dim3(grid), blk, lds, st, a);
+    }
     else if (a.H == 128 && DT == 4 && dx_bf16()) hipLaunchKernelGGL((gru_dx_bf16_kernel<384, 4>), dim3(rowwise_grid(rows, 4)), blk, 0, st, a);
     else if (a.H == 128 && DT == 1) hipLaunchKernelGGL((gru_dx_kernel<384, 1, 1, false>), dim3(rowwise_grid(rows, 1)), blk, 0, st, a);
     else if (a.H == 128 && DT == 4) hipLaunchKernelGGL((gru_dx_kernel<384, 1, 4, false>), dim3(rowwise_grid(rows, 4)), blk, 0, st, a);

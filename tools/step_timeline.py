@@ -7,13 +7,18 @@ import sys
 def main(path):
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    # step boundary = the small (dense-parameter) Adam launch that ends a step; a step that is not split has
-    # one launch only
-    adam = [i for i, r in enumerate(rows) if "adam" in r["Kernel_Name"]]
-    small = [i for i in adam if int(rows[i]["End_Timestamp"]) - int(rows[i]["Start_Timestamp"]) < 50000]
-    if len(small) >= 2:
-        adam = small
-    a, b = adam[-2], adam[-1]
+    # step boundary = the LAST Adam launch in front of a forward launch (the table's and the dense parameters' updates may be
+    # several launches; configurations with small tables end a step with two small ones)
+    adam = [i for i, r in enumerate(rows) if "adam_kernel" in r["Kernel_Name"]]
+    fwd = lambda r: any(k in r["Kernel_Name"] for k in ("fwd", "input_proj", "embed_gather"))
+    ends = []
+    for i in adam:
+        nxt = next((j for j in range(i + 1, len(rows)) if fwd(rows[j]) or "adam_kernel" in rows[j]["Kernel_Name"]), None)
+        if nxt is None or fwd(rows[nxt]):
+            ends.append(i)
+    if len(ends) < 2:
+        ends = adam
+    a, b = ends[-2], ends[-1]
     t0 = int(rows[a]["End_Timestamp"])
     for r in rows[a + 1:b + 1]:
         name = r["Kernel_Name"].split("(")[0].replace("void hpmn::", "").replace("hpmn::", "")[:44]
