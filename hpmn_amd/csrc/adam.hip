@@ -141,6 +141,9 @@ int adam_table_launch(float *p, float *g, float *m, float *v, uint8_t *flags, in
     if (thin > 256L * 16) thin = 256L * 16;
     const long cap = pass == 0 ? thin : 256L * 16;
     if (blocks > cap) blocks = cap;
+    // (r4, measured and removed: the late pass compacted per wave -- 64 flags in one load, a ballot, the marked rows processed
+    //  densely 16 at a time -- 137 us in the step's tail where this strided loop takes 124: a wave's marked rows went through
+    //  one dependent row round trip per group, the strided loop has every lane's row loads in flight at once)
     if (pass == 0)
         hipLaunchKernelGGL(adam_table_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, st, (float4 *)p, (float4 *)g,
                            (float4 *)m, (float4 *)v, flags, n4, shift, lr_t, b1, b2, eps, clip, gs);

@@ -42,14 +42,20 @@ __global__ __launch_bounds__(64) void embed_grad_scatter_kernel(
     const void *__restrict__ ids, const float *__restrict__ d_x, float *__restrict__ d_emb, int B,
     int T, int F, int E, int front_zero, int mask_id0, int groups, int nseg, int t_lo, int t_hi,
     const float *__restrict__ d_last, int t_last) {
-    const int cpw = 64 / E;                          // id columns per wave
+    const int cpw = 64 / E;                          // E-lane slots per wave
     const int seg = blockIdx.x % nseg;
     const int grp = (blockIdx.x / nseg) % groups;
     const long b = blockIdx.x / (nseg * groups);
     const int lane = threadIdx.x;
-    const int f = grp * cpw + lane / E;
+    // slots beyond the id columns this wave has take further TIME STEPS instead of idling (r4: XLong has two id columns and
+    // four slots -- half of every wave returned at once): slot = (step phase, column), the lane walks steps phase, phase + tpw, ...
+    const int fpw = (F - grp * cpw) < cpw ? (F - grp * cpw) : cpw;     // id columns of this wave
+    const int tpw = cpw / fpw;                                         // steps a wave takes at once
+    const int slot = lane / E;
+    if (slot >= tpw * fpw) return;
+    const int f = grp * cpw + slot % fpw;
+    const int tsub = slot / fpw;
     const int e = lane % E;
-    if (f >= F) return;
     const int Dx = F * E;
     const int t_begin = t_lo + seg * SSEG;
     const int t_end = (t_begin + SSEG) < t_hi ? (t_begin + SSEG) : t_hi;
@@ -57,12 +63,12 @@ __global__ __launch_bounds__(64) void embed_grad_scatter_kernel(
     const float *gp = d_x + (b * (long)(front_zero + T) + front_zero) * Dx + f * E + e;
     long run_id = -1;
     float acc = 0.f;
-    for (int t0 = t_begin; t0 < t_end; t0 += SCU) {
+    for (int t0 = t_begin + tsub; t0 < t_end; t0 += SCU * tpw) {
         long idv[SCU];
         float gv[SCU];
 #pragma unroll
         for (int i = 0; i < SCU; ++i) {
-            const int t = t0 + i;
+            const int t = t0 + i * tpw;
             idv[i] = -1;
             gv[i] = 0.f;
             if (t < t_end) {

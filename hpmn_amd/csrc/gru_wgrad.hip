@@ -267,10 +267,21 @@ static int wgrad_seq_per_wg(int T, int H) {   // T = steps per sequence in this 
     return spw < 1 ? 1 : spw;
 }
 
+// A launch that has the chip to itself (layer 0's, in the step's tail: whole_cu) is bound by ONE memory round trip per 16-row
+// tile with whatever workgroups a CU holds to overlap it: 500 three-wave workgroups are two per CU.  HPMN_WGRAD_TSPLIT=n cuts
+// its tiles into n consecutive pieces per sequence range -- n times the workgroups, three resident per CU (the kernel fits 168
+// registers for that), a slab each.  Measured at C3 (n = 1 / 2 / 3 / 4): 2.504-2.53 / 2.53 / 2.555 / 2.55-2.57 ms per step --
+// the launch itself shrinks (292 -> 248 us) but the scatter and the late table-Adam pass beside it lose what it gains (both
+// branches of the tail are bandwidth kernels) and the reduction reads n times the slabs: default 1.
+static int wgrad_tsplit(int D, int H) {
+    static const int env = [] { const char *e = getenv("HPMN_WGRAD_TSPLIT"); return e && atoi(e) > 0 ? atoi(e) : 1; }();
+    return (H == 64 && D <= 32) ? (env > 8 ? 8 : env) : 1;
+}
+
 size_t gru_wgrad_workspace_bytes(int B, int T, int D, int H) {
     const int spw = wgrad_seq_per_wg(T, H);
     const long nwg = (B + spw - 1) / spw;
-    return (size_t)nwg * (size_t)wgrad_slab_floats(D, H) * sizeof(float);
+    return (size_t)nwg * (size_t)wgrad_tsplit(D, H) * (size_t)wgrad_slab_floats(D, H) * sizeof(float);
 }
 
 template <int HT, int DT, int CS = 1>
@@ -316,13 +327,24 @@ static int launch_wgrad(const HpmnGruWgrad &a, hipStream_t st) {
     }
     // H = 64: the same reduction on the bf16 matrix pipe with split operands (gru_wgrad_bf16.hip), HPMN_WGRAD_BF16=0: fp32
     static const int bf16_env = [] { const char *e = getenv("HPMN_WGRAD_BF16"); return e ? atoi(e) : 1; }();
-    if (!(bf16_env && HT >= 2 && gru_wgrad_bf16_launch(k, nwg, rows <= solo_rows && !a.whole_cu, st)))
+    // (the time split of a whole-CU launch travels in the kernel's copy of `whole_cu`; the fp32 kernel does not know it)
+    int nslab = nwg;
+    bool done = false;
+    if (bf16_env && HT >= 2) {
+        HpmnGruWgrad kb = k;
+        const long tiles = ((a.t_len > 0 ? a.t_len : a.T) + 15) / 16;
+        const int ts = a.whole_cu && tiles >= 8 ? wgrad_tsplit(a.D, a.H) : 1;
+        kb.whole_cu = ts > 1 ? ts : 0;
+        done = gru_wgrad_bf16_launch(kb, nwg * ts, rows <= solo_rows && !a.whole_cu, st);
+        if (done) nslab = nwg * ts;
+    }
+    if (!done)
         hipLaunchKernelGGL((gru_wgrad_kernel<HT, DT, CS>), dim3((unsigned)nwg, CS), dim3(64 * (HT + DT)), lds_pad, st, k);
     int rc = check_launch();
     if (rc != HPMN_OK) return rc;
     const int H = a.H, D = a.D;
     const long n = wgrad_slab_floats(D, H);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 31) / 32)), dim3(32 * RED_G), 0, st, a.workspace, nwg, n,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 31) / 32)), dim3(32 * RED_G), 0, st, a.workspace, nslab, n,
                        a.d_wg, a.d_bg, a.d_wc, a.d_bc, (long)(D + H) * 2 * H, (long)2 * H, (long)(D + H) * H);
     return check_launch();
 }

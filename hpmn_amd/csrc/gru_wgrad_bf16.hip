@@ -53,7 +53,7 @@ __host__ __device__ inline long wgrad_slab_floats_bf(int D, int H) { return (lon
 // as in the fp32 kernel).
 template <int HT, int DT, int CS, int W>
 __device__ __forceinline__ void wgrad_bf16_wave(const HpmnGruWgrad &a, bf8 (*img)[DT + 2 * HT + 3 * HT / CS][2][64], const int bx,
-                                                const int by) {
+                                                const int by, const int tsplit) {
     constexpr int H = 32 * HT;
     constexpr int NJ = 3 * HT / CS;            // 32-column tiles of d_act held by this workgroup
     constexpr int NW = HT + DT;                // waves
@@ -80,10 +80,16 @@ __device__ __forceinline__ void wgrad_bf16_wave(const HpmnGruWgrad &a, bf8 (*img
 #pragma unroll
     for (int i = 0; i < MAXT; ++i) bsum[i] = 0.f;
 
-    const int b_begin = bx * a.seq_per_wg;
+    // (tsplit > 1: the 16-row tiles of a sequence range are cut into `tsplit` consecutive pieces, one workgroup -- and one slab --
+    //  each: more, shorter workgroups for a launch that has the chip to itself, see gru_wgrad_bf16_launch)
+    const int piece = tsplit > 1 ? bx % tsplit : 0;
+    const int bq = tsplit > 1 ? bx / tsplit : bx;
+    const int b_begin = bq * a.seq_per_wg;
     const int b_end = (b_begin + a.seq_per_wg) < a.B ? (b_begin + a.seq_per_wg) : a.B;
     const int tb = a.t_begin, te = a.t_len > 0 ? a.t_begin + a.t_len : T;
-    const int ipt = (te - tb + BR - 1) / BR;
+    const int ipt_all = (te - tb + BR - 1) / BR;
+    const int i_lo = tsplit > 1 ? (int)((long)ipt_all * piece / tsplit) : 0;
+    const int ipt = (tsplit > 1 ? (int)((long)ipt_all * (piece + 1) / tsplit) : ipt_all) - i_lo;     // tiles per sequence, this workgroup
     const int niter = (b_end - b_begin) * ipt;
 
     // raw (unconverted) values of this wave's staging tasks for one tile.  Nothing is computed on them at load time -- not even
@@ -93,7 +99,7 @@ __device__ __forceinline__ void wgrad_bf16_wave(const HpmnGruWgrad &a, bf8 (*img
     struct Raw { float v[MAXT][8]; float r2[has_rh ? 8 : 1]; };
     auto load_raw = [&](int it, Raw &g) {
         const int b = b_begin + it / ipt;
-        const int t0 = tb + (it % ipt) * BR + 8 * kg;
+        const int t0 = tb + (i_lo + it % ipt) * BR + 8 * kg;
         long rowx[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) rowx[j] = (long)b * T + ((t0 + j) < te ? (t0 + j) : (te - 1));
@@ -120,7 +126,7 @@ __device__ __forceinline__ void wgrad_bf16_wave(const HpmnGruWgrad &a, bf8 (*img
         }
     };
     auto park = [&](int buf, const Raw &g, int it) {
-        const int t0 = tb + (it % ipt) * BR + 8 * kg;
+        const int t0 = tb + (i_lo + it % ipt) * BR + 8 * kg;
 #pragma unroll
         for (int i = 0; i < MAXT; ++i) {
             const int q = W + i * NW;
@@ -218,7 +224,7 @@ __device__ __forceinline__ void wgrad_bf16_wave(const HpmnGruWgrad &a, bf8 (*img
 }
 
 template <int HT, int DT, int CS, bool XCD = true>
-__global__ __launch_bounds__(64 * (HT + DT), (HT + DT) > 5 ? 1 : 2) void gru_wgrad_bf16_kernel(const HpmnGruWgrad a) {
+__global__ __launch_bounds__(64 * (HT + DT), (HT + DT) == 3 ? 3 : ((HT + DT) > 5 ? 1 : 2)) void gru_wgrad_bf16_kernel(const HpmnGruWgrad a) {
     static_assert((3 * HT) % CS == 0 && HT + DT <= 8, "column tiles split evenly; at most eight waves");
     __shared__ __attribute__((aligned(16))) bf8 img[2][DT + 2 * HT + 3 * HT / CS][2][64];
     const int wave = threadIdx.x >> 6;          // (wave-uniform: one dispatch, then straight-line code per wave)
@@ -243,17 +249,19 @@ __global__ __launch_bounds__(64 * (HT + DT), (HT + DT) > 5 ? 1 : 2) void gru_wgr
         }
         if (bx * a.seq_per_wg >= a.B) return;    // (the grid is rounded up to whole groups of 8 ranges)
     }
-    if (wave == 0) wgrad_bf16_wave<HT, DT, CS, 0>(a, img, bx, by);
-    else if (wave == 1) wgrad_bf16_wave<HT, DT, CS, 1>(a, img, bx, by);
-    else if (wave == 2) wgrad_bf16_wave<HT, DT, CS, 2>(a, img, bx, by);
+    // (in the kernel's copy of the descriptor `whole_cu` carries the launch's time split: gru_wgrad_bf16_launch)
+    const int tsplit = CS == 1 && a.whole_cu > 1 ? a.whole_cu : 1;
+    if (wave == 0) wgrad_bf16_wave<HT, DT, CS, 0>(a, img, bx, by, tsplit);
+    else if (wave == 1) wgrad_bf16_wave<HT, DT, CS, 1>(a, img, bx, by, tsplit);
+    else if (wave == 2) wgrad_bf16_wave<HT, DT, CS, 2>(a, img, bx, by, tsplit);
     else if constexpr (NW > 3) {
-        if (wave == 3) wgrad_bf16_wave<HT, DT, CS, 3>(a, img, bx, by);
+        if (wave == 3) wgrad_bf16_wave<HT, DT, CS, 3>(a, img, bx, by, tsplit);
         else if constexpr (NW > 4) {
-            if (wave == 4) wgrad_bf16_wave<HT, DT, CS, 4>(a, img, bx, by);
+            if (wave == 4) wgrad_bf16_wave<HT, DT, CS, 4>(a, img, bx, by, tsplit);
             else if constexpr (NW > 5) {
-                if (wave == 5) wgrad_bf16_wave<HT, DT, CS, 5>(a, img, bx, by);
-                else if (wave == 6) wgrad_bf16_wave<HT, DT, CS, 6>(a, img, bx, by);
-                else wgrad_bf16_wave<HT, DT, CS, 7>(a, img, bx, by);
+                if (wave == 5) wgrad_bf16_wave<HT, DT, CS, 5>(a, img, bx, by, tsplit);
+                else if (wave == 6) wgrad_bf16_wave<HT, DT, CS, 6>(a, img, bx, by, tsplit);
+                else wgrad_bf16_wave<HT, DT, CS, 7>(a, img, bx, by, tsplit);
             }
         }
     }
