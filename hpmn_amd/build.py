@@ -73,6 +73,20 @@ def build_library(force: bool = False, verbose: bool = False, out: str = OUT, fl
     if not force and not is_stale(out, extra):
         return out
     os.makedirs(os.path.dirname(out), exist_ok=True)
+    # one builder at a time: the ranks of a data-parallel launch import the package together, and a stale library would have
+    # every one of them compile into the same object files (the others find it fresh once the first is done)
+    import fcntl
+    with open(out + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not is_stale(out, extra):
+                return out
+            return _build_locked(force, verbose, out, extra)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force: bool, verbose: bool, out: str, extra) -> str:
     objdir = os.path.join(_HERE, "lib", "obj")
     os.makedirs(objdir, exist_ok=True)
     hdrs = _headers()
