@@ -163,6 +163,22 @@ def gather_pmc_digest():
         return None
 
 
+IN_STEP_PROBE_STEPS = 24
+
+
+def in_step_probe_wanted(spec, H):
+    from hpmn_amd import ops
+    return ops.pipe_mode(spec) == "" and H != 32
+
+
+def in_step_probe_partner(model, c, step_fn):
+    """Ranks > 0 of a data-parallel run: the training steps rank 0 times its dominant kernel in (roofline_probes) are made of
+    collectives, so every rank has to run the same number of them."""
+    if in_step_probe_wanted(model.spec, c["H"]):
+        for i in range(IN_STEP_PROBE_STEPS):
+            step_fn(i)
+
+
 def roofline_probes(model, c, batches, step_fn):
     """Live timings on the stream the kernels are launched on (torch's current stream -- every HIP entry point
     takes it explicitly).  The DOMINANT kernel (layer-0 reverse scan) is timed INSIDE real training steps, with the
@@ -179,17 +195,20 @@ def roofline_probes(model, c, batches, step_fn):
 
     # -- dominant kernel, in-step
     in_step_ms = None
-    if ops.pipe_mode(spec) == "" and H != 32:
+    if in_step_probe_wanted(spec, H):
         # the library brackets layer 0's reverse-scan launch itself (hpmn_train_probe): the PRODUCT step, its weight-gradient
-        # kernels live on the helper stream
+        # kernels live on the helper stream.  EXACTLY IN_STEP_PROBE_STEPS steps whatever the probe answers: under data
+        # parallel every other rank runs the same number of them beside this one (in_step_probe_partner) -- a training step
+        # is made of collectives
         ops.train_probe(ids.device, True)
-        ts = []
-        for i in range(24):
+        ts, probing = [], True
+        for i in range(IN_STEP_PROBE_STEPS):
             step_fn(i)
-            try:
-                ts.append(ops.train_probe_ms(ids.device))
-            except Exception:
-                break
+            if probing:
+                try:
+                    ts.append(ops.train_probe_ms(ids.device))
+                except Exception:
+                    probing = False
         ops.train_probe(ids.device, False)
         if len(ts) > 8:
             ts = sorted(ts[4:])
@@ -789,6 +808,8 @@ def main():
         auc = auc_leg(c, device, rank, world, args.auc_steps, tmp)
         log("AUC leg done: test AUC %.4f" % auc["test_auc"])
 
+    if rank != 0 and world > 1 and not args.no_roofline:
+        in_step_probe_partner(model, c, step)                  # (rank 0's roofline probe below runs training steps)
     result = None
     if rank == 0:
         seqs = global_batch * args.steps

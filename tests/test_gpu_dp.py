@@ -91,6 +91,25 @@ def test_bench_gpus_n_starts_its_own_ranks(tmp_path):
     assert d["scaling"] == "weak" and d["steps"] == 4
 
 
+def test_bench_gpus_n_with_the_rank_0_legs(tmp_path):
+    """The driver's spelling has NO --no-* flags: after the timed steps rank 0 alone runs the parity gate and the roofline
+    probes -- and the probe of the dominant kernel runs TRAINING STEPS (collectives).  The other ranks have to run them
+    too (bench.in_step_probe_partner), or rank 0 waits in an all-gather while they wait in the final barrier.
+    Taobao shape (H = 64: the in-step probe exists), two gloo ranks on this box's GPU."""
+    import json
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--config", "c2", "--steps", "3",
+           "--warmup", "2", "--no-cpu-baseline", "--no-auc"]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout.decode()[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["roofline"]["ms_per_launch"] > 0 and d["parity_gate"]["pass"]
+
+
 def test_two_ranks_on_a_table_beyond_int32_rows(tmp_path):
     """Row g under data parallel: two ranks, each with a 2.2 G-row table (35 GB per buffer, param + m + v under lazy table
     Adam), int64 ids, the touched-rows exchange with int64 row ids on the wire -- against the single-process run."""
