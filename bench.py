@@ -621,6 +621,7 @@ def self_spawn(n, backend):
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))   # (the CPU legs run on rank 0 only)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # (dmabuf IPC: RCCL between processes fails with the legacy mode here)
     return subprocess.call(cmd, env=env)
 
 
@@ -664,6 +665,7 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
             torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
