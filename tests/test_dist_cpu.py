@@ -267,6 +267,29 @@ def test_chunked_async_rows_exchange_with_vector_counts():
     assert bytes0 == [max(counts0[0][c], counts0[1][c]) * ((8 if c % 2 else 4) + 16) for c in range(4)]
 
 
+def test_chunked_async_rows_exchange_four_ranks():
+    """The same exchange among FOUR ranks (the node's weak-scaling runs are 2 / 4 / 8): ragged shards of 2, 5, 8 and 11 sequences,
+    every rank ends on the bit-identical table gradient, which is the dense all-reduce's."""
+    world = 4
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_chunked_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in ps]
+    got = {r[0]: r[1:] for r in (q.get(timeout=180) for _ in range(world))}
+    [p.join(60) for p in ps]
+    assert all(p.exitcode == 0 for p in ps)
+    s0, ref0, counts0, scalar0, _, w0, bytes0 = got[0]
+    np.testing.assert_allclose(s0, ref0, rtol=0, atol=2e-6)
+    assert len(counts0) == 4 and all(len(c) == 4 for c in counts0)
+    assert scalar0 == [got[r][4] for r in range(world)] == [sum(c) for c in counts0]
+    for r in range(1, world):
+        sr, refr, countsr, scalarr, _, wr, bytesr = got[r]
+        np.testing.assert_array_equal(sr, s0)                          # replicas bit-identical
+        assert countsr == counts0 and scalarr == scalar0 and wr == w0 and bytesr == bytes0
+    assert bytes0 == [3 * max(counts0[r][c] for r in range(world)) * ((8 if c % 2 else 4) + 16) for c in range(4)]
+
+
 def test_single_process_exchange_is_the_identity():
     """world 1, no process group: the helpers return this rank's own rows (padded form) and counts without a collective."""
     rows = torch.tensor([3, 9, 11])
