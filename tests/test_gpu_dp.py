@@ -38,6 +38,14 @@ def test_two_rank_two_pass_step_matches_single_process(tmp_path, monkeypatch, ex
     _run_two_ranks(tmp_path, "gloo", exchange, extra_env={"HPMN_TWO_PASS_MIN_NUMEL": "0"})
 
 
+@pytest.mark.parametrize("exchange", ["rows", "auto"])
+def test_four_rank_two_pass_step_matches_single_process(tmp_path, monkeypatch, exchange):
+    """The same step among FOUR ranks (shards of 12 / 13 sequences; the one-sample last batch leaves three ranks with an empty
+    shard, each of which still has to enter every collective): the chunked rows exchange with four contributors per range."""
+    monkeypatch.setenv("HPMN_TWO_PASS_MIN_NUMEL", "0")
+    _run_two_ranks(tmp_path, "gloo", exchange, extra_env={"HPMN_TWO_PASS_MIN_NUMEL": "0"}, nproc=4)
+
+
 def test_two_rank_lazy_table_adam_matches_single_process(tmp_path, monkeypatch):
     """Row-wise (lazy) Adam under data parallel -- what a table sized to HBM needs (BASELINE configs[4]): every rank's
     touched rows and compact gradient rows are all-gathered, the union updated identically everywhere."""
