@@ -52,7 +52,11 @@ template <int D, bool GATHER, bool TRAIN, bool UPROD>
 __global__ __launch_bounds__(256, 1) void gru_fwd_mfma_kernel(const HpmnGruFusedFwd a) {
     constexpr int H = MH;
     constexpr int NJ = D / 16;                                              // 16-byte pieces of an input row per lane
-    __shared__ __attribute__((aligned(16))) float ring_[2][MRING][3 * H];   // xp (r | u | c)
+    // (rows padded by 4 floats: 3 H = 192 floats are three bank periods, and the producer writes a projected tile as 16 rows x
+    //  16 bytes -- one row per lane group -- which with a 192-float stride was a 16-way bank conflict per write, on the LDS pipe
+    //  the chain wave's round trips queue in: SQ_LDS_BANK_CONFLICT 28 % of this launch's LDS cycles)
+    constexpr int RINGW = 3 * H + 4;
+    __shared__ __attribute__((aligned(16))) float ring_[2][MRING][RINGW];   // xp (r | u | c)
     __shared__ __attribute__((aligned(16))) float hb_[2][MSL][H];          // h_{t-1} lives in hb[t % MSL]
     __shared__ __attribute__((aligned(16))) float rhb_[2][H];
     __shared__ float ubuf_[2][2][H];
@@ -65,7 +69,7 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_mfma_kernel(const HpmnGruFused
     const int T = a.T;
     const long b = 2 * (long)blockIdx.x + seq;
     if (b >= a.B) return;        // odd batch (before the barrier: ended waves do not take part in it)
-    float (&ring)[MRING][3 * H] = ring_[seq];
+    float (&ring)[MRING][RINGW] = ring_[seq];
     float (&hb)[MSL][H] = hb_[seq];
     float (&rhb)[H] = rhb_[seq];
     float (&ubuf)[2][H] = ubuf_[seq];

@@ -37,7 +37,7 @@ namespace hpmn {
 constexpr int RH = 64;
 constexpr int RFS = 8;          // coefficient ring depth in steps
 constexpr int RAHEAD = 3;       // chunks the feeder parks ahead of the chunk the chain wave is on
-constexpr int RROW = 192;       // floats per operand row [da_r | da_u | dc_pre]
+constexpr int RROW = 192 + 4;   // floats per operand row [da_r | da_u | dc_pre], padded off the bank period (gru_scan_bwd_feed.hip: DROW)
 constexpr int RXB = 16;         // steps per input-gradient block (= MFMA N)
 constexpr int RDR = 32;         // rows of the upper layer's operand ring and of the d_y ring
 constexpr int RDYROW = 68;      // floats per d_y ring row (64 + 4, see gru_pair_fwd.hip)

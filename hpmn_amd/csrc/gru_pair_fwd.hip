@@ -46,7 +46,7 @@ enum { SRC_GATHER = 0, SRC_GLOBAL = 1, SRC_LDS = 2 };
 
 template <bool TRAIN>
 struct SeqLds {                                   // one sequence of one layer
-    float ring[QRING][3 * QH];                    // xp (r | u | c), exponent domain
+    float ring[QRING][3 * QH + 4];                // xp (r | u | c), exponent domain; rows padded off the bank period (gru_fused_fwd3.hip)
     float hb[QSL][QH];                            // h_{t-1} in hb[t % QSL]
     float rhb[QH];
     v4f rcb[TRAIN ? QSL : 1][QH];                 // r, u, c of step t in rcb[t % QSL]

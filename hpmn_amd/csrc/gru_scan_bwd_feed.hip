@@ -43,7 +43,11 @@ namespace hpmn {
 
 constexpr int FR_STEPS = 8;     // coefficient ring depth in steps (4 chunks of 2)
 constexpr int FR_AHEAD = 3;     // chunks the feeder parks ahead of the chunk the chain wave is on
-constexpr int DROW = 192;       // floats per operand row [da_r | da_u | dc_pre]
+constexpr int DROW = 192 + 4;   // floats per operand row [da_r | da_u | dc_pre] in LDS, PADDED: 192 floats are three bank periods, so
+                                // the 16 rows of an input-gradient block (lane j reads row 16 kb + j, 16 bytes) all started in
+                                // the same banks -- a 16-way conflict on every operand read of the in-loop product, on the LDS
+                                // pipe the chain wave's round trips queue in (SQ_LDS_BANK_CONFLICT: 22 % of the launch's LDS
+                                // cycles); 196 = 4 x 49 puts them 4 banks apart
 constexpr int DXB = 16;         // steps per input-gradient block (= MFMA N)
 
 typedef float f4m __attribute__((ext_vector_type(4)));
