@@ -398,9 +398,11 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void gru_dx_bf16_kernel(const Hpm
 // adjacent lanes = one row's 128-byte line), split each 8-float fragment once, and park (hi, lo) in LDS in the B operand's
 // lane order; the four waves read their k-steps from there (two ds_read_b128 per k-step) against their stationary weights.
 // Two LDS buffers, the next tile's loads in flight underneath the current tile's 72 matrix instructions, one barrier per tile.
-// LDS slot of fragment (row, ks, p): plane ks, slot ((row + 4 (2 (ks & 1) + p)) & 31) + 32 p -- the rotation by 4 rows per
-// fragment-of-a-line puts the 16 lanes of a write group (4 rows x the 4 fragments of a line) on 16 different bank quads; a
-// reader's 16 consecutive rows of one (ks, p) are consecutive slots either way.
+// LDS slot of fragment (row, ks, p): plane ks, slot ((row + 2 (2 (ks & 1) + p)) & 31) + 32 p.  A ds_write_b128 is serviced in
+// groups of 8 contiguous lanes over 32 banks (MI355X_MICROARCH.md, LDS): here 2 rows x the 4 fragments of a line, and the
+// rotation by 2 rows per fragment-of-a-line puts them on 8 different bank quads (a rotation by 4 was a 2-way conflict on every
+// store: SQ_LDS_BANK_CONFLICT 26 % of the launch's LDS cycles); a ds_read_b128's 16-lane groups see 16 different slots mod 16
+// under any rotation of the row.
 template <int K>
 __global__ __launch_bounds__(64 * RW_WAVES, 1) void gru_dx_bf16_lds_kernel(const HpmnGruWgrad a) {
     constexpr int KS = K / 16;                      // k-steps per tile (24)
@@ -430,7 +432,7 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void gru_dx_bf16_lds_kernel(const
     }
     // staging role of this thread: row (tid >> 2) & 31 of the tile, fragments q = 8 j + 4 (tid >> 7) + (tid & 3), j < FPT
     const int s_row = (tid >> 2) & 31, s_sub = tid & 3, s_grp = tid >> 7;
-    const int s_slot = ((s_row + 4 * s_sub) & 31) + 32 * (s_sub & 1);
+    const int s_slot = ((s_row + 2 * s_sub) & 31) + 32 * (s_sub & 1);
     float4 raw[FPT][2];
     auto load_tile = [&](unsigned tile) {
         unsigned rr = tile * 32u + (unsigned)s_row;
@@ -469,7 +471,7 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void gru_dx_bf16_lds_kernel(const
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            const int slot = ((c + 4 * (2 * (ks & 1) + p)) & 31) + 32 * p;
+            const int slot = ((c + 2 * (2 * (ks & 1) + p)) & 31) + 32 * p;
             const dbf8 xh = img[buf][ks][0][slot], xl = img[buf][ks][1][slot];
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[ks], xh, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[ks], xl, acc, 0, 0, 0);
