@@ -1323,6 +1323,22 @@ def test_eight_wave_h128_scans_match_the_oracle():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
+@pytest.mark.gpu
+def test_h128_alternatives_of_round_4_match_the_oracle():
+    """The other side of the third part's switches, in a process of its own: H = 128 scans capped at one workgroup per CU
+    (HPMN_SCAN128_SOLO=3, the LDS padding), the row-per-lane input gradient (HPMN_DX_LDS=0), the weight gradients' column groups
+    in grid order (HPMN_WGRAD_XCD=0) and layer 0's whole-CU weight gradient cut into three time pieces (HPMN_WGRAD_TSPLIT=3,
+    H = 64): H = 128 forward / gradient parity, the input-gradient launch, and the H = 64 XLong gradient case."""
+    import subprocess
+    e = dict(os.environ, HPMN_SCAN128_SOLO="3", HPMN_DX_LDS="0", HPMN_WGRAD_XCD="0", HPMN_WGRAD_TSPLIT="3")
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", here, "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider",
+                        "-k", "(tiny_and_odd and 128) or industry_h128 or xlong_c4_h128 or input_gradient_launch_h128"
+                              " or xlong_c3_b66 or three_training_steps"],
+                       env=e, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 # ------------------------------------------------------------------------------- two layers per launch
 PAIR_CASES = [
     # name, B, T_lo, D_lo (gather F = D/16 or x rows), period_lo, period_up
