@@ -36,3 +36,22 @@ for lo, hi in ds.batches(500):
         assert np.isfinite([float(ce), a, l, mm]).all()
 print("xlong-style: %d steps in %.1fs" % (step, time.time() - t0))
 assert a > 0.97
+
+# H = 128 (configs[4]'s kernels: four-wave scans at two workgroups per CU, column-split weight gradients, staged input gradient)
+t0 = time.time()
+ids, label = D.make_synthetic_xlong_arrays(100000, seed=41)
+tids, tlabel = D.make_synthetic_xlong_arrays(2500, seed=42)
+m = Hpmn_Industry(tempfile.mkdtemp(), dict(ids=ids, label=label), dict(ids=tids, label=tlabel), D.xlong_feature_size(), 2, 1, 1001, 1,
+                  0.001, 128, 16, 3, [2] * 10 + [1], [1], 7, 1, True, False, emb_initializer=init, l2_reg=0, memory_reg=5e-5,
+                  verbose=False, seed=0)
+ds = m._dev(m.trainset)
+step = 0
+for lo, hi in ds.batches(500):
+    step += 1
+    out, ce = m.train_step(ds.ids[lo:hi], ds.label[lo:hi], keep_prob=0.5)
+    if step % 100 == 0:
+        a, l, mm = m.eval(m.testset, 2000)
+        print("H=128 step %d: ce %.4f test AUC %.4f logloss %.4f memloss %.2f" % (step, float(ce), a, l, mm), flush=True)
+        assert np.isfinite([float(ce), a, l, mm]).all()
+print("H=128: %d steps in %.1fs" % (step, time.time() - t0))
+assert a > 0.95
