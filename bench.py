@@ -653,6 +653,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # (before the first HIP call: the runtime reads it once)
+        # The data-parallel step has five streams (launch, auxiliary, two helpers, RCCL's) and the runtime four hardware queues
+        # by default: the auxiliary stream then shares the launch stream's queue and its early table-Adam pass runs IN FRONT of
+        # layer 0's forward instead of beside it.  One more queue, measured with one rank on RCCL (tools/dp_one_rank.py):
+        # 3.45 -> 2.99 ms per step (allreduce), 4.25 -> 3.89 (rows); eight queues are worse (3.9 / 5.6).  DESIGN.md section 5.
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "5")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:

@@ -3,6 +3,7 @@ plan sort, id gather, counts, chunked rows exchange with itself, late pass per c
 import os, sys, time, tempfile
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29611")
 os.environ["HPMN_DP_FORCE_COLLECTIVES"] = "1"
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "5")       # (as bench.py sets it for multi-rank runs; 4 = the runtime default)
 import torch, torch.distributed as td
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
