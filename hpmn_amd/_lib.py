@@ -10,7 +10,8 @@ import os
 from typing import Optional
 
 HPMN_MAX_LAYERS = 12
-HPMN_ABI_VERSION = 11
+HPMN_ABI_VERSION = 12
+HPMN_MAX_RANKS = 8
 HPMN_FWD_NO_CANDIDATE = 1
 HPMN_BWD_CANDIDATE_FROM_HS = 1
 
@@ -168,6 +169,16 @@ class HpmnScatterPlan(C.Structure):
                 ("count", C.c_void_p), ("out_rows", C.c_void_p), ("partials", C.c_void_p)]
 
 
+class HpmnRowsAdam(C.Structure):
+    _fields_ = [("world", C.c_int32), ("E", C.c_int32), ("id_flags", C.c_int32), ("counts_stride", C.c_int32),
+                ("ids", C.c_void_p), ("ids_stride", C.c_int64), ("counts", C.c_void_p),
+                ("len", C.c_int64 * HPMN_MAX_RANKS), ("first", C.c_int64 * HPMN_MAX_RANKS), ("n", C.c_int64 * HPMN_MAX_RANKS),
+                ("rows", C.c_void_p), ("rows_stride", C.c_int64), ("flags", C.c_void_p),
+                ("param", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("V", C.c_int64),
+                ("lr_t", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("clip", C.c_float),
+                ("grad_scale", C.c_float)]
+
+
 SIGNATURES = {
     "hpmn_abi_version": (C.c_int, []),
     "hpmn_strerror": (C.c_char_p, [C.c_int]),
@@ -225,6 +236,9 @@ SIGNATURES = {
     "hpmn_adam_step_table": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
                                        C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                        C.c_void_p]),
+    "hpmn_rows_sum_adam": (C.c_int, [C.POINTER(HpmnRowsAdam), C.c_void_p]),
+    "hpmn_table_mark_ranks": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p,
+                                        C.c_int64, C.c_int32, C.c_void_p]),
     "hpmn_train_ctx_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "hpmn_train_ctx_destroy": (None, [C.c_void_p]),
     "hpmn_scan_train_workspace_bytes": (C.c_size_t, [C.POINTER(HpmnScanDesc)]),

@@ -68,6 +68,9 @@ int embed_grad_segsum_launch(const HpmnScatterPlan &p, const float *d_x, float *
                              hipStream_t st);
 int adam_table_launch(float *p, float *g, float *m, float *v, uint8_t *flags, int64_t V, int E, int pass, float lr_t,
                       float b1, float b2, float eps, float clip, float gs, hipStream_t st);
+int rows_sum_adam_launch(const HpmnRowsAdam &h, hipStream_t st);
+int table_mark_ranks_launch(const void *ids, int64_t ids_stride, int32_t world, const int32_t *counts, int32_t counts_stride,
+                            int64_t cap, uint8_t *flags, int64_t V, int32_t id_flags, hipStream_t st);
 int adam_rows_launch(float *p, const float *g, float *m, float *v, const int64_t *row_ids, int64_t n_rows, int E,
                      float lr_t, float b1, float b2, float eps, float clip, float gs, hipStream_t st);
 
@@ -510,7 +513,7 @@ int hpmn_embed_grad_segsum(const HpmnScatterPlan *plan, const float *d_x, float 
                            void *stream) {
     drop_stale_hip_error();
     if (!plan || B < 0 || T < 1 || F < 1 || E < 4 || front_zero < 0) return HPMN_EINVAL;
-    if (E % 4 != 0 || 256 % (E / 4) != 0) return HPMN_EUNSUPPORTED;
+    if (E % 4 != 0 || (E / 4 & (E / 4 - 1)) != 0 || E / 4 > 64) return HPMN_EUNSUPPORTED;   // (64 / (E/4) lane groups per wave)
     if (plan->n != (int64_t)B * T * F || plan->n > 0x7fffffffLL) return HPMN_EINVAL;     // (perm / start are int32)
     if (B == 0) return HPMN_OK;
     if (!plan->perm || !plan->seg || !plan->start || !plan->rows || !plan->count || !plan->partials || !d_x) return HPMN_EINVAL;
@@ -556,12 +559,43 @@ int hpmn_adam_step_table(float *param, float *grad, float *m, float *v, uint8_t 
     //  read it only then)
     if (E % 4 != 0 || (E / 4 & (E / 4 - 1)) != 0 || E / 4 > 64) return HPMN_EUNSUPPORTED;
     if (V == 0) return HPMN_OK;
-    if (!param || !grad || !m || !v || !flags) return HPMN_EINVAL;
+    if (!param || (pass == 1 && !grad) || !m || !v || !flags) return HPMN_EINVAL;     // (pass 0 never reads the gradient)
     if ((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(m) |
          reinterpret_cast<uintptr_t>(v)) & 15)
         return HPMN_EINVAL;
     return adam_table_launch(param, grad, m, v, flags, V, E, pass, lr_t, beta1, beta2, eps, clip, grad_scale,
                              (hipStream_t)stream);
+}
+
+int hpmn_rows_sum_adam(const HpmnRowsAdam *a, void *stream) {
+    drop_stale_hip_error();
+    if (!a || a->world < 1 || a->world > HPMN_MAX_RANKS || a->E < 4 || a->V < 1 || a->ids_stride < 0 || a->rows_stride < 0)
+        return HPMN_EINVAL;
+    if (a->E % 4 != 0 || (a->E / 4 & (a->E / 4 - 1)) != 0 || a->E / 4 > 64) return HPMN_EUNSUPPORTED;
+    int64_t total = 0;
+    for (int r = 0; r < a->world; ++r) {
+        if (a->first[r] < 0 || a->n[r] < 0 || (!a->counts && a->len[r] < 0)) return HPMN_EINVAL;
+        if (a->n[r] > a->rows_stride && a->world > 1) return HPMN_EINVAL;
+        if (a->first[r] + a->n[r] > a->ids_stride && a->world > 1) return HPMN_EINVAL;
+        total += a->n[r];
+    }
+    if (total == 0) return HPMN_OK;
+    if (!a->ids || !a->rows || !a->flags || !a->param || !a->m || !a->v) return HPMN_EINVAL;
+    if (a->counts && a->counts_stride < 1) return HPMN_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(a->param) | reinterpret_cast<uintptr_t>(a->m) | reinterpret_cast<uintptr_t>(a->v) |
+         reinterpret_cast<uintptr_t>(a->rows)) & 15)
+        return HPMN_EINVAL;
+    return rows_sum_adam_launch(*a, (hipStream_t)stream);
+}
+
+int hpmn_table_mark_ranks(const void *ids, int64_t ids_stride, int32_t world, const int32_t *counts, int32_t counts_stride,
+                          int64_t cap, uint8_t *flags, int64_t V, int32_t id_flags, void *stream) {
+    drop_stale_hip_error();
+    if (world < 1 || world > HPMN_MAX_RANKS || cap < 0 || V < 1 || ids_stride < cap) return HPMN_EINVAL;
+    if (cap == 0) return HPMN_OK;
+    if (!ids || !flags || (counts && counts_stride < 1)) return HPMN_EINVAL;
+    if (reinterpret_cast<uintptr_t>(flags) & 3) return HPMN_EINVAL;
+    return table_mark_ranks_launch(ids, ids_stride, world, counts, counts_stride, cap, flags, V, id_flags, (hipStream_t)stream);
 }
 
 int hpmn_gru_fused_fwd_writes_last(void) { return gru_fused_fwd_writes_last() ? 1 : 0; }

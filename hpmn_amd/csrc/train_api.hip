@@ -327,8 +327,13 @@ int hpmn_scan_bwd(HpmnTrainCtx *ctx, const HpmnScanDesc *d, const void *ids, con
                   int32_t defer_join, void *stream) {
     (void)hipGetLastError();
     TrainCtx *c = reinterpret_cast<TrainCtx *>(ctx);
-    if (!c || !d || !ids || !wg || !wc || !d_memory || !d_wg || !d_bg || !d_wc || !d_bc || !d_emb || !workspace)
-        return HPMN_EINVAL;
+    if (!c || !d || !ids || !wg || !wc || !d_memory || !d_wg || !d_bg || !d_wc || !d_bc || !workspace) return HPMN_EINVAL;
+    // A scatter plan (hpmn_train_set_scatter_plan) is consumed by the whole-range scatter ONLY: the paths that scatter on
+    // their own -- fused into layer 0's reverse scan, the two time-cut forms -- are switched off while one is set (ADVICE r4:
+    // they used to ignore it silently and leave plan.out_rows unwritten).  With a plan that writes compact rows the dense
+    // table gradient is optional (ABI v12: hpmn_rows_sum_adam consumes the compact rows).
+    const bool has_plan = c->plan.n > 0;
+    if (!d_emb && !(has_plan && c->plan.out_rows)) return HPMN_EINVAL;
     if (d->B == 0) return HPMN_OK;
     HpmnTrainLayout L;
     if (!layout(*d, L)) return HPMN_EINVAL;
@@ -346,7 +351,7 @@ int hpmn_scan_bwd(HpmnTrainCtx *ctx, const HpmnScanDesc *d, const void *ids, con
     // weight gradient.  (The scatter is an atomic row add, so the two halves commute.)
     static const int split_env = [] { const char *e = getenv("HPMN_L0_SPLIT"); return e ? atoi(e) : 0; }();
     int cut = 0;
-    if (split_env && L.T[0] >= 256 && !gru_scan_bwd_fuses_dx(d->H, d->B)) {
+    if (split_env && !has_plan && L.T[0] >= 256 && !gru_scan_bwd_fuses_dx(d->H, d->B)) {
         const int p0 = d->periods[0], q = (p0 % 2 == 0) ? p0 : 2 * p0;
         cut = (L.T[0] / 2) / q * q;
         if (cut <= d->front_zero || cut >= L.T[0] + d->last_index) cut = 0;
@@ -542,7 +547,8 @@ int hpmn_scan_bwd(HpmnTrainCtx *ctx, const HpmnScanDesc *d, const void *ids, con
         if (probing) HIPCHK(hipEventRecord(c->probe0, st));
         const bool fused_dx = gru_scan_bwd_fuses_dx(d->H, d->B) && gru_scan_bwd_dx_width_ok(D);
         if (fused_dx) a.d_x = F(L.d_x[i]);       // the input gradient comes out of the scan launch itself
-        if (i == 0 && fused_dx && !(d->mask_id0 & HPMN_ID_I64) && gru_scan_bwd_fuses_scatter(d->H, d->B, D, d->F, d->E)) {
+        if (i == 0 && fused_dx && !has_plan && !(d->mask_id0 & HPMN_ID_I64) &&
+            gru_scan_bwd_fuses_scatter(d->H, d->B, D, d->F, d->E)) {
             // ... and goes straight into the table gradient: no d_x buffer, no scatter launch behind layer 0
             a.d_x = nullptr;
             a.scatter_ids = ids; a.d_emb = d_emb; a.Tids = d->T; a.F = d->F; a.E = d->E;
@@ -569,7 +575,7 @@ int hpmn_scan_bwd(HpmnTrainCtx *ctx, const HpmnScanDesc *d, const void *ids, con
             held[nheld++] = wa;
             HIPCHK(hipEventRecord(c->fork, st));
             HIPCHK(hipStreamWaitEvent(c->side, c->fork, 0));
-            if (l0_cut_env >= 2 && cut0 > d->front_zero && d->T + d->last_index >= cut0 - d->front_zero) {
+            if (l0_cut_env >= 2 && !has_plan && cut0 > d->front_zero && d->T + d->last_index >= cut0 - d->front_zero) {
                 // ... and the late half's scatter (with the read path's d_last row, which lies in it): the step's other tail
                 rc = embed_grad_scatter_launch(ids, F(L.d_x[0]), d_emb, d->B, d->T, d->F, d->E, d->front_zero, d->mask_id0,
                                                cut0 - d->front_zero, d->T, c->side, d_last, d->T + d->last_index);

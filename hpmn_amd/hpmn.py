@@ -207,6 +207,7 @@ class Hpmn_Basic(object):
         self.det_scatter = self._det_env == "1"
         self._plan_wants_rows = False     # (the data-parallel rows exchange sends the plan's compact rows)
         self._plan_row_bounds = None
+        self._plan_caps = (0, 0)          # (r5: capacities of the plan's `rows` / `out_rows` buffers as the exchange sends them)
         self.last_scatter_plan = None
         self._sharded_moments = False     # set once the sharded table update has run (save_model gathers the moments then)
         self.TWO_PASS_MIN_NUMEL = int(os.environ.get("HPMN_TWO_PASS_MIN_NUMEL", str(type(self).TWO_PASS_MIN_NUMEL)))
@@ -221,10 +222,35 @@ class Hpmn_Basic(object):
         self._branches = ([("User", self.spec, self.user_num_layers)] if user else []) + \
                          ([(self.item_scope, self.item_spec, self.item_num_layers)] if item else [])
         self._hip_read = bool(user and not item)     # user-only graph: the four-library-call step (no item-side scan)
+        self.compact_table_grad = self._decide_compact_table_grad()
         self._build_variables(emb_initializer, seed)
         self.adam_t = 0
         self.beta1, self.beta2, self.adam_eps = 0.9, 0.999, 1e-8   # tf.train.AdamOptimizer defaults
         os.makedirs(self._path, exist_ok=True)
+
+    def _decide_compact_table_grad(self) -> bool:
+        """r5 (ABI v12): NO dense [V, E] gradient table.  The deterministic scatter leaves one summed gradient row per distinct
+        table row of the batch (ops.ScatterPlan.out_rows), hpmn_rows_sum_adam updates exactly those rows -- all ranks' rows in
+        one launch under data parallel -- and the early pass of the two-pass table Adam covers the rest: the arithmetic of
+        code/hpmn.py:209-214's dense update with a quarter less table state (p, m, v: 3 x V x E floats instead of 4) and a
+        third of the serial tail (C3: scatter 118 us + late pass 155 us -> segmented reduction + 56 us).
+        HPMN_TABLE_GRAD: ``auto`` (default) = compact wherever the two-pass step applies (user-only graph, no l2 term, dense
+        Adam, a table of >= TWO_PASS_MIN_NUMEL elements, and under data parallel the rows exchange on <= 8 ranks);
+        ``dense`` = the r4 layout; ``compact`` = compact or raise."""
+        mode = os.environ.get("HPMN_TABLE_GRAD", "auto")
+        if mode not in ("auto", "dense", "compact"):
+            raise ValueError("HPMN_TABLE_GRAD must be auto, dense or compact (got %r)" % mode)
+        if self._det_env not in ("0", "1", "auto"):
+            # (ADVICE r4) any other spelling used to switch the plan on in one place and off in another
+            raise ValueError("HPMN_DET_SCATTER must be 0, 1 or auto (got %r)" % self._det_env)
+        ok = bool(self._hip_read and not self.l2_reg and not self.lazy_table_adam and self.TWO_PASS_TABLE_ADAM
+                  and self._table_adam_width_ok() and self._det_env != "0"
+                  and (not self._dp or (self.table_exchange in ("auto", "rows") and self.world <= ops._lib.HPMN_MAX_RANKS)))
+        if mode == "compact" and not ok:
+            raise ValueError("HPMN_TABLE_GRAD=compact needs the user-only graph, l2_reg == 0, dense Adam, E/4 a power of two "
+                             "<= 64, HPMN_DET_SCATTER != 0 and (data parallel) HPMN_TABLE_EXCHANGE auto / rows on <= 8 ranks")
+        big = self.feature_size * self.embedding_size >= self.TWO_PASS_MIN_NUMEL
+        return ok and (mode == "compact" or (mode == "auto" and big))
 
     # ------------------------------------------------------------------ graph description
     def _make_spec(self) -> ScanSpec:
@@ -278,7 +304,7 @@ class Hpmn_Basic(object):
         dev = self.device
         self.flat_param = torch.zeros(n, device=dev, dtype=torch.float32)
         # lazy table Adam: no dense table gradient exists; the flat gradient then covers the dense variables only
-        self._goff = offs[shapes[1][0]] if self.lazy_table_adam else 0
+        self._goff = offs[shapes[1][0]] if (self.lazy_table_adam or self.compact_table_grad) else 0
         self.flat_grad = torch.zeros(n - self._goff, device=dev, dtype=torch.float32)
         self._loss_acc = torch.zeros(2, device=dev, dtype=torch.float32)      # log-loss sum, memory-loss sum of a step
         self._loss_acc_clean = True
@@ -295,7 +321,7 @@ class Hpmn_Basic(object):
         for name, shape in shapes:
             k = int(np.prod(shape))
             p = self.flat_param[offs[name]:offs[name] + k].view(shape)
-            g = None if (self.lazy_table_adam and name == "Embedding/emb_mtx") else \
+            g = None if ((self.lazy_table_adam or self.compact_table_grad) and name == "Embedding/emb_mtx") else \
                 self.flat_grad[offs[name] - self._goff:offs[name] - self._goff + k].view(shape)
             if name == "Embedding/emb_mtx" and emb_initializer is not None:
                 p.copy_(torch.as_tensor(np.asarray(emb_initializer, dtype=np.float32)))
@@ -471,7 +497,7 @@ class Hpmn_Basic(object):
         # (Each hand-over between streams costs a few microseconds of queue processing: only worth it where the
         # gradient buffer is big -- C3: 213 MB -- not for the 0.5 ms steps of the small-table configurations.)
         main = torch.cuda.current_stream()
-        aux = self._aux_stream if self.flat_grad.numel() >= self.AUX_MIN_NUMEL else main
+        aux = self._aux_stream if (self.flat_grad.numel() >= self.AUX_MIN_NUMEL or self.compact_table_grad) else main
         if aux is not main:
             aux.wait_stream(main)                            # (after the previous step's optimiser, which read it)
         cleared = None
@@ -481,16 +507,18 @@ class Hpmn_Basic(object):
         # table-Adam pass its 240 us delayed that pass past the forward and cost the C3 step 0.26 ms): behind the pass, unless
         # the data-parallel rows exchange wants the distinct-row count at the start of the step.
         plan, plan_ready = None, None
-        det = self.det_scatter or (self._det_env == "auto" and self._plan_wants_rows)
-        det = bool(det and not self.lazy_table_adam and self.embedding_size % 4 == 0 and 256 % (self.embedding_size // 4) == 0)
+        det = self.det_scatter or (self._det_env == "auto" and self._plan_wants_rows) or self.compact_table_grad
+        det = bool(det and not self.lazy_table_adam and self._table_adam_width_ok())     # (E/4 a power of two <= 64: ADVICE r4)
+        want_rows = bool(self._plan_wants_rows or self.compact_table_grad)
 
         def make_plan():
             pst = self._aux_stream
             if pst != torch.cuda.current_stream():
                 pst.wait_stream(main)                        # (the ids may have been produced on the caller's stream just now)
             with torch.cuda.stream(pst):
-                pl = ops.ScatterPlan(ids, self.embedding_size, want_rows=self._plan_wants_rows,
-                                     host_count=False, row_bounds=self._plan_row_bounds if self._plan_wants_rows else None)
+                pl = ops.ScatterPlan(ids, self.embedding_size, want_rows=want_rows, host_count=False,
+                                     row_bounds=self._plan_row_bounds if self._plan_wants_rows else None,
+                                     rows_capacity=self._plan_caps[0], out_rows_capacity=self._plan_caps[1])
                 pl.ready = torch.cuda.Event()
                 pl.ready.record(pst)
             pl.record_stream(main)
@@ -600,6 +628,8 @@ class Hpmn_Basic(object):
     def train_step(self, ids: torch.Tensor, label: torch.Tensor, keep_prob=0.5, masks=None,
                    global_batch: Optional[int] = None, item_ids: Optional[torch.Tensor] = None):
         """sess.run(train_step) of code/hpmn.py:482: forward, BPTT, clip, dense TF Adam."""
+        if self.compact_table_grad:
+            return self._train_step_rows(ids, label, keep_prob, masks, global_batch)
         if self._two_pass_table_adam(ids):
             return self._train_step_two_pass(ids, label, keep_prob, masks, global_batch)
         if self._dp_two_pass(ids):
@@ -726,7 +756,7 @@ class Hpmn_Basic(object):
 
     def _two_pass_table_adam(self, ids) -> bool:
         """Single process, user-only graph, no densifying l2 term, a table big enough for the dense sweep to matter."""
-        return bool(self.TWO_PASS_TABLE_ADAM and not self._dp and self._hip_read and not self.l2_reg
+        return bool(self.TWO_PASS_TABLE_ADAM and not self._dp and self._hip_read and not self.l2_reg and not self.compact_table_grad
                     and not self.lazy_table_adam and ids.shape[0] > 0 and self.flat_grad.numel() >= self.TWO_PASS_MIN_NUMEL
                     and self._table_adam_width_ok())
 
@@ -794,7 +824,7 @@ class Hpmn_Basic(object):
         dense table Adam, the four library calls) plus the collectives.  HPMN_TABLE_EXCHANGE: ``auto`` (default) =
         ``rows`` for tables above ROWS_EXCHANGE_MIN_BYTES, else ``allreduce``; ``sharded`` / ``single`` keep their
         one-sweep forms (train_step)."""
-        return bool(self.TWO_PASS_TABLE_ADAM and self._dp and self._hip_read and not self.l2_reg
+        return bool(self.TWO_PASS_TABLE_ADAM and self._dp and self._hip_read and not self.l2_reg and not self.compact_table_grad
                     and not self.lazy_table_adam and self.table_exchange in ("auto", "rows", "allreduce")
                     and self.flat_grad.numel() >= self.TWO_PASS_MIN_NUMEL and self._table_adam_width_ok())
 
@@ -945,9 +975,153 @@ class Hpmn_Basic(object):
         self.apply_gradients(n_emb, self.flat_param.numel(), advance=False)
         return out, ce
 
+    # ------------------------------------------------------------------ r5: the step without a dense gradient table
+    def _train_step_rows(self, ids, label, keep_prob, masks, global_batch):
+        """The two-pass step on COMPACT gradient rows, one process or N (``compact_table_grad``).
+
+        Start of the step, auxiliary stream, underneath the forward: the plan of the deterministic scatter (a stable sort of
+        the batch's ids: distinct rows ascending, their count on the device); the marking of the rows SOMEBODY touches; the
+        early pass of the table Adam over all other rows (gradient exactly zero).  Data parallel: the plan's row buffer (its
+        capacity comes from the batch geometry, the same on every rank) and a vector of 1 + C counts are all-gathered there
+        as they are, and the marking sets one bit per rank from the gathered lists -- 2 collectives and 2 kernels, no padding
+        copies; the counts travel to pinned memory for the moment the host sizes the row exchange.
+        Behind BPTT: the scatter's segmented reduction writes the compact gradient rows (no dense table), and
+        ``hpmn_rows_sum_adam`` updates the touched rows -- one launch; data parallel: the rows go out as C slices of the plan's own
+        buffer (C all-gathers started back to back), and per chunk one launch adds every rank's rows in rank order, clips and
+        applies Adam while the next chunk is still on the wire.  The dense variables follow as before (join, all-reduce,
+        one small Adam launch)."""
+        V, E = self.feature_size, self.embedding_size
+        n_emb = V * E
+        if self._row_flags is None:
+            self._row_flags = ops.table_flags(V, self.device)
+        flags = self._row_flags
+        t = self.adam_t + 1
+        lr_t = self.learning_rate * math.sqrt(1.0 - self.beta2 ** t) / (1.0 - self.beta1 ** t)
+        hp = dict(beta1=self.beta1, beta2=self.beta2, eps=self.adam_eps, clip=1.0)
+        P, M, S = (b[:n_emb].view(V, E) for b in (self.flat_param, self.flat_m, self.flat_v))
+        B = ids.shape[0]
+        dp = self._dp
+        box = {}
+        if dp:
+            gb = ids.shape[0] * self.world if global_batch is None else global_batch      # (ragged shards must pass it)
+            per_sample = ids[0].numel() if B > 0 else self.spec.T * self.spec.F
+            cap = max(1, max(dist.shard_sizes(gb, self.world)) * per_sample)
+            if B * per_sample > cap:
+                raise ValueError("this rank's shard (%d rows) is larger than the largest shard of global_batch=%d over %d ranks"
+                                 % (B, gb, self.world))
+            C = max(1, int(self.table_exchange_chunks))
+            bounds = [(V * k) // C for k in range(C + 1)]
+            self._plan_wants_rows, self._plan_row_bounds = True, bounds
+            self._plan_caps = (cap, B * per_sample + cap)
+        else:
+            gb = global_batch
+            self._plan_wants_rows, self._plan_row_bounds, self._plan_caps = False, None, (0, 0)
+        self.last_scatter_plan = None
+
+        def early():                                          # runs on the auxiliary stream
+            self.flat_grad.zero_()                            # (the dense variables' gradient: a few hundred kB)
+
+            def rest():
+                if not dp:
+                    if B > 0:
+                        ops.table_mark_rows(ids, flags)
+                else:
+                    plan = self.last_scatter_plan if B > 0 else None
+                    if plan is not None:
+                        torch.cuda.current_stream().wait_event(plan.ready)
+                        rows_mine = plan.rows
+                        cnt = torch.cat([plan.count, plan.chunk_counts.to(torch.int32)])
+                    else:                                     # (an empty shard: nothing to send, every collective entered)
+                        rows_mine = torch.empty(cap, device=self.device, dtype=ids.dtype)
+                        cnt = torch.zeros(1 + C, device=self.device, dtype=torch.int32)
+                    ids_all = dist.all_gather_fixed(rows_mine)                  # [world, cap]
+                    cnt_all = dist.all_gather_fixed(cnt)                        # [world, 1 + C] int32
+                    box["ids_all"], box["cnt_all"] = ids_all, cnt_all
+                    box["counts"] = dist.HostCopy(cnt_all)
+                    ops.table_mark_ranks(ids_all, cnt_all, flags, counts_stride=1 + C)
+                v1 = V if self.EARLY_PASS_SPLIT >= 1.0 else max(1, min(V, int(V * self.EARLY_PASS_SPLIT)))
+                probe = self._split_probe if isinstance(self._split_probe, dict) and self._split_probe.get("armed") else None
+                if probe is not None:
+                    probe["a0"].record()
+                ops.adam_step_table(P[:v1], None, M[:v1], S[:v1], flags[:v1], 0, lr_t, **hp)
+                if probe is not None:
+                    probe["a1"].record()
+                if v1 >= V:
+                    return None
+
+                def rest2():                                  # (the rows the forward left no room for: beside BPTT)
+                    ops.adam_step_table(P[v1:], None, M[v1:], S[v1:], flags[v1:], 0, lr_t, **hp)
+                return rest2
+            return rest
+
+        self._tune_early_split()
+        if B > 0:
+            out, ce = self.compute_gradients(ids, label, keep_prob, masks, gb, defer_join=True, _clear_grads=early)
+        else:
+            main = torch.cuda.current_stream()
+            self._aux_stream.wait_stream(main)
+            with torch.cuda.stream(self._aux_stream):
+                r2 = early()()
+                if callable(r2):
+                    r2()
+            main.wait_stream(self._aux_stream)
+            out, ce = dict(prediction=torch.empty(0, device=self.device)), torch.zeros((), device=self.device)
+        pending = out.pop("pending", None)
+        self.adam_t = t
+        plan = self.last_scatter_plan if B > 0 else None
+        if not dp:
+            if plan is not None:
+                ops.rows_sum_adam(P, M, S, flags, plan.rows.view(1, -1), plan.out_rows.view(1, -1, E), lr_t,
+                                  counts=plan.count, **hp)
+        else:
+            main = torch.cuda.current_stream()
+            ids_all, cnt_all = box["ids_all"], box["cnt_all"]
+            for x in (ids_all, cnt_all):
+                x.record_stream(main)                         # (made on the auxiliary stream, consumed here)
+            lens, windows = dist.rows_windows(box["counts"].result())      # (an event wait, long satisfied)
+            src = plan.out_rows if plan is not None else torch.empty(cap, E, device=self.device, dtype=torch.float32)
+            wide = ids.dtype == torch.int64
+            # every chunk's all-gather is started now (they queue on RCCL's stream in order); chunk c is consumed -- all
+            # ranks' rows added in rank order, clip, Adam, in one launch -- while chunk c + 1 is still travelling
+            inflight = []
+            for first, n, capc in windows:
+                a = first[self.rank]
+                inflight.append(dist.all_gather_fixed(src[a:a + capc], async_op=True) if capc > 0 else None)
+            for (first, n, capc), item in zip(windows, inflight):
+                if item is None:
+                    continue
+                g_all, work = item
+                if work is not None:
+                    work.wait()                               # (orders the current stream behind the collective)
+                ops.rows_sum_adam(P, M, S, flags, ids_all, g_all, lr_t, lens=lens, first=first, n=n, **hp)
+            self.last_exchange_mode = "rows"
+            self.last_exchange_bytes = dist.rows_exchange_bytes_windows(windows, E, wide, self.world, cap)
+        if pending is not None:
+            pending.join()
+        lo = self._goff
+        dist.allreduce_sum_(self.flat_grad)                   # (the flat gradient holds the dense variables only)
+        ops.adam_step(self.flat_param[lo:], self.flat_grad, self.flat_m[lo:], self.flat_v[lo:], lr_t, self.beta1,
+                      self.beta2, self.adam_eps, clip=1.0)
+        return out, ce
+
+    def table_gradient(self) -> torch.Tensor:
+        """The embedding-table gradient of the last compute_gradients as a dense [V, E] tensor (inspection / tests): the
+        flat buffer's view, or -- ``compact_table_grad`` -- the scatter plan's compact rows spread out."""
+        if not self.compact_table_grad:
+            return self.grads["Embedding/emb_mtx"]
+        g = torch.zeros(self.feature_size, self.embedding_size, device=self.device, dtype=torch.float32)
+        plan = self.last_scatter_plan
+        if plan is not None:
+            u = int(plan.count.item())
+            g[plan.rows[:u].long()] = plan.out_rows[:u]
+        return g
+
     def apply_gradients(self, lo: int = 0, hi: Optional[int] = None, advance: bool = True):
         """clip + TF-form Adam over elements [lo, hi) of the flat buffers (default: everything);
         ``advance`` = this call starts a new optimiser step."""
+        if self.compact_table_grad:
+            raise RuntimeError("compact_table_grad: there is no dense table gradient to sweep -- use train_step "
+                               "(HPMN_TABLE_GRAD=dense restores the flat gradient over the table)")
         if advance:
             self.adam_t += 1
         t = self.adam_t

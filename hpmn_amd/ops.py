@@ -416,12 +416,62 @@ def adam_step_table(param, grad, m, v, flags, pass_: int, lr_t, beta1=0.9, beta2
                     grad_scale=1.0):
     """hpmn_adam_step_table: the dense table update of ``adam_step`` in two passes (0: rows no id of the batch points
     at, gradient taken as zero; 1: the marked rows, whose gradient rows and flags it clears).  [V, E] views."""
-    _chk_f32(param, grad, m, v)
+    _chk_f32(param, m, v) if grad is None else _chk_f32(param, grad, m, v)
     V, E = param.shape
-    assert grad.shape == param.shape and flags.numel() == V and flags.dtype == torch.uint8
-    rc = _lib.load().hpmn_adam_step_table(param.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(), flags.data_ptr(),
+    assert (grad is None and pass_ == 0 or grad.shape == param.shape) and flags.numel() == V and flags.dtype == torch.uint8
+    rc = _lib.load().hpmn_adam_step_table(param.data_ptr(), _ptr(grad), m.data_ptr(), v.data_ptr(), flags.data_ptr(),
                                            V, E, int(pass_), lr_t, beta1, beta2, eps, clip, grad_scale, _stream())
     _lib.check(rc, "hpmn_adam_step_table")
+
+
+def table_flags(V: int, device) -> torch.Tensor:
+    """The byte-per-row flags of the two-pass table Adam: [V] uint8 zeros over an allocation that is a multiple of 4 bytes
+    (hpmn_table_mark_ranks ORs rank bits into aligned 32-bit words)."""
+    return torch.zeros((V + 3) // 4 * 4, device=device, dtype=torch.uint8)[:V]
+
+
+def table_mark_ranks(ids_all: torch.Tensor, counts: Optional[torch.Tensor], flags: torch.Tensor, cap: Optional[int] = None,
+                     counts_stride: int = 1):
+    """hpmn_table_mark_ranks: flags[row] |= 1 << r for the valid entries of ids_all[r, :] (``counts``: int32 device tensor,
+    rank r's list length at counts[r * counts_stride]; None: the first ``cap`` entries, ids outside [0, V) ignored)."""
+    _chk_ids(ids_all)
+    assert ids_all.dim() == 2 and flags.dtype == torch.uint8 and flags.is_cuda and flags.is_contiguous()
+    world, stride = ids_all.shape
+    if counts is not None:
+        assert counts.dtype == torch.int32 and counts.is_cuda and counts.is_contiguous()
+    rc = _lib.load().hpmn_table_mark_ranks(ids_all.data_ptr(), stride, world, _ptr(counts), counts_stride,
+                                            stride if cap is None else cap, flags.data_ptr(), flags.numel(),
+                                            _idf(ids_all, False), _stream())
+    _lib.check(rc, "hpmn_table_mark_ranks")
+
+
+def rows_sum_adam(param, m, v, flags, ids_all, rows_all, lr_t, *, counts=None, counts_stride=1, lens=None, first=None,
+                  n=None, beta1=0.9, beta2=0.999, eps=1e-8, clip=1.0, grad_scale=1.0):
+    """hpmn_rows_sum_adam: the update of the TOUCHED table rows from compact gradient rows, all ranks' lists in one launch.
+    ``ids_all`` [world, ids_stride] (every rank's ascending distinct rows), ``rows_all`` [world, rows_stride, E] (their
+    gradient rows; rows_all[r][i] belongs to list entry first[r] + i), list lengths from the device tensor ``counts`` (int32,
+    rank r at counts[r * counts_stride]) or the host list ``lens``; the call consumes the window [first[r], first[r] + n[r])
+    of every list (default: everything up to ids_stride).  param / m / v: [V, E] views; flags: the rank-bit bytes."""
+    _chk_f32(param, m, v, rows_all)
+    _chk_ids(ids_all)
+    assert ids_all.dim() == 2 and rows_all.dim() == 3 and rows_all.shape[0] == ids_all.shape[0]
+    world, ids_stride = ids_all.shape
+    V, E = param.shape
+    assert rows_all.shape[2] == E and flags.numel() == V and flags.dtype == torch.uint8
+    a = _lib.HpmnRowsAdam()
+    a.world, a.E, a.id_flags, a.counts_stride = world, E, _idf(ids_all, False), counts_stride
+    a.ids, a.ids_stride = ids_all.data_ptr(), ids_stride
+    if counts is not None:
+        assert counts.dtype == torch.int32 and counts.is_cuda and counts.is_contiguous()
+        a.counts = counts.data_ptr()
+    for r in range(world):
+        a.len[r] = int(lens[r]) if lens is not None else ids_stride
+        a.first[r] = int(first[r]) if first is not None else 0
+        a.n[r] = int(n[r]) if n is not None else min(ids_stride, rows_all.shape[1]) - a.first[r]
+    a.rows, a.rows_stride = rows_all.data_ptr(), rows_all.shape[1]
+    a.flags, a.param, a.m, a.v, a.V = flags.data_ptr(), param.data_ptr(), m.data_ptr(), v.data_ptr(), V
+    a.lr_t, a.beta1, a.beta2, a.eps, a.clip, a.grad_scale = lr_t, beta1, beta2, eps, clip, grad_scale
+    _lib.check(_lib.load().hpmn_rows_sum_adam(C.byref(a), _stream()), "hpmn_rows_sum_adam")
 
 
 def scan_forward_inference(spec: ScanSpec, ids, emb, weights: Sequence[torch.Tensor], workspace=None):
@@ -826,7 +876,8 @@ class ScatterPlan:
     ``rows[:U]`` = the batch's distinct table rows (ascending), ``out_rows[:U]`` = their gradient rows once the scatter has
     run, ``count`` = U on the device; ``count_host()`` is an event-guarded read of its pinned copy (no device sync)."""
 
-    def __init__(self, ids: torch.Tensor, E: int, want_rows: bool = False, host_count: bool = False, row_bounds=None):
+    def __init__(self, ids: torch.Tensor, E: int, want_rows: bool = False, host_count: bool = False, row_bounds=None,
+                 rows_capacity: int = 0, out_rows_capacity: int = 0):
         _chk_ids(ids)
         dev = ids.device
         flat = ids.reshape(-1)
@@ -843,14 +894,19 @@ class ScatterPlan:
         # ``row_bounds`` (ascending table-row boundaries b_0 = 0 < ... < b_C = V): chunk_counts[c] = distinct rows in
         # [b_c, b_c+1) -- the data-parallel exchange sends the rows chunk by chunk (hpmn.py).  The unused tail of `rows` is
         # then filled with the id type's maximum so that a searchsorted over the whole buffer stops at the count.
-        self.rows = (torch.full((n,), torch.iinfo(ids.dtype).max, device=dev, dtype=ids.dtype) if row_bounds is not None
-                     else torch.empty(n, device=dev, dtype=ids.dtype))
+        # ``rows_capacity`` / ``out_rows_capacity`` (r5): the buffers as the data-parallel exchange sends them -- `rows` is
+        # all-gathered whole (the batch geometry's capacity, the same on every rank), slices of `out_rows` go out chunk by
+        # chunk, each as long as the LARGEST rank's chunk (what lies behind this rank's own entries is never read)
+        nr = max(n, int(rows_capacity))
+        self.rows = (torch.full((nr,), torch.iinfo(ids.dtype).max, device=dev, dtype=ids.dtype) if row_bounds is not None
+                     else torch.empty(nr, device=dev, dtype=ids.dtype))
         self.count = torch.zeros(1, **i32)
         lib = _lib.load()
         _lib.check(lib.hpmn_scatter_plan(self.sorted.data_ptr(), self.id_flags, n, self.seg.data_ptr(), self.start.data_ptr(),
                                          self.rows.data_ptr(), self.count.data_ptr(), _stream()), "hpmn_scatter_plan")
         self.partials = torch.empty(max(1, lib.hpmn_embed_grad_segsum_partials_floats(n, E)), device=dev, dtype=torch.float32)
-        self.out_rows = torch.empty(max(n, 1), E, device=dev, dtype=torch.float32) if want_rows else None
+        self.out_rows = (torch.empty(max(n, 1, int(out_rows_capacity)), E, device=dev, dtype=torch.float32)
+                         if want_rows else None)
         self.chunk_counts = None
         if row_bounds is not None:
             # (the boundaries are the same every step: their device tensor is made ONCE.  torch.as_tensor(list, device=...)
@@ -1006,7 +1062,7 @@ def abi_backward(spec: ScanSpec, ids, saved: "AbiSaved", weights, d_memory, d_la
     saved.desc.mask_id0 = _idf(ids, spec.mask_id0)     # (the scatter's ids may be narrower than the forward's: lazy table Adam)
     rc = _lib.load().hpmn_scan_bwd(ctx, C.byref(saved.desc), ids.data_ptr(), _wptrs(weights, K, 0),
                                    _wptrs(weights, K, 2), d_memory.data_ptr(), d_last.data_ptr(), arr(0), arr(1),
-                                   arr(2), arr(3), grad_out[0].data_ptr(), saved.workspace.data_ptr(),
+                                   arr(2), arr(3), _ptr(grad_out[0]), saved.workspace.data_ptr(),
                                    int(defer_join), _stream())
     _lib.check(rc, "hpmn_scan_bwd")
     if defer_join:
@@ -1102,10 +1158,6 @@ def scan_forward_train_layers(spec: ScanSpec, ids, emb, weights: Sequence[torch.
     return memory, last, saved
 
 
-# bench.py sets this to a list: the layer-0 reverse scan of every step is then bracketed by HIP events on the launch
-# stream (the weight-gradient kernels of the layer above are live on the side stream, as in any step)
-PROBE = None
-
 # measured neutral (C3 4.143 vs 4.169 ms/step, C4 10.48 vs 10.33): off by default, kept as an option
 SPLIT_LAYER0_BWD = int(os.environ.get("HPMN_SPLIT_LAYER0_BWD", "0")) != 0
 
@@ -1140,21 +1192,29 @@ def scan_backward(spec: ScanSpec, ids, saved, weights: Sequence[torch.Tensor], d
     """BPTT of scan_forward_train (every forward path leaves the same saved states).  ``scatter_plan``: the library step
     scatters through it (deterministic segmented reduction); the per-layer measurement paths keep the atomic kernel."""
     if isinstance(saved, AbiSaved):
-        if PROBE is None:
-            set_scatter_plan(d_memory.device, scatter_plan)
-            return abi_backward(spec, ids, saved, weights, d_memory, d_last, grad_out, defer_join)
-        saved = list(saved)            # bench.py's in-step probe brackets a launch: per-layer path over the same states
-        return scan_backward_layers(spec, ids, saved, weights, d_memory, d_last, grad_out, defer_join)
+        set_scatter_plan(d_memory.device, scatter_plan)
+        return abi_backward(spec, ids, saved, weights, d_memory, d_last, grad_out, defer_join)
     mode = pipe_mode(spec) if d_memory.shape[0] > 0 else ""
-    if mode == "all":
-        return pipe_backward(spec, ids, saved, weights, d_memory, d_last, grad_out, defer_join)
-    if mode == "upper":
-        return upper_backward(spec, ids, saved, weights, d_memory, d_last, grad_out, defer_join)
-    return scan_backward_layers(spec, ids, saved, weights, d_memory, d_last, grad_out, defer_join)
+    if mode in ("all", "upper"):
+        if scatter_plan is not None:
+            # (ADVICE r4) these launches scatter atomically on their own: a plan would be ignored and its compact rows
+            # -- what the data-parallel exchange sends -- never written
+            raise RuntimeError("HPMN_PIPE=%s cannot scatter through a ScatterPlan (set HPMN_DET_SCATTER=0 / HPMN_ROWS_TAIL=0)" % mode)
+        fn = pipe_backward if mode == "all" else upper_backward
+        return fn(spec, ids, saved, weights, d_memory, d_last, grad_out, defer_join)
+    return scan_backward_layers(spec, ids, saved, weights, d_memory, d_last, grad_out, defer_join, scatter_plan=scatter_plan)
+
+
+def _scatter(plan, ids, d_x0, d_emb, spec):
+    """The per-layer paths' scatter: through the plan when one is given (its compact rows are what the caller consumes)."""
+    if plan is not None and plan.n > 0:
+        embed_grad_segsum(plan, tuple(ids.shape), d_x0, d_emb, spec.front_zero, spec.mask_id0)
+    else:
+        embed_grad_scatter(ids, d_x0, d_emb, spec.front_zero, spec.mask_id0)
 
 
 def scan_backward_layers(spec: ScanSpec, ids, saved, weights: Sequence[torch.Tensor], d_memory, d_last, grad_out,
-                         defer_join: bool = False):
+                         defer_join: bool = False, scatter_plan: Optional["ScatterPlan"] = None):
     """BPTT of scan_forward_train_layers.  ``grad_out`` = [d_emb, d_wg0, d_bg0, d_wc0, d_bc0, d_wg1, ...]:
     pre-zeroed buffers (views of the optimiser's flat gradient) that are accumulated into.
 
@@ -1202,14 +1262,8 @@ def scan_backward_layers(spec: ScanSpec, ids, saved, weights: Sequence[torch.Ten
                                     gw[4 * i + 3], want_dx=False, keep=keep, t_range=(0, cut))
             else:
                 fdx = scan_bwd_fuses_dx(H, B) and in_dims[i] in (16, 32, 64)
-                if PROBE is not None and i == 0:      # bench.py: the dominant kernel timed INSIDE a real step
-                    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                    ev[0].record(main)
                 gru_scan_bwd(wg, wc, in_dims[i], hs, gates, d_memory[:, i, :], d_y, spec.periods[i], out=d_act[i],
                              d_x=d_x[i] if fdx else None)
-                if PROBE is not None and i == 0:
-                    ev[1].record(main)
-                    PROBE.append(ev)
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
                     gru_param_grads(x_in, hs, gates, d_act[i], wg, wc, gw[4 * i], gw[4 * i + 1], gw[4 * i + 2],
@@ -1218,7 +1272,7 @@ def scan_backward_layers(spec: ScanSpec, ids, saved, weights: Sequence[torch.Ten
                 gru_input_grad(d_act[i], wg, wc, in_dims[i], out=d_x[i])
         d_x0 = d_x[0]
         d_x0[:, spec.last_index, :] += d_last
-        embed_grad_scatter(ids, d_x0, d_emb, spec.front_zero, spec.mask_id0)
+        _scatter(scatter_plan, ids, d_x0, d_emb, spec)
         pending = PendingGrads([side], (keep, d_act, d_x, saved))
         if defer_join:
             return pending
@@ -1256,7 +1310,7 @@ def scan_backward_layers(spec: ScanSpec, ids, saved, weights: Sequence[torch.Ten
                         want_dx=False, keep=keep)
     d_x0 = d_x[0]
     d_x0[:, spec.last_index, :] += d_last
-    embed_grad_scatter(ids, d_x0, d_emb, spec.front_zero, spec.mask_id0)
+    _scatter(scatter_plan, ids, d_x0, d_emb, spec)
     pending = PendingGrads(set(streams[1:] + [side]), (keep, d_act, d_x, saved))
     if defer_join:
         return pending

@@ -34,10 +34,11 @@
 extern "C" {
 #endif
 
-#define HPMN_ABI_VERSION 11
+#define HPMN_ABI_VERSION 12
 #define HPMN_ID_MASK0 1   /* id-flags bit 0: id 0 gathers a zero row and receives no gradient (the Hpmn class)  */
 #define HPMN_ID_I64 2     /* id-flags bit 1: the ids tensor is int64 (default: int32)                          */
 #define HPMN_MAX_LAYERS 12
+#define HPMN_MAX_RANKS 8   /* data-parallel ranks hpmn_rows_sum_adam tells apart (a rank bit per flags byte)        */
 /* Saved gates without the candidate (ABI v11): the forward leaves the candidate third of every gates row unwritten
  * (HpmnGruFusedFwd.flags), the reverse scan recovers what it needs of it from the saved states it reads anyway
  * (HpmnGruBwd.flags): h_t = u h_{t-1} + (1 - u) c gives q = (1 - u) c = h_t - u h_{t-1}, and the candidate only ever enters
@@ -619,6 +620,48 @@ int hpmn_table_mark_rows(const void *ids, int64_t n_ids, uint8_t *flags, int64_t
 int hpmn_adam_step_table(float *param, float *grad, float *m, float *v, uint8_t *flags, int64_t V, int32_t E,
                          int32_t pass, float lr_t, float beta1, float beta2, float eps, float clip, float grad_scale,
                          void *stream);
+
+/* The update of the TOUCHED table rows from COMPACT gradient rows -- the single-GPU tail and the data-parallel exchange
+ * in one launch, with no dense [V, E] gradient table anywhere (ABI v12; csrc/rows_adam.hip).  Reference semantics:
+ * code/hpmn.py:204-214 (the IndexedSlices of :421-422 densified, clipped per element, dense TF Adam); SURVEY.md 8e (replicated
+ * tables: every rank needs the SUM of all ranks' gradient rows, clipped after the sum).
+ *   ids   [world, ids_stride]       rank r's distinct table rows, ASCENDING (hpmn_scatter_plan's `rows`), as the all-gather
+ *                                   leaves them; the first len[r] entries are valid (counts != NULL: the DEVICE value
+ *                                   counts[r * counts_stride] instead -- the single-GPU step never learns its count on the host)
+ *   rows  [world, rows_stride, E]   gradient rows (hpmn_embed_grad_segsum's `out_rows`): rows[r][i] belongs to list entry
+ *                                   first[r] + i.  The call consumes the WINDOW first[r] <= j < first[r] + n[r] of every
+ *                                   rank's list; windows of different calls must cover disjoint TABLE-ROW RANGES that are
+ *                                   the same on every rank (a chunk of the exchange = a range of table rows), so that a
+ *                                   row's entries all lie in the windows of one call.
+ *   flags [V] bytes                 bit r set <=> rank r's list holds the row (hpmn_table_mark_ranks; world == 1: any
+ *                                   non-zero byte, e.g. hpmn_table_mark_rows').  The base must be 4-byte aligned and the
+ *                                   allocation a multiple of 4 bytes.
+ * Per distinct row of the union: the lowest rank holding it adds the ranks' rows in rank order 0..world-1, clips, applies
+ * the TF-form Adam update of hpmn_adam_step to param / m / v [V, E] in place and clears the row's flag byte -- with
+ * hpmn_adam_step_table(pass 0) over the unflagged rows this IS the dense update of hpmn_adam_step, bit for bit on the same
+ * gradient rows.  E/4 a power of two <= 64; 1 <= world <= HPMN_MAX_RANKS. */
+typedef struct HpmnRowsAdam {
+    int32_t world, E;
+    int32_t id_flags;                   /* HPMN_ID_I64: ids are int64                                       */
+    int32_t counts_stride;              /* ints between two ranks' entries of `counts`                      */
+    const void *ids;
+    int64_t ids_stride;
+    const int32_t *counts;              /* optional (device)                                                */
+    int64_t len[HPMN_MAX_RANKS];        /* list lengths (used when counts == NULL)                          */
+    int64_t first[HPMN_MAX_RANKS];
+    int64_t n[HPMN_MAX_RANKS];
+    const float *rows;
+    int64_t rows_stride;                /* rows between two ranks' blocks of `rows`                         */
+    uint8_t *flags;
+    float *param, *m, *v;
+    int64_t V;
+    float lr_t, beta1, beta2, eps, clip, grad_scale;
+} HpmnRowsAdam;
+int hpmn_rows_sum_adam(const HpmnRowsAdam *args, void *stream);
+/* flags[row] |= 1 << r for the first (counts ? counts[r * counts_stride] : cap) entries of ids[r, :], r < world.
+ * Entries outside [0, V) are ignored.  Runs underneath the forward (atomic OR on the aligned 32-bit word). */
+int hpmn_table_mark_ranks(const void *ids, int64_t ids_stride, int32_t world, const int32_t *counts, int32_t counts_stride,
+                          int64_t cap, uint8_t *flags, int64_t V, int32_t id_flags, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Online incremental memory update -- the serving-time form of build_memory: ONE new event per

@@ -42,7 +42,8 @@ def test_struct_layout_matches_c_compiler(tmp_path):
                "HpmnGruBwd": _lib.HpmnGruBwd, "HpmnGruWgrad": _lib.HpmnGruWgrad, "HpmnReadDesc": _lib.HpmnReadDesc,
                "HpmnScanDesc": _lib.HpmnScanDesc, "HpmnOnlineUpdate": _lib.HpmnOnlineUpdate,
                "HpmnGruFusedFwd": _lib.HpmnGruFusedFwd, "HpmnGruPairFwd": _lib.HpmnGruPairFwd, "HpmnGruPairBwd": _lib.HpmnGruPairBwd, "HpmnPipe": _lib.HpmnPipe,
-               "HpmnTrainLayout": _lib.HpmnTrainLayout, "HpmnScatterPlan": _lib.HpmnScatterPlan}
+               "HpmnTrainLayout": _lib.HpmnTrainLayout, "HpmnScatterPlan": _lib.HpmnScatterPlan,
+               "HpmnRowsAdam": _lib.HpmnRowsAdam}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "hpmn_hip.h"', "int main(void){"]
     for name, st in structs.items():
         lines.append('printf("%s %%zu\\n", sizeof(%s));' % (name, name))
@@ -79,6 +80,18 @@ def test_error_codes_without_touching_a_device(lib):
     assert lib.hpmn_embed_gather(None, None, None, 5, 3, 6, 10, 1, None) == -2                          # E % 4
     assert lib.hpmn_embed_grad_scatter(None, None, None, 2, 5, 3, 24, 0, 10, 1, None) == -2             # 64 % E
     assert lib.hpmn_table_mark_rows(None, 0, None, 10, 2, None) == 0 and lib.hpmn_table_mark_rows(None, 4, None, 10, 2, None) == -1
+    ra = _lib.HpmnRowsAdam()
+    assert lib.hpmn_rows_sum_adam(None, None) == -1 and lib.hpmn_rows_sum_adam(C.byref(ra), None) == -1     # world == 0
+    ra.world, ra.E, ra.V = 2, 16, 100
+    assert lib.hpmn_rows_sum_adam(C.byref(ra), None) == 0                                                   # empty windows
+    ra.n[1], ra.rows_stride, ra.ids_stride = 5, 8, 8
+    assert lib.hpmn_rows_sum_adam(C.byref(ra), None) == -1                                                  # null buffers
+    ra.E = 24
+    assert lib.hpmn_rows_sum_adam(C.byref(ra), None) == -2                                                  # E/4 not a power of two
+    ra.E, ra.world = 16, 9
+    assert lib.hpmn_rows_sum_adam(C.byref(ra), None) == -1                                                  # > HPMN_MAX_RANKS
+    assert lib.hpmn_table_mark_ranks(None, 0, 2, None, 0, 0, None, 10, 0, None) == 0
+    assert lib.hpmn_table_mark_ranks(None, 8, 2, None, 0, 8, None, 10, 0, None) == -1
     plan = _lib.HpmnScatterPlan()
     plan.n = 30
     assert lib.hpmn_embed_grad_segsum(C.byref(plan), None, None, 2, 5, 3, 24, 0, 0, None, 0, None) == -2  # 256 % (E/4)

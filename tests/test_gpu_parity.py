@@ -783,7 +783,8 @@ def test_training_steps_are_bit_reproducible(dev, tmp_path, monkeypatch, name, c
         m = make_model(cfg, tmp_path / ("r%d" % r), p)
         assert m.det_scatter
         m.compute_gradients(t_ids, t_lab, keep_prob=1.0)
-        g0 = m.grads["Embedding/emb_mtx"].clone()
+        assert m.compact_table_grad                      # (r5: no dense gradient table -- the scatter's compact rows, spread out)
+        g0 = m.table_gradient().clone()
         for step in range(3):
             m.train_step(t_ids.roll(step, 0), t_lab.roll(step, 0), keep_prob=1.0)
         torch.cuda.synchronize()
@@ -1083,7 +1084,8 @@ def test_table_rows_beyond_2_gib_give_identical_results(dev, tmp_path):
     assert torch.equal(a["logit"], b["logit"]) and torch.equal(a["memory"], b["memory"])
     small.compute_gradients(ts, tl, keep_prob=1.0)
     big.compute_gradients(tb, tl, keep_prob=1.0)
-    gs, gb = small.grads["Embedding/emb_mtx"], big.grads["Embedding/emb_mtx"]
+    assert big.compact_table_grad and big.grads["Embedding/emb_mtx"] is None     # (r5: a table this size keeps NO dense gradient)
+    gs, gb = small.table_gradient(), big.table_gradient()
     np.testing.assert_allclose(gb[base:].cpu().numpy(), gs.cpu().numpy(), rtol=0, atol=1e-7)   # (atomics: last-bit order)
     assert float(gb[:base].abs().max()) == 0.0
     for k in p:
@@ -1175,17 +1177,19 @@ def test_a_table_of_more_rows_than_int32_holds(dev, tmp_path):
     assert torch.equal(a["logit"], b["logit"]) and torch.equal(a["memory"], b["memory"])
     small.compute_gradients(ts, tl, keep_prob=1.0)
     big.compute_gradients(tb, tl, keep_prob=1.0)
-    gs, gb = small.grads["Embedding/emb_mtx"], big.grads["Embedding/emb_mtx"]
+    assert big.compact_table_grad and big.grads["Embedding/emb_mtx"] is None     # (r5: param + m + v only, 105 GB)
+    gs, gb = small.table_gradient(), big.table_gradient()                        # (spread out for this comparison: 35 GB)
     np.testing.assert_allclose(gb[base:].cpu().numpy(), gs.cpu().numpy(), rtol=0, atol=1e-7)
     assert float(gb[base - 1_000_000:base].abs().max()) == 0.0 and float(gb[:1_000_000].abs().max()) == 0.0
     assert float(gb[:base].abs().max()) == 0.0                   # (one reduction over 35 GB: nothing anywhere below the top rows)
+    del gb
     small.train_step(ts, tl, keep_prob=1.0)
     big.train_step(tb, tl, keep_prob=1.0)                         # two-pass dense Adam over 2.2 G rows, int64 row marking
     torch.cuda.synchronize()
     np.testing.assert_allclose(big.params["Embedding/emb_mtx"][base:].cpu().numpy(),
                                small.params["Embedding/emb_mtx"].cpu().numpy(), rtol=0, atol=2e-6)
     assert float(big.params["Embedding/emb_mtx"][base - 1_000_000:base].abs().max()) == 0.0
-    assert float(big.flat_grad[:V * 4].view(-1)[::4099].abs().max()) == 0.0          # pass 1 cleared the rows it consumed
+    assert int(big._row_flags[base:].max()) == 0 and int(big._row_flags[::4099].max()) == 0    # the update cleared the flags it consumed
     a, b = small.forward_inference(ts), big.forward_inference(tb)
     np.testing.assert_allclose(b["logit"].cpu().numpy(), a["logit"].cpu().numpy(), rtol=0, atol=1e-5)
     del big
@@ -1197,33 +1201,44 @@ def test_two_pass_table_adam_equals_the_dense_sweep(dev, tmp_path, monkeypatch):
     """train_step's dense table update split in two passes (rows the batch does not point at early, on the auxiliary
     stream; the batch's rows behind the scatter) must leave every buffer exactly where the one-sweep path leaves it:
     parameters and both moment buffers after several steps, gradient table and row flags all-zero in between, and a
-    stand-alone compute_gradients in the middle must not confuse it."""
+    stand-alone compute_gradients in the middle must not confuse it.  r5: three forms -- the touched rows updated from the
+    scatter's COMPACT rows with no dense gradient table at all (hpmn_rows_sum_adam, the default), the r4 two-pass step over
+    a dense gradient table, the one sweep."""
     from hpmn_amd import hpmn as H
     cfg = O.HpmnConfig(4000, 2, 41, 64, 16, 3, (2, 2, 2), 3, True, 1e-5)
     p = f32_params(cfg, 71)
-    rng = np.random.default_rng(72)
     batches = [rand_ids(cfg, 6, 100 + i, ragged=True) for i in range(4)]
     results = []
-    for two_pass in (True, False):
-        monkeypatch.setattr(H.Hpmn_Basic, "TWO_PASS_TABLE_ADAM", two_pass)
+    for form in ("compact", "dense", "sweep"):
+        monkeypatch.setattr(H.Hpmn_Basic, "TWO_PASS_TABLE_ADAM", form != "sweep")
         monkeypatch.setattr(H.Hpmn_Basic, "TWO_PASS_MIN_NUMEL", 0)
+        monkeypatch.setenv("HPMN_TABLE_GRAD", "dense" if form == "dense" else "auto")
         m = make_model(cfg, tmp_path, p)
+        assert m.compact_table_grad == (form == "compact")
+        assert (m.grads["Embedding/emb_mtx"] is None) == (form == "compact")
         masks = (torch.ones(6, 200, device=dev), torch.ones(6, 80, device=dev))
         for i, (ids, label) in enumerate(batches):
             ti, tl = torch.as_tensor(ids).to(dev), torch.as_tensor(label).to(dev)
             if i == 2:
                 m.compute_gradients(ti, tl, keep_prob=1.0)            # leaves a table gradient behind
-            assert m._two_pass_table_adam(ti) == two_pass
+                if form == "compact":
+                    g_compact = m.table_gradient().clone()
+                elif form == "dense":
+                    np.testing.assert_allclose(m.grads["Embedding/emb_mtx"].cpu().numpy(), g_compact.cpu().numpy(), rtol=1e-5,
+                                               atol=1e-7)
+            assert m._two_pass_table_adam(ti) == (form == "dense")
             m.train_step(ti, tl, keep_prob=1.0, masks=masks)
-            if two_pass:
+            if form == "dense":
                 n_emb = m.params["Embedding/emb_mtx"].numel()
                 assert float(m.flat_grad[:n_emb].abs().max()) == 0.0
+            if form != "sweep":
                 assert int(m._row_flags.max()) == 0
         torch.cuda.synchronize()
         results.append([b.clone() for b in (m.flat_param, m.flat_m, m.flat_v)])
-    for a, b, name in zip(results[0], results[1], ("param", "m", "v")):
-        # (the scatter's fp32 atomics may order differently run to run: last-bit differences in touched rows)
-        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-5, atol=1e-7, err_msg=name)
+    for other in (1, 2):
+        for a, b, name in zip(results[0], results[other], ("param", "m", "v")):
+            # (the atomic scatter of the dense forms may order differently run to run: last-bit differences in touched rows)
+            np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-5, atol=1e-7, err_msg=name)
 
 
 @pytest.mark.gpu
