@@ -570,7 +570,7 @@ def cpu_baseline(c, seed=0, budget_s=25.0):
                       % (len(tt), bs, c["name"], warm, threads, sum(tt), len(tf))}
 
 
-def dp_report(model, c, batches, world, ms_per_step, n_model=8, busbw_gbps=300.0):
+def dp_report(model, c, batches, world, ms_per_step, n_model=8, busbw_gbps=300.0, one_rank=None):
     """Per-step collective bytes of the data-parallel step, measured on this run's batches, and a MODEL of what they cost
     at N = 8 (no multi-GPU box is available to the builder: the driver's SCALE run is the measurement).  The model:
     ring collectives at ``busbw_gbps`` GB/s of bus bandwidth per rank (an assumption -- 7 xGMI links x ~153 GB/s peak,
@@ -588,20 +588,75 @@ def dp_report(model, c, batches, world, ms_per_step, n_model=8, busbw_gbps=300.0
     hide_ms = 0.3
     t_dense, t_rows = dense_b / busbw_gbps / 1e6, rows_b / busbw_gbps / 1e6
     # this step's single-GPU time stands for the per-rank compute of the weak-scaling run
-    eff = lambda t: ms_per_step / (ms_per_step + max(0.0, t - hide_ms) + small_b / busbw_gbps / 1e6 + 0.02)
+    # r5: the per-rank compute of the weak-scaling run is the DATA-PARALLEL step's own time with nobody to talk to (one rank on
+    # RCCL, every collective issued, measured in a sub-run of the same timed loop) where that was measured; the plain step otherwise
+    one_rank = one_rank or {}
+    base = lambda mode: (one_rank.get(mode) or ms_per_step)
+    eff = lambda t, mode: ms_per_step / (base(mode) + max(0.0, t - hide_ms) + small_b / busbw_gbps / 1e6 + 0.02)
+    if world == 1:
+        dp_extra = {"one_rank_rccl_ms": one_rank or None, "plain_ms": ms_per_step}
+    else:
+        dp_extra = {}
     return {
+        **dp_extra,
         "table_exchange": model.table_exchange, "world": world,
         "measured_bytes_received_last_step": int(getattr(model, "last_exchange_bytes", 0)) if world > 1 else None,
         "unique_rows_per_rank_per_step": u, "table_rows": n_emb // E,
         "model_n%d" % n_model: {
             "assumed_busbw_GBps": busbw_gbps, "hidden_under_ms": hide_ms,
-            "dense_allreduce": {"bytes_per_rank": dense_b, "ms": t_dense, "weak_scaling_efficiency": eff(t_dense)},
-            "touched_rows_allgather": {"bytes_per_rank": rows_b, "ms": t_rows, "weak_scaling_efficiency": eff(t_rows)},
+            "dense_allreduce": {"bytes_per_rank": dense_b, "ms": t_dense, "weak_scaling_efficiency": eff(t_dense, "allreduce")},
+            "touched_rows_allgather": {"bytes_per_rank": rows_b, "ms": t_rows, "weak_scaling_efficiency": eff(t_rows, "rows")},
             "dense_parameters_allreduce_bytes": small_b,
             "note": "modelled, not measured; strong scaling at a fixed global batch cannot speed up the chain of scans "
                     "(its length does not depend on the batch)",
         },
     }
+
+
+# The timed region's reduced-precision products: the GRU weight gradients, layer 0's input gradient and
+# (H = 128) the input projection run as three bf16 products on split operands (hi.hi + hi.lo + lo.hi, fp32 accumulate:
+# ~16 bits of operand mantissa); evaluation-sized forward passes at H = 64 on three f16 products.  These switches put every one
+# of them back on fp32 kernels: the `ms_per_step_all_fp32` figure of the bench line is the SAME timed loop under them.
+ALL_FP32_ENV = {"HPMN_WGRAD_BF16": "0", "HPMN_BWD_DX_INLOOP": "0", "HPMN_PROJ_BF16": "0", "HPMN_DX_BF16": "0",
+                "HPMN_TILED_EVAL_MIN_ROWS": "0"}
+
+
+def dtype_string(c):
+    if c["H"] == 32:
+        return "f32"
+    s = "f32 (GRU weight gradients + layer-0 input gradient: bf16x3 split operands, f32 accumulate"
+    if c["H"] == 128:
+        s += "; input projection / input gradients: bf16x3 split"
+    if c["H"] == 64:
+        s += "; eval passes >= 1536 rows: f16x3 split"
+    return s + ")"
+
+
+def side_legs(args):
+    """The same timed loop in sub-processes (same box, same batches, no other legs): every product on fp32 kernels; the
+    data-parallel step with ONE rank on RCCL and the world-size-1 short cuts off -- what the step's machinery costs before a
+    byte crosses xGMI -- with both table exchanges."""
+    import subprocess
+    base = [sys.executable, os.path.abspath(__file__), "--config", args.config, "--steps", str(args.steps), "--warmup",
+            str(args.warmup), "--no-cpu-baseline", "--no-auc", "--no-eval", "--no-roofline", "--no-parity-gate", "--no-side-legs"]
+    if args.batch:
+        base += ["--batch", str(args.batch)]
+    if args.lazy_table_adam:
+        base += ["--lazy-table-adam"]
+
+    def run(extra_args, extra_env):
+        env = dict(os.environ)
+        env.update(extra_env)
+        try:
+            r = subprocess.run(base + extra_args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+            line = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+            return json.loads(line[-1])["ms_per_step"] if r.returncode == 0 and line else None
+        except Exception:
+            return None
+    out = {"all_fp32_ms_per_step": run([], ALL_FP32_ENV)}
+    if not args.lazy_table_adam:
+        out["one_rank_rccl_ms"] = {m: run(["--one-rank-rccl", m], {}) for m in ("rows", "allreduce")}
+    return out
 
 
 def self_spawn(n, backend):
@@ -644,7 +699,15 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1 (nccl == RCCL; gloo lets several ranks share one GPU for a dry run)")
     ap.add_argument("--auc-steps", type=int, default=300)
+    ap.add_argument("--no-side-legs", action="store_true",
+                    help="skip the sub-runs of the same timed loop: all-fp32 kernels, the data-parallel step with one rank on RCCL")
+    ap.add_argument("--one-rank-rccl", default="", choices=["", "rows", "allreduce"],
+                    help="(side leg) the DATA-PARALLEL step with a one-rank RCCL process group and the world-size-1 short cuts off")
     args = ap.parse_args()
+    if args.one_rank_rccl:
+        os.environ["HPMN_DP_FORCE_COLLECTIVES"] = "1"
+        os.environ["HPMN_TABLE_EXCHANGE"] = args.one_rank_rccl
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", os.environ.get("HPMN_ONE_RANK_QUEUES", "6"))
     c = dict(CONFIGS[args.config])
     c["config_id"] = args.config
     if args.batch:
@@ -671,6 +734,13 @@ def main():
         local_rank = local_rank % max(1, torch.cuda.device_count())      # dry run: ranks may share a device
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    if args.one_rank_rccl:
+        import socket
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(sock.getsockname()[1])
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        torch.distributed.init_process_group("nccl", rank=0, world_size=1, device_id=device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
@@ -698,9 +768,14 @@ def main():
         per_gpu, global_batch = c["batch"], c["batch"] * world
     batches = synth_batches(c, n_distinct, per_gpu, 20190521 + 3 + 1000 * rank, device)
 
+    prefetch = os.environ.get("HPMN_BENCH_NEXT_IDS", "1") != "0"
+
     def step(i):
         ids, label = batches[i % n_distinct]
-        model.train_step(ids, label, keep_prob=0.5, global_batch=global_batch)
+        # the harness knows the next batch (Hpmn.train hands it over the same way): what depends on the ids alone -- the
+        # scatter's plan, under data parallel the exchange of the ranks' distinct rows -- is prepared underneath this step's BPTT
+        nxt = dict(next_ids=batches[(i + 1) % n_distinct][0], next_global_batch=global_batch) if prefetch else {}
+        model.train_step(ids, label, keep_prob=0.5, global_batch=global_batch, **nxt)
 
     log("data ready; warmup")
     for i in range(args.warmup):
@@ -826,7 +901,7 @@ def main():
                       else "training sequences/sec (fwd+BPTT+clip+dense Adam)",
             "value": seqs / elapsed, "unit": "sequences/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": args.scaling, "vs_baseline": None, "dtype": dtype_string(c), "data": "synthetic",
             "config": {"workload": c["name"], "config_id": args.config, "per_gpu_batch": per_gpu,
                        "global_batch": global_batch, "max_len": c["T"], "scan_steps": layer_lengths(c),
                        "hidden": c["H"], "layers": c["K"], "vocab_rows": c["V"], "keep_prob": 0.5,
@@ -841,8 +916,16 @@ def main():
             result["eval_pass"] = eval_pass
         if cadence is not None:
             result["xlong_cadence"] = cadence
+        side = {}
+        if world == 1 and not args.no_side_legs and not args.one_rank_rccl:
+            log("side legs: all-fp32 kernels, the data-parallel step with one rank on RCCL")
+            side = side_legs(args)
+            if side.get("all_fp32_ms_per_step") is not None:
+                result["ms_per_step_all_fp32"] = side["all_fp32_ms_per_step"]
+                result["all_fp32_switches"] = ALL_FP32_ENV
         if not args.no_eval:                                   # (its torch.unique would show up in the PMC passes)
-            result["data_parallel"] = dp_report(model, c, batches, world, elapsed / args.steps * 1e3)
+            result["data_parallel"] = dp_report(model, c, batches, world, elapsed / args.steps * 1e3,
+                                                one_rank=side.get("one_rank_rccl_ms"))
         if auc is not None:
             result["auc"] = auc
         if not args.no_parity_gate:
@@ -859,6 +942,7 @@ def main():
             result["speedup_vs_cpu_baseline"] = result["value"] / result["cpu_baseline"]["value"]
     if world > 1:
         torch.distributed.barrier()
+    if world > 1 or args.one_rank_rccl:
         torch.distributed.destroy_process_group()
     if rank == 0:
         print(json.dumps(result))

@@ -12,6 +12,7 @@ from typing import Optional
 HPMN_MAX_LAYERS = 12
 HPMN_ABI_VERSION = 12
 HPMN_MAX_RANKS = 8
+HPMN_MAX_CHUNKS = 32
 HPMN_FWD_NO_CANDIDATE = 1
 HPMN_BWD_CANDIDATE_FROM_HS = 1
 
@@ -236,6 +237,10 @@ SIGNATURES = {
     "hpmn_adam_step_table": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
                                        C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                        C.c_void_p]),
+    "hpmn_scatter_plan_build_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int64]),
+    "hpmn_scatter_plan_build": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int32,
+                                          C.c_void_p, C.c_void_p]),
     "hpmn_rows_sum_adam": (C.c_int, [C.POINTER(HpmnRowsAdam), C.c_void_p]),
     "hpmn_table_mark_ranks": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p,
                                         C.c_int64, C.c_int32, C.c_void_p]),

@@ -69,6 +69,10 @@ int embed_grad_segsum_launch(const HpmnScatterPlan &p, const float *d_x, float *
 int adam_table_launch(float *p, float *g, float *m, float *v, uint8_t *flags, int64_t V, int E, int pass, float lr_t,
                       float b1, float b2, float eps, float clip, float gs, hipStream_t st);
 int rows_sum_adam_launch(const HpmnRowsAdam &h, hipStream_t st);
+size_t scatter_plan_build_workspace_bytes(int64_t n, int32_t id_flags, int64_t V);
+int scatter_plan_build_launch(const void *ids, int32_t id_flags, int64_t n, int64_t V, void *workspace, size_t workspace_bytes,
+                              int32_t *perm, int32_t *seg, int32_t *start, void *rows, int32_t *count,
+                              const int64_t *row_bounds, int32_t nb, int32_t *counts, hipStream_t st);
 int table_mark_ranks_launch(const void *ids, int64_t ids_stride, int32_t world, const int32_t *counts, int32_t counts_stride,
                             int64_t cap, uint8_t *flags, int64_t V, int32_t id_flags, hipStream_t st);
 int adam_rows_launch(float *p, const float *g, float *m, float *v, const int64_t *row_ids, int64_t n_rows, int E,
@@ -503,6 +507,23 @@ int hpmn_scatter_plan(const void *sorted_ids, int32_t id_flags, int64_t n, const
     if (n == 0) return HPMN_OK;
     if (!sorted_ids || !seg || !start || !rows || !count) return HPMN_EINVAL;
     return scatter_plan_launch(sorted_ids, id_flags, n, seg, start, rows, count, (hipStream_t)stream);
+}
+
+size_t hpmn_scatter_plan_build_workspace_bytes(int64_t n, int32_t id_flags, int64_t V) {
+    if (n <= 0 || n > 0x7fffffffLL || V < 1) return 0;
+    return scatter_plan_build_workspace_bytes(n, id_flags, V);
+}
+
+int hpmn_scatter_plan_build(const void *ids, int32_t id_flags, int64_t n, int64_t V, void *workspace, size_t workspace_bytes,
+                            int32_t *perm, int32_t *seg, int32_t *start, void *rows, int32_t *count,
+                            const int64_t *row_bounds, int32_t nb, int32_t *counts, void *stream) {
+    drop_stale_hip_error();
+    if (n < 0 || n > 0x7fffffffLL || V < 1 || nb < 0 || nb > HPMN_MAX_CHUNKS) return HPMN_EINVAL;
+    if (counts && (nb < 1 || (!row_bounds && nb != 1))) return HPMN_EINVAL;
+    if (n == 0) return HPMN_OK;
+    if (!ids || !workspace || !perm || !seg || !start || !rows || !count) return HPMN_EINVAL;
+    return scatter_plan_build_launch(ids, id_flags, n, V, workspace, workspace_bytes, perm, seg, start, rows, count, row_bounds,
+                                     nb, counts, (hipStream_t)stream);
 }
 
 size_t hpmn_embed_grad_segsum_partials_floats(int64_t n, int32_t E) { return n > 0 && E > 0 ? segsum_partials_floats(n, E) : 0; }

@@ -238,9 +238,10 @@ def dense_allreduce_bytes(numel: int, world: int) -> int:
 # BPTT -- slices of the plan's own buffer, padding never read -- and hpmn_rows_sum_adam consumes the gathered buffers directly:
 # no padded copies, no index_fill_ / index_add_, no dense gradient table.
 
-def all_gather_fixed(mine: torch.Tensor, async_op: bool = False):
+def all_gather_fixed(mine: torch.Tensor, async_op: bool = False, group=None):
     """[world, *mine.shape]: every rank's ``mine`` (same shape and dtype everywhere).  One rank without forced collectives:
-    a view, no copy.  ``async_op``: also returns the handle (``.wait()`` orders the current stream behind the collective)."""
+    a view, no copy.  ``async_op``: also returns the handle (``.wait()`` orders the current stream behind the collective).
+    ``group``: a second process group = a second communicator with its own stream (side_group())."""
     _, world = rank_world()
     mine = mine.contiguous()
     if world == 1 and not forced():
@@ -248,9 +249,22 @@ def all_gather_fixed(mine: torch.Tensor, async_op: bool = False):
         return (out, None) if async_op else out
     out = torch.empty((world,) + tuple(mine.shape), device=mine.device, dtype=mine.dtype)
     if async_op:
-        return out, td.all_gather_into_tensor(out.view(-1), mine.view(-1), async_op=True)
-    td.all_gather_into_tensor(out.view(-1), mine.view(-1))
+        return out, td.all_gather_into_tensor(out.view(-1), mine.view(-1), async_op=True, group=group)
+    td.all_gather_into_tensor(out.view(-1), mine.view(-1), group=group)
     return out
+
+
+_side_group = None
+
+
+def side_group():
+    """A second process group over all ranks, created once (every rank must reach this at the same point of its program):
+    collectives on it use their own communicator and stream, so an exchange prepared a step ahead never queues in front of
+    the collectives of the step that is running."""
+    global _side_group
+    if _side_group is None and td.is_available() and td.is_initialized():
+        _side_group = td.new_group()
+    return _side_group
 
 
 class HostCopy:

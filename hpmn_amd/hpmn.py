@@ -152,6 +152,10 @@ class Hpmn_Basic(object):
     eval_every = 100
     industry = False
     _dp = False                  # data-parallel code paths on (set in __init__: world > 1, or forced collectives)
+    compact_table_grad = False   # (set in __init__, _decide_compact_table_grad)
+    _prefetched = None
+    _preset_plan = None
+    _plan_stream = None
 
     def __init__(self, path, trainset, testset, feature_size, user_dim, item_dim, learning_rate,
                  hidden_size, embedding_size, hop, user_layers, item_layers, user_num_layers,
@@ -208,6 +212,8 @@ class Hpmn_Basic(object):
         self._plan_wants_rows = False     # (the data-parallel rows exchange sends the plan's compact rows)
         self._plan_row_bounds = None
         self._plan_caps = (0, 0)          # (r5: capacities of the plan's `rows` / `out_rows` buffers as the exchange sends them)
+        self._preset_plan = None          # (r5: the next compute_gradients takes this plan instead of building one)
+        self._prefetched = None           # (r5: what train_step(next_ids=) prepared for the next step)
         self.last_scatter_plan = None
         self._sharded_moments = False     # set once the sharded table update has run (save_model gathers the moments then)
         self.TWO_PASS_MIN_NUMEL = int(os.environ.get("HPMN_TWO_PASS_MIN_NUMEL", str(type(self).TWO_PASS_MIN_NUMEL)))
@@ -249,8 +255,16 @@ class Hpmn_Basic(object):
         if mode == "compact" and not ok:
             raise ValueError("HPMN_TABLE_GRAD=compact needs the user-only graph, l2_reg == 0, dense Adam, E/4 a power of two "
                              "<= 64, HPMN_DET_SCATTER != 0 and (data parallel) HPMN_TABLE_EXCHANGE auto / rows on <= 8 ranks")
-        big = self.feature_size * self.embedding_size >= self.TWO_PASS_MIN_NUMEL
+        numel = self.feature_size * self.embedding_size
+        # auto: wherever the plan is needed anyway (the data-parallel rows exchange) and where a fourth table-sized buffer is
+        # what does not fit (tables from COMPACT_MIN_BYTES: configs[4]); in a single process on the reference tables the r4 step
+        # stays -- measured r5 at C3 / C2: 2.56-2.62 vs 2.46-2.49 and 1.02-1.06 vs 0.95-0.97 ms/step, the tail there is bound by
+        # layer 0's weight gradient and HBM, not by the scatter + late pass this form shortens, and the plan's sort costs its
+        # 180 us of small launches somewhere under the scans
+        big = numel >= self.TWO_PASS_MIN_NUMEL and (self._dp or 4 * numel >= self.COMPACT_MIN_BYTES)
         return ok and (mode == "compact" or (mode == "auto" and big))
+
+    COMPACT_MIN_BYTES = int(os.environ.get("HPMN_COMPACT_MIN_BYTES", str(8 << 30)))
 
     # ------------------------------------------------------------------ graph description
     def _make_spec(self) -> ScanSpec:
@@ -512,13 +526,32 @@ class Hpmn_Basic(object):
         want_rows = bool(self._plan_wants_rows or self.compact_table_grad)
 
         def make_plan():
+            if self._preset_plan is not None:                # (r5: prepared underneath the previous step, train_step(next_ids=))
+                pl, self._preset_plan = self._preset_plan, None
+                self.last_scatter_plan = pl
+                return pl
+            if os.environ.get("HPMN_PLAN_CACHE_EXPERIMENT") == "1":      # (measurement only: what a free plan would give)
+                key = (ids.data_ptr(), tuple(ids.shape), self._plan_caps, tuple(self._plan_row_bounds or ()))
+                hit = self.__dict__.setdefault("_plan_cache", {}).get(key)
+                if hit is not None:
+                    hit.ready = torch.cuda.Event()
+                    hit.ready.record(self._aux_stream)
+                    self.last_scatter_plan = hit
+                    return hit
+            pl = make_plan_()
+            if os.environ.get("HPMN_PLAN_CACHE_EXPERIMENT") == "1":
+                self._plan_cache[key] = pl
+            return pl
+
+        def make_plan_():
             pst = self._aux_stream
             if pst != torch.cuda.current_stream():
                 pst.wait_stream(main)                        # (the ids may have been produced on the caller's stream just now)
             with torch.cuda.stream(pst):
                 pl = ops.ScatterPlan(ids, self.embedding_size, want_rows=want_rows, host_count=False,
                                      row_bounds=self._plan_row_bounds if self._plan_wants_rows else None,
-                                     rows_capacity=self._plan_caps[0], out_rows_capacity=self._plan_caps[1])
+                                     rows_capacity=self._plan_caps[0], out_rows_capacity=self._plan_caps[1],
+                                     V=self.feature_size)
                 pl.ready = torch.cuda.Event()
                 pl.ready.record(pst)
             pl.record_stream(main)
@@ -626,10 +659,15 @@ class Hpmn_Basic(object):
 
     # ------------------------------------------------------------------ one training step
     def train_step(self, ids: torch.Tensor, label: torch.Tensor, keep_prob=0.5, masks=None,
-                   global_batch: Optional[int] = None, item_ids: Optional[torch.Tensor] = None):
-        """sess.run(train_step) of code/hpmn.py:482: forward, BPTT, clip, dense TF Adam."""
+                   global_batch: Optional[int] = None, item_ids: Optional[torch.Tensor] = None,
+                   next_ids: Optional[torch.Tensor] = None, next_global_batch: Optional[int] = None):
+        """sess.run(train_step) of code/hpmn.py:482: forward, BPTT, clip, dense TF Adam.
+        ``next_ids`` (optional, a hint): the ids tensor the NEXT call will be given (and, data parallel, its global batch) --
+        what only depends on the ids (the scatter's plan; under data parallel the exchange of the ranks' distinct rows and
+        counts) is then prepared underneath this step's BPTT instead of in front of the next step's early table pass.  Every
+        rank must pass it or none (it issues collectives)."""
         if self.compact_table_grad:
-            return self._train_step_rows(ids, label, keep_prob, masks, global_batch)
+            return self._train_step_rows(ids, label, keep_prob, masks, global_batch, next_ids, next_global_batch)
         if self._two_pass_table_adam(ids):
             return self._train_step_two_pass(ids, label, keep_prob, masks, global_batch)
         if self._dp_two_pass(ids):
@@ -976,7 +1014,63 @@ class Hpmn_Basic(object):
         return out, ce
 
     # ------------------------------------------------------------------ r5: the step without a dense gradient table
-    def _train_step_rows(self, ids, label, keep_prob, masks, global_batch):
+    def _rows_geometry(self, ids, global_batch):
+        """What the plan of a step's scatter needs beyond the ids: data parallel -> (global batch, capacity of the row list
+        = the largest shard's lookups, chunk count, row boundaries of the chunks); one process -> (global_batch, 0, 0, None)."""
+        if not self._dp:
+            return global_batch, 0, 0, None
+        B = ids.shape[0]
+        gb = B * self.world if global_batch is None else global_batch      # (ragged shards must pass it)
+        per_sample = ids[0].numel() if B > 0 else self.spec.T * self.spec.F
+        cap = max(1, max(dist.shard_sizes(gb, self.world)) * per_sample)
+        if B * per_sample > cap:
+            raise ValueError("this rank's shard (%d rows) is larger than the largest shard of global_batch=%d over %d ranks"
+                             % (B, gb, self.world))
+        C = max(1, min(int(self.table_exchange_chunks), ops._lib.HPMN_MAX_CHUNKS))
+        V = self.feature_size
+        return gb, cap, C, [(V * k) // C for k in range(C + 1)]
+
+    def _rows_plan(self, ids, cap, bounds):
+        """The scatter plan of ``ids`` on the auxiliary stream (the CURRENT stream when called)."""
+        pl = ops.ScatterPlan(ids, self.embedding_size, want_rows=True, row_bounds=bounds,
+                             rows_capacity=cap, out_rows_capacity=(ids.numel() + cap) if cap else 0, V=self.feature_size)
+        pl.ready = torch.cuda.Event()
+        pl.ready.record()
+        return pl
+
+    def _rows_early_exchange(self, plan, ids_dtype, cap, C, group=None):
+        """Data parallel, on the current stream: every rank's distinct-row list and counts, as they are."""
+        if plan is not None:
+            rows_mine, cnt = plan.rows, plan.counts_vec         # [cap]; [distinct rows, and per chunk of the row range]
+        else:                                                 # (an empty shard: nothing to send, every collective entered)
+            rows_mine = torch.empty(cap, device=self.device, dtype=ids_dtype)
+            cnt = torch.zeros(1 + C, device=self.device, dtype=torch.int32)
+        ids_all = dist.all_gather_fixed(rows_mine, group=group)            # [world, cap]
+        cnt_all = dist.all_gather_fixed(cnt, group=group)                  # [world, 1 + C] int32
+        return dict(ids_all=ids_all, cnt_all=cnt_all, counts=dist.HostCopy(cnt_all))
+
+    def _prefetch_rows(self, next_ids, next_global_batch):
+        """train_step(next_ids=): the NEXT step's plan (and, data parallel, its early exchange -- on a second communicator, so
+        that it never queues in front of this step's collectives) on a stream of its own, enqueued in front of this step: it
+        has the whole step to finish in, on whatever the scans leave free, and nothing of this step waits for it.
+        (r5, measured: underneath layer 0's reverse scan it took the weight gradients' slots -- the step's tail grew by 150 us --
+        and its counts reached the host so late that the next step started 0.3 ms behind an idle device.)"""
+        if self._plan_stream is None:
+            self._plan_stream = torch.cuda.Stream(device=self.device)
+        pst = self._plan_stream
+        gb, cap, C, bounds = self._rows_geometry(next_ids, next_global_batch)
+        group = dist.side_group() if self._dp else None
+        # (next_ids must EXIST already -- a slice of a staged dataset: the stream is not made to wait for anything)
+        with torch.cuda.stream(pst):
+            plan = self._rows_plan(next_ids, cap, bounds) if next_ids.shape[0] > 0 else None
+            ex = self._rows_early_exchange(plan, next_ids.dtype, cap, C, group=group) if self._dp else None
+            done = torch.cuda.Event()
+            done.record()
+        if plan is not None:
+            plan.ready = done
+        self._prefetched = dict(key=(next_ids.data_ptr(), tuple(next_ids.shape), gb), plan=plan, ex=ex, ids=next_ids, done=done)
+
+    def _train_step_rows(self, ids, label, keep_prob, masks, global_batch, next_ids=None, next_global_batch=None):
         """The two-pass step on COMPACT gradient rows, one process or N (``compact_table_grad``).
 
         Start of the step, auxiliary stream, underneath the forward: the plan of the deterministic scatter (a stable sort of
@@ -1002,21 +1096,28 @@ class Hpmn_Basic(object):
         B = ids.shape[0]
         dp = self._dp
         box = {}
-        if dp:
-            gb = ids.shape[0] * self.world if global_batch is None else global_batch      # (ragged shards must pass it)
-            per_sample = ids[0].numel() if B > 0 else self.spec.T * self.spec.F
-            cap = max(1, max(dist.shard_sizes(gb, self.world)) * per_sample)
-            if B * per_sample > cap:
-                raise ValueError("this rank's shard (%d rows) is larger than the largest shard of global_batch=%d over %d ranks"
-                                 % (B, gb, self.world))
-            C = max(1, int(self.table_exchange_chunks))
-            bounds = [(V * k) // C for k in range(C + 1)]
-            self._plan_wants_rows, self._plan_row_bounds = True, bounds
-            self._plan_caps = (cap, B * per_sample + cap)
-        else:
-            gb = global_batch
-            self._plan_wants_rows, self._plan_row_bounds, self._plan_caps = False, None, (0, 0)
+        gb, cap, C, bounds = self._rows_geometry(ids, global_batch)
+        self._plan_wants_rows, self._plan_row_bounds = bool(dp), bounds
+        self._plan_caps = (cap, B * (ids[0].numel() if B > 0 else 0) + cap) if dp else (0, 0)
         self.last_scatter_plan = None
+        # what the previous call prepared for this one (train_step(next_ids=)): the plan and, data parallel, the exchanged lists
+        pre, self._prefetched = self._prefetched, None
+        if pre is not None and pre["key"] != (ids.data_ptr(), tuple(ids.shape), gb):
+            pre = None        # (not the batch that was announced: prepared for nothing.  The same on every rank: the key is a
+            #                    function of the call sequence, which data parallel requires to be the same everywhere)
+        if pre is not None:
+            # (made on the plan stream: the consumers' streams wait for its event and hold its buffers)
+            self._aux_stream.wait_event(pre["done"])
+            if pre["plan"] is not None:
+                pre["plan"].record_stream(torch.cuda.current_stream())
+                pre["plan"].record_stream(self._aux_stream)
+            self._preset_plan = pre["plan"]
+            if pre["ex"] is not None:
+                for x in (pre["ex"]["ids_all"], pre["ex"]["cnt_all"]):
+                    x.record_stream(self._aux_stream)
+                box.update(pre["ex"])
+        if next_ids is not None:
+            self._prefetch_rows(next_ids, next_global_batch)
 
         def early():                                          # runs on the auxiliary stream
             self.flat_grad.zero_()                            # (the dense variables' gradient: a few hundred kB)
@@ -1026,19 +1127,12 @@ class Hpmn_Basic(object):
                     if B > 0:
                         ops.table_mark_rows(ids, flags)
                 else:
-                    plan = self.last_scatter_plan if B > 0 else None
-                    if plan is not None:
-                        torch.cuda.current_stream().wait_event(plan.ready)
-                        rows_mine = plan.rows
-                        cnt = torch.cat([plan.count, plan.chunk_counts.to(torch.int32)])
-                    else:                                     # (an empty shard: nothing to send, every collective entered)
-                        rows_mine = torch.empty(cap, device=self.device, dtype=ids.dtype)
-                        cnt = torch.zeros(1 + C, device=self.device, dtype=torch.int32)
-                    ids_all = dist.all_gather_fixed(rows_mine)                  # [world, cap]
-                    cnt_all = dist.all_gather_fixed(cnt)                        # [world, 1 + C] int32
-                    box["ids_all"], box["cnt_all"] = ids_all, cnt_all
-                    box["counts"] = dist.HostCopy(cnt_all)
-                    ops.table_mark_ranks(ids_all, cnt_all, flags, counts_stride=1 + C)
+                    if "ids_all" not in box:                  # (not prepared underneath the previous step)
+                        plan = self.last_scatter_plan if B > 0 else None
+                        if plan is not None:
+                            torch.cuda.current_stream().wait_event(plan.ready)
+                        box.update(self._rows_early_exchange(plan, ids.dtype, cap, C))
+                    ops.table_mark_ranks(box["ids_all"], box["cnt_all"], flags, counts_stride=1 + C)
                 v1 = V if self.EARLY_PASS_SPLIT >= 1.0 else max(1, min(V, int(V * self.EARLY_PASS_SPLIT)))
                 probe = self._split_probe if isinstance(self._split_probe, dict) and self._split_probe.get("armed") else None
                 if probe is not None:
@@ -1069,6 +1163,7 @@ class Hpmn_Basic(object):
         pending = out.pop("pending", None)
         self.adam_t = t
         plan = self.last_scatter_plan if B > 0 else None
+        self._preset_plan = None
         if not dp:
             if plan is not None:
                 ops.rows_sum_adam(P, M, S, flags, plan.rows.view(1, -1), plan.out_rows.view(1, -1, E), lr_t,
@@ -1166,24 +1261,31 @@ class Hpmn_Basic(object):
     def train(self, epochs, batchsize):
         step, count, best = 0, 0, 0.0
         ds = self._dev(self.trainset)
-        for _ in range(epochs):
-            for lo, hi in ds.batches(batchsize):
-                step += 1
-                # data parallel: every rank takes a contiguous slice of the global batch
-                a, b = dist.shard_bounds(lo, hi, self.rank, self.world)
-                self.train_step(ds.ids[a:b], ds.label[a:b], keep_prob=0.5, global_batch=hi - lo,
-                                item_ids=None if ds.item_ids is None else ds.item_ids[a:b])
-                if step % self.eval_every == 0:
-                    result = list(self.eval(self.trainset, 4 * batchsize))
-                    result += list(self.eval(self.testset, 4 * batchsize))
-                    self.log(step, result)
-                    if not (result[3] > best):
-                        count += 1
-                        if count > 3:
-                            return best
-                    else:
-                        count = 0
-                        best = result[3]
+        self._prefetched = None
+        order = [bh for _ in range(epochs) for bh in ds.batches(batchsize)]      # stored order, every epoch (code/hpmn.py:470-472)
+        for k, (lo, hi) in enumerate(order):
+            step += 1
+            # data parallel: every rank takes a contiguous slice of the global batch
+            a, b = dist.shard_bounds(lo, hi, self.rank, self.world)
+            nxt = {}
+            if self.compact_table_grad and k + 1 < len(order):
+                # the next batch's ids are known: its scatter plan / row exchange is prepared underneath this step's BPTT
+                lo2, hi2 = order[k + 1]
+                a2, b2 = dist.shard_bounds(lo2, hi2, self.rank, self.world)
+                nxt = dict(next_ids=ds.ids[a2:b2], next_global_batch=hi2 - lo2)
+            self.train_step(ds.ids[a:b], ds.label[a:b], keep_prob=0.5, global_batch=hi - lo,
+                            item_ids=None if ds.item_ids is None else ds.item_ids[a:b], **nxt)
+            if step % self.eval_every == 0:
+                result = list(self.eval(self.trainset, 4 * batchsize))
+                result += list(self.eval(self.testset, 4 * batchsize))
+                self.log(step, result)
+                if not (result[3] > best):
+                    count += 1
+                    if count > 3:
+                        return best
+                else:
+                    count = 0
+                    best = result[3]
         return best
 
     def eval(self, dataset, batchsize):

@@ -857,6 +857,7 @@ def _ctx(device) -> int:
     return h
 
 
+FAST_PLAN = os.environ.get("HPMN_FAST_PLAN", "1") != "0"      # hpmn_scatter_plan_build instead of torch.sort & co
 _row_bounds = {}
 
 
@@ -877,45 +878,68 @@ class ScatterPlan:
     run, ``count`` = U on the device; ``count_host()`` is an event-guarded read of its pinned copy (no device sync)."""
 
     def __init__(self, ids: torch.Tensor, E: int, want_rows: bool = False, host_count: bool = False, row_bounds=None,
-                 rows_capacity: int = 0, out_rows_capacity: int = 0):
+                 rows_capacity: int = 0, out_rows_capacity: int = 0, V: Optional[int] = None):
         _chk_ids(ids)
         dev = ids.device
         flat = ids.reshape(-1)
         n = flat.numel()
         self.n, self.E, self.id_flags = n, E, _idf(ids, False)
         i32 = dict(device=dev, dtype=torch.int32)
-        self.sorted, perm = torch.sort(flat, stable=True)
-        self.perm = perm.to(torch.int32)
-        head = torch.ones(n, **i32)
-        if n > 1:
-            head[1:] = (self.sorted[1:] != self.sorted[:-1]).to(torch.int32)
-        self.seg = torch.cumsum(head, 0, dtype=torch.int32) - 1
-        self.start = torch.empty(n + 1, **i32)
-        # ``row_bounds`` (ascending table-row boundaries b_0 = 0 < ... < b_C = V): chunk_counts[c] = distinct rows in
-        # [b_c, b_c+1) -- the data-parallel exchange sends the rows chunk by chunk (hpmn.py).  The unused tail of `rows` is
-        # then filled with the id type's maximum so that a searchsorted over the whole buffer stops at the count.
+        lib = _lib.load()
         # ``rows_capacity`` / ``out_rows_capacity`` (r5): the buffers as the data-parallel exchange sends them -- `rows` is
         # all-gathered whole (the batch geometry's capacity, the same on every rank), slices of `out_rows` go out chunk by
         # chunk, each as long as the LARGEST rank's chunk (what lies behind this rank's own entries is never read)
         nr = max(n, int(rows_capacity))
-        self.rows = (torch.full((nr,), torch.iinfo(ids.dtype).max, device=dev, dtype=ids.dtype) if row_bounds is not None
-                     else torch.empty(nr, device=dev, dtype=ids.dtype))
+        self.sorted = self.workspace = self.counts_vec = self.chunk_counts = None
         self.count = torch.zeros(1, **i32)
-        lib = _lib.load()
-        _lib.check(lib.hpmn_scatter_plan(self.sorted.data_ptr(), self.id_flags, n, self.seg.data_ptr(), self.start.data_ptr(),
-                                         self.rows.data_ptr(), self.count.data_ptr(), _stream()), "hpmn_scatter_plan")
+        nb = len(row_bounds) - 1 if row_bounds is not None else 0
+        if FAST_PLAN and n > 0 and nb <= _lib.HPMN_MAX_CHUNKS:
+            # r5: one library call -- radix sort of (id, lookup) pairs over the bits the table needs, segment scan, plan
+            # kernel, per-chunk counts: ~10 launches where the torch ops below are ~45 (240 us of queue latency at C3)
+            vmax = int(V) if V else (2 ** 62 if ids.dtype == torch.int64 else 2 ** 31 - 1)
+            need = int(lib.hpmn_scatter_plan_build_workspace_bytes(n, self.id_flags, vmax))
+            if need <= 0:
+                raise _lib.HpmnLibraryError("hpmn_scatter_plan_build_workspace_bytes refused n=%d V=%d" % (n, vmax))
+            self.workspace = torch.empty(need, device=dev, dtype=torch.uint8)
+            self.perm, self.seg = torch.empty(n, **i32), torch.empty(n, **i32)
+            self.start = torch.empty(n + 1, **i32)
+            self.rows = torch.empty(nr, device=dev, dtype=ids.dtype)
+            bounds = None
+            if row_bounds is not None:
+                self.counts_vec = torch.empty(1 + nb, **i32)          # [U, distinct rows per chunk of the table's row range]
+                self.chunk_counts = self.counts_vec[1:]
+                bounds = (C.c_int64 * (nb + 1))(*[int(x) for x in row_bounds])
+            _lib.check(lib.hpmn_scatter_plan_build(flat.data_ptr(), self.id_flags, n, vmax, self.workspace.data_ptr(), need,
+                                                   self.perm.data_ptr(), self.seg.data_ptr(), self.start.data_ptr(),
+                                                   self.rows.data_ptr(), self.count.data_ptr(), bounds, nb,
+                                                   _ptr(self.counts_vec), _stream()), "hpmn_scatter_plan_build")
+        else:
+            self.sorted, perm = torch.sort(flat, stable=True)
+            self.perm = perm.to(torch.int32)
+            head = torch.ones(n, **i32)
+            if n > 1:
+                head[1:] = (self.sorted[1:] != self.sorted[:-1]).to(torch.int32)
+            self.seg = torch.cumsum(head, 0, dtype=torch.int32) - 1
+            self.start = torch.empty(n + 1, **i32)
+            # ``row_bounds`` (ascending table-row boundaries b_0 = 0 < ... < b_C = V): chunk_counts[c] = distinct rows in
+            # [b_c, b_c+1) -- the data-parallel exchange sends the rows chunk by chunk (hpmn.py).  The unused tail of `rows` is
+            # then filled with the id type's maximum so that a searchsorted over the whole buffer stops at the count.
+            self.rows = (torch.full((nr,), torch.iinfo(ids.dtype).max, device=dev, dtype=ids.dtype) if row_bounds is not None
+                         else torch.empty(nr, device=dev, dtype=ids.dtype))
+            _lib.check(lib.hpmn_scatter_plan(self.sorted.data_ptr(), self.id_flags, n, self.seg.data_ptr(), self.start.data_ptr(),
+                                             self.rows.data_ptr(), self.count.data_ptr(), _stream()), "hpmn_scatter_plan")
+            if row_bounds is not None:
+                # (the boundaries are the same every step: their device tensor is made ONCE.  torch.as_tensor(list, device=...)
+                #  here was a blocking pageable host-to-device copy on the auxiliary stream -- which had just been told to wait for
+                #  the launch stream, i.e. for the whole previous step: the host could not run ahead of the device any more and
+                #  every data-parallel step started ~1.1 ms late, r4: 3.6 -> 2.9 ms per step with one rank on RCCL)
+                b = _row_bounds_tensor(tuple(int(x) for x in row_bounds), dev, ids.dtype)
+                pos = torch.searchsorted(self.rows, b)                     # first entry >= b_c: [C + 1], pos[C] = U
+                self.chunk_counts = (pos[1:] - pos[:-1]).to(torch.int32)
+                self.counts_vec = torch.cat([self.count, self.chunk_counts])
         self.partials = torch.empty(max(1, lib.hpmn_embed_grad_segsum_partials_floats(n, E)), device=dev, dtype=torch.float32)
         self.out_rows = (torch.empty(max(n, 1, int(out_rows_capacity)), E, device=dev, dtype=torch.float32)
                          if want_rows else None)
-        self.chunk_counts = None
-        if row_bounds is not None:
-            # (the boundaries are the same every step: their device tensor is made ONCE.  torch.as_tensor(list, device=...)
-            #  here was a blocking pageable host-to-device copy on the auxiliary stream -- which had just been told to wait for
-            #  the launch stream, i.e. for the whole previous step: the host could not run ahead of the device any more and
-            #  every data-parallel step started ~1.1 ms late, r4: 3.6 -> 2.9 ms per step with one rank on RCCL)
-            b = _row_bounds_tensor(tuple(int(x) for x in row_bounds), dev, ids.dtype)
-            pos = torch.searchsorted(self.rows, b)                     # first entry >= b_c: [C + 1], pos[C] = U
-            self.chunk_counts = pos[1:] - pos[:-1]
         self._host = self._event = None
         if host_count:
             self._host = torch.empty(1, dtype=torch.int32, pin_memory=True)
@@ -938,8 +962,8 @@ class ScatterPlan:
 
     def record_stream(self, stream) -> None:
         """The plan was built on another stream than the one that consumes it."""
-        for t in (self.sorted, self.perm, self.seg, self.start, self.rows, self.count, self.partials, self.out_rows,
-                  self.chunk_counts):
+        for t in (self.sorted, self.workspace, self.perm, self.seg, self.start, self.rows, self.count, self.partials,
+                  self.out_rows, self.counts_vec):
             if t is not None:
                 t.record_stream(stream)
 

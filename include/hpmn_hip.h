@@ -38,6 +38,7 @@ extern "C" {
 #define HPMN_ID_MASK0 1   /* id-flags bit 0: id 0 gathers a zero row and receives no gradient (the Hpmn class)  */
 #define HPMN_ID_I64 2     /* id-flags bit 1: the ids tensor is int64 (default: int32)                          */
 #define HPMN_MAX_LAYERS 12
+#define HPMN_MAX_CHUNKS 32 /* row-range chunks hpmn_scatter_plan_build counts distinct rows for                        */
 #define HPMN_MAX_RANKS 8   /* data-parallel ranks hpmn_rows_sum_adam tells apart (a rank bit per flags byte)        */
 /* Saved gates without the candidate (ABI v11): the forward leaves the candidate third of every gates row unwritten
  * (HpmnGruFusedFwd.flags), the reverse scan recovers what it needs of it from the saved states it reads anyway
@@ -440,6 +441,16 @@ typedef struct HpmnScatterPlan {
 
 int hpmn_scatter_plan(const void *sorted_ids, int32_t id_flags, int64_t n, const int32_t *seg, int32_t *start, void *rows,
                       int32_t *count, void *stream);
+/* The whole plan from the UNSORTED ids in one call (ABI v12; csrc/plan_build.hip): a stable LSD radix sort of (id, lookup
+ * index) pairs over the bits V needs (library call: rocPRIM), the segment scan, hpmn_scatter_plan, and -- counts != NULL --
+ * counts[0] = U, counts[1 + c] = distinct rows in [row_bounds[c], row_bounds[c + 1]) for the nb <= HPMN_MAX_CHUNKS chunks of
+ * the table's row range a data-parallel exchange sends them in (row_bounds: HOST array [nb + 1], NULL with nb = 1: [0, V)).
+ * ids [n] int32 / int64 (HPMN_ID_I64), every id in [0, V); perm / seg [n], start [n + 1], rows [>= n], count [1], counts
+ * [1 + nb]: device.  workspace: hpmn_scatter_plan_build_workspace_bytes(n, id_flags, V) bytes (0: the library refused). */
+size_t hpmn_scatter_plan_build_workspace_bytes(int64_t n, int32_t id_flags, int64_t V);
+int hpmn_scatter_plan_build(const void *ids, int32_t id_flags, int64_t n, int64_t V, void *workspace, size_t workspace_bytes,
+                            int32_t *perm, int32_t *seg, int32_t *start, void *rows, int32_t *count,
+                            const int64_t *row_bounds, int32_t nb, int32_t *counts, void *stream);
 size_t hpmn_embed_grad_segsum_partials_floats(int64_t n, int32_t E);
 /* entries per chunk of the reduction (its summation order: a row's entries inside one chunk left to right; a row that spans
  * chunks = its per-chunk sums cut into min(16, 256/E) consecutive blocks, each block left to right, blocks in order) */

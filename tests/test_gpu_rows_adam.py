@@ -116,3 +116,31 @@ def test_rows_sum_adam_single_rank_takes_device_count_and_scatter_rows(dev):
     torch.cuda.synchronize()
     assert torch.equal(p, p2) and torch.equal(m, m2) and torch.equal(v, v2)
     assert int(flags.count_nonzero()) == 0
+
+
+@pytest.mark.parametrize("wide", [False, True])
+def test_plan_built_by_the_library_equals_the_plan_built_from_framework_ops(dev, monkeypatch, wide):
+    """hpmn_scatter_plan_build (radix sort of (id, lookup) pairs + scan + plan kernel + per-chunk counts, csrc/plan_build.hip)
+    against the r4 construction out of torch.sort(stable=True) / cumsum / searchsorted: perm, seg, start, rows, count and
+    the distinct rows per chunk of the table's row range -- integers, so equal."""
+    from hpmn_amd import ops
+    rng = np.random.default_rng(77)
+    V = 2_500_000_000 if wide else 70_001
+    ids = rng.integers(0, V, size=(9, 113, 3)).astype(np.int64 if wide else np.int32)
+    ids[:, :, 0] = ids[:, :1, 0]                                     # long runs
+    ids[2:4, 40:, 1] = 0                                             # the padding id, many times
+    t = torch.as_tensor(ids).to(dev)
+    bounds = [0, V // 3, V // 3 + 5, V - 1, V]
+    plans = []
+    for fast in (True, False):
+        monkeypatch.setattr(ops, "FAST_PLAN", fast)
+        plans.append(ops.ScatterPlan(t, 16, want_rows=True, row_bounds=bounds, rows_capacity=4000, V=V))
+    torch.cuda.synchronize()
+    a, b = plans
+    assert a.workspace is not None and b.workspace is None
+    U = int(a.count.item())
+    assert U == int(b.count.item()) == len(np.unique(ids))
+    assert torch.equal(a.perm, b.perm) and torch.equal(a.seg, b.seg)
+    assert torch.equal(a.start[:U + 1], b.start[:U + 1]) and torch.equal(a.rows[:U], b.rows[:U])
+    assert torch.equal(a.counts_vec, b.counts_vec) and int(a.counts_vec[1:].sum()) == U
+    assert a.rows.numel() == 4000 and a.rows.dtype == t.dtype
