@@ -707,7 +707,7 @@ def main():
     if args.one_rank_rccl:
         os.environ["HPMN_DP_FORCE_COLLECTIVES"] = "1"
         os.environ["HPMN_TABLE_EXCHANGE"] = args.one_rank_rccl
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", os.environ.get("HPMN_ONE_RANK_QUEUES", "6"))
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", os.environ.get("HPMN_ONE_RANK_QUEUES", "5"))
     c = dict(CONFIGS[args.config])
     c["config_id"] = args.config
     if args.batch:

@@ -192,7 +192,7 @@ class Hpmn_Basic(object):
             else bool(lazy_table_adam)
         if self.lazy_table_adam and (item or l2_reg):
             raise NotImplementedError("lazy_table_adam: user-only graph, l2_reg == 0")
-        self.table_exchange_chunks = 4
+        self.table_exchange_chunks = int(os.environ.get("HPMN_TABLE_EXCHANGE_CHUNKS", "4"))
         # how the replicas keep the (replicated) table in step: "allreduce" = sum all-reduce of the table gradient in
         # a few ranges + replicated dense Adam (every rank sweeps the whole table); "sharded" = reduce-scatter of the
         # gradient, Adam on this rank's 1/world of the rows only, all-gather of the updated rows -- the same bytes
