@@ -358,12 +358,63 @@ def roofline_probes(model, c, batches, step_fn):
             "protocol": "same cold-cache protocol as `gather`",
             "fetch_bytes_per_row": None if gpmc is None else gpmc.get("cold/embed_gather_sum_kernel")},
         "gather_in_config": in_config,
+        "gather_16m": gather_probe_16m(ids.device) if c["config_id"] == "c3" else None,
         "gather_fetch_calibration": None if gpmc is None else gpmc.get("_calibration"),
         "hbm_bytes_per_step": step_bytes,
         "algorithmic_bytes_train_per_step": alg_train,
         "hbm_over_algorithmic": None if step_bytes is None else step_bytes / alg_train,
     }
     return roof, extra
+
+
+def gather_probe_16m(device, reps=8):
+    """The gather probes with launches long enough to reach the roof (r5): 16 XLong batches' ids in ONE launch
+    (16 M lookups, 1.1 GB of rows) on a 4 GiB table, four id sets rotated.  A calibration with SEQUENTIAL ids first -- the
+    same kernels reading rows 0, 1, 2, ... -- then random ids, consumed in place (4 B id + 64 B row is all the traffic) and
+    materialised (+ 64 B written).  Fractions against the nominal 8 TB/s and against the 132 B the memory system fetches per
+    random 64-byte row (a 128-byte line per row: profiles/r04_gather_pmc.json)."""
+    from hpmn_amd import ops
+    B, T, F, E, V = 8000, 1001, 2, 16, 64 * 1024 * 1024
+    n = B * T * F
+    tab = torch.empty(V, E, device=device).normal_(0.0, 0.1)
+    g = torch.Generator(device=device).manual_seed(99)
+    rand = [torch.randint(0, V, (B, T, F), device=device, dtype=torch.int32, generator=g) for _ in range(4)]
+    seq = [((torch.arange(n, device=device, dtype=torch.int64) + k * 16000048) % V).to(torch.int32).view(B, T, F)
+           for k in range(4)]
+    out_sum = torch.zeros(B, F * E, device=device)
+    out_mat = torch.empty(B, T, F * E, device=device)
+
+    def timed(fn, sets):
+        for i in range(2):
+            fn(sets[i % 4])
+        torch.cuda.synchronize()
+        ts = []
+        for i in range(reps):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            fn(sets[i % 4])
+            b.record()
+            b.synchronize()
+            ts.append(a.elapsed_time(b))
+        return float(np.median(ts))
+
+    def row(ms, write):
+        alg = n * 68 / ms / 1e6
+        return {"ms": ms, "achieved": alg, "unit": "GB/s", "peak": PEAK_HBM_GBS, "frac": alg / PEAK_HBM_GBS,
+                "hbm_GBps_at_132B_per_row": n * (132 + write) / ms / 1e6,
+                "frac_of_the_132B_ceiling": alg / (PEAK_HBM_GBS * 68 / (132 + write))}
+    sum_fn = lambda ids: ops.embed_gather_sum(ids, tab, False, out=out_sum)
+    mat_fn = lambda ids: ops.embed_gather_seq(ids, tab, 0, False, out=out_mat)
+    res = {"lookups_per_launch": n, "table_bytes": V * E * 4, "algorithmic_bytes_per_lookup": 68,
+           "calibration_sequential_ids": {"in_place": row(timed(sum_fn, seq), 0), "materialised": row(timed(mat_fn, seq), 64)},
+           "random_ids": {"in_place": row(timed(sum_fn, rand), 0), "materialised": row(timed(mat_fn, rand), 64)},
+           "protocol": "16 reference batches' ids per launch (the 1 M-lookup launch of `gather` lasts 23 us: ramp-limited -- its "
+                       "sequential-id calibration only reaches 0.36); the calibration must exceed 0.7 of 8 TB/s before the "
+                       "random-id figure is quoted"}
+    for k in ("in_place", "materialised"):
+        for kk in ("hbm_GBps_at_132B_per_row", "frac_of_the_132B_ceiling"):
+            res["calibration_sequential_ids"][k].pop(kk)        # (sequential rows fetch 68 B per lookup, not 132)
+    return res
 
 
 def bytes_train_per_seq(c):

@@ -433,7 +433,12 @@ __global__ __launch_bounds__(256) void embed_gather_seq_kernel(const void *__res
         }
         float4 v[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) v[u] = reinterpret_cast<const float4 *>(emb)[id[u] * E4 + e4[u]];
+        for (int u = 0; u < U; ++u) {
+            // (non-temporal, as in embed_gather_sum_kernel: a gathered row is used once -- r5)
+            typedef float v4f_ __attribute__((ext_vector_type(4)));
+            const v4f_ w = __builtin_nontemporal_load(reinterpret_cast<const v4f_ *>(emb) + id[u] * E4 + e4[u]);
+            v[u] = make_float4(w[0], w[1], w[2], w[3]);
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const long i = i0 + u * stride;

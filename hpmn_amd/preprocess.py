@@ -249,9 +249,12 @@ def preprocess_amazon(review_file: str, meta_file: str, out_pkl: str, seed: int 
     return len(train), len(test), fs
 
 
-def preprocess_taobao(csv_file: str, out_pkl: str, seed: int = 1111, in_range_unknown_btag: bool = False):
-    """``in_range_unknown_btag``: write the target rows' btag as feature_size - 1 (inside the table) instead of the
-    reference's feature_size (see Schema.unknown_btag_out_of_range)."""
+def preprocess_taobao(csv_file: str, out_pkl: str, seed: int = 1111, in_range_unknown_btag: bool = True):
+    """``in_range_unknown_btag`` (default): the target rows' btag is written as feature_size - 1, the reserved id
+    INSIDE the table, so that `preprocess taobao` -> `hpmn.py taobao` runs as it stands.  False reproduces the reference's files
+    byte for byte: its target rows carry btag == feature_size (preprocess_taobao.py:48,131), one past the table -- TF's CPU
+    gather raises on that id, its GPU gather returns a zero row; the loader then needs HPMN_OOB_IDS=zero
+    (see Schema.unknown_btag_out_of_range; the byte-exact mode is what tests/golden/preprocess_reference.npz pins)."""
     import dataclasses
     schema = dataclasses.replace(TAOBAO, unknown_btag_out_of_range=not in_range_unknown_btag)
     ev, n_item, fs = remap(read_taobao(csv_file), schema)
@@ -271,13 +274,14 @@ def main(argv: Optional[List[str]] = None) -> int:
     t = sub.add_parser("taobao")
     t.add_argument("--csv", default="../data/raw_data/taobao/taobao_sample.csv")         # preprocess_taobao.py:12
     t.add_argument("--out", default="../data/taobao/dataset_hpmn.pkl")
-    t.add_argument("--in-range-unknown-btag", action="store_true",
-                   help="target btag = feature_size - 1 instead of the reference's out-of-range feature_size")
+    t.add_argument("--reference-unknown-btag", action="store_true",
+                   help="target btag = feature_size, ONE PAST the table, exactly as the reference writes it (the loader then "
+                        "needs HPMN_OOB_IDS=zero); default: the in-range id feature_size - 1")
     args = ap.parse_args(argv)
     if args.which == "amazon":
         print("train %d test %d feature_size %d" % preprocess_amazon(args.reviews, args.meta, args.out))
     else:
-        print("train %d test %d feature_size %d" % preprocess_taobao(args.csv, args.out, in_range_unknown_btag=args.in_range_unknown_btag))
+        print("train %d test %d feature_size %d" % preprocess_taobao(args.csv, args.out, in_range_unknown_btag=not args.reference_unknown_btag))
     return 0
 
 

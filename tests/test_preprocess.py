@@ -163,7 +163,11 @@ def test_taobao_pipeline_invariants(tmp_path):
                 rows.append(r)
                 f.write("%d,%d,%d,%s,%d\n" % r)
     out = str(tmp_path / "taobao" / "dataset_hpmn.pkl")
-    ntr, nte, fs = P.preprocess_taobao(path, out, in_range_unknown_btag=True)
+    ntr, nte, fs = P.preprocess_taobao(path, out)       # (the default writes the in-range unknown btag: ADVICE r4)
+    exact = str(tmp_path / "taobao_exact" / "dataset_hpmn.pkl")
+    assert P.main(["taobao", "--csv", path, "--out", exact, "--reference-unknown-btag"]) == 0
+    tr_exact, te_exact, fs_exact = datasets.load_dataset_pkl(exact)
+    assert fs_exact == fs and max(max(r[3] for r in s[1]) for s in tr_exact + te_exact) == fs        # one past the table
     n_item, n_user = len({r[1] for r in rows}), len({r[0] for r in rows})
     n_cate, n_btag = len({r[2] for r in rows}), len({r[3] for r in rows})
     assert fs == n_item + n_user + n_cate + n_btag + 1 and ntr + nte == n_user   # items, users, categories, btags, +1
