@@ -45,8 +45,9 @@ CONFIGS = {
     "c4": dict(industry=True, F=2, T=1001, H=128, K=7, periods=[2] * 10 + [1], batch=500,
                V=19002 + 3269017 + 200000, lr=0.001, memory_reg=5e-5,
                name="XLong synthetic x10 users, Hpmn_Industry 7-layer H=128 max_len=1000(+1)->1024"),
-    # configs[4] with a table far beyond the 256 MiB Infinity Cache: 256 M rows x 16 = 16 GiB, dense TF-Adam
-    # semantics (param + grad + m + v = 64 GiB of flat buffers); int32 row ids (2.1 G rows is the id limit)
+    # configs[4] with a table far beyond the 256 MiB Infinity Cache.  Default 256 M rows x 16 = 16 GiB; --vocab-rows sizes it to
+    # HBM (r5): dense TF-Adam semantics keep param + m + v (no dense gradient table: compact_table_grad) = 3 x 64 GiB at 2^30
+    # rows; ids are int32 up to 2^31 - 1 rows and int64 beyond (ABI v10)
     "c4big": dict(industry=True, F=2, T=1001, H=128, K=7, periods=[2] * 10 + [1], batch=500,
                   V=256 * 1024 * 1024, lr=0.001, memory_reg=5e-5, device_init=True,
                   name="XLong synthetic, 256 M-row table (16 GiB), Hpmn_Industry 7-layer H=128 max_len=1000(+1)->1024"),
@@ -66,7 +67,8 @@ def synth_batches(c, n_batches, batch, seed, device):
     rng = np.random.default_rng(seed)
     out = []
     for _ in range(n_batches):
-        ids = rng.integers(1, c["V"] - 30000, size=(batch, c["T"], c["F"]), dtype=np.int64).astype(np.int32)
+        ids = rng.integers(1, c["V"] - 30000, size=(batch, c["T"], c["F"]), dtype=np.int64)
+        ids = ids.astype(np.int32 if c["V"] <= 2 ** 31 - 1 else np.int64)
         ids[:, :, 0] = rng.integers(c["V"] - 30000, c["V"], size=(batch, 1))
         if not c["industry"]:
             lens = np.minimum(5 + rng.geometric(0.25, size=batch), c["T"])
@@ -417,6 +419,80 @@ def gather_probe_16m(device, reps=8):
     return res
 
 
+def table_adam_sweep_probe(model, reps=3):
+    """The dense table update's sweep alone (hpmn_adam_step_table pass 0 over the model's own table, nothing beside it): 24 B
+    moved per element -- param, m, v read and written -- the HBM-roofline stress configs[4] is named for.  lr_t = 0 and
+    beta = 1 make the pass a no-op in VALUE (p -= 0, m = 1 m + 0, v = 1 v + 0) with the arithmetic and traffic of a real one."""
+    from hpmn_amd import ops
+    V, E = model.feature_size, model.embedding_size
+    n_emb = V * E
+    P, M, S = (b[:n_emb].view(V, E) for b in (model.flat_param, model.flat_m, model.flat_v))
+    flags = model._row_flags if model._row_flags is not None else ops.table_flags(V, model.device)
+    if bool(model.lazy_table_adam):
+        return None
+    ts = []
+    for _ in range(reps + 1):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        ops.adam_step_table(P, None, M, S, flags, 0, 0.0, beta1=1.0, beta2=1.0, eps=1e-8, clip=1.0)
+        b.record()
+        b.synchronize()
+        ts.append(a.elapsed_time(b))
+    ms = float(np.median(ts[1:]))
+    byt = n_emb * 4 * 6
+    return {"kernel": "adam_table_kernel<0>", "ms": ms, "bytes": byt, "bound": "hbm", "achieved": byt / ms / 1e6, "unit": "GB/s",
+            "peak": PEAK_HBM_GBS, "frac": byt / ms / 1e6 / PEAK_HBM_GBS,
+            "note": "stand-alone sweep of the whole table (in the step it runs on the auxiliary stream beside the forward and BPTT)"}
+
+
+def input_pipeline_leg(c, device, tmp, kernel_seq_per_s, n_lines=25000, batch=500):
+    """End to end (r5): ``Hpmn_Industry.train()`` -- the reference's harness loop, code/hpmn.py:322-373 --
+    over a generated XLong TSV in the reference's line format (code/data_loader.py:59-73): 2 epochs x 100 batches of 500 = 200
+    steps.  Reported: the seconds to stage the file cold (text parsed by a process pool, array cache written, host-to-device
+    copy) and warm (cache mapped in + copy), and the training sequences/s of the loop itself beside the kernel-only figure of
+    this bench line.  The periodic evaluation is switched off for the leg (eval_every beyond the run: the metric is TRAINING
+    sequences/s; the train-to-eval cadence has its own leg, xlong_cadence)."""
+    from hpmn_amd import datasets as D
+    from hpmn_amd.hpmn import Hpmn_Industry
+    d = os.path.join(tmp, "xlong_tsv")
+    train_p, test_p = os.path.join(d, "train_corpus_total_dual.txt"), os.path.join(d, "test_corpus_total_dual.txt")
+    t0 = time.perf_counter()
+    D.write_xlong_tsv(train_p, n_lines, seed=D.SEED_BASE + 31)
+    D.write_xlong_tsv(test_p, 250, seed=D.SEED_BASE + 32)
+    t_write = time.perf_counter() - t0
+    V = D.xlong_feature_size()
+    m = Hpmn_Industry(os.path.join(tmp, "pipe_model"), train_p, test_p, V, 2, 1, 1001, 184, c["lr"], c["H"], 16, 3, c["periods"],
+                      [1], c["K"], 1, True, False, memory_reg=c["memory_reg"], verbose=False, seed=0)
+    m.eval_every = 10 ** 9
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ds = m._dev(m.trainset)
+    torch.cuda.synchronize()
+    t_cold = time.perf_counter() - t0
+    rows = int(ds.n)
+    m.invalidate_dataset()
+    del ds
+    t0 = time.perf_counter()
+    m._dev(m.trainset)
+    torch.cuda.synchronize()
+    t_warm = time.perf_counter() - t0
+    m.train(1, batch)                                     # (first touch of every code path; not timed)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    m.train(2, batch)
+    torch.cuda.synchronize()
+    t_train = time.perf_counter() - t0
+    steps = 2 * -(-rows // batch)
+    seq = 2 * rows / t_train
+    return {"tsv_lines": n_lines, "tsv_bytes": os.path.getsize(train_p), "rows": rows, "steps": steps, "batch": batch,
+            "tsv_write_seconds": t_write, "staging_cold_seconds": t_cold, "staging_warm_seconds": t_warm,
+            "staging_warm_ids_GBps": rows * 1001 * 2 * 4 / t_warm / 1e9,
+            "train_seconds": t_train, "sequences_per_s": seq, "kernel_only_sequences_per_s": kernel_seq_per_s,
+            "ratio_to_kernel_only": seq / kernel_seq_per_s,
+            "note": "Hpmn_Industry.train(2, 500) from the TSV path; ids staged once per file (int32, device-resident), batches "
+                    "are slices; the next batch's ids are handed to train_step as its next_ids hint"}
+
+
 def bytes_train_per_seq(c):
     """T*F*(4 + 3*4*E) + 4*K*H + 4 (ids, row read + gradient read-modify-write, memory, prediction)."""
     return c["T"] * c["F"] * (4 + 3 * 4 * 16) + 4 * c["K"] * c["H"] + 4
@@ -689,9 +765,12 @@ def side_legs(args):
     byte crosses xGMI -- with both table exchanges."""
     import subprocess
     base = [sys.executable, os.path.abspath(__file__), "--config", args.config, "--steps", str(args.steps), "--warmup",
-            str(args.warmup), "--no-cpu-baseline", "--no-auc", "--no-eval", "--no-roofline", "--no-parity-gate", "--no-side-legs"]
+            str(args.warmup), "--no-cpu-baseline", "--no-auc", "--no-eval", "--no-roofline", "--no-parity-gate", "--no-side-legs",
+            "--no-input-pipeline"]
     if args.batch:
         base += ["--batch", str(args.batch)]
+    if args.vocab_rows:
+        base += ["--vocab-rows", str(args.vocab_rows)]
     if args.lazy_table_adam:
         base += ["--lazy-table-adam"]
 
@@ -744,12 +823,14 @@ def main():
     ap.add_argument("--no-eval", action="store_true", help="skip the forward-only throughput leg (clean PMC profiles)")
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the reference literal)")
+    ap.add_argument("--vocab-rows", type=int, default=0, help="embedding-table rows (c4big: sized to HBM; default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-auc", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1 (nccl == RCCL; gloo lets several ranks share one GPU for a dry run)")
     ap.add_argument("--auc-steps", type=int, default=300)
+    ap.add_argument("--no-input-pipeline", action="store_true", help="skip the end-to-end train() leg from a generated TSV")
     ap.add_argument("--no-side-legs", action="store_true",
                     help="skip the sub-runs of the same timed loop: all-fp32 kernels, the data-parallel step with one rank on RCCL")
     ap.add_argument("--one-rank-rccl", default="", choices=["", "rows", "allreduce"],
@@ -763,6 +844,10 @@ def main():
     c["config_id"] = args.config
     if args.batch:
         c["batch"] = args.batch
+    if args.vocab_rows:
+        c["V"] = args.vocab_rows
+        c["name"] = c["name"].replace("256 M-row table (16 GiB)", "%.2f G-row table (%.0f GiB)"
+                                      % (args.vocab_rows / 2 ** 30, args.vocab_rows * 64 / 2 ** 30))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:
@@ -968,7 +1053,8 @@ def main():
         if cadence is not None:
             result["xlong_cadence"] = cadence
         side = {}
-        if world == 1 and not args.no_side_legs and not args.one_rank_rccl:
+        fits_twice = 2 * 4 * 4 * c["V"] * 16 < 0.8 * torch.cuda.get_device_properties(device).total_memory
+        if world == 1 and not args.no_side_legs and not args.one_rank_rccl and fits_twice:    # (the sub-runs build their own model)
             log("side legs: all-fp32 kernels, the data-parallel step with one rank on RCCL")
             side = side_legs(args)
             if side.get("all_fp32_ms_per_step") is not None:
@@ -979,6 +1065,14 @@ def main():
                                                 one_rank=side.get("one_rank_rccl_ms"))
         if auc is not None:
             result["auc"] = auc
+        if c["V"] * 16 * 4 >= (2 << 30) and world == 1:
+            result["table_adam_sweep"] = table_adam_sweep_probe(model)
+            result["config"]["table_state_bytes"] = int(model.flat_param.numel() + model.flat_m.numel() + model.flat_v.numel()
+                                                        + model.flat_grad.numel()) * 4
+            result["config"]["dense_gradient_table"] = not (model.compact_table_grad or model.lazy_table_adam)
+        if args.config == "c3" and world == 1 and not args.no_input_pipeline and not args.one_rank_rccl:
+            log("input pipeline leg: Hpmn_Industry.train() from a generated XLong TSV")
+            result["input_pipeline"] = input_pipeline_leg(c, device, tmp, seqs / elapsed)
         if not args.no_parity_gate:
             log("parity gate (golden vectors)")
             result["parity_gate"] = parity_gate(device, tmp)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B of the compact-gradient-row step against the r4 dense-gradient-table step, per config (bench lines without the side legs)
 out=gpurun_out/r5ab; mkdir -p $out
-B="python bench.py --no-cpu-baseline --no-auc --no-eval --no-roofline --no-parity-gate"
+B="python bench.py --no-cpu-baseline --no-auc --no-eval --no-roofline --no-parity-gate --no-side-legs --no-input-pipeline"
 for cfg in ${CFGS:-c3 c2 c4 c1}; do
   for mode in auto dense; do
     HPMN_TABLE_GRAD=$mode $B --config $cfg > $out/${cfg}_$mode.json 2> $out/${cfg}_$mode.err

@@ -2,7 +2,7 @@
 # kernel timelines of one step: the plain step (compact gradient rows / dense gradient table) and the data-parallel step with one rank on RCCL
 export TMPDIR=/tmp
 out=gpurun_out/r5tl; mkdir -p $out
-B="python bench.py --no-cpu-baseline --no-auc --no-eval --no-roofline --no-parity-gate --steps 12 --warmup 4 --config ${CFG:-c3}"
+B="python bench.py --no-cpu-baseline --no-auc --no-eval --no-roofline --no-parity-gate --no-side-legs --no-input-pipeline --steps 12 --warmup 4 --config ${CFG:-c3}"
 for mode in auto dense; do
   rm -rf /tmp/prof_$mode
   HPMN_TABLE_GRAD=$mode timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_$mode -- $B > $out/${mode}.out 2> $out/${mode}.err
