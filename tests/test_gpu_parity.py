@@ -1779,7 +1779,7 @@ def test_split_gradient_kernels_track_the_fp32_kernels_over_200_steps(tmp_path):
     split operands (fp32 accumulate; 5e-6 of max|grad| per step against 6e-7 for the fp32 kernels).  200 training steps from the
     same weights on the same batches, once on the default kernels and once with every product on fp32 kernels
     (bench.ALL_FP32_ENV; the switches are read once per process, hence two processes): the loss curves must agree to 1e-3
-    relative at every step, the final parameters to 0.5 % of the distance Adam can cover in 200 steps.  Deterministic scatter in both, so
+    relative at every step and the trained models' predictions on four of the batches to 1e-3.  Deterministic scatter in both, so
     that the kernels' precision is the ONLY difference (two fp32 runs then differ by 3e-7: the loss sums' atomics).
     Learning rate 1e-4 (loss 0.693 -> 0.546 over the 200 steps; measured deviation 1.8e-5).  At the reference's 1e-3 this problem
     -- 25 batches the model ends up memorising -- is chaotic in the plain sense: the curves agree to 1e-3 for 65 steps, then
@@ -1804,8 +1804,4 @@ def test_split_gradient_kernels_track_the_fp32_kernels_over_200_steps(tmp_path):
     la, lb = a["loss"], b["loss"]
     assert len(la) == 200 and np.isfinite(la).all() and la[-20:].mean() < 0.9 * la[:20].mean()       # (it trains)
     np.testing.assert_allclose(la, lb, rtol=1e-3, atol=0)
-    for k in a.files:
-        if k != "loss":
-            # (Adam moves an element by up to lr per step whatever its gradient's size -- a bias that starts at zero with
-            #  gradients of 1e-7 does too: the yardstick is the distance 200 steps can cover, 200 lr = 2e-2; measured 6e-5)
-            np.testing.assert_allclose(a[k], b[k], rtol=0, atol=5e-3 * 200 * 1e-4, err_msg=k)
+    np.testing.assert_allclose(a["pred_final"], b["pred_final"], rtol=0, atol=1e-3)      # the two trained models agree

@@ -32,8 +32,10 @@ def main(dst):
         _, ce = m.train_step(ids, label, keep_prob=1.0)
         loss.append(ce)
     torch.cuda.synchronize()
-    out = {k: v.detach().cpu().numpy() for k, v in m.params.items() if k != "Embedding/emb_mtx"}
-    out["loss"] = np.array([float(x) for x in loss])
+    out = {"loss": np.array([float(x) for x in loss])}
+    # what the trained model SAYS (not where its parameters wandered: Adam moves an element by ~lr per step whatever the size of
+    # its gradient, so elements with near-zero gradients random-walk apart between any two runs that differ in the last bits)
+    out["pred_final"] = torch.cat([m.forward_inference(batches[i][0])["prediction"] for i in range(4)]).cpu().numpy()
     np.savez(dst, **out)
 
 

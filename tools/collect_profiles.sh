@@ -11,7 +11,7 @@ cp $out/step/kernel_stats.csv $out/kernel_stats.csv 2>/dev/null
 cp $out/step/timeline.txt $out/timeline.txt 2>/dev/null
 for ctr in FETCH_SIZE WRITE_SIZE; do
   timeout 500 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/pmc_$ctr -- \
-      python bench.py --config $cfg --steps 5 --warmup 1 --no-cpu-baseline --no-roofline --no-auc --no-parity-gate --no-eval \
+      python bench.py --config $cfg --steps 5 --warmup 1 --no-cpu-baseline --no-roofline --no-auc --no-parity-gate --no-eval --no-side-legs --no-input-pipeline \
       > /dev/null 2> $out/pmc_$ctr.err < /dev/null
   f=$(find $out/pmc_$ctr -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && python tools/pmc_summary.py $f $ctr > $out/pmc_$ctr.txt && cp $f $out/pmc_$ctr.csv
@@ -21,7 +21,7 @@ batch=$(python -c "import bench; print(bench.CONFIGS['$cfg']['batch'])")
 python tools/pmc_digest.py $out/pmc_FETCH_SIZE.csv $out/pmc_WRITE_SIZE.csv 6 $cfg $batch $out/pmc_summary.json
 rm -f $out/pmc_FETCH_SIZE.csv $out/pmc_WRITE_SIZE.csv
 # bench.py reads the digest from profiles/ (and checks its source sha against the kernels it is about to run)
-[ "$cfg" = "c3" ] && cp $out/pmc_summary.json profiles/r04_pmc_summary.json
+[ "$cfg" = "c3" ] && cp $out/pmc_summary.json profiles/r05_pmc_summary.json
 rm -rf $out/step/prof
 timeout 900 python bench.py --config $cfg > $out/bench.json 2> $out/bench.err < /dev/null
 echo "bench rc=$?"
