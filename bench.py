@@ -721,8 +721,19 @@ def dp_report(model, c, batches, world, ms_per_step, n_model=8, busbw_gbps=300.0
     base = lambda mode: (one_rank.get(mode) or ms_per_step)
     eff = lambda t, mode: ms_per_step / (base(mode) + max(0.0, t - hide_ms) + small_b / busbw_gbps / 1e6 + 0.02)
     if world == 1:
-        dp_extra = {"one_rank_rccl_ms": one_rank or None, "plain_ms": ms_per_step,
-                    "id_laws_n%d" % n_model: id_law_report(c, n_model, E, busbw_gbps) if c["V"] * E <= (1 << 28) else None}
+        laws = id_law_report(c, n_model, E, busbw_gbps) if c["V"] * E <= (1 << 28) else None
+        if laws is not None:
+            # the same model per id law, with what the model above leaves out: the late pass over the UNION of the ranks' rows is
+            # larger than the single-GPU one (HBM-bound, ~3.5 TB/s); with C = 4 chunks all but the last chunk's share of it runs
+            # while later chunks are still on the wire
+            single_late = u * 6 * 4 * E + u * 4 * E
+            for law in laws.values():
+                wire = law["wire_ms_at_assumed_busbw"]
+                late_extra = max(0.0, law["late_pass_bytes"] - single_late) / 3.5e9
+                law["late_pass_extra_ms"] = late_extra
+                law["weak_scaling_efficiency_modelled"] = ms_per_step / (
+                    base("rows") + max(0.0, wire - hide_ms) + max(0.0, late_extra - 0.75 * wire) + small_b / busbw_gbps / 1e6 + 0.02)
+        dp_extra = {"one_rank_rccl_ms": one_rank or None, "plain_ms": ms_per_step, "id_laws_n%d" % n_model: laws}
     else:
         dp_extra = {}
     return {
@@ -883,10 +894,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # (before the first HIP call: the runtime reads it once)
-        # The data-parallel step has five streams (launch, auxiliary, two helpers, RCCL's) and the runtime four hardware queues
-        # by default: the auxiliary stream then shares the launch stream's queue and its early table-Adam pass runs IN FRONT of
-        # layer 0's forward instead of beside it.  One more queue, measured with one rank on RCCL (tools/dp_one_rank.py):
-        # 3.45 -> 2.99 ms per step (allreduce), 4.25 -> 3.89 (rows); eight queues are worse (3.9 / 5.6).  DESIGN.md section 5.
+        # The data-parallel step has seven streams (launch, auxiliary, two helpers, the plan's, two communicators') and the
+        # runtime four hardware queues by default: streams that share a queue serialise.  Measured with one rank on RCCL in this
+        # timed loop (r5, rows exchange): 4 / 5 / 6 / 8 queues -> 3.01 / 2.63 / 3.14 / 3.41 ms per step.  DESIGN.md section 5.
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "5")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

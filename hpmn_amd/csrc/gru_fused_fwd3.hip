@@ -1,7 +1,7 @@
 // Fused forward of one periodic-GRU layer for gfx950 (H = 64): a CHAIN wave and a PRODUCER wave per sequence, two
 // sequences per workgroup, the input projection on the MATRIX cores.
 //
-// Against the first generation (gru_fused_fwd.hip), each point measured:
+// Against the first generation (gru_fused_fwd.hip), each point measured (DESIGN_HISTORY.md 3.10):
 //   * two sequences per 4-wave workgroup.  The hardware starts a CU's next workgroup on the SIMD the previous one ended
 //     on (tools/micro/where.hip): with 2-wave workgroups the scan wave of one sequence shared a SIMD with the projection
 //     wave of the other on every CU while a SIMD sat idle;

@@ -17,7 +17,7 @@
 #include "pipe_common.h"
 
 // r4: the tile kernel's forward is the EVALUATION kernel now (ops.tiled_forward_inference); its training backward was
-// measured slower than the per-sequence kernels at the reference batch and is compiled only with
+// measured slower than the per-sequence kernels at the reference batch (DESIGN_HISTORY.md 3.7) and is compiled only with
 // -DHPMN_LEGACY_KERNELS; the default library answers hpmn_pipe_bwd with HPMN_EUNSUPPORTED.
 #ifndef HPMN_LEGACY_KERNELS
 namespace hpmn {

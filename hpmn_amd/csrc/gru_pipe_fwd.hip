@@ -195,7 +195,7 @@ __device__ __forceinline__ void pipe_fwd_body(const PipeArgs &a, const PipeLayer
     //      (slot rho & 1) in phase 1 of step rho-2, and every wave runs its input product on it while it is off
     //      the chain in step rho-1.  Prologue: rows 0,1 parked and row 0 projected, rows 2,3 in flight.
     //      (An LDS-DMA variant -- global_load_lds_dwordx4 into 8 staging slots, rows six steps in flight behind
-    //      one counted s_waitcnt -- was built and measured SLOWER: 1273 vs 972 us at K=1)
+    //      one counted s_waitcnt -- was built and measured SLOWER: 1273 vs 972 us at K=1, DESIGN_HISTORY.md 3.7.)
     f4 ra = {0.f, 0.f, 0.f, 0.f}, rb = ra;
     if (role == 2 && has_x) {
         wait_rows(T < 4 ? T : 4, T);

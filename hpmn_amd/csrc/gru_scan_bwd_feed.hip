@@ -1,6 +1,6 @@
 // Reverse (BPTT) periodic-GRU scan, H = 64, two specialised waves per sequence: a CHAIN wave and a FEEDER wave.
 //
-// Why: a single wave issues one instruction per ~5.5 cycles whatever the instruction is, so the
+// Why (DESIGN_HISTORY.md 3.10): a single wave issues one instruction per ~5.5 cycles whatever the instruction is, so the
 // length of a reverse step is the NUMBER of instructions the wave on the serial chain has to issue.  In
 // gru_scan_bwd_helper_kernel that wave still issued ~230 per step, of which only 96 (two 64x64 products) and a
 // dozen more are the recurrence: the rest was the prefetch of the saved activations (address arithmetic, loads,
@@ -28,7 +28,7 @@
 // the feeder's own stores, ordered by a barrier) 16 bytes per lane straight into operand layout.  Nobody is
 // latency-critical any more at that point -- which is what sank the same product as a CONCURRENT third role (waves on the
 // feeders' SIMDs, operands from a 32-step LDS ring): 3.62 vs 3.36 ms/step, because a SIMD does not issue its other wave's
-// VALU instructions while an fp32 MFMA is passing.
+// VALU instructions while an fp32 MFMA is passing (DESIGN_HISTORY.md 3.10).
 //
 // Hand-offs are LDS progress counters (common.h: data, lgkmcnt(0), counter; cached copies, re-read only when the
 // cached value says "wait"); no barrier in the loop.  Buffers are double-buffered by step parity: the feeder reads

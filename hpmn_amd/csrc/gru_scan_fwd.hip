@@ -1,6 +1,6 @@
 // Forward periodic-GRU layer scan for gfx950 (CDNA4) -- the serial part of build_memory.
 //
-// Work decomposition (MI355X-first, see DESIGN.md "scan kernel"):
+// Work decomposition (MI355X-first, see DESIGN_HISTORY.md 3.1):
 //   * the recurrence is serial in t and every sample is independent, so the unit of
 //     parallelism is the SEQUENCE: one 64-lane wave owns 64/H sequences, lane = hidden
 //     unit.  A launch is B*H/64 single-wave workgroups; nothing is shared between waves,

@@ -13,7 +13,7 @@
 //     conflict-free.  16-row tiles of (d_act | x | h_prev | r) are staged once per workgroup
 //     with 16-byte coalesced loads, double-buffered in LDS (every wave needs all of d_act, so
 //     staging cuts the global load instructions 12x vs operand loads straight from HBM --
-//     measured 0.52-0.65 ms -> see DESIGN.md).  A workgroup owns whole sequences;
+//     measured 0.52-0.65 ms -> see DESIGN_HISTORY.md 3.2).  A workgroup owns whole sequences;
 //     its waves split the OUTPUT tiles (wave w<DT: 32 input columns x all 3H gate columns;
 //     the others: 32 state columns of h_prev x 2H and of r*h_prev x H) and keep their
 //     3H/32 accumulator tiles (<=96 registers) resident over all rows; the next tile's HBM

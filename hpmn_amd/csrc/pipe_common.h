@@ -1,6 +1,6 @@
 // Shared pieces of the batch-tiled MFMA scan kernels (gru_pipe_fwd.hip / gru_pipe_bwd.hip), H = 64.
 //
-// Why this decomposition: one sequence per wave (gru_scan_*.hip) is latency-bound at
+// Why this decomposition (DESIGN_HISTORY.md section 3.7): one sequence per wave (gru_scan_*.hip) is latency-bound at
 // ~1250-1600 cycles per step because a single wave issues one instruction per ~5 cycles and a step needs ~100
 // packed FMAs plus two LDS broadcast round trips.  Here a workgroup owns a TILE of 16 sequences, which makes the
 // recurrent product of a step a real [3H x H] x [H x 16] contraction, and the 16x16x32 f16 MFMA does 8192 MACs in

@@ -551,7 +551,7 @@ def chunk_plan(spec: ScanSpec, nc: int):
 # The pipelined launches are parity-green but measured SLOWER at the reference batch (C3, B=500: forward 1.52 /
 # 1.42 / 1.14 ms, backward 2.31 / 2.29 / 2.29 ms for all / upper / 0) -- a tile of 16 sequences concentrates on
 # one CU the LDS traffic, transcendental work and stores that one-sequence-per-wave spreads over eight;
-# DESIGN.md section 3.7 has the per-step cycle accounting.
+# DESIGN_HISTORY.md section 3.7 has the per-step cycle accounting.
 PIPE = os.environ.get("HPMN_PIPE", "0")
 if PIPE in ("1", "true"):
     PIPE = "all"
@@ -663,7 +663,7 @@ def pipe_forward(spec: ScanSpec, ids, emb, weights: Sequence[torch.Tensor], trai
 def tiled_forward_inference(spec: ScanSpec, ids, emb, weights: Sequence[torch.Tensor], group: int = 1):
     """build_memory forward for LARGE batches (evaluation): the 16-sequence-tile kernel of hpmn_pipe_fwd -- a step's
     recurrent product as a real [3H x H] x [H x 16] contraction on the matrix cores, split-f16 operands, three products per
-    tile, fp32 accumulate -- run LAYER GROUP BY LAYER GROUP instead of all K layers in one launch.
+    tile, fp32 accumulate (DESIGN_HISTORY.md 3.7) -- run LAYER GROUP BY LAYER GROUP instead of all K layers in one launch.
 
     Per tile-step the tiled kernel costs ~1830 cycles for 16 sequences where the one-sequence-per-wave kernels cost ~1240
     for (at best) 4-8 per CU, so it wins as soon as the batch fills the chip with tiles; what lost at B = 500 was (a) 32

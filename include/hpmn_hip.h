@@ -311,7 +311,7 @@ typedef struct HpmnGruWgrad {
                               * late steps while the reverse scan is still working on the early ones. */
     int32_t whole_cu;        /* != 0: nothing latency-critical runs beside or behind this launch (the weight gradient of
                               * layer 0 at the end of BPTT): it may fill the CUs.  0: it shares the chip with a reverse
-                              * scan and is capped at one workgroup per CU */
+                              * scan and is capped at one workgroup per CU (DESIGN_HISTORY.md 3.9) */
 } HpmnGruWgrad;
 
 size_t hpmn_gru_param_grads_workspace_bytes(int32_t B, int32_t T, int32_t D, int32_t H);

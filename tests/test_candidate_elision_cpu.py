@@ -1,6 +1,6 @@
 """ABI v11, saved gates without the candidate (include/hpmn_hip.h, hpmn_amd/csrc/common.h: gru_coeff_from_states): the float32
 arithmetic the reverse-scan feeders run, restated in NumPy float32 operation by operation, against the float64 coefficients
-of BPTT through  h = u h_prev + (1 - u) c  (code/util.py:95-109) -- the error bound DESIGN.md 3.19 states, on CPU."""
+of BPTT through  h = u h_prev + (1 - u) c  (code/util.py:95-109) -- the error bound DESIGN_HISTORY.md 3.19 states, on CPU."""
 import numpy as np
 
 

@@ -1297,7 +1297,7 @@ def test_scans_give_the_same_result_beside_an_unrelated_kernel(dev, tmp_path, B,
 def test_fallback_kernel_paths_still_match_the_oracle(env):
     if env.get("HPMN_FUSED_FWD_GEN") == "1":
         _needs_legacy_build()
-    """The switches of DESIGN.md 3.11 select kernels at library load, so each set runs a slice of this file in a
+    """The switches of DESIGN_HISTORY.md 3.11 select kernels at library load, so each set runs a slice of this file in a
     process of its own: H = 64 forward/gradient parity at the tiny and odd lengths and at the XLong length."""
     import subprocess
     e = dict(os.environ)
@@ -1709,7 +1709,7 @@ def test_read_path_weight_gradients_deferred_equal_immediate_and_survive_batch_c
 
 
 def test_inference_read_launch_with_four_samples_per_workgroup_equals_two(dev, tmp_path):
-    """hpmn_read_fwd takes four samples per workgroup once the batch reaches 1024 rows: the same batch in
+    """hpmn_read_fwd takes four samples per workgroup once the batch reaches 1024 rows (DESIGN_HISTORY.md 3.15): the same batch in
     slices of 500 (two per workgroup) must give the same predictions, first-hop weights and memory loss -- per-sample
     arithmetic does not depend on the tile a sample sits in -- incl. a batch size that leaves a partial last tile."""
     from hpmn_amd import ops

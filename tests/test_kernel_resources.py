@@ -1,6 +1,6 @@
 """Build-time guards on what the compiler made of the latency-critical kernels (CPU: hipcc cross-compiles gfx950 to assembly;
 no GPU).  Two properties that neither the source nor a parity test shows and that cost double-digit percentages when they
-slipped (tools/check_resources.py):
+slipped (DESIGN_HISTORY.md 3.21, tools/check_resources.py):
 
 * the four-wave H = 128 scans must fit 256 registers (arch VGPRs + AGPRs): 257-264 is ONE wave per SIMD, and a batch of 500
   sequences then runs every scan launch in two rounds;

@@ -63,7 +63,7 @@ def main():
             nflat = len(re.findall(r"^\s+flat_(?:load|store|atomic)", text, flags=re.M))
             if nflat:
                 # an LDS or global access through a GENERIC pointer: flat_* counts in vmcnt AND lgkmcnt, so waiting for
-                # it drains the wave's global stores (progress counters of the fused forward kernel)
+                # it drains the wave's global stores (DESIGN_HISTORY.md 3.8: progress counters of the fused forward kernel)
                 print("%-58s %d flat_load/store/atomic instruction(s)  <-- generic-pointer access" % (os.path.basename(src), nflat))
             rows = PAT.findall(text)
             names = demangle([r[0] for r in rows])
