@@ -1059,11 +1059,13 @@ class Hpmn_Basic(object):
             self._plan_stream = torch.cuda.Stream(device=self.device)
         pst = self._plan_stream
         gb, cap, C, bounds = self._rows_geometry(next_ids, next_global_batch)
-        # HPMN_DP_SIDE_GROUP=1: the early exchange on a second communicator.  Default OFF (r5): issued at the START of the step
-        # the exchange is long finished when the step's own collectives are enqueued behind it on the one communicator (one rank
-        # on RCCL: 2.63 ms/step either way), and two communicators whose kernels the ranks may start in different orders are a
-        # known way to deadlock a node that nobody here can test on
-        group = dist.side_group() if (self._dp and os.environ.get("HPMN_DP_SIDE_GROUP", "0") == "1") else None
+        # The early exchange goes over a SECOND communicator (HPMN_DP_SIDE_GROUP=0: the default one).  Measured with one rank on
+        # RCCL in bench.py's timed loop: 2.60 ms/step against 2.97 on the one communicator -- its collectives then sit on that
+        # communicator's stream in front of the running step's.  Ordering argument for N > 1: a rank's side-communicator calls
+        # for step N+2 are enqueued after its main-communicator calls of step N and before those of step N+1, on every rank
+        # alike; neither kind waits for the other on the device (compute kernels never wait for a collective), so a peer that
+        # lags finishes its main-communicator calls first and then joins -- no cycle.  Unmeasured on more than one GPU.
+        group = dist.side_group() if (self._dp and os.environ.get("HPMN_DP_SIDE_GROUP", "1") != "0") else None
         # (next_ids must EXIST already -- a slice of a staged dataset: the stream is not made to wait for anything)
         with torch.cuda.stream(pst):
             plan = self._rows_plan(next_ids, cap, bounds) if next_ids.shape[0] > 0 else None
