@@ -27,16 +27,21 @@ def run(m, tr, te, steps=5, batch=50):
     ds = m._dev(tr)
     from hpmn_amd import dist
     step = 0
-    for lo, hi in ds.batches(batch):
+    # HPMN_DP_NEXT_IDS=1: every step is told the next batch's ids (what Hpmn.train() does): the next step's scatter plan and
+    # the exchange of the ranks' distinct-row lists then run a step ahead -- incl. the step whose NEXT shard is empty
+    ahead = os.environ.get("HPMN_DP_NEXT_IDS") == "1"
+    order = list(ds.batches(batch))[:steps] + [(0, 1)]
+    # (the last entry: a "last batch" of ONE sample -- with two ranks one shard is empty, and that rank must still take part
+    #  in every collective of the step)
+    for k, (lo, hi) in enumerate(order):
         a, b = dist.shard_bounds(lo, hi, m.rank, m.world)
-        m.train_step(ds.ids[a:b], ds.label[a:b], keep_prob=1.0, global_batch=hi - lo)
+        nxt = {}
+        if ahead and k + 1 < len(order):
+            lo2, hi2 = order[k + 1]
+            a2, b2 = dist.shard_bounds(lo2, hi2, m.rank, m.world)
+            nxt = dict(next_ids=ds.ids[a2:b2], next_global_batch=hi2 - lo2)
+        m.train_step(ds.ids[a:b], ds.label[a:b], keep_prob=1.0, global_batch=hi - lo, **nxt)
         step += 1
-        if step == steps:
-            break
-    # a "last batch" of ONE sample: with two ranks one shard is empty, and that rank must still take part in
-    # every collective of the step
-    a, b = dist.shard_bounds(0, 1, m.rank, m.world)
-    m.train_step(ds.ids[a:b], ds.label[a:b], keep_prob=1.0, global_batch=1)
     auc, ll, mem = m.eval(te, 64)
     out = {k: v.detach().cpu().numpy() for k, v in m.params.items()}
     out["__eval__"] = np.array([auc, ll, mem])

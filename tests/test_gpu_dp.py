@@ -38,6 +38,19 @@ def test_two_rank_two_pass_step_matches_single_process(tmp_path, monkeypatch, ex
     _run_two_ranks(tmp_path, "gloo", exchange, extra_env={"HPMN_TWO_PASS_MIN_NUMEL": "0"})
 
 
+@pytest.mark.parametrize("nproc", [2, 3])
+def test_rows_step_prepared_a_step_ahead_matches_single_process(tmp_path, monkeypatch, nproc):
+    """r5: train_step(next_ids=) -- the next step's scatter plan and the all-gather of the ranks' distinct-row lists and counts
+    are issued a step ahead, on their own stream and a second communicator; the step itself then only marks, runs the early
+    pass, and consumes the gathered rows with hpmn_rows_sum_adam.  Two and three ranks (ragged shards of 50: 16 / 17 / 17; the
+    one-sample last batch leaves all but one rank with an empty NEXT shard) against the single process, which is told its next
+    ids too."""
+    env = {"HPMN_TWO_PASS_MIN_NUMEL": "0", "HPMN_DP_NEXT_IDS": "1"}
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    _run_two_ranks(tmp_path, "gloo", "rows", extra_env=env, nproc=nproc)
+
+
 @pytest.mark.parametrize("exchange", ["rows", "auto"])
 def test_four_rank_two_pass_step_matches_single_process(tmp_path, monkeypatch, exchange):
     """The same step among FOUR ranks (shards of 12 / 13 sequences; the one-sample last batch leaves three ranks with an empty
