@@ -177,7 +177,8 @@ class HpmnRowsAdam(C.Structure):
                 ("rows", C.c_void_p), ("rows_stride", C.c_int64), ("flags", C.c_void_p),
                 ("param", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("V", C.c_int64),
                 ("lr_t", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("clip", C.c_float),
-                ("grad_scale", C.c_float)]
+                ("grad_scale", C.c_float), ("bucket_start", C.c_void_p), ("bucket_stride", C.c_int64),
+                ("bucket_shift", C.c_int32), ("pad_", C.c_int32)]
 
 
 SIGNATURES = {
@@ -243,7 +244,7 @@ SIGNATURES = {
                                           C.c_void_p, C.c_void_p]),
     "hpmn_rows_sum_adam": (C.c_int, [C.POINTER(HpmnRowsAdam), C.c_void_p]),
     "hpmn_table_mark_ranks": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p,
-                                        C.c_int64, C.c_int32, C.c_void_p]),
+                                        C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
     "hpmn_train_ctx_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "hpmn_train_ctx_destroy": (None, [C.c_void_p]),
     "hpmn_scan_train_workspace_bytes": (C.c_size_t, [C.POINTER(HpmnScanDesc)]),

@@ -74,7 +74,8 @@ int scatter_plan_build_launch(const void *ids, int32_t id_flags, int64_t n, int6
                               int32_t *perm, int32_t *seg, int32_t *start, void *rows, int32_t *count,
                               const int64_t *row_bounds, int32_t nb, int32_t *counts, hipStream_t st);
 int table_mark_ranks_launch(const void *ids, int64_t ids_stride, int32_t world, const int32_t *counts, int32_t counts_stride,
-                            int64_t cap, uint8_t *flags, int64_t V, int32_t id_flags, hipStream_t st);
+                            int64_t cap, uint8_t *flags, int64_t V, int32_t id_flags, int32_t *bstart, int64_t bstride,
+                            int32_t bshift, hipStream_t st);
 int adam_rows_launch(float *p, const float *g, float *m, float *v, const int64_t *row_ids, int64_t n_rows, int E,
                      float lr_t, float b1, float b2, float eps, float clip, float gs, hipStream_t st);
 
@@ -603,6 +604,8 @@ int hpmn_rows_sum_adam(const HpmnRowsAdam *a, void *stream) {
     if (total == 0) return HPMN_OK;
     if (!a->ids || !a->rows || !a->flags || !a->param || !a->m || !a->v) return HPMN_EINVAL;
     if (a->counts && a->counts_stride < 1) return HPMN_EINVAL;
+    if (a->bucket_start && (a->bucket_shift < 0 || a->bucket_shift > 62 || a->bucket_stride < ((a->V - 1) >> a->bucket_shift) + 2))
+        return HPMN_EINVAL;
     if ((reinterpret_cast<uintptr_t>(a->param) | reinterpret_cast<uintptr_t>(a->m) | reinterpret_cast<uintptr_t>(a->v) |
          reinterpret_cast<uintptr_t>(a->rows)) & 15)
         return HPMN_EINVAL;
@@ -610,13 +613,16 @@ int hpmn_rows_sum_adam(const HpmnRowsAdam *a, void *stream) {
 }
 
 int hpmn_table_mark_ranks(const void *ids, int64_t ids_stride, int32_t world, const int32_t *counts, int32_t counts_stride,
-                          int64_t cap, uint8_t *flags, int64_t V, int32_t id_flags, void *stream) {
+                          int64_t cap, uint8_t *flags, int64_t V, int32_t id_flags, int32_t *bucket_start, int64_t bucket_stride,
+                          int32_t bucket_shift, void *stream) {
     drop_stale_hip_error();
     if (world < 1 || world > HPMN_MAX_RANKS || cap < 0 || V < 1 || ids_stride < cap) return HPMN_EINVAL;
+    if (bucket_start && (bucket_shift < 0 || bucket_shift > 62 || bucket_stride < ((V - 1) >> bucket_shift) + 2)) return HPMN_EINVAL;
     if (cap == 0) return HPMN_OK;
     if (!ids || !flags || (counts && counts_stride < 1)) return HPMN_EINVAL;
     if (reinterpret_cast<uintptr_t>(flags) & 3) return HPMN_EINVAL;
-    return table_mark_ranks_launch(ids, ids_stride, world, counts, counts_stride, cap, flags, V, id_flags, (hipStream_t)stream);
+    return table_mark_ranks_launch(ids, ids_stride, world, counts, counts_stride, cap, flags, V, id_flags, bucket_start,
+                                   bucket_stride, bucket_shift, (hipStream_t)stream);
 }
 
 int hpmn_gru_fused_fwd_writes_last(void) { return gru_fused_fwd_writes_last() ? 1 : 0; }

@@ -39,6 +39,9 @@ struct RowsAdamK {
     float4 *p, *m, *v;
     long V;
     float lr_t, b1, b2, eps, clip, gs;
+    const int *bstart;            // optional bucket index over the lists: [world, bstride], see table_mark_ranks_kernel
+    long bstride;
+    int bshift;
 };
 
 __device__ __forceinline__ void adam_elem_r(float &p, float g, float &m, float &v, float lr_t, float b1, float b2, float eps,
@@ -119,12 +122,20 @@ __global__ __launch_bounds__(256) void rows_sum_adam_kernel(RowsAdamK a) {
         }
     }
     int lo[W], hi[W];
+    const long bkt = a.bstart != nullptr && x >= 0 ? (x >> a.bshift) : 0;
 #pragma unroll
     for (int r2 = 1; r2 < W; ++r2) {
         lo[r2] = 0;
         hi[r2] = 0;
-        if (r2 < a.world && ((mask >> r2) & 1u))
-            hi[r2] = (int)(a.counts ? (long)a.counts[(long)r2 * a.counts_stride] : a.len[r2]);
+        if (r2 < a.world && ((mask >> r2) & 1u)) {
+            if (a.bstart != nullptr) {
+                // the bucket index narrows the search to the list entries of x's bucket (a handful): 3-4 probes instead of 19
+                lo[r2] = a.bstart[(long)r2 * a.bstride + bkt];
+                hi[r2] = a.bstart[(long)r2 * a.bstride + bkt + 1];
+            } else {
+                hi[r2] = (int)(a.counts ? (long)a.counts[(long)r2 * a.counts_stride] : a.len[r2]);
+            }
+        }
     }
     for (;;) {
         bool more = false;
@@ -190,17 +201,36 @@ __global__ __launch_bounds__(256) void rows_sum_adam_kernel(RowsAdamK a) {
 
 // flags[row] |= 1 << r for the first len[r] rows of rank r's list.  A byte per row, rows of different ranks may share a
 // 32-bit word: the OR is an atomic on the aligned word (off the serial chain: this runs underneath the forward).
+// Optionally (bstart != NULL) the same pass builds a BUCKET INDEX over every list for hpmn_rows_sum_adam's searches:
+// bstart[r][b] = first entry of list r whose id >> bshift is >= b, for b = 0 .. nb (bstart[r][nb] = len).  The entry that opens a
+// bucket fills the slots of the empty buckets in front of it, the last entry the slots behind it (lists are ascending).
 __global__ __launch_bounds__(256) void table_mark_ranks_kernel(const void *__restrict__ ids, long ids_stride, int world,
                                                                const int *__restrict__ counts, int counts_stride, long cap,
-                                                               uint8_t *__restrict__ flags, long V, int id_flags) {
+                                                               uint8_t *__restrict__ flags, long V, int id_flags,
+                                                               int *__restrict__ bstart, long bstride, int bshift, long nb) {
     const long stride = (long)gridDim.x * blockDim.x;
     const long total = cap * world;
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
         const int r = (int)(t / cap);
         const long j = t - (long)r * cap;
         const long len = counts ? (long)counts[(long)r * counts_stride] : cap;
+        if (bstart != nullptr && len == 0 && j == 0)
+            for (long b = 0; b <= nb; ++b) bstart[(long)r * bstride + b] = 0;
         if (j >= len) continue;
         const long x = load_id(ids, (long)r * ids_stride + j, id_flags);
+        if (bstart != nullptr) {
+            // (entries outside [0, V) do not occur in a plan's list; clamped so that the index stays well-formed anyway)
+            const long xc = x < 0 ? 0 : (x >= V ? V - 1 : x);
+            const long b = xc >> bshift;
+            long bp = -1;
+            if (j > 0) {
+                const long y = load_id(ids, (long)r * ids_stride + j - 1, id_flags);
+                bp = (y < 0 ? 0 : (y >= V ? V - 1 : y)) >> bshift;
+            }
+            for (long bb = bp + 1; bb <= b; ++bb) bstart[(long)r * bstride + bb] = (int)j;
+            if (j == len - 1)
+                for (long bb = b + 1; bb <= nb; ++bb) bstart[(long)r * bstride + bb] = (int)len;
+        }
         if (x < 0 || x >= V) continue;
         unsigned *word = reinterpret_cast<unsigned *>(flags + (x & ~3L));
         const unsigned bit = (1u << r) << (8 * (int)(x & 3L));
@@ -209,12 +239,15 @@ __global__ __launch_bounds__(256) void table_mark_ranks_kernel(const void *__res
 }
 
 int table_mark_ranks_launch(const void *ids, int64_t ids_stride, int32_t world, const int32_t *counts, int32_t counts_stride,
-                            int64_t cap, uint8_t *flags, int64_t V, int32_t id_flags, hipStream_t st) {
+                            int64_t cap, uint8_t *flags, int64_t V, int32_t id_flags, int32_t *bstart, int64_t bstride,
+                            int32_t bshift, hipStream_t st) {
     if (cap == 0 || world == 0) return HPMN_OK;
     long blocks = (cap * world + 255) / 256;
     if (blocks > 256L * 4) blocks = 256L * 4;            // (a thin grid: it shares the chip with the forward scans)
+    const long nb = bstart ? ((V - 1) >> bshift) + 1 : 0;
     hipLaunchKernelGGL(table_mark_ranks_kernel, dim3((unsigned)blocks), dim3(256), 0, st, ids, (long)ids_stride, (int)world,
-                       counts, (int)counts_stride, (long)cap, flags, (long)V, (int)id_flags);
+                       counts, (int)counts_stride, (long)cap, flags, (long)V, (int)id_flags, bstart, (long)bstride, (int)bshift,
+                       nb);
     return check_launch();
 }
 
@@ -233,6 +266,7 @@ int rows_sum_adam_launch(const HpmnRowsAdam &h, hipStream_t st) {
     a.p = reinterpret_cast<float4 *>(h.param); a.m = reinterpret_cast<float4 *>(h.m); a.v = reinterpret_cast<float4 *>(h.v);
     a.V = h.V;
     a.lr_t = h.lr_t; a.b1 = h.beta1; a.b2 = h.beta2; a.eps = h.eps; a.clip = h.clip; a.gs = h.grad_scale;
+    a.bstart = h.bucket_start; a.bstride = h.bucket_stride; a.bshift = h.bucket_shift;
     const long total = a.ent_off[h.world];
     if (total == 0) return HPMN_OK;
     if (h.world == 1) {

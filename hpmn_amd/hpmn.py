@@ -1138,7 +1138,12 @@ class Hpmn_Basic(object):
                         if plan is not None:
                             torch.cuda.current_stream().wait_event(plan.ready)
                         box.update(self._rows_early_exchange(plan, ids.dtype, cap, C))
-                    ops.table_mark_ranks(box["ids_all"], box["cnt_all"], flags, counts_stride=1 + C)
+                    if self.world > 1:
+                        # (a bucket index over the gathered lists, built by the marking pass: the late launch's searches then
+                        #  probe a handful of entries instead of a whole list)
+                        box["buckets"] = ops.RowBuckets(self.world, V, cap, self.device)
+                        box["buckets"].start.record_stream(torch.cuda.current_stream())
+                    ops.table_mark_ranks(box["ids_all"], box["cnt_all"], flags, counts_stride=1 + C, buckets=box.get("buckets"))
                 v1 = V if self.EARLY_PASS_SPLIT >= 1.0 else max(1, min(V, int(V * self.EARLY_PASS_SPLIT)))
                 probe = self._split_probe if isinstance(self._split_probe, dict) and self._split_probe.get("armed") else None
                 if probe is not None:
@@ -1177,7 +1182,7 @@ class Hpmn_Basic(object):
         else:
             main = torch.cuda.current_stream()
             ids_all, cnt_all = box["ids_all"], box["cnt_all"]
-            for x in (ids_all, cnt_all):
+            for x in (ids_all, cnt_all) + ((box["buckets"].start,) if "buckets" in box else ()):
                 x.record_stream(main)                         # (made on the auxiliary stream, consumed here)
             lens, windows = dist.rows_windows(box["counts"].result())      # (an event wait, long satisfied)
             src = plan.out_rows if plan is not None else torch.empty(cap, E, device=self.device, dtype=torch.float32)
@@ -1194,7 +1199,8 @@ class Hpmn_Basic(object):
                 g_all, work = item
                 if work is not None:
                     work.wait()                               # (orders the current stream behind the collective)
-                ops.rows_sum_adam(P, M, S, flags, ids_all, g_all, lr_t, lens=lens, first=first, n=n, **hp)
+                ops.rows_sum_adam(P, M, S, flags, ids_all, g_all, lr_t, lens=lens, first=first, n=n,
+                                  buckets=box.get("buckets"), **hp)
             self.last_exchange_mode = "rows"
             self.last_exchange_bytes = dist.rows_exchange_bytes_windows(windows, E, wide, self.world, cap)
         if pending is not None:

@@ -430,23 +430,41 @@ def table_flags(V: int, device) -> torch.Tensor:
     return torch.zeros((V + 3) // 4 * 4, device=device, dtype=torch.uint8)[:V]
 
 
+class RowBuckets:
+    """A bucket index over every rank's ascending row list (hpmn_table_mark_ranks builds it, hpmn_rows_sum_adam searches through
+    it): start[r, b] = first entry of list r whose id >> shift is >= b.  ~4 list entries per bucket at the lists' capacity."""
+
+    def __init__(self, world: int, V: int, cap: int, device):
+        target = max(1024, int(cap) // 4)
+        shift = 0
+        while ((V - 1) >> shift) + 1 > target:
+            shift += 1
+        self.shift, self.nb = shift, ((V - 1) >> shift) + 1
+        self.start = torch.empty(world, self.nb + 2, device=device, dtype=torch.int32)
+
+
 def table_mark_ranks(ids_all: torch.Tensor, counts: Optional[torch.Tensor], flags: torch.Tensor, cap: Optional[int] = None,
-                     counts_stride: int = 1):
+                     counts_stride: int = 1, buckets: Optional[RowBuckets] = None):
     """hpmn_table_mark_ranks: flags[row] |= 1 << r for the valid entries of ids_all[r, :] (``counts``: int32 device tensor,
-    rank r's list length at counts[r * counts_stride]; None: the first ``cap`` entries, ids outside [0, V) ignored)."""
+    rank r's list length at counts[r * counts_stride]; None: the first ``cap`` entries, ids outside [0, V) ignored).
+    ``buckets``: the same pass fills the bucket index."""
     _chk_ids(ids_all)
     assert ids_all.dim() == 2 and flags.dtype == torch.uint8 and flags.is_cuda and flags.is_contiguous()
     world, stride = ids_all.shape
     if counts is not None:
         assert counts.dtype == torch.int32 and counts.is_cuda and counts.is_contiguous()
+    if buckets is not None:
+        assert buckets.start.shape[0] == world
     rc = _lib.load().hpmn_table_mark_ranks(ids_all.data_ptr(), stride, world, _ptr(counts), counts_stride,
                                             stride if cap is None else cap, flags.data_ptr(), flags.numel(),
-                                            _idf(ids_all, False), _stream())
+                                            _idf(ids_all, False), _ptr(buckets.start if buckets is not None else None),
+                                            buckets.start.shape[1] if buckets is not None else 0,
+                                            buckets.shift if buckets is not None else 0, _stream())
     _lib.check(rc, "hpmn_table_mark_ranks")
 
 
 def rows_sum_adam(param, m, v, flags, ids_all, rows_all, lr_t, *, counts=None, counts_stride=1, lens=None, first=None,
-                  n=None, beta1=0.9, beta2=0.999, eps=1e-8, clip=1.0, grad_scale=1.0):
+                  n=None, beta1=0.9, beta2=0.999, eps=1e-8, clip=1.0, grad_scale=1.0, buckets: Optional[RowBuckets] = None):
     """hpmn_rows_sum_adam: the update of the TOUCHED table rows from compact gradient rows, all ranks' lists in one launch.
     ``ids_all`` [world, ids_stride] (every rank's ascending distinct rows), ``rows_all`` [world, rows_stride, E] (their
     gradient rows; rows_all[r][i] belongs to list entry first[r] + i), list lengths from the device tensor ``counts`` (int32,
@@ -471,6 +489,8 @@ def rows_sum_adam(param, m, v, flags, ids_all, rows_all, lr_t, *, counts=None, c
     a.rows, a.rows_stride = rows_all.data_ptr(), rows_all.shape[1]
     a.flags, a.param, a.m, a.v, a.V = flags.data_ptr(), param.data_ptr(), m.data_ptr(), v.data_ptr(), V
     a.lr_t, a.beta1, a.beta2, a.eps, a.clip, a.grad_scale = lr_t, beta1, beta2, eps, clip, grad_scale
+    if buckets is not None and world > 1:
+        a.bucket_start, a.bucket_stride, a.bucket_shift = buckets.start.data_ptr(), buckets.start.shape[1], buckets.shift
     _lib.check(_lib.load().hpmn_rows_sum_adam(C.byref(a), _stream()), "hpmn_rows_sum_adam")
 
 

@@ -667,12 +667,20 @@ typedef struct HpmnRowsAdam {
     float *param, *m, *v;
     int64_t V;
     float lr_t, beta1, beta2, eps, clip, grad_scale;
+    /* optional bucket index over the lists (hpmn_table_mark_ranks builds it): bucket_start[r * bucket_stride + b] = first entry
+     * of list r whose id >> bucket_shift is >= b, b = 0 .. ((V - 1) >> bucket_shift) + 1.  NULL: every search covers a whole list */
+    const int32_t *bucket_start;
+    int64_t bucket_stride;
+    int32_t bucket_shift, pad_;
 } HpmnRowsAdam;
 int hpmn_rows_sum_adam(const HpmnRowsAdam *args, void *stream);
 /* flags[row] |= 1 << r for the first (counts ? counts[r * counts_stride] : cap) entries of ids[r, :], r < world.
- * Entries outside [0, V) are ignored.  Runs underneath the forward (atomic OR on the aligned 32-bit word). */
+ * Entries outside [0, V) are ignored.  Runs underneath the forward (atomic OR on the aligned 32-bit word).
+ * bucket_start != NULL: the same pass writes the bucket index HpmnRowsAdam describes (bucket_stride >= ((V-1) >> bucket_shift) + 2
+ * ints per rank; every slot is written). */
 int hpmn_table_mark_ranks(const void *ids, int64_t ids_stride, int32_t world, const int32_t *counts, int32_t counts_stride,
-                          int64_t cap, uint8_t *flags, int64_t V, int32_t id_flags, void *stream);
+                          int64_t cap, uint8_t *flags, int64_t V, int32_t id_flags, int32_t *bucket_start, int64_t bucket_stride,
+                          int32_t bucket_shift, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Online incremental memory update -- the serving-time form of build_memory: ONE new event per

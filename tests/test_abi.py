@@ -90,8 +90,8 @@ def test_error_codes_without_touching_a_device(lib):
     assert lib.hpmn_rows_sum_adam(C.byref(ra), None) == -2                                                  # E/4 not a power of two
     ra.E, ra.world = 16, 9
     assert lib.hpmn_rows_sum_adam(C.byref(ra), None) == -1                                                  # > HPMN_MAX_RANKS
-    assert lib.hpmn_table_mark_ranks(None, 0, 2, None, 0, 0, None, 10, 0, None) == 0
-    assert lib.hpmn_table_mark_ranks(None, 8, 2, None, 0, 8, None, 10, 0, None) == -1
+    assert lib.hpmn_table_mark_ranks(None, 0, 2, None, 0, 0, None, 10, 0, None, 0, 0, None) == 0
+    assert lib.hpmn_table_mark_ranks(None, 8, 2, None, 0, 8, None, 10, 0, None, 0, 0, None) == -1
     plan = _lib.HpmnScatterPlan()
     plan.n = 30
     assert lib.hpmn_embed_grad_segsum(C.byref(plan), None, None, 2, 5, 3, 24, 0, 0, None, 0, None) == -2  # 256 % (E/4)

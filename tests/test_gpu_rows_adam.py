@@ -41,9 +41,10 @@ def _dense_reference(p, m, v, lists, grads, lr_t, dev):
     return p2, m2, v2
 
 
+@pytest.mark.parametrize("bucketed", [False, True])
 @pytest.mark.parametrize("world,E,idt,chunks", [(1, 16, np.int32, 1), (2, 16, np.int32, 1), (3, 16, np.int64, 3),
                                                  (8, 16, np.int32, 4), (8, 4, np.int32, 2), (5, 64, np.int64, 1)])
-def test_rows_sum_adam_is_the_dense_two_pass_update_bit_for_bit(dev, world, E, idt, chunks):
+def test_rows_sum_adam_is_the_dense_two_pass_update_bit_for_bit(dev, world, E, idt, chunks, bucketed):
     from hpmn_amd import ops
     rng = np.random.default_rng(1000 * world + E + chunks)
     V = 20011
@@ -63,8 +64,16 @@ def test_rows_sum_adam_is_the_dense_two_pass_update_bit_for_bit(dev, world, E, i
     want = _dense_reference(p, m, v, lists, grads, lr_t, dev)
 
     flags = ops.table_flags(V, dev)
-    ops.table_mark_ranks(ids_all, counts, flags)
+    # (bucketed: the marking pass also builds the bucket index the late launch searches through -- a tiny capacity here, so that
+    #  buckets hold many entries, some none, and the lists of a few ranks end far below the last bucket)
+    bk = ops.RowBuckets(world, V, 2048 if world % 2 else 64, dev) if bucketed else None
+    ops.table_mark_ranks(ids_all, counts, flags, buckets=bk)
     torch.cuda.synchronize()
+    if bk is not None:
+        st = bk.start.cpu().numpy()
+        for r, rows in enumerate(lists):
+            want_st = np.searchsorted(rows >> bk.shift, np.arange(bk.nb + 1), side="left")
+            assert (st[r, :bk.nb + 1] == want_st).all()
     f = flags.cpu().numpy()
     mask = np.zeros(V, np.uint8)
     for r, rows in enumerate(lists):
@@ -82,9 +91,10 @@ def test_rows_sum_adam_is_the_dense_two_pass_update_bit_for_bit(dev, world, E, i
         for r in range(world):
             rows_all[r, :n[r]] = grads[r][first[r]:first[r] + n[r]]
         if c % 2 == 0:
-            ops.rows_sum_adam(p, m, v, flags, ids_all, rows_all, lr_t, counts=counts, first=first, n=n)
+            ops.rows_sum_adam(p, m, v, flags, ids_all, rows_all, lr_t, counts=counts, first=first, n=n, buckets=bk)
         else:                                                                   # host-side lengths instead of device counts
-            ops.rows_sum_adam(p, m, v, flags, ids_all, rows_all, lr_t, lens=[len(x) for x in lists], first=first, n=n)
+            ops.rows_sum_adam(p, m, v, flags, ids_all, rows_all, lr_t, lens=[len(x) for x in lists], first=first, n=n,
+                              buckets=bk)
     torch.cuda.synchronize()
     assert torch.equal(p, want[0]) and torch.equal(m, want[1]) and torch.equal(v, want[2])
     assert int(flags.count_nonzero()) == 0                                      # left all-zero for the next step

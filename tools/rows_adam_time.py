@@ -39,9 +39,12 @@ for world in (1, 2, 4, 8):
     rows_all = torch.randn(world, cap, E, device=dev)
     flags = ops.table_flags(V, dev)
     union = len(np.unique(np.concatenate(lists)))
-    mark = lambda: ops.table_mark_ranks(ids_all, counts, flags)
+    bk = ops.RowBuckets(world, V, cap, dev)
+    mark = lambda: ops.table_mark_ranks(ids_all, counts, flags, buckets=bk)
     t_mark = timed(mark, lambda: flags.zero_())
-    t = timed(lambda: ops.rows_sum_adam(p, m, v, flags, ids_all, rows_all, 1e-3, counts=counts), mark)
+    t_nb = timed(lambda: ops.rows_sum_adam(p, m, v, flags, ids_all, rows_all, 1e-3, counts=counts), mark)
+    t = timed(lambda: ops.rows_sum_adam(p, m, v, flags, ids_all, rows_all, 1e-3, counts=counts, buckets=bk), mark)
+    print("   (without the bucket index: %.1f us; buckets: shift %d, %d per rank)" % (t_nb, bk.shift, bk.nb))
     byt = union * E * 4 * 6 + sum(len(x) for x in lists) * (E * 4 + 4 + 1)
     # the dense form: gradient table + pass 1
     g = torch.zeros(V, E, device=dev)
