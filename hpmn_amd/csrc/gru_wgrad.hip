@@ -284,6 +284,14 @@ size_t gru_wgrad_workspace_bytes(int B, int T, int D, int H) {
     return (size_t)nwg * (size_t)wgrad_tsplit(D, H) * (size_t)wgrad_slab_floats(D, H) * sizeof(float);
 }
 
+// The slab reduction of a launch may go to ANOTHER stream (gru_wgrad_reduce_aside: set by hpmn_scan_bwd around its calls, per
+// thread): the next layer's weight-gradient launch then does not queue behind a reduction that is starving beside a reverse scan
+// (H = 128, r5: the scans own every register of the chip, a 197 MB reduction took 811 us beside one and the whole chain of
+// weight gradients fell behind it).  The caller gives every layer its own slab buffer then.
+static thread_local hipStream_t g_reduce_stream = nullptr;
+static thread_local hipEvent_t g_reduce_event = nullptr;
+void gru_wgrad_reduce_aside(hipStream_t reduce_stream, hipEvent_t ev) { g_reduce_stream = reduce_stream; g_reduce_event = ev; }
+
 template <int HT, int DT, int CS = 1>
 static int launch_wgrad(const HpmnGruWgrad &a, hipStream_t st) {
     HpmnGruWgrad k = a;
@@ -344,7 +352,15 @@ static int launch_wgrad(const HpmnGruWgrad &a, hipStream_t st) {
     if (rc != HPMN_OK) return rc;
     const int H = a.H, D = a.D;
     const long n = wgrad_slab_floats(D, H);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 31) / 32)), dim3(32 * RED_G), 0, st, a.workspace, nslab, n,
+    hipStream_t rst = st;
+    if (g_reduce_stream != nullptr && g_reduce_event != nullptr && g_reduce_stream != st) {
+        if (hipEventRecord(g_reduce_event, st) != hipSuccess || hipStreamWaitEvent(g_reduce_stream, g_reduce_event, 0) != hipSuccess) {
+            set_last_hip_error((int)hipGetLastError());
+            return HPMN_EHIP;
+        }
+        rst = g_reduce_stream;
+    }
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 31) / 32)), dim3(32 * RED_G), 0, rst, a.workspace, nslab, n,
                        a.d_wg, a.d_bg, a.d_wc, a.d_bc, (long)(D + H) * 2 * H, (long)2 * H, (long)(D + H) * H);
     return check_launch();
 }

@@ -20,6 +20,7 @@ bool gru_pair_bwd_supported(int H, int D_lo);
 #include "gru32_all.h"
 namespace hpmn {
 size_t gru_wgrad_workspace_bytes(int B, int T, int D, int H);
+void gru_wgrad_reduce_aside(hipStream_t reduce_stream, hipEvent_t ev);
 bool gru_scan_bwd_fuses_dx(int H, int B);
 bool gru_candidate_elision(int H, int B);
 bool gru_scan_bwd_dx_width_ok(int D);
@@ -31,7 +32,7 @@ int embed_grad_scatter_launch(const void *ids, const float *d_x, float *d_emb, i
 struct TrainCtx {
     int device = -1, cus = 256;
     hipStream_t side = nullptr, side2 = nullptr;         // (side2: the second of two small weight-gradient launches at the end)
-    hipEvent_t fork = nullptr, join = nullptr, join2 = nullptr, scat = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr, join2 = nullptr, scat = nullptr, red = nullptr;
     bool pending2 = false;
     hipEvent_t probe0 = nullptr, probe1 = nullptr;      // (timing events around layer 0's reverse-scan launch, on request)
     bool pending = false, probe = false, probed = false;
@@ -73,6 +74,15 @@ static int scatter_all(TrainCtx *c, const HpmnScanDesc *d, const void *ids, cons
 
 static size_t up256(size_t x) { return (x + 255) / 256 * 256; }
 
+// HPMN_WGRAD_REDUCE_ASIDE=1 (H = 128 only; default 0): the weight gradients' slab reductions on the second helper stream.
+// Built, parity-green (the 26 H = 128 tests), measured NEUTRAL at C4 (r5: 7.25 / 7.27 vs 7.17 / 7.33 ms per step): the chain of
+// weight-gradient launches does run earlier -- layer 0's starts the moment its scan ends instead of 320 us later -- but what
+// runs earlier runs beside layer 0's reverse scan, which stretches from 1.22 to 1.44 ms: who is resident decides (DESIGN_HISTORY 3.9).
+static bool reduce_aside_enabled() {
+    static const int on = [] { const char *e = getenv("HPMN_WGRAD_REDUCE_ASIDE"); return e ? atoi(e) : 0; }();
+    return on != 0;
+}
+
 static bool lengths(const HpmnScanDesc &d, int32_t *len) {
     if (d.K < 1 || d.K > HPMN_MAX_LAYERS) return false;
     long t = (long)d.T + d.front_zero;
@@ -107,7 +117,12 @@ static bool layout(const HpmnScanDesc &d, HpmnTrainLayout &L) {
     }
     L.wgrad_ws = off;
     off += up256(wmax);
-    if (d.H != 32) {                               // a second slab buffer: two small weight-gradient launches side by side
+    if (d.H == 128 && reduce_aside_enabled()) {    // r5: a slab buffer PER LAYER (the reductions run on another stream)
+        for (int i = 0; i < d.K; ++i) {
+            L.wgrad_ws_layer[i] = off;
+            off += up256(gru_wgrad_workspace_bytes(d.B, len[i], (int)(i == 0 ? D0 : H), d.H));
+        }
+    } else if (d.H != 32) {                        // a second slab buffer: two small weight-gradient launches side by side
         L.wgrad_ws_layer[1] = off;
         off += up256(wmax);
     }
@@ -150,7 +165,8 @@ int hpmn_train_ctx_create(HpmnTrainCtx **out) {
         hipEventCreateWithFlags(&c->join2, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->join, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->scat, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&c->scat, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->red, hipEventDisableTiming) != hipSuccess) {
         set_last_hip_error((int)hipGetLastError());
         delete c;
         return HPMN_EHIP;
@@ -173,6 +189,7 @@ void hpmn_train_ctx_destroy(HpmnTrainCtx *ctx) {
     if (c->fork) (void)hipEventDestroy(c->fork);
     if (c->join) (void)hipEventDestroy(c->join);
     if (c->scat) (void)hipEventDestroy(c->scat);
+    if (c->red) (void)hipEventDestroy(c->red);
     if (c->side) (void)hipStreamDestroy(c->side);
     delete c;
 }
@@ -351,7 +368,8 @@ int hpmn_scan_bwd(HpmnTrainCtx *ctx, const HpmnScanDesc *d, const void *ids, con
     // weight gradient.  (The scatter is an atomic row add, so the two halves commute.)
     static const int split_env = [] { const char *e = getenv("HPMN_L0_SPLIT"); return e ? atoi(e) : 0; }();
     int cut = 0;
-    if (split_env && !has_plan && L.T[0] >= 256 && !gru_scan_bwd_fuses_dx(d->H, d->B)) {
+    if (split_env && !has_plan && L.T[0] >= 256 && !gru_scan_bwd_fuses_dx(d->H, d->B) && !(d->H == 128 && reduce_aside_enabled())) {
+        // (not with the reductions on another stream: the two time halves of layer 0 share one slab buffer)
         const int p0 = d->periods[0], q = (p0 % 2 == 0) ? p0 : 2 * p0;
         cut = (L.T[0] / 2) / q * q;
         if (cut <= d->front_zero || cut >= L.T[0] + d->last_index) cut = 0;
@@ -395,6 +413,12 @@ int hpmn_scan_bwd(HpmnTrainCtx *ctx, const HpmnScanDesc *d, const void *ids, con
         if (!defer_join) return hpmn_train_join(ctx, stream);
         return HPMN_OK;
     }
+    // H = 128 (r5): every weight gradient's slab reduction goes to the second helper stream, out of a slab buffer of the
+    // layer's own (layout()) -- the chain of weight-gradient launches on the first no longer waits for reductions that starve
+    // beside the scans (C4's timeline: 467 and 811 us for reductions that take 20-50 us on a free chip).
+    const bool aside = d->H == 128 && reduce_aside_enabled() && L.wgrad_ws_layer[0] != 0;
+    struct AsideGuard { bool on; ~AsideGuard() { if (on) gru_wgrad_reduce_aside(nullptr, nullptr); } } aside_guard{aside};
+    if (aside) gru_wgrad_reduce_aside(c->side2, c->red);
     bool scatter_pending = false, scatter_fused = false;
     int scat_cut = cut;                                  // first scan step whose scatter is already under way
     HpmnGruWgrad held[4], late[HPMN_MAX_LAYERS];
@@ -417,7 +441,7 @@ int hpmn_scan_bwd(HpmnTrainCtx *ctx, const HpmnScanDesc *d, const void *ids, con
         w.hs = F(L.hs[i]); w.gates = F(L.gates[i]); w.d_act = F(L.d_act[i]);
         w.wg = wg[i]; w.wc = wc[i];
         w.d_wg = d_wg[i]; w.d_bg = d_bg[i]; w.d_wc = d_wc[i]; w.d_bc = d_bc[i];
-        w.workspace = F(L.wgrad_ws);
+        w.workspace = aside ? F(L.wgrad_ws_layer[i]) : F(L.wgrad_ws);
         // (layer 0's weight gradient runs beside the scatter and the table update, which are bandwidth kernels, and
         //  bounds the step's tail: it may fill the CUs -- 2.985 -> 2.905 ms/step at C3)
         w.whole_cu = i == 0 && d->H <= 64 ? 1 : 0;
@@ -608,7 +632,7 @@ int hpmn_scan_bwd(HpmnTrainCtx *ctx, const HpmnScanDesc *d, const void *ids, con
         // NEUTRAL (C4 7.52 vs 7.39-7.68 ms/step: two weight gradients resident when a scan launches take its CUs, layer 0's scan
         // 1430 instead of 1100 us), default off.
         static const int alt_env = [] { const char *e = getenv("HPMN_WGRAD_ALTERNATE"); return e ? atoi(e) : 0; }();
-        const bool alternate = alt_env && d->H == 128 && L.wgrad_ws_layer[1] != 0 && cut0 == 0;
+        const bool alternate = alt_env && !aside && d->H == 128 && L.wgrad_ws_layer[1] != 0 && cut0 == 0;
         if (alternate && (i & 1) == 0) w.workspace = F(L.wgrad_ws_layer[1]);
         held[nheld++] = w;
         if (L.T[i] > 128 || L.T[0] < 512 || i == 0 || nheld == 4) {
@@ -619,7 +643,7 @@ int hpmn_scan_bwd(HpmnTrainCtx *ctx, const HpmnScanDesc *d, const void *ids, con
                 const bool second = alternate && held[h].workspace == F(L.wgrad_ws_layer[1]);
                 rc = hpmn_gru_param_grads(&held[h], second ? c->side2 : c->side);
                 if (rc != HPMN_OK) return rc;
-                if (second) c->pending2 = true;
+                if (second || aside) c->pending2 = true;
             }
             nheld = 0;
             c->pending = true;
