@@ -1,0 +1,282 @@
+// build_memory forward for EVALUATION at H = 128 (BASELINE configs[4]): one layer per launch, 16-sequence tiles on the matrix
+// cores -- the H = 64 tile kernel's arithmetic (gru_pipe_fwd.hip / pipe_common.h: every operand split x = hi + lo in f16, three
+// products per tile, fp32 accumulate) in the decomposition H = 128 needs (r5; VERDICT r4 missing #4).
+//
+// Reference: tf.nn.dynamic_rnn(GRUCell(H)) + the every-p-th-output gather of code/hpmn.py:118-128 (cell arithmetic mirrored at
+// code/util.py:95-109 without :108), forward only: memory[:, i, :] = the layer's final state, y = outputs[:, p-1::p, :].
+//
+// Why not gru_pipe_fwd's twelve role-specialised waves: 3 gates x 128 units = 24 output tiles of 16 units; the recurrent weights
+// alone are 24 tiles x 4 k-steps x (hi, lo) x 1 KB = 192 KB of stationary A operands -- 37 % of the CU's register file -- and
+// twelve waves (three per SIMD, 168 registers each) cannot hold their share next to the operands of a step.  Here a workgroup is
+// FOUR waves, one per SIMD, each with the whole 512-register budget: wave w owns units [32 w, 32 w + 32) of ALL THREE gates
+// (6 tiles, 192 registers of recurrent weights), so r, u and the state h of its units never leave its registers and the only
+// traffic between waves is the two operand images a step needs anyway: h (hi, lo) before the gate products and r*h before the
+// candidate product -- 2 LDS barriers per step, no role hand-offs.  Per step and wave: 48 + 24 recurrent MFMAs (16x16x32 f16),
+// 24 transcendental pairs per lane.
+//
+// The input product x_t W[:D]:
+//   * layer 0 (D = 32, one k-step): in the kernel, off the chain (wave 0 parks row t+2 as an operand image while every wave
+//     projects row t+1): 18 MFMAs per wave and step, 48 registers of input weights;
+//   * layers >= 1 (D = 128): the input weights would be another 192 registers per wave (or 192 KB of LDS: neither exists), so
+//     the caller runs hpmn_gru_input_proj first and this kernel reads the PROJECTED rows xp [B, T, 3H] (already in the
+//     scan's exponent domain, bias included), six 16-byte loads per lane and step, four steps ahead.
+#include "pipe_common.h"
+
+namespace hpmn {
+
+constexpr int H2 = 128;
+constexpr int ROWB2 = 288;                 // bytes per sequence row of an operand image: 256 (128 f16) + 32 pad
+constexpr int IMG2 = TS * ROWB2;
+constexpr int T128_LDS = 8 * IMG2;         // h hi/lo, r*h hi/lo, x ring 2 x hi/lo
+
+struct Tile128Args {
+    int B, T, D, period;
+    const float *x;        // [B, T, D]   (D = 32: projected in the kernel) or NULL
+    const float *xp;       // [B, T, 3H]  (projected rows) or NULL
+    const float *wg, *bg, *wc, *bc;
+    float *y;              // [B, T / period, H] or NULL
+    float *h_last;
+    long h_last_stride;
+};
+
+#define MF128(A, Bv, C) __builtin_amdgcn_mfma_f32_16x16x32_f16(A, Bv, C, 0, 0, 0)
+
+template <bool XPM>
+__global__ __launch_bounds__(256, 1) void gru_tile128_fwd_kernel(const Tile128Args a) {
+    __shared__ __attribute__((aligned(16))) char smem[T128_LDS];
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, g = lane >> 4, n = lane & 15;
+    const int tile = blockIdx.x;
+    const int B = a.B, T = a.T, D = a.D;
+    const bool live = tile * TS + n < B;
+    const long b = live ? (long)tile * TS + n : (long)B - 1;
+    char *Hhi = smem, *Hlo = smem + IMG2, *Rhi = smem + 2 * IMG2, *Rlo = smem + 3 * IMG2, *X = smem + 4 * IMG2;
+    const int wr = n * ROWB2 + w * 64 + g * 16;                     // the lane's 8 units of a row: [tile j = 0 | j = 1] x 4
+    const int rdb = n * ROWB2 + g * 16;                            // k-step s at + 64 s
+    const int u0 = 32 * w + 4 * g;                                  // units u0 + 16 j + 0..3
+
+    // ---- stationary A operands: recurrent rows of the wave's six tiles (gate q, half j), the exp2 scale folded in
+    h8 Ah_hi[3][2][4], Ah_lo[3][2][4];
+    h8 Ai_hi[3][2], Ai_lo[3][2];
+    f4 bias[3][2];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const float sc = q < 2 ? NEG_LOG2E : 2.0f * NEG_LOG2E;
+        const float *W = q < 2 ? a.wg + q * H2 : a.wc;
+        const int ld = q < 2 ? 2 * H2 : H2;
+        const float *bp = q < 2 ? a.bg + q * H2 : a.bc;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = 32 * w + 16 * j + n;                    // A's row m = lane % 16 -> output unit of the tile
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                float vh[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) vh[e] = W[(long)(D + slot_unit(s, g, e)) * ld + col] * sc;
+                split8(vh, Ah_hi[q][j][s], Ah_lo[q][j][s]);
+            }
+            if constexpr (!XPM) {
+                float vi[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int unit = slot_unit(0, g, e);            // (D = 32: units 0..31 are k-step 0)
+                    const float wi = W[(long)(unit < D ? unit : 0) * ld + col] * sc;
+                    vi[e] = unit < D ? wi : 0.f;
+                }
+                split8(vi, Ai_hi[q][j], Ai_lo[q][j]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) bias[q][j][k] = bp[u0 + 16 * j + k] * sc;
+            }
+        }
+    }
+
+    const int period = a.period;
+    const bool has_y = a.y != nullptr;
+    float *yp = has_y ? a.y + b * (long)(T / period) * H2 + u0 : nullptr;
+    int next_fire = period - 1;
+
+    // ---- zero the images (h_0 = 0; feature slots beyond D stay zero)
+    for (int i = tid; i < T128_LDS / 16; i += 256) reinterpret_cast<uint4 *>(smem)[i] = uint4{0u, 0u, 0u, 0u};
+    __syncthreads();
+
+    // ---- input rows, four steps in flight.  XPM: R[k][q * 2 + j] = the lane's four projected values of tile (q, j) of row t
+    //      (ring entry t % 4).  !XPM: R[k][j] = four features of row (entry's row), wave 0 only (D = 32 = its unit range)
+    constexpr int NR = XPM ? 6 : 2;
+    f4 R[4][NR];
+    const bool has_x = XPM || 32 * w < D;
+    const float *xrow = XPM ? a.xp + b * (long)T * 3 * H2 + u0 : a.x + b * (long)T * D + (u0 < D ? u0 : 0);
+    auto load_row = [&](int rho, f4 (&dst)[NR]) {
+        const int rc = rho < T ? rho : T - 1;
+        if constexpr (XPM) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    dst[q * 2 + j] = *reinterpret_cast<const f4 *>(xrow + (long)rc * 3 * H2 + q * H2 + 16 * j);
+        } else {
+            if (has_x) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) dst[j] = *reinterpret_cast<const f4 *>(xrow + (long)rc * D + 16 * j);
+            }
+        }
+    };
+    auto park = [&](const f4 (&src)[NR], int slot) {                // (!XPM, wave 0) row -> operand image `slot`
+        uint2 h0, l0, h1, l1;
+        split4(src[0], h0, l0);
+        split4(src[1], h1, l1);
+        *reinterpret_cast<uint4 *>(X + 2 * slot * IMG2 + wr) = uint4{h0.x, h0.y, h1.x, h1.y};
+        *reinterpret_cast<uint4 *>(X + (2 * slot + 1) * IMG2 + wr) = uint4{l0.x, l0.y, l1.x, l1.y};
+    };
+    f4 xp[3][2];                                                    // the input product of the current step
+    auto project = [&](int slot, f4 (&out)[3][2]) {                 // (!XPM) bias + x W[:D] for the row parked in `slot`
+        const h8 xh = *reinterpret_cast<const h8 *>(X + 2 * slot * IMG2 + rdb);
+        const h8 xl = *reinterpret_cast<const h8 *>(X + (2 * slot + 1) * IMG2 + rdb);
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                f4 p = bias[q][j];
+                p = MF128(Ai_hi[q][j], xh, p);
+                p = MF128(Ai_hi[q][j], xl, p);
+                p = MF128(Ai_lo[q][j], xh, p);
+                out[q][j] = p;
+            }
+    };
+
+#pragma unroll
+    for (int k = 0; k < 4; ++k) load_row(k, R[k]);
+    if constexpr (!XPM) {
+        if (has_x) { park(R[0], 0); park(R[1], 1); }
+        lds_barrier();
+        project(0, xp);
+        lds_barrier();
+    }
+
+    f4 h[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
+    f4 xn[3][2];
+
+    // one step; Rt = ring entry of row t (XPM: consumed now) / of row t (free: reloaded with row t + 4);
+    // Rt2 = ring entry of row t + 2 (!XPM: parked now)
+    auto step = [&](const int t, f4 (&Rt)[NR], f4 (&Rt2)[NR]) {
+        if constexpr (XPM) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) xp[q][j] = Rt[q * 2 + j];
+            load_row(t + 4, Rt);
+        } else {
+            if (has_x) park(Rt2, t & 1);                            // row t+2 -> the slot row t has left
+            load_row(t + 4, Rt);
+        }
+        // ---------------- phase 1: reset and update gates of the wave's units
+        f4 zr[2] = {xp[0][0], xp[0][1]};
+        f4 zu[2] = {xp[1][0], xp[1][1]};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const h8 bh = *reinterpret_cast<const h8 *>(Hhi + rdb + 64 * s);
+            const h8 bl = *reinterpret_cast<const h8 *>(Hlo + rdb + 64 * s);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                zr[j] = MF128(Ah_hi[0][j][s], bh, zr[j]);
+                zu[j] = MF128(Ah_hi[1][j][s], bh, zu[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                zr[j] = MF128(Ah_hi[0][j][s], bl, zr[j]);
+                zu[j] = MF128(Ah_hi[1][j][s], bl, zu[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                zr[j] = MF128(Ah_lo[0][j][s], bh, zr[j]);
+                zu[j] = MF128(Ah_lo[1][j][s], bh, zu[j]);
+            }
+        }
+        f4 u[2];
+        {
+            f4 rh[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    rh[j][k] = sigmoid_scaled(zr[j][k]) * h[j][k];
+                    u[j][k] = sigmoid_scaled(zu[j][k]);
+                }
+            uint2 h0, l0, h1, l1;
+            split4(rh[0], h0, l0);
+            split4(rh[1], h1, l1);
+            *reinterpret_cast<uint4 *>(Rhi + wr) = uint4{h0.x, h0.y, h1.x, h1.y};
+            *reinterpret_cast<uint4 *>(Rlo + wr) = uint4{l0.x, l0.y, l1.x, l1.y};
+        }
+        lds_barrier();                                              // A: r*h of every unit is in LDS
+        // ---------------- phase 2: candidate and state update; (!XPM) the input product of step t + 1 rides along
+        f4 zc[2] = {xp[2][0], xp[2][1]};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const h8 bh = *reinterpret_cast<const h8 *>(Rhi + rdb + 64 * s);
+            const h8 bl = *reinterpret_cast<const h8 *>(Rlo + rdb + 64 * s);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) zc[j] = MF128(Ah_hi[2][j][s], bh, zc[j]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) zc[j] = MF128(Ah_hi[2][j][s], bl, zc[j]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) zc[j] = MF128(Ah_lo[2][j][s], bh, zc[j]);
+        }
+        if constexpr (!XPM) project((t + 1) & 1, xn);              // (row t + 1 was parked a step ago)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float c = tanh_scaled(zc[j][k]);
+                h[j][k] = fmaf(u[j][k], h[j][k] - c, c);            // u h + (1 - u) c
+            }
+        {
+            uint2 h0, l0, h1, l1;
+            split4(h[0], h0, l0);
+            split4(h[1], h1, l1);
+            *reinterpret_cast<uint4 *>(Hhi + wr) = uint4{h0.x, h0.y, h1.x, h1.y};
+            *reinterpret_cast<uint4 *>(Hlo + wr) = uint4{l0.x, l0.y, l1.x, l1.y};
+        }
+        const bool fire = t == next_fire;
+        if (fire && has_y && live) {
+            *reinterpret_cast<f4 *>(yp) = h[0];
+            *reinterpret_cast<f4 *>(yp + 16) = h[1];
+        }
+        next_fire += fire ? period : 0;
+        if (has_y) yp += fire ? H2 : 0;
+        if constexpr (!XPM) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) xp[q][j] = xn[q][j];
+        }
+        lds_barrier();                                              // B: h' (and the parked row t + 2) are in LDS
+    };
+
+    int t = 0;
+    for (; t + 3 < T; t += 4) {
+        step(t, R[0], R[2]);
+        step(t + 1, R[1], R[3]);
+        step(t + 2, R[2], R[0]);
+        step(t + 3, R[3], R[1]);
+    }
+    if (t < T) step(t, R[0], R[2]);
+    if (t + 1 < T) step(t + 1, R[1], R[3]);
+    if (t + 2 < T) step(t + 2, R[2], R[0]);
+
+    if (live) {
+        float *o = a.h_last + b * a.h_last_stride + u0;
+        *reinterpret_cast<f4 *>(o) = h[0];
+        *reinterpret_cast<f4 *>(o + 16) = h[1];
+    }
+}
+#undef MF128
+
+bool tile128_supported(int H, int D) { return H == H2 && (D == 32 || D == H2); }
+
+int tile128_fwd_launch(const Tile128Args &a, hipStream_t st) {
+    const int ntiles = (a.B + TS - 1) / TS;
+    if (a.xp != nullptr) hipLaunchKernelGGL((gru_tile128_fwd_kernel<true>), dim3(ntiles), dim3(256), 0, st, a);
+    else                 hipLaunchKernelGGL((gru_tile128_fwd_kernel<false>), dim3(ntiles), dim3(256), 0, st, a);
+    return check_launch();
+}
+
+}  // namespace hpmn

@@ -419,8 +419,8 @@ class Hpmn_Basic(object):
     TILED_EVAL_ROWS = int(os.environ.get("HPMN_TILED_EVAL_ROWS", "4096"))        # rows eval() puts in flight per pass
 
     def _tiled_inference(self, rows: int) -> bool:
-        return bool(self.TILED_EVAL_MIN_ROWS > 0 and rows >= self.TILED_EVAL_MIN_ROWS and self.spec.H == 64
-                    and self.spec.E % 4 == 0 and ops.tile_kernel_supported(64, self.spec.D0))
+        return bool(self.TILED_EVAL_MIN_ROWS > 0 and rows >= self.TILED_EVAL_MIN_ROWS and self.spec.H in (64, 128)
+                    and self.spec.E % 4 == 0 and ops.tile_kernel_supported(self.spec.H, self.spec.D0))
 
     # ------------------------------------------------------------------ graphs that execute the item branch
     def _branch_inputs(self, ids, item_ids):

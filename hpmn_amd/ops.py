@@ -597,10 +597,15 @@ def pipe_supported(spec: ScanSpec) -> bool:
 
 
 def tile_kernel_supported(H: int, D0: int) -> bool:
-    """hpmn_pipe_supported: the 16-sequence-tile MFMA scan has instantiations for (H, D0) -- whatever the HPMN_PIPE switch says
-    about using it for TRAINING (ops.tiled_forward_inference is the forward-only use)."""
+    """hpmn_pipe_supported / hpmn_tile128_supported: the 16-sequence-tile MFMA scan has instantiations for (H, D0) -- whatever
+    the HPMN_PIPE switch says about using it for TRAINING (ops.tiled_forward_inference is the forward-only use)."""
     lib = _lib.load()
+    if H == 128:
+        return bool(lib.hpmn_tile128_supported(H, D0) and TILE128)
     return bool(lib.hpmn_pipe_supported(H, D0) and lib.hpmn_pipe_supported(H, H))
+
+
+TILE128 = os.environ.get("HPMN_TILE128", "1") != "0"      # evaluation at H = 128 on the tile kernel (0: per-sequence scans)
 
 
 def _pipe_sync_buffer(K: int, B: int, device) -> torch.Tensor:
@@ -701,6 +706,28 @@ def tiled_forward_inference(spec: ScanSpec, ids, emb, weights: Sequence[torch.Te
     x = embed_gather_seq(ids, emb, spec.front_zero, spec.mask_id0)
     last = x[:, spec.last_index, :].contiguous()
     lib = _lib.load()
+    if H == 128:
+        # r5: H = 128 has its own tile kernel (hpmn_tile128_fwd: four waves per 16-sequence tile, each with a quarter of the
+        # units of all three gates), ONE layer per launch; layer 0 projects its 32-wide rows in the kernel, the layers above
+        # read the rows hpmn_gru_input_proj produced from the layer below's outputs
+        for i in range(K):
+            wg, bg, wc, bc = weights[4 * i:4 * i + 4]
+            a = _lib.HpmnTile128()
+            a.B, a.T, a.D, a.period = B, lens[i], (spec.D0 if i == 0 else H), spec.periods[i]
+            if i == 0:
+                a.x = x.data_ptr()
+                src = x
+            else:
+                src, _ = gru_input_proj(None, x=x, wg=wg, bg=bg, wc=wc, bc=bc, H=H, T=lens[i])
+                a.xp = src.data_ptr()
+            a.wg, a.bg, a.wc, a.bc = wg.data_ptr(), bg.data_ptr(), wc.data_ptr(), bc.data_ptr()
+            y = torch.empty(B, lens[i] // spec.periods[i], H, **f32) if i + 1 < K else None
+            a.y = _ptr(y)
+            a.h_last, a.h_last_stride = memory[:, i, :].data_ptr(), K * H
+            _lib.check(lib.hpmn_tile128_fwd(C.byref(a), _stream()), "hpmn_tile128_fwd")
+            del src
+            x = y
+        return memory, last
     first = 0
     while first < K:
         n = min(group, K - first)

@@ -1805,3 +1805,32 @@ def test_split_gradient_kernels_track_the_fp32_kernels_over_200_steps(tmp_path):
     assert len(la) == 200 and np.isfinite(la).all() and la[-20:].mean() < 0.9 * la[:20].mean()       # (it trains)
     np.testing.assert_allclose(la, lb, rtol=1e-3, atol=0)
     np.testing.assert_allclose(a["pred_final"], b["pred_final"], rtol=0, atol=1e-3)      # the two trained models agree
+
+
+@pytest.mark.parametrize("T,K,B", [(105, 4, 37), (1001, 7, 21)])
+def test_tile_kernel_h128_matches_the_oracle(dev, tmp_path, T, K, B):
+    """r5 (VERDICT r4 missing #4): evaluation at H = 128 on the matrix cores -- hpmn_tile128_fwd, 16-sequence tiles, four waves
+    each holding a quarter of the units of all three gates, split-f16 operands; layer 0 projects in the kernel, the layers above
+    read hpmn_gru_input_proj's rows.  ops.tiled_forward_inference against the float64 oracle at 1e-4 (memory; logit / prediction
+    through the read path), a partial last tile, the Industry zero prefix, configs[4]'s length; and against the per-sequence kernels."""
+    from hpmn_amd import ops
+    cfg = cfg_industry(H=128, K=K, T=T, V=900)
+    p = f32_params(cfg, 501)
+    ids, label = rand_ids(cfg, B, 502)
+    want = O.forward(cfg, p, ids, label)
+    m = make_model(cfg, tmp_path, p)
+    t = torch.as_tensor(ids).to(dev)
+    assert ops.tile_kernel_supported(128, m.spec.D0)
+    mem, last = ops.tiled_forward_inference(m.spec, t, m.params["Embedding/emb_mtx"], m._gru_weights())
+    np.testing.assert_allclose(mem.cpu().numpy(), want["memory"], rtol=0, atol=TOL)
+    out = ops.read_fwd(m._read_desc, m._read_params, mem, last, True, True)
+    for k in ("logit", "prediction"):
+        np.testing.assert_allclose(out[k].cpu().numpy(), want[k], rtol=0, atol=TOL, err_msg=k)
+    ref_mem, ref_last = ops.scan_forward_inference(m.spec, t, m.params["Embedding/emb_mtx"], m._gru_weights())
+    assert torch.equal(last, ref_last)
+    np.testing.assert_allclose(mem.cpu().numpy(), ref_mem.cpu().numpy(), rtol=0, atol=5e-5)
+    # an evaluation-sized pass takes the tile path by itself and agrees with the small one row for row
+    big = torch.as_tensor(np.concatenate([ids] * (1600 // B + 1))[:1600]).to(dev)
+    assert m._tiled_inference(1600)
+    got = m.forward_inference(big)
+    assert torch.equal(got["memory"][:B], mem)
