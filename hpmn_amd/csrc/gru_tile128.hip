@@ -99,11 +99,14 @@ __global__ __launch_bounds__(256, 1) void gru_tile128_fwd_kernel(const Tile128Ar
     __syncthreads();
 
     // ---- input rows, four steps in flight.  XPM: R[k][q * 2 + j] = the lane's four projected values of tile (q, j) of row t
-    //      (ring entry t % 4).  !XPM: R[k][j] = four features of row (entry's row), wave 0 only (D = 32 = its unit range)
-    constexpr int NR = XPM ? 6 : 2;
+    //      (ring entry t % 4).  !XPM (D = 32): the 16 x 32 floats of a row are TWO per lane over the workgroup's 256 lanes --
+    //      lane (w, g, n) brings features 8 w + 2 g, + 1 of sequence n and parks them where the operand image wants them
+    //      (the first version had wave 0 load and park the whole row while the other three waited at the barrier)
+    constexpr int NR = XPM ? 6 : 1;
     f4 R[4][NR];
-    const bool has_x = XPM || 32 * w < D;
-    const float *xrow = XPM ? a.xp + b * (long)T * 3 * H2 + u0 : a.x + b * (long)T * D + (u0 < D ? u0 : 0);
+    const int pf = 8 * w + 2 * g;                                   // (!XPM) this lane's feature pair
+    const int park_off = n * ROWB2 + ((pf & 15) >> 2) * 16 + (pf >> 4) * 8 + (pf & 3) * 2;
+    const float *xrow = XPM ? a.xp + b * (long)T * 3 * H2 + u0 : a.x + b * (long)T * D + pf;
     auto load_row = [&](int rho, f4 (&dst)[NR]) {
         const int rc = rho < T ? rho : T - 1;
         if constexpr (XPM) {
@@ -113,18 +116,16 @@ __global__ __launch_bounds__(256, 1) void gru_tile128_fwd_kernel(const Tile128Ar
                 for (int j = 0; j < 2; ++j)
                     dst[q * 2 + j] = *reinterpret_cast<const f4 *>(xrow + (long)rc * 3 * H2 + q * H2 + 16 * j);
         } else {
-            if (has_x) {
-#pragma unroll
-                for (int j = 0; j < 2; ++j) dst[j] = *reinterpret_cast<const f4 *>(xrow + (long)rc * D + 16 * j);
-            }
+            const f2 v = *reinterpret_cast<const f2 *>(xrow + (long)rc * D);
+            dst[0][0] = v.x;
+            dst[0][1] = v.y;
         }
     };
-    auto park = [&](const f4 (&src)[NR], int slot) {                // (!XPM, wave 0) row -> operand image `slot`
-        uint2 h0, l0, h1, l1;
-        split4(src[0], h0, l0);
-        split4(src[1], h1, l1);
-        *reinterpret_cast<uint4 *>(X + 2 * slot * IMG2 + wr) = uint4{h0.x, h0.y, h1.x, h1.y};
-        *reinterpret_cast<uint4 *>(X + (2 * slot + 1) * IMG2 + wr) = uint4{l0.x, l0.y, l1.x, l1.y};
+    auto park = [&](const f4 (&src)[NR], int slot) {                // (!XPM) the lane's two features -> operand image `slot`
+        const _Float16 h0 = (_Float16)src[0][0], h1 = (_Float16)src[0][1];
+        const _Float16 l0 = (_Float16)(src[0][0] - (float)h0), l1 = (_Float16)(src[0][1] - (float)h1);
+        *reinterpret_cast<h2 *>(X + 2 * slot * IMG2 + park_off) = h2{h0, h1};
+        *reinterpret_cast<h2 *>(X + (2 * slot + 1) * IMG2 + park_off) = h2{l0, l1};
     };
     f4 xp[3][2];                                                    // the input product of the current step
     auto project = [&](int slot, f4 (&out)[3][2]) {                 // (!XPM) bias + x W[:D] for the row parked in `slot`
@@ -145,7 +146,8 @@ __global__ __launch_bounds__(256, 1) void gru_tile128_fwd_kernel(const Tile128Ar
 #pragma unroll
     for (int k = 0; k < 4; ++k) load_row(k, R[k]);
     if constexpr (!XPM) {
-        if (has_x) { park(R[0], 0); park(R[1], 1); }
+        park(R[0], 0);
+        park(R[1], 1);
         lds_barrier();
         project(0, xp);
         lds_barrier();
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(256, 1) void gru_tile128_fwd_kernel(const Tile128Ar
                 for (int j = 0; j < 2; ++j) xp[q][j] = Rt[q * 2 + j];
             load_row(t + 4, Rt);
         } else {
-            if (has_x) park(Rt2, t & 1);                            // row t+2 -> the slot row t has left
+            park(Rt2, t & 1);                                       // row t+2 -> the slot row t has left
             load_row(t + 4, Rt);
         }
         // ---------------- phase 1: reset and update gates of the wave's units
