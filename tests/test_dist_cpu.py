@@ -302,3 +302,81 @@ def test_single_process_exchange_is_the_identity():
     dist.sum_rows_into_(dst, ids_all, g_all, [3])
     np.testing.assert_array_equal(dst[rows].numpy(), g.numpy())
     assert float(dst.sum()) == float(g.sum())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# r5: the rows exchange as the data-parallel step issues it (hpmn_amd/hpmn.py:_train_step_rows) -- the plan's row buffer of
+# the batch geometry's capacity and a [total, c_0 .. c_{C-1}] count vector gathered as they are (dist.all_gather_fixed, the
+# counts on their way to the host: dist.HostCopy), the windows of every chunk (dist.rows_windows), slices of the compact
+# gradient rows as long as the LARGEST rank's chunk (what lies behind a rank's own entries is garbage and must never be
+# read), and the consumer's contract: per distinct row the ranks' rows added in rank order.  The consumer here is a torch
+# emulation of hpmn_rows_sum_adam's summation (the kernel needs a GPU: tests/test_gpu_rows_adam.py holds it to this).
+def _r5_worker(rank, world, port, q, C):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        V, E, cap = 211, 4, 64
+        rng = np.random.default_rng(100 + rank)
+        n = [17, 0, 40, 9][rank % 4]                                       # ragged; one rank with nothing to send
+        rows = np.sort(rng.choice(V, size=n, replace=False)).astype(np.int32)
+        grads = rng.standard_normal((n, E)).astype(np.float32)
+        bounds = [(V * k) // C for k in range(C + 1)]
+        pos = np.searchsorted(rows, bounds)
+        cnt = torch.as_tensor(np.concatenate([[n], pos[1:] - pos[:-1]]).astype(np.int32))
+        rows_buf = torch.full((cap,), 2 ** 31 - 1, dtype=torch.int32)       # the plan's buffer: tail is never read
+        rows_buf[:n] = torch.as_tensor(rows)
+        out_rows = torch.full((n + cap, E), float("nan"))                   # garbage behind the rank's own entries
+        out_rows[:n] = torch.as_tensor(grads)
+        ids_all = dist.all_gather_fixed(rows_buf)
+        cnt_all = dist.all_gather_fixed(cnt)
+        lens, windows = dist.rows_windows(dist.HostCopy(cnt_all).result())
+        assert lens[rank] == n and len(windows) == C and ids_all.shape == (world, cap)
+        dense = torch.zeros(V, E)
+        for first, nn, capc in windows:
+            if capc == 0:
+                continue
+            a = first[rank]
+            g_all, work = dist.all_gather_fixed(out_rows[a:a + capc], async_op=True)
+            if work is not None:
+                work.wait()
+            for r in range(world):                                          # rank order, one rank at a time
+                idx = ids_all[r, first[r]:first[r] + nn[r]].long()
+                dense.index_add_(0, idx, g_all[r, :nn[r]])
+        assert bool(torch.isfinite(dense).all())
+        mine = torch.zeros(V, E)
+        mine[torch.as_tensor(rows).long()] = torch.as_tensor(grads)
+        want = mine.clone()
+        td.all_reduce(want)                                                 # the dense exchange it replaces
+        recv = dist.rows_exchange_bytes_windows(windows, E, False, world, cap)
+        q.put((rank, dense.numpy(), want.numpy(), recv))
+    finally:
+        td.destroy_process_group()
+
+
+def _run_r5(world, C):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_r5_worker, args=(r, world, port, q, C)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda x: x[0])
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    for rank, dense, want, recv in res:
+        np.testing.assert_array_equal(dense, res[0][1])                     # every replica: the same bits
+        np.testing.assert_allclose(dense, want, rtol=0, atol=1e-6)          # == the dense all-reduce up to the order of addends
+        assert recv == res[0][3] and recv > 0
+
+
+def test_r5_rows_exchange_from_plan_buffers_two_ranks():
+    _run_r5(2, 1)
+
+
+def test_r5_rows_exchange_from_plan_buffers_four_ranks_chunked():
+    _run_r5(4, 3)
