@@ -17,9 +17,12 @@
 // The input product x_t W[:D]:
 //   * layer 0 (D = 32, one k-step): in the kernel, off the chain (wave 0 parks row t+2 as an operand image while every wave
 //     projects row t+1): 18 MFMAs per wave and step, 48 registers of input weights;
-//   * layers >= 1 (D = 128): the input weights would be another 192 registers per wave (or 192 KB of LDS: neither exists), so
-//     the caller runs hpmn_gru_input_proj first and this kernel reads the PROJECTED rows xp [B, T, 3H] (already in the
-//     scan's exponent domain, bias included), six 16-byte loads per lane and step, four steps ahead.
+//   * layers >= 1 (D = 128): the input weights are another 192 KB of operands (hi + lo): 192 registers per wave, or 192 KB of
+//     LDS -- neither exists.  SPLIT BETWEEN THE TWO they fit: the hi halves (96 KB) live in LDS, laid out so that a wave's
+//     fragment read is one linear ds_read_b128 per lane, the lo halves (96 registers per wave) in registers; of the three
+//     products of a tile, W_hi x_hi and W_hi x_lo take their A operand from LDS, W_lo x_hi from registers (mode 2).
+//     The first version (mode 1, kept: `xp` given) read rows hpmn_gru_input_proj had PROJECTED -- xp [B, T, 3H], 3.5 KB of
+//     HBM traffic per row-step for write + read-back against 0.5 KB for the rows themselves: 37 % of an evaluation pass.
 #include "pipe_common.h"
 
 namespace hpmn {
@@ -28,6 +31,7 @@ constexpr int H2 = 128;
 constexpr int ROWB2 = 288;                 // bytes per sequence row of an operand image: 256 (128 f16) + 32 pad
 constexpr int IMG2 = TS * ROWB2;
 constexpr int T128_LDS = 8 * IMG2;         // h hi/lo, r*h hi/lo, x ring 2 x hi/lo
+constexpr int T128_WLDS = 4 * 3 * 2 * 4 * 64 * 16;   // (mode 2) hi halves of the input weights: [wave][gate][half][k-step][lane] x 16 B
 
 struct Tile128Args {
     int B, T, D, period;
@@ -41,9 +45,15 @@ struct Tile128Args {
 
 #define MF128(A, Bv, C) __builtin_amdgcn_mfma_f32_16x16x32_f16(A, Bv, C, 0, 0, 0)
 
-template <bool XPM>
+// MODE 0: x rows with D = 32, projected in the kernel (weights in registers); 1: projected rows xp; 2: x rows with D = 128,
+// projected in the kernel (hi halves of the input weights in LDS, lo halves in registers)
+template <int MODE>
 __global__ __launch_bounds__(256, 1) void gru_tile128_fwd_kernel(const Tile128Args a) {
-    __shared__ __attribute__((aligned(16))) char smem[T128_LDS];
+    constexpr bool XPM = MODE == 1;
+    constexpr bool P128 = MODE == 2;
+    constexpr int NKS = P128 ? 4 : 1;                               // k-steps of the input product
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *Wlds = smem + T128_LDS + (threadIdx.x >> 6) * (T128_WLDS / 4);     // (mode 2) this wave's fragments
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, g = lane >> 4, n = lane & 15;
     const int tile = blockIdx.x;
     const int B = a.B, T = a.T, D = a.D;
@@ -56,7 +66,7 @@ __global__ __launch_bounds__(256, 1) void gru_tile128_fwd_kernel(const Tile128Ar
 
     // ---- stationary A operands: recurrent rows of the wave's six tiles (gate q, half j), the exp2 scale folded in
     h8 Ah_hi[3][2][4], Ah_lo[3][2][4];
-    h8 Ai_hi[3][2], Ai_lo[3][2];
+    h8 Ai_hi[3][2], Ai_lo[3][2][NKS];                               // (Ai_hi: mode 0 only -- mode 2 keeps the hi halves in LDS)
     f4 bias[3][2];
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
@@ -75,14 +85,20 @@ __global__ __launch_bounds__(256, 1) void gru_tile128_fwd_kernel(const Tile128Ar
                 split8(vh, Ah_hi[q][j][s], Ah_lo[q][j][s]);
             }
             if constexpr (!XPM) {
-                float vi[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int unit = slot_unit(0, g, e);            // (D = 32: units 0..31 are k-step 0)
-                    const float wi = W[(long)(unit < D ? unit : 0) * ld + col] * sc;
-                    vi[e] = unit < D ? wi : 0.f;
+                for (int s = 0; s < NKS; ++s) {
+                    float vi[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int unit = slot_unit(s, g, e);        // (D = 32: units 0..31 are k-step 0)
+                        const float wi = W[(long)(unit < D ? unit : 0) * ld + col] * sc;
+                        vi[e] = unit < D ? wi : 0.f;
+                    }
+                    h8 hi;
+                    split8(vi, hi, Ai_lo[q][j][s]);
+                    if constexpr (P128) *reinterpret_cast<h8 *>(Wlds + ((((q * 2 + j) * 4 + s) * 64) + lane) * 16) = hi;
+                    else Ai_hi[q][j] = hi;
                 }
-                split8(vi, Ai_hi[q][j], Ai_lo[q][j]);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) bias[q][j][k] = bp[u0 + 16 * j + k] * sc;
             }
@@ -102,11 +118,12 @@ __global__ __launch_bounds__(256, 1) void gru_tile128_fwd_kernel(const Tile128Ar
     //      (ring entry t % 4).  !XPM (D = 32): the 16 x 32 floats of a row are TWO per lane over the workgroup's 256 lanes --
     //      lane (w, g, n) brings features 8 w + 2 g, + 1 of sequence n and parks them where the operand image wants them
     //      (the first version had wave 0 load and park the whole row while the other three waited at the barrier)
-    constexpr int NR = XPM ? 6 : 1;
+    //      !XPM (D = 128, mode 2): eight per lane, in the lane's own unit positions: R[k][j] = features u0 + 16 j + 0..3
+    constexpr int NR = XPM ? 6 : (P128 ? 2 : 1);
     f4 R[4][NR];
     const int pf = 8 * w + 2 * g;                                   // (!XPM) this lane's feature pair
     const int park_off = n * ROWB2 + ((pf & 15) >> 2) * 16 + (pf >> 4) * 8 + (pf & 3) * 2;
-    const float *xrow = XPM ? a.xp + b * (long)T * 3 * H2 + u0 : a.x + b * (long)T * D + pf;
+    const float *xrow = XPM ? a.xp + b * (long)T * 3 * H2 + u0 : a.x + b * (long)T * D + (P128 ? u0 : pf);
     auto load_row = [&](int rho, f4 (&dst)[NR]) {
         const int rc = rho < T ? rho : T - 1;
         if constexpr (XPM) {
@@ -115,13 +132,24 @@ __global__ __launch_bounds__(256, 1) void gru_tile128_fwd_kernel(const Tile128Ar
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     dst[q * 2 + j] = *reinterpret_cast<const f4 *>(xrow + (long)rc * 3 * H2 + q * H2 + 16 * j);
+        } else if constexpr (P128) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) dst[j] = *reinterpret_cast<const f4 *>(xrow + (long)rc * D + 16 * j);
         } else {
             const f2 v = *reinterpret_cast<const f2 *>(xrow + (long)rc * D);
             dst[0][0] = v.x;
             dst[0][1] = v.y;
         }
     };
-    auto park = [&](const f4 (&src)[NR], int slot) {                // (!XPM) the lane's two features -> operand image `slot`
+    auto park = [&](const f4 (&src)[NR], int slot) {                // (!XPM) the lane's features -> operand image `slot`
+        if constexpr (P128) {
+            uint2 h0, l0, h1, l1;
+            split4(src[0], h0, l0);
+            split4(src[NR - 1], h1, l1);
+            *reinterpret_cast<uint4 *>(X + 2 * slot * IMG2 + wr) = uint4{h0.x, h0.y, h1.x, h1.y};
+            *reinterpret_cast<uint4 *>(X + (2 * slot + 1) * IMG2 + wr) = uint4{l0.x, l0.y, l1.x, l1.y};
+            return;
+        }
         const _Float16 h0 = (_Float16)src[0][0], h1 = (_Float16)src[0][1];
         const _Float16 l0 = (_Float16)(src[0][0] - (float)h0), l1 = (_Float16)(src[0][1] - (float)h1);
         *reinterpret_cast<h2 *>(X + 2 * slot * IMG2 + park_off) = h2{h0, h1};
@@ -129,18 +157,28 @@ __global__ __launch_bounds__(256, 1) void gru_tile128_fwd_kernel(const Tile128Ar
     };
     f4 xp[3][2];                                                    // the input product of the current step
     auto project = [&](int slot, f4 (&out)[3][2]) {                 // (!XPM) bias + x W[:D] for the row parked in `slot`
-        const h8 xh = *reinterpret_cast<const h8 *>(X + 2 * slot * IMG2 + rdb);
-        const h8 xl = *reinterpret_cast<const h8 *>(X + (2 * slot + 1) * IMG2 + rdb);
 #pragma unroll
         for (int q = 0; q < 3; ++q)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                f4 p = bias[q][j];
-                p = MF128(Ai_hi[q][j], xh, p);
-                p = MF128(Ai_hi[q][j], xl, p);
-                p = MF128(Ai_lo[q][j], xh, p);
-                out[q][j] = p;
-            }
+            for (int j = 0; j < 2; ++j) out[q][j] = bias[q][j];
+#pragma unroll
+        for (int s = 0; s < NKS; ++s) {
+            const h8 xh = *reinterpret_cast<const h8 *>(X + 2 * slot * IMG2 + rdb + 64 * s);
+            const h8 xl = *reinterpret_cast<const h8 *>(X + (2 * slot + 1) * IMG2 + rdb + 64 * s);
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    h8 ahi;
+                    if constexpr (P128) ahi = *reinterpret_cast<const h8 *>(Wlds + ((((q * 2 + j) * 4 + s) * 64) + lane) * 16);
+                    else ahi = Ai_hi[q][j];
+                    f4 p = out[q][j];
+                    p = MF128(ahi, xh, p);
+                    p = MF128(ahi, xl, p);
+                    p = MF128(Ai_lo[q][j][s], xh, p);
+                    out[q][j] = p;
+                }
+        }
     };
 
 #pragma unroll
@@ -154,7 +192,6 @@ __global__ __launch_bounds__(256, 1) void gru_tile128_fwd_kernel(const Tile128Ar
     }
 
     f4 h[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
-    f4 xn[3][2];
 
     // one step; Rt = ring entry of row t (XPM: consumed now) / of row t (free: reloaded with row t + 4);
     // Rt2 = ring entry of row t + 2 (!XPM: parked now)
@@ -222,7 +259,9 @@ __global__ __launch_bounds__(256, 1) void gru_tile128_fwd_kernel(const Tile128Ar
 #pragma unroll
             for (int j = 0; j < 2; ++j) zc[j] = MF128(Ah_lo[2][j][s], bh, zc[j]);
         }
-        if constexpr (!XPM) project((t + 1) & 1, xn);              // (row t + 1 was parked a step ago)
+        // (xp is dead here: its values have become the accumulators zr, zu, zc -- the next step's input product goes straight
+        //  into it; row t + 1 was parked a step ago)
+        if constexpr (!XPM) project((t + 1) & 1, xp);
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -244,12 +283,6 @@ __global__ __launch_bounds__(256, 1) void gru_tile128_fwd_kernel(const Tile128Ar
         }
         next_fire += fire ? period : 0;
         if (has_y) yp += fire ? H2 : 0;
-        if constexpr (!XPM) {
-#pragma unroll
-            for (int q = 0; q < 3; ++q)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) xp[q][j] = xn[q][j];
-        }
         lds_barrier();                                              // B: h' (and the parked row t + 2) are in LDS
     };
 
@@ -276,8 +309,15 @@ bool tile128_supported(int H, int D) { return H == H2 && (D == 32 || D == H2); }
 
 int tile128_fwd_launch(const Tile128Args &a, hipStream_t st) {
     const int ntiles = (a.B + TS - 1) / TS;
-    if (a.xp != nullptr) hipLaunchKernelGGL((gru_tile128_fwd_kernel<true>), dim3(ntiles), dim3(256), 0, st, a);
-    else                 hipLaunchKernelGGL((gru_tile128_fwd_kernel<false>), dim3(ntiles), dim3(256), 0, st, a);
+    static bool attr_set = false;
+    if (!attr_set) {     // dynamic LDS above 64 KiB has to be allowed per function
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gru_tile128_fwd_kernel<2>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, T128_LDS + T128_WLDS);
+        attr_set = true;
+    }
+    if (a.xp != nullptr) hipLaunchKernelGGL((gru_tile128_fwd_kernel<1>), dim3(ntiles), dim3(256), T128_LDS, st, a);
+    else if (a.D == H2)  hipLaunchKernelGGL((gru_tile128_fwd_kernel<2>), dim3(ntiles), dim3(256), T128_LDS + T128_WLDS, st, a);
+    else                 hipLaunchKernelGGL((gru_tile128_fwd_kernel<0>), dim3(ntiles), dim3(256), T128_LDS, st, a);
     return check_launch();
 }
 

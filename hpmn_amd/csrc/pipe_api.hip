@@ -121,7 +121,7 @@ int hpmn_tile128_fwd(const HpmnTile128 *p, void *stream) {
     if (!tile128_supported(128, p->D)) return HPMN_EUNSUPPORTED;
     if (p->B == 0) return HPMN_OK;
     if ((p->x == nullptr) == (p->xp == nullptr)) return HPMN_EINVAL;          // exactly one of the two
-    if (p->x != nullptr && p->D != 32) return HPMN_EUNSUPPORTED;               // (in-kernel projection: one k-step)
+    if (p->x != nullptr && p->D != 32 && p->D != 128) return HPMN_EUNSUPPORTED;
     if (!p->wg || !p->wc || !p->h_last || (p->x && (!p->bg || !p->bc))) return HPMN_EINVAL;
     if (p->y && p->T % p->period != 0) return HPMN_EINVAL;
     Tile128Args a;

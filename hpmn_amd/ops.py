@@ -606,6 +606,7 @@ def tile_kernel_supported(H: int, D0: int) -> bool:
 
 
 TILE128 = os.environ.get("HPMN_TILE128", "1") != "0"      # evaluation at H = 128 on the tile kernel (0: per-sequence scans)
+TILE128_XP = os.environ.get("HPMN_TILE128_XP", "0") == "1"   # its upper layers on rows projected by hpmn_gru_input_proj (first version)
 
 
 def _pipe_sync_buffer(K: int, B: int, device) -> torch.Tensor:
@@ -714,7 +715,9 @@ def tiled_forward_inference(spec: ScanSpec, ids, emb, weights: Sequence[torch.Te
             wg, bg, wc, bc = weights[4 * i:4 * i + 4]
             a = _lib.HpmnTile128()
             a.B, a.T, a.D, a.period = B, lens[i], (spec.D0 if i == 0 else H), spec.periods[i]
-            if i == 0:
+            if i == 0 or not TILE128_XP:
+                # (layers >= 1, r5 second version: the 128-wide rows projected in the kernel too -- hi halves of the input weights
+                #  in LDS, lo halves in registers -- instead of 3.5 KB per row-step of projected rows through HBM)
                 a.x = x.data_ptr()
                 src = x
             else:

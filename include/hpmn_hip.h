@@ -684,8 +684,8 @@ int hpmn_table_mark_ranks(const void *ids, int64_t ids_stride, int32_t world, co
 
 /* Evaluation at H = 128 on the matrix cores (ABI v12; csrc/gru_tile128.hip): ONE layer of build_memory, forward only, 16-sequence
  * tiles, split-f16 operands (three products, fp32 accumulate) -- tf.nn.dynamic_rnn(GRUCell(128)) + the every-period-th output of
- * code/hpmn.py:118-128.  Either x [B, T, 32] (layer 0: the gathered rows, projected in the kernel) or xp [B, T, 384] (layers >= 1:
- * the rows hpmn_gru_input_proj produced) is given, the other is NULL.  y [B, T / period, 128] may be NULL (top layer);
+ * code/hpmn.py:118-128.  Either x [B, T, D] (D = 32: layer 0's gathered rows; D = 128: the outputs of the layer below; projected in
+ * the kernel) or xp [B, T, 384] (rows hpmn_gru_input_proj produced) is given, the other is NULL.  y [B, T / period, 128] may be NULL (top layer);
  * h_last[b * h_last_stride + 0..127] receives the final state (= memory[:, i, :]). */
 typedef struct HpmnTile128 {
     int32_t B, T, D, period;

@@ -1809,13 +1809,17 @@ def test_split_gradient_kernels_track_the_fp32_kernels_over_200_steps(tmp_path):
     np.testing.assert_allclose(a["pred_final"], b["pred_final"], rtol=0, atol=1e-3)      # the two trained models agree
 
 
+@pytest.mark.parametrize("xp_rows", [False, True])
 @pytest.mark.parametrize("T,K,B", [(105, 4, 37), (1001, 7, 21)])
-def test_tile_kernel_h128_matches_the_oracle(dev, tmp_path, T, K, B):
+def test_tile_kernel_h128_matches_the_oracle(dev, tmp_path, monkeypatch, T, K, B, xp_rows):
     """r5 (VERDICT r4 missing #4): evaluation at H = 128 on the matrix cores -- hpmn_tile128_fwd, 16-sequence tiles, four waves
     each holding a quarter of the units of all three gates, split-f16 operands; layer 0 projects in the kernel, the layers above
     read hpmn_gru_input_proj's rows.  ops.tiled_forward_inference against the float64 oracle at 1e-4 (memory; logit / prediction
     through the read path), a partial last tile, the Industry zero prefix, configs[4]'s length; and against the per-sequence kernels."""
     from hpmn_amd import ops
+    # (xp_rows: the upper layers on rows hpmn_gru_input_proj projected -- the kernel's mode 1; default: projected in the kernel,
+    #  mode 2 -- layer 0 is mode 0 in both)
+    monkeypatch.setattr(ops, "TILE128_XP", xp_rows)
     cfg = cfg_industry(H=128, K=K, T=T, V=900)
     p = f32_params(cfg, 501)
     ids, label = rand_ids(cfg, B, 502)
