@@ -181,9 +181,9 @@ class HpmnRowsAdam(C.Structure):
                 ("bucket_shift", C.c_int32), ("pad_", C.c_int32)]
 
 
-class HpmnTile128(C.Structure):
-    _fields_ = [("B", C.c_int32), ("T", C.c_int32), ("D", C.c_int32), ("period", C.c_int32),
-                ("x", C.c_void_p), ("xp", C.c_void_p), ("wg", C.c_void_p), ("bg", C.c_void_p), ("wc", C.c_void_p),
+class HpmnTileFwd(C.Structure):
+    _fields_ = [("B", C.c_int32), ("T", C.c_int32), ("D", C.c_int32), ("H", C.c_int32), ("period", C.c_int32),
+                ("pad_", C.c_int32), ("x", C.c_void_p), ("xp", C.c_void_p), ("wg", C.c_void_p), ("bg", C.c_void_p), ("wc", C.c_void_p),
                 ("bc", C.c_void_p), ("y", C.c_void_p), ("h_last", C.c_void_p), ("h_last_stride", C.c_int64)]
 
 
@@ -248,8 +248,8 @@ SIGNATURES = {
     "hpmn_scatter_plan_build": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int32,
                                           C.c_void_p, C.c_void_p]),
-    "hpmn_tile128_supported": (C.c_int, [C.c_int32, C.c_int32]),
-    "hpmn_tile128_fwd": (C.c_int, [C.POINTER(HpmnTile128), C.c_void_p]),
+    "hpmn_tile_supported": (C.c_int, [C.c_int32, C.c_int32]),
+    "hpmn_tile_fwd": (C.c_int, [C.POINTER(HpmnTileFwd), C.c_void_p]),
     "hpmn_rows_sum_adam": (C.c_int, [C.POINTER(HpmnRowsAdam), C.c_void_p]),
     "hpmn_table_mark_ranks": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p,
                                         C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),

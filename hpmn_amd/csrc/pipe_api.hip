@@ -21,6 +21,8 @@ struct Tile128Args {
 };
 bool tile128_supported(int H, int D);
 int tile128_fwd_launch(const Tile128Args &a, hipStream_t st);
+bool tile64_supported(int H, int D);
+int tile64_fwd_launch(const Tile128Args &a, hipStream_t st);
 
 static constexpr size_t DUMP_BYTES = 16384;   // 256 lanes x 16 B, plus the +2H float offsets of the gate stores
 
@@ -113,22 +115,22 @@ int hpmn_pipe_bwd(const HpmnPipe *p, void *stream) {
     return pipe_bwd_launch(a, device_cus(), (hipStream_t)stream);
 }
 
-int hpmn_tile128_supported(int32_t H, int32_t D) { return tile128_supported(H, D) ? 1 : 0; }
+int hpmn_tile_supported(int32_t H, int32_t D) { return (tile128_supported(H, D) || tile64_supported(H, D)) ? 1 : 0; }
 
-int hpmn_tile128_fwd(const HpmnTile128 *p, void *stream) {
+int hpmn_tile_fwd(const HpmnTileFwd *p, void *stream) {
     (void)hipGetLastError();
-    if (!p || p->B < 0 || p->T < 1 || p->period < 1 || p->D < 1) return HPMN_EINVAL;
-    if (!tile128_supported(128, p->D)) return HPMN_EUNSUPPORTED;
+    if (!p || p->B < 0 || p->T < 1 || p->period < 1 || p->D < 1 || p->H < 1) return HPMN_EINVAL;
+    if (!tile128_supported(p->H, p->D) && !tile64_supported(p->H, p->D)) return HPMN_EUNSUPPORTED;
     if (p->B == 0) return HPMN_OK;
     if ((p->x == nullptr) == (p->xp == nullptr)) return HPMN_EINVAL;          // exactly one of the two
-    if (p->x != nullptr && p->D != 32 && p->D != 128) return HPMN_EUNSUPPORTED;
+    if (p->H == 64 && p->xp != nullptr) return HPMN_EUNSUPPORTED;              // (H = 64 always projects in the kernel)
     if (!p->wg || !p->wc || !p->h_last || (p->x && (!p->bg || !p->bc))) return HPMN_EINVAL;
     if (p->y && p->T % p->period != 0) return HPMN_EINVAL;
     Tile128Args a;
     a.B = p->B; a.T = p->T; a.D = p->D; a.period = p->period;
     a.x = p->x; a.xp = p->xp; a.wg = p->wg; a.bg = p->bg; a.wc = p->wc; a.bc = p->bc;
     a.y = p->y; a.h_last = p->h_last; a.h_last_stride = (long)p->h_last_stride;
-    return tile128_fwd_launch(a, (hipStream_t)stream);
+    return p->H == 64 ? tile64_fwd_launch(a, (hipStream_t)stream) : tile128_fwd_launch(a, (hipStream_t)stream);
 }
 
 int hpmn_embed_gather_seq(const void *ids, const float *emb, float *out, int32_t B, int32_t Tids, int32_t F,

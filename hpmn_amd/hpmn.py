@@ -1312,7 +1312,10 @@ class Hpmn_Basic(object):
             # batches of the per-batch memory_loss SUMS (code/hpmn.py:360-369, :512-519) = the sum over all rows divided by the
             # number of reference batches, whatever the grouping -- so only the float32 summation order differs.
             n_ref = -(-ds.n // batchsize)
-            per_pass = batchsize * max(1, self.TILED_EVAL_ROWS // batchsize)   # (<= 4096 rows = 256 tiles: one round of CUs)
+            # (<= 4096 rows = 256 tiles: one round of CUs on the kernels that hold a CU per tile; H = 64: the four-wave kernel
+            #  takes two tiles per CU -- 8192 rows per pass, r5)
+            rows_per_pass = self.TILED_EVAL_ROWS * (2 if (self.spec.H == 64 and ops.TILE64 and self.TILED_EVAL_ROWS == 4096) else 1)
+            per_pass = batchsize * max(1, rows_per_pass // batchsize)
             total = torch.zeros(1, device=self.device)
             for lo in range(0, ds.n, per_pass):
                 out = self.forward_inference(ds.ids[lo:lo + per_pass], want_logit=False, want_att=False)

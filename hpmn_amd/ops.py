@@ -597,15 +597,26 @@ def pipe_supported(spec: ScanSpec) -> bool:
 
 
 def tile_kernel_supported(H: int, D0: int) -> bool:
-    """hpmn_pipe_supported / hpmn_tile128_supported: the 16-sequence-tile MFMA scan has instantiations for (H, D0) -- whatever
+    """hpmn_pipe_supported / hpmn_tile_supported: the 16-sequence-tile MFMA scan has instantiations for (H, D0) -- whatever
     the HPMN_PIPE switch says about using it for TRAINING (ops.tiled_forward_inference is the forward-only use)."""
     lib = _lib.load()
     if H == 128:
-        return bool(lib.hpmn_tile128_supported(H, D0) and TILE128)
+        return bool(lib.hpmn_tile_supported(H, D0) and TILE128)
     return bool(lib.hpmn_pipe_supported(H, D0) and lib.hpmn_pipe_supported(H, H))
 
 
 TILE128 = os.environ.get("HPMN_TILE128", "1") != "0"      # evaluation at H = 128 on the tile kernel (0: per-sequence scans)
+_cus = {}
+
+
+def _cu_count(dev) -> int:
+    k = str(dev)
+    if k not in _cus:
+        _cus[k] = int(torch.cuda.get_device_properties(dev).multi_processor_count)
+    return _cus[k]
+
+
+TILE64 = os.environ.get("HPMN_TILE64", "1") != "0"        # evaluation at H = 64 on the four-wave tile kernel (0: gru_pipe_fwd_kernel)
 TILE128_XP = os.environ.get("HPMN_TILE128_XP", "0") == "1"   # its upper layers on rows projected by hpmn_gru_input_proj (first version)
 
 
@@ -707,15 +718,18 @@ def tiled_forward_inference(spec: ScanSpec, ids, emb, weights: Sequence[torch.Te
     x = embed_gather_seq(ids, emb, spec.front_zero, spec.mask_id0)
     last = x[:, spec.last_index, :].contiguous()
     lib = _lib.load()
-    if H == 128:
-        # r5: H = 128 has its own tile kernel (hpmn_tile128_fwd: four waves per 16-sequence tile, each with a quarter of the
-        # units of all three gates), ONE layer per launch; layer 0 projects its 32-wide rows in the kernel, the layers above
-        # read the rows hpmn_gru_input_proj produced from the layer below's outputs
+    # (H = 64: the four-wave kernel pays from two tiles per CU -- C3 shape, build_memory: 2.2 M sequences/s at 8 192 rows against
+    #  1.6 M on the twelve-wave kernel, but 1.48 M against 1.57 M at 4 096, where every CU holds one tile and nothing interleaves)
+    many_tiles = (B + 15) // 16 > _cu_count(dev)
+    if H == 128 or (H == 64 and TILE64 and many_tiles and lib.hpmn_tile_supported(64, spec.D0)):
+        # r5: hpmn_tile_fwd -- four waves per 16-sequence tile, each with a quarter of the units of ALL THREE gates (r, u and the
+        # state stay in its registers), ONE layer per launch, the rows projected in the kernel.  H = 128 (gru_tile128.hip) and,
+        # second generation of the H = 64 evaluation kernel, gru_tile64.hip (two or three tiles share a CU)
         for i in range(K):
             wg, bg, wc, bc = weights[4 * i:4 * i + 4]
-            a = _lib.HpmnTile128()
-            a.B, a.T, a.D, a.period = B, lens[i], (spec.D0 if i == 0 else H), spec.periods[i]
-            if i == 0 or not TILE128_XP:
+            a = _lib.HpmnTileFwd()
+            a.B, a.T, a.D, a.H, a.period = B, lens[i], (spec.D0 if i == 0 else H), H, spec.periods[i]
+            if i == 0 or not TILE128_XP or H == 64:
                 # (layers >= 1, r5 second version: the 128-wide rows projected in the kernel too -- hi halves of the input weights
                 #  in LDS, lo halves in registers -- instead of 3.5 KB per row-step of projected rows through HBM)
                 a.x = x.data_ptr()
@@ -727,7 +741,7 @@ def tiled_forward_inference(spec: ScanSpec, ids, emb, weights: Sequence[torch.Te
             y = torch.empty(B, lens[i] // spec.periods[i], H, **f32) if i + 1 < K else None
             a.y = _ptr(y)
             a.h_last, a.h_last_stride = memory[:, i, :].data_ptr(), K * H
-            _lib.check(lib.hpmn_tile128_fwd(C.byref(a), _stream()), "hpmn_tile128_fwd")
+            _lib.check(lib.hpmn_tile_fwd(C.byref(a), _stream()), "hpmn_tile_fwd")
             del src
             x = y
         return memory, last

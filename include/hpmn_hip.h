@@ -682,21 +682,23 @@ int hpmn_table_mark_ranks(const void *ids, int64_t ids_stride, int32_t world, co
                           int64_t cap, uint8_t *flags, int64_t V, int32_t id_flags, int32_t *bucket_start, int64_t bucket_stride,
                           int32_t bucket_shift, void *stream);
 
-/* Evaluation at H = 128 on the matrix cores (ABI v12; csrc/gru_tile128.hip): ONE layer of build_memory, forward only, 16-sequence
- * tiles, split-f16 operands (three products, fp32 accumulate) -- tf.nn.dynamic_rnn(GRUCell(128)) + the every-period-th output of
- * code/hpmn.py:118-128.  Either x [B, T, D] (D = 32: layer 0's gathered rows; D = 128: the outputs of the layer below; projected in
- * the kernel) or xp [B, T, 384] (rows hpmn_gru_input_proj produced) is given, the other is NULL.  y [B, T / period, 128] may be NULL (top layer);
- * h_last[b * h_last_stride + 0..127] receives the final state (= memory[:, i, :]). */
-typedef struct HpmnTile128 {
-    int32_t B, T, D, period;
+/* Evaluation on the matrix cores, one layer per launch (ABI v12; csrc/gru_tile64.hip, gru_tile128.hip): ONE layer of build_memory,
+ * forward only, 16-sequence tiles, split-f16 operands (three products, fp32 accumulate) -- tf.nn.dynamic_rnn(GRUCell(H)) + the
+ * every-period-th output of code/hpmn.py:118-128.  H = 64: x [B, T, D], D in {16, 32, 48, 64}.  H = 128: either x [B, T, D]
+ * (D = 32: layer 0's gathered rows; D = 128: the outputs of the layer below; projected in the kernel) or xp [B, T, 384] (rows
+ * hpmn_gru_input_proj produced) is given, the other is NULL.  y [B, T / period, H] may be NULL (top layer);
+ * h_last[b * h_last_stride + 0..H-1] receives the final state (= memory[:, i, :]). */
+typedef struct HpmnTileFwd {
+    int32_t B, T, D, H;
+    int32_t period, pad_;
     const float *x, *xp;
     const float *wg, *bg, *wc, *bc;
     float *y;
     float *h_last;
     int64_t h_last_stride;
-} HpmnTile128;
-int hpmn_tile128_supported(int32_t H, int32_t D);
-int hpmn_tile128_fwd(const HpmnTile128 *args, void *stream);
+} HpmnTileFwd;
+int hpmn_tile_supported(int32_t H, int32_t D);
+int hpmn_tile_fwd(const HpmnTileFwd *args, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Online incremental memory update -- the serving-time form of build_memory: ONE new event per

@@ -43,7 +43,7 @@ def test_struct_layout_matches_c_compiler(tmp_path):
                "HpmnScanDesc": _lib.HpmnScanDesc, "HpmnOnlineUpdate": _lib.HpmnOnlineUpdate,
                "HpmnGruFusedFwd": _lib.HpmnGruFusedFwd, "HpmnGruPairFwd": _lib.HpmnGruPairFwd, "HpmnGruPairBwd": _lib.HpmnGruPairBwd, "HpmnPipe": _lib.HpmnPipe,
                "HpmnTrainLayout": _lib.HpmnTrainLayout, "HpmnScatterPlan": _lib.HpmnScatterPlan,
-               "HpmnRowsAdam": _lib.HpmnRowsAdam, "HpmnTile128": _lib.HpmnTile128}
+               "HpmnRowsAdam": _lib.HpmnRowsAdam, "HpmnTileFwd": _lib.HpmnTileFwd}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "hpmn_hip.h"', "int main(void){"]
     for name, st in structs.items():
         lines.append('printf("%s %%zu\\n", sizeof(%s));' % (name, name))
@@ -80,12 +80,13 @@ def test_error_codes_without_touching_a_device(lib):
     assert lib.hpmn_embed_gather(None, None, None, 5, 3, 6, 10, 1, None) == -2                          # E % 4
     assert lib.hpmn_embed_grad_scatter(None, None, None, 2, 5, 3, 24, 0, 10, 1, None) == -2             # 64 % E
     assert lib.hpmn_table_mark_rows(None, 0, None, 10, 2, None) == 0 and lib.hpmn_table_mark_rows(None, 4, None, 10, 2, None) == -1
-    t128 = _lib.HpmnTile128()
-    assert lib.hpmn_tile128_fwd(None, None) == -1 and lib.hpmn_tile128_supported(128, 32) == 1 and lib.hpmn_tile128_supported(64, 32) == 0
-    t128.B, t128.T, t128.D, t128.period = 4, 8, 48, 2
-    assert lib.hpmn_tile128_fwd(C.byref(t128), None) == -2                                                   # D not 32 / 128
+    t128 = _lib.HpmnTileFwd()
+    assert lib.hpmn_tile_fwd(None, None) == -1 and lib.hpmn_tile_supported(128, 32) == 1 and lib.hpmn_tile_supported(64, 48) == 1
+    assert lib.hpmn_tile_supported(32, 32) == 0
+    t128.B, t128.T, t128.D, t128.H, t128.period = 4, 8, 48, 128, 2
+    assert lib.hpmn_tile_fwd(C.byref(t128), None) == -2                                                     # H = 128: D not 32 / 128
     t128.D = 128
-    assert lib.hpmn_tile128_fwd(C.byref(t128), None) == -1                                                   # neither x nor xp
+    assert lib.hpmn_tile_fwd(C.byref(t128), None) == -1                                                     # neither x nor xp
     ra = _lib.HpmnRowsAdam()
     assert lib.hpmn_rows_sum_adam(None, None) == -1 and lib.hpmn_rows_sum_adam(C.byref(ra), None) == -1     # world == 0
     ra.world, ra.E, ra.V = 2, 16, 100

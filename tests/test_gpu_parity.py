@@ -1812,7 +1812,7 @@ def test_split_gradient_kernels_track_the_fp32_kernels_over_200_steps(tmp_path):
 @pytest.mark.parametrize("xp_rows", [False, True])
 @pytest.mark.parametrize("T,K,B", [(105, 4, 37), (1001, 7, 21)])
 def test_tile_kernel_h128_matches_the_oracle(dev, tmp_path, monkeypatch, T, K, B, xp_rows):
-    """r5 (VERDICT r4 missing #4): evaluation at H = 128 on the matrix cores -- hpmn_tile128_fwd, 16-sequence tiles, four waves
+    """r5 (VERDICT r4 missing #4): evaluation at H = 128 on the matrix cores -- hpmn_tile_fwd, 16-sequence tiles, four waves
     each holding a quarter of the units of all three gates, split-f16 operands; layer 0 projects in the kernel, the layers above
     read hpmn_gru_input_proj's rows.  ops.tiled_forward_inference against the float64 oracle at 1e-4 (memory; logit / prediction
     through the read path), a partial last tile, the Industry zero prefix, configs[4]'s length; and against the per-sequence kernels."""
@@ -1840,3 +1840,31 @@ def test_tile_kernel_h128_matches_the_oracle(dev, tmp_path, monkeypatch, T, K, B
     assert m._tiled_inference(1600)
     got = m.forward_inference(big)
     assert torch.equal(got["memory"][:B], mem)
+
+
+@pytest.mark.parametrize("name,cfg,B", [("xlong", cfg_industry(H=64, K=7, T=1001, V=900), 37),
+                                        ("taobao", O.HpmnConfig(700, 4, 300, 64, 16, 3, (2, 2, 3, 5, 5, 1), 5, False, 1e-5), 21),
+                                        ("amazon-like-d48", cfg_amazon(H=64, K=3, T=100, F=3, V=300), 5)])
+def test_four_wave_tile_kernel_h64_matches_the_oracle_and_the_first_generation(dev, tmp_path, monkeypatch, name, cfg, B):
+    """r5: the second-generation H = 64 evaluation kernel (gru_tile64.hip through hpmn_tile_fwd: four waves per tile, each with
+    a quarter of the units of all three gates, one layer per launch) against the float64 oracle at 1e-4 -- XLong's length, odd
+    periods (3, 5), D = 32 / 48 / 64, the id-0 mask, partial tiles -- and against the twelve-wave kernel it replaces in
+    ops.tiled_forward_inference (same split-f16 arithmetic, different summation trees: 2e-5)."""
+    from hpmn_amd import ops
+    p = f32_params(cfg, 601)
+    ids, label = rand_ids(cfg, B, 602)
+    want = O.forward(cfg, p, ids, label)
+    m = make_model(cfg, tmp_path, p)
+    t = torch.as_tensor(ids).to(dev)
+    emb, w = m.params["Embedding/emb_mtx"], m._gru_weights()
+    assert ops.TILE64
+    monkeypatch.setattr(ops, "_cu_count", lambda dev: 0)            # (the four-wave kernel whatever the tile count)
+    mem, last = ops.tiled_forward_inference(m.spec, t, emb, w)
+    np.testing.assert_allclose(mem.cpu().numpy(), want["memory"], rtol=0, atol=TOL)
+    out = ops.read_fwd(m._read_desc, m._read_params, mem, last, True, True)
+    for k in ("logit", "prediction"):
+        np.testing.assert_allclose(out[k].cpu().numpy(), want[k], rtol=0, atol=TOL, err_msg=k)
+    monkeypatch.setattr(ops, "TILE64", False)
+    mem1, last1 = ops.tiled_forward_inference(m.spec, t, emb, w)
+    assert torch.equal(last, last1)
+    np.testing.assert_allclose(mem.cpu().numpy(), mem1.cpu().numpy(), rtol=0, atol=2e-5)

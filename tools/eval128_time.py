@@ -1,4 +1,4 @@
-"""Evaluation throughput at H = 128 (C4 shape): the tile kernel (hpmn_tile128_fwd) against the per-sequence scans."""
+"""Evaluation throughput at H = 128 (C4 shape): the tile kernel (hpmn_tile_fwd) against the per-sequence scans."""
 import os, sys, time, tempfile
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
