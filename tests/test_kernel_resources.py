@@ -64,3 +64,28 @@ def test_two_layer_forward_keeps_nothing_in_scratch(tmp_path):
     assert len(pair) == 6, sorted(info)
     for name, (total, occupancy, loops) in pair.items():
         assert total <= 256 and occupancy >= 2 and not loops, "%s: %d registers, scratch in loops %s" % (name, total, loops)
+
+
+def test_tile_evaluation_kernels_keep_their_time_loops_out_of_scratch(tmp_path):
+    """r5: the four-wave tile kernels (hpmn_tile_fwd).  H = 64 must fit TWO workgroups per CU (its whole advantage over the
+    twelve-wave kernel is two tiles interleaving on a CU: cut for three or four the loop spilled and a pass took 1.7x as long);
+    H = 128 may use the whole 512-register budget -- mode 2 even spills while it prepares its weight fragments -- but no
+    time loop of any of them may touch scratch."""
+    import check_resources
+    info = check_resources.kernel_info(_assembly(tmp_path, "gru_tile64"))
+    k64 = {k: v for k, v in info.items() if "gru_tile64_fwd_kernel" in k}
+    assert len(k64) == 2, sorted(info)
+    for name, (total, occupancy, loops) in k64.items():
+        assert total <= 256 and occupancy >= 2 and not loops, "%s: %d registers, scratch in loops %s" % (name, total, loops)
+    text = _assembly(tmp_path, "gru_tile128")
+    info = check_resources.kernel_info(text)
+    k128 = {k: v for k, v in info.items() if "gru_tile128_fwd_kernel" in k}
+    assert len(k128) == 3, sorted(info)
+    for name, (total, occupancy, loops) in k128.items():
+        assert total <= 512 and occupancy >= 1, name
+        # scratch only in front of the time loop: behind the step loop's first barrier pair nothing touches it
+        body = text[text.index(name + ":"):]
+        body = body[:body.index("s_endpgm")].split("\n")
+        bars = [i for i, l in enumerate(body) if "s_barrier" in l]
+        assert len(bars) >= 10, name
+        assert not any("scratch_" in l for l in body[bars[2]:]), name + ": scratch behind the prologue"
