@@ -984,6 +984,17 @@ def main():
         elapsed = float(t.item())
 
     log("timed region done: %.1f ms/step" % (elapsed / args.steps * 1e3))
+    # data parallel: the replicas must hold the SAME BITS after the timed steps (same addends in the same order on every rank:
+    # hpmn_rows_sum_adam's rank-order sum / the all-reduce's result, then the same update) -- a checksum over the bit patterns
+    # of every parameter and both moment buffers, gathered and compared
+    replicas_identical = None
+    if world > 1:
+        bits = lambda t: t.view(torch.int32).to(torch.int64).sum()
+        mine = torch.stack([bits(model.flat_param), bits(model.flat_m), bits(model.flat_v)])
+        alls = [torch.empty_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(alls, mine)
+        replicas_identical = bool(all(torch.equal(a, alls[0]) for a in alls))
+        log("replicas identical: %s" % replicas_identical)
     # quick quality signal on the bench batches (not a trained AUC: weights saw only W+K steps)
     finite = True
     if not args.no_eval:
@@ -1088,6 +1099,8 @@ def main():
             "algorithmic": {"gru_flops_fwd_per_seq": algorithmic_flops_fwd(c),
                             "train_tflops_equiv": 3 * algorithmic_flops_fwd(c) * seqs / elapsed / 1e12},
         }
+        if replicas_identical is not None:
+            result["replicas_identical"] = replicas_identical
         result["eval_sequences_per_s"] = eval_seq_per_s        # forward only, rank-0 clock (not barrier-bracketed)
         if eval_pass is not None:
             result["eval_pass"] = eval_pass

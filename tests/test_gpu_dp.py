@@ -129,6 +129,7 @@ def test_bench_gpus_n_with_the_rank_0_legs(tmp_path):
     assert len(lines) == 1, r.stdout.decode()[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["roofline"]["ms_per_launch"] > 0 and d["parity_gate"]["pass"]
+    assert d["replicas_identical"] is True          # (r5: bit patterns of parameters and moments, compared across the ranks)
 
 
 def test_two_ranks_on_a_table_beyond_int32_rows(tmp_path):
