@@ -790,7 +790,8 @@ def side_legs(args):
         env = dict(os.environ)
         env.update(extra_env)
         try:
-            r = subprocess.run(base + extra_args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+            # (bounded: a sub-run that cannot come up -- no RCCL on this box, say -- costs three minutes, not the bench line)
+            r = subprocess.run(base + extra_args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=180)
             line = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
             return json.loads(line[-1])["ms_per_step"] if r.returncode == 0 and line else None
         except Exception:
