@@ -263,8 +263,14 @@ def side_group():
     the collectives of the step that is running."""
     global _side_group
     if _side_group is None and td.is_available() and td.is_initialized():
-        _side_group = td.new_group()
-    return _side_group
+        try:
+            _side_group = td.new_group()
+        except Exception as e:                     # (a backend that cannot make a second communicator: the main one serves)
+            import warnings
+            warnings.warn("hpmn_amd.dist: no second process group (%s: %s); the step-ahead exchange uses the default one"
+                          % (type(e).__name__, e))
+            _side_group = False
+    return _side_group or None
 
 
 class HostCopy:
