@@ -955,6 +955,14 @@ def main():
         nxt = dict(next_ids=batches[(i + 1) % n_distinct][0], next_global_batch=global_batch) if prefetch else {}
         model.train_step(ids, label, keep_prob=0.5, global_batch=global_batch, **nxt)
 
+    # the host loop runs ahead of the device; a full (generation 2) pass of Python's cycle collector over torch's ~1 M
+    # objects takes ~35 ms -- 0.15 ms/step of a 200-step C1 run when it lands in the timed region.  Collect now, and keep
+    # the survivors out of later passes.  BEFORE the warm-up steps, not between them and the timed region (r5): those 35-40 ms
+    # with the device idle let its clocks fall back, and the first ten steps after such a gap run at 3.1, 2.95, 2.8, 2.7, 2.6 ...
+    # instead of 2.5 ms (tools/r5_step_ramp.py: a 20-step region 2.60-2.98 ms/step after the gap, 2.53 without it) -- the
+    # warm-up steps warm the clocks as well as the caches only if the timed steps FOLLOW them.
+    gc.collect()
+    gc.freeze()
     log("data ready; warmup")
     for i in range(args.warmup):
         step(i)
@@ -962,11 +970,6 @@ def main():
             torch.cuda.synchronize()
             log("first step done")
     torch.cuda.synchronize()
-    # the host loop runs ahead of the device; a full (generation 2) pass of Python's cycle collector over torch's ~1 M
-    # objects takes ~35 ms -- 0.15 ms/step of a 200-step C1 run when it lands in the timed region.  Collect now, and keep
-    # the survivors out of later passes.
-    gc.collect()
-    gc.freeze()
     log("timing %d steps" % args.steps)
     if world > 1:
         torch.distributed.barrier()
