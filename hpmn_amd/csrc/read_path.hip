@@ -22,10 +22,17 @@ namespace hpmn {
 #define HPMN_READ_RS 2
 #endif
 constexpr int RS = HPMN_READ_RS;          // samples per workgroup
+// threads per workgroup: a RUN-TIME quantity in the device code (r5) -- the inference launch and the fp32 training launch run
+// four waves, the training launch on bf16 fragments eight (two per SIMD: its phases are instruction streams of a few hundred
+// instructions per wave, and a lone wave issues one instruction per ~5 cycles; C3 -19 us, C1 -10 us per launch against four)
 #ifndef HPMN_READ_RT
 #define HPMN_READ_RT 256
 #endif
-constexpr int RT = HPMN_READ_RT;        // threads
+#ifndef HPMN_READ_RT_BF
+#define HPMN_READ_RT_BF 512
+#endif
+constexpr int RT_BASE = HPMN_READ_RT, RT_BF = HPMN_READ_RT_BF, RT_MAX = RT_BF > RT_BASE ? RT_BF : RT_BASE;
+#define RT ((int)blockDim.x)
 constexpr int A1 = 80, A2 = 40;      // attention MLP widths (code/hpmn.py:137-138)
 constexpr int F1 = 200, F2 = 80;     // head widths (code/hpmn.py:191,193)
 // Row strides in LDS: every activation row is padded by 4 floats.  The products read an operand row per lane (16 bytes
@@ -467,21 +474,26 @@ __host__ __device__ inline long img_layout(const HpmnReadDesc &d0, const HpmnRea
 //     in LDS and after one barrier all threads add the four partials in wave order (deterministic), bias, activation.
 // (The first version walked tile by tile with a three-chunk ring of fragments: every tile began with an exposed L2 round trip
 //  and repeated the split -- 4H -> 80 took 14 k cycles per hop at C3 where the fp32 form took 18 k, its transpose 10 k against 9 k.)
-constexpr int BF_MAXT = 8;
-constexpr int KS_PART_FLOATS = (RT / 64) * 16 * (16 * BF_MAXT + 4);
+constexpr int BF_MAXT = 4;                 // column tiles per wave
+constexpr int BF_WAVES = RT_BF / 64;
+static_assert(BF_WAVES * BF_MAXT >= 32, "4H <= 512 columns over the waves' tiles");
+constexpr int KS_PART_FLOATS = BF_WAVES * 16 * (16 * 8 + 4);
 template <int ACT, bool ACCUM, int NS>
 __device__ __forceinline__ void dense_bf(const float *X, int ldx, int R, int Kd, const uint4 *img, const float *bias, int N,
                                          float *Y, int ldy, float *part) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n = lane & 15, kg = lane >> 4;
+    const int nw = RT / 64;
     const int nch = (Kd + 31) >> 5, ntile = (N + 15) >> 4;
-    const bool ks = nch >= 4 && ntile <= BF_MAXT;                     // (workgroup-uniform)
-    const int cstep = ks ? RT / 64 : 1, c0 = ks ? wave : 0;
-    const int tstep = ks ? 1 : RT / 64, t0 = ks ? 0 : wave;
+    const bool ks = nch >= 4 && ntile <= 8;                           // (workgroup-uniform)
+    // K-split: G groups of four column tiles x S = nw / G shares of the chunks; otherwise the tiles go round the waves
+    const int G = ks ? (ntile + BF_MAXT - 1) / BF_MAXT : 1, S = ks ? nw / G : 1;
+    const int cstep = S, c0 = ks ? wave % S : 0;
+    const int tstep = ks ? 1 : nw, t0 = ks ? (wave / S) * BF_MAXT : wave;
     const float *xr = X + (n < R ? n : R - 1) * ldx;
     rf4 acc[BF_MAXT];
-    // (the bias rides in the accumulators of the wave that owns the tile -- K-split: wave 0's partial -- requested here, in
-    //  front of the chunks: asked for in the epilogue it was a round trip of its own per call)
-    const bool addb = bias != nullptr && (!ks || wave == 0);
+    // (the bias rides in the accumulators of the wave that owns the tile -- K-split: the first share's partial -- requested
+    //  here, in front of the chunks: asked for in the epilogue it was a round trip of its own per call)
+    const bool addb = bias != nullptr && (!ks || c0 == 0);
 #pragma unroll
     for (int j = 0; j < BF_MAXT; ++j) {
         const int col = 16 * (t0 + j * tstep) + n;
@@ -539,19 +551,18 @@ __device__ __forceinline__ void dense_bf(const float *X, int ldx, int R, int Kd,
         const int NP = 16 * ntile + 4;
 #pragma unroll
         for (int j = 0; j < BF_MAXT; ++j)
-            if (j < ntile) {
+            if (t0 + j < ntile) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) part[(wave * 16 + 4 * kg + i) * NP + 16 * j + n] = acc[j][i];
+                for (int i = 0; i < 4; ++i) part[(c0 * 16 + 4 * kg + i) * NP + 16 * (t0 + j) + n] = acc[j][i];
             }
         __syncthreads();
         BFCLK(44);
-        // thread = (column, row parity): N <= 128
+        // thread = (column, row): N <= 128; the shares added in order
         const int col = threadIdx.x & 127;
         if (col < N) {
             for (int r = threadIdx.x >> 7; r < R; r += RT / 128) {
                 float v = part[r * NP + col];
-#pragma unroll
-                for (int w = 1; w < RT / 64; ++w) v += part[(w * 16 + r) * NP + col];
+                for (int w = 1; w < S; ++w) v += part[(w * 16 + r) * NP + col];
                 if (ACT == 1) v = fmaxf(v, 0.f);
                 if (ACT == 2) v = elu(v);
                 if (ACCUM) v += Y[r * ldy + col];
@@ -794,8 +805,9 @@ __host__ __device__ inline size_t carve_branch(BranchSmem &x, float *base, size_
     return off;
 }
 
+// train: 0 inference, 1 training, 2 training on bf16 fragments (+ the K-split layers' partial sums)
 __host__ __device__ inline size_t carve_all(ReadSmem &s, float *base, const HpmnReadDesc &d0, const HpmnReadDesc &d1, int nb,
-                                            bool train, int RS) {
+                                            int train, int RS) {
     s.rs = RS;
     size_t off = 0;
     auto take = [&](size_t n) { float *r = base ? base + off : nullptr; off += (n + 3) / 4 * 4; return r; };
@@ -813,7 +825,7 @@ __host__ __device__ inline size_t carve_all(ReadSmem &s, float *base, const Hpmn
     s.mk2 = take((size_t)RS * F2P);
     s.dmem = s.t1 = s.t2 = s.dq = s.tq = s.drep = s.part = nullptr;
     if (train) {
-        s.part = take((size_t)KS_PART_FLOATS);
+        if (train == 2) s.part = take((size_t)KS_PART_FLOATS);
         s.dmem = take(RKm * (m.Hmax + PADF));
         s.t1 = take(RKm * A1P > (size_t)RS * F1P ? RKm * A1P : (size_t)RS * F1P);
         s.t2 = take(RKm * A2P > (size_t)RS * F2P ? RKm * A2P : (size_t)RS * F2P);
@@ -824,12 +836,12 @@ __host__ __device__ inline size_t carve_all(ReadSmem &s, float *base, const Hpmn
     return off + 16;
 }
 
-inline size_t read_smem_floats(const HpmnReadDesc *d, int nb, bool train, int rs) {
+inline size_t read_smem_floats(const HpmnReadDesc *d, int nb, int train, int rs) {
     ReadSmem s;
     return carve_all(s, nullptr, d[0], d[nb > 1 ? 1 : 0], nb, train, rs);
 }
 
-__device__ inline void carve(ReadSmem &s, float *base, const ReadArgs &a, bool train) {
+__device__ inline void carve(ReadSmem &s, float *base, const ReadArgs &a, int train) {
     carve_all(s, base, a.d[0], a.d[1], a.nb, train, a.rs);
     const ReadDims m = read_dims(a.d[0], a.d[1], a.nb);
     for (int o = threadIdx.x; o < m.Zmax; o += RT) s.zero[o] = 0.f;   // visible after the caller's first barrier
@@ -1010,11 +1022,11 @@ __device__ inline void load_tile_inputs(const ReadArgs &a, const ReadSmem &s, lo
     __syncthreads();
 }
 
-__global__ __launch_bounds__(RT) void read_fwd_kernel(const ReadArgs a, const float *__restrict__ P, float *pred,
+__global__ __launch_bounds__(RT_BASE) void read_fwd_kernel(const ReadArgs a, const float *__restrict__ P, float *pred,
                                                       float *logit, float *mem_loss) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     ReadSmem s;
-    carve(s, smem, a, false);
+    carve(s, smem, a, 0);
     const long b0 = (long)blockIdx.x * a.rs;
     const int B = a.d[0].B;
     const int R = (B - b0) < a.rs ? (int)(B - b0) : a.rs;
@@ -1171,7 +1183,7 @@ __device__ __forceinline__ void read_backward_branch(const HpmnReadDesc &d, cons
 // outputs: pred [B]; loss_out[0] += sum ll_b, loss_out[1] += sum cov_b (atomics); d_memory [B,K,H] and d_last [B,D0] of
 // every branch; a.tape: the operand rows of the read-path weight-gradient products (read_wgrad_kernel forms them).
 template <bool BF>
-__global__ __launch_bounds__(RT) void read_fwd_bwd_kernel(const ReadArgs a, const float *__restrict__ P,
+__global__ __launch_bounds__(BF ? RT_BF : RT_BASE) void read_fwd_bwd_kernel(const ReadArgs a, const float *__restrict__ P,
                                                           const int32_t *__restrict__ label,
                                                           const float *__restrict__ mask1,
                                                           const float *__restrict__ mask2, float keep_prob,
@@ -1181,7 +1193,7 @@ __global__ __launch_bounds__(RT) void read_fwd_bwd_kernel(const ReadArgs a, cons
     ReadSmem s;
     const HpmnReadDesc &d = a.d[0];
     const int W = a.W, WP = W + PADF;
-    carve(s, smem, a, true);
+    carve(s, smem, a, BF ? 2 : 1);
     const int tid = threadIdx.x;
     const long b0 = (long)blockIdx.x * a.rs;
     const int R = (d.B - b0) < a.rs ? (int)(d.B - b0) : a.rs;
@@ -1535,13 +1547,13 @@ int read_fwd_launch_n(const HpmnReadDesc *const *d, int nb, const float *P, cons
     a.rs = RS;
     if (rs_env == 4 || (rs_env == 0 && a.d[0].B >= 1024)) a.rs = 4;
     if (a.rs * kmax > 32) a.rs = RS;
-    size_t lds = read_smem_floats(a.d, nb, false, a.rs) * sizeof(float);
-    if (lds > 160 * 1024 && a.rs != RS) { a.rs = RS; lds = read_smem_floats(a.d, nb, false, a.rs) * sizeof(float); }
+    size_t lds = read_smem_floats(a.d, nb, 0, a.rs) * sizeof(float);
+    if (lds > 160 * 1024 && a.rs != RS) { a.rs = RS; lds = read_smem_floats(a.d, nb, 0, a.rs) * sizeof(float); }
     if (lds > 160 * 1024) return HPMN_EUNSUPPORTED;
     hipError_t e = hipFuncSetAttribute((const void *)read_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { set_last_hip_error((int)e); return HPMN_EHIP; }
     const unsigned grid = (unsigned)((a.d[0].B + a.rs - 1) / a.rs);
-    hipLaunchKernelGGL(read_fwd_kernel, dim3(grid), dim3(RT), lds, st, a, P, pred, logit, mem_loss);
+    hipLaunchKernelGGL(read_fwd_kernel, dim3(grid), dim3(RT_BASE), lds, st, a, P, pred, logit, mem_loss);
     return check_launch();
 }
 
@@ -1553,9 +1565,10 @@ int read_fwd_bwd_launch_n(const HpmnReadDesc *const *d, int nb, const float *P, 
     int rc = read_args(a, d, nb, memory, last, d_memory, d_last, nullptr);
     if (rc != HPMN_OK) return rc;
     a.rs = RS;
-    const size_t lds = read_smem_floats(a.d, nb, true, a.rs) * sizeof(float);
+    bool bf = read_bf_enabled() && read_bf_shapes_ok(d, nb);
+    size_t lds = read_smem_floats(a.d, nb, bf ? 2 : 1, a.rs) * sizeof(float);
+    if (bf && lds > 160 * 1024) { bf = false; lds = read_smem_floats(a.d, nb, 1, a.rs) * sizeof(float); }
     if (lds > 160 * 1024) return HPMN_EUNSUPPORTED;
-    const bool bf = read_bf_enabled() && read_bf_shapes_ok(d, nb);
     const void *fn = bf ? (const void *)read_fwd_bwd_kernel<true> : (const void *)read_fwd_bwd_kernel<false>;
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { set_last_hip_error((int)e); return HPMN_EHIP; }
@@ -1574,10 +1587,10 @@ int read_fwd_bwd_launch_n(const HpmnReadDesc *const *d, int nb, const float *P, 
         hipLaunchKernelGGL(read_wimg_kernel, dim3((unsigned)((ia.items + 3) / 4)), dim3(256), 0, st, ia);
         rc = check_launch();
         if (rc != HPMN_OK) return rc;
-        hipLaunchKernelGGL(read_fwd_bwd_kernel<true>, dim3(grid), dim3(RT), lds, st, a, P, label, mask1, mask2, keep_prob,
+        hipLaunchKernelGGL(read_fwd_bwd_kernel<true>, dim3(grid), dim3(RT_BF), lds, st, a, P, label, mask1, mask2, keep_prob,
                            inv_global_batch, memory_reg, pred, loss_out);
     } else {
-        hipLaunchKernelGGL(read_fwd_bwd_kernel<false>, dim3(grid), dim3(RT), lds, st, a, P, label, mask1, mask2, keep_prob,
+        hipLaunchKernelGGL(read_fwd_bwd_kernel<false>, dim3(grid), dim3(RT_BASE), lds, st, a, P, label, mask1, mask2, keep_prob,
                            inv_global_batch, memory_reg, pred, loss_out);
     }
     rc = check_launch();
