@@ -757,13 +757,16 @@ def dp_report(model, c, batches, world, ms_per_step, n_model=8, busbw_gbps=300.0
 # ~16 bits of operand mantissa); evaluation-sized forward passes at H = 64 on three f16 products.  These switches put every one
 # of them back on fp32 kernels: the `ms_per_step_all_fp32` figure of the bench line is the SAME timed loop under them.
 ALL_FP32_ENV = {"HPMN_WGRAD_BF16": "0", "HPMN_BWD_DX_INLOOP": "0", "HPMN_PROJ_BF16": "0", "HPMN_DX_BF16": "0",
-                "HPMN_TILED_EVAL_MIN_ROWS": "0"}
+                "HPMN_TILED_EVAL_MIN_ROWS": "0", "HPMN_READ_BF16": "0"}
 
 
 def dtype_string(c):
+    # (r5: the read path's TRAINING launch runs its dense layers on the bf16 pipe -- three planes / six products in the forward,
+    #  i.e. fp32-equivalent, two planes / three products in its input-gradient products)
+    read = "read-path training launch: bf16 split operands, 3 planes forward (2^-24), 2 planes input gradients"
     if c["H"] == 32:
-        return "f32"
-    s = "f32 (GRU weight gradients + layer-0 input gradient: bf16x3 split operands, f32 accumulate"
+        return "f32 (%s)" % read
+    s = "f32 (%s; GRU weight gradients + layer-0 input gradient: bf16x3 split operands, f32 accumulate" % read
     if c["H"] == 128:
         s += "; input projection / input gradients: bf16x3 split"
     if c["H"] == 64:

@@ -71,6 +71,13 @@ __shared__ unsigned long long rck_acc[48], rck_last;
 #endif
 
 
+// The barriers of these kernels order LDS traffic only: nothing a workgroup writes to global memory (the tape, d_memory, d_last,
+// the predictions, the loss atomics) is read again inside the launch.  __syncthreads() also waits for every outstanding global
+// STORE of the wave (s_waitcnt vmcnt(0) in front of s_barrier): each tape_store in front of a barrier cost the workgroup a round
+// trip to memory -- ~20 of them per training launch, 2-4 k cycles each (tools/read_clock.sh: the two 128-float tape rows of mark
+// 39 took 3.9 k cycles per hop).  r5: wait for the LDS counter alone.
+__device__ __forceinline__ void rsync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ float elu(float x) { return x > 0.f ? x : __expf(x) - 1.f; }
 
 // Dropout keep factor (0 or 1) of unit j of sample b in head layer `layer`: the caller's mask when one is
@@ -520,9 +527,8 @@ __device__ __forceinline__ void dense_bf(const float *X, int ldx, int R, int Kd,
         const bool live = k0 < Kd;                                    // (Kd % 8 == 0: a lane's eight k-steps are all in or out)
         const int ko = live ? k0 : 0;
         const float4 a0 = *reinterpret_cast<const float4 *>(xr + ko), a1 = *reinterpret_cast<const float4 *>(xr + ko + 4);
+        // (a lane beyond Kd reads the row's first eight values -- finite activations -- against fragment entries that are zero)
         float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = live ? v[e] : 0.f;
         rbf8 ap[NS];
         split_planes<NS>(v, ap);
         BFCLK(42);
@@ -555,7 +561,7 @@ __device__ __forceinline__ void dense_bf(const float *X, int ldx, int R, int Kd,
 #pragma unroll
                 for (int i = 0; i < 4; ++i) part[(c0 * 16 + 4 * kg + i) * NP + 16 * (t0 + j) + n] = acc[j][i];
             }
-        __syncthreads();
+        rsync();
         BFCLK(44);
         // thread = (column, row): N <= 128; the shares added in order
         const int col = threadIdx.x & 127;
@@ -871,7 +877,7 @@ __device__ __forceinline__ void read_forward_branch(const HpmnReadDesc &d, const
     const int tid = threadIdx.x;
     // q0 = last Wq + bq  (code/hpmn.py:173)
     dense_fwd_i<0, BF>(x.last, D0P, R, D0, P + d.off_wq, P + d.off_bq, H, x.q, HP, ib + im.wq[bi][0], s.part);
-    __syncthreads();
+    rsync();
     RCLK(2);
     for (int hop = 0; hop < d.hop; ++hop) {
         const float *q = x.q + (size_t)hop * s.rs * HP;
@@ -882,19 +888,19 @@ __device__ __forceinline__ void read_forward_branch(const HpmnReadDesc &d, const
             float *xi = s.inp + (size_t)row * IP;
             xi[i] = qv; xi[H + i] = mv; xi[2 * H + i] = qv - mv; xi[3 * H + i] = qv * mv;
         }
-        __syncthreads();
+        rsync();
         RCLK(3);
         float *x1 = x.x1 + (size_t)hop * s.rs * K * A1P, *x2 = x.x2 + (size_t)hop * s.rs * K * A2P;
         float *sc = x.sc + (size_t)hop * s.rs * K;
         const int *oa = d.off_att[hop];
         dense_fwd_i<1, BF>(s.inp, IP, RK, 4 * H, P + oa[0], P + oa[1], A1, x1, A1P, ib + im.att[bi][hop][0][0], s.part);
-        __syncthreads();
+        rsync();
         RCLK(4);
         dense_fwd_i<1, BF>(x1, A1P, RK, A1, P + oa[2], P + oa[3], A2, x2, A2P, ib + im.att[bi][hop][1][0], s.part);
-        __syncthreads();
+        rsync();
         RCLK(5);
         dense_fwd<0>(x2, A2P, RK, A2, P + oa[4], P + oa[5], 1, sc, 1);
-        __syncthreads();
+        rsync();
         RCLK(6);
         // softmax over the K slots of each sample (code/hpmn.py:141)
         if (tid < R) {
@@ -905,12 +911,12 @@ __device__ __forceinline__ void read_forward_branch(const HpmnReadDesc &d, const
             const float inv = 1.f / den;
             for (int k = 0; k < K; ++k) sc[tid * K + k] *= inv;
         }
-        __syncthreads();
+        rsync();
         RCLK(7);
         // q' = q Hmap + sum_k score_k m_k   (code/hpmn.py:143-144, 179)
         float *qn = x.q + (size_t)(hop + 1) * s.rs * HP;
         dense_fwd_i<0, BF>(q, HP, R, H, P + d.off_map, nullptr, H, qn, HP, ib + im.map[bi][0], s.part);        // q Hmap (no bias)
-        __syncthreads();
+        rsync();
         RCLK(8);
         for (int o = tid; o < R * H; o += RT) {
             const int r = o / H, n = o - r * H;
@@ -918,7 +924,7 @@ __device__ __forceinline__ void read_forward_branch(const HpmnReadDesc &d, const
             for (int k = 0; k < K; ++k) acc = fmaf(sc[r * K + k], x.mem[(r * K + k) * HP + n], acc);
             qn[r * HP + n] = acc;
         }
-        __syncthreads();
+        rsync();
         RCLK(9);
     }
     // covariance regulariser (code/hpmn.py:161-170): per-sample Frobenius norm of the off-diagonal cov.
@@ -928,7 +934,7 @@ __device__ __forceinline__ void read_forward_branch(const HpmnReadDesc &d, const
         for (int i = 0; i < H; ++i) a += x.mem[o * HP + i];
         x.cmean[o] = a / H;
     }
-    __syncthreads();
+    rsync();
     for (int o = tid; o < RK * K; o += RT) {
         const int rk = o / K, j = o - rk * K;       // rk = r*K + k
         const int r = rk / K, k = rk - r * K;
@@ -941,13 +947,13 @@ __device__ __forceinline__ void read_forward_branch(const HpmnReadDesc &d, const
         }
         x.ccov[o] = cv;
     }
-    __syncthreads();
+    rsync();
     if (tid < R) {
         float ss = 0.f;
         for (int o = 0; o < K * K; ++o) { const float cv = x.ccov[tid * K * K + o]; ss = fmaf(cv, cv, ss); }
         x.cnorm[tid] = sqrtf(ss);
     }
-    __syncthreads();
+    rsync();
     RCLK(10);
 }
 
@@ -977,9 +983,9 @@ __device__ __forceinline__ void read_forward_tile(const ReadArgs &a, const float
         }
         off += H + D0;
     }
-    __syncthreads();
+    rsync();
     dense_fwd_i<2, BF>(s.rep, WP, R, W, P + d0.off_fc[0], P + d0.off_fc[1], F1, s.h1, F1P, a.im.base + a.im.fc[0][0], s.part);
-    __syncthreads();
+    rsync();
     RCLK(12);
     const bool drop = mask1 != nullptr || mask2 != nullptr || (d0.dropout_seed != 0 && keep_prob < 1.f);
     if (drop) {
@@ -991,20 +997,20 @@ __device__ __forceinline__ void read_forward_tile(const ReadArgs &a, const float
 #pragma unroll 1
         for (int o = tid; o < R * F2; o += RT)
             s.mk2[(o / F2) * F2P + o % F2] = keep_factor(mask2, d0.dropout_seed, 2, b0 + o / F2, o % F2, F2, keep_prob) / keep_prob;
-        __syncthreads();
+        rsync();
         for (int o = tid; o < R * F1P; o += RT) s.h1[o] *= s.mk1[o];       // (the pad columns: finite garbage, never read)
-        __syncthreads();
+        rsync();
     }
     RCLK(13);
     dense_fwd_i<2, BF>(s.h1, F1P, R, F1, P + d0.off_fc[2], P + d0.off_fc[3], F2, s.h2, F2P, a.im.base + a.im.fc[1][0], s.part);
-    __syncthreads();
+    rsync();
     RCLK(14);
     if (drop) {
         for (int o = tid; o < R * F2P; o += RT) s.h2[o] *= s.mk2[o];
-        __syncthreads();
+        rsync();
     }
     dense_fwd<0>(s.h2, F2P, R, F2, P + d0.off_fc[4], P + d0.off_fc[5], 1, s.t3, 1);
-    __syncthreads();
+    rsync();
     RCLK(15);
 }
 
@@ -1019,7 +1025,7 @@ __device__ inline void load_tile_inputs(const ReadArgs &a, const ReadSmem &s, lo
     // pad columns that elementwise loops sweep: defined values (mask products over whole padded rows)
     for (int o = threadIdx.x; o < s.rs * F1P; o += RT) { s.h1[o] = 0.f; s.mk1[o] = 0.f; }
     for (int o = threadIdx.x; o < s.rs * F2P; o += RT) { s.h2[o] = 0.f; s.mk2[o] = 0.f; }
-    __syncthreads();
+    rsync();
 }
 
 __global__ __launch_bounds__(RT_BASE) void read_fwd_kernel(const ReadArgs a, const float *__restrict__ P, float *pred,
@@ -1074,7 +1080,7 @@ __device__ __forceinline__ void read_backward_branch(const HpmnReadDesc &d, cons
         }
         s.dmem[rk * HP + i] = acc;
     }
-    __syncthreads();
+    rsync();
     RCLK(25);
 
     // ---- hops backward (reverse order) ---------------------------------------------------------
@@ -1095,7 +1101,7 @@ __device__ __forceinline__ void read_backward_branch(const HpmnReadDesc &d, cons
             const int row = o / H, i = o - row * H;
             s.dmem[row * HP + i] = fmaf(sc[row], s.dq[(row / K) * HP + i], s.dmem[row * HP + i]);
         }
-        __syncthreads();
+        rsync();
         RCLK(26);
         // softmax backward: d s_k = sc_k (d sc_k - sum_j sc_j d sc_j)
         if (tid < R) {
@@ -1103,7 +1109,7 @@ __device__ __forceinline__ void read_backward_branch(const HpmnReadDesc &d, cons
             for (int k = 0; k < K; ++k) dot = fmaf(sc[tid * K + k], dsc[tid * K + k], dot);
             for (int k = 0; k < K; ++k) dsc[tid * K + k] = sc[tid * K + k] * (dsc[tid * K + k] - dot);
         }
-        __syncthreads();
+        rsync();
         RCLK(27);
         // rebuild inp of this hop (the forward overwrote it hop by hop)
         for (int o = tid; o < RK * H; o += RT) {
@@ -1116,33 +1122,33 @@ __device__ __forceinline__ void read_backward_branch(const HpmnReadDesc &d, cons
         tape_store(th + tb.x2, b0 * K, x2, A2P, RK, A2);
         tape_store(th + tb.dsc, b0 * K, dsc, 1, RK, 1);
         dense_bwd_x<false>(dsc, 1, RK, 1, P + oa[4], A2, s.t2, A2P);
-        __syncthreads();
+        rsync();
         RCLK(28);
         for (int o = tid; o < RK * A2P; o += RT) s.t2[o] = x2[o] > 0.f ? s.t2[o] : 0.f;      // relu
-        __syncthreads();
+        rsync();
         RCLK(29);
         tape_store(th + tb.x1, b0 * K, x1, A1P, RK, A1);
         tape_store(th + tb.dt2, b0 * K, s.t2, A2P, RK, A2);
         RCLK(30);
         dense_bwd_x_i<false, BF>(s.t2, A2P, RK, A2, P + oa[2], A1, s.t1, A1P, ib + im.att[bi][hop][1][1], s.part);
-        __syncthreads();
+        rsync();
         RCLK(31);
         for (int o = tid; o < RK * A1P; o += RT) s.t1[o] = x1[o] > 0.f ? s.t1[o] : 0.f;      // relu
-        __syncthreads();
+        rsync();
         RCLK(32);
         tape_store(th + tb.inp, b0 * K, s.inp, IP, RK, 4 * H);
         tape_store(th + tb.dt1, b0 * K, s.t1, A1P, RK, A1);
         // d inp [RK, 4H] -> reuse s.inp AFTER the tape has its copy
-        __syncthreads();
+        rsync();
         RCLK(33);
         dense_bwd_x_i<false, BF>(s.t1, A1P, RK, A1, P + oa[0], 4 * H, s.inp, IP, ib + im.att[bi][hop][0][1], s.part);
-        __syncthreads();
+        rsync();
         RCLK(34);
         // inp = [q, m, q-m, q*m]:  dq_row = d0 + d2 + d3*m ; dm += d1 - d2 + d3*q
         // new dq (gradient wrt the query entering the hop) = dq' Hmap^T + sum_k dq_row
         float *dqn = s.tq;          // [R][H+]
         dense_bwd_x_i<false, BF>(s.dq, HP, R, H, P + d.off_map, H, dqn, HP, ib + im.map[bi][1], s.part);     // dq' Hmap^T
-        __syncthreads();
+        rsync();
         RCLK(35);
         for (int o = tid; o < R * H; o += RT) {
             const int r = o / H, i = o - r * H;
@@ -1158,23 +1164,23 @@ __device__ __forceinline__ void read_backward_branch(const HpmnReadDesc &d, cons
             const float *di = s.inp + (size_t)row * IP;
             s.dmem[row * HP + i] += di[H + i] - di[2 * H + i] + di[3 * H + i] * q[(row / K) * HP + i];
         }
-        __syncthreads();
+        rsync();
         for (int o = tid; o < R * H; o += RT) { const int r = o / H, i = o - r * H; s.dq[r * HP + i] = dqn[r * HP + i]; }
-        __syncthreads();
+        rsync();
         RCLK(36);
     }
     // q0 = last Wq + bq
     tape_store(tape + tb.last, b0, x.last, D0P, R, D0);
     tape_store(tape + tb.dq0, b0, s.dq, HP, R, H);
     dense_bwd_x_i<true, BF>(s.dq, HP, R, H, P + d.off_wq, D0, s.drep + doff, WP, ib + im.wq[bi][1], s.part);      // += dq Wq^T onto the head part
-    __syncthreads();
+    rsync();
     RCLK(37);
     for (int o = tid; o < R * D0; o += RT) {
         const int r = o / D0, i = o - r * D0;
         d_last[b0 * D0 + o] = s.drep[r * WP + doff + i];
     }
     for (int o = tid; o < RK * H; o += RT) d_memory[b0 * K * H + o] = s.dmem[(o / H) * HP + o % H];
-    __syncthreads();
+    rsync();
     RCLK(38);
 }
 
@@ -1246,7 +1252,7 @@ __global__ __launch_bounds__(BF ? RT_BF : RT_BASE) void read_fwd_bwd_kernel(cons
         const float dp = (-y / (p + eps) + (1.f - y) / (1.f - p + eps)) * inv_global_batch;
         dlg[tid] = dp * p * (1.f - p);
     }
-    __syncthreads();
+    rsync();
     RCLK(16);
 
     // ---- head backward ------------------------------------------------------------------------
@@ -1254,7 +1260,7 @@ __global__ __launch_bounds__(BF ? RT_BF : RT_BASE) void read_fwd_bwd_kernel(cons
     tape_store(tape + tp.h2, b0, s.h2, F2P, R, F2);
     tape_store(tape + tp.dlg, b0, dlg, 1, R, 1);
     dense_bwd_x<false>(dlg, 1, R, 1, P + d.off_fc[4], F2, s.t2, F2P);        // d h2 (post-dropout)
-    __syncthreads();
+    rsync();
     RCLK(17);
     // through dropout2 and elu2: h2 = elu(a2) * mask/keep.  elu'(a) = a>0 ? 1 : elu(a)+1; recover from h2.
     for (int o = tid; o < R * F2; o += RT) {
@@ -1264,13 +1270,13 @@ __global__ __launch_bounds__(BF ? RT_BF : RT_BASE) void read_fwd_bwd_kernel(cons
         const float hv = mk != 0.f ? s.h2[oo] / mk : 0.f;                    // elu(a2); irrelevant where mask==0
         s.t2[oo] = s.t2[oo] * mk * (hv > 0.f ? 1.f : hv + 1.f);
     }
-    __syncthreads();
+    rsync();
     RCLK(18);
     tape_store(tape + tp.h1, b0, s.h1, F1P, R, F1);
     tape_store(tape + tp.dt2, b0, s.t2, F2P, R, F2);
     RCLK(19);
     dense_bwd_x_i<false, BF>(s.t2, F2P, R, F2, P + d.off_fc[2], F1, s.t1, F1P, a.im.base + a.im.fc[1][1], s.part);     // d h1 (post-dropout)
-    __syncthreads();
+    rsync();
     RCLK(20);
     for (int o = tid; o < R * F1; o += RT) {
         const int oo = (o / F1) * F1P + o % F1;
@@ -1279,13 +1285,13 @@ __global__ __launch_bounds__(BF ? RT_BF : RT_BASE) void read_fwd_bwd_kernel(cons
         const float hv = mk != 0.f ? s.h1[oo] / mk : 0.f;
         s.t1[oo] = s.t1[oo] * mk * (hv > 0.f ? 1.f : hv + 1.f);
     }
-    __syncthreads();
+    rsync();
     RCLK(21);
     tape_store(tape + tp.rep, b0, s.rep, WP, R, W);
     tape_store(tape + tp.dt1, b0, s.t1, F1P, R, F1);
     RCLK(22);
     dense_bwd_x_i<false, BF>(s.t1, F1P, R, F1, P + d.off_fc[0], W, s.drep, WP, a.im.base + a.im.fc[0][1], s.part);   // d bn-output
-    __syncthreads();
+    rsync();
     RCLK(23);
     // bn affine: rep = v*gamma*scale + beta  ->  d gamma, d beta (tape: v and the gradient wrt rep), d v;
     // v = concat_b [q_final_b, last_b]
@@ -1306,12 +1312,12 @@ __global__ __launch_bounds__(BF ? RT_BF : RT_BASE) void read_fwd_bwd_kernel(cons
             off += H + D0;
         }
     }
-    __syncthreads();          // the loop below rescales s.drep in place
+    rsync();          // the loop below rescales s.drep in place
     for (int o = tid; o < R * W; o += RT) {
         const int r = o / W, i = o - r * W;
         s.drep[r * WP + i] *= P[d.off_gamma + i] * bn_scale;            // now: gradient wrt [q_final_b, last_b] of every branch
     }
-    __syncthreads();
+    rsync();
     RCLK(24);
     // ---- the branches ---------------------------------------------------------------------------
     int off = 0;
@@ -1320,7 +1326,7 @@ __global__ __launch_bounds__(BF ? RT_BF : RT_BASE) void read_fwd_bwd_kernel(cons
         if (b >= a.nb) break;
         const int H = a.d[b].H, D0 = a.d[b].D0;
         for (int o = tid; o < R * H; o += RT) s.dq[(o / H) * (H + PADF) + o % H] = s.drep[(o / H) * WP + off + (o % H)];
-        __syncthreads();
+        rsync();
         read_backward_branch<BF>(a.d[b], P, s, s.br[b], R, memory_reg, tape, tp.br[b], a.d_memory[b], a.d_last[b], b0, off + H, W,
                                  a.im, b);
         off += H + D0;
@@ -1447,7 +1453,7 @@ __global__ __launch_bounds__(32 * RRED_G) void read_reduce_kernel(const float *_
     }
     for (; w < ntile; w += RRED_G) s0 += slabs[(long)w * n + ec];
     part[g][c] = (s0 + s1) + (s2 + s3);
-    __syncthreads();
+    rsync();
     if (g != 0 || e >= n) return;
     float tot = part[0][c];
 #pragma unroll

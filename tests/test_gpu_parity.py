@@ -1809,6 +1809,36 @@ def test_split_gradient_kernels_track_the_fp32_kernels_over_200_steps(tmp_path):
     np.testing.assert_allclose(a["pred_final"], b["pred_final"], rtol=0, atol=1e-3)      # the two trained models agree
 
 
+def test_read_training_launch_on_bf16_fragments_tracks_the_fp32_launch(tmp_path):
+    """r5: the read path's TRAINING launch runs its dense layers on v_mfma_f32_16x16x32_bf16 with split
+    operands -- three planes and the six products of order <= 2 in the forward (fp32-equivalent: 2^-24), two planes in the
+    input-gradient products -- from per-step weight fragment images (csrc/read_path.hip: read_wimg_kernel, dense_bf); the r4
+    launch (fp32 matrix instructions, HPMN_READ_BF16=0) is the same arithmetic in fp32.  One compute_gradients each, same seeded
+    weights and batch (two processes: the switch is read once): predictions to 4e-6, loss to 2e-6 relative, every dense
+    variable's gradient to 5e-5 of the gradient's largest element (measured: 1.0e-6 / 3.7e-7 / 8.5e-6), at the XLong slot count
+    (14 of 16 tile rows, an odd batch) and at the Amazon one (H = 32)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for tag, val in (("bf16", "1"), ("fp32", "0")):
+        env = dict(os.environ)
+        env["HPMN_READ_BF16"] = val
+        env["HPMN_DET_SCATTER"] = "1"
+        dst = str(tmp_path / (tag + ".npz"))
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "read_bf_worker.py"), dst], env=env,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        outs.append(np.load(dst))
+    a, b = outs
+    for tag in ("xlong", "small"):
+        np.testing.assert_allclose(a[tag + "_pred"], b[tag + "_pred"], rtol=0, atol=4e-6, err_msg=tag)
+        np.testing.assert_allclose(a[tag + "_ce"], b[tag + "_ce"], rtol=2e-6, atol=0, err_msg=tag)
+        ga, gb = a[tag + "_grad"], b[tag + "_grad"]
+        assert np.isfinite(ga).all() and float(np.abs(gb).max()) > 0
+        assert float(np.abs(ga - gb).max()) <= 5e-5 * float(np.abs(gb).max()), (tag, float(np.abs(ga - gb).max()), float(np.abs(gb).max()))
+        np.testing.assert_allclose(a[tag + "_table_grad_abs"], b[tag + "_table_grad_abs"], rtol=2e-5)
+
+
 @pytest.mark.parametrize("xp_rows", [False, True])
 @pytest.mark.parametrize("T,K,B", [(105, 4, 37), (1001, 7, 21)])
 def test_tile_kernel_h128_matches_the_oracle(dev, tmp_path, monkeypatch, T, K, B, xp_rows):
