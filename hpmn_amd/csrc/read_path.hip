@@ -777,9 +777,12 @@ struct ReadSmem {
     float *mk1;      // [RS][F1]  dropout factor mask/keep_prob of the tile (training)
     float *mk2;      // [RS][F2]
     float *part;     // (training) the K-split layers' partial sums, one 16 x N block per wave (dense_bf_ks)
+    float *wcol;     // the single-column layers' weights + bias: [branch][hop][WCOL] (A2 + 1 used), then the head's [F2 + 1]
     int rs;          // samples per workgroup (the "RS" of the comments above)
 };
 
+constexpr int WCOL = A2 + 4;                 // floats per attention logit layer in s.wcol: 40 weights, the bias, pad
+constexpr int WCOL_HEAD = 2 * MAXHOP * WCOL; // offset of the head's logit layer (F2 weights + bias)
 struct ReadDims { int Kmax, Hmax, Zmax, W; };
 __host__ __device__ inline ReadDims read_dims(const HpmnReadDesc &d0, const HpmnReadDesc &d1, int nb) {
     ReadDims m;
@@ -829,6 +832,7 @@ __host__ __device__ inline size_t carve_all(ReadSmem &s, float *base, const Hpmn
     s.zero = take((size_t)m.Zmax);
     s.mk1 = take((size_t)RS * F1P);
     s.mk2 = take((size_t)RS * F2P);
+    s.wcol = take((size_t)WCOL_HEAD + F2 + 4);
     s.dmem = s.t1 = s.t2 = s.dq = s.tq = s.drep = s.part = nullptr;
     if (train) {
         if (train == 2) s.part = take((size_t)KS_PART_FLOATS);
@@ -899,17 +903,23 @@ __device__ __forceinline__ void read_forward_branch(const HpmnReadDesc &d, const
         dense_fwd_i<1, BF>(x1, A1P, RK, A1, P + oa[2], P + oa[3], A2, x2, A2P, ib + im.att[bi][hop][1][0], s.part);
         rsync();
         RCLK(5);
-        dense_fwd<0>(x2, A2P, RK, A2, P + oa[4], P + oa[5], 1, sc, 1);
+        const float *wc = s.wcol + (bi * MAXHOP + hop) * WCOL;
+        dense_fwd_col<0>(x2, A2P, RK, A2, wc, wc + A2, sc, 1);
         rsync();
         RCLK(6);
-        // softmax over the K slots of each sample (code/hpmn.py:141)
-        if (tid < R) {
-            float mx = -3.4e38f;
-            for (int k = 0; k < K; ++k) mx = fmaxf(mx, sc[tid * K + k]);
-            float den = 0.f;
-            for (int k = 0; k < K; ++k) { const float e = __expf(sc[tid * K + k] - mx); sc[tid * K + k] = e; den += e; }
-            const float inv = 1.f / den;
-            for (int k = 0; k < K; ++k) sc[tid * K + k] *= inv;
+        // softmax over the K slots of each sample (code/hpmn.py:141): a lane per (sample, slot) -- every lane walks its sample's
+        // K scores (independent LDS reads) for the maximum and the denominator; the scores are rewritten behind a barrier
+        // (r4: one thread per sample, three dependent passes over the slots)
+        {
+            float mine = 0.f, mx = -3.4e38f, den = 0.f;
+            const int r = tid / K;
+            if (tid < RK) {
+                for (int k = 0; k < K; ++k) mx = fmaxf(mx, sc[r * K + k]);
+                for (int k = 0; k < K; ++k) den += __expf(sc[r * K + k] - mx);
+                mine = __expf(sc[tid] - mx) / den;
+            }
+            rsync();
+            if (tid < RK) sc[tid] = mine;
         }
         rsync();
         RCLK(7);
@@ -948,10 +958,15 @@ __device__ __forceinline__ void read_forward_branch(const HpmnReadDesc &d, const
         x.ccov[o] = cv;
     }
     rsync();
-    if (tid < R) {
-        float ss = 0.f;
-        for (int o = 0; o < K * K; ++o) { const float cv = x.ccov[tid * K * K + o]; ss = fmaf(cv, cv, ss); }
-        x.cnorm[tid] = sqrtf(ss);
+    {   // (a wave per sample, lanes over the K x K entries; r4: one thread walked them)
+        const int wv = tid >> 6, ln = tid & 63;
+        for (int r = wv; r < R; r += RT / 64) {
+            float ss = 0.f;
+            for (int o = ln; o < K * K; o += 64) { const float cv = x.ccov[r * K * K + o]; ss = fmaf(cv, cv, ss); }
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) ss += __shfl_xor(ss, m);
+            if (ln == 0) x.cnorm[r] = sqrtf(ss);
+        }
     }
     rsync();
     RCLK(10);
@@ -1009,19 +1024,26 @@ __device__ __forceinline__ void read_forward_tile(const ReadArgs &a, const float
         for (int o = tid; o < R * F2P; o += RT) s.h2[o] *= s.mk2[o];
         rsync();
     }
-    dense_fwd<0>(s.h2, F2P, R, F2, P + d0.off_fc[4], P + d0.off_fc[5], 1, s.t3, 1);
+    dense_fwd_col<0>(s.h2, F2P, R, F2, s.wcol + WCOL_HEAD, s.wcol + WCOL_HEAD + F2, s.t3, 1);
     rsync();
     RCLK(15);
 }
 
-__device__ inline void load_tile_inputs(const ReadArgs &a, const ReadSmem &s, long b0, int R) {
+__device__ inline void load_tile_inputs(const ReadArgs &a, const float *P, const ReadSmem &s, long b0, int R) {
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         if (b >= a.nb) break;
         const int K = a.d[b].K, H = a.d[b].H, D0 = a.d[b].D0;
         for (int o = threadIdx.x; o < R * K * H; o += RT) s.br[b].mem[(o / H) * (H + PADF) + o % H] = a.memory[b][b0 * K * H + o];
         for (int o = threadIdx.x; o < R * D0; o += RT) s.br[b].last[(o / D0) * (D0 + PADF) + o % D0] = a.last[b][b0 * D0 + o];
+        // the logit layers' weight column and bias (r5): every use of them from global memory was a round trip of its own on
+        // the workgroup's only path (the forward's wave-per-row reduction: one for the column, one for the bias behind it)
+        for (int o = threadIdx.x; o < a.d[b].hop * (A2 + 1); o += RT) {
+            const int h = o / (A2 + 1), i = o - h * (A2 + 1);
+            s.wcol[(b * MAXHOP + h) * WCOL + i] = P[i < A2 ? a.d[b].off_att[h][4] + i : a.d[b].off_att[h][5]];
+        }
     }
+    for (int o = threadIdx.x; o < F2 + 1; o += RT) s.wcol[WCOL_HEAD + o] = P[o < F2 ? a.d[0].off_fc[4] + o : a.d[0].off_fc[5]];
     // pad columns that elementwise loops sweep: defined values (mask products over whole padded rows)
     for (int o = threadIdx.x; o < s.rs * F1P; o += RT) { s.h1[o] = 0.f; s.mk1[o] = 0.f; }
     for (int o = threadIdx.x; o < s.rs * F2P; o += RT) { s.h2[o] = 0.f; s.mk2[o] = 0.f; }
@@ -1036,7 +1058,7 @@ __global__ __launch_bounds__(RT_BASE) void read_fwd_kernel(const ReadArgs a, con
     const long b0 = (long)blockIdx.x * a.rs;
     const int B = a.d[0].B;
     const int R = (B - b0) < a.rs ? (int)(B - b0) : a.rs;
-    load_tile_inputs(a, s, b0, R);
+    load_tile_inputs(a, P, s, b0, R);
     float *cov = s.t3 + 32;
     read_forward_tile<false>(a, P, s, R, nullptr, nullptr, 1.f, b0, cov);
     const int tid = threadIdx.x;
@@ -1104,10 +1126,16 @@ __device__ __forceinline__ void read_backward_branch(const HpmnReadDesc &d, cons
         rsync();
         RCLK(26);
         // softmax backward: d s_k = sc_k (d sc_k - sum_j sc_j d sc_j)
-        if (tid < R) {
-            float dot = 0.f;
-            for (int k = 0; k < K; ++k) dot = fmaf(sc[tid * K + k], dsc[tid * K + k], dot);
-            for (int k = 0; k < K; ++k) dsc[tid * K + k] = sc[tid * K + k] * (dsc[tid * K + k] - dot);
+        {
+            float mine = 0.f;
+            if (tid < RK) {
+                const int r = tid / K;
+                float dot = 0.f;
+                for (int k = 0; k < K; ++k) dot = fmaf(sc[r * K + k], dsc[r * K + k], dot);
+                mine = sc[tid] * (dsc[tid] - dot);
+            }
+            rsync();
+            if (tid < RK) dsc[tid] = mine;
         }
         rsync();
         RCLK(27);
@@ -1121,11 +1149,17 @@ __device__ __forceinline__ void read_backward_branch(const HpmnReadDesc &d, cons
         // fc3 (A2 -> 1, no activation)
         tape_store(th + tb.x2, b0 * K, x2, A2P, RK, A2);
         tape_store(th + tb.dsc, b0 * K, dsc, 1, RK, 1);
-        dense_bwd_x<false>(dsc, 1, RK, 1, P + oa[4], A2, s.t2, A2P);
+        // d x2 = d sc (x) w3, through the relu in the same pass (r4: an outer-product call that fetched the column from global
+        // memory, a barrier, then the relu pass)
+        {
+            const float *wc = s.wcol + (bi * MAXHOP + hop) * WCOL;
+            for (int o = tid; o < RK * A2; o += RT) {
+                const int row = o / A2, i = o - row * A2;
+                s.t2[row * A2P + i] = x2[row * A2P + i] > 0.f ? dsc[row] * wc[i] : 0.f;
+            }
+        }
         rsync();
         RCLK(28);
-        for (int o = tid; o < RK * A2P; o += RT) s.t2[o] = x2[o] > 0.f ? s.t2[o] : 0.f;      // relu
-        rsync();
         RCLK(29);
         tape_store(th + tb.x1, b0 * K, x1, A1P, RK, A1);
         tape_store(th + tb.dt2, b0 * K, s.t2, A2P, RK, A2);
@@ -1157,15 +1191,13 @@ __device__ __forceinline__ void read_backward_branch(const HpmnReadDesc &d, cons
                 const float *di = s.inp + (size_t)(r * K + k) * IP;
                 acc += di[i] + di[2 * H + i] + di[3 * H + i] * x.mem[(r * K + k) * HP + i];
             }
-            dqn[r * HP + i] = acc;
+            s.dq[r * HP + i] = acc;            // (dq' is no longer needed: its Hmap^T product sits in dqn, its tape copy is out)
         }
         for (int o = tid; o < RK * H; o += RT) {
             const int row = o / H, i = o - row * H;
             const float *di = s.inp + (size_t)row * IP;
             s.dmem[row * HP + i] += di[H + i] - di[2 * H + i] + di[3 * H + i] * q[(row / K) * HP + i];
         }
-        rsync();
-        for (int o = tid; o < R * H; o += RT) { const int r = o / H, i = o - r * H; s.dq[r * HP + i] = dqn[r * HP + i]; }
         rsync();
         RCLK(36);
     }
@@ -1232,7 +1264,7 @@ __global__ __launch_bounds__(BF ? RT_BF : RT_BASE) void read_fwd_bwd_kernel(cons
             warm ^= wb[l * 32];
         }
     }
-    load_tile_inputs(a, s, b0, R);
+    load_tile_inputs(a, P, s, b0, R);
     RCLK(1);
     float *cov = s.t3 + 32;
     read_forward_tile<BF>(a, P, s, R, mask1, mask2, keep_prob, b0, cov);
@@ -1259,16 +1291,16 @@ __global__ __launch_bounds__(BF ? RT_BF : RT_BASE) void read_fwd_bwd_kernel(cons
     // fc3: logit = h2 W3 + b3
     tape_store(tape + tp.h2, b0, s.h2, F2P, R, F2);
     tape_store(tape + tp.dlg, b0, dlg, 1, R, 1);
-    dense_bwd_x<false>(dlg, 1, R, 1, P + d.off_fc[4], F2, s.t2, F2P);        // d h2 (post-dropout)
-    rsync();
     RCLK(17);
-    // through dropout2 and elu2: h2 = elu(a2) * mask/keep.  elu'(a) = a>0 ? 1 : elu(a)+1; recover from h2.
+    // d h2 (post-dropout) = d logit (x) w3, then through dropout2 and elu2 in the same pass: h2 = elu(a2) * mask/keep.
+    // elu'(a) = a>0 ? 1 : elu(a)+1; recover from h2.
     for (int o = tid; o < R * F2; o += RT) {
-        const int oo = (o / F2) * F2P + o % F2;
+        const int r = o / F2, i = o - r * F2;
+        const int oo = r * F2P + i;
         float mk = 1.f;
         if (drop) mk = s.mk2[oo];
         const float hv = mk != 0.f ? s.h2[oo] / mk : 0.f;                    // elu(a2); irrelevant where mask==0
-        s.t2[oo] = s.t2[oo] * mk * (hv > 0.f ? 1.f : hv + 1.f);
+        s.t2[oo] = dlg[r] * s.wcol[WCOL_HEAD + i] * mk * (hv > 0.f ? 1.f : hv + 1.f);
     }
     rsync();
     RCLK(18);
