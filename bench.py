@@ -761,9 +761,9 @@ ALL_FP32_ENV = {"HPMN_WGRAD_BF16": "0", "HPMN_BWD_DX_INLOOP": "0", "HPMN_PROJ_BF
 
 
 def dtype_string(c):
-    # (r5: the read path's TRAINING launch runs its dense layers on the bf16 pipe -- three planes / six products in the forward,
-    #  i.e. fp32-equivalent, two planes / three products in its input-gradient products)
-    read = "read-path training launch: bf16 split operands, 3 planes forward (2^-24), 2 planes input gradients"
+    # (r5: the read path's TRAINING launch runs its dense layers on the bf16 pipe -- three planes per operand, the six products
+    #  of order <= 2: fp32-equivalent, measured 7e-7 of max|grad| from the fp32 launch)
+    read = "read-path training launch: bf16 3-plane split operands, six products = fp32-equivalent"
     if c["H"] == 32:
         return "f32 (%s)" % read
     s = "f32 (%s; GRU weight gradients + layer-0 input gradient: bf16x3 split operands, f32 accumulate" % read

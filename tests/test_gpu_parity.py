@@ -1811,11 +1811,13 @@ def test_split_gradient_kernels_track_the_fp32_kernels_over_200_steps(tmp_path):
 
 def test_read_training_launch_on_bf16_fragments_tracks_the_fp32_launch(tmp_path):
     """r5: the read path's TRAINING launch runs its dense layers on v_mfma_f32_16x16x32_bf16 with split
-    operands -- three planes and the six products of order <= 2 in the forward (fp32-equivalent: 2^-24), two planes in the
-    input-gradient products -- from per-step weight fragment images (csrc/read_path.hip: read_wimg_kernel, dense_bf); the r4
+    operands -- three bf16 planes per fp32 operand and the six products of order <= 2, forward and input-gradient products alike
+    (fp32-equivalent: what is dropped is below 2^-24 of a product) -- from per-step weight fragment images (csrc/read_path.hip: read_wimg_kernel, dense_bf); the r4
     launch (fp32 matrix instructions, HPMN_READ_BF16=0) is the same arithmetic in fp32.  One compute_gradients each, same seeded
     weights and batch (two processes: the switch is read once): predictions to 4e-6, loss to 2e-6 relative, every dense
-    variable's gradient to 5e-5 of the gradient's largest element (measured: 1.0e-6 / 3.7e-7 / 8.5e-6), at the XLong slot count
+    variable's gradient to 5e-6 of the gradient's largest element (measured: 6.3e-7 / 2.2e-7 / 6.8e-7; with TWO planes in the
+    input-gradient products the gradients were at 8.5e-6 and test_three_training_steps_track_the_restatement lost an element
+    to Adam's normalisation -- three planes cost nothing measurable), at the XLong slot count
     (14 of 16 tile rows, an odd batch) and at the Amazon one (H = 32)."""
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -1835,8 +1837,8 @@ def test_read_training_launch_on_bf16_fragments_tracks_the_fp32_launch(tmp_path)
         np.testing.assert_allclose(a[tag + "_ce"], b[tag + "_ce"], rtol=2e-6, atol=0, err_msg=tag)
         ga, gb = a[tag + "_grad"], b[tag + "_grad"]
         assert np.isfinite(ga).all() and float(np.abs(gb).max()) > 0
-        assert float(np.abs(ga - gb).max()) <= 5e-5 * float(np.abs(gb).max()), (tag, float(np.abs(ga - gb).max()), float(np.abs(gb).max()))
-        np.testing.assert_allclose(a[tag + "_table_grad_abs"], b[tag + "_table_grad_abs"], rtol=2e-5)
+        assert float(np.abs(ga - gb).max()) <= 5e-6 * float(np.abs(gb).max()), (tag, float(np.abs(ga - gb).max()), float(np.abs(gb).max()))
+        np.testing.assert_allclose(a[tag + "_table_grad_abs"], b[tag + "_table_grad_abs"], rtol=5e-6)
 
 
 @pytest.mark.parametrize("xp_rows", [False, True])
