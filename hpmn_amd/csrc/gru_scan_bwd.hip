@@ -453,6 +453,12 @@ bool gru_scan_bwd_feed_scatter_ok(int D, int F, int E);      // gru_scan_bwd_fee
 // the atomics lengthen layer 0's launch by 67 us (732 vs 665), and the 140 us scatter launch it removes was hidden anyway --
 // the step's tail is bounded by layer 0's weight gradient (300 us), which now shares the memory system with the late
 // table-Adam pass alone and both get slower (396 + 290 us instead of 303 + 186).
+// HPMN_FUSED_SCATTER=2 (r5): the scatter inside the LOOP of the chain + feeder kernel (D <= 32: the in-loop input gradient's
+// tiles go straight into the table gradient; hpmn_scan_bwd then keeps d_x as the scratch the kernel wants)
+bool gru_scan_bwd_scatter_inloop(int D) {
+    static const int on = [] { const char *e = getenv("HPMN_FUSED_SCATTER"); return e ? atoi(e) : 0; }();
+    return on == 2 && D <= 32;
+}
 bool gru_scan_bwd_fuses_scatter(int H, int B, int D, int F, int E) {
     static const int on = [] { const char *e = getenv("HPMN_FUSED_SCATTER"); return e ? atoi(e) : 0; }();
     return on && H == 64 && bwd_helper_enabled() >= 2 && B <= 640 && gru_scan_bwd_fuses_dx(H, B) &&

@@ -82,7 +82,7 @@ template <int DXD, bool SCAT = false, bool LOOPDX = false, bool CFH = false>
 __global__ __launch_bounds__(256, 1) void gru_scan_bwd_feed_kernel(const HpmnGruBwd a) {
     constexpr int H = 64;
     constexpr bool DX = DXD > 0;
-    static_assert(!LOOPDX || (DXD > 0 && DXD <= 32 && !SCAT), "in-loop input gradient: D = 16 / 32, no fused scatter");
+    static_assert(!LOOPDX || (DXD > 0 && DXD <= 32), "in-loop input gradient: D = 16 / 32");
     constexpr int NSLOT = LOOPDX ? 32 : 2;                                 // operand rows kept in LDS (step parity / ring)
     __shared__ __attribute__((aligned(16))) v4f ringA_[2][FR_STEPS][H];    // dy, k1, k2, k3
     __shared__ __attribute__((aligned(16))) f2 ringB_[2][FR_STEPS][H];     // r, u
@@ -203,6 +203,19 @@ __global__ __launch_bounds__(256, 1) void gru_scan_bwd_feed_kernel(const HpmnGru
         }
         xf4 xacc = {0.f, 0.f, 0.f, 0.f};
         float *dxb = LOOPDX ? a.d_x + (b * (long)T) * DXD + 4 * kg : nullptr;
+        // LOOPDX + SCAT (r5, HPMN_FUSED_SCATTER=2): a finished 16-iteration x 16-column tile goes straight into the table gradient --
+        // column tile ct IS id column ct (E = 16) -- instead of into d_x and through a scatter launch behind the scan.  Branch-free
+        // like the rest of the feeder's loop: the id of the lane's row and the read path's d_last piece are requested when the
+        // tile's first unit starts (five iterations before they are needed); rows that must not be added (the zero prefix, the
+        // masked id 0, clamped lanes) add into the lane's own place of the d_x buffer, which nobody reads.
+        int sc_id = 0, sc_flag = 0;
+        xf4 sc_dl = {0.f, 0.f, 0.f, 0.f};
+        const float *dlb = nullptr;
+        float dlm = 0.f;
+        if constexpr (SCAT && LOOPDX) {
+            dlm = a.d_last != nullptr ? 1.f : 0.f;
+            dlb = (a.d_last != nullptr ? a.d_last + b * (long)DXD : a.wc) + 4 * kg;      // (no d_last: any finite floats, times 0)
+        }
         auto dx_unit = [&](auto uc, int kb) {
             constexpr int U = decltype(uc)::value;
             if constexpr (LOOPDX && U >= 0 && U < NU) {
@@ -214,12 +227,27 @@ __global__ __launch_bounds__(256, 1) void gru_scan_bwd_feed_kernel(const HpmnGru
                 xbf8 bh, bl;
                 split_bf16x8(b0, b1, bh, bl);
                 if constexpr (ks == 0) xacc = xf4{0.f, 0.f, 0.f, 0.f};
+                if constexpr (ks == 0 && SCAT) {
+                    const int t = t_hi - 1 - it, ti = t - a.front_zero;
+                    sc_id = reinterpret_cast<const int *>(a.scatter_ids)[(b * (long)a.Tids + (ti > 0 ? ti : 0)) * a.F + ct];
+                    sc_dl = *reinterpret_cast<const xf4 *>(dlb + 16 * ct);
+                    sc_flag = (it_raw < nsteps && ti >= 0) ? (t == a.last_t ? 2 : 1) : 0;
+                }
                 xacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wAh[U], bh, xacc, 0, 0, 0);
                 xacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wAh[U], bl, xacc, 0, 0, 0);
                 xacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wAl[U], bh, xacc, 0, 0, 0);
                 // (no branch in here -- the feeder's prefetch loads are in flight and a branch's join would wait for all of
                 //  them: a clamped lane holds the last row's result and stores it to the last row's place once more)
-                if constexpr (ks == 5) *reinterpret_cast<xf4 *>(dxb + (long)(t_hi - 1 - it) * DXD + 16 * ct) = xacc;
+                if constexpr (ks == 5 && !SCAT) *reinterpret_cast<xf4 *>(dxb + (long)(t_hi - 1 - it) * DXD + 16 * ct) = xacc;
+                if constexpr (ks == 5 && SCAT) {
+                    const bool ok = sc_flag != 0 && !((a.mask_id0 & HPMN_ID_MASK0) && sc_id == 0);
+                    const float m = sc_flag == 2 ? dlm : 0.f;
+                    float *dst = ok ? a.d_emb + (long)sc_id * 16 + 4 * kg : dxb + (long)(t_hi - 1 - it) * DXD + 16 * ct;
+                    atomicAdd(dst, fmaf(m, sc_dl[0], xacc[0]));
+                    atomicAdd(dst + 1, fmaf(m, sc_dl[1], xacc[1]));
+                    atomicAdd(dst + 2, fmaf(m, sc_dl[2], xacc[2]));
+                    atomicAdd(dst + 3, fmaf(m, sc_dl[3], xacc[3]));
+                }
             }
         };
         auto dx_block = [&](int kb) {            // a whole block at once (behind the unrolled loop, and the last blocks)
@@ -494,6 +522,12 @@ bool gru_scan_bwd_feed_scatter_ok(int D, int F, int E) { return E == 16 && D == 
 template <bool CFH>
 static int feed_launch(const HpmnGruBwd &a, hipStream_t st) {
     const dim3 grid((a.B + 1) / 2);
+    if (a.d_emb != nullptr && a.d_x != nullptr && a.D <= 32) {
+        // the in-loop input gradient with the scatter fused into it (d_x: scratch for the rows that are not added)
+        if (a.D == 16) hipLaunchKernelGGL((gru_scan_bwd_feed_kernel<16, true, true, CFH>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((gru_scan_bwd_feed_kernel<32, true, true, CFH>), grid, dim3(256), 0, st, a);
+        return check_launch();
+    }
     if (a.d_emb != nullptr) {
         if (a.D == 16) hipLaunchKernelGGL((gru_scan_bwd_feed_kernel<16, true, false, CFH>), grid, dim3(256), 0, st, a);
         else if (a.D == 32) hipLaunchKernelGGL((gru_scan_bwd_feed_kernel<32, true, false, CFH>), grid, dim3(256), 0, st, a);

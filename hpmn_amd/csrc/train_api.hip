@@ -25,6 +25,7 @@ bool gru_scan_bwd_fuses_dx(int H, int B);
 bool gru_candidate_elision(int H, int B);
 bool gru_scan_bwd_dx_width_ok(int D);
 bool gru_scan_bwd_fuses_scatter(int H, int B, int D, int F, int E);
+bool gru_scan_bwd_scatter_inloop(int D);
 int embed_grad_scatter_launch(const void *ids, const float *d_x, float *d_emb, int32_t B, int32_t T,
                               int32_t F, int32_t E, int32_t front_zero, int32_t mask_id0, int32_t t_lo, int32_t t_hi,
                               hipStream_t st, const float *d_last = nullptr, int32_t t_last = 0);
@@ -574,7 +575,7 @@ int hpmn_scan_bwd(HpmnTrainCtx *ctx, const HpmnScanDesc *d, const void *ids, con
         if (i == 0 && fused_dx && !has_plan && !(d->mask_id0 & HPMN_ID_I64) &&
             gru_scan_bwd_fuses_scatter(d->H, d->B, D, d->F, d->E)) {
             // ... and goes straight into the table gradient: no d_x buffer, no scatter launch behind layer 0
-            a.d_x = nullptr;
+            if (!gru_scan_bwd_scatter_inloop(D)) a.d_x = nullptr;
             a.scatter_ids = ids; a.d_emb = d_emb; a.Tids = d->T; a.F = d->F; a.E = d->E;
             a.front_zero = d->front_zero; a.mask_id0 = d->mask_id0; a.last_t = L.T[0] + d->last_index;
             a.d_last = d->T + d->last_index >= 0 ? d_last : nullptr;

@@ -1293,7 +1293,8 @@ def test_scans_give_the_same_result_beside_an_unrelated_kernel(dev, tmp_path, B,
     {"HPMN_BWD_DX_WAVE": "0", "HPMN_L0_SPLIT": "1"},                           # separate input-gradient launches, layer 0 split in time
     {"HPMN_PAIR_FWD": "0", "HPMN_PAIR_BWD": "0", "HPMN_PAIR_INFER": "0"},      # one launch per layer (no two-layer launches)
     {"HPMN_PAIR_FWD": "1", "HPMN_PAIR_BWD": "1", "HPMN_FUSED_SCATTER": "1"},   # the other pairing; scatter fused into layer 0's launch
-], ids=["gen1", "one-wave", "dx-launches+split", "no-pairs", "pairs-alt"])
+    {"HPMN_FUSED_SCATTER": "2"},                                               # (r5) the scatter inside the LOOP of layer 0's reverse scan
+], ids=["gen1", "one-wave", "dx-launches+split", "no-pairs", "pairs-alt", "scatter-in-loop"])
 def test_fallback_kernel_paths_still_match_the_oracle(env):
     if env.get("HPMN_FUSED_FWD_GEN") == "1":
         _needs_legacy_build()
