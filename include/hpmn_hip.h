@@ -536,6 +536,10 @@ int hpmn_embed_gather_sum(const void *ids, const float *emb, float *out, int32_t
  *                      allocation -- only parameter positions of its slab part are ever rewritten), and two
  *                      more launches form gW = X^T dY over the batch rows in 16 row chunks and add the chunks
  *                      in a fixed order (deterministic).
+ *                      r5: for K <= 8 slots, H <= 128 the training launch runs its dense layers on the bf16 matrix
+ *                      pipe with three-plane split operands (the six products of order <= 2: fp32-equivalent) out
+ *                      of weight FRAGMENT images it builds in the same workspace with one small launch in front of
+ *                      itself (the size functions include them); HPMN_READ_BF16=0 keeps the fp32 launch.
  * ---------------------------------------------------------------------------------- */
 typedef struct HpmnReadDesc {
     int32_t B, K, H, D0, hop;

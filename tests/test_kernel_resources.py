@@ -89,3 +89,28 @@ def test_tile_evaluation_kernels_keep_their_time_loops_out_of_scratch(tmp_path):
         bars = [i for i, l in enumerate(body) if "s_barrier" in l]
         assert len(bars) >= 10, name
         assert not any("scratch_" in l for l in body[bars[2]:]), name + ": scratch behind the prologue"
+
+
+def test_read_training_launch_on_eight_waves_fits_the_register_file(tmp_path):
+    """r5: the read path's training launch on bf16 fragments runs EIGHT waves per workgroup (two per SIMD): it must fit 256
+    registers per wave -- 257 would not launch at all -- and what the compiler spills to get there must stay small (the first
+    eight-wave build spilled 165 registers; with four column tiles per wave instead of eight: 4).  The fp32 launch and the
+    inference launch keep four waves and two workgroups per CU."""
+    import re
+    text = _assembly(tmp_path, "read_path")
+
+    def facts(prefix):
+        m = re.search(r"^(%s\w*):\s*; @" % prefix, text, re.M)
+        assert m, prefix
+        body = text[m.start():]
+        body = body[:body.index("; Occupancy:") + 40]
+        regs = int(re.search(r"; TotalNumVgprs: (\d+)", body).group(1))
+        occ = int(re.search(r"; Occupancy: (\d+)", body).group(1))
+        scratch = sum(1 for l in body[:body.index("s_endpgm")].split("\n") if "scratch_" in l)
+        return regs, occ, scratch
+
+    regs, occ, scratch = facts("_ZN4hpmn19read_fwd_bwd_kernelILb1")
+    assert regs <= 256 and occ >= 2 and scratch <= 16, (regs, occ, scratch)
+    for prefix in ("_ZN4hpmn19read_fwd_bwd_kernelILb0", "_ZN4hpmn15read_fwd_kernel"):
+        regs, occ, scratch = facts(prefix)
+        assert regs <= 256 and occ >= 2 and scratch == 0, (prefix, regs, occ, scratch)
