@@ -8,7 +8,7 @@ mkdir -p $out
 for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_MFMA" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY"; do
   d=$out/p; rm -rf $d
   timeout 400 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $d -- \
-      python bench.py --config $cfg --steps 4 --warmup 2 --no-eval --no-parity-gate --no-cpu-baseline --no-auc --no-roofline > /dev/null 2> $out/err.txt < /dev/null
+      python bench.py --config $cfg --steps 4 --warmup 2 --no-eval --no-parity-gate --no-cpu-baseline --no-auc --no-roofline --no-side-legs --no-input-pipeline > /dev/null 2> $out/err.txt < /dev/null
   f=$(find $d -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && python - "$f" >> $out/sq_summary.txt <<'PY'
 import csv, sys, collections
