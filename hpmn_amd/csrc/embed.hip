@@ -37,11 +37,11 @@ __global__ __launch_bounds__(256) void embed_gather_kernel(const void *__restric
 // of equal ids and flushes it with one atomic per element when the id changes.  Runs are
 // merely split at segment boundaries.  E must divide 64.
 constexpr int SCU = 8;      // steps per load chunk
-constexpr int SSEG = 128;   // steps per wave
+constexpr int SSEG = 128;   // steps per wave at most (r5: fewer where the launch would otherwise be a few hundred waves, below)
 __global__ __launch_bounds__(64) void embed_grad_scatter_kernel(
     const void *__restrict__ ids, const float *__restrict__ d_x, float *__restrict__ d_emb, int B,
     int T, int F, int E, int front_zero, int mask_id0, int groups, int nseg, int t_lo, int t_hi,
-    const float *__restrict__ d_last, int t_last) {
+    const float *__restrict__ d_last, int t_last, int sseg) {
     const int cpw = 64 / E;                          // E-lane slots per wave
     const int seg = blockIdx.x % nseg;
     const int grp = (blockIdx.x / nseg) % groups;
@@ -57,8 +57,8 @@ __global__ __launch_bounds__(64) void embed_grad_scatter_kernel(
     const int tsub = slot / fpw;
     const int e = lane % E;
     const int Dx = F * E;
-    const int t_begin = t_lo + seg * SSEG;
-    const int t_end = (t_begin + SSEG) < t_hi ? (t_begin + SSEG) : t_hi;
+    const int t_begin = t_lo + seg * sseg;
+    const int t_end = (t_begin + sseg) < t_hi ? (t_begin + sseg) : t_hi;
     const long idp = (b * T) * F + f;               // index of ids[b, 0, f]
     const float *gp = d_x + (b * (long)(front_zero + T) + front_zero) * Dx + f * E + e;
     long run_id = -1;
@@ -200,9 +200,17 @@ int embed_grad_scatter_launch(const void *ids, const float *d_x, float *d_emb, i
     if (B == 0 || t_hi <= t_lo) return HPMN_OK;
     const int cpw = 64 / E;
     const int groups = (F + cpw - 1) / cpw;
-    const int nseg = (t_hi - t_lo + SSEG - 1) / SSEG;
+    // A wave walks its segment in chunks of 8 steps, one memory round trip per chunk: at the Amazon / Taobao shapes (128
+    // sequences of 100 / 300 steps) 128-step segments made the launch 128 / 384 waves of 13 / 16 round trips one behind the other --
+    // 36 / 50 us on the step's tail for 38 k / 154 k lookups.  Segments shrink (not below 16 steps) until the launch has ~2 000
+    // waves; runs of equal ids are merely split at a few more boundaries.  XLong (500 x 1 001 steps) keeps 128.
+    const int want_seg = (int)((2048 + (long)B * groups - 1) / ((long)B * groups));
+    int sseg = (t_hi - t_lo + want_seg - 1) / want_seg;
+    sseg = (sseg + 15) / 16 * 16;
+    sseg = sseg < 16 ? 16 : (sseg > SSEG ? SSEG : sseg);
+    const int nseg = (t_hi - t_lo + sseg - 1) / sseg;
     hipLaunchKernelGGL(embed_grad_scatter_kernel, dim3((unsigned)(B * groups * nseg)), dim3(64), 0, st, ids,
-                       d_x, d_emb, B, T, F, E, front_zero, mask_id0, groups, nseg, t_lo, t_hi, d_last, t_last);
+                       d_x, d_emb, B, T, F, E, front_zero, mask_id0, groups, nseg, t_lo, t_hi, d_last, t_last, sseg);
     return check_launch();
 }
 

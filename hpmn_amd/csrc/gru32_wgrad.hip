@@ -27,14 +27,22 @@ struct Wgrad32Args {
 // slab of one workgroup: rows (D + 32 features + 1 bias row) x 96 columns, row-major
 __host__ __device__ inline long wgrad32_slab_floats(int D) { return (long)(D + 33) * 96; }
 
-__global__ __launch_bounds__(256) void gru32_wgrad_all_kernel(const Wgrad32Args a) {
+// r5: EIGHT waves -- two halves of the time axis x four tile waves.  A workgroup is one sequence (B < 256) whose 100 steps
+// were 13 groups of 8 steps, one memory round trip per group, one behind the other: 40 us for 100 MFLOP on the tail of the
+// Amazon step.  More workgroups per sequence would mean more slabs (31 KB each, written and read back); here the second half's
+// waves hand their accumulators to the first half's through LDS and the workgroup still writes ONE slab.
+constexpr int W32_PIECES = 2;
+__global__ __launch_bounds__(256 * W32_PIECES) void gru32_wgrad_all_kernel(const Wgrad32Args a) {
     constexpr int H = 32;
     const int L = blockIdx.y;
     const int D = a.D[L], T = a.T[L];
     const int NR = D + H + 1;                           // operand rows ("features"): x | h_prev | 1
     const int nrt = (NR + 31) / 32;                     // 32-row tiles of the output
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = (threadIdx.x >> 6) & 3, piece = threadIdx.x >> 8, lane = threadIdx.x & 63;
     const int c = lane & 31, kk = lane >> 5;            // column within a tile, k index (row parity)
+    // this half's steps: whole groups of 8
+    const int ngrp = (T + 7) / 8, g0 = piece == 0 ? 0 : (ngrp + 1) / 2, g1 = piece == 0 ? (ngrp + 1) / 2 : ngrp;
+    const int t_begin = 8 * g0, t_stop = 8 * g1 < T ? 8 * g1 : T;
     const int b0 = blockIdx.x * a.spw;
     const int b1 = b0 + a.spw < a.B ? b0 + a.spw : a.B;
     const float *X = a.x[L], *HS = a.hs[L], *G = a.gates[L], *DA = a.d_act[L];
@@ -52,7 +60,7 @@ __global__ __launch_bounds__(256) void gru32_wgrad_all_kernel(const Wgrad32Args 
         // four 2-step MFMA operand pairs per tile in flight: the loads of a group are issued before its matrix instructions
         // (one dependent L2 round trip per k-step left the launch at 69 us for 100 MFLOP)
         constexpr int UN = 4;
-        for (int t0 = 0; t0 < T; t0 += 2 * UN) {
+        for (int t0 = t_begin; t0 < t_stop; t0 += 2 * UN) {
             float av[MAXT][UN], bv[MAXT][UN];
 #pragma unroll
             for (int q = 0; q < MAXT; ++q) {
@@ -63,7 +71,7 @@ __global__ __launch_bounds__(256) void gru32_wgrad_all_kernel(const Wgrad32Args 
 #pragma unroll
                 for (int s2 = 0; s2 < UN; ++s2) {
                     const int t = t0 + 2 * s2 + kk;
-                    const bool live = on && t < T;
+                    const bool live = on && t < t_stop;
                     const int tc = t < T ? t : T - 1;
                     float v = 0.f;
                     if (f < D) v = xb[(long)tc * D + f];
@@ -86,6 +94,20 @@ __global__ __launch_bounds__(256) void gru32_wgrad_all_kernel(const Wgrad32Args 
             }
         }
     }
+    // the second half's accumulators -> the first half's, lane for lane
+    __shared__ float red[4][MAXT * 16][64];
+    if (piece == 1) {
+#pragma unroll
+        for (int q = 0; q < MAXT; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[wave][q * 16 + r][lane] = acc[q][r];
+    }
+    __syncthreads();
+    if (piece == 1) return;
+#pragma unroll
+    for (int q = 0; q < MAXT; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] += red[wave][q * 16 + r][lane];
     // C/D layout of 32x32x2: rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column lane & 31
     float *slab = a.slab[L] + (long)blockIdx.x * wgrad32_slab_floats(D);
 #pragma unroll
@@ -102,22 +124,32 @@ __global__ __launch_bounds__(256) void gru32_wgrad_all_kernel(const Wgrad32Args 
     }
 }
 
-// d_w += sum over workgroups of the slabs; blockIdx.y = layer.  One thread per element, slabs summed in order.
-__global__ __launch_bounds__(256) void gru32_wgrad_reduce_kernel(const Wgrad32Args a) {
+// d_w += sum over workgroups of the slabs; blockIdx.y = layer.  r5: 32 elements x 8 groups per workgroup -- group g adds slabs
+// g, g + 8, ... (four running sums), the groups' sums are added in order: deterministic as before (one thread per element walked
+// all 128 slabs: 32 dependent round trips, 17 us on the Amazon step's tail).
+constexpr int RG32 = 8;
+__global__ __launch_bounds__(32 * RG32) void gru32_wgrad_reduce_kernel(const Wgrad32Args a) {
     constexpr int H = 32;
+    __shared__ float part[RG32][32];
     const int L = blockIdx.y;
     const int D = a.D[L];
     const long n = wgrad32_slab_floats(D);
-    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n) return;
-    const float *s = a.slab[L] + e;
+    const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const long e = (long)blockIdx.x * 32 + c;
+    const long ec = e < n ? e : n - 1;
+    const float *s = a.slab[L] + ec;
     float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
-    int w = 0;
-    for (; w + 3 < a.nwg; w += 4) {
-        t0 += s[(long)w * n]; t1 += s[(long)(w + 1) * n]; t2 += s[(long)(w + 2) * n]; t3 += s[(long)(w + 3) * n];
+    int w = g;
+    for (; w + 3 * RG32 < a.nwg; w += 4 * RG32) {
+        t0 += s[(long)w * n]; t1 += s[(long)(w + RG32) * n]; t2 += s[(long)(w + 2 * RG32) * n]; t3 += s[(long)(w + 3 * RG32) * n];
     }
-    for (; w < a.nwg; ++w) t0 += s[(long)w * n];
-    const float tot = (t0 + t1) + (t2 + t3);
+    for (; w < a.nwg; w += RG32) t0 += s[(long)w * n];
+    part[g][c] = (t0 + t1) + (t2 + t3);
+    __syncthreads();
+    if (g != 0 || e >= n) return;
+    float tot = part[0][c];
+#pragma unroll
+    for (int k = 1; k < RG32; ++k) tot += part[k][c];
     const int row = (int)(e / 96), col = (int)(e - (long)row * 96);
     if (row < D + H) {
         if (col < 2 * H) a.d_wg[L][(long)row * 2 * H + col] += tot;
@@ -155,10 +187,10 @@ int gru32_wgrad_all_launch(int B, int K, const int *D, const int *T, const float
         off += (long)a.nwg * n;
         nmax = n > nmax ? n : nmax;
     }
-    hipLaunchKernelGGL(gru32_wgrad_all_kernel, dim3(a.nwg, K), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(gru32_wgrad_all_kernel, dim3(a.nwg, K), dim3(256 * W32_PIECES), 0, st, a);
     int rc = check_launch();
     if (rc != HPMN_OK) return rc;
-    hipLaunchKernelGGL(gru32_wgrad_reduce_kernel, dim3((unsigned)((nmax + 255) / 256), K), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(gru32_wgrad_reduce_kernel, dim3((unsigned)((nmax + 31) / 32), K), dim3(32 * RG32), 0, st, a);
     return check_launch();
 }
 
