@@ -73,12 +73,16 @@ __global__ __launch_bounds__(256 * W32_PIECES) void gru32_wgrad_all_kernel(const
                     const int t = t0 + 2 * s2 + kk;
                     const bool live = on && t < t_stop;
                     const int tc = t < T ? t : T - 1;
-                    float v = 0.f;
-                    if (f < D) v = xb[(long)tc * D + f];
-                    else if (f < D + H) {
-                        v = hb[(long)tc * H + (f - D)];
-                        if (ct == 2) v *= gb[(long)tc * 3 * H + (f - D)];          // r * h_prev for the candidate columns
-                    } else if (f == D + H) v = 1.f;
+                    // BRANCH-FREE (r5): which operand a lane feeds -- an x column, a state column (times r for the candidate
+                    // columns), the bias row's 1 -- differs from lane to lane inside a tile, and as branches around the loads
+                    // every one of the group's 12 operand fetches was waited for at its join: 12 round trips per group
+                    // instead of one, 37 us for 100 MFLOP.  Addresses are selected, every load is issued, values are selected.
+                    const bool is_x = f < D, is_h = !is_x && f < D + H;
+                    const int fh = is_h ? f - D : 0;
+                    const float *src = is_x ? xb + (long)tc * D + f : hb + (long)tc * H + fh;
+                    const float raw = *src;
+                    const float rg = gb[(long)tc * 3 * H + fh];
+                    float v = is_x ? raw : (is_h ? raw * (ct == 2 ? rg : 1.f) : (f == D + H ? 1.f : 0.f));
                     av[q][s2] = live ? v : 0.f;
                     const float w = db[(long)tc * 3 * H + 32 * ct + c];
                     bv[q][s2] = live ? w : 0.f;
