@@ -603,19 +603,26 @@ class Hpmn_Basic(object):
                                keep_prob, 1.0 / float(global_batch), self.memory_reg, dropout_seed=seed,
                                loss_out=self._loss_acc, defer_param_grads=True)
         self._loss_acc_clean = False
-        if aux is not main:
-            aux.wait_stream(main)
-        with torch.cuda.stream(aux):
+        sums = (torch.empty if ids.shape[0] > 0 else torch.zeros)(3, device=self.device, dtype=torch.float32)
+
+        def read_param_grads():
             # the read path's weight gradients (only the optimiser needs them: off the serial chain where there is an
             # auxiliary stream) and, from the same two launches, the loss scalars + the cleared accumulator
-            sums = (torch.empty if ids.shape[0] > 0 else torch.zeros)(3, device=self.device, dtype=torch.float32)
-            out.pop("reduce_param_grads")(sums)
-            self._loss_acc_clean = True
-            out["log_loss_sum"], out["memory_loss"], ce = sums[0], sums[1], sums[2]
-            if aux is not main:
-                sums.record_stream(main)
-            if callable(rest2):
-                rest2()                                      # (second part of the early table-Adam pass: beside BPTT)
+            with torch.cuda.stream(aux):
+                out.pop("reduce_param_grads")(sums)
+                self._loss_acc_clean = True
+                if aux is not main:
+                    sums.record_stream(main)
+                if callable(rest2):
+                    rest2()                                  # (second part of the early table-Adam pass: beside BPTT)
+
+        # (small tables keep their housekeeping on the caller's stream: there the two launches go BEHIND the reverse scans
+        #  -- r5: in front of them they were 15 us of the Amazon step's serial chain, behind them they fill the slack the
+        #  table update's chain has against the GRU weight gradients' on the helper stream)
+        if aux is not main:
+            aux.wait_stream(main)
+            read_param_grads()
+        out["log_loss_sum"], out["memory_loss"], ce = sums[0], sums[1], sums[2]
         if self.lazy_table_adam:
             # touched rows only: the scatter goes to a COMPACT [U, E] buffer through ids remapped to 0..U-1 (row 0 of
             # it stays original id 0, so the id-0 mask of the Hpmn graph keeps working on the remapped ids)
@@ -638,6 +645,8 @@ class Hpmn_Basic(object):
         pending = ops.scan_backward(self.spec, scatter_ids, saved, weights, out["d_memory"], out["d_last"], grad_out,
                                     defer_join=defer_join and not self.l2_reg, scatter_plan=plan)
         out["pending"] = pending
+        if aux is main:
+            read_param_grads()
         if callable(rest):
             # HPMN_EARLY_PASS=bwd: the early table-Adam pass beside layer 0's REVERSE launch instead of beside its forward
             # (which can then be one of the two-layer launches, HPMN_PAIR_FWD=1)
