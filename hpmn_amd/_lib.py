@@ -10,7 +10,7 @@ import os
 from typing import Optional
 
 HPMN_MAX_LAYERS = 12
-HPMN_ABI_VERSION = 12
+HPMN_ABI_VERSION = 13
 HPMN_MAX_RANKS = 8
 HPMN_MAX_CHUNKS = 32
 HPMN_FWD_NO_CANDIDATE = 1
@@ -280,6 +280,9 @@ SIGNATURES = {
     "hpmn_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                  C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                  C.c_void_p]),
+    "hpmn_adam_step_clear": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                       C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                       C.c_void_p]),
 }
 
 

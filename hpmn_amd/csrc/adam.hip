@@ -15,7 +15,11 @@ __device__ __forceinline__ void adam_elem(float &p, float g, float &m, float &v,
     p -= lr_t * m / (sqrtf(v) + eps);
 }
 
-__global__ __launch_bounds__(256) void adam_kernel_v4(float4 *__restrict__ p, const float4 *__restrict__ g,
+// CLEAR (hpmn_adam_step_clear, ABI v13): the gradient is CONSUMED -- written back as zeros -- so that the caller's next step
+// needs no clearing launch in front of its first kernel (the Amazon step began with a 6.4 us fill of its 16 MB gradient buffer
+// on the only stream it has; +4 B per element here, in a launch that streams 28)
+template <bool CLEAR>
+__global__ __launch_bounds__(256) void adam_kernel_v4(float4 *__restrict__ p, float4 *__restrict__ g,
                                                       float4 *__restrict__ m, float4 *__restrict__ v, long n4,
                                                       float lr_t, float b1, float b2, float eps, float clip,
                                                       float gs) {
@@ -23,6 +27,7 @@ __global__ __launch_bounds__(256) void adam_kernel_v4(float4 *__restrict__ p, co
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
         float4 pp = p[i], mm = m[i], vv = v[i];
         const float4 gg = g[i];
+        if (CLEAR) g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         adam_elem(pp.x, gg.x, mm.x, vv.x, lr_t, b1, b2, eps, clip, gs);
         adam_elem(pp.y, gg.y, mm.y, vv.y, lr_t, b1, b2, eps, clip, gs);
         adam_elem(pp.z, gg.z, mm.z, vv.z, lr_t, b1, b2, eps, clip, gs);
@@ -31,14 +36,17 @@ __global__ __launch_bounds__(256) void adam_kernel_v4(float4 *__restrict__ p, co
     }
 }
 
-__global__ __launch_bounds__(256) void adam_kernel_v1(float *__restrict__ p, const float *__restrict__ g,
+template <bool CLEAR>
+__global__ __launch_bounds__(256) void adam_kernel_v1(float *__restrict__ p, float *__restrict__ g,
                                                       float *__restrict__ m, float *__restrict__ v, long n,
                                                       float lr_t, float b1, float b2, float eps, float clip,
                                                       float gs) {
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         float pp = p[i], mm = m[i], vv = v[i];
-        adam_elem(pp, g[i], mm, vv, lr_t, b1, b2, eps, clip, gs);
+        const float gi = g[i];
+        if (CLEAR) g[i] = 0.f;
+        adam_elem(pp, gi, mm, vv, lr_t, b1, b2, eps, clip, gs);
         p[i] = pp; m[i] = mm; v[i] = vv;
     }
 }
@@ -164,8 +172,9 @@ int adam_rows_launch(float *p, const float *g, float *m, float *v, const int64_t
     return check_launch();
 }
 
-int adam_launch(float *p, const float *g, float *m, float *v, int64_t n, float lr_t, float b1, float b2,
-                float eps, float clip, float gs, hipStream_t st) {
+template <bool CLEAR>
+static int adam_launch_t(float *p, float *g, float *m, float *v, int64_t n, float lr_t, float b1, float b2,
+                         float eps, float clip, float gs, hipStream_t st) {
     if (n == 0) return HPMN_OK;
     const bool aligned = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) |
                            reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15) == 0;
@@ -173,15 +182,24 @@ int adam_launch(float *p, const float *g, float *m, float *v, int64_t n, float l
         const long n4 = n / 4;
         long blocks = (n4 + 255) / 256;
         if (blocks > 256L * 16) blocks = 256L * 16;
-        hipLaunchKernelGGL(adam_kernel_v4, dim3((unsigned)blocks), dim3(256), 0, st, (float4 *)p,
-                           (const float4 *)g, (float4 *)m, (float4 *)v, n4, lr_t, b1, b2, eps, clip, gs);
+        hipLaunchKernelGGL(adam_kernel_v4<CLEAR>, dim3((unsigned)blocks), dim3(256), 0, st, (float4 *)p,
+                           (float4 *)g, (float4 *)m, (float4 *)v, n4, lr_t, b1, b2, eps, clip, gs);
     } else {
         long blocks = (n + 255) / 256;
         if (blocks > 256L * 16) blocks = 256L * 16;
-        hipLaunchKernelGGL(adam_kernel_v1, dim3((unsigned)blocks), dim3(256), 0, st, p, g, m, v, (long)n, lr_t,
+        hipLaunchKernelGGL(adam_kernel_v1<CLEAR>, dim3((unsigned)blocks), dim3(256), 0, st, p, g, m, v, (long)n, lr_t,
                            b1, b2, eps, clip, gs);
     }
     return check_launch();
+}
+
+int adam_launch(float *p, const float *g, float *m, float *v, int64_t n, float lr_t, float b1, float b2,
+                float eps, float clip, float gs, hipStream_t st) {
+    return adam_launch_t<false>(p, const_cast<float *>(g), m, v, n, lr_t, b1, b2, eps, clip, gs, st);      // (never written)
+}
+int adam_clear_launch(float *p, float *g, float *m, float *v, int64_t n, float lr_t, float b1, float b2,
+                      float eps, float clip, float gs, hipStream_t st) {
+    return adam_launch_t<true>(p, g, m, v, n, lr_t, b1, b2, eps, clip, gs, st);
 }
 
 }  // namespace hpmn

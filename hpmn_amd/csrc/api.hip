@@ -58,6 +58,8 @@ int embed_grad_scatter_launch(const void *ids, const float *d_x, float *d_emb, i
                               hipStream_t st, const float *d_last = nullptr, int32_t t_last = 0);
 int adam_launch(float *p, const float *g, float *m, float *v, int64_t n, float lr_t, float b1, float b2,
                 float eps, float clip, float gs, hipStream_t st);
+int adam_clear_launch(float *p, float *g, float *m, float *v, int64_t n, float lr_t, float b1, float b2,
+                      float eps, float clip, float gs, hipStream_t st);
 int table_mark_launch(const void *ids, int64_t n, uint8_t *flags, int64_t V, int32_t id_flags, hipStream_t st);
 int scatter_plan_launch(const void *sorted_ids, int32_t id_flags, int64_t n, const int32_t *seg, int32_t *start, void *rows,
                         int32_t *count, hipStream_t st);
@@ -550,6 +552,15 @@ int hpmn_adam_step(float *param, const float *grad, float *m, float *v, int64_t 
     if (n == 0) return HPMN_OK;
     if (!param || !grad || !m || !v) return HPMN_EINVAL;
     return adam_launch(param, grad, m, v, n, lr_t, beta1, beta2, eps, clip, grad_scale, (hipStream_t)stream);
+}
+
+int hpmn_adam_step_clear(float *param, float *grad, float *m, float *v, int64_t n, float lr_t, float beta1,
+                         float beta2, float eps, float clip, float grad_scale, void *stream) {
+    drop_stale_hip_error();
+    if (n < 0) return HPMN_EINVAL;
+    if (n == 0) return HPMN_OK;
+    if (!param || !grad || !m || !v) return HPMN_EINVAL;
+    return adam_clear_launch(param, grad, m, v, n, lr_t, beta1, beta2, eps, clip, grad_scale, (hipStream_t)stream);
 }
 
 int hpmn_adam_step_rows(float *param, const float *grad_rows, float *m, float *v, const int64_t *row_ids,

@@ -154,6 +154,7 @@ class Hpmn_Basic(object):
     _dp = False                  # data-parallel code paths on (set in __init__: world > 1, or forced collectives)
     compact_table_grad = False   # (set in __init__, _decide_compact_table_grad)
     _prefetched = None
+    _flat_grad_clean = False
     _preset_plan = None
     _plan_stream = None
 
@@ -322,6 +323,8 @@ class Hpmn_Basic(object):
         self.flat_grad = torch.zeros(n - self._goff, device=dev, dtype=torch.float32)
         self._loss_acc = torch.zeros(2, device=dev, dtype=torch.float32)      # log-loss sum, memory-loss sum of a step
         self._loss_acc_clean = True
+        # (r5) the plain train_step's Adam launches consume the gradient (hpmn_adam_step_clear): all-zero again behind them
+        self._flat_grad_clean = True
         # two-pass dense table Adam (train_step): rows the batch points at / whether the table gradient is all-zero
         self._row_flags: Optional[torch.Tensor] = None
         self._table_grad_clean = True
@@ -498,9 +501,11 @@ class Hpmn_Basic(object):
         B = ids.shape[0]
         if global_batch is None:
             global_batch = B * self.world
+        grad_was_clean, self._flat_grad_clean = self._flat_grad_clean, False
         if B == 0 or not self._hip_read:
             self.flat_grad.zero_()
             self._table_grad_clean = True
+            self._flat_grad_clean = B == 0
         if B == 0:
             return dict(prediction=torch.empty(0, device=self.device)), torch.zeros((), device=self.device)
         if not self._hip_read:
@@ -563,8 +568,8 @@ class Hpmn_Basic(object):
             rest = None
             if _clear_grads is not None:
                 rest = _clear_grads()                        # train_step's two-pass table update (see there)
-            else:
-                self.flat_grad.zero_()
+            elif not grad_was_clean:
+                self.flat_grad.zero_()                       # (the plain train_step leaves it all-zero: no launch here then)
             if not self._loss_acc_clean:
                 self._loss_acc.zero_()                       # (normally the previous step's reduce launch has cleared it)
             if callable(rest):
@@ -753,13 +758,15 @@ class Hpmn_Basic(object):
             works = [dist.allreduce_sum_async(self.flat_grad[a:b]) for a, b in bounds]
             for i, ((a, b), w) in enumerate(zip(bounds, works)):
                 w.wait()                                     # orders the current stream after the collective
-                self.apply_gradients(a, b, advance=(i == 0))
+                self.apply_gradients(a, b, advance=(i == 0), clear=True)
         else:
-            self.apply_gradients(0, n_emb, advance=True)
+            self.apply_gradients(0, n_emb, advance=True, clear=True)
         if pending is not None:
             pending.join()
         dist.allreduce_sum_(self.flat_grad[n_emb:])
-        self.apply_gradients(n_emb, self.flat_param.numel(), advance=False)
+        self.apply_gradients(n_emb, self.flat_param.numel(), advance=False, clear=True)
+        # (every element of the flat gradient has been consumed by a clearing Adam launch -- unless the table went the sharded way)
+        self._flat_grad_clean = not (self._dp and self.table_exchange == "sharded")
         return out, ce
 
     # ------------------------------------------------------------------ dense table Adam in two passes
@@ -1232,9 +1239,9 @@ class Hpmn_Basic(object):
             g[plan.rows[:u].long()] = plan.out_rows[:u]
         return g
 
-    def apply_gradients(self, lo: int = 0, hi: Optional[int] = None, advance: bool = True):
+    def apply_gradients(self, lo: int = 0, hi: Optional[int] = None, advance: bool = True, clear: bool = False):
         """clip + TF-form Adam over elements [lo, hi) of the flat buffers (default: everything);
-        ``advance`` = this call starts a new optimiser step."""
+        ``advance`` = this call starts a new optimiser step; ``clear``: the gradient elements are consumed (left zero)."""
         if self.compact_table_grad:
             raise RuntimeError("compact_table_grad: there is no dense table gradient to sweep -- use train_step "
                                "(HPMN_TABLE_GRAD=dense restores the flat gradient over the table)")
@@ -1245,7 +1252,7 @@ class Hpmn_Basic(object):
         hi = self.flat_param.numel() if hi is None else hi
         with torch.no_grad():
             ops.adam_step(self.flat_param[lo:hi], self.flat_grad[lo:hi], self.flat_m[lo:hi], self.flat_v[lo:hi],
-                          lr_t, self.beta1, self.beta2, self.adam_eps, clip=1.0)
+                          lr_t, self.beta1, self.beta2, self.adam_eps, clip=1.0, clear_grad=clear)
 
     # ------------------------------------------------------------------ datasets
     def _dev(self, dataset) -> _DeviceDataset:

@@ -381,14 +381,16 @@ def embed_grad_scatter(ids, d_x, d_emb, front_zero, mask_id0):
     _lib.check(rc, "hpmn_embed_grad_scatter")
 
 
-def adam_step(param, grad, m, v, lr_t, beta1=0.9, beta2=0.999, eps=1e-8, clip=1.0, grad_scale=1.0):
-    """hpmn_adam_step over flat fp32 buffers (code/hpmn.py:209-214)."""
+def adam_step(param, grad, m, v, lr_t, beta1=0.9, beta2=0.999, eps=1e-8, clip=1.0, grad_scale=1.0, clear_grad=False):
+    """hpmn_adam_step over flat fp32 buffers (code/hpmn.py:209-214).  ``clear_grad``: hpmn_adam_step_clear -- the gradient is
+    consumed (left all-zero for the next step)."""
     _chk_f32(param, grad, m, v)
     n = param.numel()
     assert grad.numel() == n and m.numel() == n and v.numel() == n
-    rc = _lib.load().hpmn_adam_step(param.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(), n,
-                                     lr_t, beta1, beta2, eps, clip, grad_scale, _stream())
-    _lib.check(rc, "hpmn_adam_step")
+    fn = _lib.load().hpmn_adam_step_clear if clear_grad else _lib.load().hpmn_adam_step
+    rc = fn(param.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(), n, lr_t, beta1, beta2, eps, clip, grad_scale,
+            _stream())
+    _lib.check(rc, "hpmn_adam_step_clear" if clear_grad else "hpmn_adam_step")
 
 
 def adam_step_rows(param, grad_rows, m, v, row_ids, lr_t, beta1=0.9, beta2=0.999, eps=1e-8, clip=1.0, grad_scale=1.0):

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define HPMN_ABI_VERSION 12
+#define HPMN_ABI_VERSION 13
 #define HPMN_ID_MASK0 1   /* id-flags bit 0: id 0 gathers a zero row and receives no gradient (the Hpmn class)  */
 #define HPMN_ID_I64 2     /* id-flags bit 1: the ids tensor is int64 (default: int32)                          */
 #define HPMN_MAX_LAYERS 12
@@ -611,6 +611,12 @@ int hpmn_embed_grad_scatter(const void *ids, const float *d_x, float *d_emb,
 int hpmn_adam_step(float *param, const float *grad, float *m, float *v, int64_t n,
                    float lr_t, float beta1, float beta2, float eps, float clip,
                    float grad_scale, void *stream);
+/* (ABI v13) The same update, and the gradient it has consumed is written back as ZEROS: a caller that keeps one flat
+ * gradient buffer (code/hpmn.py:204-214 densifies every gradient) then needs no clearing launch in front of its next
+ * step -- at the Amazon shape that launch was 6 us of a 0.26 ms step, on the only stream. */
+int hpmn_adam_step_clear(float *param, float *grad, float *m, float *v, int64_t n,
+                         float lr_t, float beta1, float beta2, float eps, float clip,
+                         float grad_scale, void *stream);
 /* Row-wise ("lazy") form for embedding tables too large for the dense sweep (BASELINE configs[4]: a table
  * sized to HBM cannot also hold a dense gradient, and 28 B/element of dense Adam traffic over 10^9+ rows is the
  * whole step): the same update applied only to the n_rows table rows row_ids[u] (distinct), whose clipped

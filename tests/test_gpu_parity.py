@@ -573,6 +573,22 @@ def test_table_adam_in_two_passes_is_bit_identical_to_the_dense_kernel(dev, E):
     assert float(grad.abs().max()) == 0.0 and int(flags.max()) == 0
 
 
+@pytest.mark.parametrize("n", [4 * 1000 + 4, 1237])
+def test_adam_step_clear_is_adam_step_and_consumes_the_gradient(dev, n):
+    """hpmn_adam_step_clear (ABI v13): bit for bit the update of hpmn_adam_step (clip + TF-form Adam, code/hpmn.py:209-214), and
+    the gradient buffer is all-zero behind it (vectorised and scalar forms: n % 4 == 0 aligned / an odd length)."""
+    from hpmn_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(3 + n)
+    mk = lambda s: (torch.randn(n, generator=g) * s).to(dev)
+    p, grad, m, v = mk(1.0), mk(2.0), mk(0.1), mk(0.01).abs()
+    ref = [t.clone() for t in (p, m, v)]
+    ops.adam_step(ref[0], grad.clone(), ref[1], ref[2], 0.0021)
+    ops.adam_step(p, grad, m, v, 0.0021, clear_grad=True)
+    torch.cuda.synchronize()
+    assert torch.equal(p, ref[0]) and torch.equal(m, ref[1]) and torch.equal(v, ref[2])
+    assert float(grad.abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("industry", [False, True])
 def test_three_training_steps_track_the_restatement(dev, tmp_path, industry):
     """sess.run(train_step) x3 with keep_prob 1 (dropout RNG cannot be matched): parameters after
