@@ -573,6 +573,31 @@ def test_table_adam_in_two_passes_is_bit_identical_to_the_dense_kernel(dev, E):
     assert float(grad.abs().max()) == 0.0 and int(flags.max()) == 0
 
 
+def test_plain_train_step_leaves_the_flat_gradient_all_zero_and_skips_the_clearing_launch(dev, tmp_path):
+    """r5: the small-table train_step's Adam launches consume the gradient (hpmn_adam_step_clear), so the next
+    compute_gradients finds an all-zero buffer and issues no clearing launch; a buffer somebody else left dirty is still
+    cleared.  Gradients after train_step + compute_gradients == gradients of compute_gradients on a fresh model state."""
+    cfg = cfg_amazon(K=3, T=60, V=150)
+    p = f32_params(cfg, 301)
+    ids, label = rand_ids(cfg, 9, 302)
+    ti, tl = torch.as_tensor(ids).to(dev), torch.as_tensor(label).to(dev)
+    m = make_model(cfg, tmp_path, p, lr=0.002)
+    assert not m._two_pass_table_adam(ti) and not m.compact_table_grad          # (the plain path)
+    m.train_step(ti, tl, keep_prob=1.0)
+    torch.cuda.synchronize()
+    assert m._flat_grad_clean and float(m.flat_grad.abs().max()) == 0.0
+    m.compute_gradients(ti, tl, keep_prob=1.0)                                   # (no clearing launch: the buffer is clean)
+    g1 = m.flat_grad.clone()
+    assert not m._flat_grad_clean and float(g1.abs().max()) > 0
+    m.compute_gradients(ti, tl, keep_prob=1.0)                                   # (dirty: cleared first, not accumulated into)
+    tol = 2e-6 * float(g1.abs().max())                                           # (the scatter's atomics)
+    assert float((m.flat_grad - g1).abs().max()) <= tol
+    # the same parameters in a second model whose buffer was never touched by a clearing Adam launch
+    m2 = make_model(cfg, tmp_path, {k: v.detach().cpu().numpy() for k, v in m.params.items()}, lr=0.002)
+    m2.compute_gradients(ti, tl, keep_prob=1.0)
+    assert float((m2.flat_grad - g1).abs().max()) <= tol
+
+
 @pytest.mark.parametrize("n", [4 * 1000 + 4, 1237])
 def test_adam_step_clear_is_adam_step_and_consumes_the_gradient(dev, n):
     """hpmn_adam_step_clear (ABI v13): bit for bit the update of hpmn_adam_step (clip + TF-form Adam, code/hpmn.py:209-214), and
