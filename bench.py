@@ -697,7 +697,7 @@ def cpu_baseline(c, seed=0, budget_s=25.0):
                       % (len(tt), bs, c["name"], warm, threads, sum(tt), len(tf))}
 
 
-def dp_report(model, c, batches, world, ms_per_step, n_model=8, busbw_gbps=300.0, one_rank=None):
+def dp_report(model, c, batches, world, ms_per_step, n_model=8, busbw_gbps=300.0, one_rank=None, laws=None, standin=None):
     """Per-step collective bytes of the data-parallel step, measured on this run's batches, and a MODEL of what they cost
     at N = 8 (no multi-GPU box is available to the builder: the driver's SCALE run is the measurement).  The model:
     ring collectives at ``busbw_gbps`` GB/s of bus bandwidth per rank (an assumption -- 7 xGMI links x ~153 GB/s peak,
@@ -721,7 +721,8 @@ def dp_report(model, c, batches, world, ms_per_step, n_model=8, busbw_gbps=300.0
     base = lambda mode: (one_rank.get(mode) or ms_per_step)
     eff = lambda t, mode: ms_per_step / (base(mode) + max(0.0, t - hide_ms) + small_b / busbw_gbps / 1e6 + 0.02)
     if world == 1:
-        laws = id_law_report(c, n_model, E, busbw_gbps) if c["V"] * E <= (1 << 28) else None
+        if laws is None:
+            laws = id_law_report(c, n_model, E, busbw_gbps) if c["V"] * E <= (1 << 28) else None
         if laws is not None:
             # the same model per id law, with what the model above leaves out: the late pass over the UNION of the ranks' rows is
             # larger than the single-GPU one (HBM-bound, ~3.5 TB/s); with C = 4 chunks all but the last chunk's share of it runs
@@ -733,6 +734,16 @@ def dp_report(model, c, batches, world, ms_per_step, n_model=8, busbw_gbps=300.0
                 law["late_pass_extra_ms"] = late_extra
                 law["weak_scaling_efficiency_modelled"] = ms_per_step / (
                     base("rows") + max(0.0, wire - hide_ms) + max(0.0, late_extra - 0.75 * wire) + small_b / busbw_gbps / 1e6 + 0.02)
+            # r5: the same with the exposed wire time MEASURED (one rank on RCCL, sleep kernels standing in for the wire)
+            for key, name in (("uniform", "uniform"), ("zipf1.1", "zipf_1.1")):
+                t = (standin or {}).get(key)
+                law = laws.get(name)
+                if t and law is not None and one_rank.get("rows"):
+                    law["one_rank_rccl_wire_standin_ms"] = t
+                    law["exposed_wire_ms_measured"] = t - one_rank["rows"]
+                    law["weak_scaling_efficiency_measured_overlap"] = ms_per_step / (
+                        t + max(0.0, law["late_pass_extra_ms"] - 0.75 * law["wire_ms_at_assumed_busbw"])
+                        + small_b / busbw_gbps / 1e6 + 0.02)
         dp_extra = {"one_rank_rccl_ms": one_rank or None, "plain_ms": ms_per_step, "id_laws_n%d" % n_model: laws}
     else:
         dp_extra = {}
@@ -774,10 +785,16 @@ def dtype_string(c):
     return s + ")"
 
 
-def side_legs(args):
+WIRE_STANDIN = (300.0, 8)          # GB/s of bus bandwidth, ranks: the stand-in wire of the one-rank rows run (see side_legs)
+
+
+def side_legs(args, zipf_fraction=None):
     """The same timed loop in sub-processes (same box, same batches, no other legs): every product on fp32 kernels; the
     data-parallel step with ONE rank on RCCL and the world-size-1 short cuts off -- what the step's machinery costs before a
-    byte crosses xGMI -- with both table exchanges."""
+    byte crosses xGMI -- with both table exchanges; and (XLong, r5: VERDICT r4 #3) the rows step once more with a STAND-IN for
+    the wire: sleep kernels on a stream of their own hold every chunk of the exchange back by what the bytes a rank would
+    receive at 8 ranks take at 300 GB/s (HPMN_DP_WIRE_STANDIN, hpmn.py) -- the step's real kernels around a wire of the modelled
+    length; what it gains over the run without is the exchange's exposed time.  Uniform ids, and the Zipf(1.1) volume."""
     import subprocess
     base = [sys.executable, os.path.abspath(__file__), "--config", args.config, "--steps", str(args.steps), "--warmup",
             str(args.warmup), "--no-cpu-baseline", "--no-auc", "--no-eval", "--no-roofline", "--no-parity-gate", "--no-side-legs",
@@ -802,6 +819,12 @@ def side_legs(args):
     out = {"all_fp32_ms_per_step": run([], ALL_FP32_ENV)}
     if not args.lazy_table_adam:
         out["one_rank_rccl_ms"] = {m: run(["--one-rank-rccl", m], {}) for m in ("rows", "allreduce")}
+        if args.config == "c3":
+            spec = "%g,%d" % WIRE_STANDIN
+            out["one_rank_rccl_wire_standin_ms"] = {"uniform": run(["--one-rank-rccl", "rows"], {"HPMN_DP_WIRE_STANDIN": spec})}
+            if zipf_fraction:
+                out["one_rank_rccl_wire_standin_ms"]["zipf1.1"] = run(
+                    ["--one-rank-rccl", "rows"], {"HPMN_DP_WIRE_STANDIN": "%s,%.4f" % (spec, zipf_fraction)})
     return out
 
 
@@ -1113,17 +1136,24 @@ def main():
             result["eval_pass"] = eval_pass
         if cadence is not None:
             result["xlong_cadence"] = cadence
-        side = {}
+        side, laws, zf = {}, None, None
         fits_twice = 2 * 4 * 4 * c["V"] * 16 < 0.8 * torch.cuda.get_device_properties(device).total_memory
         if world == 1 and not args.no_side_legs and not args.one_rank_rccl and fits_twice:    # (the sub-runs build their own model)
             log("side legs: all-fp32 kernels, the data-parallel step with one rank on RCCL")
-            side = side_legs(args)
+            if not args.no_eval and c["V"] * 16 <= (1 << 28):
+                laws = id_law_report(c, 8, 16, WIRE_STANDIN[0])
+                try:
+                    zf = laws["zipf_1.1"]["rows_exchange_bytes_received_per_rank"] / laws["uniform"]["rows_exchange_bytes_received_per_rank"]
+                except Exception:
+                    zf = None
+            side = side_legs(args, zipf_fraction=zf)
             if side.get("all_fp32_ms_per_step") is not None:
                 result["ms_per_step_all_fp32"] = side["all_fp32_ms_per_step"]
                 result["all_fp32_switches"] = ALL_FP32_ENV
         if not args.no_eval:                                   # (its torch.unique would show up in the PMC passes)
             result["data_parallel"] = dp_report(model, c, batches, world, elapsed / args.steps * 1e3,
-                                                one_rank=side.get("one_rank_rccl_ms"))
+                                                one_rank=side.get("one_rank_rccl_ms"), laws=laws,
+                                                standin=side.get("one_rank_rccl_wire_standin_ms"))
         if auc is not None:
             result["auc"] = auc
         if c["V"] * 16 * 4 >= (2 << 30) and world == 1:

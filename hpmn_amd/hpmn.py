@@ -1092,6 +1092,40 @@ class Hpmn_Basic(object):
             plan.ready = done
         self._prefetched = dict(key=(next_ids.data_ptr(), tuple(next_ids.shape), gb), plan=plan, ex=ex, ids=next_ids, done=done)
 
+    # MEASUREMENT ONLY: HPMN_DP_WIRE_STANDIN="<GB/s>,<ranks>[,<fraction of the rows>]" -- with ONE rank on RCCL the
+    # all-gathers are local copies; a stream of its own then holds every chunk back by the time the bytes this rank would
+    # RECEIVE at <ranks> ranks take at <GB/s> (sleep kernels, one behind the other like transfers on one link, each starting
+    # when its chunk's rows exist), and the late launches wait for that instead of for the copy.  What the step gains over the
+    # run without it is the exchange's EXPOSED time with this step's real kernels around it.
+    WIRE_STANDIN = os.environ.get("HPMN_DP_WIRE_STANDIN", "")
+    _wire_stream = None
+    _sleep_cycles_per_us = None
+
+    def _wire_standin(self, windows, inflight, E):
+        gbps, ranks, frac = (list(map(float, self.WIRE_STANDIN.split(","))) + [1.0])[:3]
+        if self._wire_stream is None:
+            self._wire_stream = torch.cuda.Stream(device=self.device)
+            # torch.cuda._sleep counts ticks of a device clock: calibrate once
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); torch.cuda._sleep(20_000_000); b.record(); b.synchronize()
+            self._sleep_cycles_per_us = 20_000_000 / (a.elapsed_time(b) * 1e3)
+        out = []
+        with torch.cuda.stream(self._wire_stream):
+            for (first, n, capc), item in zip(windows, inflight):
+                if item is None:
+                    out.append(None)
+                    continue
+                if item[1] is not None:
+                    item[1].wait()                            # (this stream behind the chunk's collective)
+                us = (ranks - 1.0) * frac * capc * E * 4 / (gbps * 1e3)
+                torch.cuda._sleep(max(1, int(us * self._sleep_cycles_per_us)))
+                ev = torch.cuda.Event()
+                ev.record()
+                item[0].record_stream(torch.cuda.current_stream())
+                out.append(ev)
+        return out
+
     def _train_step_rows(self, ids, label, keep_prob, masks, global_batch, next_ids=None, next_global_batch=None):
         """The two-pass step on COMPACT gradient rows, one process or N (``compact_table_grad``).
 
@@ -1209,11 +1243,14 @@ class Hpmn_Basic(object):
             for first, n, capc in windows:
                 a = first[self.rank]
                 inflight.append(dist.all_gather_fixed(src[a:a + capc], async_op=True) if capc > 0 else None)
-            for (first, n, capc), item in zip(windows, inflight):
+            wired = self._wire_standin(windows, inflight, E) if self.WIRE_STANDIN else None
+            for ci, ((first, n, capc), item) in enumerate(zip(windows, inflight)):
                 if item is None:
                     continue
                 g_all, work = item
-                if work is not None:
+                if wired is not None:
+                    main.wait_event(wired[ci])                # (the chunk "arrives" when its stand-in transfer ends)
+                elif work is not None:
                     work.wait()                               # (orders the current stream behind the collective)
                 ops.rows_sum_adam(P, M, S, flags, ids_all, g_all, lr_t, lens=lens, first=first, n=n,
                                   buckets=box.get("buckets"), **hp)
