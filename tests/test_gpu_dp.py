@@ -77,7 +77,7 @@ def test_two_rank_training_over_rccl_matches_single_process(tmp_path):
     _run_two_ranks(tmp_path, "nccl", "rows", extra_env={"HPMN_TWO_PASS_MIN_NUMEL": "0"})
 
 
-@pytest.mark.parametrize("exchange", ["rows", "rows_ahead", "allreduce", "sharded", "lazy"])
+@pytest.mark.parametrize("exchange", ["rows", "rows_ahead", "rows_wire_standin", "allreduce", "sharded", "lazy"])
 def test_every_collective_of_the_step_runs_on_rccl_with_one_rank(tmp_path, monkeypatch, exchange):
     """RCCL refuses two ranks on one device and the boxes have one GPU, so until r4 no RCCL call of the data-parallel
     step had ever executed.  HPMN_DP_FORCE_COLLECTIVES=1 removes the world-size-1 short cuts: a ONE-rank "nccl" process
@@ -90,6 +90,11 @@ def test_every_collective_of_the_step_runs_on_rccl_with_one_rank(tmp_path, monke
         # (r5: the next step's plan + id exchange a step ahead, on the plan stream and the SECOND RCCL communicator)
         env["HPMN_DP_NEXT_IDS"] = "1"
         monkeypatch.setenv("HPMN_DP_NEXT_IDS", "1")
+        exchange = "rows"
+    if exchange == "rows_wire_standin":
+        # (r5, measurement switch: sleep kernels on a stream of their own stand in for the wire -- the late launches wait for
+        #  them instead of for the collective; the result must not change)
+        env["HPMN_DP_WIRE_STANDIN"] = "300,8"
         exchange = "rows"
     if exchange == "lazy":
         env["HPMN_LAZY_TABLE_ADAM"] = "1"
