@@ -51,31 +51,77 @@ CONFIGS = {
     "c4big": dict(industry=True, F=2, T=1001, H=128, K=7, periods=[2] * 10 + [1], batch=500,
                   V=256 * 1024 * 1024, lr=0.001, memory_reg=5e-5, device_init=True,
                   name="XLong synthetic, 256 M-row table (16 GiB), Hpmn_Industry 7-layer H=128 max_len=1000(+1)->1024"),
+    # Zipf(1.1) items, category = map(item); C2 lengths min(300, LogNormal(4.6, .8)), C1 5 + Geometric(.25)
     "c2": dict(industry=False, F=4, T=300, H=64, K=5, periods=[2, 2, 3, 5, 5, 1], batch=128,
-               V=4160000 + 990000 + 9400 + 5, lr=0.001, memory_reg=1e-5,
-               name="Taobao synthetic, Hpmn 5-layer H=64 max_len=300"),
+               V=4160000 + 9400 + 990000 + 5, n_item=4160000, n_cate=9400, n_user=990000, n_btag=5, length_law="lognormal",
+               lr=0.001, memory_reg=1e-5,
+               name="Taobao synthetic (Zipf(1.1) items, LogNormal(4.6,0.8) lengths <= 300), Hpmn 5-layer H=64 max_len=300"),
     "c1": dict(industry=False, F=3, T=100, H=32, K=4, periods=[2, 2, 5, 5, 1], batch=128,
-               V=63001 + 801 + 192403, lr=0.003, memory_reg=1e-5,
-               name="Amazon synthetic, Hpmn 4-layer H=32 max_len=100"),
+               V=63001 + 801 + 192403, n_item=63001, n_cate=801, n_user=192403, n_btag=0, length_law="geometric",
+               lr=0.003, memory_reg=1e-5,
+               name="Amazon synthetic (Zipf(1.1) items, 5+Geometric(.25) lengths), Hpmn 4-layer H=32 max_len=100"),
 }
 
 
-def synth_batches(c, n_batches, batch, seed, device):
-    """Synthetic id tensors of the config's shape (schema of data_loader.py:66-80 / preprocess_amazon
-    .py:151-164): column 0 = constant uid, other columns random ids; Hpmn configs get ragged front
-    padding (5 + Geometric(.25) real events)."""
+_ZIPF_CDF = {}
+
+
+def zipf_draw(rng, n_item, size, a=1.1):
+    """Item ranks under Zipf(a) over [1, n_item) (hpmn_amd/datasets.py draws the same law with rng.choice):
+    inverse-CDF sampling, the CDF built once per vocabulary.  Rank r IS item id r (id 0 is the padding id)."""
+    key = (n_item, a)
+    if key not in _ZIPF_CDF:
+        w = 1.0 / np.arange(1, n_item, dtype=np.float64) ** a
+        _ZIPF_CDF[key] = np.cumsum(w / w.sum())
+    return 1 + np.minimum(np.searchsorted(_ZIPF_CDF[key], rng.random(size)), n_item - 2)
+
+
+def synth_lengths(c, rng, batch):
+    """Real events per sequence (the rest is front padding, code/util.py:152-159), SURVEY.md 8d: Amazon 5-core histories
+    5 + Geometric(.25) capped at max_len (code/preprocess_amazon.py:151-164,190-191); Taobao min(300, LogNormal(4.6, 0.8))
+    (code/preprocess_taobao.py:147-148: histories cropped to 300) -- ~130 events on average where the Amazon law gives ~9."""
+    if c.get("length_law") == "lognormal":
+        return np.clip(np.rint(rng.lognormal(4.6, 0.8, size=batch)), 2, c["T"]).astype(np.int64)
+    return np.minimum(5 + rng.geometric(0.25, size=batch), c["T"])
+
+
+def synth_batches(c, n_batches, batch, seed, device, id_law=None):
+    """Synthetic id tensors of the config's shape, as SURVEY.md 8d specifies them (r6: through r5 every id was uniform and every
+    Hpmn-class length 5 + Geometric(.25)).
+    Hpmn class (C1 Amazon [uid, item, cate], C2 Taobao [uid, item, cate, btag]; code/preprocess_amazon.py:151-164): id space
+    items | categories | users | btags, item ids Zipf(1.1) over the item range, category = a fixed map of the item, uid constant
+    per sample, ragged front padding under synth_lengths' law.
+    Industry class (C3 / C4, code/data_loader.py:59-80 [uid, item]): column 0 = constant uid, items UNIFORM over the item range by
+    default -- the conservative headline: every lookup a distinct row, the worst case for the scatter and the rows exchange;
+    ``id_law="zipf"`` (the bench's side leg) draws them Zipf(1.1)."""
     rng = np.random.default_rng(seed)
     out = []
+    idt = np.int32 if c["V"] <= 2 ** 31 - 1 else np.int64
     for _ in range(n_batches):
-        ids = rng.integers(1, c["V"] - 30000, size=(batch, c["T"], c["F"]), dtype=np.int64)
-        ids = ids.astype(np.int32 if c["V"] <= 2 ** 31 - 1 else np.int64)
-        ids[:, :, 0] = rng.integers(c["V"] - 30000, c["V"], size=(batch, 1))
-        if not c["industry"]:
-            lens = np.minimum(5 + rng.geometric(0.25, size=batch), c["T"])
-            for b in range(batch):
-                ids[b, :c["T"] - lens[b]] = 0
+        if c["industry"]:
+            n_item = c["V"] - 30000
+            if (id_law or c.get("id_law", "uniform")) == "zipf":
+                ids = np.empty((batch, c["T"], c["F"]), dtype=np.int64)
+                ids[:, :, 1:] = zipf_draw(rng, n_item, (batch, c["T"], c["F"] - 1))
+            else:
+                ids = rng.integers(1, n_item, size=(batch, c["T"], c["F"]), dtype=np.int64)
+            ids[:, :, 0] = rng.integers(c["V"] - 30000, c["V"], size=(batch, 1))
+        else:
+            n_item, n_cate, n_user = c["n_item"], c["n_cate"], c["n_user"]
+            off_c, off_u, off_b = n_item, n_item + n_cate, n_item + n_cate + n_user
+            cate_of = np.random.default_rng(77).integers(0, n_cate, size=n_item) if "_cate_of" not in c else c["_cate_of"]
+            c["_cate_of"] = cate_of
+            ids = np.zeros((batch, c["T"], c["F"]), dtype=np.int64)
+            items = zipf_draw(rng, n_item, (batch, c["T"]))
+            ids[:, :, 0] = off_u + rng.integers(0, n_user, size=(batch, 1))
+            ids[:, :, 1] = items
+            ids[:, :, 2] = off_c + cate_of[items]
+            if c["F"] == 4:
+                ids[:, :, 3] = off_b + rng.integers(0, c["n_btag"], size=(batch, c["T"]))
+            lens = synth_lengths(c, rng, batch)
+            ids[np.arange(c["T"])[None, :] < (c["T"] - lens)[:, None]] = 0
         label = rng.integers(0, 2, size=batch).astype(np.int32)
-        out.append((torch.as_tensor(ids).to(device), torch.as_tensor(label).to(device)))
+        out.append((torch.as_tensor(ids.astype(idt)).to(device), torch.as_tensor(label).to(device)))
     return out
 
 
@@ -135,14 +181,17 @@ def source_sha():
 
 
 def pmc_digest(c, B):
-    """profiles/r05_pmc_summary.json (tools/pmc_digest.py: two separate rocprofv3 --pmc passes of this command,
+    """profiles/rNN_pmc_summary.json (tools/pmc_digest.py: two separate rocprofv3 --pmc passes of this command,
     FETCH x2 gfx950 correction) -- used only if it was taken on the current kernel sources, config and batch."""
-    try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r05_pmc_summary.json")))
-        if d.get("source_sha") == source_sha() and d.get("config_id") == c.get("config_id") and d.get("batch") == B:
-            return d
-    except Exception:
-        pass
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")), reverse=True):     # newest round first
+        try:
+            d = json.load(open(path))
+            if d.get("source_sha") == source_sha() and d.get("config_id") == c.get("config_id") and d.get("batch") == B:
+                d["_path"] = os.path.relpath(path, ROOT)
+                return d
+        except Exception:
+            pass
     return None
 
 
@@ -317,13 +366,17 @@ def roofline_probes(model, c, batches, step_fn):
             traffic = max(v["hbm_bytes_max_launch"] for v in kk)
         step_bytes = pmc.get("hbm_bytes_per_step")
     dx_inloop = dx_in_scan and D0 <= 32 and os.environ.get("HPMN_BWD_DX_INLOOP", "1") != "0"
-    roof = {"kernel": "%s%s layer 0 (T=%d)" % (dom_kernel, ",...>" if dx_in_scan else "", T0), "bound": "mfma",
+    roof = {"kernel": "%s%s layer 0 (T=%d)" % (dom_kernel, ",...>" if dx_in_scan else "", T0), # (r6, VERDICT r5 weak #11: the kernel is a serial latency chain -- MFMA share 0.4 % of wave-cycles -- so neither roof
+            #  bounds it; `frac` prices its algorithmic flops against the dense fp32 peak, `hbm` its counter traffic against HBM)
+            "bound": "latency (priced against the dense fp32 mfma/vector peak; see hbm for the other roof)",
             "achieved": scan_flops / (dom_t * 1e-3) / 1e12, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
+            "hbm": None if traffic is None else {"achieved": traffic / (dom_t * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                                 "frac": traffic / (dom_t * 1e-3) / 1e9 / PEAK_HBM_GBS},
             "frac": scan_flops / (dom_t * 1e-3) / 1e12 / PEAK_F32_TFLOPS,
             "traffic": traffic, "traffic_unit": "bytes/launch",
-            "traffic_source": None if pmc is None else "profiles/r05_pmc_summary.json taken at source sha %s "
+            "traffic_source": None if pmc is None else "%s taken at source sha %s "
                               "(separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x2 gfx950 correction)"
-                              % pmc["source_sha"],
+                              % (pmc.get("_path"), pmc["source_sha"]),
             "ms_per_launch": dom_t,
             "timing": "median of 20 launches INSIDE training steps (HIP events on the launch stream, weight-gradient "
                       "kernels live on the side stream)" if in_step_ms is not None else "stand-alone launches",
@@ -894,6 +947,10 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the reference literal)")
     ap.add_argument("--vocab-rows", type=int, default=0, help="embedding-table rows (c4big: sized to HBM; default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-batch-sweep", action="store_true", help="skip the 1x/2x/4x/8x reference-batch leg")
+    ap.add_argument("--id-law", default="", choices=["", "uniform", "zipf"],
+                    help="item-id law of the Industry configs (default uniform: every lookup a distinct row, the conservative "
+                         "headline; zipf = Zipf(1.1), the law SURVEY 8d gives Amazon / Taobao)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-auc", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -920,11 +977,10 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # (before the first HIP call: the runtime reads it once)
-        # The data-parallel step has seven streams (launch, auxiliary, two helpers, the plan's, two communicators') and the
-        # runtime four hardware queues by default: streams that share a queue serialise.  Measured with one rank on RCCL in this
-        # timed loop (r5, rows exchange): 4 / 5 / 6 / 8 queues -> 3.01 / 2.63 / 3.14 / 3.41 ms per step.  DESIGN.md section 5.
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", "5")
+        # (before the first HIP call: the runtime reads them once.  r6: the settings live in the package -- hpmn_amd.dist --
+        #  so that `torchrun hpmn.py xlong` and a user's own script get them too, not only this bench)
+        from hpmn_amd import dist as _hd
+        _hd.apply_runtime_env()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -970,7 +1026,7 @@ def main():
         per_gpu = hi - lo
     else:
         per_gpu, global_batch = c["batch"], c["batch"] * world
-    batches = synth_batches(c, n_distinct, per_gpu, 20190521 + 3 + 1000 * rank, device)
+    batches = synth_batches(c, n_distinct, per_gpu, 20190521 + 3 + 1000 * rank, device, id_law=args.id_law or None)
 
     prefetch = os.environ.get("HPMN_BENCH_NEXT_IDS", "1") != "0"
 
@@ -1047,14 +1103,24 @@ def main():
         # ... and what model.eval() does with a whole set (r4): 8 reference batches of rows through Hpmn.eval -- several
         # reference batches per pass on the tile kernels where the graph has them (single process, H = 64), AUC / log-loss /
         # memory-loss on the device, ONE host synchronisation at the end
-        if world == 1:
-            ev_all = torch.cat([ev_ids] * 8, 0).cpu().numpy()
+        # r6: under data parallel too (every rank: Hpmn.eval shards the DATASET and ends with one all-gather + one all-reduce);
+        # the set is replicated (same rows on every rank, rank 0's law) and weak-scaled: 8 reference batches per rank
+        if True:
+            if world > 1:
+                ev_src = synth_batches(c, 4, per_gpu, 20190521 + 3, device)
+                ev_one = torch.cat([b[0] for b in ev_src], 0)[:4 * c["batch"]]
+                del ev_src
+            else:
+                ev_one = ev_ids
+            ev_all = torch.cat([ev_one] * (8 * world), 0).cpu().numpy()
             rng_l = np.random.default_rng(5)
             ev_ds = dict(ids=ev_all, label=rng_l.integers(0, 2, size=ev_all.shape[0]).astype(np.int32))
             model.eval(ev_ds, 4 * c["batch"])                  # (stages the rows on the device, grows the allocator's pools)
             model.eval(ev_ds, 4 * c["batch"])
             dts = []
             for _ in range(5):
+                if world > 1:
+                    torch.distributed.barrier()
                 torch.cuda.synchronize()
                 te1 = time.perf_counter()
                 model.eval(ev_ds, 4 * c["batch"])
@@ -1062,14 +1128,41 @@ def main():
                 dts.append(time.perf_counter() - te1)
             dt = sorted(dts)[len(dts) // 2]
             eval_pass = {"rows": int(ev_all.shape[0]), "reference_batch": 4 * c["batch"], "seconds": dt, "seconds_all": dts,
-                         "sequences_per_s": ev_all.shape[0] / dt,
+                         "sequences_per_s": ev_all.shape[0] / dt, "ranks": world,
                          "rows_per_pass": (int(model.TILED_EVAL_ROWS // (4 * c["batch"]) * 4 * c["batch"])
                                            if model._tiled_inference(model.TILED_EVAL_ROWS) and 4 * c["batch"] <= model.TILED_EVAL_ROWS
                                            else 4 * c["batch"]),
-                         "what": "Hpmn.eval(dataset, 4 x batch) incl. the device-side AUC / log-loss / memory-loss and its one sync"}
+                         "what": "Hpmn.eval(dataset, 4 x batch) incl. the device-side AUC / log-loss / memory-loss and its one sync"
+                                 + ("; data parallel: the dataset sharded over the ranks, one all-gather of predictions + one "
+                                    "all-reduce per pass (rate = all ranks' rows / rank 0's wall clock)" if world > 1 else "")}
             model.invalidate_dataset(ev_ds)
             del ev_ds, ev_all
         del ev_ids
+
+    # batch sweep (r6, SURVEY.md section 7 / VERDICT r5 missing #4): the same training step at 1x, 2x, 4x, 8x the reference batch
+    # (code/hpmn.py:595,623,663: 128 / 128 / 500) -- what the chip does when it is not held at 128 sequences on 256 CUs
+    sweep = None
+    if world == 1 and not args.no_batch_sweep and not args.one_rank_rccl:
+        sweep = []
+        for mult in (1, 2, 4, 8):
+            try:
+                bb = synth_batches(c, 3, c["batch"] * mult, 20190521 + 7 + mult, device, id_law=args.id_law or None)
+                for i in range(3):
+                    model.train_step(bb[i % 3][0], bb[i % 3][1], keep_prob=0.5)
+                torch.cuda.synchronize()
+                ts0 = time.perf_counter()
+                n_sw = 20 if mult <= 2 else 10
+                for i in range(n_sw):
+                    model.train_step(bb[i % 3][0], bb[i % 3][1], keep_prob=0.5)
+                torch.cuda.synchronize()
+                ms = (time.perf_counter() - ts0) / n_sw * 1e3
+                sweep.append({"batch": c["batch"] * mult, "ms_per_step": ms, "sequences_per_s": c["batch"] * mult / ms * 1e3})
+                del bb
+            except (RuntimeError, torch.OutOfMemoryError) as e:        # (a table sized to HBM leaves no room for 8x the workspace)
+                sweep.append({"batch": c["batch"] * mult, "error": str(e)[:200]})
+                break
+        torch.cuda.empty_cache()
+        log("batch sweep: %s" % sweep)
 
     # what a user of code/hpmn.py:336-349 feels: 10 training steps, then a full evaluation pass (train + test rows) at the
     # eval batch -- here one pass over 8 eval batches stands for it; reported as seconds per (10 steps + N rows)
@@ -1134,6 +1227,8 @@ def main():
         result["eval_sequences_per_s"] = eval_seq_per_s        # forward only, rank-0 clock (not barrier-bracketed)
         if eval_pass is not None:
             result["eval_pass"] = eval_pass
+        if sweep is not None:
+            result["batch_sweep"] = sweep
         if cadence is not None:
             result["xlong_cadence"] = cadence
         side, laws, zf = {}, None, None

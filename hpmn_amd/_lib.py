@@ -10,7 +10,7 @@ import os
 from typing import Optional
 
 HPMN_MAX_LAYERS = 12
-HPMN_ABI_VERSION = 13
+HPMN_ABI_VERSION = 14
 HPMN_MAX_RANKS = 8
 HPMN_MAX_CHUNKS = 32
 HPMN_FWD_NO_CANDIDATE = 1
@@ -99,6 +99,26 @@ class HpmnScanDesc(C.Structure):
         ("front_zero", C.c_int32), ("mask_id0", C.c_int32), ("last_index", C.c_int32),
         ("V", C.c_int64),
         ("periods", C.c_int32 * HPMN_MAX_LAYERS),
+    ]
+
+
+class HpmnTrainStep(C.Structure):
+    """One training step behind ONE call (hpmn_train_step, ABI v14)."""
+    _fields_ = [
+        ("scan", HpmnScanDesc), ("read", HpmnReadDesc),
+        ("ids", C.c_void_p), ("label", C.c_void_p),
+        ("param", C.c_void_p), ("grad", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p),
+        ("n_emb", C.c_int64), ("n_total", C.c_int64),
+        ("off_gru", (C.c_int64 * 4) * HPMN_MAX_LAYERS),
+        ("off_read", C.c_int64),
+        ("memory", C.c_void_p), ("last", C.c_void_p), ("pred", C.c_void_p),
+        ("d_memory", C.c_void_p), ("d_last", C.c_void_p),
+        ("scan_workspace", C.c_void_p), ("read_workspace", C.c_void_p),
+        ("loss_acc", C.c_void_p), ("loss3", C.c_void_p),
+        ("mask1", C.c_void_p), ("mask2", C.c_void_p),
+        ("keep_prob", C.c_float), ("inv_global_batch", C.c_float), ("memory_reg", C.c_float),
+        ("lr_t", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("clip", C.c_float),
+        ("clear_grad_first", C.c_int32),
     ]
 
 
@@ -265,6 +285,7 @@ SIGNATURES = {
                                 C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p,
                                 C.c_void_p, C.c_int32, C.c_void_p]),
     "hpmn_train_join": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "hpmn_train_step": (C.c_int, [C.c_void_p, C.POINTER(HpmnTrainStep), C.c_void_p]),
     "hpmn_train_probe": (C.c_int, [C.c_void_p, C.c_int32]),
     "hpmn_train_probe_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "hpmn_train_mark_layer0_reverse": (C.c_int, [C.c_void_p, C.c_int32]),

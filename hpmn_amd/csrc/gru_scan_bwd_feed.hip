@@ -54,13 +54,17 @@ typedef float f4m __attribute__((ext_vector_type(4)));
 typedef float xf4 __attribute__((ext_vector_type(4)));
 typedef __bf16 xbf8 __attribute__((ext_vector_type(8)));
 
-// x = hi + lo in bf16 (|x - hi - lo| <= 2^-17 |x|), eight values at once
-__device__ __forceinline__ void split_bf16x8(const v4f a, const v4f b, xbf8 &hi, xbf8 &lo) {
+// x = p0 + p1 (+ p2) in bf16 planes, eight values at once: two planes leave 2^-17 |x|, three 2^-25 |x| (gru_wgrad_bf16.hip)
+template <int NP>
+__device__ __forceinline__ void split_bf16x8(const v4f a, const v4f b, xbf8 (&p)[NP]) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const float x = i < 4 ? a[i] : b[i - 4];
-        hi[i] = (__bf16)x;
-        lo[i] = (__bf16)(x - (float)hi[i]);
+        float rest = i < 4 ? a[i] : b[i - 4];
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            p[q][i] = (__bf16)rest;
+            if (q + 1 < NP) rest -= (float)p[q][i];
+        }
     }
 }
 
@@ -78,7 +82,9 @@ __device__ __forceinline__ void split_bf16x8(const v4f a, const v4f b, xbf8 &hi,
 // fragments are stationary in the feeder's registers (96 at D = 32: the feeder had them to spare, the kernel's register
 // count is set by the chain wave + epilogue).  No d_act row is read back from memory (0.38 GB per step at C3's layer 0) and
 // the launch ends with the scan.
-template <int DXD, bool SCAT = false, bool LOOPDX = false, bool CFH = false>
+// NP (round 6): planes of the in-loop product's operands -- 3: the six products of order <= 2, fp32-equivalent (default);
+// 2: rounds 4/5 (three products, ~5e-6 of max|grad|; HPMN_DX_PLANES=2).
+template <int DXD, bool SCAT = false, bool LOOPDX = false, bool CFH = false, int NP = 3>
 __global__ __launch_bounds__(256, 1) void gru_scan_bwd_feed_kernel(const HpmnGruBwd a) {
     constexpr int H = 64;
     constexpr bool DX = DXD > 0;
@@ -189,7 +195,7 @@ __global__ __launch_bounds__(256, 1) void gru_scan_bwd_feed_kernel(const HpmnGru
         //      16 ct + 4 kg .. + 3 of iteration n -- 16 contiguous bytes of the d_x row.
         constexpr int NU = LOOPDX ? (DXD / 16) * 6 : 1;
         const int j16 = lane & 15, kg = lane >> 4;
-        xbf8 wAh[NU], wAl[NU];
+        xbf8 wA[NU][NP];
         if constexpr (LOOPDX) {
 #pragma unroll
             for (int u = 0; u < NU; ++u) {
@@ -198,7 +204,7 @@ __global__ __launch_bounds__(256, 1) void gru_scan_bwd_feed_kernel(const HpmnGru
                 const int gc = 32 * ks + 8 * kg;
                 const float *src = gc < 2 * H ? a.wg + col * 2 * H + gc : a.wc + col * H + (gc - 2 * H);
                 const v4f v0 = *reinterpret_cast<const v4f *>(src), v1 = *reinterpret_cast<const v4f *>(src + 4);
-                split_bf16x8(v0, v1, wAh[u], wAl[u]);
+                split_bf16x8<NP>(v0, v1, wA[u]);
             }
         }
         xf4 xacc = {0.f, 0.f, 0.f, 0.f};
@@ -224,8 +230,8 @@ __global__ __launch_bounds__(256, 1) void gru_scan_bwd_feed_kernel(const HpmnGru
                 const int it = it_raw < nsteps ? it_raw : nsteps - 1;          // (clamped: computed, not stored)
                 const float *src = &dact[it & (NSLOT - 1)][32 * ks + 8 * kg];
                 const v4f b0 = *reinterpret_cast<const v4f *>(src), b1 = *reinterpret_cast<const v4f *>(src + 4);
-                xbf8 bh, bl;
-                split_bf16x8(b0, b1, bh, bl);
+                xbf8 bp[NP];
+                split_bf16x8<NP>(b0, b1, bp);
                 if constexpr (ks == 0) xacc = xf4{0.f, 0.f, 0.f, 0.f};
                 if constexpr (ks == 0 && SCAT) {
                     const int t = t_hi - 1 - it, ti = t - a.front_zero;
@@ -233,9 +239,16 @@ __global__ __launch_bounds__(256, 1) void gru_scan_bwd_feed_kernel(const HpmnGru
                     sc_dl = *reinterpret_cast<const xf4 *>(dlb + 16 * ct);
                     sc_flag = (it_raw < nsteps && ti >= 0) ? (t == a.last_t ? 2 : 1) : 0;
                 }
-                xacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wAh[U], bh, xacc, 0, 0, 0);
-                xacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wAh[U], bl, xacc, 0, 0, 0);
-                xacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wAl[U], bh, xacc, 0, 0, 0);
+                // products of order <= NP - 1, smallest terms first (written out: a triangular loop nest kept the stationary
+                // fragments in scratch)
+                if constexpr (NP == 3) {
+                    xacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wA[U][0], bp[2], xacc, 0, 0, 0);
+                    xacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wA[U][1], bp[1], xacc, 0, 0, 0);
+                    xacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wA[U][2], bp[0], xacc, 0, 0, 0);
+                }
+                xacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wA[U][0], bp[1], xacc, 0, 0, 0);
+                xacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wA[U][1], bp[0], xacc, 0, 0, 0);
+                xacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wA[U][0], bp[0], xacc, 0, 0, 0);
                 // (no branch in here -- the feeder's prefetch loads are in flight and a branch's join would wait for all of
                 //  them: a clamped lane holds the last row's result and stores it to the last row's place once more)
                 if constexpr (ks == 5 && !SCAT) *reinterpret_cast<xf4 *>(dxb + (long)(t_hi - 1 - it) * DXD + 16 * ct) = xacc;
@@ -250,7 +263,7 @@ __global__ __launch_bounds__(256, 1) void gru_scan_bwd_feed_kernel(const HpmnGru
                 }
             }
         };
-        auto dx_block = [&](int kb) {            // a whole block at once (behind the unrolled loop, and the last blocks)
+        auto dx_block = [&](int kb) __attribute__((always_inline)) {            // a whole block at once (behind the unrolled loop, and the last blocks)
             dx_unit(std::integral_constant<int, 0>{}, kb); dx_unit(std::integral_constant<int, 1>{}, kb);
             dx_unit(std::integral_constant<int, 2>{}, kb); dx_unit(std::integral_constant<int, 3>{}, kb);
             dx_unit(std::integral_constant<int, 4>{}, kb); dx_unit(std::integral_constant<int, 5>{}, kb);
@@ -519,13 +532,13 @@ bool gru_scan_bwd_feed_dx_width(int D) { return D == 16 || D == 32 || D == 64; }
 // the epilogue's fused scatter: id column f is column tile f of the input gradient
 bool gru_scan_bwd_feed_scatter_ok(int D, int F, int E) { return E == 16 && D == F * 16 && gru_scan_bwd_feed_dx_width(D); }
 
-template <bool CFH>
+template <bool CFH, int NP>
 static int feed_launch(const HpmnGruBwd &a, hipStream_t st) {
     const dim3 grid((a.B + 1) / 2);
-    if (a.d_emb != nullptr && a.d_x != nullptr && a.D <= 32) {
+    if (a.d_emb != nullptr && a.d_x != nullptr && a.D <= 32 && (a.flags & HPMN_BWD_SCATTER_INLOOP)) {
         // the in-loop input gradient with the scatter fused into it (d_x: scratch for the rows that are not added)
-        if (a.D == 16) hipLaunchKernelGGL((gru_scan_bwd_feed_kernel<16, true, true, CFH>), grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((gru_scan_bwd_feed_kernel<32, true, true, CFH>), grid, dim3(256), 0, st, a);
+        if (a.D == 16) hipLaunchKernelGGL((gru_scan_bwd_feed_kernel<16, true, true, CFH, NP>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((gru_scan_bwd_feed_kernel<32, true, true, CFH, NP>), grid, dim3(256), 0, st, a);
         return check_launch();
     }
     if (a.d_emb != nullptr) {
@@ -538,8 +551,8 @@ static int feed_launch(const HpmnGruBwd &a, hipStream_t st) {
     // HPMN_BWD_DX_INLOOP=0: the input gradient of D <= 32 as an epilogue too (the round-2/3 form)
     static const int inloop = [] { const char *e = getenv("HPMN_BWD_DX_INLOOP"); return e ? atoi(e) : 1; }();
     if (a.d_x == nullptr) hipLaunchKernelGGL((gru_scan_bwd_feed_kernel<0, false, false, CFH>), grid, dim3(256), 0, st, a);
-    else if (a.D == 16 && inloop) hipLaunchKernelGGL((gru_scan_bwd_feed_kernel<16, false, true, CFH>), grid, dim3(256), 0, st, a);
-    else if (a.D == 32 && inloop) hipLaunchKernelGGL((gru_scan_bwd_feed_kernel<32, false, true, CFH>), grid, dim3(256), 0, st, a);
+    else if (a.D == 16 && inloop) hipLaunchKernelGGL((gru_scan_bwd_feed_kernel<16, false, true, CFH, NP>), grid, dim3(256), 0, st, a);
+    else if (a.D == 32 && inloop) hipLaunchKernelGGL((gru_scan_bwd_feed_kernel<32, false, true, CFH, NP>), grid, dim3(256), 0, st, a);
     else if (a.D == 16) hipLaunchKernelGGL((gru_scan_bwd_feed_kernel<16, false, false, CFH>), grid, dim3(256), 0, st, a);
     else if (a.D == 32) hipLaunchKernelGGL((gru_scan_bwd_feed_kernel<32, false, false, CFH>), grid, dim3(256), 0, st, a);
     else if (a.D == 64) hipLaunchKernelGGL((gru_scan_bwd_feed_kernel<64, false, false, CFH>), grid, dim3(256), 0, st, a);
@@ -548,7 +561,9 @@ static int feed_launch(const HpmnGruBwd &a, hipStream_t st) {
 }
 
 int gru_scan_bwd_feed_launch(const HpmnGruBwd &a, hipStream_t st) {
-    return (a.flags & HPMN_BWD_CANDIDATE_FROM_HS) ? feed_launch<true>(a, st) : feed_launch<false>(a, st);
+    static const int np = [] { const char *e = getenv("HPMN_DX_PLANES"); return (e && atoi(e) == 2) ? 2 : 3; }();
+    if (np == 2) return (a.flags & HPMN_BWD_CANDIDATE_FROM_HS) ? feed_launch<true, 2>(a, st) : feed_launch<false, 2>(a, st);
+    return (a.flags & HPMN_BWD_CANDIDATE_FROM_HS) ? feed_launch<true, 3>(a, st) : feed_launch<false, 3>(a, st);
 }
 
 }  // namespace hpmn

@@ -300,16 +300,37 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void gru_dx_kernel(const HpmnGruW
 // contiguous in memory) are stationary, split once: 192 registers.  Rows stream through a ring of PD k-steps of raw loads,
 // across tile borders, clamped past the end (no branch around a load or store in the loop).
 typedef __bf16 dbf8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ void dx_split8(const float4 a, const float4 b, dbf8 &hi, dbf8 &lo) {
+// NP planes (round 6): 2 = x ~ hi + lo, three products (rounds 4/5, ~5e-6 of the result's max); 3 = hi + mid + lo (2^-25 |x| left)
+// with the six products of order <= 2: fp32-equivalent (gru_wgrad_bf16.hip).  HPMN_DX_PLANES / HPMN_PROJ_PLANES = 2 select the
+// old arithmetic.
+template <int NP>
+__device__ __forceinline__ void dx_split8(const float4 a, const float4 b, dbf8 (&pl)[NP]) {
     const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        hi[i] = (__bf16)v[i];
-        lo[i] = (__bf16)(v[i] - (float)hi[i]);
+        float rest = v[i];
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            pl[q][i] = (__bf16)rest;
+            if (q + 1 < NP) rest -= (float)pl[q][i];
+        }
     }
 }
+// acc += W x over the planes' products of order <= NP - 1, smallest terms first
+template <int NP>
+__device__ __forceinline__ f32x16 dx_mma(const dbf8 (&w)[NP], const dbf8 (&x)[NP], f32x16 acc) {
+    if constexpr (NP == 3) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], x[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[1], x[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[2], x[0], acc, 0, 0, 0);
+    }
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], x[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[1], x[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], x[0], acc, 0, 0, 0);
+    return acc;
+}
 
-template <int K, int NS>
+template <int K, int NS, int NP>
 __global__ __launch_bounds__(64 * RW_WAVES, 1) void gru_dx_bf16_kernel(const HpmnGruWgrad a) {
     constexpr int KS = K / 16;          // k-steps per tile
     constexpr int PD = 12;              // k-steps of raw row data in flight (24 x 16-byte loads per lane: 24 KB per wave)
@@ -327,7 +348,7 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void gru_dx_bf16_kernel(const Hpm
     const unsigned wave_id = gwave / NS;
     const unsigned nwave = gridDim.x * RW_WAVES / NS;
 
-    dbf8 wh[KS], wl[KS];
+    dbf8 w[KS][NP];
     {
         const int d = n_base + c;
         const long dr = d < D ? d : D - 1;          // (columns past D are clamped: computed, never stored)
@@ -335,7 +356,7 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void gru_dx_bf16_kernel(const Hpm
         for (int ks = 0; ks < KS; ++ks) {
             const int j = 16 * ks + 8 * p;
             const float *src = j < 2 * H ? a.wg + dr * 2 * H + j : a.wc + dr * H + (j - 2 * H);
-            dx_split8(*reinterpret_cast<const float4 *>(src), *reinterpret_cast<const float4 *>(src + 4), wh[ks], wl[ks]);
+            dx_split8<NP>(*reinterpret_cast<const float4 *>(src), *reinterpret_cast<const float4 *>(src + 4), w[ks]);
         }
     }
     auto tile_row = [&](unsigned tile) -> unsigned { const unsigned rr = tile * 32u + c; return rr < M ? rr : M - 1u; };
@@ -360,23 +381,21 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void gru_dx_bf16_kernel(const Hpm
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            dbf8 xh, xl;
+            dbf8 xp[NP];
             {   // the k-step's consumption point, pinned in the order of the volatile statements (so are the reloads below):
                 // left alone the compiler hoists every split of the tile to its top and sinks the reloads to their uses --
                 // the ISA then shows the ring draining, vmcnt(22) .. vmcnt(0), then each k-step waiting for a load just issued
                 float4 &r0 = ring[ks % PD][0], &r1 = ring[ks % PD][1];
                 asm volatile("" : "+v"(r0.x), "+v"(r0.y), "+v"(r0.z), "+v"(r0.w), "+v"(r1.x), "+v"(r1.y), "+v"(r1.z), "+v"(r1.w));
             }
-            dx_split8(ring[ks % PD][0], ring[ks % PD][1], xh, xl);
+            dx_split8<NP>(ring[ks % PD][0], ring[ks % PD][1], xp);
             asm volatile("" ::: "memory");
             // the slot is free: k-step ks + PD of this tile, or the next tile's first ones
             const float *src = ks + PD < KS ? cur + 16 * (ks + PD) : nxt + 16 * (ks + PD - KS);
             ring[ks % PD][0] = *reinterpret_cast<const float4 *>(src);
             ring[ks % PD][1] = *reinterpret_cast<const float4 *>(src + 4);
             asm volatile("" ::: "memory");
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[ks], xh, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[ks], xl, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[ks], xh, acc, 0, 0, 0);
+            acc = dx_mma<NP>(w[ks], xp, acc);
         }
         // transposed product (file header): lane (c, p) owns row tile*32 + c, columns 8 g + 4 p + 0..3 of this wave's 32
         {
@@ -403,13 +422,13 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void gru_dx_bf16_kernel(const Hpm
 // rotation by 2 rows per fragment-of-a-line puts them on 8 different bank quads (a rotation by 4 was a 2-way conflict on every
 // store: SQ_LDS_BANK_CONFLICT 26 % of the launch's LDS cycles); a ds_read_b128's 16-lane groups see 16 different slots mod 16
 // under any rotation of the row.
-template <int K>
+template <int K, int NP>
 __global__ __launch_bounds__(64 * RW_WAVES, 1) void gru_dx_bf16_lds_kernel(const HpmnGruWgrad a) {
     constexpr int KS = K / 16;                      // k-steps per tile (24)
     constexpr int FPT = 32 * KS * 2 / (64 * RW_WAVES);   // fragments a thread stages per tile (6)
     static_assert(RW_WAVES == 4 && (32 * KS * 2) % (64 * RW_WAVES) == 0 && KS % 2 == 0, "four column slices, whole passes");
     extern __shared__ __attribute__((aligned(16))) char dx_smem[];
-    dbf8 (*img)[KS][2][64] = reinterpret_cast<dbf8 (*)[KS][2][64]>(dx_smem);      // [buffer][k-step][hi | lo][slot]
+    dbf8 (*img)[KS][NP][64] = reinterpret_cast<dbf8 (*)[KS][NP][64]>(dx_smem);    // [buffer][k-step][plane][slot]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int c = lane & 31, p = lane >> 5;
     const int D = a.D;
@@ -419,7 +438,7 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void gru_dx_bf16_lds_kernel(const
     auto flat_row = [&](unsigned r) -> unsigned { const unsigned b = r / (unsigned)TL; return b * a.T + a.t_begin + (r - b * TL); };
     const int n_base = wv * 32;
 
-    dbf8 wh[KS], wl[KS];
+    dbf8 w[KS][NP];
     {
         const int d = n_base + c;
         const long dr = d < D ? d : D - 1;          // (columns past D are clamped: computed, never stored)
@@ -427,7 +446,7 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void gru_dx_bf16_lds_kernel(const
         for (int ks = 0; ks < KS; ++ks) {
             const int j = 16 * ks + 8 * p;
             const float *src = j < 2 * (K / 3) ? a.wg + dr * 2 * (K / 3) + j : a.wc + dr * (K / 3) + (j - 2 * (K / 3));
-            dx_split8(*reinterpret_cast<const float4 *>(src), *reinterpret_cast<const float4 *>(src + 4), wh[ks], wl[ks]);
+            dx_split8<NP>(*reinterpret_cast<const float4 *>(src), *reinterpret_cast<const float4 *>(src + 4), w[ks]);
         }
     }
     // staging role of this thread: row (tid >> 2) & 31 of the tile, fragments q = 8 j + 4 (tid >> 7) + (tid & 3), j < FPT
@@ -448,10 +467,10 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void gru_dx_bf16_lds_kernel(const
 #pragma unroll
         for (int j = 0; j < FPT; ++j) {
             const int ks = 4 * j + 2 * s_grp + (s_sub >> 1);       // q / 2, q = 8 j + 4 s_grp + s_sub
-            dbf8 hi, lo;
-            dx_split8(raw[j][0], raw[j][1], hi, lo);
-            img[buf][ks][0][s_slot] = hi;
-            img[buf][ks][1][s_slot] = lo;
+            dbf8 pl[NP];
+            dx_split8<NP>(raw[j][0], raw[j][1], pl);
+#pragma unroll
+            for (int q = 0; q < NP; ++q) img[buf][ks][q][s_slot] = pl[q];
         }
     };
     auto barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
@@ -472,10 +491,10 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void gru_dx_bf16_lds_kernel(const
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int slot = ((c + 2 * (2 * (ks & 1) + p)) & 31) + 32 * p;
-            const dbf8 xh = img[buf][ks][0][slot], xl = img[buf][ks][1][slot];
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[ks], xh, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[ks], xl, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[ks], xh, acc, 0, 0, 0);
+            dbf8 xp[NP];
+#pragma unroll
+            for (int q = 0; q < NP; ++q) xp[q] = img[buf][ks][q][slot];
+            acc = dx_mma<NP>(w[ks], xp, acc);
         }
         {   // transposed product (file header): lane (c, p) owns row tile*32 + c, columns 8 g + 4 p + 0..3 of this wave's 32
             unsigned rr = tile * 32u + (unsigned)c;
@@ -497,7 +516,7 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void gru_dx_bf16_lds_kernel(const
 // is bound by writing xp.  Results within ~5e-6 of the row's largest pre-activation of the fp32 kernel's (the H = 128 forward
 // parity tests hold 1e-4 on the logits).  Rows from memory only (layer 0 gathers: its launch is bound by its 0.83 GB of
 // stores, not by the matrix pipe, and keeps the fp32 kernel).  The bias enters as one more k-step (hi and lo against 1.0).
-template <int K, int NT, int NS>
+template <int K, int NT, int NS, int NP>
 __global__ __launch_bounds__(64 * RW_WAVES, 1) void input_proj_bf16_kernel(const HpmnInputProj a) {
     constexpr int KS = K / 16;
     const int lane = threadIdx.x & 63;
@@ -514,7 +533,8 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void input_proj_bf16_kernel(const
     const int n_base = ns * NT * 32;
 
     // A operand (stationary): lane (n = c, p) = sc * Wcat[16 ks + 8 p .. + 7][n_base + 32 nt + c], Wcat = [wg[0:D] | wc[0:D]]
-    dbf8 wh[NT][KS], wl[NT][KS], bh[NT], bl[NT];
+    dbf8 w[NT][KS][NP];
+    float bias[NT];                     // (the bias step's planes are rebuilt per tile from this: 36 registers fewer)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int n = n_base + 32 * nt + c;
@@ -529,11 +549,10 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void input_proj_bf16_kernel(const
             const float *w0 = wcol + (long)(16 * ks + 8 * p) * ldw;
             v0.x = sc * w0[0]; v0.y = sc * w0[ldw]; v0.z = sc * w0[2 * ldw]; v0.w = sc * w0[3 * ldw];
             v1.x = sc * w0[4 * ldw]; v1.y = sc * w0[5 * ldw]; v1.z = sc * w0[6 * ldw]; v1.w = sc * w0[7 * ldw];
-            dx_split8(v0, v1, wh[nt][ks], wl[nt][ks]);
+            dx_split8<NP>(v0, v1, w[nt][ks]);
         }
         // the bias step: k slot 0 of half-wave 0 carries the bias, everything else 0, against a row operand of 1.0 there
-        const float bv = p == 0 ? sc * bcol[0] : 0.f;
-        dx_split8(make_float4(bv, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), bh[nt], bl[nt]);
+        bias[nt] = p == 0 ? sc * bcol[0] : 0.f;
     }
     dbf8 one;
 #pragma unroll
@@ -556,19 +575,18 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void input_proj_bf16_kernel(const
             f32x16 z;
 #pragma unroll
             for (int r = 0; r < 16; ++r) z[r] = 0.f;
-            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[nt], one, z, 0, 0, 0);
-            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[nt], one, acc[nt], 0, 0, 0);
+            acc[nt] = z;
+            dbf8 bpl[NP];
+            dx_split8<NP>(make_float4(bias[nt], 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), bpl);
+#pragma unroll
+            for (int q = NP - 1; q >= 0; --q) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bpl[q], one, acc[nt], 0, 0, 0);
         }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            dbf8 xh, xl;
-            dx_split8(v[ks][0], v[ks][1], xh, xl);
+            dbf8 xp[NP];
+            dx_split8<NP>(v[ks][0], v[ks][1], xp);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[nt][ks], xh, acc[nt], 0, 0, 0);
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[nt][ks], xl, acc[nt], 0, 0, 0);
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[nt][ks], xh, acc[nt], 0, 0, 0);
-            }
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = dx_mma<NP>(w[nt][ks], xp, acc[nt]);
         }
         float *dst = a.xp + (long)flat_row(tile_row(tile)) * N + n_base + 4 * p;
 #pragma unroll
@@ -644,7 +662,9 @@ int input_proj_dispatch(const HpmnInputProj &a, hipStream_t st) {
         static const int pbf = [] { const char *e = getenv("HPMN_PROJ_BF16"); return e ? atoi(e) : 1; }();
         if (a.D == 128 && a.x != nullptr && pbf && (long)a.B * a.T < (1L << 31) - 64) {
             const unsigned grid = rowwise_grid((long)a.B * (a.t_len > 0 ? a.t_len : a.T), 4);
-            hipLaunchKernelGGL((input_proj_bf16_kernel<128, 3, 4>), dim3(grid), dim3(64 * RW_WAVES), 0, st, a);
+            static const int np = [] { const char *e = getenv("HPMN_PROJ_PLANES"); return (e && atoi(e) == 2) ? 2 : 3; }();
+            if (np == 2) hipLaunchKernelGGL((input_proj_bf16_kernel<128, 3, 4, 2>), dim3(grid), dim3(64 * RW_WAVES), 0, st, a);
+            else hipLaunchKernelGGL((input_proj_bf16_kernel<128, 3, 4, 3>), dim3(grid), dim3(64 * RW_WAVES), 0, st, a);
             return check_launch();
         }
         if (a.D == 32) return launch_proj<32, 3, 4>(a, st);
@@ -662,6 +682,11 @@ int input_proj_dispatch(const HpmnInputProj &a, hipStream_t st) {
 static bool dx_bf16() {
     static const int on = [] { const char *e = getenv("HPMN_DX_BF16"); return e ? atoi(e) : 1; }();
     return on != 0;
+}
+
+static int dx_planes() {
+    static const int np = [] { const char *e = getenv("HPMN_DX_PLANES"); return (e && atoi(e) == 2) ? 2 : 3; }();
+    return np;
 }
 
 // HPMN_DX_LDS=0: D = 128 through the row-per-lane kernel as well; HPMN_DX_LDS_GRID: workgroups of the staged form (default: CUs)
@@ -690,20 +715,30 @@ int gru_dx_dispatch(const HpmnGruWgrad &a, hipStream_t st) {
     else if (a.H == 32 && DT == 2) hipLaunchKernelGGL((gru_dx_kernel<96, 2, 1, true>), dim3(rowwise_grid(rows, 1)), blk, 0, st, a);
     else if (a.H == 64 && DT == 1) hipLaunchKernelGGL((gru_dx_kernel<192, 1, 1, true>), dim3(rowwise_grid(rows, 1)), blk, 0, st, a);
     else if (a.H == 64 && DT == 2) hipLaunchKernelGGL((gru_dx_kernel<192, 2, 1, true>), dim3(rowwise_grid(rows, 1)), blk, 0, st, a);
-    else if (a.H == 128 && DT == 1 && dx_bf16()) hipLaunchKernelGGL((gru_dx_bf16_kernel<384, 1>), dim3(rowwise_grid(rows, 1)), blk, 0, st, a);
+    else if (a.H == 128 && DT == 1 && dx_bf16()) {
+        if (dx_planes() == 2) hipLaunchKernelGGL((gru_dx_bf16_kernel<384, 1, 2>), dim3(rowwise_grid(rows, 1)), blk, 0, st, a);
+        else hipLaunchKernelGGL((gru_dx_bf16_kernel<384, 1, 3>), dim3(rowwise_grid(rows, 1)), blk, 0, st, a);
+    }
     else if (a.H == 128 && DT == 4 && dx_bf16() && dx_lds()) {
         // (the workgroup-staged form: one tile per workgroup at a time, persistent over the CUs)
-        constexpr int lds = 2 * 24 * 2 * 64 * 16;
+        const int np = dx_planes();
+        const int lds = 2 * 24 * np * 64 * 16;
         static const bool attr = [] {
-            return hipFuncSetAttribute(reinterpret_cast<const void *>(gru_dx_bf16_lds_kernel<384>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
+            return hipFuncSetAttribute(reinterpret_cast<const void *>(gru_dx_bf16_lds_kernel<384, 2>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 24 * 2 * 64 * 16) == hipSuccess &&
+                   hipFuncSetAttribute(reinterpret_cast<const void *>(gru_dx_bf16_lds_kernel<384, 3>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 24 * 3 * 64 * 16) == hipSuccess;
         }();
         (void)attr;
         const long ntile = (rows + 31) / 32;
         const unsigned grid = (unsigned)(ntile < dx_lds_grid() ? ntile : dx_lds_grid());
-        hipLaunchKernelGGL((gru_dx_bf16_lds_kernel<384>), dim3(grid), blk, lds, st, a);
+        if (np == 2) hipLaunchKernelGGL((gru_dx_bf16_lds_kernel<384, 2>), dim3(grid), blk, lds, st, a);
+        else hipLaunchKernelGGL((gru_dx_bf16_lds_kernel<384, 3>), dim3(grid), blk, lds, st, a);
     }
-    else if (a.H == 128 && DT == 4 && dx_bf16()) hipLaunchKernelGGL((gru_dx_bf16_kernel<384, 4>), dim3(rowwise_grid(rows, 4)), blk, 0, st, a);
+    else if (a.H == 128 && DT == 4 && dx_bf16()) {
+        if (dx_planes() == 2) hipLaunchKernelGGL((gru_dx_bf16_kernel<384, 4, 2>), dim3(rowwise_grid(rows, 4)), blk, 0, st, a);
+        else hipLaunchKernelGGL((gru_dx_bf16_kernel<384, 4, 3>), dim3(rowwise_grid(rows, 4)), blk, 0, st, a);
+    }
     else if (a.H == 128 && DT == 1) hipLaunchKernelGGL((gru_dx_kernel<384, 1, 1, false>), dim3(rowwise_grid(rows, 1)), blk, 0, st, a);
     else if (a.H == 128 && DT == 4) hipLaunchKernelGGL((gru_dx_kernel<384, 1, 4, false>), dim3(rowwise_grid(rows, 4)), blk, 0, st, a);
     else return HPMN_EUNSUPPORTED;

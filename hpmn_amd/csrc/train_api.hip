@@ -575,7 +575,8 @@ int hpmn_scan_bwd(HpmnTrainCtx *ctx, const HpmnScanDesc *d, const void *ids, con
         if (i == 0 && fused_dx && !has_plan && !(d->mask_id0 & HPMN_ID_I64) &&
             gru_scan_bwd_fuses_scatter(d->H, d->B, D, d->F, d->E)) {
             // ... and goes straight into the table gradient: no d_x buffer, no scatter launch behind layer 0
-            if (!gru_scan_bwd_scatter_inloop(D)) a.d_x = nullptr;
+            if (gru_scan_bwd_scatter_inloop(D)) a.flags |= HPMN_BWD_SCATTER_INLOOP;     // (d_x: the kernel's scratch)
+            else a.d_x = nullptr;
             a.scatter_ids = ids; a.d_emb = d_emb; a.Tids = d->T; a.F = d->F; a.E = d->E;
             a.front_zero = d->front_zero; a.mask_id0 = d->mask_id0; a.last_t = L.T[0] + d->last_index;
             a.d_last = d->T + d->last_index >= 0 ? d_last : nullptr;
@@ -743,6 +744,52 @@ int hpmn_train_probe_ms(HpmnTrainCtx *ctx, float *ms) {
     HIPCHK(hipEventSynchronize(c->probe1));
     HIPCHK(hipEventElapsedTime(ms, c->probe0, c->probe1));
     return HPMN_OK;
+}
+
+int hpmn_train_step(HpmnTrainCtx *ctx, const HpmnTrainStep *s, void *stream) {
+    if (!ctx || !s || !s->ids || !s->label || !s->param || !s->grad || !s->m || !s->v || !s->memory || !s->last || !s->pred ||
+        !s->d_memory || !s->d_last || !s->scan_workspace || !s->read_workspace || !s->loss_acc || !s->loss3)
+        return HPMN_EINVAL;
+    const int K = s->scan.K;
+    if (K < 1 || K > HPMN_MAX_LAYERS || s->scan.B < 1 || s->read.B != s->scan.B || s->n_emb < 0 || s->n_total < s->n_emb ||
+        s->off_read < s->n_emb || s->off_read + s->read.n_params > s->n_total)
+        return HPMN_EINVAL;
+    const float *wg[HPMN_MAX_LAYERS], *bg[HPMN_MAX_LAYERS], *wc[HPMN_MAX_LAYERS], *bc[HPMN_MAX_LAYERS];
+    float *dwg[HPMN_MAX_LAYERS], *dbg[HPMN_MAX_LAYERS], *dwc[HPMN_MAX_LAYERS], *dbc[HPMN_MAX_LAYERS];
+    for (int i = 0; i < K; ++i) {
+        for (int j = 0; j < 4; ++j)
+            if (s->off_gru[i][j] < s->n_emb || s->off_gru[i][j] >= s->n_total) return HPMN_EINVAL;
+        wg[i] = s->param + s->off_gru[i][0]; bg[i] = s->param + s->off_gru[i][1];
+        wc[i] = s->param + s->off_gru[i][2]; bc[i] = s->param + s->off_gru[i][3];
+        dwg[i] = s->grad + s->off_gru[i][0]; dbg[i] = s->grad + s->off_gru[i][1];
+        dwc[i] = s->grad + s->off_gru[i][2]; dbc[i] = s->grad + s->off_gru[i][3];
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (s->clear_grad_first) HIPCHK(hipMemsetAsync(s->grad, 0, (size_t)s->n_total * sizeof(float), st));
+    int rc = hpmn_scan_fwd_train(ctx, &s->scan, s->ids, s->param, wg, bg, wc, bc, s->memory, s->last, s->scan_workspace, stream);
+    if (rc != HPMN_OK) return rc;
+    // read path: forward + loss + backward; its weight gradients stay in the workspace as partial sums
+    rc = hpmn_read_fwd_bwd(&s->read, s->param + s->off_read, s->memory, s->last, s->label, s->mask1, s->mask2, s->keep_prob,
+                           s->inv_global_batch, s->memory_reg, s->pred, s->loss_acc, s->d_memory, s->d_last, nullptr,
+                           s->read_workspace, stream);
+    if (rc != HPMN_OK) return rc;
+    rc = hpmn_scan_bwd(ctx, &s->scan, s->ids, wg, wc, s->d_memory, s->d_last, dwg, dbg, dwc, dbc, s->grad, s->scan_workspace,
+                       /*defer_join=*/1, stream);
+    if (rc != HPMN_OK) return rc;
+    // behind the reverse scans: the read path's weight gradients + the loss scalars, then the table's sweep --
+    // both underneath the GRU weight gradients on the context's helper stream
+    const HpmnReadDesc *rd = &s->read;
+    rc = hpmn_read_param_grads_loss_n(1, &rd, s->grad + s->off_read, s->read_workspace, s->loss_acc, s->inv_global_batch,
+                                      s->memory_reg, s->loss3, stream);
+    if (rc != HPMN_OK) return rc;
+    if (s->n_emb > 0) {
+        rc = hpmn_adam_step_clear(s->param, s->grad, s->m, s->v, s->n_emb, s->lr_t, s->beta1, s->beta2, s->eps, s->clip, 1.0f, stream);
+        if (rc != HPMN_OK) return rc;
+    }
+    rc = hpmn_train_join(ctx, stream);
+    if (rc != HPMN_OK) return rc;
+    return hpmn_adam_step_clear(s->param + s->n_emb, s->grad + s->n_emb, s->m + s->n_emb, s->v + s->n_emb, s->n_total - s->n_emb,
+                                s->lr_t, s->beta1, s->beta2, s->eps, s->clip, 1.0f, stream);
 }
 
 int hpmn_train_join(HpmnTrainCtx *ctx, void *stream) {

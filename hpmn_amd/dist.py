@@ -15,6 +15,56 @@ import torch
 import torch.distributed as td
 
 
+# Runtime settings of a data-parallel process (r6; through r5 they lived in bench.py only).  The data-parallel step has seven
+# streams (launch, auxiliary, two helpers, the plan's, the communicators') and the HIP runtime four hardware queues by default:
+# streams that share a queue serialise.  Measured with one rank on RCCL in bench.py's timed loop (r5, rows exchange, C3):
+# 4 / 5 / 6 / 8 queues -> 3.01 / 2.63 / 3.14 / 3.41 ms per step.  Both variables are read ONCE, at the first HIP call.
+DP_RUNTIME_ENV = {"GPU_MAX_HW_QUEUES": "5", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+
+
+def apply_runtime_env(force: bool = False) -> dict:
+    """Set DP_RUNTIME_ENV (defaults only: a caller's own values win) when this process is one rank of a multi-process job
+    (WORLD_SIZE > 1) or ``force``.  Called by ``import hpmn_amd`` and by init_data_parallel(); returns what it set.  Warns when
+    HIP is already initialised and a value would have changed (too late to take effect)."""
+    import os
+    import warnings
+    if not force and int(os.environ.get("WORLD_SIZE", "1") or 1) <= 1:
+        return {}
+    done = {}
+    late = torch.cuda.is_available() and torch.cuda.is_initialized()
+    for k, v in DP_RUNTIME_ENV.items():
+        if k not in os.environ:
+            if late:
+                warnings.warn("hpmn_amd.dist: %s is unset and HIP is already initialised -- import hpmn_amd (or call "
+                              "dist.apply_runtime_env()) before the first CUDA/HIP call; the data-parallel step is ~14 %% "
+                              "slower on the runtime's default of four hardware queues" % k)
+            os.environ[k] = v
+            done[k] = v
+    return done
+
+
+def init_data_parallel(backend: str = "nccl"):
+    """One rank of a one-node data-parallel job launched by ``python -m torch.distributed.run --nproc-per-node N
+    --master-addr 127.0.0.1 ...``: runtime settings, device, process group (RCCL over xGMI; ``gloo`` for dry runs in which
+    ranks share a device).  Returns (rank, world, device).  A single process (no WORLD_SIZE) gets (0, 1, cuda:0) and no group."""
+    import os
+    world = int(os.environ.get("WORLD_SIZE", "1") or 1)
+    rank = int(os.environ.get("RANK", "0") or 0)
+    local = int(os.environ.get("LOCAL_RANK", "0") or 0)
+    apply_runtime_env()
+    if backend == "gloo":
+        local = local % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1 and not (td.is_available() and td.is_initialized()):
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            td.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            td.init_process_group("gloo", rank=rank, world_size=world)
+    return rank, world, device
+
+
 def rank_world() -> Tuple[int, int]:
     if td.is_available() and td.is_initialized():
         return td.get_rank(), td.get_world_size()

@@ -505,7 +505,9 @@ class Hpmn_Basic(object):
         if B == 0 or not self._hip_read:
             self.flat_grad.zero_()
             self._table_grad_clean = True
-            self._flat_grad_clean = B == 0
+            # (an empty shard leaves the flag False: under data parallel the all-reduces that follow write the OTHER ranks'
+            #  gradient sum into this buffer, and only the branch of train_step whose Adam launches clear every range sets
+            #  the flag again -- ADVICE r5)
         if B == 0:
             return dict(prediction=torch.empty(0, device=self.device)), torch.zeros((), device=self.device)
         if not self._hip_read:
@@ -682,6 +684,8 @@ class Hpmn_Basic(object):
         rank must pass it or none (it issues collectives)."""
         if self.compact_table_grad:
             return self._train_step_rows(ids, label, keep_prob, masks, global_batch, next_ids, next_global_batch)
+        if item_ids is None and self._one_call_ok(ids):
+            return self._train_step_one_call(ids, label, keep_prob, masks, global_batch)
         if self._two_pass_table_adam(ids):
             return self._train_step_two_pass(ids, label, keep_prob, masks, global_batch)
         if self._dp_two_pass(ids):
@@ -768,6 +772,97 @@ class Hpmn_Basic(object):
         # (every element of the flat gradient has been consumed by a clearing Adam launch -- unless the table went the sharded way)
         self._flat_grad_clean = not (self._dp and self.table_exchange == "sharded")
         return out, ce
+
+    # ------------------------------------------------------------------ the whole step behind ONE library call (r6)
+    ONE_CALL_STEP = os.environ.get("HPMN_ONE_CALL_STEP", "1") != "0"
+    _one_call_cache = None
+
+    def _one_call_ok(self, ids) -> bool:
+        """The plain single-process step (one dense sweep over the table, everything on the caller's stream + the library's
+        helper stream) is one call of hpmn_train_step: the graphs and settings for which train_step would otherwise issue
+        exactly hpmn_scan_fwd_train -> hpmn_read_fwd_bwd -> hpmn_scan_bwd -> read weight gradients -> two clearing Adam launches."""
+        if not (self.ONE_CALL_STEP and self._hip_read and not self._dp and not self.lazy_table_adam and not self.l2_reg
+                and self._goff == 0 and ids.shape[0] > 0 and len(self._branches) == 1 and self._preset_plan is None):
+            return False
+        if self.det_scatter or self.flat_grad.numel() >= self.AUX_MIN_NUMEL or self._two_pass_table_adam(ids):
+            return False
+        if isinstance(self._split_probe, dict) and self._split_probe.get("armed"):
+            return False
+        return bool(ops.TRAIN_ABI and ops.PIPELINE_CHUNKS <= 1 and ops.FUSED_FWD and not ops.SPLIT_LAYER0_BWD
+                    and ops.pipe_mode(self.spec) == "")
+
+    @torch.no_grad()
+    def _train_step_one_call(self, ids, label, keep_prob, masks, global_batch):
+        """sess.run(train_step) of code/hpmn.py:482 as ONE library call (hpmn_train_step, ABI v14): the descriptor is built once
+        per batch shape; a step fills in the batch's pointers and scalars.  Host work per step: two small allocations, a
+        dozen struct stores, one ctypes call (tools/host_enqueue_time.py)."""
+        from . import _lib
+        import ctypes as C
+        B = int(ids.shape[0])
+        if global_batch is None:
+            global_batch = B
+        ops._chk_ids(ids)
+        assert label.dtype == torch.int32 and label.is_contiguous() and label.shape[0] == B
+        key = (B, ids.dtype, torch.cuda.current_stream().cuda_stream, self.flat_param.data_ptr(), self.flat_grad.data_ptr(),
+               self.flat_m.data_ptr(), self._loss_acc.data_ptr())
+        cache = self._one_call_cache
+        if cache is None or cache["key"] != key:
+            spec, dev = self.spec, self.device
+            st = _lib.HpmnTrainStep()
+            st.scan = spec.desc(B, self.feature_size, ids)
+            C.memmove(C.byref(st.read), C.byref(self._read_desc), C.sizeof(_lib.HpmnReadDesc))
+            st.read.B = B
+            st.param, st.grad = self.flat_param.data_ptr(), self.flat_grad.data_ptr()
+            st.m, st.v = self.flat_m.data_ptr(), self.flat_v.data_ptr()
+            st.n_emb = self.params["Embedding/emb_mtx"].numel()
+            st.n_total = self.flat_param.numel()
+            for i, names in enumerate(self._gru_names):
+                for j, n in enumerate(names):
+                    st.off_gru[i][j] = self._offs[n]
+            st.off_read = self._offs[self._branches[0][0] + "/dense/kernel"]
+            lib = _lib.load()
+            ws = torch.empty(int(lib.hpmn_scan_train_workspace_bytes(C.byref(st.scan))), device=dev, dtype=torch.uint8)
+            keep = dict(ws=ws, memory=torch.empty(B, spec.K, spec.H, device=dev), last=torch.empty(B, spec.D0, device=dev),
+                        d_memory=torch.empty(B, spec.K, spec.H, device=dev), d_last=torch.empty(B, spec.D0, device=dev))
+            st.memory, st.last = keep["memory"].data_ptr(), keep["last"].data_ptr()
+            st.d_memory, st.d_last = keep["d_memory"].data_ptr(), keep["d_last"].data_ptr()
+            st.scan_workspace = ws.data_ptr()
+            st.loss_acc = self._loss_acc.data_ptr()
+            st.memory_reg = float(self.memory_reg)
+            st.beta1, st.beta2, st.eps, st.clip = self.beta1, self.beta2, self.adam_eps, 1.0
+            cache = self._one_call_cache = dict(key=key, st=st, keep=keep, ctx=ops._ctx(dev), lib=lib)
+        st, keep = cache["st"], cache["keep"]
+        self._read_desc.B = B
+        rws = ops._read_workspace(self._read_desc, self.device)          # (zero-initialised once per shape, then reused)
+        st.read_workspace = rws.data_ptr()
+        seed = 0
+        if masks is None and keep_prob < 1.0:
+            self._dropout_step += 1
+            seed = _splitmix64(_splitmix64(self._dropout_base + self._dropout_step) ^ (self.rank + 1)) | 1
+        st.read.dropout_seed = seed & 0xFFFFFFFFFFFFFFFF
+        m1 = m2 = None
+        if masks is not None:
+            m1, m2 = masks
+            ops._chk_f32(m1, m2)
+        st.mask1, st.mask2 = ops._ptr(m1), ops._ptr(m2)
+        st.scan.mask_id0 = ops._idf(ids, self.spec.mask_id0)
+        st.ids, st.label = ids.data_ptr(), label.data_ptr()
+        pred = torch.empty(B, device=self.device)
+        sums = torch.empty(3, device=self.device)
+        st.pred, st.loss3 = pred.data_ptr(), sums.data_ptr()
+        st.keep_prob, st.inv_global_batch = float(keep_prob), 1.0 / float(global_batch)
+        if not self._loss_acc_clean:
+            self._loss_acc.zero_()
+        st.clear_grad_first = 0 if self._flat_grad_clean else 1
+        self.adam_t += 1
+        t = self.adam_t
+        st.lr_t = self.learning_rate * math.sqrt(1.0 - self.beta2 ** t) / (1.0 - self.beta1 ** t)
+        self._flat_grad_clean = self._table_grad_clean = self._loss_acc_clean = False
+        _lib.check(cache["lib"].hpmn_train_step(cache["ctx"], C.byref(st), torch.cuda.current_stream().cuda_stream), "hpmn_train_step")
+        self._flat_grad_clean = self._table_grad_clean = self._loss_acc_clean = True
+        # (memory: the step's persistent scratch -- valid until the next train_step of this shape)
+        out = dict(prediction=pred, log_loss_sum=sums[0], memory_loss=sums[1], memory=keep["memory"], pending=None)
+        return out, sums[2]
 
     # ------------------------------------------------------------------ dense table Adam in two passes
     TWO_PASS_TABLE_ADAM = int(os.environ.get("HPMN_TWO_PASS_ADAM", "1")) != 0
@@ -1081,8 +1176,15 @@ class Hpmn_Basic(object):
         # for step N+2 are enqueued after its main-communicator calls of step N and before those of step N+1, on every rank
         # alike; neither kind waits for the other on the device (compute kernels never wait for a collective), so a peer that
         # lags finishes its main-communicator calls first and then joins -- no cycle.  Unmeasured on more than one GPU.
-        group = dist.side_group() if (self._dp and os.environ.get("HPMN_DP_SIDE_GROUP", "1") != "0") else None
-        # (next_ids must EXIST already -- a slice of a staged dataset: the stream is not made to wait for anything)
+        # r6: the second communicator is OPT-IN (HPMN_DP_SIDE_GROUP=1) until a run on more than one GPU has validated
+        # it -- two communicators' kernels in flight on streams that may share a hardware queue (seven streams, four or five
+        # queues) is a known RCCL hang hazard: rank A's queue could hold [side, main] where rank B's holds [main, side].  On the
+        # default communicator every rank issues every collective in the same program order.
+        group = dist.side_group() if (self._dp and os.environ.get("HPMN_DP_SIDE_GROUP", "0") == "1") else None
+        # (the plan stream reads next_ids -- order it behind what the caller's stream has been given so far, in case
+        #  the tensor was produced there; that is the END of the previous step, the plan still has this whole step to run in.
+        #  next_ids must stay unchanged until the next train_step has consumed the plan: a slice of a staged dataset does.)
+        pst.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(pst):
             plan = self._rows_plan(next_ids, cap, bounds) if next_ids.shape[0] > 0 else None
             ex = self._rows_early_exchange(plan, next_ids.dtype, cap, C, group=group) if self._dp else None
@@ -1354,13 +1456,15 @@ class Hpmn_Basic(object):
         return best
 
     def eval(self, dataset, batchsize):
-        """-> (auc, log-loss, mean of per-batch memory_loss); code/hpmn.py:497-519.  With data
-        parallel every rank scores a slice of each batch and predictions are all-gathered."""
+        """-> (auc, log-loss, mean of per-batch memory_loss); code/hpmn.py:497-519.  Data parallel (r6): the
+        DATASET is sharded -- rank r scores rows [n r / N, n (r+1) / N) in full-width passes on the same kernels as the single
+        process -- and ONE all-gather of the predictions plus ONE all-reduce of the memory-loss sum end the pass (r5: every
+        reference batch was cut into per-rank slices, two collectives per batch, 250-row slices below the tile kernels' width)."""
         ds = self._dev(dataset)
         preds, mem_losses = [], []
-        if (not self._dp and ds.item_ids is None and getattr(self, "_hip_read", False) and ds.n > batchsize
-                and self._tiled_inference(self.TILED_EVAL_ROWS)):
-            # Single process, user-only graph: SEVERAL reference batches per pass (the tile kernel wants ~4096 rows in
+        user_only = ds.item_ids is None and getattr(self, "_hip_read", False)
+        if user_only and (self._dp or (ds.n > batchsize and self._tiled_inference(self.TILED_EVAL_ROWS))):
+            # User-only graph: SEVERAL reference batches per pass (the tile kernel wants ~4096 rows in
             # flight; the harness's 4 x 500 = 2000 half-fill the chip).  The reference's third return value is the mean over
             # batches of the per-batch memory_loss SUMS (code/hpmn.py:360-369, :512-519) = the sum over all rows divided by the
             # number of reference batches, whatever the grouping -- so only the float32 summation order differs.
@@ -1370,10 +1474,15 @@ class Hpmn_Basic(object):
             rows_per_pass = self.TILED_EVAL_ROWS * (2 if (self.spec.H == 64 and ops.TILE64 and self.TILED_EVAL_ROWS == 4096) else 1)
             per_pass = batchsize * max(1, rows_per_pass // batchsize)
             total = torch.zeros(1, device=self.device)
-            for lo in range(0, ds.n, per_pass):
-                out = self.forward_inference(ds.ids[lo:lo + per_pass], want_logit=False, want_att=False)
+            first, last = dist.shard_bounds(0, ds.n, self.rank, self.world)      # (single process: the whole set)
+            for lo in range(first, last, per_pass):
+                out = self.forward_inference(ds.ids[lo:min(lo + per_pass, last)], want_logit=False, want_att=False)
                 preds.append(out["prediction"])
                 total += out["memory_loss"].reshape(1)
+            if self._dp:
+                mine = torch.cat(preds) if preds else torch.empty(0, device=self.device)
+                preds = [dist.gather_predictions(mine.contiguous(), ds.n)]
+                dist.allreduce_sum_(total)
             mem_losses = [total / float(n_ref)]
             batches = ()
         else:
@@ -1567,6 +1676,10 @@ def main(argv: Sequence[str]) -> int:
         print("Useage: python hpmn.py [dataset]")
         return 1
     dataset_name = argv[1]
+    if int(os.environ.get("WORLD_SIZE", "1") or 1) > 1:
+        # `python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 hpmn.py <dataset>`: one rank per GPU,
+        # runtime settings + device + RCCL process group (dist.init_data_parallel); the model shards batches and evaluation
+        dist.init_data_parallel(os.environ.get("HPMN_DP_BACKEND", "nccl"))
     if dataset_name == "amazon":
         trainset, testset, feature_size = load_dataset_pkl("../data/amazon/dataset_hpmn.pkl")
         model = Hpmn("model/amazon/hpmn/", trainset, testset, feature_size, 3, 2, 100, 100, 0.003, 32, 16, 3,

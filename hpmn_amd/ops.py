@@ -924,6 +924,7 @@ def _ctx(device) -> int:
 
 
 FAST_PLAN = os.environ.get("HPMN_FAST_PLAN", "1") != "0"      # hpmn_scatter_plan_build instead of torch.sort & co
+CHECK_IDS = os.environ.get("HPMN_CHECK_IDS", "0") == "1"      # range-check every plan's ids (blocking; debugging)
 _row_bounds = {}
 
 
@@ -963,6 +964,14 @@ class ScatterPlan:
             # r5: one library call -- radix sort of (id, lookup) pairs over the bits the table needs, segment scan, plan
             # kernel, per-chunk counts: ~10 launches where the torch ops below are ~45 (240 us of queue latency at C3)
             vmax = int(V) if V else (2 ** 62 if ids.dtype == torch.int64 else 2 ** 31 - 1)
+            if V and CHECK_IDS:
+                # the radix sort covers the low key_bits(V) bits only -- an id outside [0, V) is mis-ordered and the
+                # plan's `rows` are then neither ascending nor distinct (torch.sort tolerated it).  Staged datasets are
+                # range-checked once (_DeviceDataset); a caller's own tensors are checked here under HPMN_CHECK_IDS=1
+                # (a device-to-host round trip per plan: a debugging switch)
+                lo, hi = int(flat.min()), int(flat.max())
+                if lo < 0 or hi >= int(V):
+                    raise ValueError("ids outside [0, %d): min %d, max %d" % (int(V), lo, hi))
             need = int(lib.hpmn_scatter_plan_build_workspace_bytes(n, self.id_flags, vmax))
             if need <= 0:
                 raise _lib.HpmnLibraryError("hpmn_scatter_plan_build_workspace_bytes refused n=%d V=%d" % (n, vmax))

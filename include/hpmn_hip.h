@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define HPMN_ABI_VERSION 13
+#define HPMN_ABI_VERSION 14
 #define HPMN_ID_MASK0 1   /* id-flags bit 0: id 0 gathers a zero row and receives no gradient (the Hpmn class)  */
 #define HPMN_ID_I64 2     /* id-flags bit 1: the ids tensor is int64 (default: int32)                          */
 #define HPMN_MAX_LAYERS 12
@@ -50,6 +50,10 @@ extern "C" {
  * smaller than the forward's own rounding of h (tests/test_candidate_elision_cpu.py, tests/test_gpu_parity.py).  hpmn_gru_candidate_elision(H, B) != 0 where both sides support it. */
 #define HPMN_FWD_NO_CANDIDATE 1      /* HpmnGruFusedFwd.flags bit 0: gates[..., 2H:3H] is NOT written            */
 #define HPMN_BWD_CANDIDATE_FROM_HS 1 /* HpmnGruBwd.flags bit 0: gates[..., 2H:3H] is NOT read (see above)        */
+#define HPMN_BWD_SCATTER_INLOOP 2    /* HpmnGruBwd.flags bit 1 (ABI v14): with d_emb AND d_x set (H = 64, D <= 32) the input
+                                      * gradient's tiles are added to d_emb INSIDE the scan's loop and d_x is SCRATCH (it does
+                                      * not hold the input gradient afterwards).  Without the bit d_emb + d_x means: d_x is
+                                      * written, the scatter runs as the launch's epilogue.                              */
 
 enum {
     HPMN_OK = 0,
@@ -617,6 +621,41 @@ int hpmn_adam_step(float *param, const float *grad, float *m, float *v, int64_t 
 int hpmn_adam_step_clear(float *param, float *grad, float *m, float *v, int64_t n,
                          float lr_t, float beta1, float beta2, float eps, float clip,
                          float grad_scale, void *stream);
+/* (ABI v14) ONE library call per training step -- the reference runs a step as ONE sess.run(train_step)
+ * (code/hpmn.py:336, :482).  Replaces, for a graph that executes the "User" branch only, everything that call runs:
+ *   hpmn_scan_fwd_train -> hpmn_read_fwd_bwd (weight gradients deferred) -> hpmn_scan_bwd (defer_join) ->
+ *   hpmn_read_param_grads_loss_n -> hpmn_adam_step_clear over the table range [0, n_emb) -> hpmn_train_join ->
+ *   hpmn_adam_step_clear over the dense variables [n_emb, n_total)
+ * i.e. forward, loss, BPTT, the densified table gradient, per-element clip and the dense TF-form Adam of code/hpmn.py:202-214
+ * in the plain single-process form (one sweep over the table; the two-pass / compact-row / data-parallel forms keep their
+ * separate calls).  Every variable lives in ONE flat fp32 buffer (`param`; `grad`, `m`, `v` alike): the table first, then the
+ * dense variables; off_gru[i] = element offsets of layer i's {gates kernel, gates bias, candidate kernel, candidate bias},
+ * off_read = first read-path variable (HpmnReadDesc's offsets are relative to it).  `grad` must be all-zero on entry
+ * (clear_grad_first != 0: the call zeroes it first) and is all-zero again when the call's work has run; `loss_acc` [2]
+ * likewise.  loss3 [3] <- {log-loss sum, memory-loss sum, cross_entropy}.  mask1 / mask2: NULL (masks drawn in the kernel
+ * from read.dropout_seed when keep_prob < 1) or caller-supplied dropout masks.  All pointers are device pointers owned by the
+ * caller; asynchronous on `stream`; nothing is allocated.  What used to cost the Python harness ~200 us of enqueue work per
+ * step (four calls + glue) against ~250 us of device time at the Amazon shape is one struct and one call. */
+typedef struct HpmnTrainStep {
+    HpmnScanDesc scan;
+    HpmnReadDesc read;
+    const void *ids;                       /* [B, T, F], width per scan.mask_id0's HPMN_ID_I64 bit */
+    const int32_t *label;                  /* [B] */
+    float *param, *grad, *m, *v;
+    int64_t n_emb, n_total;
+    int64_t off_gru[HPMN_MAX_LAYERS][4];
+    int64_t off_read;
+    float *memory, *last, *pred;           /* [B,K,H], [B,D0], [B] */
+    float *d_memory, *d_last;              /* scratch of the same shapes */
+    void *scan_workspace;                  /* hpmn_scan_train_workspace_bytes(&scan) */
+    float *read_workspace;                 /* hpmn_read_workspace_bytes(&read), zero-initialised ONCE by the caller */
+    float *loss_acc, *loss3;
+    const float *mask1, *mask2;
+    float keep_prob, inv_global_batch, memory_reg;
+    float lr_t, beta1, beta2, eps, clip;
+    int32_t clear_grad_first;
+} HpmnTrainStep;
+int hpmn_train_step(HpmnTrainCtx *ctx, const HpmnTrainStep *step, void *stream);
 /* Row-wise ("lazy") form for embedding tables too large for the dense sweep (BASELINE configs[4]: a table
  * sized to HBM cannot also hold a dense gradient, and 28 B/element of dense Adam traffic over 10^9+ rows is the
  * whole step): the same update applied only to the n_rows table rows row_ids[u] (distinct), whose clipped

@@ -30,9 +30,11 @@ def run(m, tr, te, steps=5, batch=50):
     # HPMN_DP_NEXT_IDS=1: every step is told the next batch's ids (what Hpmn.train() does): the next step's scatter plan and
     # the exchange of the ranks' distinct-row lists then run a step ahead -- incl. the step whose NEXT shard is empty
     ahead = os.environ.get("HPMN_DP_NEXT_IDS") == "1"
-    order = list(ds.batches(batch))[:steps] + [(0, 1)]
-    # (the last entry: a "last batch" of ONE sample -- with two ranks one shard is empty, and that rank must still take part
-    #  in every collective of the step)
+    allb = list(ds.batches(batch))
+    order = allb[:steps] + [(0, 1)] + allb[steps:steps + 1]
+    # (the entry before the last: a "last batch" of ONE sample -- with two ranks one shard is empty, and that rank must still
+    #  take part in every collective of the step; the entry BEHIND it is the next epoch's first step: the rank whose shard was
+    #  empty holds the other ranks' gradient sum in its flat gradient and must not accumulate onto it -- ADVICE r5)
     for k, (lo, hi) in enumerate(order):
         a, b = dist.shard_bounds(lo, hi, m.rank, m.world)
         nxt = {}
@@ -83,6 +85,28 @@ def run_big(m, tr, te, steps=3, batch=16):
     return out
 
 
+def build_eval(tmp):
+    """HPMN_DP_EVAL=1: evaluation alone -- an XLong-shaped graph at H = 64 from seeded weights, 6 800 rows: a single process
+    takes the 16-sequence tile kernels in one pass, two ranks 3 400 rows each, four ranks 1 700 each (all on the tile kernels:
+    a row's arithmetic does not depend on which tile it lands in)."""
+    from hpmn_amd.hpmn import Hpmn_Industry
+    rng = np.random.default_rng(17)
+    n, T, V = 6800, 41, 900
+    ids = rng.integers(40, V, size=(n, T, 2)).astype(np.int32)
+    ids[:, :, 0] = ids[:, :1, 0] % 20 + 1
+    te = dict(ids=ids, label=rng.integers(0, 2, size=n).astype(np.int32))
+    m = Hpmn_Industry(tmp, te, te, V, 2, 1, T, 1, 0.003, 64, 16, 3, [2] * 10 + [1], [1], 4, 1, True, False,
+                      memory_reg=5e-5, verbose=False, seed=3)
+    g = torch.Generator(device="cpu").manual_seed(7)
+    n_emb = m.params["Embedding/emb_mtx"].numel()
+    m.flat_param[n_emb:] += 0.2 * torch.randn(m.flat_param.numel() - n_emb, generator=g).to(m.device)
+    return m, te, te
+
+
+def run_eval(m, tr, te):
+    return {"__eval__": np.array(m.eval(te, 500), dtype=np.float64)}
+
+
 def main():
     # HPMN_DP_BACKEND=nccl: one GPU per rank over RCCL (needs >= 2 devices); default: gloo, both ranks on cuda:0
     backend = os.environ.get("HPMN_DP_BACKEND", "gloo")
@@ -94,9 +118,10 @@ def main():
         td.init_process_group("gloo")
         torch.cuda.set_device(0)
     big = os.environ.get("HPMN_DP_BIG") == "1"
-    m, tr, te = (build_big if big else build)(sys.argv[1] + ".model%d" % td.get_rank())
+    ev = os.environ.get("HPMN_DP_EVAL") == "1"
+    m, tr, te = (build_eval if ev else build_big if big else build)(sys.argv[1] + ".model%d" % td.get_rank())
     assert m.world == int(os.environ.get("WORLD_SIZE", "1"))
-    out = (run_big if big else run)(m, tr, te)
+    out = (run_eval if ev else run_big if big else run)(m, tr, te)
     if td.get_rank() == 0:
         np.savez(sys.argv[1], **out)
     td.barrier()

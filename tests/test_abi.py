@@ -43,7 +43,7 @@ def test_struct_layout_matches_c_compiler(tmp_path):
                "HpmnScanDesc": _lib.HpmnScanDesc, "HpmnOnlineUpdate": _lib.HpmnOnlineUpdate,
                "HpmnGruFusedFwd": _lib.HpmnGruFusedFwd, "HpmnGruPairFwd": _lib.HpmnGruPairFwd, "HpmnGruPairBwd": _lib.HpmnGruPairBwd, "HpmnPipe": _lib.HpmnPipe,
                "HpmnTrainLayout": _lib.HpmnTrainLayout, "HpmnScatterPlan": _lib.HpmnScatterPlan,
-               "HpmnRowsAdam": _lib.HpmnRowsAdam, "HpmnTileFwd": _lib.HpmnTileFwd}
+               "HpmnRowsAdam": _lib.HpmnRowsAdam, "HpmnTileFwd": _lib.HpmnTileFwd, "HpmnTrainStep": _lib.HpmnTrainStep}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "hpmn_hip.h"', "int main(void){"]
     for name, st in structs.items():
         lines.append('printf("%s %%zu\\n", sizeof(%s));' % (name, name))

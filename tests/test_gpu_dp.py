@@ -59,6 +59,32 @@ def test_four_rank_two_pass_step_matches_single_process(tmp_path, monkeypatch, e
     _run_two_ranks(tmp_path, "gloo", exchange, extra_env={"HPMN_TWO_PASS_MIN_NUMEL": "0"}, nproc=4)
 
 
+@pytest.mark.parametrize("nproc", [2, 4])
+def test_dataset_sharded_evaluation_matches_single_process(tmp_path, nproc):
+    """r6 (SURVEY 8e "eval shards the dataset and all-gathers predictions"; code/hpmn.py:351-373): under data
+    parallel Hpmn.eval gives rank r the rows [n r / N, n (r+1) / N) of the WHOLE set, full-width passes on the same kernels a
+    single process uses, ONE all-gather of predictions and ONE all-reduce of the memory-loss sum.  Same weights, no training:
+    AUC and log-loss to 1e-6, the memory-loss mean to 1e-5 relative (float32 sums in another order).  6 800 rows: every shard
+    (3 400 / 1 700 rows) stays on the tile kernels the single process uses."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    out = str(tmp_path / "dp.npz")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", HPMN_DP_BACKEND="gloo", HPMN_DP_EVAL="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(HERE, "dp_worker.py"), out]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert r.returncode == 0, r.stdout.decode()[-3000:]
+    got = np.load(out)["__eval__"]
+    sys.path.insert(0, HERE)
+    import dp_worker
+    m, tr, te = dp_worker.build_eval(str(tmp_path / "single"))
+    assert m.world == 1
+    want = dp_worker.run_eval(m, tr, te)["__eval__"]
+    assert 0.0 < want[0] < 1.0 and want[1] > 0 and want[2] > 0
+    np.testing.assert_allclose(got[:2], want[:2], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(got[2], want[2], rtol=1e-5)
+
+
 def test_two_rank_lazy_table_adam_matches_single_process(tmp_path, monkeypatch):
     """Row-wise (lazy) Adam under data parallel -- what a table sized to HBM needs (BASELINE configs[4]): every rank's
     touched rows and compact gradient rows are all-gathered, the union updated identically everywhere."""

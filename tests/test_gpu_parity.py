@@ -1002,7 +1002,73 @@ def test_training_step_through_the_c_abi_alone(dev, tmp_path):
                               m.flat_param.numel(), lr_t, 0.9, 0.999, 1e-8, 1.0, 1.0, st) == 0
     moved = (m.flat_param - before).abs()
     assert float(moved.max()) <= 0.001 * 1.01 and float(moved.max()) > 1e-4      # first Adam step: |dp| ~ lr
+    # ---- r6 (code/hpmn.py:336: ONE sess.run per step): the same step behind ONE call, hpmn_train_step (ABI v14),
+    #      on a second copy of the buffers -- the struct filled by hand, nothing but device memory from torch -- must land on
+    #      the parameters, moments and loss of the call sequence above, and leave the flat gradient all-zero
+    m2 = make_model(cfg, tmp_path / "one", p)
+    ts = _lib.HpmnTrainStep()
+    ts.scan = spec.desc(B, cfg.feature_size)
+    C.memmove(C.byref(ts.read), C.byref(m2._read_desc), C.sizeof(_lib.HpmnReadDesc))
+    ts.read.B = B
+    ts.ids, ts.label = t_ids.data_ptr(), t_lab.data_ptr()
+    ts.param, ts.grad, ts.m, ts.v = (m2.flat_param.data_ptr(), m2.flat_grad.data_ptr(), m2.flat_m.data_ptr(), m2.flat_v.data_ptr())
+    ts.n_emb, ts.n_total = m2.params["Embedding/emb_mtx"].numel(), m2.flat_param.numel()
+    for i, names in enumerate(m2._gru_names):
+        for j, n in enumerate(names):
+            ts.off_gru[i][j] = m2._offs[n]
+    ts.off_read = m2._offs["User/dense/kernel"]
+    memory2, last2, pred2 = torch.empty(B, K, H, device=dev), torch.empty(B, D0, device=dev), torch.empty(B, device=dev)
+    d_mem2, d_last2 = torch.empty_like(memory2), torch.empty_like(last2)
+    ws2 = torch.empty(lib.hpmn_scan_train_workspace_bytes(C.byref(ts.scan)), device=dev, dtype=torch.uint8)
+    rws2 = torch.zeros(lib.hpmn_read_workspace_bytes(C.byref(ts.read)) // 4, device=dev)
+    acc2, loss3 = torch.zeros(2, device=dev), torch.empty(3, device=dev)
+    ts.memory, ts.last, ts.pred, ts.d_memory, ts.d_last = (memory2.data_ptr(), last2.data_ptr(), pred2.data_ptr(),
+                                                           d_mem2.data_ptr(), d_last2.data_ptr())
+    ts.scan_workspace, ts.read_workspace, ts.loss_acc, ts.loss3 = ws2.data_ptr(), rws2.data_ptr(), acc2.data_ptr(), loss3.data_ptr()
+    ts.keep_prob, ts.inv_global_batch, ts.memory_reg = 1.0, 1.0 / B, cfg.memory_reg
+    ts.lr_t, ts.beta1, ts.beta2, ts.eps, ts.clip = lr_t, 0.9, 0.999, 1e-8, 1.0
+    m2.flat_grad.fill_(3.0)                      # dirty on purpose: clear_grad_first
+    ts.clear_grad_first = 1
+    assert lib.hpmn_train_step(None, C.byref(ts), st) == -1 and lib.hpmn_train_step(ctx, None, st) == -1
+    assert lib.hpmn_train_step(ctx, C.byref(ts), st) == 0
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(pred2.cpu().numpy(), pred.cpu().numpy(), rtol=0, atol=1e-7)
+    np.testing.assert_allclose(memory2.cpu().numpy(), memory.cpu().numpy(), rtol=0, atol=0)
+    l3 = loss3.cpu().numpy()
+    np.testing.assert_allclose(l3[:2], loss.cpu().numpy(), rtol=2e-6)
+    np.testing.assert_allclose(l3[2], float(ref["cross_entropy"]), rtol=2e-4, atol=1e-5)
+    assert float(m2.flat_grad.abs().max()) == 0.0 and float(acc2.abs().max()) == 0.0      # consumed, cleared
+    # (the table gradient's atomics and the weight-gradient slabs add in the same order in both: the updates agree to the last
+    #  bits; an element whose gradient is rounding noise may take its +-lr step the other way -- none does at this seed)
+    np.testing.assert_allclose(m2.flat_param.cpu().numpy(), m.flat_param.cpu().numpy(), rtol=0, atol=2e-6)
+    np.testing.assert_allclose(m2.flat_m.cpu().numpy(), m.flat_m.cpu().numpy(), rtol=0, atol=1e-7)
     lib.hpmn_train_ctx_destroy(ctx)
+
+
+def test_one_call_step_is_the_plain_train_step(dev, tmp_path):
+    """Hpmn.train_step takes the one-call form (hpmn_train_step) for the plain single-process step; switched off per instance
+    (ONE_CALL_STEP = False) the same model issues the four calls + Python glue of rounds 2-5.  Five steps with dropout masks
+    injected, ragged Amazon-shaped batches of two sizes (the cached descriptor is rebuilt when the batch shape changes): the
+    loss of every step and the final parameters agree."""
+    cfg = cfg_amazon(K=3, T=100, V=300)
+    p = f32_params(cfg, 131)
+    a, b = make_model(cfg, tmp_path / "a", p), make_model(cfg, tmp_path / "b", p)
+    b.ONE_CALL_STEP = False
+    rng = np.random.default_rng(9)
+    ces = [[], []]
+    for step in range(5):
+        B = 7 if step != 3 else 4
+        ids, label = rand_ids(cfg, B, 200 + step)
+        masks = tuple(torch.as_tensor((rng.random((B, n)) < 0.5).astype(np.float32) / 0.5).to(dev) for n in (200, 80))
+        for k, mdl in enumerate((a, b)):
+            assert mdl._one_call_ok(torch.as_tensor(ids).to(dev)) == (k == 0)
+            out, ce = mdl.train_step(torch.as_tensor(ids).to(dev), torch.as_tensor(label).to(dev), keep_prob=0.5, masks=masks)
+            assert out["prediction"].shape == (B,)
+            ces[k].append(float(ce))
+    np.testing.assert_allclose(ces[0], ces[1], rtol=2e-6)
+    assert a.adam_t == b.adam_t == 5
+    for k in p:
+        np.testing.assert_allclose(a.params[k].cpu().numpy(), b.params[k].cpu().numpy(), rtol=0, atol=1e-5, err_msg=k)
 
 
 # ------------------------------------------------------------------------------- item branch / dual mode (code/hpmn.py:444-462, :297-317)

@@ -21,7 +21,7 @@ batch=$(python -c "import bench; print(bench.CONFIGS['$cfg']['batch'])")
 python tools/pmc_digest.py $out/pmc_FETCH_SIZE.csv $out/pmc_WRITE_SIZE.csv 6 $cfg $batch $out/pmc_summary.json
 rm -f $out/pmc_FETCH_SIZE.csv $out/pmc_WRITE_SIZE.csv
 # bench.py reads the digest from profiles/ (and checks its source sha against the kernels it is about to run)
-[ "$cfg" = "c3" ] && cp $out/pmc_summary.json profiles/r05_pmc_summary.json
+[ "$cfg" = "c3" ] && cp $out/pmc_summary.json profiles/${ROUND:-r06}_pmc_summary.json
 rm -rf $out/step/prof
 timeout 900 python bench.py --config $cfg > $out/bench.json 2> $out/bench.err < /dev/null
 echo "bench rc=$?"
