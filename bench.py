@@ -816,26 +816,40 @@ def dp_report(model, c, batches, world, ms_per_step, n_model=8, busbw_gbps=300.0
     }
 
 
-# The timed region's reduced-precision products: the GRU weight gradients, layer 0's input gradient and
-# (H = 128) the input projection run as three bf16 products on split operands (hi.hi + hi.lo + lo.hi, fp32 accumulate:
-# ~16 bits of operand mantissa); evaluation-sized forward passes at H = 64 on three f16 products.  These switches put every one
-# of them back on fp32 kernels: the `ms_per_step_all_fp32` figure of the bench line is the SAME timed loop under them.
+# The timed region's products on the bf16 matrix pipe: the read path, the GRU weight gradients, layer 0's input gradient and
+# (H = 128) the input projections / input gradients -- since r6 all of them on THREE planes per operand with the six products
+# of order <= 2 (fp32-equivalent; rounds 4/5: two planes, three products, ~16 bits of operand mantissa: TWO_PLANES_ENV);
+# evaluation-sized forward passes on three f16 products.  These switches put every one of them on fp32 kernels: the
+# `ms_per_step_all_fp32` figure of the bench line is the SAME timed loop under them.
 ALL_FP32_ENV = {"HPMN_WGRAD_BF16": "0", "HPMN_BWD_DX_INLOOP": "0", "HPMN_PROJ_BF16": "0", "HPMN_DX_BF16": "0",
                 "HPMN_TILED_EVAL_MIN_ROWS": "0", "HPMN_READ_BF16": "0"}
 
 
+# the fp32 kernels for exactly the GRU products that have a split-bf16 form (weight gradients, input gradients, H = 128 projections)
+FP32_GRU_ENV = {k: ALL_FP32_ENV[k] for k in ("HPMN_WGRAD_BF16", "HPMN_BWD_DX_INLOOP", "HPMN_PROJ_BF16", "HPMN_DX_BF16")}
+
+
+# rounds 4/5's arithmetic for the same products: TWO bf16 planes per operand, three products (~5e-6 of max|grad|)
+TWO_PLANES_ENV = {"HPMN_WGRAD_PLANES": "2", "HPMN_DX_PLANES": "2", "HPMN_PROJ_PLANES": "2"}
+
+
 def dtype_string(c):
-    # (r5: the read path's TRAINING launch runs its dense layers on the bf16 pipe -- three planes per operand, the six products
-    #  of order <= 2: fp32-equivalent, measured 7e-7 of max|grad| from the fp32 launch)
-    read = "read-path training launch: bf16 3-plane split operands, six products = fp32-equivalent"
+    """The arithmetic of the timed region.  r6: every matrix product of the training step that runs on the bf16 pipe takes its
+    fp32 operands as THREE bf16 planes and accumulates the six products of order <= 2 in fp32 -- what is dropped is below 2^-24
+    of a product: fp32-equivalent (weight gradients 6e-7 of max|grad| against float64, the fp32 matrix pipe 6e-7, rounds 4/5's
+    two planes 5e-6; tests/test_gpu_parity.py::test_split_gradient_kernels_are_fp32_equivalent).  The recurrences, the
+    gather / scatter and the optimiser are plain fp32."""
+    two = [k for k in TWO_PLANES_ENV if os.environ.get(k) == "2"]
     if c["H"] == 32:
-        return "f32 (%s)" % read
-    s = "f32 (%s; GRU weight gradients + layer-0 input gradient: bf16x3 split operands, f32 accumulate" % read
+        return "f32 (read-path products: bf16 3-plane split operands, six products, f32 accumulate = fp32-equivalent)"
+    s = "f32 (matrix products of the step -- read path, GRU weight gradients, layer-0 input gradient"
     if c["H"] == 128:
-        s += "; input projection / input gradients: bf16x3 split"
-    if c["H"] == 64:
-        s += "; eval passes >= 1536 rows: f16x3 split"
-    return s + ")"
+        s += ", input projections / input gradients"
+    s += ": bf16 3-plane split operands, six products, f32 accumulate = fp32-equivalent"
+    if two:
+        s += "; EXCEPT two planes / three products (~5e-6 of max|grad|) where %s" % ",".join(two)
+    s += "; eval passes >= 1536 rows: f16x3 split on the tile kernels, memory <= 5e-5 from the fp32 kernels)"
+    return s
 
 
 WIRE_STANDIN = (300.0, 8)          # GB/s of bus bandwidth, ranks: the stand-in wire of the one-rank rows run (see side_legs)
@@ -870,6 +884,8 @@ def side_legs(args, zipf_fraction=None):
         except Exception:
             return None
     out = {"all_fp32_ms_per_step": run([], ALL_FP32_ENV)}
+    if CONFIGS[args.config]["H"] >= 64:
+        out["two_planes_ms_per_step"] = run([], TWO_PLANES_ENV)      # (rounds 4/5's arithmetic, for comparison)
     if not args.lazy_table_adam:
         out["one_rank_rccl_ms"] = {m: run(["--one-rank-rccl", m], {}) for m in ("rows", "allreduce")}
         if args.config == "c3":
@@ -1242,6 +1258,9 @@ def main():
                 except Exception:
                     zf = None
             side = side_legs(args, zipf_fraction=zf)
+            if side.get("two_planes_ms_per_step") is not None:
+                result["ms_per_step_two_planes"] = side["two_planes_ms_per_step"]
+                result["two_planes_switches"] = TWO_PLANES_ENV
             if side.get("all_fp32_ms_per_step") is not None:
                 result["ms_per_step_all_fp32"] = side["all_fp32_ms_per_step"]
                 result["all_fp32_switches"] = ALL_FP32_ENV

@@ -95,6 +95,27 @@ __global__ __launch_bounds__(256, 1) void gru_scan_bwd_feed_kernel(const HpmnGru
     __shared__ __attribute__((aligned(16))) float dact_[2][NSLOT][DROW];   // da_r | da_u | dc_pre of iteration k in row k % NSLOT
     __shared__ float eU_[2][2][H];
     __shared__ int ctr_[2][4];
+    // (r6) three planes: the LO plane of the in-loop product's stationary weight fragments lives here (12 KB at D = 32, one copy
+    // for the workgroup's two feeders; read once per product that uses it, behind the e_u hand-off) -- in registers it took the
+    // kernel from 280 to 336 registers per wave, and a weight-gradient workgroup (192) no longer fitted beside the scan on a
+    // SIMD's 512: the weight gradients of layers 1-6 then ran BEHIND layer 0's reverse scan instead of underneath it and the C3
+    // step went from 2.39 to 2.79 ms (profiles/r06_experiments.txt: the scan launch itself was 30 us FASTER).
+    constexpr int NWLO = (LOOPDX && NP == 3) ? 6 * (DXD / 16) : 1;
+    __shared__ __attribute__((aligned(16))) xbf8 wlo_[NWLO][64];
+    if constexpr (LOOPDX && NP == 3) {
+        constexpr int NCT_ = DXD / 16;
+        for (int sidx = threadIdx.x; sidx < NWLO * 64; sidx += 256) {
+            const int u = sidx >> 6, ln = sidx & 63;
+            const int ks = u / NCT_, ct = u % NCT_;
+            const long col = 16 * ct + (ln & 15);
+            const int gc = 32 * ks + 8 * (ln >> 4);
+            const float *src = gc < 2 * H ? a.wg + col * 2 * H + gc : a.wc + col * H + (gc - 2 * H);
+            const v4f v0 = *reinterpret_cast<const v4f *>(src), v1 = *reinterpret_cast<const v4f *>(src + 4);
+            xbf8 pl[3];
+            split_bf16x8<3>(v0, v1, pl);
+            wlo_[u][ln] = pl[2];
+        }
+    }
 
     const int lane = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;
@@ -193,73 +214,138 @@ __global__ __launch_bounds__(256, 1) void gru_scan_bwd_feed_kernel(const HpmnGru
         //      (j, kg) = W[input column 16 ct + j][gate columns 32 ks + 8 kg .. + 7], W = [wg[0:D] | wc[0:D]]; B operand: lane
         //      (n, kg) = d_act[iteration 16 kb + n][the same gate columns], out of the ring; C: lane (n, kg) holds input columns
         //      16 ct + 4 kg .. + 3 of iteration n -- 16 contiguous bytes of the d_x row.
-        constexpr int NU = LOOPDX ? (DXD / 16) * 6 : 1;
+        // (r6) A block's product is 6 k slices (32 of the 192 gate columns each) x NCT column tiles (16 input columns each).  The
+        // column tiles of a slice multiply the SAME rows of the ring: the slice's fragment is read and split ONCE (rounds 4/5:
+        // per (column tile, slice)), and with three planes per operand a tile takes six products where it took three.  What
+        // shapes the schedule is the ISA's view of the feeder (an in-order wave pays >= 32 cycles of issue per matrix
+        // instruction; the chain wave waits for e_u and for nothing else):
+        //  * D = 32, units U = 0 .. 12, one per iteration:  U = 2 ks: read + split slice ks (44 VALU) WHILE the matrix pipe does
+        //    tile 1 of slice ks - 1 (six products on the planes split two units ago: independent of the split, so the compiler
+        //    interleaves them);  U = 2 ks + 1: tile 0 of slice ks;  U = 12: tile 1 of slice 5.  Never more than six matrix
+        //    instructions per iteration (rounds 4/5: three).
+        //  * D = 16, units U = ks: read, split, six products.
+        //  * every unit is PINNED between the iteration's e_u hand-off and the next iteration's wait: an empty statement
+        //    "produces" the planes the unit's products read (nothing of the unit can be hoisted above the hand-off -- the first
+        //    shared-split version had the compiler issue the second tile's products in front of the e_u product, 2.80 ms per C3
+        //    step against 2.39) and one "uses" the accumulators at its end (nothing can sink into the next iteration).
+        constexpr int NCT = LOOPDX ? DXD / 16 : 1;
+        constexpr int NU = LOOPDX ? (NCT == 2 ? 13 : 6) : 1;
+        constexpr int NBUF = NCT == 2 ? 2 : 1;
         const int j16 = lane & 15, kg = lane >> 4;
-        xbf8 wA[NU][NP];
+        constexpr int NR = NP == 3 ? 2 : NP;      // planes of the stationary fragments kept in registers (the lo plane: wlo_)
+        xbf8 wA[6 * NCT][NR];                     // [ks * NCT + ct]
         if constexpr (LOOPDX) {
 #pragma unroll
-            for (int u = 0; u < NU; ++u) {
-                const int ct = u / 6, ks = u % 6;
+            for (int u = 0; u < 6 * NCT; ++u) {
+                const int ks = u / NCT, ct = u % NCT;
                 const long col = 16 * ct + j16;
                 const int gc = 32 * ks + 8 * kg;
                 const float *src = gc < 2 * H ? a.wg + col * 2 * H + gc : a.wc + col * H + (gc - 2 * H);
                 const v4f v0 = *reinterpret_cast<const v4f *>(src), v1 = *reinterpret_cast<const v4f *>(src + 4);
-                split_bf16x8<NP>(v0, v1, wA[u]);
+                xbf8 pl[NP];
+                split_bf16x8<NP>(v0, v1, pl);
+#pragma unroll
+                for (int q2 = 0; q2 < NR; ++q2) wA[u][q2] = pl[q2];
             }
         }
-        xf4 xacc = {0.f, 0.f, 0.f, 0.f};
+        xf4 xacc[NCT];
+        xbf8 bp[NBUF][NP];                        // slice fragments, split (slice ks in buffer ks % NBUF)
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) xacc[c] = xf4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q1 = 0; q1 < NBUF; ++q1)
+#pragma unroll
+            for (int q2 = 0; q2 < NP; ++q2)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bp[q1][q2][e] = (__bf16)0.f;
         float *dxb = LOOPDX ? a.d_x + (b * (long)T) * DXD + 4 * kg : nullptr;
         // LOOPDX + SCAT (r5, HPMN_FUSED_SCATTER=2): a finished 16-iteration x 16-column tile goes straight into the table gradient --
         // column tile ct IS id column ct (E = 16) -- instead of into d_x and through a scatter launch behind the scan.  Branch-free
         // like the rest of the feeder's loop: the id of the lane's row and the read path's d_last piece are requested when the
-        // tile's first unit starts (five iterations before they are needed); rows that must not be added (the zero prefix, the
+        // block's first unit starts (iterations before they are needed); rows that must not be added (the zero prefix, the
         // masked id 0, clamped lanes) add into the lane's own place of the d_x buffer, which nobody reads.
-        int sc_id = 0, sc_flag = 0;
-        xf4 sc_dl = {0.f, 0.f, 0.f, 0.f};
+        int sc_id[NCT], sc_flag = 0;
+        xf4 sc_dl[NCT];
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) { sc_id[c] = 0; sc_dl[c] = xf4{0.f, 0.f, 0.f, 0.f}; }
         const float *dlb = nullptr;
         float dlm = 0.f;
         if constexpr (SCAT && LOOPDX) {
             dlm = a.d_last != nullptr ? 1.f : 0.f;
             dlb = (a.d_last != nullptr ? a.d_last + b * (long)DXD : a.wc) + 4 * kg;      // (no d_last: any finite floats, times 0)
         }
-        auto dx_unit = [&](auto uc, int kb) {
+        auto dx_unit = [&](auto uc, int kb) __attribute__((always_inline)) {
             constexpr int U = decltype(uc)::value;
             if constexpr (LOOPDX && U >= 0 && U < NU) {
-                constexpr int ct = U / 6, ks = U % 6;
                 const int it_raw = DXB * kb + j16;
                 const int it = it_raw < nsteps ? it_raw : nsteps - 1;          // (clamped: computed, not stored)
-                const float *src = &dact[it & (NSLOT - 1)][32 * ks + 8 * kg];
-                const v4f b0 = *reinterpret_cast<const v4f *>(src), b1 = *reinterpret_cast<const v4f *>(src + 4);
-                xbf8 bp[NP];
-                split_bf16x8<NP>(b0, b1, bp);
-                if constexpr (ks == 0) xacc = xf4{0.f, 0.f, 0.f, 0.f};
-                if constexpr (ks == 0 && SCAT) {
-                    const int t = t_hi - 1 - it, ti = t - a.front_zero;
-                    sc_id = reinterpret_cast<const int *>(a.scatter_ids)[(b * (long)a.Tids + (ti > 0 ? ti : 0)) * a.F + ct];
-                    sc_dl = *reinterpret_cast<const xf4 *>(dlb + 16 * ct);
-                    sc_flag = (it_raw < nsteps && ti >= 0) ? (t == a.last_t ? 2 : 1) : 0;
+                // what this unit does (compile-time): split slice `ss` (-1: none), multiply tile `mc` of slice `ms` (-1: none)
+                constexpr int ss = NCT == 2 ? ((U % 2 == 0 && U < 12) ? U / 2 : -1) : U;
+                constexpr int mc = NCT == 2 ? (U % 2 == 0 ? 1 : 0) : 0;
+                constexpr int ms = NCT == 2 ? (U % 2 == 0 ? U / 2 - 1 : U / 2) : U;
+                if constexpr (ms >= 0) {
+                    // (pin: the planes the products read are "produced" here, behind the e_u hand-off)
+                    xbf8 (&mp)[NP] = bp[ms % NBUF];
+#pragma unroll
+                    for (int q2 = 0; q2 < NP; ++q2) asm volatile("" : "+v"(mp[q2]));
                 }
-                // products of order <= NP - 1, smallest terms first (written out: a triangular loop nest kept the stationary
-                // fragments in scratch)
-                if constexpr (NP == 3) {
-                    xacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wA[U][0], bp[2], xacc, 0, 0, 0);
-                    xacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wA[U][1], bp[1], xacc, 0, 0, 0);
-                    xacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wA[U][2], bp[0], xacc, 0, 0, 0);
+                if constexpr (ss >= 0) {
+                    const float *src = &dact[it & (NSLOT - 1)][32 * ss + 8 * kg];
+                    const v4f b0 = *reinterpret_cast<const v4f *>(src), b1 = *reinterpret_cast<const v4f *>(src + 4);
+                    split_bf16x8<NP>(b0, b1, bp[ss % NBUF]);
+                    if constexpr (ss == 0 && SCAT) {
+                        const int t = t_hi - 1 - it, ti = t - a.front_zero;
+#pragma unroll
+                        for (int c = 0; c < NCT; ++c) {
+                            sc_id[c] = reinterpret_cast<const int *>(a.scatter_ids)[(b * (long)a.Tids + (ti > 0 ? ti : 0)) * a.F + c];
+                            sc_dl[c] = *reinterpret_cast<const xf4 *>(dlb + 16 * c);
+                        }
+                        sc_flag = (it_raw < nsteps && ti >= 0) ? (t == a.last_t ? 2 : 1) : 0;
+                    }
                 }
-                xacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wA[U][0], bp[1], xacc, 0, 0, 0);
-                xacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wA[U][1], bp[0], xacc, 0, 0, 0);
-                xacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wA[U][0], bp[0], xacc, 0, 0, 0);
-                // (no branch in here -- the feeder's prefetch loads are in flight and a branch's join would wait for all of
-                //  them: a clamped lane holds the last row's result and stores it to the last row's place once more)
-                if constexpr (ks == 5 && !SCAT) *reinterpret_cast<xf4 *>(dxb + (long)(t_hi - 1 - it) * DXD + 16 * ct) = xacc;
-                if constexpr (ks == 5 && SCAT) {
-                    const bool ok = sc_flag != 0 && !((a.mask_id0 & HPMN_ID_MASK0) && sc_id == 0);
-                    const float m = sc_flag == 2 ? dlm : 0.f;
-                    float *dst = ok ? a.d_emb + (long)sc_id * 16 + 4 * kg : dxb + (long)(t_hi - 1 - it) * DXD + 16 * ct;
-                    atomicAdd(dst, fmaf(m, sc_dl[0], xacc[0]));
-                    atomicAdd(dst + 1, fmaf(m, sc_dl[1], xacc[1]));
-                    atomicAdd(dst + 2, fmaf(m, sc_dl[2], xacc[2]));
-                    atomicAdd(dst + 3, fmaf(m, sc_dl[3], xacc[3]));
+                if constexpr (ms < 0 && ss >= 0) {
+                    xbf8 (&sp)[NP] = bp[ss % NBUF];
+#pragma unroll
+                    for (int q2 = 0; q2 < NP; ++q2) asm volatile("" : "+v"(sp[q2]));
+                }
+                if constexpr (ms >= 0) {
+                    xbf8 (&mp)[NP] = bp[ms % NBUF];
+                    xbf8 (&w)[NR] = wA[ms * NCT + mc];
+                    xf4 acc = ms == 0 ? xf4{0.f, 0.f, 0.f, 0.f} : xacc[mc];
+                    // products of order <= NP - 1, smallest terms first
+                    if constexpr (NP == 3) {
+                        const xbf8 w2 = wlo_[ms * NCT + mc][lane];
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0], mp[2], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[1], mp[1], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2, mp[0], acc, 0, 0, 0);
+                    }
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0], mp[1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[1], mp[0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0], mp[0], acc, 0, 0, 0);
+                    // (pin: "used" here -- not sunk into the next iteration)
+                    asm volatile("" : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]), "+a"(acc[3]));
+                    xacc[mc] = acc;
+                    if constexpr (ss >= 0) {                 // (... nor is the split: its reads' latency lies under the products)
+                        xbf8 (&sp)[NP] = bp[ss % NBUF];
+#pragma unroll
+                        for (int q2 = 0; q2 < NP; ++q2) asm volatile("" : "+v"(sp[q2]));
+                    }
+                    // (no branch in here -- the feeder's prefetch loads are in flight and a branch's join would wait for all of
+                    //  them: a clamped lane holds the last row's result and stores it to the last row's place once more)
+                    if constexpr (ms == 5) {
+                        constexpr int c = mc;
+                        if constexpr (!SCAT) {
+                            *reinterpret_cast<xf4 *>(dxb + (long)(t_hi - 1 - it) * DXD + 16 * c) = acc;
+                        } else {
+                            const bool ok = sc_flag != 0 && !((a.mask_id0 & HPMN_ID_MASK0) && sc_id[c] == 0);
+                            const float m = sc_flag == 2 ? dlm : 0.f;
+                            float *dst = ok ? a.d_emb + (long)sc_id[c] * 16 + 4 * kg : dxb + (long)(t_hi - 1 - it) * DXD + 16 * c;
+                            atomicAdd(dst, fmaf(m, sc_dl[c][0], acc[0]));
+                            atomicAdd(dst + 1, fmaf(m, sc_dl[c][1], acc[1]));
+                            atomicAdd(dst + 2, fmaf(m, sc_dl[c][2], acc[2]));
+                            atomicAdd(dst + 3, fmaf(m, sc_dl[c][3], acc[3]));
+                        }
+                    }
                 }
             }
         };
@@ -270,6 +356,7 @@ __global__ __launch_bounds__(256, 1) void gru_scan_bwd_feed_kernel(const HpmnGru
             dx_unit(std::integral_constant<int, 6>{}, kb); dx_unit(std::integral_constant<int, 7>{}, kb);
             dx_unit(std::integral_constant<int, 8>{}, kb); dx_unit(std::integral_constant<int, 9>{}, kb);
             dx_unit(std::integral_constant<int, 10>{}, kb); dx_unit(std::integral_constant<int, 11>{}, kb);
+            dx_unit(std::integral_constant<int, 12>{}, kb);
         };
 
         float *dap = a.d_act + (b * (long)T + (t_hi - 1)) * 3 * H + l;     // row of iteration 0
@@ -318,7 +405,8 @@ __global__ __launch_bounds__(256, 1) void gru_scan_bwd_feed_kernel(const HpmnGru
             park_chunk(qq + FR_AHEAD + 1, w1);
         };
         if constexpr (LOOPDX) {
-            // 16 iterations k = 16 n + 2 .. 16 n + 17 per trip, unit p at iteration 16 n + 2 + p (p < NU <= 12): block
+            // 16 iterations k = 16 n + 2 .. 16 n + 17 per trip, unit p at iteration 16 n + 2 + p (p < NU <= 13; the ring is last
+            // READ by unit 10 at D = 32, 5 at D = 16): block
             // kb = n - 1, whose rows were complete at iteration 16 n and stay in the ring until the chain wave starts iteration
             // 16 (n + 1) -- which needs e_u(16 n + 15), published two iterations after the last unit's reads.
             if (q + 7 < nfull) {                   // (the first trip: no block is complete yet)
@@ -333,7 +421,7 @@ __global__ __launch_bounds__(256, 1) void gru_scan_bwd_feed_kernel(const HpmnGru
                 group(q, std::integral_constant<int, 0>{}, kb);
                 group(q + 2, std::integral_constant<int, 4>{}, kb);
                 group(q + 4, std::integral_constant<int, 8>{}, kb);
-                group(q + 6, std::integral_constant<int, -1>{}, -1);
+                group(q + 6, std::integral_constant<int, 12>{}, kb);     // (unit 12: D = 32's last tile; 13 .. 15 do not exist)
             }
             // the block that was complete when the loop ended, at once: up to 15 iterations follow, the last of which may
             // start overwriting it (a pause of ~2 steps for the chain wave, once per launch)

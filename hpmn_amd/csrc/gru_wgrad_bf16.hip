@@ -61,7 +61,7 @@ __device__ __forceinline__ f32x16b mma_planes(const bf8 (&a)[NP], const bf8 (&b)
 
 __host__ __device__ inline long wgrad_slab_floats_bf(int D, int H) { return (long)(D + H) * 3 * H + 3 * H; }   // == gru_wgrad.hip
 
-// blocks of a tile, in LDS order: [0, DT) x, [DT, DT+HT) h_prev, [DT+HT, DT+2HT) r*h_prev, then 3HT blocks of d_act.
+// blocks of a tile: [0, DT) x, [DT, DT+HT) h_prev (+ r*h_prev) -- each kept in its wave's registers (r6) --, then 3HT blocks of d_act in LDS.
 // The body is instantiated PER WAVE (W is a template argument, the kernel dispatches once at the top): which blocks a wave
 // stages and which source each comes from are then compile-time facts and the time loop is straight-line code -- with the
 // wave index at run time every staging load sat inside a (uniform) branch and was waited for at its join, vmcnt(0), before
@@ -71,7 +71,7 @@ __host__ __device__ inline long wgrad_slab_floats_bf(int D, int H) { return (lon
 // accumulator tiles would be 192 registers; each group stages only ITS columns of d_act (plus x, h_prev, r: re-read per group,
 // as in the fp32 kernel).
 template <int HT, int DT, int CS, int W, int NP>
-__device__ __forceinline__ void wgrad_bf16_wave(const HpmnGruWgrad &a, bf8 (*img)[DT + 2 * HT + 3 * HT / CS][NP][64], const int bx,
+__device__ __forceinline__ void wgrad_bf16_wave(const HpmnGruWgrad &a, bf8 (*img)[3 * HT / CS][NP][64], const int bx,
                                                 const int by, const int tsplit) {
     constexpr int H = 32 * HT;
     constexpr int NJ = 3 * HT / CS;            // 32-column tiles of d_act held by this workgroup
@@ -144,6 +144,13 @@ __device__ __forceinline__ void wgrad_bf16_wave(const HpmnGruWgrad &a, bf8 (*img
             }
         }
     };
+    // r6: task 0 of wave W is block W -- the wave's OWN operand block (x tile W for the input-column waves, h_prev tile W - DT
+    // and r * h_prev for the others): staged and consumed by the same wave, lane for lane (the fragment order in LDS was lane
+    // order).  It stays in REGISTERS (ap: x / h_prev, cp: x / r * h_prev); only the d_act blocks, which every wave reads, go
+    // through LDS -- 5 of 11 blocks' writes and reads less at H = 64, D = 32, and the image shrinks from 11 to 6 blocks (with
+    // three planes: 36 KB instead of 66).
+    static_assert(MAXT >= 1, "every wave stages its own operand block");
+    bf8 ap[NP], cp[NP];
     auto park = [&](int buf, const Raw &g, int it) {
         const int t0 = tb + (i_lo + it % ipt) * BR + 8 * kg;
 #pragma unroll
@@ -156,19 +163,24 @@ __device__ __forceinline__ void wgrad_bf16_wave(const HpmnGruWgrad &a, bf8 (*img
                 if (q < DT) live = live && (32 * q + c) < D;
                 v[j] = live ? g.v[i][j] : 0.f;
             }
-            const int blk = q < DT + HT ? q : q + HT;                               // image block: x | h_prev | (r h_prev) | d_act
             const Frag<NP> f = split8<NP>(v);
+            if (q < DT + HT) {                                                      // (i == 0: the wave's own block)
 #pragma unroll
-            for (int pl = 0; pl < NP; ++pl) img[buf][blk][pl][lane] = f.p[pl];
-            if (q >= DT && q < DT + HT) {                                           // r * h_prev (not stored by the forward)
-                float w[8];
+                for (int pl = 0; pl < NP; ++pl) ap[pl] = f.p[pl];
+                if (q >= DT) {                                                      // r * h_prev (not stored by the forward)
+                    float w[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) w[j] = v[j] * g.r2[j];
-                const Frag<NP> f2 = split8<NP>(w);
+                    for (int j = 0; j < 8; ++j) w[j] = v[j] * g.r2[j];
+                    const Frag<NP> f2 = split8<NP>(w);
 #pragma unroll
-                for (int pl = 0; pl < NP; ++pl) img[buf][q + HT][pl][lane] = f2.p[pl];
-            }
-            if (q >= DT + HT) {
+                    for (int pl = 0; pl < NP; ++pl) cp[pl] = f2.p[pl];
+                } else {
+#pragma unroll
+                    for (int pl = 0; pl < NP; ++pl) cp[pl] = f.p[pl];
+                }
+            } else {
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl) img[buf][q - DT - HT][pl][lane] = f.p[pl];
                 float s = 0.f;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) s += v[j];
@@ -181,18 +193,11 @@ __device__ __forceinline__ void wgrad_bf16_wave(const HpmnGruWgrad &a, bf8 (*img
     // behind them.  (Distance two -- two tiles of raw values in registers -- was tried: 165-245 registers spilled beside the
     // 96 accumulators; the second workgroup on the CU is what overlaps the round trip instead.)
     auto compute = [&](int buf) {
-        constexpr int qa = role_x ? tile : DT + tile;      // x block / h_prev block (r*h_prev: + HT)
-        bf8 ap[NP], cp[NP];
-#pragma unroll
-        for (int pl = 0; pl < NP; ++pl) {
-            ap[pl] = img[buf][qa][pl][lane];
-            cp[pl] = img[buf][role_x ? qa : qa + HT][pl][lane];
-        }
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             bf8 bp[NP];
 #pragma unroll
-            for (int pl = 0; pl < NP; ++pl) bp[pl] = img[buf][DT + 2 * HT + j][pl][lane];
+            for (int pl = 0; pl < NP; ++pl) bp[pl] = img[buf][j][pl][lane];
             // gate columns (tile < 2 HT) pair with x / h_prev, candidate columns with x / r * h_prev
             const bool gate = (jb + j) < 2 * HT;               // (uniform per workgroup)
             bf8 xp[NP];
@@ -248,10 +253,12 @@ __device__ __forceinline__ void wgrad_bf16_wave(const HpmnGruWgrad &a, bf8 (*img
     }
 }
 
-template <int HT, int DT, int CS, bool XCD = true, int NP = 3>
-__global__ __launch_bounds__(64 * (HT + DT), (HT + DT) == 3 ? (NP == 2 ? 3 : 2) : ((HT + DT) > 5 ? 1 : 2)) void gru_wgrad_bf16_kernel(const HpmnGruWgrad a) {
+// LB3: three workgroups per CU for the three-wave shape (H = 64, D <= 32): 168 registers, the rest spilled (12 dwords with two
+// planes, 27 with three) -- against two workgroups per CU without spills (the default since r6, see launch_bf16).
+template <int HT, int DT, int CS, bool XCD = true, int NP = 3, bool LB3 = true>
+__global__ __launch_bounds__(64 * (HT + DT), (HT + DT) == 3 ? (LB3 ? 3 : 2) : ((HT + DT) > 5 ? 1 : 2)) void gru_wgrad_bf16_kernel(const HpmnGruWgrad a) {
     static_assert((3 * HT) % CS == 0 && HT + DT <= 8, "column tiles split evenly; at most eight waves");
-    __shared__ __attribute__((aligned(16))) bf8 img[2][DT + 2 * HT + 3 * HT / CS][NP][64];
+    __shared__ __attribute__((aligned(16))) bf8 img[2][3 * HT / CS][NP][64];      // (the d_act blocks only, see wgrad_bf16_wave)
     const int wave = threadIdx.x >> 6;          // (wave-uniform: one dispatch, then straight-line code per wave)
     constexpr int NW = HT + DT;
     // The CS column groups of a sequence range read the SAME x / h_prev / r rows.  Linear workgroup id L runs on XCD L % 8
@@ -298,7 +305,7 @@ static int wgrad_planes() {
     return np;
 }
 
-template <int HT, int DT, int CS, int NP>
+template <int HT, int DT, int CS, int NP, bool LB3>
 static void launch_bf16_np(const HpmnGruWgrad &k, int nwg, bool solo, hipStream_t st) {
     // (one workgroup per CU beside a reverse scan, as in gru_wgrad.hip: unused dynamic LDS caps the occupancy; by default for
     //  H <= 64 only -- the H = 128 form is shaped around its column split; HPMN_WGRAD_SOLO_ROWS reaches it too)
@@ -306,9 +313,11 @@ static void launch_bf16_np(const HpmnGruWgrad &k, int nwg, bool solo, hipStream_
     if (solo) {
         static const size_t p = [] {
             hipFuncAttributes fa = {};
-            const void *fn = reinterpret_cast<const void *>(gru_wgrad_bf16_kernel<HT, DT, CS, true, NP>);
+            const void *fn = reinterpret_cast<const void *>(gru_wgrad_bf16_kernel<HT, DT, CS, true, NP, LB3>);
             if (hipFuncGetAttributes(&fa, fn) != hipSuccess) return (size_t)0;
-            const size_t want = 82 * 1024;
+            // (r6: 72 KB, was 82: layer 0's reverse scan holds 88 KB with the three-plane in-loop product's lo fragments in LDS,
+            //  and the weight-gradient workgroup still has to fit beside it in the CU's 160 KB)
+            const size_t want = 72 * 1024;
             const size_t q = fa.sharedSizeBytes < want ? want - fa.sharedSizeBytes : 0;
             (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q);
             return q;
@@ -318,15 +327,25 @@ static void launch_bf16_np(const HpmnGruWgrad &k, int nwg, bool solo, hipStream_
     const unsigned grid = CS > 1 ? (unsigned)((nwg + 7) / 8) * 8u * CS : (unsigned)nwg;
     static const int xcd_env = [] { const char *e = getenv("HPMN_WGRAD_XCD"); return e ? atoi(e) : 1; }();
     if (CS > 1 && !xcd_env)
-        hipLaunchKernelGGL((gru_wgrad_bf16_kernel<HT, DT, CS, false, NP>), dim3(grid), dim3(64 * (HT + DT)), pad, st, k);
+        hipLaunchKernelGGL((gru_wgrad_bf16_kernel<HT, DT, CS, false, NP, LB3>), dim3(grid), dim3(64 * (HT + DT)), pad, st, k);
     else
-        hipLaunchKernelGGL((gru_wgrad_bf16_kernel<HT, DT, CS, true, NP>), dim3(grid), dim3(64 * (HT + DT)), pad, st, k);
+        hipLaunchKernelGGL((gru_wgrad_bf16_kernel<HT, DT, CS, true, NP, LB3>), dim3(grid), dim3(64 * (HT + DT)), pad, st, k);
 }
 
 template <int HT, int DT, int CS>
 static void launch_bf16(const HpmnGruWgrad &k, int nwg, bool solo, hipStream_t st) {
-    if (wgrad_planes() == 2) launch_bf16_np<HT, DT, CS, 2>(k, nwg, solo, st);
-    else launch_bf16_np<HT, DT, CS, 3>(k, nwg, solo, st);
+    // (r6, with the wave's own operand block in registers: two workgroups per CU without spills beat three with 12 / 27 spilled
+    //  dwords -- alone on the chip 165 vs 188 us (two planes), 223 vs 257 (three); C3 step 2.415 vs 2.441 -- HPMN_WGRAD_OCC=3)
+    static const int occ = [] { const char *e = getenv("HPMN_WGRAD_OCC"); return e ? atoi(e) : 2; }();
+    if constexpr (HT + DT == 3) {
+        if (occ == 2) {
+            if (wgrad_planes() == 2) launch_bf16_np<HT, DT, CS, 2, false>(k, nwg, solo, st);
+            else launch_bf16_np<HT, DT, CS, 3, false>(k, nwg, solo, st);
+            return;
+        }
+    }
+    if (wgrad_planes() == 2) launch_bf16_np<HT, DT, CS, 2, true>(k, nwg, solo, st);
+    else launch_bf16_np<HT, DT, CS, 3, true>(k, nwg, solo, st);
 }
 
 // H = 64 with D <= 64, H = 128 with D = 32 / 128.  Returns false when the shape is not served (the caller keeps the fp32 kernel).

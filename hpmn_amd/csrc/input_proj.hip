@@ -533,7 +533,13 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void input_proj_bf16_kernel(const
     const int n_base = ns * NT * 32;
 
     // A operand (stationary): lane (n = c, p) = sc * Wcat[16 ks + 8 p .. + 7][n_base + 32 nt + c], Wcat = [wg[0:D] | wc[0:D]]
-    dbf8 w[NT][KS][NP];
+    // Three planes: the weights' hi and mid planes are stationary in registers (192), the LO plane (only ever multiplied with
+    // the rows' hi plane) lives in LDS in lane order -- one linear 16-byte read per lane and product: with all three planes in
+    // registers (288 + two row images + 48 accumulators) the kernel ran out of the 512 and spilled (r6: twice the time).
+    constexpr int NR = NP == 3 ? 2 : NP;               // planes kept in registers
+    __shared__ __attribute__((aligned(16))) dbf8 wlo[NP == 3 ? RW_WAVES : 1][NP == 3 ? NT : 1][NP == 3 ? KS : 1][64];
+    const int wv = threadIdx.x >> 6;
+    dbf8 w[NT][KS][NR];
     float bias[NT];                     // (the bias step's planes are rebuilt per tile from this: 36 registers fewer)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -549,7 +555,11 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void input_proj_bf16_kernel(const
             const float *w0 = wcol + (long)(16 * ks + 8 * p) * ldw;
             v0.x = sc * w0[0]; v0.y = sc * w0[ldw]; v0.z = sc * w0[2 * ldw]; v0.w = sc * w0[3 * ldw];
             v1.x = sc * w0[4 * ldw]; v1.y = sc * w0[5 * ldw]; v1.z = sc * w0[6 * ldw]; v1.w = sc * w0[7 * ldw];
-            dx_split8<NP>(v0, v1, w[nt][ks]);
+            dbf8 pl[NP];
+            dx_split8<NP>(v0, v1, pl);
+#pragma unroll
+            for (int q = 0; q < NR; ++q) w[nt][ks][q] = pl[q];
+            if constexpr (NP == 3) wlo[wv][nt][ks][lane] = pl[2];
         }
         // the bias step: k slot 0 of half-wave 0 carries the bias, everything else 0, against a row operand of 1.0 there
         bias[nt] = p == 0 ? sc * bcol[0] : 0.f;
@@ -586,7 +596,19 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void input_proj_bf16_kernel(const
             dbf8 xp[NP];
             dx_split8<NP>(v[ks][0], v[ks][1], xp);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[nt] = dx_mma<NP>(w[nt][ks], xp, acc[nt]);
+            for (int nt = 0; nt < NT; ++nt) {
+                if constexpr (NP == 3) {
+                    const dbf8 w2 = wlo[wv][nt][ks][lane];              // (written by this very lane: no barrier)
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[nt][ks][0], xp[2], acc[nt], 0, 0, 0);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[nt][ks][1], xp[1], acc[nt], 0, 0, 0);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, xp[0], acc[nt], 0, 0, 0);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[nt][ks][0], xp[1], acc[nt], 0, 0, 0);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[nt][ks][1], xp[0], acc[nt], 0, 0, 0);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[nt][ks][0], xp[0], acc[nt], 0, 0, 0);
+                } else {
+                    acc[nt] = dx_mma<NP>(w[nt][ks], xp, acc[nt]);
+                }
+            }
         }
         float *dst = a.xp + (long)flat_row(tile_row(tile)) * N + n_base + 4 * p;
 #pragma unroll

@@ -161,8 +161,24 @@ int hpmn_train_ctx_create(HpmnTrainCtx **out) {
     if (hipGetDevice(&c->device) != hipSuccess) { delete c; return HPMN_ENODEVICE; }
     int n = 0;
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && n > 0) c->cus = n;
-    if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking) != hipSuccess ||
+    // r6: the helper streams are created at the device's HIGHEST priority (HPMN_SIDE_PRIORITY=0: plain streams, rounds 2-5).
+    // (1) The runtime keeps a pool of hardware queues PER PRIORITY and hands streams of one priority their queues round-robin:
+    //     the step's other streams (the caller's, the auxiliary, the plan's, RCCL's) are plain ones, so the helper stream can
+    //     no longer land on the CALLER's queue -- which is what happened to the data-parallel rows step on the default
+    //     communicator (one rank on RCCL, C3, profiles/r06_timeline_rows_sg0.txt: the weight gradients of layers 1-6 sat IN
+    //     FRONT of layer 0's reverse scan on one queue instead of underneath it: 3.23 ms per step against 2.86 with a second
+    //     communicator, whose extra stream merely shifted the round-robin).
+    // (2) When a CU frees up, pending workgroups of the helper stream (weight gradients, slab reductions) are dispatched in
+    //     front of a reverse scan's next round (H = 128: 500 one-CU workgroups on 256 CUs run in two rounds; the 3 084 small
+    //     workgroups of a slab reduction found a dozen free CUs: 454 / 793 us beside the scans against 5-20 alone).
+    static const int side_prio = [] { const char *e = getenv("HPMN_SIDE_PRIORITY"); return e ? atoi(e) : 1; }();
+    int prio_lo = 0, prio_hi = 0;
+    if (side_prio) (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    auto mk = [&](hipStream_t *st) {
+        return side_prio ? hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio_hi) : hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+    };
+    if (mk(&c->side) != hipSuccess ||
+        mk(&c->side2) != hipSuccess ||
         hipEventCreateWithFlags(&c->join2, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->join, hipEventDisableTiming) != hipSuccess ||

@@ -780,33 +780,40 @@ class Hpmn_Basic(object):
     def _one_call_ok(self, ids) -> bool:
         """The plain single-process step (one dense sweep over the table, everything on the caller's stream + the library's
         helper stream) is one call of hpmn_train_step: the graphs and settings for which train_step would otherwise issue
-        exactly hpmn_scan_fwd_train -> hpmn_read_fwd_bwd -> hpmn_scan_bwd -> read weight gradients -> two clearing Adam launches."""
-        if not (self.ONE_CALL_STEP and self._hip_read and not self._dp and not self.lazy_table_adam and not self.l2_reg
-                and self._goff == 0 and ids.shape[0] > 0 and len(self._branches) == 1 and self._preset_plan is None):
+        exactly hpmn_scan_fwd_train -> hpmn_read_fwd_bwd -> hpmn_scan_bwd -> read weight gradients -> two clearing Adam launches.
+        (The static part of the answer is cached per batch shape: the check itself was 8 us of a 60 us step.)"""
+        if not self.ONE_CALL_STEP or self._preset_plan is not None or (self._split_probe.__class__ is dict and self._split_probe.get("armed")):
             return False
-        if self.det_scatter or self.flat_grad.numel() >= self.AUX_MIN_NUMEL or self._two_pass_table_adam(ids):
-            return False
-        if isinstance(self._split_probe, dict) and self._split_probe.get("armed"):
-            return False
-        return bool(ops.TRAIN_ABI and ops.PIPELINE_CHUNKS <= 1 and ops.FUSED_FWD and not ops.SPLIT_LAYER0_BWD
-                    and ops.pipe_mode(self.spec) == "")
+        key = (ids.shape, ids.dtype)
+        ok = self._one_call_static.get(key)
+        if ok is None:
+            ok = bool(self._hip_read and not self._dp and not self.lazy_table_adam and not self.l2_reg and self._goff == 0
+                      and ids.shape[0] > 0 and len(self._branches) == 1 and not self.det_scatter
+                      and self.flat_grad.numel() < self.AUX_MIN_NUMEL and not self._two_pass_table_adam(ids)
+                      and ops.TRAIN_ABI and ops.PIPELINE_CHUNKS <= 1 and ops.FUSED_FWD and not ops.SPLIT_LAYER0_BWD
+                      and ops.pipe_mode(self.spec) == "")
+            if self.__dict__.get("_one_call_static") is None:
+                self._one_call_static = {}
+            self._one_call_static[key] = ok
+        return ok
+
+    _one_call_static = {}
 
     @torch.no_grad()
     def _train_step_one_call(self, ids, label, keep_prob, masks, global_batch):
         """sess.run(train_step) of code/hpmn.py:482 as ONE library call (hpmn_train_step, ABI v14): the descriptor is built once
         per batch shape; a step fills in the batch's pointers and scalars.  Host work per step: two small allocations, a
         dozen struct stores, one ctypes call (tools/host_enqueue_time.py)."""
-        from . import _lib
-        import ctypes as C
-        B = int(ids.shape[0])
+        B = ids.shape[0]
         if global_batch is None:
             global_batch = B
-        ops._chk_ids(ids)
-        assert label.dtype == torch.int32 and label.is_contiguous() and label.shape[0] == B
-        key = (B, ids.dtype, torch.cuda.current_stream().cuda_stream, self.flat_param.data_ptr(), self.flat_grad.data_ptr(),
-               self.flat_m.data_ptr(), self._loss_acc.data_ptr())
+        stream = torch.cuda.current_stream().cuda_stream
+        key = (B, ids.dtype, stream, self.flat_param.data_ptr(), self.flat_grad.data_ptr(), self.flat_m.data_ptr())
         cache = self._one_call_cache
         if cache is None or cache["key"] != key:
+            from . import _lib
+            import ctypes as C
+            ops._chk_ids(ids)
             spec, dev = self.spec, self.device
             st = _lib.HpmnTrainStep()
             st.scan = spec.desc(B, self.feature_size, ids)
@@ -822,47 +829,51 @@ class Hpmn_Basic(object):
             st.off_read = self._offs[self._branches[0][0] + "/dense/kernel"]
             lib = _lib.load()
             ws = torch.empty(int(lib.hpmn_scan_train_workspace_bytes(C.byref(st.scan))), device=dev, dtype=torch.uint8)
+            self._read_desc.B = B
             keep = dict(ws=ws, memory=torch.empty(B, spec.K, spec.H, device=dev), last=torch.empty(B, spec.D0, device=dev),
-                        d_memory=torch.empty(B, spec.K, spec.H, device=dev), d_last=torch.empty(B, spec.D0, device=dev))
+                        d_memory=torch.empty(B, spec.K, spec.H, device=dev), d_last=torch.empty(B, spec.D0, device=dev),
+                        rws=ops._read_workspace(self._read_desc, dev), acc=self._loss_acc)   # (zero-initialised once, then reused)
             st.memory, st.last = keep["memory"].data_ptr(), keep["last"].data_ptr()
             st.d_memory, st.d_last = keep["d_memory"].data_ptr(), keep["d_last"].data_ptr()
-            st.scan_workspace = ws.data_ptr()
+            st.scan_workspace, st.read_workspace = ws.data_ptr(), keep["rws"].data_ptr()
             st.loss_acc = self._loss_acc.data_ptr()
             st.memory_reg = float(self.memory_reg)
             st.beta1, st.beta2, st.eps, st.clip = self.beta1, self.beta2, self.adam_eps, 1.0
-            cache = self._one_call_cache = dict(key=key, st=st, keep=keep, ctx=ops._ctx(dev), lib=lib)
-        st, keep = cache["st"], cache["keep"]
-        self._read_desc.B = B
-        rws = ops._read_workspace(self._read_desc, self.device)          # (zero-initialised once per shape, then reused)
-        st.read_workspace = rws.data_ptr()
+            st.scan.mask_id0 = ops._idf(ids, self.spec.mask_id0)
+            cache = self._one_call_cache = dict(key=key, st=st, keep=keep, ctx=ops._ctx(dev), fn=lib.hpmn_train_step, ref=C.byref(st),
+                                                check=_lib.check)
+        st = cache["st"]
+        if label.dtype != torch.int32 or label.shape[0] != B or not label.is_contiguous() or not ids.is_contiguous():
+            raise ValueError("train_step: ids [B,T,F] and label [B] int32, contiguous")
         seed = 0
-        if masks is None and keep_prob < 1.0:
-            self._dropout_step += 1
-            seed = _splitmix64(_splitmix64(self._dropout_base + self._dropout_step) ^ (self.rank + 1)) | 1
-        st.read.dropout_seed = seed & 0xFFFFFFFFFFFFFFFF
-        m1 = m2 = None
-        if masks is not None:
+        if masks is None:
+            if keep_prob < 1.0:
+                self._dropout_step += 1
+                seed = _splitmix64(_splitmix64(self._dropout_base + self._dropout_step) ^ (self.rank + 1)) | 1
+            st.mask1 = st.mask2 = None
+        else:
             m1, m2 = masks
             ops._chk_f32(m1, m2)
-        st.mask1, st.mask2 = ops._ptr(m1), ops._ptr(m2)
-        st.scan.mask_id0 = ops._idf(ids, self.spec.mask_id0)
+            st.mask1, st.mask2 = m1.data_ptr(), m2.data_ptr()
+        st.read.dropout_seed = seed & 0xFFFFFFFFFFFFFFFF
         st.ids, st.label = ids.data_ptr(), label.data_ptr()
         pred = torch.empty(B, device=self.device)
         sums = torch.empty(3, device=self.device)
         st.pred, st.loss3 = pred.data_ptr(), sums.data_ptr()
-        st.keep_prob, st.inv_global_batch = float(keep_prob), 1.0 / float(global_batch)
+        st.keep_prob, st.inv_global_batch = keep_prob, 1.0 / global_batch
         if not self._loss_acc_clean:
             self._loss_acc.zero_()
         st.clear_grad_first = 0 if self._flat_grad_clean else 1
-        self.adam_t += 1
-        t = self.adam_t
+        self.adam_t = t = self.adam_t + 1
         st.lr_t = self.learning_rate * math.sqrt(1.0 - self.beta2 ** t) / (1.0 - self.beta1 ** t)
         self._flat_grad_clean = self._table_grad_clean = self._loss_acc_clean = False
-        _lib.check(cache["lib"].hpmn_train_step(cache["ctx"], C.byref(st), torch.cuda.current_stream().cuda_stream), "hpmn_train_step")
+        rc = cache["fn"](cache["ctx"], cache["ref"], stream)
+        if rc != 0:
+            cache["check"](rc, "hpmn_train_step")
         self._flat_grad_clean = self._table_grad_clean = self._loss_acc_clean = True
         # (memory: the step's persistent scratch -- valid until the next train_step of this shape)
-        out = dict(prediction=pred, log_loss_sum=sums[0], memory_loss=sums[1], memory=keep["memory"], pending=None)
-        return out, sums[2]
+        ll, ml, ce = sums.unbind(0)
+        return dict(prediction=pred, log_loss_sum=ll, memory_loss=ml, memory=cache["keep"]["memory"], pending=None), ce
 
     # ------------------------------------------------------------------ dense table Adam in two passes
     TWO_PASS_TABLE_ADAM = int(os.environ.get("HPMN_TWO_PASS_ADAM", "1")) != 0
@@ -1185,14 +1196,37 @@ class Hpmn_Basic(object):
         #  the tensor was produced there; that is the END of the previous step, the plan still has this whole step to run in.
         #  next_ids must stay unchanged until the next train_step has consumed the plan: a slice of a staged dataset does.)
         pst.wait_stream(torch.cuda.current_stream())
+        # r6: WITHOUT the second communicator the early exchange is issued at the END of this step (_prefetch_exchange), not here:
+        # collectives of one communicator run in issue order on its stream, and issued here they sat in front of THIS step's row
+        # exchange and dense all-reduce waiting for a plan that is built on whatever the scans leave free (one rank on RCCL, C3:
+        # 3.35 ms/step against 3.21 with no hint at all and 2.95 on the second communicator).  At the end of the step the plan
+        # is long done and nothing of this step queues behind it.
+        defer = bool(self._dp and group is None)
         with torch.cuda.stream(pst):
             plan = self._rows_plan(next_ids, cap, bounds) if next_ids.shape[0] > 0 else None
-            ex = self._rows_early_exchange(plan, next_ids.dtype, cap, C, group=group) if self._dp else None
+            ex = self._rows_early_exchange(plan, next_ids.dtype, cap, C, group=group) if (self._dp and not defer) else None
             done = torch.cuda.Event()
             done.record()
         if plan is not None:
             plan.ready = done
-        self._prefetched = dict(key=(next_ids.data_ptr(), tuple(next_ids.shape), gb), plan=plan, ex=ex, ids=next_ids, done=done)
+        self._prefetched = dict(key=(next_ids.data_ptr(), tuple(next_ids.shape), gb), plan=plan, ex=ex, ids=next_ids, done=done,
+                                defer=(next_ids.dtype, cap, C) if defer else None)
+
+    def _prefetch_exchange(self):
+        """End of a data-parallel rows step: the NEXT step's early exchange (every rank's distinct-row list and counts) on the
+        default communicator, behind this step's collectives; the plan stream carries it (its plan is there)."""
+        pf = self._prefetched
+        if pf is None or pf.get("defer") is None:
+            return
+        dtype, cap, C = pf["defer"]
+        pst = self._plan_stream
+        with torch.cuda.stream(pst):
+            pf["ex"] = self._rows_early_exchange(pf["plan"], dtype, cap, C, group=None)
+            done = torch.cuda.Event()
+            done.record()
+        pf["done"], pf["defer"] = done, None
+        if pf["plan"] is not None:
+            pf["plan"].ready = done
 
     # MEASUREMENT ONLY (VERDICT r4 #3): HPMN_DP_WIRE_STANDIN="<GB/s>,<ranks>[,<fraction of the rows>]" -- with ONE rank on RCCL the
     # all-gathers are local copies; a stream of its own then holds every chunk back by the time the bytes this rank would
@@ -1364,6 +1398,8 @@ class Hpmn_Basic(object):
         dist.allreduce_sum_(self.flat_grad)                   # (the flat gradient holds the dense variables only)
         ops.adam_step(self.flat_param[lo:], self.flat_grad, self.flat_m[lo:], self.flat_v[lo:], lr_t, self.beta1,
                       self.beta2, self.adam_eps, clip=1.0)
+        if dp:
+            self._prefetch_exchange()                         # (the next step's lists and counts, behind this step's collectives)
         return out, ce
 
     def table_gradient(self) -> torch.Tensor:

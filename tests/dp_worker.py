@@ -97,9 +97,12 @@ def build_eval(tmp):
     te = dict(ids=ids, label=rng.integers(0, 2, size=n).astype(np.int32))
     m = Hpmn_Industry(tmp, te, te, V, 2, 1, T, 1, 0.003, 64, 16, 3, [2] * 10 + [1], [1], 4, 1, True, False,
                       memory_reg=5e-5, verbose=False, seed=3)
+    # (weights of a trained model's size.  Variable by variable: the flat buffer pads the table region to a multiple of
+    #  256 x world, so an offset into it is not the same variable in a single process and under data parallel)
     g = torch.Generator(device="cpu").manual_seed(7)
-    n_emb = m.params["Embedding/emb_mtx"].numel()
-    m.flat_param[n_emb:] += 0.2 * torch.randn(m.flat_param.numel() - n_emb, generator=g).to(m.device)
+    for name in sorted(m.params):
+        if name != "Embedding/emb_mtx":
+            m.params[name] += 0.2 * torch.randn(m.params[name].shape, generator=g).to(m.device)
     return m, te, te
 
 

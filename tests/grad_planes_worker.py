@@ -31,6 +31,7 @@ def main(dst):
         res, ce = m.compute_gradients(torch.as_tensor(ids).to(dev), torch.as_tensor(label).to(dev), keep_prob=1.0)
         torch.cuda.synchronize()
         out[tag + "/ce"] = np.array(float(ce))
+        out[tag + "/memory"] = res["memory"].detach().cpu().numpy()
         for name in m.params:
             out[tag + "/" + name.replace("/", "|")] = m.grads[name].detach().cpu().numpy()
     np.savez(dst, **out)
