@@ -70,7 +70,7 @@ __host__ __device__ inline long wgrad_slab_floats_bf(int D, int H) { return (lon
 // CS = column split (H = 128): blockIdx.y picks one of CS groups of 3 HT / CS consecutive 32-column tiles of d_act -- twelve
 // accumulator tiles would be 192 registers; each group stages only ITS columns of d_act (plus x, h_prev, r: re-read per group,
 // as in the fp32 kernel).
-template <int HT, int DT, int CS, int W, int NP>
+template <int HT, int DT, int CS, int W, int NP, bool PF2>
 __device__ __forceinline__ void wgrad_bf16_wave(const HpmnGruWgrad &a, bf8 (*img)[3 * HT / CS][NP][64], const int bx,
                                                 const int by, const int tsplit) {
     constexpr int H = 32 * HT;
@@ -212,13 +212,35 @@ __device__ __forceinline__ void wgrad_bf16_wave(const HpmnGruWgrad &a, bf8 (*img
         load_raw(0, sa);
         park(0, sa, 0);
     }
-    __syncthreads();
-    for (int it = 0; it < niter; ++it) {
-        const int buf = it & 1;
-        load_raw(it < last ? it + 1 : last, sa);          // (clamped: no branch around the loads)
-        compute(buf);
-        if (it < last) park(buf ^ 1, sa, it + 1);
+    if constexpr (PF2) {
+        // (r6) prefetch distance TWO: tile it + 2's loads are issued in front of tile it's matrix instructions and parked a whole
+        // iteration later -- twice the bytes in flight per workgroup.  32 more registers: affordable since the H = 64 shapes run
+        // at two workgroups per CU (256 registers per wave), which r4's attempt at three per CU (170) did not have.
+        Raw sb;
+        auto clampi = [&](int i) { return i < last ? i : (last > 0 ? last : 0); };
+        load_raw(clampi(1), sa);
         __syncthreads();
+        int it = 0;
+        for (; it + 1 < niter; it += 2) {
+            load_raw(clampi(it + 2), sb);
+            compute(0);
+            park(1, sa, it + 1);
+            __syncthreads();
+            load_raw(clampi(it + 3), sa);
+            compute(1);
+            if (it + 2 < niter) park(0, sb, it + 2);
+            __syncthreads();
+        }
+        if (it < niter) compute(0);
+    } else {
+        __syncthreads();
+        for (int it = 0; it < niter; ++it) {
+            const int buf = it & 1;
+            load_raw(it < last ? it + 1 : last, sa);          // (clamped: no branch around the loads)
+            compute(buf);
+            if (it < last) park(buf ^ 1, sa, it + 1);
+            __syncthreads();
+        }
     }
 
     // ---- epilogue: this workgroup's partial slab (summed by wgrad_reduce_kernel), C/D layout of the 32x32 instructions:
@@ -255,7 +277,7 @@ __device__ __forceinline__ void wgrad_bf16_wave(const HpmnGruWgrad &a, bf8 (*img
 
 // LB3: three workgroups per CU for the three-wave shape (H = 64, D <= 32): 168 registers, the rest spilled (12 dwords with two
 // planes, 27 with three) -- against two workgroups per CU without spills (the default since r6, see launch_bf16).
-template <int HT, int DT, int CS, bool XCD = true, int NP = 3, bool LB3 = true>
+template <int HT, int DT, int CS, bool XCD = true, int NP = 3, bool LB3 = true, bool PF2 = false>
 __global__ __launch_bounds__(64 * (HT + DT), (HT + DT) == 3 ? (LB3 ? 3 : 2) : ((HT + DT) > 5 ? 1 : 2)) void gru_wgrad_bf16_kernel(const HpmnGruWgrad a) {
     static_assert((3 * HT) % CS == 0 && HT + DT <= 8, "column tiles split evenly; at most eight waves");
     __shared__ __attribute__((aligned(16))) bf8 img[2][3 * HT / CS][NP][64];      // (the d_act blocks only, see wgrad_bf16_wave)
@@ -283,17 +305,17 @@ __global__ __launch_bounds__(64 * (HT + DT), (HT + DT) == 3 ? (LB3 ? 3 : 2) : ((
     }
     // (in the kernel's copy of the descriptor `whole_cu` carries the launch's time split: gru_wgrad_bf16_launch)
     const int tsplit = CS == 1 && a.whole_cu > 1 ? a.whole_cu : 1;
-    if (wave == 0) wgrad_bf16_wave<HT, DT, CS, 0, NP>(a, img, bx, by, tsplit);
-    else if (wave == 1) wgrad_bf16_wave<HT, DT, CS, 1, NP>(a, img, bx, by, tsplit);
-    else if (wave == 2) wgrad_bf16_wave<HT, DT, CS, 2, NP>(a, img, bx, by, tsplit);
+    if (wave == 0) wgrad_bf16_wave<HT, DT, CS, 0, NP, PF2>(a, img, bx, by, tsplit);
+    else if (wave == 1) wgrad_bf16_wave<HT, DT, CS, 1, NP, PF2>(a, img, bx, by, tsplit);
+    else if (wave == 2) wgrad_bf16_wave<HT, DT, CS, 2, NP, PF2>(a, img, bx, by, tsplit);
     else if constexpr (NW > 3) {
-        if (wave == 3) wgrad_bf16_wave<HT, DT, CS, 3, NP>(a, img, bx, by, tsplit);
+        if (wave == 3) wgrad_bf16_wave<HT, DT, CS, 3, NP, PF2>(a, img, bx, by, tsplit);
         else if constexpr (NW > 4) {
-            if (wave == 4) wgrad_bf16_wave<HT, DT, CS, 4, NP>(a, img, bx, by, tsplit);
+            if (wave == 4) wgrad_bf16_wave<HT, DT, CS, 4, NP, PF2>(a, img, bx, by, tsplit);
             else if constexpr (NW > 5) {
-                if (wave == 5) wgrad_bf16_wave<HT, DT, CS, 5, NP>(a, img, bx, by, tsplit);
-                else if (wave == 6) wgrad_bf16_wave<HT, DT, CS, 6, NP>(a, img, bx, by, tsplit);
-                else wgrad_bf16_wave<HT, DT, CS, 7, NP>(a, img, bx, by, tsplit);
+                if (wave == 5) wgrad_bf16_wave<HT, DT, CS, 5, NP, PF2>(a, img, bx, by, tsplit);
+                else if (wave == 6) wgrad_bf16_wave<HT, DT, CS, 6, NP, PF2>(a, img, bx, by, tsplit);
+                else wgrad_bf16_wave<HT, DT, CS, 7, NP, PF2>(a, img, bx, by, tsplit);
             }
         }
     }
@@ -305,7 +327,7 @@ static int wgrad_planes() {
     return np;
 }
 
-template <int HT, int DT, int CS, int NP, bool LB3>
+template <int HT, int DT, int CS, int NP, bool LB3, bool PF2 = false>
 static void launch_bf16_np(const HpmnGruWgrad &k, int nwg, bool solo, hipStream_t st) {
     // (one workgroup per CU beside a reverse scan, as in gru_wgrad.hip: unused dynamic LDS caps the occupancy; by default for
     //  H <= 64 only -- the H = 128 form is shaped around its column split; HPMN_WGRAD_SOLO_ROWS reaches it too)
@@ -313,7 +335,7 @@ static void launch_bf16_np(const HpmnGruWgrad &k, int nwg, bool solo, hipStream_
     if (solo) {
         static const size_t p = [] {
             hipFuncAttributes fa = {};
-            const void *fn = reinterpret_cast<const void *>(gru_wgrad_bf16_kernel<HT, DT, CS, true, NP, LB3>);
+            const void *fn = reinterpret_cast<const void *>(gru_wgrad_bf16_kernel<HT, DT, CS, true, NP, LB3, PF2>);
             if (hipFuncGetAttributes(&fa, fn) != hipSuccess) return (size_t)0;
             // (r6: 72 KB, was 82: layer 0's reverse scan holds 88 KB with the three-plane in-loop product's lo fragments in LDS,
             //  and the weight-gradient workgroup still has to fit beside it in the CU's 160 KB)
@@ -327,9 +349,9 @@ static void launch_bf16_np(const HpmnGruWgrad &k, int nwg, bool solo, hipStream_
     const unsigned grid = CS > 1 ? (unsigned)((nwg + 7) / 8) * 8u * CS : (unsigned)nwg;
     static const int xcd_env = [] { const char *e = getenv("HPMN_WGRAD_XCD"); return e ? atoi(e) : 1; }();
     if (CS > 1 && !xcd_env)
-        hipLaunchKernelGGL((gru_wgrad_bf16_kernel<HT, DT, CS, false, NP, LB3>), dim3(grid), dim3(64 * (HT + DT)), pad, st, k);
+        hipLaunchKernelGGL((gru_wgrad_bf16_kernel<HT, DT, CS, false, NP, LB3, PF2>), dim3(grid), dim3(64 * (HT + DT)), pad, st, k);
     else
-        hipLaunchKernelGGL((gru_wgrad_bf16_kernel<HT, DT, CS, true, NP, LB3>), dim3(grid), dim3(64 * (HT + DT)), pad, st, k);
+        hipLaunchKernelGGL((gru_wgrad_bf16_kernel<HT, DT, CS, true, NP, LB3, PF2>), dim3(grid), dim3(64 * (HT + DT)), pad, st, k);
 }
 
 template <int HT, int DT, int CS>
@@ -337,6 +359,18 @@ static void launch_bf16(const HpmnGruWgrad &k, int nwg, bool solo, hipStream_t s
     // (r6, with the wave's own operand block in registers: two workgroups per CU without spills beat three with 12 / 27 spilled
     //  dwords -- alone on the chip 165 vs 188 us (two planes), 223 vs 257 (three); C3 step 2.415 vs 2.441 -- HPMN_WGRAD_OCC=3)
     static const int occ = [] { const char *e = getenv("HPMN_WGRAD_OCC"); return e ? atoi(e) : 2; }();
+    // (prefetch distance two where the launch is not beside a scan: alone on the chip 218 -> 193 us with three planes, 162 -> 151
+    //  with two (D = 32); 240 -> 217 at D = 64; C3 step 2.50 -> 2.47-2.49, C2 0.925 -> 0.915.  HPMN_WGRAD_PF=1: distance one)
+    static const int pf = [] { const char *e = getenv("HPMN_WGRAD_PF"); return e ? atoi(e) : 2; }();
+    if constexpr (HT == 2) {                      // (H = 64: two workgroups per CU, 256 registers per wave)
+        // (never beside a reverse scan -- `solo`: that launch's waves must stay within 512 - 288 = 224 registers to share a SIMD
+        //  with the scan's, which is what the r6 register cliff was about; distance two is 228-253)
+        if (pf == 2 && !solo && (occ == 2 || HT + DT != 3)) {
+            if (wgrad_planes() == 2) launch_bf16_np<HT, DT, CS, 2, HT + DT != 3, true>(k, nwg, solo, st);
+            else launch_bf16_np<HT, DT, CS, 3, HT + DT != 3, true>(k, nwg, solo, st);
+            return;
+        }
+    }
     if constexpr (HT + DT == 3) {
         if (occ == 2) {
             if (wgrad_planes() == 2) launch_bf16_np<HT, DT, CS, 2, false>(k, nwg, solo, st);

@@ -328,7 +328,10 @@ class Hpmn_Basic(object):
         # two-pass dense table Adam (train_step): rows the batch points at / whether the table gradient is all-zero
         self._row_flags: Optional[torch.Tensor] = None
         self._table_grad_clean = True
-        self._aux_stream = torch.cuda.Stream(device=dev)                      # housekeeping off the serial chain
+        # housekeeping off the serial chain.  HPMN_AUX_PRIORITY=1 (r6, measurement switch): the auxiliary and plan streams at high
+        # priority, i.e. in the hardware-queue pool of the library's helper streams instead of the caller's and RCCL's
+        self._bg_priority = -1 if os.environ.get("HPMN_AUX_PRIORITY", "0") == "1" else 0
+        self._aux_stream = torch.cuda.Stream(device=dev, priority=self._bg_priority)
         self.flat_m = torch.zeros(n, device=dev, dtype=torch.float32)
         self.flat_v = torch.zeros(n, device=dev, dtype=torch.float32)
         self.params: Dict[str, torch.Tensor] = {}
@@ -1171,13 +1174,15 @@ class Hpmn_Basic(object):
         cnt_all = dist.all_gather_fixed(cnt, group=group)                  # [world, 1 + C] int32
         return dict(ids_all=ids_all, cnt_all=cnt_all, counts=dist.HostCopy(cnt_all))
 
-    def _prefetch_rows(self, next_ids, next_global_batch):
+    def _prefetch_rows(self, next_ids, next_global_batch, after=None):
         """train_step(next_ids=): the NEXT step's plan (and, data parallel, its early exchange -- on a second communicator, so
         that it never queues in front of this step's collectives) on a stream of its own, enqueued in front of this step: it
         has the whole step to finish in, on whatever the scans leave free, and nothing of this step waits for it.
         (r5, measured: underneath layer 0's reverse scan it took the weight gradients' slots -- the step's tail grew by 150 us --
         and its counts reached the host so late that the next step started 0.3 ms behind an idle device.)"""
         if self._plan_stream is None:
+            # (plain priority: with the plan's ~20 sort launches at high priority the rows step went from 2.6 to 4.3 ms -- they are
+            #  dispatched in front of the scans' workgroups)
             self._plan_stream = torch.cuda.Stream(device=self.device)
         pst = self._plan_stream
         gb, cap, C, bounds = self._rows_geometry(next_ids, next_global_batch)
@@ -1195,7 +1200,10 @@ class Hpmn_Basic(object):
         # (the plan stream reads next_ids -- order it behind what the caller's stream has been given so far, in case
         #  the tensor was produced there; that is the END of the previous step, the plan still has this whole step to run in.
         #  next_ids must stay unchanged until the next train_step has consumed the plan: a slice of a staged dataset does.)
-        pst.wait_stream(torch.cuda.current_stream())
+        if after is not None:
+            pst.wait_event(after)                             # (the caller's stream as it was when the step STARTED)
+        else:
+            pst.wait_stream(torch.cuda.current_stream())
         # r6: WITHOUT the second communicator the early exchange is issued at the END of this step (_prefetch_exchange), not here:
         # collectives of one communicator run in issue order on its stream, and issued here they sat in front of THIS step's row
         # exchange and dense all-reduce waiting for a plan that is built on whatever the scans leave free (one rank on RCCL, C3:
@@ -1308,8 +1316,14 @@ class Hpmn_Basic(object):
                 for x in (pre["ex"]["ids_all"], pre["ex"]["cnt_all"]):
                     x.record_stream(self._aux_stream)
                 box.update(pre["ex"])
+        step_start = None
         if next_ids is not None:
-            self._prefetch_rows(next_ids, next_global_batch)
+            step_start = torch.cuda.Event()
+            step_start.record()
+        # (r6: the NEXT step's plan is enqueued BEHIND this step's forward + BPTT, not in front of them: under data parallel the
+        #  host waits for the exchanged counts once per step, so it is never far ahead of the device, and the plan's ~20 launches
+        #  in front of the forward were 0.3 ms of every step during which the device waited for the host -- timeline
+        #  profiles/r06_timeline_rows.txt: the forward started 365 us into the step)
 
         def early():                                          # runs on the auxiliary stream
             self.flat_grad.zero_()                            # (the dense variables' gradient: a few hundred kB)
@@ -1361,6 +1375,10 @@ class Hpmn_Basic(object):
         self.adam_t = t
         plan = self.last_scatter_plan if B > 0 else None
         self._preset_plan = None
+        if next_ids is not None:
+            # (its own stream, ordered behind the caller's stream as it was at the START of the step -- not behind the BPTT just
+            #  enqueued: it runs on whatever this step's scans leave free)
+            self._prefetch_rows(next_ids, next_global_batch, after=step_start)
         if not dp:
             if plan is not None:
                 ops.rows_sum_adam(P, M, S, flags, plan.rows.view(1, -1), plan.out_rows.view(1, -1, E), lr_t,

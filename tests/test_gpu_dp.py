@@ -64,8 +64,8 @@ def test_dataset_sharded_evaluation_matches_single_process(tmp_path, nproc):
     """r6 (SURVEY 8e "eval shards the dataset and all-gathers predictions"; code/hpmn.py:351-373): under data
     parallel Hpmn.eval gives rank r the rows [n r / N, n (r+1) / N) of the WHOLE set, full-width passes on the same kernels a
     single process uses, ONE all-gather of predictions and ONE all-reduce of the memory-loss sum.  Same weights, no training:
-    AUC and log-loss to 1e-6, the memory-loss mean to 1e-5 relative (float32 sums in another order).  6 800 rows: every shard
-    (3 400 / 1 700 rows) stays on the tile kernels the single process uses."""
+    AUC to 1e-6, log-loss to 2e-6 relative, the memory-loss mean to 1e-5 relative (float32 sums in another order).  6 800 rows:
+    every shard (3 400 / 1 700 rows) stays on tile kernels like the single process."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     out = str(tmp_path / "dp.npz")
@@ -81,7 +81,9 @@ def test_dataset_sharded_evaluation_matches_single_process(tmp_path, nproc):
     assert m.world == 1
     want = dp_worker.run_eval(m, tr, te)["__eval__"]
     assert 0.0 < want[0] < 1.0 and want[1] > 0 and want[2] > 0
-    np.testing.assert_allclose(got[:2], want[:2], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(got[0], want[0], rtol=0, atol=1e-6)           # AUC
+    np.testing.assert_allclose(got[1], want[1], rtol=2e-6)                   # log-loss (measured 2.4e-7: the shards' 3 400 / 1 700 rows
+    #                                                                          take the twelve-wave tile kernel, 6 800 the four-wave one)
     np.testing.assert_allclose(got[2], want[2], rtol=1e-5)
 
 
