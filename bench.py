@@ -1097,6 +1097,23 @@ def main():
         torch.distributed.all_gather(alls, mine)
         replicas_identical = bool(all(torch.equal(a, alls[0]) for a in alls))
         log("replicas identical: %s" % replicas_identical)
+    # r6: the first real multi-GPU run should say WHERE a step's time goes: eight more steps of the data-parallel
+    # rows step with timing events between its phases (main stream; max over ranks of the per-rank means)
+    dp_phases = None
+    if (world > 1 or args.one_rank_rccl) and getattr(model, "compact_table_grad", False):
+        model._phase_probe = []
+        for i in range(8):
+            step(args.warmup + args.steps + 100 + i)
+        torch.cuda.synchronize()
+        pr, model._phase_probe = model._phase_probe, None
+        if pr:
+            ms = torch.tensor([[a.elapsed_time(b) for a, b in zip(pe[:-1], pe[1:])] for pe in pr[2:]], dtype=torch.float64).mean(0).to(device)
+            if world > 1:
+                torch.distributed.all_reduce(ms, op=torch.distributed.ReduceOp.MAX)
+            dp_phases = {"forward_read_bptt_scatter": float(ms[0]), "rows_exchange_and_table_update": float(ms[1]),
+                         "join_dense_allreduce_adam": float(ms[2]), "note": "ms, main stream, mean of 6 steps, max over ranks; the early "
+                         "table pass and the weight gradients run beside the first phase on their own streams"}
+            log("data-parallel phases: %s" % dp_phases)
     # quick quality signal on the bench batches (not a trained AUC: weights saw only W+K steps)
     finite = True
     if not args.no_eval:
@@ -1144,7 +1161,7 @@ def main():
                 dts.append(time.perf_counter() - te1)
             dt = sorted(dts)[len(dts) // 2]
             eval_pass = {"rows": int(ev_all.shape[0]), "reference_batch": 4 * c["batch"], "seconds": dt, "seconds_all": dts,
-                         "sequences_per_s": ev_all.shape[0] / dt, "ranks": world,
+                         "sequences_per_s": ev_all.shape[0] / dt, "sequences_per_s_best": ev_all.shape[0] / min(dts), "ranks": world,
                          "rows_per_pass": (int(model.TILED_EVAL_ROWS // (4 * c["batch"]) * 4 * c["batch"])
                                            if model._tiled_inference(model.TILED_EVAL_ROWS) and 4 * c["batch"] <= model.TILED_EVAL_ROWS
                                            else 4 * c["batch"]),
@@ -1268,6 +1285,8 @@ def main():
             result["data_parallel"] = dp_report(model, c, batches, world, elapsed / args.steps * 1e3,
                                                 one_rank=side.get("one_rank_rccl_ms"), laws=laws,
                                                 standin=side.get("one_rank_rccl_wire_standin_ms"))
+        if dp_phases is not None:
+            result["dp_phases_ms"] = dp_phases
         if auc is not None:
             result["auc"] = auc
         if c["V"] * 16 * 4 >= (2 << 30) and world == 1:

@@ -779,6 +779,7 @@ class Hpmn_Basic(object):
     # ------------------------------------------------------------------ the whole step behind ONE library call (r6)
     ONE_CALL_STEP = os.environ.get("HPMN_ONE_CALL_STEP", "1") != "0"
     _one_call_cache = None
+    _phase_probe = None          # a list: the data-parallel rows step appends (start, BPTT enqueued, table updated, done) timing events
 
     def _one_call_ok(self, ids) -> bool:
         """The plain single-process step (one dense sweep over the table, everything on the caller's stream + the library's
@@ -1320,6 +1321,10 @@ class Hpmn_Basic(object):
         if next_ids is not None:
             step_start = torch.cuda.Event()
             step_start.record()
+        probe = self._phase_probe
+        if probe is not None:
+            pe = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            pe[0].record()
         # (r6: the NEXT step's plan is enqueued BEHIND this step's forward + BPTT, not in front of them: under data parallel the
         #  host waits for the exchanged counts once per step, so it is never far ahead of the device, and the plan's ~20 launches
         #  in front of the forward were 0.3 ms of every step during which the device waited for the host -- timeline
@@ -1375,6 +1380,8 @@ class Hpmn_Basic(object):
         self.adam_t = t
         plan = self.last_scatter_plan if B > 0 else None
         self._preset_plan = None
+        if probe is not None:
+            pe[1].record()                                    # (forward + read path + BPTT + the scatter's segmented reduction)
         if next_ids is not None:
             # (its own stream, ordered behind the caller's stream as it was at the START of the step -- not behind the BPTT just
             #  enqueued: it runs on whatever this step's scans leave free)
@@ -1410,12 +1417,17 @@ class Hpmn_Basic(object):
                                   buckets=box.get("buckets"), **hp)
             self.last_exchange_mode = "rows"
             self.last_exchange_bytes = dist.rows_exchange_bytes_windows(windows, E, wide, self.world, cap)
+        if probe is not None:
+            pe[2].record()                                    # (the rows exchange and the touched rows' update)
         if pending is not None:
             pending.join()
         lo = self._goff
         dist.allreduce_sum_(self.flat_grad)                   # (the flat gradient holds the dense variables only)
         ops.adam_step(self.flat_param[lo:], self.flat_grad, self.flat_m[lo:], self.flat_v[lo:], lr_t, self.beta1,
                       self.beta2, self.adam_eps, clip=1.0)
+        if probe is not None:
+            pe[3].record()                                    # (join of layer 0's weight gradient, dense all-reduce, dense Adam)
+            probe.append(pe)
         if dp:
             self._prefetch_exchange()                         # (the next step's lists and counts, behind this step's collectives)
         return out, ce

@@ -11,7 +11,7 @@ cp $out/step/kernel_stats.csv $out/kernel_stats.csv 2>/dev/null
 cp $out/step/timeline.txt $out/timeline.txt 2>/dev/null
 for ctr in FETCH_SIZE WRITE_SIZE; do
   timeout 500 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/pmc_$ctr -- \
-      python bench.py --config $cfg --steps 5 --warmup 1 --no-cpu-baseline --no-roofline --no-auc --no-parity-gate --no-eval --no-side-legs --no-input-pipeline \
+      python bench.py --config $cfg --steps 5 --warmup 1 --no-cpu-baseline --no-roofline --no-auc --no-parity-gate --no-eval --no-side-legs --no-input-pipeline --no-batch-sweep \
       > /dev/null 2> $out/pmc_$ctr.err < /dev/null
   f=$(find $out/pmc_$ctr -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && python tools/pmc_summary.py $f $ctr > $out/pmc_$ctr.txt && cp $f $out/pmc_$ctr.csv
