@@ -886,6 +886,10 @@ def side_legs(args, zipf_fraction=None):
     out = {"all_fp32_ms_per_step": run([], ALL_FP32_ENV)}
     if CONFIGS[args.config]["H"] >= 64:
         out["two_planes_ms_per_step"] = run([], TWO_PLANES_ENV)      # (rounds 4/5's arithmetic, for comparison)
+    if CONFIGS[args.config]["industry"] and args.id_law != "zipf" and not args.vocab_rows:
+        # the same step on Zipf(1.1) item ids (the law SURVEY 8d gives Amazon / Taobao; the headline's uniform ids are the worst
+        # case for the data-parallel exchange and the EASY case for the scatter: r6's auto choice of the scatter is what this shows)
+        out["zipf_ids_ms_per_step"] = run(["--id-law", "zipf"], {})
     if not args.lazy_table_adam:
         out["one_rank_rccl_ms"] = {m: run(["--one-rank-rccl", m], {}) for m in ("rows", "allreduce")}
         if args.config == "c3":
@@ -1250,6 +1254,11 @@ def main():
                        "global_batch": global_batch, "max_len": c["T"], "scan_steps": layer_lengths(c),
                        "hidden": c["H"], "layers": c["K"], "vocab_rows": c["V"], "keep_prob": 0.5,
                        "parallelism": "dp%d" % world, "predictions_finite": finite,
+                       "id_law": (args.id_law or "uniform") if c["industry"] else "zipf(1.1) items",
+                       "table_scatter": ("sorted-segment reduction" if (model.det_scatter or model.compact_table_grad) else
+                                         "atomic row adds, runs of equal ids pre-reduced"
+                                         + (" + per-wave LDS table over equal ids (HPMN_ID_HOT)" if model.spec.hot_ids else ""))
+                                        + " (%.2f distinct rows per run of equal ids in the first batch)" % model._probe_id_law(batches[0][0]),
                        "table_optimizer": "lazy (row-wise) Adam -- DEVIATION from the reference's dense TF Adam"
                                           if args.lazy_table_adam else "dense TF Adam over every row (reference semantics)"},
             "algorithmic": {"gru_flops_fwd_per_seq": algorithmic_flops_fwd(c),
@@ -1278,6 +1287,8 @@ def main():
             if side.get("two_planes_ms_per_step") is not None:
                 result["ms_per_step_two_planes"] = side["two_planes_ms_per_step"]
                 result["two_planes_switches"] = TWO_PLANES_ENV
+            if side.get("zipf_ids_ms_per_step") is not None:
+                result["ms_per_step_zipf_ids"] = side["zipf_ids_ms_per_step"]
             if side.get("all_fp32_ms_per_step") is not None:
                 result["ms_per_step_all_fp32"] = side["all_fp32_ms_per_step"]
                 result["all_fp32_switches"] = ALL_FP32_ENV

@@ -38,10 +38,24 @@ __global__ __launch_bounds__(256) void embed_gather_kernel(const void *__restric
 // merely split at segment boundaries.  E must divide 64.
 constexpr int SCU = 8;      // steps per load chunk
 constexpr int SSEG = 128;   // steps per wave at most (r5: fewer where the launch would otherwise be a few hundred waves, below)
+// HOT (r6, HPMN_ID_HOT): a run's sum goes into a 64-entry LDS table keyed by the id (a slot is claimed with a compare-and-swap
+// by the run's first lane; a slot held by another id: the atomic row add as before) and the table is flushed with one atomic
+// row add per entry at the end -- a row that many lookups of the segment share (Zipf's head, Taobao's 4-valued btag column:
+// 16 k lookups of a C2 batch on 5 rows) costs the wave ONE global row add instead of one per run.  Uniform ids gain nothing
+// and pay the table's traffic: the host picks the form from the first batch (hpmn.py: _scatter_hint).
+constexpr int SHT = 64;     // table entries per wave
+template <bool HOT>
 __global__ __launch_bounds__(64) void embed_grad_scatter_kernel(
     const void *__restrict__ ids, const float *__restrict__ d_x, float *__restrict__ d_emb, int B,
     int T, int F, int E, int front_zero, int mask_id0, int groups, int nseg, int t_lo, int t_hi,
     const float *__restrict__ d_last, int t_last, int sseg) {
+    __shared__ long long hkey[HOT ? SHT : 1];
+    __shared__ float htab[HOT ? 1024 : 1];                   // [entry][e]: nh = min(64, 1024 / E) entries of E floats
+    const int nh = (1024 / E) < SHT ? (1024 / E) : SHT;      // (a power of two: E | 64)
+    if constexpr (HOT) {
+        hkey[threadIdx.x] = -1;                              // (64 threads == SHT entries)
+        __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0): the wave's own LDS writes have landed (one wave: no barrier)
+    }
     const int cpw = 64 / E;                          // E-lane slots per wave
     const int seg = blockIdx.x % nseg;
     const int grp = (blockIdx.x / nseg) % groups;
@@ -63,6 +77,26 @@ __global__ __launch_bounds__(64) void embed_grad_scatter_kernel(
     const float *gp = d_x + (b * (long)(front_zero + T) + front_zero) * Dx + f * E + e;
     long run_id = -1;
     float acc = 0.f;
+    auto flush_run = [&](long id, float sum) {
+        if constexpr (HOT) {
+            const int h = (int)((id * 0x9E3779B1u) >> 13) & (nh - 1);
+            int ok = 0;
+            if (e == 0) {
+                // (a fresh entry's row is zeroed by its claimer BEFORE the other lanes add: they learn `ok` through the
+                //  shuffle below, i.e. after this lane's LDS operations were issued -- LDS runs a wave's operations in order)
+                const long long old = atomicCAS(reinterpret_cast<unsigned long long *>(&hkey[h]), (unsigned long long)-1LL,
+                                                (unsigned long long)id);
+                ok = (old == -1LL || old == (long long)id) ? ((old == -1LL) ? 2 : 1) : 0;
+                if (ok == 2)
+                    for (int q = 0; q < E; ++q) htab[h * E + q] = 0.f;
+            }
+            ok = __shfl(ok, 0, E);                           // (the slot's E lanes are in here together: E | 64)
+            if (ok) atomicAdd(&htab[h * E + e], sum);
+            else atomicAdd(d_emb + id * E + e, sum);
+        } else {
+            atomicAdd(d_emb + id * E + e, sum);
+        }
+    };
     for (int t0 = t_begin + tsub; t0 < t_end; t0 += SCU * tpw) {
         long idv[SCU];
         float gv[SCU];
@@ -83,15 +117,23 @@ __global__ __launch_bounds__(64) void embed_grad_scatter_kernel(
         for (int i = 0; i < SCU; ++i) {
             if (idv[i] < 0) continue;
             if (idv[i] != run_id) {
-                if (run_id >= 0 && !id_masked(run_id, mask_id0))
-                    atomicAdd(d_emb + run_id * E + e, acc);
+                if (run_id >= 0 && !id_masked(run_id, mask_id0)) flush_run(run_id, acc);
                 run_id = idv[i];
                 acc = 0.f;
             }
             acc += gv[i];
         }
     }
-    if (run_id >= 0 && !id_masked(run_id, mask_id0)) atomicAdd(d_emb + run_id * E + e, acc);
+    if (run_id >= 0 && !id_masked(run_id, mask_id0)) flush_run(run_id, acc);
+    if constexpr (HOT) {
+        // every lane is back here (the early return above is per SLOT: whole 16-lane groups); the table: entry h, element e
+        // (the lanes still here are the wave's ACTIVE slots, 0 .. tpw * fpw - 1: they share the table's entries)
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        for (int h = slot; h < nh; h += tpw * fpw) {
+            const long long k = hkey[h];
+            if (k >= 0) atomicAdd(d_emb + k * E + e, htab[h * E + e]);
+        }
+    }
 }
 
 // The gather CONSUMED IN PLACE: out[b, f*E + e] = sum_t emb[ids[b,t,f], e] (mask as above) -- the pooled form of
@@ -209,8 +251,15 @@ int embed_grad_scatter_launch(const void *ids, const float *d_x, float *d_emb, i
     sseg = (sseg + 15) / 16 * 16;
     sseg = sseg < 16 ? 16 : (sseg > SSEG ? SSEG : sseg);
     const int nseg = (t_hi - t_lo + sseg - 1) / sseg;
-    hipLaunchKernelGGL(embed_grad_scatter_kernel, dim3((unsigned)(B * groups * nseg)), dim3(64), 0, st, ids,
-                       d_x, d_emb, B, T, F, E, front_zero, mask_id0, groups, nseg, t_lo, t_hi, d_last, t_last, sseg);
+    // HPMN_SCATTER_HOT=0 / 1: never / always the table form (default: the caller's HPMN_ID_HOT hint)
+    static const int hot_env = [] { const char *e = getenv("HPMN_SCATTER_HOT"); return e ? atoi(e) : -1; }();
+    const bool hot = hot_env >= 0 ? hot_env != 0 : (mask_id0 & HPMN_ID_HOT) != 0;
+    if (hot)
+        hipLaunchKernelGGL(embed_grad_scatter_kernel<true>, dim3((unsigned)(B * groups * nseg)), dim3(64), 0, st, ids,
+                           d_x, d_emb, B, T, F, E, front_zero, mask_id0, groups, nseg, t_lo, t_hi, d_last, t_last, sseg);
+    else
+        hipLaunchKernelGGL(embed_grad_scatter_kernel<false>, dim3((unsigned)(B * groups * nseg)), dim3(64), 0, st, ids,
+                           d_x, d_emb, B, T, F, E, front_zero, mask_id0, groups, nseg, t_lo, t_hi, d_last, t_last, sseg);
     return check_launch();
 }
 

@@ -37,6 +37,10 @@ extern "C" {
 #define HPMN_ABI_VERSION 14
 #define HPMN_ID_MASK0 1   /* id-flags bit 0: id 0 gathers a zero row and receives no gradient (the Hpmn class)  */
 #define HPMN_ID_I64 2     /* id-flags bit 1: the ids tensor is int64 (default: int32)                          */
+#define HPMN_ID_HOT 4     /* id-flags bit 2 (ABI v14; a HINT to the gradient scatter, ignored elsewhere): many lookups share
+                           * few rows (a heavy-tailed id law, a 4-valued behaviour-tag column): hpmn_embed_grad_scatter / the
+                           * scatter inside hpmn_scan_bwd pre-reduce equal ids of a wave's time segment in an LDS table before
+                           * the atomic row adds -- same sums, fewer atomics on the hot rows                           */
 #define HPMN_MAX_LAYERS 12
 #define HPMN_MAX_CHUNKS 32 /* row-range chunks hpmn_scatter_plan_build counts distinct rows for                        */
 #define HPMN_MAX_RANKS 8   /* data-parallel ranks hpmn_rows_sum_adam tells apart (a rank bit per flags byte)        */
