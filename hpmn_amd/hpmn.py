@@ -1199,8 +1199,10 @@ class Hpmn_Basic(object):
         and its counts reached the host so late that the next step started 0.3 ms behind an idle device.)"""
         if self._plan_stream is None:
             # (plain priority: with the plan's ~20 sort launches at high priority the rows step went from 2.6 to 4.3 ms -- they are
-            #  dispatched in front of the scans' workgroups)
-            self._plan_stream = torch.cuda.Stream(device=self.device)
+            #  dispatched in front of the scans' workgroups.  HPMN_PLAN_ON_AUX=1: no stream of its own -- the auxiliary stream,
+            #  behind the early table pass: one stream fewer to share the runtime's hardware queues)
+            self._plan_stream = (self._aux_stream if os.environ.get("HPMN_PLAN_ON_AUX", "0") == "1"
+                                 else torch.cuda.Stream(device=self.device))
         pst = self._plan_stream
         gb, cap, C, bounds = self._rows_geometry(next_ids, next_global_batch)
         # The early exchange goes over a SECOND communicator (HPMN_DP_SIDE_GROUP=0: the default one).  Measured with one rank on
