@@ -1258,7 +1258,7 @@ def main():
                        "table_scatter": ("sorted-segment reduction" if (model.det_scatter or model.compact_table_grad) else
                                          "atomic row adds, runs of equal ids pre-reduced"
                                          + (" + per-wave LDS table over equal ids (HPMN_ID_HOT)" if model.spec.hot_ids else ""))
-                                        + " (%.2f distinct rows per run of equal ids in the first batch)" % model._probe_id_law(batches[0][0]),
+                                        + " (%.2f distinct rows per run of equal ids in the first batch)" % (model.auto_det_distinct_fraction or model._probe_id_law(batches[0][0])),
                        "table_optimizer": "lazy (row-wise) Adam -- DEVIATION from the reference's dense TF Adam"
                                           if args.lazy_table_adam else "dense TF Adam over every row (reference semantics)"},
             "algorithmic": {"gru_flops_fwd_per_seq": algorithmic_flops_fwd(c),

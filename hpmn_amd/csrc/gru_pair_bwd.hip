@@ -403,10 +403,14 @@ __global__ __launch_bounds__(512, 2) void gru_pair_bwd_kernel(const PairBwdArgs 
 
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int seq = w & 1;
-    int role = w >> 1;                               // 0 lower chain, 1 lower feeder, 2 upper chain, 3 upper feeder
+    // (r6) flags bit 2: ONE sequence per workgroup, four waves (launched with 256 threads): the roles land on four SIMDs instead of
+    // sharing two -- for batches that leave the chip's CUs to spare (B <= CUs: Taobao's 128), where two chain waves per SIMD
+    // cost the pace-setting layer 8-17 % (DESIGN_HISTORY 3.12) and buy nothing
+    const bool single = (p.flags & 4) != 0;
+    const int seq = single ? 0 : (w & 1);
+    int role = single ? w : (w >> 1);                               // 0 lower chain, 1 lower feeder, 2 upper chain, 3 upper feeder
     if ((p.flags & 1) && role >= 2) role ^= 1;
-    const long b = 2 * (long)blockIdx.x + seq;
+    const long b = single ? (long)blockIdx.x : 2 * (long)blockIdx.x + seq;
     if (b >= p.lo.B) return;                         // odd batch (before the barrier: ended waves do not take part in it)
     BwdLds<2> &SL = lo_[seq];
     BwdLds<RDR> &SU = up_[seq];
@@ -443,10 +447,25 @@ __global__ __launch_bounds__(512, 2) void gru_pair_bwd_kernel(const PairBwdArgs 
 
 bool gru_pair_bwd_supported(int H, int D_lo) { return H == RH && (D_lo == 16 || D_lo == 32 || D_lo == 64); }
 
+// (r6) one sequence per workgroup where the batch leaves CUs to spare: HPMN_PAIR_SINGLE=0 / 1, default: B <= number of CUs
+static bool pair_single_seq(int B) {
+    static const int env = [] { const char *e = getenv("HPMN_PAIR_SINGLE"); return e ? atoi(e) : -1; }();
+    if (env >= 0) return env != 0;
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return 256;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return 256;
+        return n;
+    }();
+    return B <= cus;
+}
+
 int gru_pair_bwd_launch(const HpmnGruBwd &lo, const HpmnGruBwd &up, int flags, hipStream_t st) {
     PairBwdArgs p = {};
     p.lo = lo; p.up = up; p.flags = flags;
-    const dim3 grid((lo.B + 1) / 2), blk(512);
+    const bool single = pair_single_seq(lo.B);
+    if (single) p.flags |= 4;
+    const dim3 grid(single ? lo.B : (lo.B + 1) / 2), blk(single ? 256 : 512);
     // (the candidate switch is a template argument of the whole launch: both layers the same way)
     const bool cfh = (lo.flags & HPMN_BWD_CANDIDATE_FROM_HS) != 0;
     if (cfh != ((up.flags & HPMN_BWD_CANDIDATE_FROM_HS) != 0)) return HPMN_EUNSUPPORTED;

@@ -434,10 +434,14 @@ __global__ __launch_bounds__(512, 2) void gru_pair_fwd_kernel(const PairFwdArgs 
 
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform, and known to be
-    const int seq = w & 1;
-    int role = w >> 1;                               // 0 lower chain, 1 lower producer, 2 upper chain, 3 upper producer
+    // (r6) flags bit 2: ONE sequence per workgroup, four waves (launched with 256 threads): the roles land on four SIMDs instead of
+    // sharing two -- for batches that leave the chip's CUs to spare (B <= CUs: Taobao's 128), where two chain waves per SIMD
+    // cost the pace-setting layer 8-17 % (DESIGN_HISTORY 3.12) and buy nothing
+    const bool single = (p.flags & 4) != 0;
+    const int seq = single ? 0 : (w & 1);
+    int role = single ? w : (w >> 1);                               // 0 lower chain, 1 lower producer, 2 upper chain, 3 upper producer
     if ((p.flags & 1) && role >= 2) role ^= 1;
-    const long b = 2 * (long)blockIdx.x + seq;
+    const long b = single ? (long)blockIdx.x : 2 * (long)blockIdx.x + seq;
     if (b >= p.lo.B) return;                         // odd batch (before the barrier: ended waves do not take part in it)
     const bool alone = (p.flags & 2) != 0;           // (measurement: the lower layer only)
     if (alone && role >= 2) return;
@@ -526,6 +530,19 @@ int gru_proj_images_launch(int n, const float *const *wg, const float *const *bg
 size_t gru_pair_fwd_scratch_bytes() { return 2 * gru_proj_image_floats(64) * sizeof(float); }
 
 // img_lo / img_up: ready-made images (gru_proj_images_launch) or NULL: built here, into scratch
+// (r6) one sequence per workgroup where the batch leaves CUs to spare: HPMN_PAIR_SINGLE=0 / 1, default: B <= number of CUs
+static bool pair_single_seq(int B) {
+    static const int env = [] { const char *e = getenv("HPMN_PAIR_SINGLE"); return e ? atoi(e) : -1; }();
+    if (env >= 0) return env != 0;
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return 256;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return 256;
+        return n;
+    }();
+    return B <= cus;
+}
+
 int gru_pair_fwd_launch(const HpmnGruFusedFwd &lo, const HpmnGruFusedFwd &up, int flags, float *scratch,
                         const float *img_lo, const float *img_up, hipStream_t st) {
     PairFwdArgs p = {};
@@ -544,7 +561,9 @@ int gru_pair_fwd_launch(const HpmnGruFusedFwd &lo, const HpmnGruFusedFwd &up, in
     p.wimg_up = img_up;
     p.wimg_lo = need_lo ? img_lo : nullptr;
     const bool train = lo.hs != nullptr;
-    const dim3 grid((lo.B + 1) / 2), blk(512);
+    const bool single = pair_single_seq(lo.B);
+    if (single) p.flags |= 4;
+    const dim3 grid(single ? lo.B : (lo.B + 1) / 2), blk(single ? 256 : 512);
     const bool gather = lo.x == nullptr;
 #define PAIR_LAUNCH(D0, SRC0)                                                                              \
     do {                                                                                                     \

@@ -685,6 +685,8 @@ class Hpmn_Basic(object):
         what only depends on the ids (the scatter's plan; under data parallel the exchange of the ranks' distinct rows and
         counts) is then prepared underneath this step's BPTT instead of in front of the next step's early table pass.  Every
         rank must pass it or none (it issues collectives)."""
+        if self.auto_det_distinct_fraction is None and ids.shape[0] > 0:
+            self._probe_id_law(ids, set_hint=True)
         if self.compact_table_grad:
             return self._train_step_rows(ids, label, keep_prob, masks, global_batch, next_ids, next_global_batch)
         if item_ids is None and self._one_call_ok(ids):
@@ -922,16 +924,22 @@ class Hpmn_Basic(object):
     # under a heavy-tailed law -- Zipf(1.1) over the XLong item range puts 12 % of a batch's lookups on ONE row -- those
     # serialise in one L2 channel: C3 3.01 ms/step against 2.45 on uniform ids.  Measured alternatives on the same Zipf batches:
     # the sorted-segment reduction (every distinct row added once; its plan is ~0.2 ms of small launches) 2.51; the atomic
-    # kernel with an LDS table per wave (HPMN_ID_HOT) 2.40 -- and 2.505 on uniform ids, where it has nothing to gain: it is simply
-    # ON (ops.ScanSpec.hot_ids), no decision to take.  What is left here is the measurement itself, for the bench line.
+    # kernel with an LDS table per wave over equal ids (HPMN_ID_HOT) 2.40.  On uniform ids the table has nothing to gain and
+    # makes the scatter launch 105 -> 133 us.  So the model looks at its FIRST training batch once (one torch.unique, one host
+    # synchronisation in its life): distinct rows per run of equal ids below one half -> the hint is set.
     auto_det_distinct_fraction = None
     _auto_det_decision = None
+    _hot_hint_mode = os.environ.get("HPMN_SCATTER_HOT_HINT", "auto")
 
-    def _probe_id_law(self, ids) -> float:
+    def _probe_id_law(self, ids, set_hint: bool = False) -> float:
         """Distinct rows per RUN of equal ids along t (what the atomic scatter issues is one row add per run -- the constant uid
         column of a sequence is one run): ~0.93 on uniform XLong ids, 0.20 on Zipf(1.1), 0.24 on the Taobao shape."""
         runs = int((ids[:, 1:] != ids[:, :-1]).sum()) + ids.shape[0] * ids.shape[2]
         self.auto_det_distinct_fraction = int(torch.unique(ids).numel()) / float(max(1, runs))
+        if set_hint and self._hot_hint_mode == "auto":
+            for _, spec, _ in self._branches[:1]:
+                object.__setattr__(spec, "hot_ids", self.auto_det_distinct_fraction < 0.5)   # (frozen dataclass: a hint, not the graph)
+            self._one_call_cache = None                       # (its descriptor carries the id flags)
         return self.auto_det_distinct_fraction
 
     def _two_pass_table_adam(self, ids) -> bool:

@@ -81,10 +81,11 @@ class ScanSpec:
             t //= self.periods[i]
         return out
 
-    # (r6) HPMN_ID_HOT: the gradient scatter pre-reduces a wave's equal ids in an LDS table before its atomic row adds.  On by
-    # default: it costs nothing measurable on uniform ids (C3 2.505 vs 2.500 ms/step) and is the difference between 3.01 and
-    # 2.40 ms on Zipf(1.1) item ids, where 12 % of a batch's lookups share ONE row; Taobao's 4-valued btag column: C2 0.93 -> 0.91
-    hot_ids = os.environ.get("HPMN_SCATTER_HOT_HINT", "1") != "0"
+    # (r6) HPMN_ID_HOT: the gradient scatter pre-reduces a wave's equal ids in an LDS table before its atomic row adds: the
+    # difference between 3.01 and 2.40 ms per C3 step on Zipf(1.1) item ids (12 % of a batch's lookups share ONE row); Taobao's
+    # 4-valued btag column: C2 0.93 -> 0.91.  On uniform ids the table only costs (the scatter launch 105 -> 133 us in C3's tail).
+    # HPMN_SCATTER_HOT_HINT = auto (default: the model looks at its first training batch, hpmn.py _probe_id_law), 0, 1.
+    hot_ids = os.environ.get("HPMN_SCATTER_HOT_HINT", "auto") == "1"
 
     def id_flags(self, ids) -> int:
         return _idf(ids, self.mask_id0) | (4 if self.hot_ids else 0)

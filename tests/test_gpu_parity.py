@@ -1446,7 +1446,9 @@ def test_scans_give_the_same_result_beside_an_unrelated_kernel(dev, tmp_path, B,
     {"HPMN_PAIR_FWD": "0", "HPMN_PAIR_BWD": "0", "HPMN_PAIR_INFER": "0"},      # one launch per layer (no two-layer launches)
     {"HPMN_PAIR_FWD": "1", "HPMN_PAIR_BWD": "1", "HPMN_FUSED_SCATTER": "1"},   # the other pairing; scatter fused into layer 0's launch
     {"HPMN_FUSED_SCATTER": "2"},                                               # (r5) the scatter inside the LOOP of layer 0's reverse scan
-], ids=["gen1", "one-wave", "dx-launches+split", "no-pairs", "pairs-alt", "scatter-in-loop"])
+    {"HPMN_PAIR_SINGLE": "0"},                                                 # (r6) two sequences per workgroup in the two-layer launches
+                                                                               # whatever the batch (default below 256 sequences: one)
+], ids=["gen1", "one-wave", "dx-launches+split", "no-pairs", "pairs-alt", "scatter-in-loop", "pairs-two-per-wg"])
 def test_fallback_kernel_paths_still_match_the_oracle(env):
     if env.get("HPMN_FUSED_FWD_GEN") == "1":
         _needs_legacy_build()
@@ -1460,6 +1462,8 @@ def test_fallback_kernel_paths_still_match_the_oracle(env):
     pick = ("xlong_c3_shape or c_abi_alone" if env.get("HPMN_FUSED_SCATTER") == "2" else
             "(tiny_and_odd and 64) or xlong_c3_shape or c_abi_alone or (beside_an_unrelated and 6-3-41)"
             " or (beside_an_unrelated and 3-5-297)")
+    if "HPMN_PAIR_SINGLE" in env:
+        pick += " or xlong_c3_b66 or two_layers_in_one_launch"
     r = subprocess.run([sys.executable, "-m", "pytest", here, "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider", "-k", pick],
                        env=e, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
