@@ -447,7 +447,9 @@ __global__ __launch_bounds__(512, 2) void gru_pair_bwd_kernel(const PairBwdArgs 
 
 bool gru_pair_bwd_supported(int H, int D_lo) { return H == RH && (D_lo == 16 || D_lo == 32 || D_lo == 64); }
 
-// (r6) one sequence per workgroup where the batch leaves CUs to spare: HPMN_PAIR_SINGLE=0 / 1, default: B <= number of CUs
+// (r6) one sequence per workgroup where the batch leaves at least half of the CUs empty even so: HPMN_PAIR_SINGLE=0 / 1, default
+// B <= CUs / 2 (measured: C3 at 128 sequences 2.03 -> 1.84 ms/step, C2 at 128 0.917 -> 0.911; at 256 sequences -- every CU taken by
+// a four-wave workgroup, none left for the weight gradients -- 0.97 -> 1.02)
 static bool pair_single_seq(int B) {
     static const int env = [] { const char *e = getenv("HPMN_PAIR_SINGLE"); return e ? atoi(e) : -1; }();
     if (env >= 0) return env != 0;
@@ -457,7 +459,7 @@ static bool pair_single_seq(int B) {
         if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return 256;
         return n;
     }();
-    return B <= cus;
+    return 2 * B <= cus;
 }
 
 int gru_pair_bwd_launch(const HpmnGruBwd &lo, const HpmnGruBwd &up, int flags, hipStream_t st) {

@@ -530,7 +530,9 @@ int gru_proj_images_launch(int n, const float *const *wg, const float *const *bg
 size_t gru_pair_fwd_scratch_bytes() { return 2 * gru_proj_image_floats(64) * sizeof(float); }
 
 // img_lo / img_up: ready-made images (gru_proj_images_launch) or NULL: built here, into scratch
-// (r6) one sequence per workgroup where the batch leaves CUs to spare: HPMN_PAIR_SINGLE=0 / 1, default: B <= number of CUs
+// (r6) one sequence per workgroup where the batch leaves at least half of the CUs empty even so: HPMN_PAIR_SINGLE=0 / 1, default
+// B <= CUs / 2 (measured: C3 at 128 sequences 2.03 -> 1.84 ms/step, C2 at 128 0.917 -> 0.911; at 256 sequences -- every CU taken by
+// a four-wave workgroup, none left for the weight gradients -- 0.97 -> 1.02)
 static bool pair_single_seq(int B) {
     static const int env = [] { const char *e = getenv("HPMN_PAIR_SINGLE"); return e ? atoi(e) : -1; }();
     if (env >= 0) return env != 0;
@@ -540,7 +542,7 @@ static bool pair_single_seq(int B) {
         if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return 256;
         return n;
     }();
-    return B <= cus;
+    return 2 * B <= cus;
 }
 
 int gru_pair_fwd_launch(const HpmnGruFusedFwd &lo, const HpmnGruFusedFwd &up, int flags, float *scratch,

@@ -789,15 +789,30 @@ int hpmn_train_step(HpmnTrainCtx *ctx, const HpmnTrainStep *s, void *stream) {
                            s->inv_global_batch, s->memory_reg, s->pred, s->loss_acc, s->d_memory, s->d_last, nullptr,
                            s->read_workspace, stream);
     if (rc != HPMN_OK) return rc;
+    // The read path's weight gradients + the loss scalars need only the tape the launch above left.  HPMN_READ_GRADS_ASIDE=1 puts
+    // them on the context's helper stream underneath the reverse scans instead of behind them on the caller's stream -- measured
+    // (r6, C1): 0.259 against 0.252 ms/step; at 512 sequences 0.357 against 0.350: the helper stream's first launch then waits
+    // for a cross-queue event instead of being queued behind the scatter, and the join at the end has two launches more in
+    // front of it.  Off (r5 found the same for a Python-side auxiliary stream).
+    TrainCtx *c = reinterpret_cast<TrainCtx *>(ctx);
+    static const int rd_aside = [] { const char *e = getenv("HPMN_READ_GRADS_ASIDE"); return e ? atoi(e) : 0; }();
+    const HpmnReadDesc *rd = &s->read;
+    if (rd_aside) {
+        HIPCHK(hipEventRecord(c->fork, st));
+        HIPCHK(hipStreamWaitEvent(c->side, c->fork, 0));
+        rc = hpmn_read_param_grads_loss_n(1, &rd, s->grad + s->off_read, s->read_workspace, s->loss_acc, s->inv_global_batch,
+                                          s->memory_reg, s->loss3, c->side);
+        if (rc != HPMN_OK) return rc;
+        c->pending = true;
+    }
     rc = hpmn_scan_bwd(ctx, &s->scan, s->ids, wg, wc, s->d_memory, s->d_last, dwg, dbg, dwc, dbc, s->grad, s->scan_workspace,
                        /*defer_join=*/1, stream);
     if (rc != HPMN_OK) return rc;
-    // behind the reverse scans: the read path's weight gradients + the loss scalars, then the table's sweep --
-    // both underneath the GRU weight gradients on the context's helper stream
-    const HpmnReadDesc *rd = &s->read;
-    rc = hpmn_read_param_grads_loss_n(1, &rd, s->grad + s->off_read, s->read_workspace, s->loss_acc, s->inv_global_batch,
-                                      s->memory_reg, s->loss3, stream);
-    if (rc != HPMN_OK) return rc;
+    if (!rd_aside) {
+        rc = hpmn_read_param_grads_loss_n(1, &rd, s->grad + s->off_read, s->read_workspace, s->loss_acc, s->inv_global_batch,
+                                          s->memory_reg, s->loss3, stream);
+        if (rc != HPMN_OK) return rc;
+    }
     if (s->n_emb > 0) {
         rc = hpmn_adam_step_clear(s->param, s->grad, s->m, s->v, s->n_emb, s->lr_t, s->beta1, s->beta2, s->eps, s->clip, 1.0f, stream);
         if (rc != HPMN_OK) return rc;

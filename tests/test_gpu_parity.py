@@ -1447,7 +1447,7 @@ def test_scans_give_the_same_result_beside_an_unrelated_kernel(dev, tmp_path, B,
     {"HPMN_PAIR_FWD": "1", "HPMN_PAIR_BWD": "1", "HPMN_FUSED_SCATTER": "1"},   # the other pairing; scatter fused into layer 0's launch
     {"HPMN_FUSED_SCATTER": "2"},                                               # (r5) the scatter inside the LOOP of layer 0's reverse scan
     {"HPMN_PAIR_SINGLE": "0"},                                                 # (r6) two sequences per workgroup in the two-layer launches
-                                                                               # whatever the batch (default below 256 sequences: one)
+                                                                               # whatever the batch (default up to 128 sequences: one)
 ], ids=["gen1", "one-wave", "dx-launches+split", "no-pairs", "pairs-alt", "scatter-in-loop", "pairs-two-per-wg"])
 def test_fallback_kernel_paths_still_match_the_oracle(env):
     if env.get("HPMN_FUSED_FWD_GEN") == "1":
